@@ -1,0 +1,192 @@
+/* miwave — C ABI of the MI355X wavefront path-tracing core.
+ *
+ * This is the drop-in boundary: everything below Mitsuba 2's
+ * SamplingIntegrator::render() / Scene::ray_intersect() for the `path`
+ * integrator runs behind these entry points on one gfx950 device. The host
+ * side (mitsuba2_amd/host, C++17) mirrors the reference's plugin classes and
+ * calls only what is declared here: plain pointers and sizes, int status codes,
+ * no exceptions, no C++ or torch types.
+ *
+ * Conventions: every function returns MI_OK (0) or a negative mi_status; the
+ * text of the last failure is mi_last_error(ctx). The caller owns every host
+ * buffer it passes; a ctx owns all device memory it allocates; one ctx per GPU;
+ * a ctx is thread-compatible (one host thread at a time). Pointers are host
+ * addresses unless a field says "device".
+ */
+#ifndef MIWAVE_H
+#define MIWAVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx mi_ctx;
+typedef int32_t mi_status;
+
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID = -1,      /* bad argument / unsupported plugin parameter          */
+    MI_ERR_DEVICE = -2,       /* HIP runtime failure (text in mi_last_error)           */
+    MI_ERR_STATE = -3,        /* call out of order (e.g. render before bvh_build)      */
+    MI_ERR_CANCELLED = -4     /* mi_cancel() or timeout: render() returned false       */
+};
+
+/* ---- scene description (flat POD) -------------------------------------------------
+ * Replaces what Scene(props) collects (src/librender/scene.cpp:22-104): shapes
+ * (triangle meshes, include/mitsuba/render/mesh.h:80-104 buffers), their BSDFs
+ * and area emitters. Vertex indices in `faces` are global (into the pooled
+ * vertex arrays). Faces of shape s are the contiguous range
+ * [first_face, first_face + face_count): global primitive id == face index,
+ * like ShapeKDTree::m_primitive_map (kdtree.h:2335-2353). */
+
+enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2 };
+enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2 };
+enum { MI_SHAPE_HAS_NORMALS = 1 };
+
+typedef struct {
+    uint32_t type;        /* MI_BSDF_*                                                   */
+    uint32_t flags;       /* roughconductor: MI_BSDF_FLAG_*                              */
+    /* diffuse  (src/bsdfs/diffuse.cpp:72):         [0..2] reflectance
+     * dielectric (src/bsdfs/dielectric.cpp:174-199): [0] eta = int_ior/ext_ior,
+     *                                              [1..3] specular_reflectance, [4..6] specular_transmittance
+     * roughconductor (src/bsdfs/roughconductor.cpp:146-194): [0] alpha_u, [1] alpha_v,
+     *                                              [2..4] eta, [5..7] k, [8..10] specular_reflectance */
+    float params[14];
+} mi_bsdf;
+
+typedef struct {
+    uint32_t bsdf;        /* index into bsdfs                                            */
+    int32_t  emitter;     /* index into emitters, or -1                                  */
+    uint32_t flags;       /* MI_SHAPE_HAS_NORMALS                                        */
+    uint32_t first_face, face_count;
+} mi_shape;
+
+typedef struct {          /* area light, src/emitters/area.cpp                            */
+    uint32_t shape;       /* the shape it is attached to                                 */
+    float radiance[3];
+} mi_emitter;
+
+typedef struct {
+    const float    *vertex_positions;  /* 3 * vertex_count                               */
+    const float    *vertex_normals;    /* 3 * vertex_count, or NULL                      */
+    uint32_t        vertex_count;
+    const uint32_t *faces;             /* 3 * face_count                                 */
+    uint32_t        face_count;
+    const mi_shape   *shapes;   uint32_t shape_count;
+    const mi_bsdf    *bsdfs;    uint32_t bsdf_count;
+    const mi_emitter *emitters; uint32_t emitter_count;
+} mi_scene_desc;
+
+/* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */
+typedef struct {          /* SoA, n entries each (Ray3f: o, d, mint, maxt)               */
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt;
+} mi_rays_soa;
+
+typedef struct {          /* PreliminaryIntersection3f: t, prim_uv, prim_index, shape    */
+    float *t, *u, *v;     /* t = +inf on a miss; any-hit: t = 0 (hit) or +inf            */
+    uint32_t *prim;       /* global primitive id, 0xffffffff on a miss (may be NULL)     */
+    uint32_t *shape;      /* shape index, 0xffffffff on a miss (may be NULL)             */
+} mi_hits_soa;
+
+/* ---- render job ---------------------------------------------------------------------
+ * Everything SamplingIntegrator::render() derives on the host
+ * (src/librender/integrator.cpp:51-139) is passed in precomputed. */
+typedef struct {
+    int32_t crop_x, crop_y, crop_w, crop_h;   /* film->crop_offset() / crop_size()       */
+    uint32_t spp;                             /* sampler->sample_count()                 */
+    int32_t max_depth, rr_depth;              /* integrator.cpp:305-314                  */
+    uint64_t base_seed;                       /* sampler `seed` property                 */
+    int32_t block_size;                       /* integrator.cpp:88-97                    */
+    /* spiral visitation id of every block, row-major over the block grid
+     * (ceil(crop_w/bs) x ceil(crop_h/bs)); seeds are block_id*bs^2 + morton_i
+     * (integrator.cpp:198, spiral.cpp:41) */
+    const uint32_t *block_ids;
+    uint32_t block_count;
+    /* pixel-tile shard: row-major block indices this ctx renders; NULL = all      */
+    const uint32_t *tile_list;
+    uint32_t tile_count;
+    /* perspective sensor (src/sensors/perspective.cpp:118-141), column-major 4x4  */
+    float sample_to_camera[16];
+    float to_world[16];
+    float near_clip, far_clip;
+    float principal_point_offset[2];
+    /* reconstruction filter (include/mitsuba/core/rfilter.h:62-65, rfilter.cpp:9-20) */
+    float filter_lut[32];
+    float filter_radius;
+    int32_t filter_border;
+    /* output: crop_w*crop_h*5 values X,Y,Z,A,W (integrator.cpp:71-72)             */
+    int32_t film_on_device;                   /* 0: host pointer, 1: device pointer      */
+    int32_t film_f64;                         /* 0: float32 film, 1: float64 accumulators*/
+    int32_t profile;                          /* 1: time every launch with HIP events    */
+    float timeout_s;                          /* <= 0: none (integrator.cpp:34)          */
+} mi_render_cfg;
+
+typedef struct {
+    uint64_t samples;          /* camera samples finished                               */
+    uint64_t segments;         /* depth-loop iterations that reached shading            */
+    uint64_t shadow_rays;
+    uint64_t iterations;       /* wavefront iterations launched                         */
+    uint64_t lanes;            /* pixels (lanes) in the job                             */
+    double ms_render;          /* wall time of the last mi_render (host clock)          */
+    /* HIP-event time per kernel class, summed over launches (profile=1 only)     */
+    double ms_trace_closest, ms_trace_any, ms_shade, ms_init, ms_resolve;
+    uint64_t n_trace_closest, n_trace_any, n_shade;
+    double ms_bvh_build;
+    uint32_t bvh_nodes, bvh_tris, bvh_depth;
+} mi_counters;
+
+/* ---- entry points -------------------------------------------------------------------- */
+
+/* number of visible HIP devices */
+mi_status mi_device_count(int32_t *count);
+/* create a context on `device`; *out is NULL on failure */
+mi_status mi_create(int32_t device, mi_ctx **out);
+void      mi_destroy(mi_ctx *ctx);
+/* run all work on this hipStream_t (e.g. torch's current stream); NULL = default */
+mi_status mi_set_stream(mi_ctx *ctx, void *hip_stream);
+
+/* Scene(props): copy the flat scene to HBM; builds emitter sampling tables
+ * (Mesh::build_pmf, src/librender/mesh.cpp:285-312) */
+mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
+/* Scene::accel_init_cpu (src/librender/scene_native.inl:3-10): build the BVH.
+ * quality 0 = LBVH built on the device, 1 = binned SAH built on the host */
+mi_status mi_bvh_build(mi_ctx *ctx, int32_t quality);
+
+/* Scene::ray_intersect_preliminary (any_hit = 0) / Scene::ray_test (any_hit = 1),
+ * include/mitsuba/render/scene.h:38-128, for n rays. */
+mi_status mi_trace(mi_ctx *ctx, const mi_rays_soa *rays, const mi_hits_soa *hits,
+                   uint64_t n, int32_t any_hit);
+
+/* SamplingIntegrator::render (integrator.cpp:51-179) with PathIntegrator::sample
+ * (src/integrators/path.cpp:100-211): renders the ctx's tile shard into `film`.
+ * Returns MI_ERR_CANCELLED if mi_cancel()/timeout stopped it (film holds the
+ * partial result, like the reference's `return !m_stop`). */
+mi_status mi_render(mi_ctx *ctx, const mi_render_cfg *cfg, void *film);
+/* Integrator::cancel() — may be called from another thread */
+mi_status mi_cancel(mi_ctx *ctx);
+
+mi_status   mi_get_counters(mi_ctx *ctx, mi_counters *out);
+const char *mi_last_error(mi_ctx *ctx);
+
+/* Device-side evaluation of the leaf functions, for known-answer parity tests
+ * (one work item per entry; `in`/`out` are host arrays of n * stride floats). */
+enum {
+    MI_EVAL_PCG32 = 0,            /* in: seed lo, seed hi (as bits)      out: 8 floats   */
+    MI_EVAL_SINCOS = 1,           /* in: x                               out: sin, cos   */
+    MI_EVAL_COSINE_HEMISPHERE = 2,/* in: u1,u2                           out: wo.xyz,pdf */
+    MI_EVAL_BSDF = 3,             /* in: bsdf idx, wi.xyz, s1, s2x, s2y, wo.xyz (10)
+                                     out: sample{wo.xyz,pdf,eta,type,w.rgb} eval.rgb pdf (13) */
+    MI_EVAL_FRESNEL = 4,          /* in: cos_theta_i, eta                out: r,cos_t,eta_it,eta_ti */
+    MI_EVAL_CAMERA_RAY = 5,       /* in: x,y (film sample)               out: o.xyz,d.xyz,mint,maxt */
+    MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2                 out: d.xyz,dist,pdf,spec.rgb,p.xyz,n.xyz (14) */
+    MI_EVAL_FP_SEMANTICS = 7      /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
+};
+mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
+                  const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIWAVE_H */

@@ -1,0 +1,151 @@
+"""ctypes declarations of the C ABI (include/miwave.h) and of the host facade (mih_*).
+
+Loading fails loudly when the native libraries are missing: there is no Python
+or CPU fallback for any entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_u32_p = C.POINTER(C.c_uint32)
+c_i32_p = C.POINTER(C.c_int32)
+
+
+class mi_bsdf(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("params", C.c_float * 14)]
+
+
+class mi_shape(C.Structure):
+    _fields_ = [("bsdf", C.c_uint32), ("emitter", C.c_int32), ("flags", C.c_uint32),
+                ("first_face", C.c_uint32), ("face_count", C.c_uint32)]
+
+
+class mi_emitter(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("radiance", C.c_float * 3)]
+
+
+class mi_scene_desc(C.Structure):
+    _fields_ = [("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_count", C.c_uint32),
+                ("faces", c_u32_p), ("face_count", C.c_uint32),
+                ("shapes", C.POINTER(mi_shape)), ("shape_count", C.c_uint32),
+                ("bsdfs", C.POINTER(mi_bsdf)), ("bsdf_count", C.c_uint32),
+                ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32)]
+
+
+class mi_rays_soa(C.Structure):
+    _fields_ = [(n, c_float_p) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "mint", "maxt")]
+
+
+class mi_hits_soa(C.Structure):
+    _fields_ = [("t", c_float_p), ("u", c_float_p), ("v", c_float_p), ("prim", c_u32_p), ("shape", c_u32_p)]
+
+
+class mi_render_cfg(C.Structure):
+    _fields_ = [("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
+                ("spp", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
+                ("base_seed", C.c_uint64), ("block_size", C.c_int32),
+                ("block_ids", c_u32_p), ("block_count", C.c_uint32),
+                ("tile_list", c_u32_p), ("tile_count", C.c_uint32),
+                ("sample_to_camera", C.c_float * 16), ("to_world", C.c_float * 16),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("principal_point_offset", C.c_float * 2),
+                ("filter_lut", C.c_float * 32), ("filter_radius", C.c_float), ("filter_border", C.c_int32),
+                ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("profile", C.c_int32),
+                ("timeout_s", C.c_float)]
+
+
+class mi_counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("iterations", C.c_uint64), ("lanes", C.c_uint64), ("ms_render", C.c_double),
+                ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double), ("ms_shade", C.c_double),
+                ("ms_init", C.c_double), ("ms_resolve", C.c_double),
+                ("n_trace_closest", C.c_uint64), ("n_trace_any", C.c_uint64), ("n_shade", C.c_uint64),
+                ("ms_bvh_build", C.c_double), ("bvh_nodes", C.c_uint32), ("bvh_tris", C.c_uint32),
+                ("bvh_depth", C.c_uint32)]
+
+
+MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
+MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
+               FP_SEMANTICS=7)
+MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8)}
+
+# every symbol include/miwave.h declares (tests check that the library exports all of them)
+MI_SYMBOLS = ["mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
+              "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval"]
+
+
+def _load(name):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build the native libraries first (python -m mitsuba2_amd.build). "
+            "mitsuba2_amd has no CPU fallback." % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def load_device_lib():
+    lib = _load("libmiwave.so")
+    vp = C.c_void_p
+    lib.mi_device_count.argtypes = [c_i32_p]; lib.mi_device_count.restype = C.c_int32
+    lib.mi_create.argtypes = [C.c_int32, C.POINTER(vp)]; lib.mi_create.restype = C.c_int32
+    lib.mi_destroy.argtypes = [vp]; lib.mi_destroy.restype = None
+    lib.mi_set_stream.argtypes = [vp, vp]; lib.mi_set_stream.restype = C.c_int32
+    lib.mi_scene_upload.argtypes = [vp, C.POINTER(mi_scene_desc)]; lib.mi_scene_upload.restype = C.c_int32
+    lib.mi_bvh_build.argtypes = [vp, C.c_int32]; lib.mi_bvh_build.restype = C.c_int32
+    lib.mi_trace.argtypes = [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64, C.c_int32]
+    lib.mi_trace.restype = C.c_int32
+    lib.mi_render.argtypes = [vp, C.POINTER(mi_render_cfg), vp]; lib.mi_render.restype = C.c_int32
+    lib.mi_cancel.argtypes = [vp]; lib.mi_cancel.restype = C.c_int32
+    lib.mi_get_counters.argtypes = [vp, C.POINTER(mi_counters)]; lib.mi_get_counters.restype = C.c_int32
+    lib.mi_last_error.argtypes = [vp]; lib.mi_last_error.restype = C.c_char_p
+    lib.mi_eval.argtypes = [vp, C.c_int32, C.POINTER(mi_render_cfg), c_float_p, C.c_int32, c_float_p, C.c_int32,
+                            C.c_uint64]
+    lib.mi_eval.restype = C.c_int32
+    return lib
+
+
+def load_host_lib():
+    load_device_lib()
+    lib = _load("libmiwave_host.so")
+    vp, cp, f, i32, u32, u64 = C.c_void_p, C.c_char_p, C.c_float, C.c_int32, C.c_uint32, C.c_uint64
+    sig = {
+        "mih_last_error": (cp, []),
+        "mih_props_create": (vp, [cp]), "mih_props_destroy": (None, [vp]),
+        "mih_props_set_float": (None, [vp, cp, f]), "mih_props_set_int": (None, [vp, cp, C.c_int64]),
+        "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),
+        "mih_props_set_color": (None, [vp, cp, f, f, f]),
+        "mih_props_set_lookat": (None, [vp, cp, c_float_p, c_float_p, c_float_p]),
+        "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]),
+        "mih_bsdf_record": (i32, [vp, C.POINTER(mi_bsdf)]), "mih_bsdf_flags": (u32, [vp]),
+        "mih_bsdf_sample": (i32, [vp, c_float_p, f, c_float_p, c_float_p]),
+        "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),
+        "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),
+        "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p]), "mih_mesh_destroy": (None, [vp]),
+        "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),
+        "mih_scene_create": (vp, []), "mih_scene_destroy": (None, [vp]),
+        "mih_scene_add_shape": (i32, [vp, vp]), "mih_scene_build": (i32, [vp, i32, i32]),
+        "mih_scene_desc": (C.POINTER(mi_scene_desc), [vp]), "mih_scene_ctx": (vp, [vp]),
+        "mih_scene_ray_intersect": (i32, [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), u64]),
+        "mih_scene_ray_test": (i32, [vp, C.POINTER(mi_rays_soa), c_float_p, u64]),
+        "mih_film_create": (vp, [vp]), "mih_film_destroy": (None, [vp]),
+        "mih_film_set_filter": (i32, [vp, cp, vp]),
+        "mih_film_data": (c_float_p, [vp, C.POINTER(u64)]), "mih_film_develop_rgb": (i32, [vp, c_float_p]),
+        "mih_sampler_create": (vp, [vp]), "mih_sampler_destroy": (None, [vp]),
+        "mih_sampler_seed": (None, [vp, u64]), "mih_sampler_next_1d": (f, [vp]),
+        "mih_sensor_create": (vp, [vp, vp, vp]), "mih_sensor_destroy": (None, [vp]),
+        "mih_sensor_sample_ray": (i32, [vp, f, f, c_float_p]), "mih_sensor_x_fov": (f, [vp]),
+        "mih_integrator_create": (vp, [vp]), "mih_integrator_destroy": (None, [vp]),
+        "mih_integrator_set_shard": (None, [vp, u32, u32]), "mih_integrator_set_profile": (None, [vp, i32]),
+        "mih_integrator_cancel": (None, [vp]), "mih_integrator_render": (i32, [vp, vp, vp]),
+        "mih_integrator_counters": (i32, [vp, C.POINTER(mi_counters)]),
+        "mih_make_render_cfg": (i32, [vp, vp, C.POINTER(mi_render_cfg), c_u32_p, c_u32_p, u32, u32]),
+        "mih_spiral": (i32, [i32, i32, i32, i32, i32, c_i32_p, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

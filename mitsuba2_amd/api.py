@@ -1,0 +1,365 @@
+"""Thin Python objects over the host facade — test / benchmark plumbing.
+
+The classes carry the reference's plugin names and property names
+(`diffuse.reflectance`, `perspective.fov`, `hdrfilm.width`, `path.max_depth` …)
+so that scripts written against Mitsuba 2's Python API read the same way; all
+logic lives in libmiwave_host.so (C++) and libmiwave.so (HIP).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (mi_counters, mi_hits_soa, mi_rays_soa, mi_render_cfg, mi_scene_desc, c_float_p, c_u32_p)
+
+_host = None
+_dev = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        _host = _capi.load_host_lib()
+    return _host
+
+
+def device_lib():
+    global _dev
+    if _dev is None:
+        _dev = _capi.load_device_lib()
+    return _dev
+
+
+def _err():
+    return host_lib().mih_last_error().decode()
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+class Properties:
+    """Properties(plugin_name, **values): float / int / bool / str / 3-tuple (rgb) values;
+    `to_world=dict(origin=, target=, up=)` becomes a look-at transform."""
+
+    def __init__(self, plugin, **kw):
+        L = host_lib()
+        self.h = L.mih_props_create(plugin.encode())
+        for k, v in kw.items():
+            n = k.encode()
+            if isinstance(v, bool):
+                L.mih_props_set_bool(self.h, n, int(v))
+            elif isinstance(v, int):
+                L.mih_props_set_int(self.h, n, v)
+            elif isinstance(v, float):
+                L.mih_props_set_float(self.h, n, v)
+            elif isinstance(v, str):
+                L.mih_props_set_string(self.h, n, v.encode())
+            elif isinstance(v, dict):
+                o = np.asarray(v["origin"], np.float32); t = np.asarray(v["target"], np.float32)
+                u = np.asarray(v.get("up", (0, 1, 0)), np.float32)
+                L.mih_props_set_lookat(self.h, n, _fp(o), _fp(t), _fp(u))
+            else:
+                r, g, b = [float(x) for x in v]
+                L.mih_props_set_color(self.h, n, r, g, b)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_props_destroy(self.h)
+            self.h = None
+
+
+class BSDF:
+    def __init__(self, plugin, **kw):
+        self._p = Properties(plugin, **kw)
+        self.h = host_lib().mih_bsdf_create(self._p.h)
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def record(self):
+        r = _capi.mi_bsdf()
+        host_lib().mih_bsdf_record(self.h, C.byref(r))
+        return r
+
+    def flags(self):
+        return host_lib().mih_bsdf_flags(self.h)
+
+    def sample(self, wi, sample1, sample2):
+        """-> dict(wo, pdf, eta, sampled_type, weight)  (BSDF::sample, local frame)"""
+        wi = np.asarray(wi, np.float32); s2 = np.asarray(sample2, np.float32); out = np.zeros(9, np.float32)
+        if host_lib().mih_bsdf_sample(self.h, _fp(wi), float(sample1), _fp(s2), _fp(out)) != 0:
+            raise RuntimeError(_err())
+        return dict(wo=out[0:3].copy(), pdf=out[3], eta=out[4], sampled_type=int(out[5:6].view(np.uint32)[0]),
+                    weight=out[6:9].copy())
+
+    def eval_pdf(self, wi, wo):
+        wi = np.asarray(wi, np.float32); wo = np.asarray(wo, np.float32); out = np.zeros(4, np.float32)
+        if host_lib().mih_bsdf_eval_pdf(self.h, _fp(wi), _fp(wo), _fp(out)) != 0:
+            raise RuntimeError(_err())
+        return out[0:3].copy(), out[3]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_bsdf_destroy(self.h); self.h = None
+
+
+class AreaLight:
+    def __init__(self, radiance):
+        self._p = Properties("area", radiance=tuple(radiance))
+        self.h = host_lib().mih_emitter_create(self._p.h)
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_emitter_destroy(self.h); self.h = None
+
+
+class Mesh:
+    def __init__(self, name, vertices, faces, normals=None, bsdf=None, emitter=None):
+        self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        self.faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        self.h = host_lib().mih_mesh_create(name.encode(), _fp(self.vertices), len(self.vertices),
+                                            self.faces.ctypes.data_as(c_u32_p), len(self.faces),
+                                            None if self.normals is None else _fp(self.normals))
+        if not self.h:
+            raise RuntimeError(_err())
+        self.bsdf, self.emitter = bsdf, emitter
+        if bsdf is not None:
+            host_lib().mih_mesh_set_bsdf(self.h, bsdf.h)
+        if emitter is not None:
+            host_lib().mih_mesh_set_emitter(self.h, emitter.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_mesh_destroy(self.h); self.h = None
+
+
+def _rays_struct(o, d, mint, maxt):
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+    n = len(o)
+    cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+    cols.append(np.ascontiguousarray(np.broadcast_to(np.asarray(mint, np.float32), (n,))))
+    cols.append(np.ascontiguousarray(np.broadcast_to(np.asarray(maxt, np.float32), (n,))))
+    r = mi_rays_soa(*[_fp(c) for c in cols])
+    return r, cols, n
+
+
+def _hits_struct(n):
+    t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    prim = np.zeros(n, np.uint32); shape = np.zeros(n, np.uint32)
+    h = mi_hits_soa(_fp(t), _fp(u), _fp(v), prim.ctypes.data_as(c_u32_p), shape.ctypes.data_as(c_u32_p))
+    return h, dict(t=t, u=u, v=v, prim=prim, shape=shape)
+
+
+class Scene:
+    def __init__(self, shapes):
+        self.shapes = list(shapes)
+        self.h = host_lib().mih_scene_create()
+        for s in self.shapes:
+            if host_lib().mih_scene_add_shape(self.h, s.h) != 0:
+                raise RuntimeError(_err())
+        self.device = None
+
+    def build(self, device=0, bvh_quality=1):
+        """device < 0: flatten only (host-side description, no GPU)."""
+        if host_lib().mih_scene_build(self.h, device, bvh_quality) != 0:
+            raise RuntimeError(_err())
+        self.device = device
+        return self
+
+    def desc(self):
+        return host_lib().mih_scene_desc(self.h)
+
+    def ctx(self):
+        return host_lib().mih_scene_ctx(self.h)
+
+    def ray_intersect(self, o, d, mint=0.0, maxt=np.inf):
+        """Scene::ray_intersect_preliminary for a batch -> dict(t,u,v,prim,shape)"""
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        h, out = _hits_struct(n)
+        if host_lib().mih_scene_ray_intersect(self.h, C.byref(r), C.byref(h), n) != 0:
+            raise RuntimeError(_err())
+        return out
+
+    def ray_test(self, o, d, mint=0.0, maxt=np.inf):
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        t = np.zeros(n, np.float32)
+        if host_lib().mih_scene_ray_test(self.h, C.byref(r), _fp(t), n) != 0:
+            raise RuntimeError(_err())
+        return np.isfinite(t)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_scene_destroy(self.h); self.h = None
+
+
+class Film:
+    def __init__(self, rfilter="gaussian", **kw):
+        self._p = Properties("hdrfilm", **kw)
+        self.h = host_lib().mih_film_create(self._p.h)
+        if not self.h:
+            raise RuntimeError(_err())
+        if rfilter != "gaussian":
+            if host_lib().mih_film_set_filter(self.h, rfilter.encode(), None) != 0:
+                raise RuntimeError(_err())
+
+    def data(self, shape):
+        n = C.c_uint64()
+        p = host_lib().mih_film_data(self.h, C.byref(n))
+        a = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        return a.reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_film_destroy(self.h); self.h = None
+
+
+class Sampler:
+    def __init__(self, **kw):
+        self._p = Properties("independent", **kw)
+        self.h = host_lib().mih_sampler_create(self._p.h)
+
+    def seed(self, off):
+        host_lib().mih_sampler_seed(self.h, off)
+
+    def next_1d(self):
+        return host_lib().mih_sampler_next_1d(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_sampler_destroy(self.h); self.h = None
+
+
+class Sensor:
+    def __init__(self, film, sampler, **kw):
+        self.film, self.sampler = film, sampler
+        self._p = Properties("perspective", **kw)
+        self.h = host_lib().mih_sensor_create(self._p.h, film.h, sampler.h)
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def sample_ray(self, x, y):
+        out = np.zeros(8, np.float32)
+        if host_lib().mih_sensor_sample_ray(self.h, float(x), float(y), _fp(out)) != 0:
+            raise RuntimeError(_err())
+        return out
+
+    def x_fov(self):
+        return host_lib().mih_sensor_x_fov(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_sensor_destroy(self.h); self.h = None
+
+
+class RenderJob:
+    """The host-side job description (mi_render_cfg + its tables), kept alive together."""
+
+    def __init__(self, cfg, block_ids, tiles):
+        self.cfg, self.block_ids, self.tiles = cfg, block_ids, tiles
+
+
+class PathIntegrator:
+    def __init__(self, **kw):
+        self._p = Properties("path", **kw)
+        self.h = host_lib().mih_integrator_create(self._p.h)
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def set_shard(self, rank, world):
+        host_lib().mih_integrator_set_shard(self.h, rank, world)
+
+    def set_profile(self, on=True):
+        host_lib().mih_integrator_set_profile(self.h, int(on))
+
+    def render(self, scene, sensor):
+        """SamplingIntegrator::render -> True (finished) / False (cancelled, timeout)"""
+        r = host_lib().mih_integrator_render(self.h, scene.h, sensor.h)
+        if r < 0:
+            raise RuntimeError(_err())
+        return bool(r)
+
+    def counters(self):
+        c = mi_counters()
+        host_lib().mih_integrator_counters(self.h, C.byref(c))
+        return c
+
+    def render_job(self, sensor, n_threads=1, capacity=1 << 16):
+        cfg = mi_render_cfg()
+        block_ids = np.zeros(capacity, np.uint32); tiles = np.zeros(capacity, np.uint32)
+        if host_lib().mih_make_render_cfg(self.h, sensor.h, C.byref(cfg), block_ids.ctypes.data_as(c_u32_p),
+                                          tiles.ctypes.data_as(c_u32_p), capacity, n_threads) != 0:
+            raise RuntimeError(_err())
+        return RenderJob(cfg, block_ids, tiles)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_integrator_destroy(self.h); self.h = None
+
+
+def spiral(w, h, block_size, offset=(0, 0)):
+    n = ((w + block_size - 1) // block_size) * ((h + block_size - 1) // block_size)
+    out = np.zeros((n, 5), np.int32)
+    host_lib().mih_spiral(w, h, offset[0], offset[1], block_size, out.ctypes.data_as(_capi.c_i32_p), n)
+    return out
+
+
+# ---- direct C-ABI helpers (tests call the boundary itself) -----------------------------------------
+class Device:
+    """One mi_ctx on one GPU, driven through the raw C ABI."""
+
+    def __init__(self, device=0):
+        self.L = device_lib()
+        self.ctx = C.c_void_p()
+        st = self.L.mi_create(device, C.byref(self.ctx))
+        if st != 0:
+            raise RuntimeError("mi_create failed (%d): %s" % (st, self.L.mi_last_error(None).decode()))
+
+    def check(self, st):
+        if st != 0:
+            raise RuntimeError("miwave error %d: %s" % (st, self.L.mi_last_error(self.ctx).decode()))
+
+    def upload(self, desc, bvh_quality=1):
+        self.check(self.L.mi_scene_upload(self.ctx, desc))
+        self.check(self.L.mi_bvh_build(self.ctx, bvh_quality))
+
+    def trace(self, o, d, mint=0.0, maxt=np.inf, any_hit=False):
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        h, out = _hits_struct(n)
+        self.check(self.L.mi_trace(self.ctx, C.byref(r), C.byref(h), n, int(any_hit)))
+        return out
+
+    def render(self, job, f64=False, profile=False):
+        cfg = job.cfg
+        cfg.film_on_device = 0; cfg.film_f64 = int(f64); cfg.profile = int(profile)
+        n = cfg.crop_w * cfg.crop_h * 5
+        film = np.zeros(n, np.float64 if f64 else np.float32)
+        st = self.L.mi_render(self.ctx, C.byref(cfg), film.ctypes.data_as(C.c_void_p))
+        if st not in (0, _capi.MI_ERR_CANCELLED):
+            self.check(st)
+        return film.reshape(cfg.crop_h, cfg.crop_w, 5), st
+
+    def counters(self):
+        c = mi_counters()
+        self.L.mi_get_counters(self.ctx, C.byref(c))
+        return c
+
+    def eval(self, op, inputs, cfg=None):
+        i_s, o_s = _capi.MI_EVAL_STRIDES[op]
+        a = np.ascontiguousarray(inputs, np.float32).reshape(-1, i_s)
+        out = np.zeros((len(a), o_s), np.float32)
+        self.check(self.L.mi_eval(self.ctx, op, C.byref(cfg) if cfg is not None else None, _fp(a), i_s, _fp(out), o_s,
+                                  len(a)))
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.L.mi_destroy(self.ctx); self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,298 @@
+// BSDF kernels on the path: smooth diffuse, smooth dielectric, rough conductor
+// (GGX / Beckmann microfacet with visible-normal sampling), plus Fresnel terms.
+//
+// Follows: src/bsdfs/diffuse.cpp:78-135, src/bsdfs/dielectric.cpp:201-320,
+// src/bsdfs/roughconductor.cpp:196-382, include/mitsuba/render/microfacet.h:184-418,
+// include/mitsuba/render/fresnel.h:34-116,275-294.
+// Unpolarized RGB only (the scalar_rgb variant); TransportMode::Radiance.
+#pragma once
+#include "base.h"
+#include "warp.h"
+#include "shape.h"
+
+namespace miw {
+
+// BSDFFlags subset (include/mitsuba/render/bsdf.h:40-124)
+enum : uint32_t {
+    BSDF_DiffuseReflection = 0x00002, BSDF_GlossyReflection = 0x00008,
+    BSDF_DeltaReflection   = 0x00020, BSDF_DeltaTransmission = 0x00040,
+    BSDF_Smooth = 0x00002 | 0x00004 | 0x00008 | 0x00010,
+    BSDF_Delta  = 0x00001 | 0x00020 | 0x00040,
+};
+
+enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2 };
+enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
+
+// 64-byte material record (host fills it from the plugin's Properties)
+//   diffuse:        p[0..2] reflectance
+//   dielectric:     p[0] eta (= int_ior/ext_ior), p[1..3] specular_reflectance,
+//                   p[4..6] specular_transmittance
+//   roughconductor: p[0] alpha_u, p[1] alpha_v, p[2..4] eta, p[5..7] k,
+//                   p[8..10] specular_reflectance; flags bit0 = GGX, bit1 = sample_visible
+struct BsdfRec { uint32_t type, flags; float p[14]; };
+
+struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
+
+MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
+    return b.type == BSDF_TYPE_DIFFUSE ? BSDF_DiffuseReflection
+         : b.type == BSDF_TYPE_DIELECTRIC ? (BSDF_DeltaReflection | BSDF_DeltaTransmission)
+         : BSDF_GlossyReflection;
+}
+
+// ---- Fresnel ---------------------------------------------------------------------
+// fresnel.h:34-70
+MIW_HD void fresnel(float cos_theta_i, float eta, float &r_out, float &cos_theta_t_out,
+                    float &eta_it_out, float &eta_ti_out) {
+    bool outside = cos_theta_i >= 0.f;
+    float rcp_eta = rcp(eta),
+          eta_it = outside ? eta : rcp_eta,
+          eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fnmadd(fnmadd(cos_theta_i, cos_theta_i, 1.f), eta_ti * eta_ti, 1.f);
+    float cos_theta_i_abs = abs_(cos_theta_i);
+    float cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+    bool index_matched = eta == 1.f,
+         special_case = index_matched || cos_theta_i_abs == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fnmadd(eta_it, cos_theta_t_abs, cos_theta_i_abs) /
+                 fmadd(eta_it, cos_theta_t_abs, cos_theta_i_abs);
+    float a_p = fnmadd(eta_it, cos_theta_i_abs, cos_theta_t_abs) /
+                 fmadd(eta_it, cos_theta_i_abs, cos_theta_t_abs);
+    float r = .5f * (sqr(a_s) + sqr(a_p));
+    if (special_case) r = r_sc;
+    r_out = r;
+    cos_theta_t_out = mulsign_neg(cos_theta_t_abs, cos_theta_i);
+    eta_it_out = eta_it; eta_ti_out = eta_ti;
+}
+
+// fresnel.h:92-116 (one colour channel)
+MIW_HD float fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) {
+    float cos_theta_i_2 = cos_theta_i * cos_theta_i,
+          sin_theta_i_2 = 1.f - cos_theta_i_2,
+          sin_theta_i_4 = sin_theta_i_2 * sin_theta_i_2;
+    float temp_1   = eta_r * eta_r - eta_i * eta_i - sin_theta_i_2,
+          a_2_pb_2 = safe_sqrt(temp_1 * temp_1 + 4.f * eta_i * eta_i * eta_r * eta_r),
+          a        = safe_sqrt(.5f * (a_2_pb_2 + temp_1));
+    float term_1 = a_2_pb_2 + cos_theta_i_2,
+          term_2 = 2.f * cos_theta_i * a;
+    float r_s = (term_1 - term_2) / (term_1 + term_2);
+    float term_3 = a_2_pb_2 * cos_theta_i_2 + sin_theta_i_4,
+          term_4 = term_2 * sin_theta_i_2;
+    float r_p = r_s * (term_3 - term_4) / (term_3 + term_4);
+    return .5f * (r_s + r_p);
+}
+
+// fresnel.h:275-294
+MIW_HD V3 reflect(V3 wi) { return v3(-wi.x, -wi.y, wi.z); }
+MIW_HD V3 reflect(V3 wi, V3 m) { return fmsub3(m, 2.f * dot(wi, m), wi); }
+MIW_HD V3 refract(V3 wi, float cos_theta_t, float eta_ti) {
+    return v3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);
+}
+
+// ---- Microfacet distribution (microfacet.h) ----------------------------------------
+struct Microfacet { uint32_t type; float alpha_u, alpha_v; bool sample_visible; };
+
+MIW_HD Microfacet microfacet_make(uint32_t type, float au, float av, bool sv) {
+    Microfacet d; d.type = type; d.sample_visible = sv;
+    d.alpha_u = max_(au, 1e-4f); d.alpha_v = max_(av, 1e-4f);   // configure(), :415-418
+    return d;
+}
+
+// :184-202 — only GGX is evaluated on device this round; Beckmann needs exp()
+MIW_HD float mf_eval(const Microfacet &d, V3 m) {
+    float alpha_uv = d.alpha_u * d.alpha_v,
+          cos_theta = m.z,
+          result;
+    result = rcp(MIW_PI * alpha_uv *
+                 sqr(sqr(m.x / d.alpha_u) + sqr(m.y / d.alpha_v) + sqr(m.z)));
+    return (result * cos_theta > 1e-20f) ? result : 0.f;
+}
+
+// :331-355
+MIW_HD float mf_smith_g1(const Microfacet &d, V3 v, V3 m) {
+    float xy_alpha_2 = sqr(d.alpha_u * v.x) + sqr(d.alpha_v * v.y),
+          tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z),
+          result;
+    result = 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
+    if (xy_alpha_2 == 0.f) result = 1.f;
+    if (dot(v, m) * v.z <= 0.f) result = 0.f;
+    return result;
+}
+MIW_HD float mf_G(const Microfacet &d, V3 wi, V3 wo, V3 m) {      // :319-321
+    return mf_smith_g1(d, wi, m) * mf_smith_g1(d, wo, m);
+}
+
+// :358-411, GGX branch :396-410
+MIW_HD V2 mf_sample_visible_11(float cos_theta_i, V2 sample) {
+    V2 p = square_to_uniform_disk_concentric(sample);
+    float s = .5f * (1.f + cos_theta_i);
+    p.y = lerp_(safe_sqrt(1.f - sqr(p.x)), p.y, s);
+    float x = p.x, y = p.y,
+          z = safe_sqrt(1.f - squared_norm2(p));
+    float sin_theta_i = safe_sqrt(1.f - sqr(cos_theta_i));
+    float nrm = rcp(fmadd(sin_theta_i, y, cos_theta_i * z));
+    return v2(fmsub(cos_theta_i, y, sin_theta_i * z) * nrm, x * nrm);
+}
+
+// :214-223
+MIW_HD float mf_pdf(const Microfacet &d, V3 wi, V3 m) {
+    float result = mf_eval(d, m);
+    if (d.sample_visible) result *= mf_smith_g1(d, wi, m) * abs_dot(wi, m) / wi.z;
+    else                  result *= m.z;
+    return result;
+}
+
+// :234-316
+MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &pdf_out) {
+    if (!d.sample_visible) {
+        float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2, pdf;
+        // isotropic azimuth (:240-243); the anisotropic branch needs tan() and is
+        // rejected at scene upload for sample_visible=false.
+        sincos_((2.f * MIW_PI) * sample.y, sin_phi, cos_phi);
+        alpha_2 = d.alpha_u * d.alpha_u;
+        float tan_theta_m_2 = alpha_2 * sample.x / (1.f - sample.x);
+        cos_theta = rsqrt(1.f + tan_theta_m_2);
+        cos_theta_2 = sqr(cos_theta);
+        float temp = 1.f + tan_theta_m_2 / alpha_2,
+              cos_theta_3 = max_(cos_theta_2 * cos_theta, 1e-20f);
+        pdf = rcp(MIW_PI * d.alpha_u * d.alpha_v * cos_theta_3 * sqr(temp));
+        float sin_theta = __builtin_sqrtf(1.f - cos_theta_2);
+        m_out = v3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
+        pdf_out = pdf;
+    } else {
+        float sin_phi, cos_phi, cos_theta;
+        V3 wi_p = normalize(v3(d.alpha_u * wi.x, d.alpha_v * wi.y, wi.z));   // step 1
+        sincos_phi(wi_p, sin_phi, cos_phi);
+        cos_theta = wi_p.z;
+        V2 slope = mf_sample_visible_11(cos_theta, sample);                  // step 2
+        slope = v2(fmsub(cos_phi, slope.x, sin_phi * slope.y) * d.alpha_u,   // step 3
+                   fmadd(sin_phi, slope.x, cos_phi * slope.y) * d.alpha_v);
+        V3 m = normalize(v3(-slope.x, -slope.y, 1.f));                       // step 4
+        pdf_out = mf_eval(d, m) * mf_smith_g1(d, wi, m) * abs_dot(wi, m) / wi.z;
+        m_out = m;
+    }
+}
+
+// ---- SmoothDiffuse (diffuse.cpp) ------------------------------------------------
+MIW_HD V3 diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs) {
+    float cos_theta_i = wi.z;
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    if (!(cos_theta_i > 0.f)) return v3(0.f);                        // :88-91
+    bs.wo = square_to_cosine_hemisphere(sample2);
+    bs.pdf = square_to_cosine_hemisphere_pdf(bs.wo);
+    bs.eta = 1.f;
+    bs.sampled_type = BSDF_DiffuseReflection;
+    return (bs.pdf > 0.f) ? v3(b.p[0], b.p[1], b.p[2]) : v3(0.f);    // :101
+}
+MIW_HD V3 diffuse_eval(const BsdfRec &b, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return v3(0.f);
+    return v3(b.p[0], b.p[1], b.p[2]) * MIW_INV_PI * cos_theta_o;    // :116-117
+}
+MIW_HD float diffuse_pdf(V3 wi, V3 wo) {
+    float pdf = square_to_cosine_hemisphere_pdf(wo);
+    return (wi.z > 0.f && wo.z > 0.f) ? pdf : 0.f;
+}
+
+// ---- SmoothDielectric (dielectric.cpp:201-310, unpolarized branch :289-307) -------
+MIW_HD V3 dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &bs) {
+    float cos_theta_i = wi.z;
+    float r_i, cos_theta_t, eta_it, eta_ti;
+    fresnel(cos_theta_i, b.p[0], r_i, cos_theta_t, eta_it, eta_ti);
+    float t_i = 1.f - r_i;
+    bool selected_r = sample1 <= r_i;                                // :221
+    bs.pdf = selected_r ? r_i : t_i;
+    bs.sampled_type = selected_r ? BSDF_DeltaReflection : BSDF_DeltaTransmission;
+    bs.wo = selected_r ? reflect(wi) : refract(wi, cos_theta_t, eta_ti);
+    bs.eta = selected_r ? 1.f : eta_it;
+    V3 weight = v3(1.f);                                             // :290
+    if (selected_r) weight = weight * v3(b.p[1], b.p[2], b.p[3]);    // :296-297
+    else {
+        weight = weight * v3(b.p[4], b.p[5], b.p[6]);                // :299-300
+        weight = weight * sqr(eta_ti);                               // :302-307 (Radiance mode)
+    }
+    return weight;
+}
+
+// ---- RoughConductor (roughconductor.cpp) -------------------------------------------
+MIW_HD Microfacet rc_distr(const BsdfRec &b) {
+    return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[1], (b.flags & 2u) != 0);
+}
+MIW_HD V3 rc_fresnel(const BsdfRec &b, float c) {
+    return v3(fresnel_conductor(c, b.p[2], b.p[5]),
+              fresnel_conductor(c, b.p[3], b.p[6]),
+              fresnel_conductor(c, b.p[4], b.p[7]));
+}
+// :196-275
+MIW_HD V3 roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs) {
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    float cos_theta_i = wi.z;
+    if (!(cos_theta_i > 0.f)) return v3(0.f);
+    Microfacet distr = rc_distr(b);
+    V3 m;
+    mf_sample(distr, wi, sample2, m, bs.pdf);
+    bs.wo = reflect(wi, m);
+    bs.eta = 1.f;
+    bs.sampled_type = BSDF_GlossyReflection;
+    bool active = bs.pdf != 0.f && bs.wo.z > 0.f;
+    float weight;
+    if (distr.sample_visible) weight = mf_smith_g1(distr, bs.wo, m);
+    else weight = mf_G(distr, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
+    bs.pdf /= 4.f * dot(bs.wo, m);
+    V3 F = rc_fresnel(b, dot(wi, m));
+    V3 w = v3(weight) * v3(b.p[8], b.p[9], b.p[10]);
+    return active ? F * w : v3(0.f);
+}
+// :277-345
+MIW_HD V3 roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return v3(0.f);
+    V3 H = normalize(wo + wi);
+    Microfacet distr = rc_distr(b);
+    float D = mf_eval(distr, H);
+    bool active = D != 0.f;
+    float G = mf_G(distr, wi, wo, H);
+    float res = D * G / (4.f * wi.z);
+    V3 F = rc_fresnel(b, dot(wi, H));
+    V3 result = v3(res) * v3(b.p[8], b.p[9], b.p[10]);
+    return active ? F * result : v3(0.f);
+}
+// :347-382
+MIW_HD float roughconductor_pdf(const BsdfRec &b, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    V3 m = normalize(wo + wi);
+    bool active = cos_theta_i > 0.f && cos_theta_o > 0.f && dot(wi, m) > 0.f && dot(wo, m) > 0.f;
+    if (!active) return 0.f;
+    Microfacet distr = rc_distr(b);
+    float result;
+    if (distr.sample_visible)
+        result = mf_eval(distr, m) * mf_smith_g1(distr, wi, m) / (4.f * cos_theta_i);
+    else
+        result = mf_pdf(distr, wi, m) / (4.f * dot(wo, m));
+    return result;
+}
+
+// ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
+// Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
+MIW_HD V3 bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs) {
+    switch (b.type) {
+        case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs);
+        case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs);
+        default:                   return roughconductor_sample(b, wi, sample2, bs);
+    }
+}
+MIW_HD V3 bsdf_eval(const BsdfRec &b, V3 wi, V3 wo) {
+    switch (b.type) {
+        case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo);
+        case BSDF_TYPE_DIELECTRIC: return v3(0.f);                   // dielectric.cpp:312-315
+        default:                   return roughconductor_eval(b, wi, wo);
+    }
+}
+MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {
+    switch (b.type) {
+        case BSDF_TYPE_DIFFUSE:    return diffuse_pdf(wi, wo);
+        case BSDF_TYPE_DIELECTRIC: return 0.f;                       // dielectric.cpp:317-320
+        default:                   return roughconductor_pdf(b, wi, wo);
+    }
+}
+
+} // namespace miw

@@ -1,0 +1,313 @@
+// The path integrator re-expressed as per-lane wavefront stages.
+//
+// One lane = one pixel. scalar_rgb seeds one PCG32 per pixel and runs that
+// pixel's spp samples back to back on the same stream
+// (src/librender/integrator.cpp:196-209, src/librender/sampler.cpp:30-34), so
+// the sample loop of a pixel is serial; parallelism is across pixels. A lane
+// that finishes sample j regenerates sample j+1 in place.
+//
+// PathIntegrator::sample (src/integrators/path.cpp:100-211) is cut at its two
+// Scene::ray_intersect / ray_test calls into:
+//   lane_generate : render_sample prologue (integrator.cpp:233-261) -> primary ray
+//   [trace closest]                            -> hit queue
+//   lane_shade    : one iteration of the depth loop (path.cpp:124-208) -> shadow
+//                   ray + pending contribution, extension ray; on termination
+//                   the render_sample epilogue (integrator.cpp:264-287): splat,
+//                   advance, regenerate.
+//   [trace any]   : shadow visibility (scene.cpp:203-207)
+// The pending emitter-sampling contribution of iteration k is added at the top
+// of lane_shade in iteration k+1, before that iteration's emission term — the
+// same order of float additions into `result` as the reference.
+//
+// Queue layout in HBM: structure-of-16-byte-fields, one array per field group,
+// indexed by lane; every access below is one aligned dwordx4 (or dwordx2) per
+// lane, contiguous across a wavefront.
+#pragma once
+#include "base.h"
+#include "rng.h"
+#include "scene.h"
+#include "film.h"
+
+namespace miw {
+
+struct alignas(16) F4 { float x, y, z, w; };
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+struct alignas(8)  F2 { float x, y; };
+
+// lane flag word (st.z)
+enum : uint32_t {
+    LF_DEPTH_MASK  = 0x0fffu,
+    LF_VALID_RAY   = 1u << 12,   // first intersection was valid (alpha, path.cpp:121)
+    LF_PREV_DELTA  = 1u << 13,   // last BSDF sample was a delta lobe
+    LF_HAS_SHADOW  = 1u << 14,   // shadow ray + pending contribution queued
+    LF_RAY_ACTIVE  = 1u << 15,   // extension / primary ray queued
+    LF_DONE        = 1u << 16,   // all spp of this pixel finished
+    LF_DEAD_PENDING= 1u << 17,   // path over, waiting for its last shadow ray
+};
+
+struct LaneQueues {
+    // path state (48 B/lane + 8 B position sample + 4 B static pixel id)
+    F4 *tp;        // throughput.rgb, eta
+    F4 *res;       // result.rgb, prev bsdf pdf
+    U4 *st;        // rng state lo, hi, flags|depth, sample index
+    F2 *pos;       // position_sample of the sample in flight
+    const uint32_t *pixel;  // x | y << 16 (film coordinates incl. crop offset)
+    // extension / primary ray queue (32 B/lane)
+    F4 *ray_o;     // o.xyz, mint
+    F4 *ray_d;     // d.xyz, maxt
+    // hit queue (16 B/lane)
+    F4 *hit;       // t, u, v, bits(tri index in leaf order | MIW_MISS)
+    // shadow queue (32 B + 4 B/lane); origin and mint are shared with ray_o
+    F4 *sh_d;      // d.xyz, maxt
+    F4 *sh_c;      // pending contribution rgb
+    uint32_t *sh_vis; // 1 = unoccluded (written by the any-hit trace)
+};
+
+struct RenderParams {
+    SensorRec sensor;
+    FilmRec film;
+    uint32_t spp;
+    int32_t max_depth, rr_depth;
+    uint32_t n_lanes;
+};
+
+// per-launch device counters (mi_get_counters)
+struct Counters {
+    unsigned long long segments;   // iterations of the depth loop that reached shading
+    unsigned long long samples;    // finished camera samples
+    unsigned long long shadow_rays;
+    unsigned long long active_lanes; // lanes not DONE after the last shade pass
+};
+
+MIW_HD float next_1d(PCG32 &r) { return pcg32_next_f32(r); }
+MIW_HD V2 next_2d(PCG32 &r) { float a = pcg32_next_f32(r); float b = pcg32_next_f32(r); return v2(a, b); }
+
+// integrator.cpp:233-261 — start sample `sample_idx` of this lane's pixel, or
+// retire the lane. Writes ray + fresh path state into the caller's registers.
+struct LaneRegs {
+    PCG32 rng;
+    uint32_t flags, sample_idx;
+    V3 tp, res; float eta, prev_pdf;
+    V2 pos;
+    Ray ray;
+};
+
+MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L) {
+    if (L.sample_idx >= P.spp) {                         // pixel finished: retire the lane
+        L.flags = LF_DONE;
+        L.ray.o = L.ray.d = v3(0.f); L.ray.mint = 0.f; L.ray.maxt = -1.f;   // maxt < 0: no ray queued
+        return;
+    }
+    float px = (float) (pixel & 0xffffu), py = (float) (pixel >> 16);
+    V2 j = next_2d(L.rng);                               // :242
+    L.pos = v2(px + j.x, py + j.y);
+    (void) next_1d(L.rng);                               // :252 wavelength sample, always drawn
+    V2 adj = v2((L.pos.x - (float) P.film.crop_x) / (float) P.film.crop_w,    // :254-256
+                (L.pos.y - (float) P.film.crop_y) / (float) P.film.crop_h);
+    L.ray = sensor_sample_ray(P.sensor, adj);            // :258
+    L.tp = v3(1.f); L.res = v3(0.f); L.eta = 1.f; L.prev_pdf = 0.f;   // path.cpp:111-116
+    L.flags = 1u | LF_RAY_ACTIVE;                        // depth = 1
+}
+
+// integrator.cpp:264-287 — convert, splat, advance
+template <typename Add>
+MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, Add add) {
+    V3 xyz = srgb_to_xyz(L.res);                         // :272-273 (ray_weight == 1 in RGB)
+    float aovs[5] = { xyz.x, xyz.y, xyz.z, (L.flags & LF_VALID_RAY) ? 1.f : 0.f, 1.f };
+    film_splat(P.film, (int) (pixel & 0xffffu), (int) (pixel >> 16), L.pos, aovs, add);
+    L.sample_idx++;                                      // :287
+}
+
+MIW_HD void lane_load(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
+    U4 st = Q.st[lane];
+    L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
+    L.rng.inc = MIW_PCG32_SCALAR_INC;
+    L.flags = st.z; L.sample_idx = st.w;
+}
+MIW_HD void lane_load_path(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
+    F4 a = Q.tp[lane], b = Q.res[lane];
+    L.tp = v3(a.x, a.y, a.z); L.eta = a.w;
+    L.res = v3(b.x, b.y, b.z); L.prev_pdf = b.w;
+    F2 p = Q.pos[lane]; L.pos = v2(p.x, p.y);
+}
+MIW_HD void lane_store(const LaneQueues &Q, uint32_t lane, const LaneRegs &L, bool store_pos) {
+    U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
+    st.z = L.flags; st.w = L.sample_idx;
+    Q.st[lane] = st;
+    F4 a; a.x = L.tp.x; a.y = L.tp.y; a.z = L.tp.z; a.w = L.eta; Q.tp[lane] = a;
+    F4 b; b.x = L.res.x; b.y = L.res.y; b.z = L.res.z; b.w = L.prev_pdf; Q.res[lane] = b;
+    if (store_pos) { F2 p; p.x = L.pos.x; p.y = L.pos.y; Q.pos[lane] = p; }
+    F4 o; o.x = L.ray.o.x; o.y = L.ray.o.y; o.z = L.ray.o.z; o.w = L.ray.mint; Q.ray_o[lane] = o;
+    F4 d; d.x = L.ray.d.x; d.y = L.ray.d.y; d.z = L.ray.d.z; d.w = L.ray.maxt; Q.ray_d[lane] = d;
+}
+MIW_HD void lane_clear_shadow(const LaneQueues &Q, uint32_t lane) {
+    F4 dead; dead.x = dead.y = dead.z = 0.f; dead.w = -1.f;   // maxt < 0: no shadow ray queued
+    Q.sh_d[lane] = dead;
+}
+
+// Stage 0: seed every lane (sampler.cpp:83-96 via integrator.cpp:198) and
+// start its first sample. `seed` = base_seed + block_id * block_size^2 + morton_i.
+MIW_HD void lane_init(const RenderParams &P, const LaneQueues &Q, uint32_t lane, uint32_t pixel, uint64_t seed) {
+    LaneRegs L;
+    pcg32_seed(L.rng, seed, MIW_PCG32_DEFAULT_STREAM);
+    L.sample_idx = 0; L.flags = 0;
+    L.tp = v3(1.f); L.res = v3(0.f); L.eta = 1.f; L.prev_pdf = 0.f; L.pos = v2(0.f, 0.f);
+    L.ray.o = L.ray.d = v3(0.f); L.ray.mint = 0.f; L.ray.maxt = -1.f;
+    lane_begin_sample(P, pixel, L);
+    lane_store(Q, lane, L, true);
+    lane_clear_shadow(Q, lane);
+    Q.sh_vis[lane] = 0;
+}
+// A lane of the launch grid that maps to no pixel (clipped edge block, integrator.cpp:201-202)
+MIW_HD void lane_init_unused(const LaneQueues &Q, uint32_t lane) {
+    LaneRegs L;
+    L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC; L.sample_idx = 0; L.flags = LF_DONE;
+    L.tp = v3(0.f); L.res = v3(0.f); L.eta = 0.f; L.prev_pdf = 0.f; L.pos = v2(0.f, 0.f);
+    L.ray.o = L.ray.d = v3(0.f); L.ray.mint = 0.f; L.ray.maxt = -1.f;
+    lane_store(Q, lane, L, true);
+    lane_clear_shadow(Q, lane);
+    Q.sh_vis[lane] = 0;
+}
+
+// Stage 2: one iteration of the depth loop for one lane.
+// Returns true while the lane still has work (not DONE).
+template <typename Add>
+MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
+                       uint32_t lane, Counters *cnt_local, Add add) {
+    LaneRegs L;
+    lane_load(Q, lane, L);
+    if (L.flags & LF_DONE) return false;
+    lane_load_path(Q, lane, L);
+    const uint32_t pixel = Q.pixel[lane];
+    const bool had_shadow = (L.flags & LF_HAS_SHADOW) != 0;
+
+    // (k-1)'s emitter-sampling contribution, now that its shadow ray is resolved
+    // (path.cpp:171 with spec[ray_test] = 0 from scene.cpp:206)
+    if (had_shadow) {
+        if (Q.sh_vis[lane]) { F4 c = Q.sh_c[lane]; L.res = L.res + v3(c.x, c.y, c.z); }
+        L.flags &= ~LF_HAS_SHADOW;
+    }
+
+    bool finished = false;        // the camera sample in flight is complete
+
+    if (L.flags & LF_DEAD_PENDING) {
+        finished = true;
+    } else {
+        const uint32_t depth = L.flags & LF_DEPTH_MASK;
+        F4 h = Q.hit[lane];
+        const uint32_t tri_idx = f2u(h.w);
+        const bool valid = tri_idx != MIW_MISS;
+        F4 ro = Q.ray_o[lane], rd = Q.ray_d[lane];
+        V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
+
+        SurfaceInteraction si;
+        uint32_t bsdf_index = 0;
+        int32_t emitter = -1;                            // scene.h:243-253 (no environment emitter)
+        if (valid) {
+            const Tri &tr = sc.tris[tri_idx];
+            const ShapeRec &shape = sc.shapes[tr.shape];
+            const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
+            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+            si.shape = tr.shape; si.prim = tr.prim;
+            emitter = shape.emitter; bsdf_index = shape.bsdf;
+        }
+        if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
+
+        // ---- intersection with emitters, path.cpp:126-129 ----
+        if (emitter >= 0) {
+            float emission_weight = 1.f;                 // :109
+            if (depth > 1) {                             // :194-205, evaluated lazily
+                float emitter_pdf = 0.f;
+                if (!(L.flags & LF_PREV_DELTA)) {
+                    // DirectionSample3f ds(si_bsdf, si), records.h:167-173
+                    V3 d = si.p - ray_o;
+                    float dist = norm(d);
+                    d = d / dist;
+                    emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, si.sh.n);
+                }
+                emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
+            }
+            L.res = L.res + emission_weight * L.tp * emitter_eval(sc.emitters[emitter], si.wi);
+        }
+
+        bool active = valid;                             // :131
+
+        // ---- Russian roulette, :137-141 (the draw happens even for dead paths) ----
+        if ((int32_t) depth > P.rr_depth) {
+            float q = min_(hmax(L.tp) * sqr(L.eta), .95f);
+            active = (next_1d(L.rng) < q) && active;
+            L.tp = L.tp * rcp(q);
+        }
+
+        // ---- termination, :147-149 ----
+        if (depth >= (uint32_t) P.max_depth || !active) {
+            finished = true;
+        } else {
+            if (cnt_local) cnt_local->segments++;
+            const BsdfRec &bsdf = sc.bsdfs[bsdf_index];
+            const uint32_t bflags = bsdf_flags(bsdf);
+            L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
+            L.ray.d = v3(0.f); L.ray.maxt = -1.f;
+
+            // ---- emitter sampling, :155-172 ----
+            if (bflags & BSDF_Smooth) {
+                DirectionSample ds;
+                V3 emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds);
+                if (ds.pdf != 0.f) {
+                    V3 wo = to_local(si.sh, ds.d);
+                    V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);
+                    float bpdf = bsdf_pdf(bsdf, si.wi, wo);
+                    float mis = mis_weight(ds.pdf, bpdf);
+                    V3 c = mis * L.tp * bsdf_val * emitter_val;
+                    if (!all_zero(c)) {
+                        // shadow ray, scene.cpp:203-205
+                        F4 sd; sd.x = ds.d.x; sd.y = ds.d.y; sd.z = ds.d.z;
+                        sd.w = ds.dist * (1.f - MIW_SHADOW_EPSILON);
+                        Q.sh_d[lane] = sd;
+                        F4 sc4; sc4.x = c.x; sc4.y = c.y; sc4.z = c.z; sc4.w = 0.f;
+                        Q.sh_c[lane] = sc4;
+                        L.flags |= LF_HAS_SHADOW;
+                        if (cnt_local) cnt_local->shadow_rays++;
+                    }
+                }
+            }
+
+            // ---- BSDF sampling, :177-186 (Clang order: next_1d, then next_2d) ----
+            float s1 = next_1d(L.rng);
+            V2 s2 = next_2d(L.rng);
+            BSDFSample bs;
+            V3 bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs);
+            L.tp = L.tp * bsdf_val;
+            if (all_zero(L.tp)) {                        // :182-184
+                if (L.flags & LF_HAS_SHADOW) {
+                    // the sample ends once its last shadow ray has been resolved
+                    L.flags = (L.flags & ~LF_RAY_ACTIVE) | LF_DEAD_PENDING;
+                } else {
+                    finished = true;
+                }
+            } else {
+                L.eta *= bs.eta;                         // :186
+                L.ray.d = to_world(si.sh, bs.wo);        // :189, interaction.h:58-61
+                L.ray.maxt = MIW_INFINITY;
+                L.prev_pdf = bs.pdf;
+                L.flags = (L.flags & ~(LF_DEPTH_MASK | LF_PREV_DELTA)) | ((depth + 1) & LF_DEPTH_MASK)
+                        | ((bs.sampled_type & BSDF_Delta) ? LF_PREV_DELTA : 0u) | LF_RAY_ACTIVE;
+            }
+        }
+    }
+
+    bool store_pos = false;
+    if (finished) {
+        // ---- splat, advance, regenerate (integrator.cpp:264-287) ----
+        lane_finish_sample(P, pixel, L, add);
+        if (cnt_local) cnt_local->samples++;
+        L.flags = 0;
+        lane_begin_sample(P, pixel, L);
+        store_pos = true;
+    }
+    lane_store(Q, lane, L, store_pos);
+    if (had_shadow && !(L.flags & LF_HAS_SHADOW)) lane_clear_shadow(Q, lane);
+    return !(L.flags & LF_DONE);
+}
+
+} // namespace miw

@@ -1,0 +1,161 @@
+// Flat scene view handed to every hot-path function (pointers are HBM addresses
+// on the device, ordinary host addresses in the CPU checker), the area emitter
+// (src/emitters/area.cpp), Scene::sample_emitter_direction / pdf_emitter_direction
+// (src/librender/scene.cpp:164-231) and the perspective sensor
+// (src/sensors/perspective.cpp:182-216).
+#pragma once
+#include "base.h"
+#include "shape.h"
+#include "bsdf.h"
+
+namespace miw {
+
+#define MIW_MISS 0xffffffffu     /* "no triangle" in the hit queue */
+
+// 64-byte BVH2 node: both child boxes live in the parent so one aligned 64 B
+// fetch feeds two slab tests. child >= 0: inner node index; child < 0: leaf,
+// ~child = (first_tri << 4) | (count - 1), count in 1..16; an absent child has
+// an inverted box (lo = +inf, hi = -inf) and child = -1... see bvh.h.
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t parent;      // -1 for the root
+    int32_t pad;
+};
+
+struct ShapeRec {
+    uint32_t bsdf;       // index into bsdfs
+    int32_t  emitter;    // index into emitters or -1
+    uint32_t flags;      // bit0: has vertex normals
+    uint32_t pad;
+};
+
+struct EmitterRec {
+    float radiance[3];
+    uint32_t shape;
+    uint32_t tri_first;  // first face of this emitter in emit_tri / emit_pmf / emit_cdf
+    uint32_t tri_count;
+    uint32_t valid_lo, valid_hi;
+    float sum, normalization;
+    uint32_t flags;      // bit0: emit_vnorm valid for this emitter
+    uint32_t pad;
+};
+
+struct SceneView {
+    const BvhNode *nodes;   uint32_t node_count;
+    const Tri     *tris;    uint32_t tri_count;     // BVH leaf order
+    const float   *tri_vn;                          // 9 floats per tri (leaf order) or nullptr
+    const ShapeRec *shapes; uint32_t shape_count;
+    const BsdfRec  *bsdfs;  uint32_t bsdf_count;
+    const EmitterRec *emitters; uint32_t emitter_count;
+    const float *emit_tri;                          // 9 floats per emitter face
+    const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
+    const float *emit_pmf, *emit_cdf;
+};
+
+struct DirectionSample { V3 p, n, d; float dist, pdf; uint32_t emitter; };
+
+MIW_HD MeshSampler emitter_mesh(const SceneView &sc, const EmitterRec &e) {
+    MeshSampler m;
+    m.tri = sc.emit_tri + 9 * (size_t) e.tri_first;
+    m.vnorm = (e.flags & 1u) ? sc.emit_vnorm + 9 * (size_t) e.tri_first : nullptr;
+    m.pmf = sc.emit_pmf + e.tri_first;
+    m.cdf = sc.emit_cdf + e.tri_first;
+    m.count = e.tri_count;
+    m.valid_lo = e.valid_lo; m.valid_hi = e.valid_hi;
+    m.sum = e.sum; m.normalization = e.normalization;
+    return m;
+}
+
+// scene.cpp:164-200 + area.cpp:121-166 + shape.cpp:292-309, *without* the
+// visibility test (the shadow ray is a separate wavefront stage). Returns the
+// unoccluded emitter value; `ds.pdf == 0` means "no sample" (path.cpp:160).
+MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds) {
+    if (sc.emitter_count == 0) {                       // scene.cpp:208-211
+        ds.p = ds.n = ds.d = v3(0.f); ds.dist = 0.f; ds.pdf = 0.f; ds.emitter = 0;
+        return v3(0.f);
+    }
+    uint32_t index = 0;
+    float emitter_pdf = 1.f;
+    if (sc.emitter_count > 1) {                        // scene.cpp:180-188
+        float n = (float) sc.emitter_count;
+        emitter_pdf = 1.f / n;
+        uint32_t i = (uint32_t) (sample.x * n);
+        index = i < sc.emitter_count - 1 ? i : sc.emitter_count - 1;
+        sample.x = (sample.x - (float) index * emitter_pdf) * n;
+    }
+    const EmitterRec &e = sc.emitters[index];
+    MeshSampler mesh = emitter_mesh(sc, e);
+    // Shape::sample_direction, shape.cpp:292-309
+    PositionSample ps = mesh_sample_position(mesh, sample);
+    ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf; ds.emitter = index;
+    ds.d = ds.p - ref_p;
+    float dist_squared = squared_norm(ds.d);
+    ds.dist = __builtin_sqrtf(dist_squared);
+    ds.d = ds.d / ds.dist;
+    float dp = abs_dot(ds.d, ds.n);
+    ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+    // AreaLight::sample_direction, area.cpp:131-136,165
+    bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+    V3 spec = v3(e.radiance[0], e.radiance[1], e.radiance[2]) / ds.pdf;
+    if (!active) spec = v3(0.f);
+    if (sc.emitter_count > 1) {                        // scene.cpp:195-197
+        ds.pdf *= emitter_pdf;
+        spec = spec * rcp(emitter_pdf);
+    }
+    return spec;
+}
+
+// scene.cpp:216-231 + area.cpp:168-187 + shape.cpp:311-323.
+// `ds_d`, `ds_dist`, `ds_n` come from DirectionSample(si_bsdf, si) (records.h:167-173).
+MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n) {
+    const EmitterRec &e = sc.emitters[emitter];
+    float dp = dot(ds_d, ds_n);
+    bool active = dp < 0.f;
+    float pdf = e.normalization,
+          adp = abs_dot(ds_d, ds_n);
+    pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
+    float value = active ? pdf : 0.f;
+    if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);
+    return value;
+}
+
+// AreaLight::eval, area.cpp:63-71
+MIW_HD V3 emitter_eval(const EmitterRec &e, V3 wi) {
+    return wi.z > 0.f ? v3(e.radiance[0], e.radiance[1], e.radiance[2]) : v3(0.f);
+}
+
+// path.cpp:223-227
+MIW_HD float mis_weight(float pdf_a, float pdf_b) {
+    pdf_a *= pdf_a; pdf_b *= pdf_b;
+    return pdf_a > 0.f ? pdf_a / (pdf_a + pdf_b) : 0.f;
+}
+
+// ---- perspective sensor -------------------------------------------------------------------
+// The host precomputes sample_to_camera (sensor.h:196-231, inverse) and the
+// camera-to-world matrix (transform.h:241-269) once; perspective.cpp:182-216
+// is what runs per sample. `position_sample` is already divided by the crop
+// size (integrator.cpp:254-256).
+struct SensorRec {
+    float sample_to_camera[16];
+    float to_world[16];
+    float near_clip, far_clip;
+    float pp_offset[2];          // principal point offset (perspective.cpp:111-116)
+};
+
+MIW_HD Ray sensor_sample_ray(const SensorRec &s, V2 position_sample) {
+    V3 near_p = xf_point_persp(s.sample_to_camera,
+                               v3(position_sample.x + s.pp_offset[0],
+                                  position_sample.y + s.pp_offset[1], 0.f));
+    V3 d = normalize(near_p);
+    float inv_z = rcp(d.z);
+    Ray r;
+    r.mint = s.near_clip * inv_z;
+    r.maxt = s.far_clip * inv_z;
+    r.o = xf_point_affine(s.to_world, v3(0.f));
+    r.d = xf_vector(s.to_world, d);
+    return r;
+}
+
+} // namespace miw

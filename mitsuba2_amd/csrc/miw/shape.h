@@ -1,0 +1,141 @@
+// Triangle intersection, surface-interaction reconstruction and mesh area
+// sampling — the Mesh/Shape part of the hot path.
+//
+// Follows: include/mitsuba/render/mesh.h:194-226 (Moeller-Trumbore, no culling),
+// src/librender/mesh.cpp:449-545 (compute_surface_interaction),
+// include/mitsuba/render/interaction.h:58-61,153-156,571-596,
+// src/librender/mesh.cpp:352-397 (sample_position),
+// include/mitsuba/core/distr_1d.h:144-203 (DiscreteDistribution).
+#pragma once
+#include "base.h"
+#include "warp.h"
+
+namespace miw {
+
+struct Ray { V3 o, d; float mint, maxt; };
+
+// One triangle as the device stores it (48 B, BVH leaf order). p1/p2 are kept
+// (not edges) because compute_surface_interaction interpolates the original
+// vertices (mesh.cpp:484); the edges are one exactly-rounded subtraction away.
+struct Tri {
+    float p0[3], p1[3], p2[3];
+    uint32_t shape;      // index into the shape table
+    uint32_t prim;       // global primitive id (scene order) — closest-hit tie break
+    uint32_t pad;
+};
+
+MIW_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
+
+// mesh.h:194-226. Returns true on a hit inside [mint, maxt].
+MIW_HD bool ray_intersect_triangle(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, float maxt,
+                                   float &t_out, float &u_out, float &v_out) {
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    V3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    float t = dot(e2, qvec) * inv_det;
+    active = active && t >= mint && t <= maxt;
+    t_out = t; u_out = u; v_out = v;
+    return active;
+}
+
+// What the shading stage needs of a SurfaceInteraction3f (interaction.h).
+struct SurfaceInteraction {
+    float t;
+    V3 p, n;          // position, geometric normal
+    Frame sh;         // shading frame
+    V3 wi;            // incident direction, local frame
+    V2 uv;
+    uint32_t shape, prim;
+};
+
+// mesh.cpp:449-545 + interaction.h:571-596, for meshes without texcoords.
+// `vn` = per-vertex normals of this face or nullptr (mesh.cpp:514-519).
+MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
+                                        float t, float b1, float b2, V3 ray_d,
+                                        SurfaceInteraction &si) {
+    float b0 = 1.f - b1 - b2;
+    V3 dp0 = p1 - p0, dp1 = p2 - p0;
+    si.t = t;
+    si.p = p0 * b0 + p1 * b1 + p2 * b2;                // mesh.cpp:484
+    si.n = normalize(cross(dp0, dp1));                 // :487
+    si.uv = v2(b1, b2);                                // :490
+    V3 dp_du, dp_dv;
+    coordinate_system(si.n, dp_du, dp_dv);             // :491
+    if (vn) {                                          // :514-519
+        V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
+        si.sh.n = normalize(n0 * b0 + n1 * b1 + n2 * b2);
+    } else {
+        si.sh.n = si.n;                                // :541
+    }
+    // initialize_sh_frame, interaction.h:153-156
+    si.sh.s = normalize(fnmadd3(si.sh.n, dot(si.sh.n, dp_du), dp_du));
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = to_local(si.sh, -ray_d);                   // interaction.h:591
+}
+
+// interaction.h:58-61 — (1 + hmax(abs(p))) * RayEpsilon
+MIW_HD float spawn_mint(V3 p) { return (1.f + hmax(abs3(p))) * MIW_RAY_EPSILON; }
+
+// ---- area sampling of an emitter mesh -----------------------------------------
+// Per-emitter tables built on the host exactly as DiscreteDistribution does
+// (distr_1d.h:55-87: CDF accumulated in double, stored float).
+struct MeshSampler {
+    const float *tri;     // 9 floats per face: p0,p1,p2 (face order of the mesh)
+    const float *vnorm;   // 9 floats per face or nullptr
+    const float *pmf;     // face areas (unnormalized)
+    const float *cdf;     // running sum (unnormalized)
+    uint32_t count;       // number of faces
+    uint32_t valid_lo, valid_hi; // first / last face with non-zero area
+    float sum, normalization;
+};
+
+// distr_1d.h:144-154: first index in [valid_lo, valid_hi] with cdf[idx] >= value
+MIW_HD uint32_t distr_sample(const MeshSampler &m, float value) {
+    value *= m.sum;
+    uint32_t lo = m.valid_lo, hi = m.valid_hi;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (m.cdf[mid] < value) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct PositionSample { V3 p, n; V2 uv; float pdf; };
+
+// mesh.cpp:352-397
+MIW_HD PositionSample mesh_sample_position(const MeshSampler &m, V2 sample) {
+    // sample_reuse, distr_1d.h:193-203
+    uint32_t idx = distr_sample(m, sample.y);
+    float pmf = m.pmf[idx] * m.normalization,
+          cdf = idx > 0 ? m.cdf[idx - 1] * m.normalization : 0.f;
+    sample.y = (sample.y - cdf) / pmf;
+
+    const float *f = m.tri + 9 * (size_t) idx;
+    V3 p0 = ld3(f), p1 = ld3(f + 3), p2 = ld3(f + 6);
+    V3 e0 = p1 - p0, e1 = p2 - p0;
+    V2 b = square_to_uniform_triangle(sample);
+
+    PositionSample ps;
+    ps.p = p0 + e0 * b.x + e1 * b.y;
+    ps.pdf = m.normalization;
+    ps.uv = b;
+    if (m.vnorm) {
+        const float *vn = m.vnorm + 9 * (size_t) idx;
+        V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
+        ps.n = normalize(n0 * (1.f - b.x - b.y) + n1 * b.x + n2 * b.y);
+    } else {
+        ps.n = normalize(cross(e0, e1));
+    }
+    return ps;
+}
+
+// mesh.h:107-117
+MIW_HD float face_area(V3 p0, V3 p1, V3 p2) { return 0.5f * norm(cross(p1 - p0, p2 - p0)); }
+
+} // namespace miw

@@ -1,0 +1,743 @@
+// libmiwave.so — gfx950 kernels and the C ABI declared in include/miwave.h.
+//
+// Kernel set (one launch each per wavefront iteration, all over lane-indexed
+// SoA-of-16-byte-field queues in HBM, see miw/path.h):
+//   k_init_lanes     render_block prologue: pixel <-> lane map, PCG32 seeding,
+//                    first camera ray          (integrator.cpp:181-261)
+//   k_trace<closest> Scene::ray_intersect_preliminary over the ray queue
+//   k_trace<any>     Scene::ray_test over the shadow queue
+//   k_shade          one depth-loop iteration of PathIntegrator::sample, plus
+//                    ImageBlock::put + regeneration when a sample ends
+//   k_film_resolve   float64 accumulators -> float32 XYZAW film
+//   k_trace_soa      the public mi_trace entry (caller's SoA rays)
+//   k_eval           leaf-function known-answer evaluation (mi_eval)
+// The BVH (+ all triangles when they fit) is staged in LDS by every trace
+// workgroup; traversal is stackless (miw/bvh.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include <string>
+#include <vector>
+#include <chrono>
+#include <atomic>
+#include <algorithm>
+
+#include "../../include/miwave.h"
+#include "miw/base.h"
+#include "miw/rng.h"
+#include "miw/warp.h"
+#include "miw/shape.h"
+#include "miw/bsdf.h"
+#include "miw/scene.h"
+#include "miw/film.h"
+#include "miw/bvh.h"
+#include "miw/path.h"
+#include "bvh_build.h"
+
+using namespace miw;
+
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
+static_assert(sizeof(Tri) == 48, "Tri must be 48 bytes");
+static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layout");
+
+#define MIW_BLOCK 256
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+
+struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
+    uint32_t nodes_staged;  // first `nodes_staged` BVH nodes (breadth-first = top of tree)
+    uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
+};
+
+__device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
+    const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
+    uint32_t n16 = cfg.nodes_staged * (sizeof(BvhNode) / 16);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) smem[i] = src_n[i];
+    const uint4 *src_t = reinterpret_cast<const uint4 *>(sc.tris);
+    uint32_t t16 = cfg.tris_staged * (sizeof(Tri) / 16);
+    uint4 *dst_t = smem + n16;
+    for (uint32_t i = threadIdx.x; i < t16; i += blockDim.x) dst_t[i] = src_t[i];
+    __syncthreads();
+}
+
+template <bool AnyHit>
+__device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
+                                          V3 o, V3 d, float mint, float maxt, Hit &h) {
+    RayPrep r = ray_prepare(o, d, mint, maxt);
+    const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
+    const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
+    const BvhNode *gnodes = sc.nodes;
+    const Tri *gtris = sc.tris;
+    if (cfg.nodes_staged >= sc.node_count && cfg.tris_staged >= sc.tri_count) {
+        // whole scene is LDS resident: pure ds_read traversal
+        auto node_at = [lnodes](int32_t i) -> const BvhNode & { return lnodes[i]; };
+        auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
+    } else {
+        uint32_t ns = cfg.nodes_staged;
+        auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
+            return (uint32_t) i < ns ? lnodes[i] : gnodes[i];
+        };
+        auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+
+struct InitArgs {
+    const uint32_t *block_ids;    // per block (row-major grid)
+    const uint32_t *tile_list;    // or nullptr
+    uint32_t blocks_x, blocks_y;
+    uint32_t bs, bs2_log2;
+    uint64_t base_seed;
+};
+
+__global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQueues Q, uint32_t *pixel_out, InitArgs A) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= P.n_lanes) return;
+    uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
+    uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
+    uint32_t x, y;
+    morton_decode2(i, x, y);                                   // integrator.cpp:200
+    int32_t bw = P.film.crop_w - (int32_t) (bx * A.bs), bh = P.film.crop_h - (int32_t) (by * A.bs);
+    if (bw > (int32_t) A.bs) bw = (int32_t) A.bs;
+    if (bh > (int32_t) A.bs) bh = (int32_t) A.bs;
+    if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
+        pixel_out[lane] = 0;
+        lane_init_unused(Q, lane);
+        return;
+    }
+    uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
+    uint32_t pixel = px | (py << 16);
+    pixel_out[lane] = pixel;
+    uint64_t seed = A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i;   // :198
+    lane_init(P, Q, lane, pixel, seed);
+}
+
+template <bool AnyHit>
+__global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q, uint32_t n_lanes, TraceLds cfg) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n_lanes) return;
+    F4 d = AnyHit ? Q.sh_d[lane] : Q.ray_d[lane];
+    if (d.w < 0.f) return;                                     // no ray queued for this lane
+    F4 o = Q.ray_o[lane];
+    Hit h;
+    bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, h);
+    if (AnyHit) {
+        Q.sh_vis[lane] = hit ? 0u : 1u;
+    } else {
+        F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
+        Q.hit[lane] = r;
+    }
+}
+
+struct FilmAdd {
+    double *accum;
+    __device__ __forceinline__ void operator()(int texel, int k, float v) const {
+        unsafeAtomicAdd(accum + (size_t) texel * MIW_FILM_CHANNELS + k, (double) v);
+    }
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    if (lane < P.n_lanes) {
+        FilmAdd add; add.accum = accum;
+        // a lane that had a shadow ray queued must clear it if it queues none now
+        bool alive = lane_shade(P, sc, Q, lane, &local, add);
+        local.active_lanes = alive ? 1 : 0;
+    }
+    unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples),
+                       c = wave_sum(local.shadow_rays), d = wave_sum(local.active_lanes);
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&cnt->segments, a);
+        if (b) atomicAdd(&cnt->samples, b);
+        if (c) atomicAdd(&cnt->shadow_rays, c);
+        if (d) atomicAdd(&cnt->active_lanes, d);
+    }
+}
+
+__global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (out64) out64[i] = accum[i]; else out32[i] = (float) accum[i];
+}
+
+struct SoaRays { const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt; };
+struct SoaHits { float *t, *u, *v; uint32_t *prim, *shape; };
+
+template <bool AnyHit>
+__global__ __launch_bounds__(MIW_BLOCK) void k_trace_soa(SceneView sc, SoaRays R, SoaHits H, uint64_t n, TraceLds cfg) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Hit h;
+    bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(R.ox[i], R.oy[i], R.oz[i]), v3(R.dx[i], R.dy[i], R.dz[i]),
+                                 R.mint[i], R.maxt[i], h);
+    H.t[i] = hit ? h.t : MIW_INFINITY;
+    if (H.u) H.u[i] = h.u;
+    if (H.v) H.v[i] = h.v;
+    if (H.prim) H.prim[i] = hit ? h.prim : 0xffffffffu;
+    if (H.shape) H.shape[i] = hit ? sc.tris[h.tri].shape : 0xffffffffu;
+}
+
+__global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, int is, float *out, int os, uint64_t n) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + i * (uint64_t) is;
+    float *o = out + i * (uint64_t) os;
+    switch (op) {
+        case MI_EVAL_PCG32: {
+            PCG32 r; pcg32_seed(r, (uint64_t) f2u(a[0]) | ((uint64_t) f2u(a[1]) << 32), MIW_PCG32_DEFAULT_STREAM);
+            for (int k = 0; k < 8; ++k) o[k] = pcg32_next_f32(r);
+        } break;
+        case MI_EVAL_SINCOS: sincos_(a[0], o[0], o[1]); break;
+        case MI_EVAL_COSINE_HEMISPHERE: {
+            V3 w = square_to_cosine_hemisphere(v2(a[0], a[1]));
+            o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = square_to_cosine_hemisphere_pdf(w);
+        } break;
+        case MI_EVAL_BSDF: {
+            const BsdfRec &b = sc.bsdfs[f2u(a[0])];
+            V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
+            BSDFSample bs; V3 w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs);
+            o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
+            o[6] = w.x; o[7] = w.y; o[8] = w.z;
+            V3 e = bsdf_eval(b, wi, wo); o[9] = e.x; o[10] = e.y; o[11] = e.z;
+            o[12] = bsdf_pdf(b, wi, wo);
+        } break;
+        case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
+        case MI_EVAL_CAMERA_RAY: {
+            V2 adj = v2((a[0] - (float) P.film.crop_x) / (float) P.film.crop_w,
+                        (a[1] - (float) P.film.crop_y) / (float) P.film.crop_h);
+            Ray r = sensor_sample_ray(P.sensor, adj);
+            o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.mint; o[7] = r.maxt;
+        } break;
+        case MI_EVAL_EMITTER_SAMPLE: {
+            DirectionSample ds; V3 s = sample_emitter_direction(sc, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds);
+            o[0] = ds.d.x; o[1] = ds.d.y; o[2] = ds.d.z; o[3] = ds.dist; o[4] = ds.pdf;
+            o[5] = s.x; o[6] = s.y; o[7] = s.z; o[8] = ds.p.x; o[9] = ds.p.y; o[10] = ds.p.z;
+            o[11] = ds.n.x; o[12] = ds.n.y; o[13] = ds.n.z;
+        } break;
+        case MI_EVAL_FP_SEMANTICS: {
+            float x = a[0], y = a[1], z = a[2];
+            o[0] = x + y; o[1] = x * y; o[2] = x / y; o[3] = __builtin_sqrtf(abs_(x));
+            o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
+        } break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void) hipFree(p);
+        p = nullptr; n = 0;
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **) &p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &v, hipStream_t s) {
+        hipError_t e = resize(std::max<size_t>(v.size(), 1));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::atomic<int> cancel{0};
+
+    // host copy of the scene (input order)
+    std::vector<Tri> tris_in;
+    std::vector<float> tri_vn_in;       // 9 per tri or empty
+    std::vector<ShapeRec> shapes;
+    std::vector<BsdfRec> bsdfs;
+    std::vector<EmitterRec> emitters;
+    std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
+    bool have_scene = false, have_bvh = false;
+
+    // device scene
+    DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
+    DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters;
+    DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
+    SceneView view{};
+    TraceLds lds_cfg{}; size_t lds_bytes = 0;
+
+    // render state
+    DevBuf<F4> q_tp, q_res, q_ray_o, q_ray_d, q_hit, q_sh_d, q_sh_c;
+    DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
+    DevBuf<double> d_accum; DevBuf<float> d_film32;
+    DevBuf<uint32_t> d_block_ids, d_tile_list;
+    DevBuf<Counters> d_cnt;
+    Counters *h_cnt = nullptr;          // pinned
+
+    std::vector<hipEvent_t> ev_pool;
+    mi_counters counters{};
+};
+
+static mi_status fail(mi_ctx *c, mi_status code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->error = buf;
+    return code;
+}
+#define HIP_TRY(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(c, MI_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static thread_local std::string g_global_error;
+
+extern "C" {
+
+mi_status mi_device_count(int32_t *count) {
+    if (!count) return MI_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; g_global_error = hipGetErrorString(e); return MI_ERR_DEVICE; }
+    *count = n;
+    return MI_OK;
+}
+
+mi_status mi_create(int32_t device, mi_ctx **out) {
+    if (!out) return MI_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_global_error = "no HIP device visible"; return MI_ERR_DEVICE; }
+    if (device < 0 || device >= n) { g_global_error = "device index out of range"; return MI_ERR_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { g_global_error = "hipSetDevice failed"; return MI_ERR_DEVICE; }
+    mi_ctx *c = new mi_ctx();
+    c->device = device;
+    if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters)) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
+    *out = c;
+    return MI_OK;
+}
+
+void mi_destroy(mi_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipDeviceSynchronize();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_bsdfs.release();
+    c->d_emitters.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
+    c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
+    c->d_accum.release(); c->d_film32.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
+    if (c->h_cnt) (void) hipHostFree(c->h_cnt);
+    delete c;
+}
+
+mi_status mi_set_stream(mi_ctx *c, void *s) { if (!c) return MI_ERR_INVALID; c->stream = (hipStream_t) s; return MI_OK; }
+
+const char *mi_last_error(mi_ctx *c) { return c ? c->error.c_str() : g_global_error.c_str(); }
+
+mi_status mi_cancel(mi_ctx *c) { if (!c) return MI_ERR_INVALID; c->cancel.store(1); return MI_OK; }
+
+mi_status mi_get_counters(mi_ctx *c, mi_counters *out) {
+    if (!c || !out) return MI_ERR_INVALID;
+    *out = c->counters;
+    return MI_OK;
+}
+
+// ---- scene upload ---------------------------------------------------------------------
+mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
+    if (!c || !s) return MI_ERR_INVALID;
+    c->have_scene = c->have_bvh = false;
+    if (s->face_count && (!s->vertex_positions || !s->faces)) return fail(c, MI_ERR_INVALID, "scene: null geometry pointers");
+    if (!s->shapes || s->shape_count == 0) return fail(c, MI_ERR_INVALID, "scene: no shapes");
+    if (!s->bsdfs || s->bsdf_count == 0) return fail(c, MI_ERR_INVALID, "scene: no bsdfs");
+    if (s->face_count >= (1u << 28)) return fail(c, MI_ERR_INVALID, "scene: too many faces");
+
+    c->tris_in.assign(s->face_count, Tri{});
+    std::vector<uint32_t> face_shape(s->face_count, 0xffffffffu);
+    bool any_normals = false;
+    c->shapes.resize(s->shape_count);
+    for (uint32_t i = 0; i < s->shape_count; ++i) {
+        const mi_shape &sh = s->shapes[i];
+        if (sh.bsdf >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "shape %u: bsdf index out of range", i);
+        if (sh.emitter >= (int32_t) s->emitter_count) return fail(c, MI_ERR_INVALID, "shape %u: emitter index out of range", i);
+        if ((uint64_t) sh.first_face + sh.face_count > s->face_count) return fail(c, MI_ERR_INVALID, "shape %u: face range out of bounds", i);
+        if ((sh.flags & MI_SHAPE_HAS_NORMALS) && !s->vertex_normals) return fail(c, MI_ERR_INVALID, "shape %u: HAS_NORMALS without vertex_normals", i);
+        for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) {
+            if (face_shape[f] != 0xffffffffu) return fail(c, MI_ERR_INVALID, "face %u belongs to two shapes", f);
+            face_shape[f] = i;
+        }
+        ShapeRec r; r.bsdf = sh.bsdf; r.emitter = sh.emitter; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
+        c->shapes[i] = r;
+        any_normals = any_normals || (r.flags & 1u);
+    }
+    c->tri_vn_in.clear();
+    if (any_normals) c->tri_vn_in.assign((size_t) s->face_count * 9, 0.f);
+    for (uint32_t f = 0; f < s->face_count; ++f) {
+        if (face_shape[f] == 0xffffffffu) return fail(c, MI_ERR_INVALID, "face %u belongs to no shape", f);
+        Tri &t = c->tris_in[f];
+        for (int k = 0; k < 3; ++k) {
+            uint32_t vi = s->faces[3 * f + k];
+            if (vi >= s->vertex_count) return fail(c, MI_ERR_INVALID, "face %u: vertex index out of range", f);
+            float *dst = k == 0 ? t.p0 : (k == 1 ? t.p1 : t.p2);
+            memcpy(dst, s->vertex_positions + 3 * (size_t) vi, 12);
+            if (any_normals && (c->shapes[face_shape[f]].flags & 1u))
+                memcpy(&c->tri_vn_in[(size_t) f * 9 + 3 * k], s->vertex_normals + 3 * (size_t) vi, 12);
+        }
+        t.shape = face_shape[f]; t.prim = f; t.pad = 0;
+    }
+    c->bsdfs.resize(s->bsdf_count);
+    for (uint32_t i = 0; i < s->bsdf_count; ++i) {
+        const mi_bsdf &b = s->bsdfs[i];
+        if (b.type > MI_BSDF_ROUGHCONDUCTOR) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
+        if (b.type == MI_BSDF_ROUGHCONDUCTOR) {
+            if (!(b.flags & MI_BSDF_FLAG_GGX))
+                return fail(c, MI_ERR_INVALID, "bsdf %u: roughconductor distribution 'beckmann' is not implemented on the device; use 'ggx'", i);
+            if (!(b.flags & MI_BSDF_FLAG_SAMPLE_VISIBLE) && b.params[0] != b.params[1])
+                return fail(c, MI_ERR_INVALID, "bsdf %u: anisotropic roughconductor needs sample_visible=true", i);
+        }
+        BsdfRec r; r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
+        c->bsdfs[i] = r;
+    }
+    // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
+    c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
+    bool any_emit_normals = false;
+    for (uint32_t i = 0; i < s->emitter_count; ++i) {
+        const mi_emitter &e = s->emitters[i];
+        if (e.shape >= s->shape_count) return fail(c, MI_ERR_INVALID, "emitter %u: shape index out of range", i);
+        const mi_shape &sh = s->shapes[e.shape];
+        if (sh.emitter != (int32_t) i) return fail(c, MI_ERR_INVALID, "emitter %u: shape %u does not point back to it", i, e.shape);
+        if (sh.face_count == 0) return fail(c, MI_ERR_INVALID, "emitter %u: cannot create sampling table for an empty mesh", i);
+        EmitterRec r; memset(&r, 0, sizeof r);
+        memcpy(r.radiance, e.radiance, 12);
+        r.shape = e.shape; r.tri_first = (uint32_t) c->emit_pmf.size(); r.tri_count = sh.face_count;
+        r.flags = (sh.flags & MI_SHAPE_HAS_NORMALS) ? 1u : 0u;
+        any_emit_normals = any_emit_normals || r.flags;
+        double sum = 0.0; uint32_t vlo = 0xffffffffu, vhi = 0;
+        for (uint32_t k = 0; k < sh.face_count; ++k) {
+            const Tri &t = c->tris_in[sh.first_face + k];
+            float area = face_area(ld3(t.p0), ld3(t.p1), ld3(t.p2));
+            if (area < 0.f) return fail(c, MI_ERR_INVALID, "emitter %u: negative face area", i);
+            c->emit_pmf.push_back(area);
+            sum += (double) area;
+            c->emit_cdf.push_back((float) sum);
+            if (area > 0.f) { if (vlo == 0xffffffffu) vlo = k; vhi = k; }
+            for (int q = 0; q < 3; ++q) c->emit_tri.push_back(t.p0[q]);
+            for (int q = 0; q < 3; ++q) c->emit_tri.push_back(t.p1[q]);
+            for (int q = 0; q < 3; ++q) c->emit_tri.push_back(t.p2[q]);
+            for (int q = 0; q < 9; ++q)
+                c->emit_vnorm.push_back(r.flags ? c->tri_vn_in[(size_t) (sh.first_face + k) * 9 + q] : 0.f);
+        }
+        if (vlo == 0xffffffffu) return fail(c, MI_ERR_INVALID, "emitter %u: no probability mass found", i);
+        r.valid_lo = vlo; r.valid_hi = vhi;
+        r.sum = (float) sum; r.normalization = (float) (1.0 / sum);
+        c->emitters.push_back(r);
+    }
+    if (!any_emit_normals) c->emit_vnorm.clear();
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_shapes.upload(c->shapes, c->stream));
+    HIP_TRY(c, c->d_bsdfs.upload(c->bsdfs, c->stream));
+    HIP_TRY(c, c->d_emitters.upload(c->emitters, c->stream));
+    HIP_TRY(c, c->d_emit_tri.upload(c->emit_tri, c->stream));
+    HIP_TRY(c, c->d_emit_vnorm.upload(c->emit_vnorm, c->stream));
+    HIP_TRY(c, c->d_emit_pmf.upload(c->emit_pmf, c->stream));
+    HIP_TRY(c, c->d_emit_cdf.upload(c->emit_cdf, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_scene = true;
+    return MI_OK;
+}
+
+// ---- BVH build ------------------------------------------------------------------------
+mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
+    if (!c) return MI_ERR_INVALID;
+    if (!c->have_scene) return fail(c, MI_ERR_STATE, "mi_bvh_build: no scene uploaded");
+    if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
+    auto t0 = std::chrono::steady_clock::now();
+    // quality 0 (device LBVH) falls back to the host SAH builder this round
+    BvhBuildResult r = bvh_build_sah(c->tris_in);
+    if (r.depth > MIW_BVH_MAX_DEPTH) return fail(c, MI_ERR_INVALID, "BVH depth %u exceeds the traversal trail", r.depth);
+    std::vector<float> vn;
+    if (!c->tri_vn_in.empty()) {
+        vn.resize(c->tri_vn_in.size());
+        for (size_t i = 0; i < r.order.size(); ++i)
+            memcpy(&vn[i * 9], &c->tri_vn_in[(size_t) r.order[i] * 9], 36);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_nodes.upload(r.nodes, c->stream));
+    HIP_TRY(c, c->d_tris.upload(r.tris, c->stream));
+    HIP_TRY(c, c->d_tri_vn.upload(vn, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    SceneView &v = c->view;
+    v.nodes = c->d_nodes.p; v.node_count = (uint32_t) r.nodes.size();
+    v.tris = c->d_tris.p; v.tri_count = (uint32_t) r.tris.size();
+    v.tri_vn = vn.empty() ? nullptr : c->d_tri_vn.p;
+    v.shapes = c->d_shapes.p; v.shape_count = (uint32_t) c->shapes.size();
+    v.bsdfs = c->d_bsdfs.p; v.bsdf_count = (uint32_t) c->bsdfs.size();
+    v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();
+    v.emit_tri = c->d_emit_tri.p; v.emit_vnorm = c->emit_vnorm.empty() ? nullptr : c->d_emit_vnorm.p;
+    v.emit_pmf = c->d_emit_pmf.p; v.emit_cdf = c->d_emit_cdf.p;
+
+    // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
+    // otherwise the top of the tree only.
+    size_t all = r.nodes.size() * sizeof(BvhNode) + r.tris.size() * sizeof(Tri);
+    if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
+    else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
+    c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
+
+    c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = r.depth;
+    c->have_bvh = true;
+    return MI_OK;
+}
+
+// ---- mi_trace --------------------------------------------------------------------------
+mi_status mi_trace(mi_ctx *c, const mi_rays_soa *rays, const mi_hits_soa *hits, uint64_t n, int32_t any_hit) {
+    if (!c || !rays || !hits) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_trace: call mi_scene_upload and mi_bvh_build first");
+    if (n == 0) return MI_OK;
+    if (!hits->t) return fail(c, MI_ERR_INVALID, "mi_trace: hits->t is required");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> in, out; DevBuf<uint32_t> outu;
+    HIP_TRY(c, in.resize(8 * n)); HIP_TRY(c, out.resize(3 * n)); HIP_TRY(c, outu.resize(2 * n));
+    const float *src[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->mint, rays->maxt };
+    for (int k = 0; k < 8; ++k) {
+        if (!src[k]) { in.release(); out.release(); outu.release(); return fail(c, MI_ERR_INVALID, "mi_trace: null ray array"); }
+        HIP_TRY(c, hipMemcpyAsync(in.p + k * n, src[k], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    SoaRays R = { in.p, in.p + n, in.p + 2 * n, in.p + 3 * n, in.p + 4 * n, in.p + 5 * n, in.p + 6 * n, in.p + 7 * n };
+    SoaHits H = { out.p, out.p + n, out.p + 2 * n, outu.p, outu.p + n };
+    dim3 grid((unsigned) ((n + MIW_BLOCK - 1) / MIW_BLOCK)), block(MIW_BLOCK);
+    if (any_hit) hipLaunchKernelGGL(k_trace_soa<true>, grid, block, c->lds_bytes, c->stream, c->view, R, H, n, c->lds_cfg);
+    else         hipLaunchKernelGGL(k_trace_soa<false>, grid, block, c->lds_bytes, c->stream, c->view, R, H, n, c->lds_cfg);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(hits->t, out.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hits->u) HIP_TRY(c, hipMemcpyAsync(hits->u, out.p + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hits->v) HIP_TRY(c, hipMemcpyAsync(hits->v, out.p + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hits->prim) HIP_TRY(c, hipMemcpyAsync(hits->prim, outu.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (hits->shape) HIP_TRY(c, hipMemcpyAsync(hits->shape, outu.p + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    in.release(); out.release(); outu.release();
+    return MI_OK;
+}
+
+// ---- render ----------------------------------------------------------------------------
+static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &P) {
+    if (cfg->crop_w <= 0 || cfg->crop_h <= 0 || cfg->crop_x < 0 || cfg->crop_y < 0)
+        return fail(c, MI_ERR_INVALID, "render: bad crop window");
+    if (cfg->crop_x + cfg->crop_w > 65535 || cfg->crop_y + cfg->crop_h > 65535)
+        return fail(c, MI_ERR_INVALID, "render: film larger than 65535 pixels per side");
+    if (cfg->block_size <= 0 || (cfg->block_size & (cfg->block_size - 1)))
+        return fail(c, MI_ERR_INVALID, "render: block_size must be a power of two");
+    if (cfg->rr_depth <= 0) return fail(c, MI_ERR_INVALID, "\"rr_depth\" must be set to a value greater than zero!");
+    if (cfg->max_depth < 0 && cfg->max_depth != -1) return fail(c, MI_ERR_INVALID, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (cfg->filter_radius <= 0.f || cfg->filter_radius > 4.f) return fail(c, MI_ERR_INVALID, "render: filter radius out of range (0, 4]");
+    memset(&P, 0, sizeof P);
+    memcpy(P.sensor.sample_to_camera, cfg->sample_to_camera, 64);
+    memcpy(P.sensor.to_world, cfg->to_world, 64);
+    P.sensor.near_clip = cfg->near_clip; P.sensor.far_clip = cfg->far_clip;
+    P.sensor.pp_offset[0] = cfg->principal_point_offset[0]; P.sensor.pp_offset[1] = cfg->principal_point_offset[1];
+    P.film.crop_w = cfg->crop_w; P.film.crop_h = cfg->crop_h; P.film.crop_x = cfg->crop_x; P.film.crop_y = cfg->crop_y;
+    P.film.block_size = cfg->block_size; P.film.border = cfg->filter_border;
+    P.film.radius = cfg->filter_radius;
+    P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
+    memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
+    P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
+    return MI_OK;
+}
+
+mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
+    if (!c || !cfg || !film) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_render: call mi_scene_upload and mi_bvh_build first");
+    RenderParams P;
+    mi_status st = fill_params(c, cfg, P);
+    if (st != MI_OK) return st;
+    const uint32_t bs = (uint32_t) cfg->block_size, bs2 = bs * bs;
+    uint32_t bs2_log2 = 0; while ((1u << bs2_log2) < bs2) ++bs2_log2;
+    const uint32_t blocks_x = (cfg->crop_w + bs - 1) / bs, blocks_y = (cfg->crop_h + bs - 1) / bs;
+    if (!cfg->block_ids || cfg->block_count != blocks_x * blocks_y)
+        return fail(c, MI_ERR_INVALID, "render: block_ids must hold %u entries", blocks_x * blocks_y);
+    uint32_t n_tiles = cfg->tile_list ? cfg->tile_count : cfg->block_count;
+    if (cfg->tile_list)
+        for (uint32_t i = 0; i < n_tiles; ++i)
+            if (cfg->tile_list[i] >= cfg->block_count) return fail(c, MI_ERR_INVALID, "render: tile_list entry out of range");
+    uint64_t n_lanes64 = (uint64_t) n_tiles * bs2;
+    if (n_lanes64 >= (1ull << 31)) return fail(c, MI_ERR_INVALID, "render: too many lanes");
+    const uint32_t n_lanes = (uint32_t) n_lanes64;
+    P.n_lanes = n_lanes;
+    const size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * MIW_FILM_CHANNELS;
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    auto wall0 = std::chrono::steady_clock::now();
+    c->cancel.store(0);
+
+    size_t nl = std::max<uint32_t>(n_lanes, 1);
+    HIP_TRY(c, c->q_tp.resize(nl)); HIP_TRY(c, c->q_res.resize(nl)); HIP_TRY(c, c->q_ray_o.resize(nl));
+    HIP_TRY(c, c->q_ray_d.resize(nl)); HIP_TRY(c, c->q_hit.resize(nl)); HIP_TRY(c, c->q_sh_d.resize(nl));
+    HIP_TRY(c, c->q_sh_c.resize(nl)); HIP_TRY(c, c->q_st.resize(nl)); HIP_TRY(c, c->q_pos.resize(nl));
+    HIP_TRY(c, c->q_pixel.resize(nl)); HIP_TRY(c, c->q_sh_vis.resize(nl));
+    HIP_TRY(c, c->d_accum.resize(film_n)); HIP_TRY(c, c->d_cnt.resize(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, sizeof(Counters), s));
+    HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
+    HIP_TRY(c, hipMemcpyAsync(c->d_block_ids.p, cfg->block_ids, cfg->block_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (cfg->tile_list && n_tiles) {
+        HIP_TRY(c, c->d_tile_list.resize(n_tiles));
+        HIP_TRY(c, hipMemcpyAsync(c->d_tile_list.p, cfg->tile_list, n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+
+    LaneQueues Q;
+    Q.tp = c->q_tp.p; Q.res = c->q_res.p; Q.st = c->q_st.p; Q.pos = c->q_pos.p; Q.pixel = c->q_pixel.p;
+    Q.ray_o = c->q_ray_o.p; Q.ray_d = c->q_ray_d.p; Q.hit = c->q_hit.p;
+    Q.sh_d = c->q_sh_d.p; Q.sh_c = c->q_sh_c.p; Q.sh_vis = c->q_sh_vis.p;
+
+    mi_counters &K = c->counters;
+    K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
+    K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = 0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = 0;
+
+    // event pool for per-launch timing
+    struct Stamp { int cls; size_t e0, e1; };
+    std::vector<Stamp> stamps;
+    size_t ev_used = 0;
+    auto get_event = [&](size_t &idx) -> hipError_t {
+        if (ev_used == c->ev_pool.size()) {
+            hipEvent_t e; hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) return r;
+            c->ev_pool.push_back(e);
+        }
+        idx = ev_used++;
+        return hipSuccess;
+    };
+    auto drain_stamps = [&]() {
+        for (const Stamp &t : stamps) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev_pool[t.e0], c->ev_pool[t.e1]) != hipSuccess) continue;
+            switch (t.cls) {
+                case 0: K.ms_trace_closest += ms; break;
+                case 1: K.ms_trace_any += ms; break;
+                case 2: K.ms_shade += ms; break;
+                case 3: K.ms_init += ms; break;
+                default: K.ms_resolve += ms; break;
+            }
+        }
+        stamps.clear(); ev_used = 0;
+    };
+#define MIW_TIMED(cls_, launch) do {                                                   \
+        size_t e0_ = 0, e1_ = 0;                                                       \
+        if (cfg->profile) { HIP_TRY(c, get_event(e0_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e0_], s)); } \
+        launch;                                                                        \
+        if (cfg->profile) { HIP_TRY(c, get_event(e1_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e1_], s)); \
+                            stamps.push_back({ cls_, e0_, e1_ }); }                    \
+    } while (0)
+
+    mi_status result = MI_OK;
+    if (n_lanes > 0) {
+        dim3 grid((n_lanes + MIW_BLOCK - 1) / MIW_BLOCK), block(MIW_BLOCK);
+        InitArgs A; A.block_ids = c->d_block_ids.p; A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
+        A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
+        MIW_TIMED(3, hipLaunchKernelGGL(k_init_lanes, grid, block, 0, s, P, Q, c->q_pixel.p, A));
+        HIP_TRY(c, hipGetLastError());
+
+        const int check_every = 16;
+        bool first = true;
+        for (;;) {
+            for (int it = 0; it < check_every; ++it) {
+                if (!first) {
+                    MIW_TIMED(1, hipLaunchKernelGGL(k_trace<true>, grid, block, c->lds_bytes, s, c->view, Q, n_lanes, c->lds_cfg));
+                    K.n_trace_any++;
+                }
+                MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, n_lanes, c->lds_cfg));
+                K.n_trace_closest++;
+                if (it == check_every - 1)
+                    HIP_TRY(c, hipMemsetAsync(&c->d_cnt.p->active_lanes, 0, sizeof(unsigned long long), s));
+                MIW_TIMED(2, hipLaunchKernelGGL(k_shade, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p));
+                K.n_shade++; K.iterations++;
+                first = false;
+            }
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (cfg->profile) drain_stamps();
+            if (c->h_cnt->active_lanes == 0) break;
+            if (c->cancel.load()) { result = MI_ERR_CANCELLED; break; }
+            if (cfg->timeout_s > 0.f &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > cfg->timeout_s) {
+                result = MI_ERR_CANCELLED; break;
+            }
+        }
+        K.samples = c->h_cnt->samples; K.segments = c->h_cnt->segments; K.shadow_rays = c->h_cnt->shadow_rays;
+    }
+
+    // develop: accumulators -> caller's film
+    {
+        dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
+        void *dst = film;
+        bool staged = !cfg->film_on_device;
+        if (staged) {
+            if (cfg->film_f64) dst = nullptr; else { HIP_TRY(c, c->d_film32.resize(film_n)); dst = c->d_film32.p; }
+        }
+        if (cfg->film_f64) {
+            if (staged) {
+                HIP_TRY(c, hipMemcpyAsync(film, c->d_accum.p, film_n * sizeof(double), hipMemcpyDeviceToHost, s));
+            } else {
+                MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, (float *) nullptr, (double *) dst, film_n));
+            }
+        } else {
+            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, (float *) dst, (double *) nullptr, film_n));
+            if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_film32.p, film_n * sizeof(float), hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (cfg->profile) drain_stamps();
+    }
+#undef MIW_TIMED
+    K.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (result == MI_ERR_CANCELLED) c->error = "render cancelled";
+    return result;
+}
+
+// ---- mi_eval -----------------------------------------------------------------------------
+mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *in, int32_t is, float *out, int32_t os, uint64_t n) {
+    if (!c || !in || !out || is <= 0 || os <= 0) return MI_ERR_INVALID;
+    if (n == 0) return MI_OK;
+    RenderParams P; memset(&P, 0, sizeof P);
+    if (op == MI_EVAL_CAMERA_RAY) {
+        if (!cfg) return fail(c, MI_ERR_INVALID, "mi_eval: camera ray needs a render cfg");
+        mi_status st = fill_params(c, cfg, P);
+        if (st != MI_OK) return st;
+    }
+    if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE) && !c->have_bvh)
+        return fail(c, MI_ERR_STATE, "mi_eval: scene required");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> din, dout;
+    HIP_TRY(c, din.resize(n * is)); HIP_TRY(c, dout.resize(n * os));
+    HIP_TRY(c, hipMemcpyAsync(din.p, in, n * is * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dout.p, 0, n * os * sizeof(float), c->stream));
+    hipLaunchKernelGGL(k_eval, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, op, P, c->view, din.p, is, dout.p, os, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * os * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    din.release(); dout.release();
+    return MI_OK;
+}
+
+} // extern "C"

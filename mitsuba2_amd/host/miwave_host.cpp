@@ -1,0 +1,833 @@
+// Implementation of the host classes declared in miwave_host.h, plus the C
+// facade (`mih_*`) that Python's ctypes binds for tests and the benchmark.
+#include "miwave_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../csrc/miw/base.h"
+#include "../csrc/miw/rng.h"
+#include "../csrc/miw/bsdf.h"
+#include "../csrc/miw/scene.h"
+
+namespace miwave {
+
+[[noreturn]] static void Throw(const std::string &msg) { throw std::runtime_error(msg); }
+
+// ============================================================================================
+// Transform4f
+// ============================================================================================
+static void mat_identity(float *m) { std::memset(m, 0, 64); m[0] = m[5] = m[10] = m[15] = 1.f; }
+// enoki Matrix * Matrix: column j of the result = sum_k A.col(k) * B(k, j), fma chain
+static void mat_mul(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float s = a[0 * 4 + i] * b[j * 4 + 0];
+            for (int k = 1; k < 4; ++k) s = miw::fmadd(a[k * 4 + i], b[j * 4 + k], s);
+            r[j * 4 + i] = s;
+        }
+    std::memcpy(out, r, 64);
+}
+
+Transform4f::Transform4f() { mat_identity(m); mat_identity(inv); }
+
+Transform4f Transform4f::translate(const Vector3f &v) {
+    Transform4f t;
+    t.m[12] = v[0]; t.m[13] = v[1]; t.m[14] = v[2];
+    t.inv[12] = -v[0]; t.inv[13] = -v[1]; t.inv[14] = -v[2];
+    return t;
+}
+Transform4f Transform4f::scale(const Vector3f &v) {
+    Transform4f t;
+    t.m[0] = v[0]; t.m[5] = v[1]; t.m[10] = v[2];
+    t.inv[0] = 1.f / v[0]; t.inv[5] = 1.f / v[1]; t.inv[10] = 1.f / v[2];
+    return t;
+}
+Transform4f Transform4f::perspective(float fov, float near_, float far_) {
+    float recip = 1.f / (far_ - near_);
+    float tan_ = std::tan(fov * .5f * (MIW_PI / 180.f)), cot = 1.f / tan_;
+    Transform4f t;
+    std::memset(t.m, 0, 64); std::memset(t.inv, 0, 64);
+    // trafo = diag(cot, cot, far*recip, 0); trafo(2,3) = -near*far*recip; trafo(3,2) = 1   [(row, col)]
+    t.m[0] = cot; t.m[5] = cot; t.m[10] = far_ * recip;
+    t.m[3 * 4 + 2] = -near_ * far_ * recip;
+    t.m[2 * 4 + 3] = 1.f;
+    // inv = diag(tan, tan, 0, 1/near); inv(2,3) = 1; inv(3,2) = (near - far) / (far * near)
+    t.inv[0] = tan_; t.inv[5] = tan_; t.inv[15] = 1.f / near_;
+    t.inv[3 * 4 + 2] = 1.f;
+    t.inv[2 * 4 + 3] = (near_ - far_) / (far_ * near_);
+    return t;
+}
+Transform4f Transform4f::look_at(const Point3f &origin, const Point3f &target, const Vector3f &up) {
+    using namespace miw;
+    V3 o = v3(origin[0], origin[1], origin[2]);
+    V3 dir = normalize(v3(target[0], target[1], target[2]) - o);
+    dir = normalize(dir);
+    V3 left = normalize(cross(v3(up[0], up[1], up[2]), dir));
+    V3 new_up = cross(dir, left);
+    Transform4f t;
+    float *m = t.m;
+    m[0] = left.x;  m[1] = left.y;  m[2] = left.z;  m[3] = 0.f;
+    m[4] = new_up.x; m[5] = new_up.y; m[6] = new_up.z; m[7] = 0.f;
+    m[8] = dir.x;   m[9] = dir.y;   m[10] = dir.z;  m[11] = 0.f;
+    m[12] = o.x;    m[13] = o.y;    m[14] = o.z;    m[15] = 1.f;
+    // inverse = rows (left, new_up, dir), last column = inverse * (-origin, 1)
+    float *iv = t.inv;
+    std::memset(iv, 0, 64);
+    iv[0] = left.x; iv[4] = left.y; iv[8] = left.z;
+    iv[1] = new_up.x; iv[5] = new_up.y; iv[9] = new_up.z;
+    iv[2] = dir.x; iv[6] = dir.y; iv[10] = dir.z;
+    iv[15] = 1.f;
+    float col[4];
+    for (int i = 0; i < 4; ++i) {
+        float s = iv[0 * 4 + i] * (-o.x);
+        s = fmadd(iv[1 * 4 + i], -o.y, s);
+        s = fmadd(iv[2 * 4 + i], -o.z, s);
+        s = fmadd(iv[3 * 4 + i], 1.f, s);
+        col[i] = s;
+    }
+    iv[12] = col[0]; iv[13] = col[1]; iv[14] = col[2]; iv[15] = col[3];
+    return t;
+}
+Transform4f Transform4f::operator*(const Transform4f &o) const {
+    Transform4f r;
+    mat_mul(m, o.m, r.m);
+    mat_mul(o.inv, inv, r.inv);
+    return r;
+}
+Transform4f Transform4f::inverse() const {
+    Transform4f r;
+    std::memcpy(r.m, inv, 64); std::memcpy(r.inv, m, 64);
+    return r;
+}
+bool Transform4f::has_scale() const {
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            float sum = 0.f;
+            for (int k = 0; k < 3; ++k) sum += m[i * 4 + k] * m[j * 4 + k];
+            if (i == j && std::abs(sum - 1.f) > 1e-3f) return true;
+        }
+    return false;
+}
+
+// ============================================================================================
+// Properties
+// ============================================================================================
+template <typename T> static const T *prop_get(const std::map<std::string, Properties::Value> &m, const std::string &n) {
+    auto it = m.find(n);
+    if (it == m.end()) return nullptr;
+    return std::get_if<T>(&it->second);
+}
+#define MIW_PROP_GETTER(fn, T, type_name)                                                            \
+    T Properties::fn(const std::string &n) const {                                                   \
+        if (!has_property(n)) Throw("Property \"" + n + "\" has not been specified!");               \
+        const T *v = prop_get<T>(m_values, n);                                                       \
+        if (!v) Throw("The property \"" + n + "\" has the wrong type (expected <" type_name ">).");  \
+        return *v;                                                                                   \
+    }                                                                                                \
+    T Properties::fn(const std::string &n, T def) const {                                            \
+        if (!has_property(n)) return def;                                                            \
+        return fn(n);                                                                                \
+    }
+MIW_PROP_GETTER(bool_, bool, "boolean")
+MIW_PROP_GETTER(int_, int64_t, "integer")
+std::string Properties::string(const std::string &n) const {
+    if (!has_property(n)) Throw("Property \"" + n + "\" has not been specified!");
+    const std::string *v = prop_get<std::string>(m_values, n);
+    if (!v) Throw("The property \"" + n + "\" has the wrong type (expected <string>).");
+    return *v;
+}
+std::string Properties::string(const std::string &n, const std::string &def) const {
+    return has_property(n) ? string(n) : def;
+}
+float Properties::float_(const std::string &n) const {
+    if (!has_property(n)) Throw("Property \"" + n + "\" has not been specified!");
+    if (const float *v = prop_get<float>(m_values, n)) return *v;
+    if (const int64_t *v = prop_get<int64_t>(m_values, n)) return (float) *v;
+    Throw("The property \"" + n + "\" has the wrong type (expected <float>).");
+}
+float Properties::float_(const std::string &n, float def) const { return has_property(n) ? float_(n) : def; }
+Color3f Properties::texture(const std::string &n) const {
+    if (!has_property(n)) Throw("Property \"" + n + "\" has not been specified!");
+    if (const Color3f *v = prop_get<Color3f>(m_values, n)) return *v;
+    if (const float *v = prop_get<float>(m_values, n)) return Color3f{ *v, *v, *v };
+    Throw("The property \"" + n + "\" has the wrong type (expected <rgb> or <float>; only constant textures are supported).");
+}
+Color3f Properties::texture(const std::string &n, float def) const {
+    return has_property(n) ? texture(n) : Color3f{ def, def, def };
+}
+Transform4f Properties::transform(const std::string &n, const Transform4f &def) const {
+    if (!has_property(n)) return def;
+    const Transform4f *v = prop_get<Transform4f>(m_values, n);
+    if (!v) Throw("The property \"" + n + "\" has the wrong type (expected <transform>).");
+    return *v;
+}
+
+// ============================================================================================
+// Reconstruction filters
+// ============================================================================================
+float ReconstructionFilter::eval_discretized(float x) const {
+    int index = std::min((int) std::abs(x * m_scale_factor), 31);
+    return m_values[index];
+}
+void ReconstructionFilter::init_discretization() {
+    const int RES = 31;                                        // MTS_FILTER_RESOLUTION
+    m_values.resize(RES + 1);
+    for (int i = 0; i < RES; ++i) m_values[i] = eval((m_radius * i) / RES);
+    m_values[RES] = 0;
+    m_scale_factor = RES / m_radius;
+    m_border_size = (uint32_t) (int) std::ceil(m_radius - .5f - 2.f * MIW_RAY_EPSILON);
+}
+GaussianFilter::GaussianFilter(const Properties &props) {
+    m_stddev = props.float_("stddev", 0.5f);
+    m_radius = 4 * m_stddev;
+    m_alpha = -1.f / (2.f * m_stddev * m_stddev);
+    m_bias = std::exp(m_alpha * (m_radius * m_radius));
+    init_discretization();
+}
+float GaussianFilter::eval(float x) const { return std::max(0.f, std::exp(m_alpha * (x * x)) - m_bias); }
+BoxFilter::BoxFilter(const Properties &props) {
+    m_radius = props.float_("radius", .5f) + MIW_RAY_EPSILON;
+    init_discretization();
+}
+float BoxFilter::eval(float x) const { return std::abs(x) <= m_radius ? 1.f : 0.f; }
+
+// ============================================================================================
+// Film
+// ============================================================================================
+Film::Film(const Properties &props) {
+    m_size = { (int) props.int_("width", 768), (int) props.int_("height", 576) };
+    m_crop_offset = { (int) props.int_("crop_offset_x", 0), (int) props.int_("crop_offset_y", 0) };
+    m_crop_size = { (int) props.int_("crop_width", m_size[0]), (int) props.int_("crop_height", m_size[1]) };
+    // set_crop_window, film.cpp:54-66
+    if (m_crop_offset[0] < 0 || m_crop_offset[1] < 0 || m_crop_size[0] <= 0 || m_crop_size[1] <= 0 ||
+        m_crop_offset[0] + m_crop_size[0] > m_size[0] || m_crop_offset[1] + m_crop_size[1] > m_size[1])
+        Throw("Invalid crop window specification!");
+    m_filter = std::make_shared<GaussianFilter>();             // film.cpp:45-49
+}
+void Film::prepare(const std::vector<std::string> &channels) {
+    m_channels = channels;
+    m_storage.assign((size_t) m_crop_size[0] * m_crop_size[1] * channels.size(), 0.f);
+}
+std::vector<float> Film::bitmap_rgb() const {
+    size_t n = (size_t) m_crop_size[0] * m_crop_size[1];
+    std::vector<float> rgb(n * 3);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = &m_storage[i * 5];
+        float inv_w = p[4] != 0.f ? 1.f / p[4] : 0.f;         // struct.cpp:1734-1745 weight normalisation
+        miw::V3 c = miw::xyz_to_srgb(miw::v3(p[0] * inv_w, p[1] * inv_w, p[2] * inv_w));
+        rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+    }
+    return rgb;
+}
+
+// ============================================================================================
+// Spiral
+// ============================================================================================
+Spiral::Spiral(std::array<int, 2> size, std::array<int, 2> offset, size_t block_size, size_t passes)
+    : m_block_size(block_size), m_size(size), m_offset(offset), m_remaining_passes(passes) {
+    m_blocks = { (int) std::ceil((float) m_size[0] / (float) m_block_size),
+                 (int) std::ceil((float) m_size[1] / (float) m_block_size) };
+    m_block_count = (size_t) m_blocks[0] * m_blocks[1];
+    reset();
+}
+void Spiral::reset() {
+    m_block_counter = 0;
+    m_current_direction = Direction::Right;
+    m_position = { m_blocks[0] / 2, m_blocks[1] / 2 };
+    m_steps_left = 1;
+    m_steps = 1;
+}
+Spiral::Block Spiral::next_block() {
+    if (m_block_count == m_block_counter) {
+        if (m_remaining_passes > 1) { --m_remaining_passes; reset(); }
+        else return { { 0, 0 }, { 0, 0 }, (size_t) -1 };
+    }
+    size_t block_id = m_block_counter + (m_remaining_passes - 1) * m_block_count;
+    std::array<int, 2> offset = { m_position[0] * (int) m_block_size, m_position[1] * (int) m_block_size };
+    std::array<int, 2> size = { std::min((int) m_block_size, m_size[0] - offset[0]),
+                                std::min((int) m_block_size, m_size[1] - offset[1]) };
+    offset[0] += m_offset[0]; offset[1] += m_offset[1];
+    ++m_block_counter;
+    if (m_block_counter != m_block_count) {
+        do {
+            switch (m_current_direction) {
+                case Direction::Right: ++m_position[0]; break;
+                case Direction::Down:  ++m_position[1]; break;
+                case Direction::Left:  --m_position[0]; break;
+                case Direction::Up:    --m_position[1]; break;
+            }
+            if (--m_steps_left == 0) {
+                m_current_direction = Direction(((int) m_current_direction + 1) % 4);
+                if (m_current_direction == Direction::Left || m_current_direction == Direction::Right) ++m_steps;
+                m_steps_left = m_steps;
+            }
+        } while (m_position[0] < 0 || m_position[1] < 0 || m_position[0] >= m_blocks[0] || m_position[1] >= m_blocks[1]);
+    }
+    return { offset, size, block_id };
+}
+
+// ============================================================================================
+// Sampler
+// ============================================================================================
+IndependentSampler::IndependentSampler(const Properties &props) {
+    m_sample_count = (size_t) props.int_("sample_count", 4);   // sampler.cpp:14-18
+    m_base_seed = (uint64_t) props.int_("seed", 0);
+    m_state = 0; m_inc = 0;
+    seed(MIW_PCG32_DEFAULT_STATE);                             // independent.cpp:62-63
+}
+std::shared_ptr<IndependentSampler> IndependentSampler::clone() const {
+    auto s = std::make_shared<IndependentSampler>();
+    s->m_sample_count = m_sample_count; s->m_base_seed = m_base_seed;
+    return s;
+}
+void IndependentSampler::seed(uint64_t seed_offset) {
+    miw::PCG32 r; miw::pcg32_seed(r, m_base_seed + seed_offset, MIW_PCG32_DEFAULT_STREAM);
+    m_state = r.state; m_inc = r.inc;
+}
+float IndependentSampler::next_1d() {
+    miw::PCG32 r; r.state = m_state; r.inc = m_inc;
+    float v = miw::pcg32_next_f32(r);
+    m_state = r.state;
+    return v;
+}
+std::array<float, 2> IndependentSampler::next_2d() { float a = next_1d(), b = next_1d(); return { a, b }; }
+
+// ============================================================================================
+// Sensor
+// ============================================================================================
+static std::string to_lower(std::string s) { for (char &c : s) c = (char) std::tolower(c); return s; }
+static float rad_to_deg(float v) { return v * (180.f / MIW_PI); }
+static float deg_to_rad(float v) { return v * (MIW_PI / 180.f); }
+
+float parse_fov(const Properties &props, float aspect) {
+    if (props.has_property("fov") && props.has_property("focal_length"))
+        Throw("Please specify either a focal length ('focal_length') or a field of view ('fov')!");
+    float fov; std::string fov_axis;
+    if (props.has_property("fov")) {
+        fov = props.float_("fov");
+        fov_axis = to_lower(props.string("fov_axis", "x"));
+        if (fov_axis == "smaller") fov_axis = aspect > 1 ? "y" : "x";
+        else if (fov_axis == "larger") fov_axis = aspect > 1 ? "x" : "y";
+    } else {
+        std::string f = props.string("focal_length", "50mm");
+        if (f.size() >= 2 && f.substr(f.size() - 2) == "mm") f = f.substr(0, f.size() - 2);
+        float value;
+        try { value = std::stof(f); } catch (...) {
+            Throw("Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!");
+        }
+        fov = 2.f * rad_to_deg(std::atan(std::sqrt(float(36 * 36 + 24 * 24)) / (2.f * value)));
+        fov_axis = "diagonal";
+    }
+    float result;
+    if (fov_axis == "x") result = fov;
+    else if (fov_axis == "y") result = rad_to_deg(2.f * std::atan(std::tan(.5f * deg_to_rad(fov)) * aspect));
+    else if (fov_axis == "diagonal") {
+        float diagonal = 2.f * std::tan(.5f * deg_to_rad(fov));
+        float width = diagonal / std::sqrt(1.f + 1.f / (aspect * aspect));
+        result = rad_to_deg(2.f * std::atan(width * .5f));
+    } else Throw("The 'fov_axis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!");
+    if (result <= 0.f || result >= 180.f) Throw("The horizontal field of view must be in the range [0, 180]!");
+    return result;
+}
+
+PerspectiveCamera::PerspectiveCamera(const Properties &props, std::shared_ptr<Film> film,
+                                     std::shared_ptr<IndependentSampler> sampler)
+    : m_film(std::move(film)), m_sampler(std::move(sampler)) {
+    if (!m_film) m_film = std::make_shared<Film>();
+    if (!m_sampler) m_sampler = std::make_shared<IndependentSampler>();
+    m_near_clip = props.float_("near_clip", 1e-2f);            // sensor.cpp:94-96
+    m_far_clip = props.float_("far_clip", 1e4f);
+    if (m_near_clip <= 0.f) Throw("The 'near_clip' parameter must be greater than zero!");
+    if (m_near_clip >= m_far_clip) Throw("The 'near_clip' parameter must be smaller than 'far_clip'.");
+    m_to_world = props.transform("to_world", Transform4f());
+    auto size = m_film->size();
+    m_x_fov = parse_fov(props, size[0] / (float) size[1]);
+    if (m_to_world.has_scale()) Throw("Scale factors in the camera-to-world transformation are not allowed!");
+    update_camera_transforms();
+    auto crop = m_film->crop_size();
+    m_pp_offset = { props.float_("principal_point_offset_x", 0.f) * ((float) size[0] / (float) crop[0]),
+                    props.float_("principal_point_offset_y", 0.f) * ((float) size[1] / (float) crop[1]) };
+}
+void PerspectiveCamera::update_camera_transforms() {
+    // perspective_projection, include/mitsuba/render/sensor.h:196-231
+    auto fs = m_film->size(); auto cs = m_film->crop_size(); auto co = m_film->crop_offset();
+    float fx = (float) fs[0], fy = (float) fs[1];
+    float rel_size_x = (float) cs[0] / fx, rel_size_y = (float) cs[1] / fy,
+          rel_off_x = (float) co[0] / fx, rel_off_y = (float) co[1] / fy;
+    float aspect = fx / fy;
+    m_camera_to_sample =
+        Transform4f::scale({ 1.f / rel_size_x, 1.f / rel_size_y, 1.f }) *
+        Transform4f::translate({ -rel_off_x, -rel_off_y, 0.f }) *
+        Transform4f::scale({ -0.5f, -0.5f * aspect, 1.f }) *
+        Transform4f::translate({ -1.f, -1.f / aspect, 0.f }) *
+        Transform4f::perspective(m_x_fov, m_near_clip, m_far_clip);
+    m_sample_to_camera = m_camera_to_sample.inverse();
+}
+Ray3f PerspectiveCamera::sample_ray(const std::array<float, 2> &position_sample) const {
+    miw::SensorRec s;
+    std::memcpy(s.sample_to_camera, m_sample_to_camera.m, 64);
+    std::memcpy(s.to_world, m_to_world.m, 64);
+    s.near_clip = m_near_clip; s.far_clip = m_far_clip; s.pp_offset[0] = m_pp_offset[0]; s.pp_offset[1] = m_pp_offset[1];
+    miw::Ray r = miw::sensor_sample_ray(s, miw::v2(position_sample[0], position_sample[1]));
+    Ray3f out; out.o = { r.o.x, r.o.y, r.o.z }; out.d = { r.d.x, r.d.y, r.d.z }; out.mint = r.mint; out.maxt = r.maxt;
+    return out;
+}
+
+// ============================================================================================
+// BSDFs
+// ============================================================================================
+static const struct { const char *name; float value; } ior_data[] = {
+    { "vacuum", 1.0f }, { "helium", 1.000036f }, { "hydrogen", 1.000132f }, { "air", 1.000277f },
+    { "carbon dioxide", 1.00045f }, { "water", 1.3330f }, { "acetone", 1.36f }, { "ethanol", 1.361f },
+    { "carbon tetrachloride", 1.461f }, { "glycerol", 1.4729f }, { "benzene", 1.501f },
+    { "silicone oil", 1.52045f }, { "bromine", 1.661f }, { "water ice", 1.31f }, { "fused quartz", 1.458f },
+    { "pyrex", 1.470f }, { "acrylic glass", 1.49f }, { "polypropylene", 1.49f }, { "bk7", 1.5046f },
+    { "sodium chloride", 1.544f }, { "amber", 1.55f }, { "pet", 1.5750f }, { "diamond", 2.419f },
+    { nullptr, 0.f }
+};
+float lookup_ior(const Properties &props, const std::string &name, const std::string &def) {
+    auto by_name = [](const std::string &n) -> float {
+        std::string l = to_lower(n);
+        for (auto *e = ior_data; e->name; ++e) if (l == e->name) return e->value;
+        Throw("Unable to find an IOR value for \"" + l + "\"!");
+    };
+    if (props.has_property(name)) {
+        try { return props.float_(name); } catch (const std::runtime_error &) { return by_name(props.string(name)); }
+    }
+    return by_name(def);
+}
+
+static const miw::BsdfRec &as_rec(const mi_bsdf &b) { return *reinterpret_cast<const miw::BsdfRec *>(&b); }
+uint32_t BSDF::flags() const { return miw::bsdf_flags(as_rec(m_rec)); }
+std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &wi, float s1, const std::array<float, 2> &s2) const {
+    miw::BSDFSample bs;
+    miw::V3 w = miw::bsdf_sample(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), s1, miw::v2(s2[0], s2[1]), bs);
+    BSDFSample3f o; o.wo = { bs.wo.x, bs.wo.y, bs.wo.z }; o.pdf = bs.pdf; o.eta = bs.eta; o.sampled_type = bs.sampled_type;
+    return { o, Color3f{ w.x, w.y, w.z } };
+}
+Color3f BSDF::eval(const Vector3f &wi, const Vector3f &wo) const {
+    miw::V3 v = miw::bsdf_eval(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]));
+    return { v.x, v.y, v.z };
+}
+float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
+    return miw::bsdf_pdf(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]));
+}
+
+static void check_reflectance(const Color3f &c, const char *what) {  // src/spectra/srgb.cpp:30-31
+    for (float v : c) if (v < 0.f || v > 1.f) Throw(std::string(what) + ": values must be in the range [0, 1]!");
+}
+SmoothDiffuse::SmoothDiffuse(const Properties &props) {
+    Color3f r = props.texture("reflectance", .5f);
+    check_reflectance(r, "reflectance");
+    m_rec.type = MI_BSDF_DIFFUSE; m_rec.flags = 0;
+    m_rec.params[0] = r[0]; m_rec.params[1] = r[1]; m_rec.params[2] = r[2];
+}
+SmoothDielectric::SmoothDielectric(const Properties &props) {
+    float int_ior = lookup_ior(props, "int_ior", "bk7"), ext_ior = lookup_ior(props, "ext_ior", "air");
+    if (int_ior < 0 || ext_ior < 0) Throw("The interior and exterior indices of refraction must be positive!");
+    Color3f sr = props.texture("specular_reflectance", 1.f), stt = props.texture("specular_transmittance", 1.f);
+    check_reflectance(sr, "specular_reflectance"); check_reflectance(stt, "specular_transmittance");
+    m_rec.type = MI_BSDF_DIELECTRIC; m_rec.flags = 0;
+    m_rec.params[0] = int_ior / ext_ior;
+    for (int i = 0; i < 3; ++i) { m_rec.params[1 + i] = sr[i]; m_rec.params[4 + i] = stt[i]; }
+}
+RoughConductor::RoughConductor(const Properties &props) {
+    std::string material = props.string("material", "none");
+    Color3f eta, k;
+    if (props.has_property("eta") || material == "none") {
+        eta = props.texture("eta", 0.f); k = props.texture("k", 1.f);
+        if (material != "none") Throw("Should specify either (eta, k) or material, not both.");
+    } else {
+        Throw("complex_ior_from_file: the IOR data files are not available; specify 'eta' and 'k' explicitly.");
+    }
+    uint32_t flags = 0;
+    if (props.has_property("distribution")) {
+        std::string distr = to_lower(props.string("distribution"));
+        if (distr == "beckmann") flags |= 0;
+        else if (distr == "ggx") flags |= MI_BSDF_FLAG_GGX;
+        else Throw("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+    }
+    if (props.bool_("sample_visible", true)) flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
+    float au, av;
+    if (props.has_property("alpha_u") || props.has_property("alpha_v")) {
+        if (!props.has_property("alpha_u") || !props.has_property("alpha_v"))
+            Throw("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+        if (props.has_property("alpha")) Throw("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+        au = props.float_("alpha_u"); av = props.float_("alpha_v");
+    } else {
+        au = av = props.float_("alpha", 0.1f);
+    }
+    Color3f sr = props.texture("specular_reflectance", 1.f);
+    check_reflectance(sr, "specular_reflectance");
+    m_rec.type = MI_BSDF_ROUGHCONDUCTOR; m_rec.flags = flags;
+    m_rec.params[0] = au; m_rec.params[1] = av;
+    for (int i = 0; i < 3; ++i) { m_rec.params[2 + i] = eta[i]; m_rec.params[5 + i] = k[i]; m_rec.params[8 + i] = sr[i]; }
+}
+
+AreaLight::AreaLight(const Properties &props) {
+    m_radiance = props.texture("radiance", 1.f);               // area.cpp:55 (D65(1) ~ white in RGB mode)
+}
+
+// ============================================================================================
+// Mesh / Scene
+// ============================================================================================
+Mesh::Mesh(std::string name, std::vector<float> p, std::vector<uint32_t> f, std::vector<float> n)
+    : m_name(std::move(name)), m_positions(std::move(p)), m_normals(std::move(n)), m_faces(std::move(f)) {
+    if (m_positions.size() % 3 || m_faces.size() % 3) Throw("Mesh: buffer sizes must be multiples of 3");
+    if (!m_normals.empty() && m_normals.size() != m_positions.size()) Throw("Mesh: vertex normal count mismatch");
+    for (uint32_t i : m_faces) if (i >= vertex_count()) Throw("Mesh: face references a vertex out of range");
+}
+
+bool PreliminaryIntersection3f::is_valid() const { return t != std::numeric_limits<float>::infinity(); }
+
+Scene::Scene() {}
+Scene::~Scene() { if (m_ctx) mi_destroy(m_ctx); }
+void Scene::add_shape(std::shared_ptr<Mesh> mesh) {
+    if (m_built) Throw("Scene: cannot add shapes after build()");
+    m_shapes.push_back(std::move(mesh));
+}
+static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
+                    std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
+                    std::vector<mi_emitter> &erecs) {
+    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear();
+    bool any_normals = false;
+    for (auto &m : shapes) any_normals = any_normals || m->has_vertex_normals();
+    std::map<const BSDF *, uint32_t> bsdf_index;
+    for (auto &m : shapes) {
+        uint32_t vbase = (uint32_t) (pos.size() / 3), fbase = (uint32_t) (faces.size() / 3);
+        pos.insert(pos.end(), m->vertex_positions_buffer().begin(), m->vertex_positions_buffer().end());
+        if (any_normals) {
+            if (m->has_vertex_normals()) nrm.insert(nrm.end(), m->vertex_normals_buffer().begin(), m->vertex_normals_buffer().end());
+            else nrm.insert(nrm.end(), m->vertex_positions_buffer().size(), 0.f);
+        }
+        for (uint32_t i : m->faces_buffer()) faces.push_back(i + vbase);
+        mi_shape s{};
+        std::shared_ptr<BSDF> b = m->bsdf();
+        if (!b) {                                              // shape.cpp:75-81: diffuse, 0.5 (0 for emitters)
+            Properties p("diffuse");
+            if (m->emitter()) p.set_float("reflectance", 0.f);
+            b = std::make_shared<SmoothDiffuse>(p);
+            m->set_bsdf(b);
+        }
+        auto it = bsdf_index.find(b.get());
+        if (it == bsdf_index.end()) { it = bsdf_index.emplace(b.get(), (uint32_t) brecs.size()).first; brecs.push_back(b->record()); }
+        s.bsdf = it->second;
+        s.emitter = -1;
+        if (m->emitter()) {
+            s.emitter = (int32_t) erecs.size();
+            mi_emitter e{}; e.shape = (uint32_t) srecs.size();
+            Color3f r = m->emitter()->radiance(); e.radiance[0] = r[0]; e.radiance[1] = r[1]; e.radiance[2] = r[2];
+            erecs.push_back(e);
+        }
+        s.flags = m->has_vertex_normals() ? MI_SHAPE_HAS_NORMALS : 0;
+        s.first_face = fbase; s.face_count = m->face_count();
+        srecs.push_back(s);
+    }
+}
+void Scene::build(int device, int bvh_quality) {
+    if (m_shapes.empty()) Throw("Scene: no shapes");
+    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters);
+    m_desc.vertex_positions = m_positions.data();
+    m_desc.vertex_normals = m_normals.empty() ? nullptr : m_normals.data();
+    m_desc.vertex_count = (uint32_t) (m_positions.size() / 3);
+    m_desc.faces = m_faces.data(); m_desc.face_count = (uint32_t) (m_faces.size() / 3);
+    m_desc.shapes = m_shape_recs.data(); m_desc.shape_count = (uint32_t) m_shape_recs.size();
+    m_desc.bsdfs = m_bsdf_recs.data(); m_desc.bsdf_count = (uint32_t) m_bsdf_recs.size();
+    m_desc.emitters = m_emitters.data(); m_desc.emitter_count = (uint32_t) m_emitters.size();
+    m_built = true;
+    if (device < 0) return;                                    // flatten only (host-side tests)
+    if (!m_ctx) {
+        mi_status st = mi_create(device, &m_ctx);
+        if (st != MI_OK) Throw(std::string("mi_create failed: ") + mi_last_error(nullptr));
+    }
+    if (mi_scene_upload(m_ctx, &m_desc) != MI_OK) Throw(std::string("mi_scene_upload: ") + mi_last_error(m_ctx));
+    if (mi_bvh_build(m_ctx, bvh_quality) != MI_OK) Throw(std::string("mi_bvh_build: ") + mi_last_error(m_ctx));
+}
+void Scene::ray_intersect_preliminary(const mi_rays_soa &rays, const mi_hits_soa &hits, uint64_t n) const {
+    if (!m_ctx) Throw("Scene: not built on a device");
+    if (mi_trace(m_ctx, &rays, &hits, n, 0) != MI_OK) Throw(std::string("mi_trace: ") + mi_last_error(m_ctx));
+}
+void Scene::ray_test(const mi_rays_soa &rays, float *t_out, uint64_t n) const {
+    if (!m_ctx) Throw("Scene: not built on a device");
+    mi_hits_soa h{}; h.t = t_out;
+    if (mi_trace(m_ctx, &rays, &h, n, 1) != MI_OK) Throw(std::string("mi_trace: ") + mi_last_error(m_ctx));
+}
+PreliminaryIntersection3f Scene::ray_intersect_preliminary(const Ray3f &r) const {
+    mi_rays_soa rays{ &r.o[0], &r.o[1], &r.o[2], &r.d[0], &r.d[1], &r.d[2], &r.mint, &r.maxt };
+    PreliminaryIntersection3f pi{};
+    mi_hits_soa hits{ &pi.t, &pi.u, &pi.v, &pi.prim_index, &pi.shape_index };
+    ray_intersect_preliminary(rays, hits, 1);
+    return pi;
+}
+bool Scene::ray_test(const Ray3f &r) const {
+    mi_rays_soa rays{ &r.o[0], &r.o[1], &r.o[2], &r.d[0], &r.d[1], &r.d[2], &r.mint, &r.maxt };
+    float t;
+    ray_test(rays, &t, 1);
+    return t != std::numeric_limits<float>::infinity();
+}
+
+// ============================================================================================
+// PathIntegrator
+// ============================================================================================
+static uint32_t round_to_power_of_two(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return v == 0 ? 0 : r; }
+
+PathIntegrator::PathIntegrator(const Properties &props) {
+    m_block_size = (uint32_t) props.int_("block_size", 0);
+    uint32_t bs = round_to_power_of_two(m_block_size);
+    if (m_block_size > 0 && bs != m_block_size) m_block_size = bs;   // integrator.cpp:27-32 (warns)
+    m_samples_per_pass = (uint32_t) props.int_("samples_per_pass", (int64_t) (uint32_t) -1);
+    m_timeout = props.float_("timeout", -1.f);
+    m_hide_emitters = props.bool_("hide_emitters", false);
+    m_rr_depth = (int) props.int_("rr_depth", 5);
+    if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
+    m_max_depth = (int) props.int_("max_depth", -1);
+    if (m_max_depth < 0 && m_max_depth != -1) Throw("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+}
+void PathIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
+
+void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+                                     std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
+                                     uint32_t n_threads) const {
+    std::memset(&cfg, 0, sizeof cfg);
+    const Film *film = sensor->film().get();
+    auto cs = film->crop_size(); auto co = film->crop_offset();
+    size_t total_spp = sensor->sampler()->sample_count();
+    size_t spp_pass = (m_samples_per_pass == (uint32_t) -1) ? total_spp : std::min((size_t) m_samples_per_pass, total_spp);
+    if (spp_pass == 0 || (total_spp % spp_pass) != 0)
+        Throw("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(spp_pass) + ").");
+    if (spp_pass != total_spp)
+        Throw("samples_per_pass < sample_count is not supported: a pixel's PCG32 stream is consumed in one pass.");
+    // block size, integrator.cpp:88-97 (MTS_BLOCK_SIZE = 32, spiral.h:9-10)
+    uint32_t bs = m_block_size;
+    if (bs == 0) {
+        bs = 32;
+        while (true) {
+            size_t blocks = (size_t) ((cs[0] + bs - 1) / bs) * ((cs[1] + bs - 1) / bs);
+            if (bs == 1 || blocks >= n_threads) break;
+            bs /= 2;
+        }
+    }
+    cfg.crop_x = co[0]; cfg.crop_y = co[1]; cfg.crop_w = cs[0]; cfg.crop_h = cs[1];
+    cfg.spp = (uint32_t) total_spp; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+    cfg.base_seed = sensor->sampler()->base_seed();
+    cfg.block_size = (int32_t) bs;
+    // spiral visitation order -> block id per row-major block (spiral.cpp)
+    Spiral spiral(cs, co, bs, 1);
+    uint32_t nbx = (cs[0] + bs - 1) / bs;
+    block_ids.assign(spiral.block_count(), 0);
+    std::vector<uint32_t> by_id(spiral.block_count());
+    for (size_t i = 0; i < spiral.block_count(); ++i) {
+        Spiral::Block b = spiral.next_block();
+        uint32_t bx = (uint32_t) (b.offset[0] - co[0]) / bs, by = (uint32_t) (b.offset[1] - co[1]) / bs;
+        block_ids[by * nbx + bx] = (uint32_t) b.block_id;
+        by_id[b.block_id] = by * nbx + bx;
+    }
+    tiles.clear();
+    if (m_world > 1)                                           // interleaved shard over the spiral order
+        for (size_t id = m_rank; id < by_id.size(); id += m_world) tiles.push_back(by_id[id]);
+    cfg.block_ids = block_ids.data(); cfg.block_count = (uint32_t) block_ids.size();
+    cfg.tile_list = m_world > 1 ? tiles.data() : nullptr; cfg.tile_count = (uint32_t) tiles.size();
+    std::memcpy(cfg.sample_to_camera, sensor->sample_to_camera().m, 64);
+    std::memcpy(cfg.to_world, sensor->world_transform().m, 64);
+    cfg.near_clip = sensor->near_clip(); cfg.far_clip = sensor->far_clip();
+    auto pp = sensor->principal_point_offset();
+    cfg.principal_point_offset[0] = pp[0]; cfg.principal_point_offset[1] = pp[1];
+    const ReconstructionFilter *rf = film->reconstruction_filter();
+    for (int i = 0; i < 32; ++i) cfg.filter_lut[i] = rf->values()[i];
+    cfg.filter_radius = rf->radius(); cfg.filter_border = (int32_t) rf->border_size();
+    cfg.timeout_s = m_timeout; cfg.profile = m_profile ? 1 : 0;
+}
+
+bool PathIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+    if (!scene || !sensor) Throw("render(): null scene or sensor");
+    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
+    Film *film = sensor->film().get();
+    film->prepare({ "X", "Y", "Z", "A", "W" });                // integrator.cpp:67-73
+    mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
+    make_render_cfg(sensor, cfg, block_ids, tiles);
+    m_active_ctx.store(scene->ctx());
+    mi_status st = mi_render(scene->ctx(), &cfg, film->storage().data());
+    m_active_ctx.store(nullptr);
+    mi_get_counters(scene->ctx(), &m_counters);
+    if (st == MI_ERR_CANCELLED) return false;
+    if (st != MI_OK) Throw(std::string("mi_render: ") + mi_last_error(scene->ctx()));
+    return true;
+}
+
+} // namespace miwave
+
+// ==============================================================================================
+// C facade for ctypes (tests / bench plumbing). Handles are heap boxes of shared_ptr.
+// ==============================================================================================
+using namespace miwave;
+
+static thread_local std::string g_err;
+#define MIH_TRY try {
+#define MIH_CATCH(fail_value) } catch (const std::exception &e) { g_err = e.what(); return fail_value; }
+
+template <typename T> struct Box { std::shared_ptr<T> p; };
+
+extern "C" {
+
+const char *mih_last_error() { return g_err.c_str(); }
+
+void *mih_props_create(const char *plugin) { return new Properties(plugin ? plugin : ""); }
+void mih_props_destroy(void *p) { delete (Properties *) p; }
+void mih_props_set_float(void *p, const char *n, float v) { ((Properties *) p)->set_float(n, v); }
+void mih_props_set_int(void *p, const char *n, int64_t v) { ((Properties *) p)->set_int(n, v); }
+void mih_props_set_bool(void *p, const char *n, int v) { ((Properties *) p)->set_bool(n, v != 0); }
+void mih_props_set_string(void *p, const char *n, const char *v) { ((Properties *) p)->set_string(n, v); }
+void mih_props_set_color(void *p, const char *n, float r, float g, float b) { ((Properties *) p)->set_color(n, Color3f{ r, g, b }); }
+void mih_props_set_lookat(void *p, const char *n, const float *origin, const float *target, const float *up) {
+    ((Properties *) p)->set_transform(n, Transform4f::look_at({ origin[0], origin[1], origin[2] },
+                                                              { target[0], target[1], target[2] }, { up[0], up[1], up[2] }));
+}
+
+void *mih_bsdf_create(void *props) {
+    MIH_TRY
+        const Properties &p = *(Properties *) props;
+        std::shared_ptr<BSDF> b;
+        if (p.plugin_name() == "diffuse") b = std::make_shared<SmoothDiffuse>(p);
+        else if (p.plugin_name() == "dielectric") b = std::make_shared<SmoothDielectric>(p);
+        else if (p.plugin_name() == "roughconductor") b = std::make_shared<RoughConductor>(p);
+        else throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
+        return new Box<BSDF>{ b }; MIH_CATCH(nullptr)
+}
+void mih_bsdf_destroy(void *b) { delete (Box<BSDF> *) b; }
+int mih_bsdf_record(void *b, mi_bsdf *out) { *out = ((Box<BSDF> *) b)->p->record(); return 0; }
+uint32_t mih_bsdf_flags(void *b) { return ((Box<BSDF> *) b)->p->flags(); }
+// out: wo.xyz, pdf, eta, sampled_type(bits), weight.rgb
+int mih_bsdf_sample(void *b, const float *wi, float s1, const float *s2, float *out) {
+    MIH_TRY
+        auto r = ((Box<BSDF> *) b)->p->sample({ wi[0], wi[1], wi[2] }, s1, { s2[0], s2[1] });
+        out[0] = r.first.wo[0]; out[1] = r.first.wo[1]; out[2] = r.first.wo[2]; out[3] = r.first.pdf; out[4] = r.first.eta;
+        std::memcpy(&out[5], &r.first.sampled_type, 4);
+        out[6] = r.second[0]; out[7] = r.second[1]; out[8] = r.second[2];
+        return 0; MIH_CATCH(-1)
+}
+int mih_bsdf_eval_pdf(void *b, const float *wi, const float *wo, float *out) {
+    MIH_TRY
+        Color3f e = ((Box<BSDF> *) b)->p->eval({ wi[0], wi[1], wi[2] }, { wo[0], wo[1], wo[2] });
+        out[0] = e[0]; out[1] = e[1]; out[2] = e[2];
+        out[3] = ((Box<BSDF> *) b)->p->pdf({ wi[0], wi[1], wi[2] }, { wo[0], wo[1], wo[2] });
+        return 0; MIH_CATCH(-1)
+}
+
+void *mih_emitter_create(void *props) {
+    MIH_TRY
+        const Properties &p = *(Properties *) props;
+        if (p.plugin_name() != "area") throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
+        return new Box<AreaLight>{ std::make_shared<AreaLight>(p) }; MIH_CATCH(nullptr)
+}
+void mih_emitter_destroy(void *e) { delete (Box<AreaLight> *) e; }
+
+void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals) {
+    MIH_TRY
+        std::vector<float> p(pos, pos + 3 * (size_t) nv);
+        std::vector<uint32_t> f(faces, faces + 3 * (size_t) nf);
+        std::vector<float> n; if (normals) n.assign(normals, normals + 3 * (size_t) nv);
+        return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n)) }; MIH_CATCH(nullptr)
+}
+void mih_mesh_destroy(void *m) { delete (Box<Mesh> *) m; }
+void mih_mesh_set_bsdf(void *m, void *b) { ((Box<Mesh> *) m)->p->set_bsdf(((Box<BSDF> *) b)->p); }
+void mih_mesh_set_emitter(void *m, void *e) { ((Box<Mesh> *) m)->p->set_emitter(((Box<AreaLight> *) e)->p); }
+
+void *mih_scene_create() { return new Box<Scene>{ std::make_shared<Scene>() }; }
+void mih_scene_destroy(void *s) { delete (Box<Scene> *) s; }
+int mih_scene_add_shape(void *s, void *m) { MIH_TRY ((Box<Scene> *) s)->p->add_shape(((Box<Mesh> *) m)->p); return 0; MIH_CATCH(-1) }
+// device < 0: flatten only (no GPU needed); otherwise upload + build the BVH
+int mih_scene_build(void *s, int device, int quality) { MIH_TRY ((Box<Scene> *) s)->p->build(device, quality); return 0; MIH_CATCH(-1) }
+const mi_scene_desc *mih_scene_desc(void *s) { return &((Box<Scene> *) s)->p->desc(); }
+mi_ctx *mih_scene_ctx(void *s) { return ((Box<Scene> *) s)->p->ctx(); }
+int mih_scene_ray_intersect(void *s, const mi_rays_soa *rays, const mi_hits_soa *hits, uint64_t n) {
+    MIH_TRY ((Box<Scene> *) s)->p->ray_intersect_preliminary(*rays, *hits, n); return 0; MIH_CATCH(-1)
+}
+int mih_scene_ray_test(void *s, const mi_rays_soa *rays, float *t, uint64_t n) {
+    MIH_TRY ((Box<Scene> *) s)->p->ray_test(*rays, t, n); return 0; MIH_CATCH(-1)
+}
+
+void *mih_film_create(void *props) { MIH_TRY return new Box<Film>{ std::make_shared<Film>(*(Properties *) props) }; MIH_CATCH(nullptr) }
+void mih_film_destroy(void *f) { delete (Box<Film> *) f; }
+int mih_film_set_filter(void *f, const char *name, void *props) {
+    MIH_TRY
+        std::shared_ptr<ReconstructionFilter> rf;
+        Properties def(name);
+        const Properties &p = props ? *(Properties *) props : def;
+        if (std::string(name) == "gaussian") rf = std::make_shared<GaussianFilter>(p);
+        else if (std::string(name) == "box") rf = std::make_shared<BoxFilter>(p);
+        else throw std::runtime_error(std::string("Plugin \"") + name + "\" not found!");
+        ((Box<Film> *) f)->p->set_reconstruction_filter(rf);
+        return 0; MIH_CATCH(-1)
+}
+const float *mih_film_data(void *f, uint64_t *count) {
+    auto &s = ((Box<Film> *) f)->p->storage();
+    if (count) *count = s.size();
+    return s.data();
+}
+int mih_film_develop_rgb(void *f, float *out) {
+    MIH_TRY auto rgb = ((Box<Film> *) f)->p->bitmap_rgb(); std::memcpy(out, rgb.data(), rgb.size() * 4); return 0; MIH_CATCH(-1)
+}
+void *mih_sampler_create(void *props) { MIH_TRY return new Box<IndependentSampler>{ std::make_shared<IndependentSampler>(*(Properties *) props) }; MIH_CATCH(nullptr) }
+void mih_sampler_destroy(void *s) { delete (Box<IndependentSampler> *) s; }
+void mih_sampler_seed(void *s, uint64_t off) { ((Box<IndependentSampler> *) s)->p->seed(off); }
+float mih_sampler_next_1d(void *s) { return ((Box<IndependentSampler> *) s)->p->next_1d(); }
+
+void *mih_sensor_create(void *props, void *film, void *sampler) {
+    MIH_TRY
+        const Properties &p = *(Properties *) props;
+        if (p.plugin_name() != "perspective") throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
+        return new Box<PerspectiveCamera>{ std::make_shared<PerspectiveCamera>(
+            p, film ? ((Box<Film> *) film)->p : nullptr, sampler ? ((Box<IndependentSampler> *) sampler)->p : nullptr) }; MIH_CATCH(nullptr)
+}
+void mih_sensor_destroy(void *s) { delete (Box<PerspectiveCamera> *) s; }
+int mih_sensor_sample_ray(void *s, float x, float y, float *out8) {
+    MIH_TRY
+        Ray3f r = ((Box<PerspectiveCamera> *) s)->p->sample_ray({ x, y });
+        out8[0] = r.o[0]; out8[1] = r.o[1]; out8[2] = r.o[2]; out8[3] = r.d[0]; out8[4] = r.d[1]; out8[5] = r.d[2];
+        out8[6] = r.mint; out8[7] = r.maxt; return 0; MIH_CATCH(-1)
+}
+float mih_sensor_x_fov(void *s) { return ((Box<PerspectiveCamera> *) s)->p->x_fov(); }
+
+void *mih_integrator_create(void *props) {
+    MIH_TRY
+        const Properties &p = *(Properties *) props;
+        if (p.plugin_name() != "path") throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
+        return new Box<PathIntegrator>{ std::make_shared<PathIntegrator>(p) }; MIH_CATCH(nullptr)
+}
+void mih_integrator_destroy(void *i) { delete (Box<PathIntegrator> *) i; }
+void mih_integrator_set_shard(void *i, uint32_t rank, uint32_t world) { ((Box<PathIntegrator> *) i)->p->set_shard(rank, world); }
+void mih_integrator_set_profile(void *i, int on) { ((Box<PathIntegrator> *) i)->p->set_profile(on != 0); }
+void mih_integrator_cancel(void *i) { ((Box<PathIntegrator> *) i)->p->cancel(); }
+// 1 = finished, 0 = cancelled / timed out, -1 = error
+int mih_integrator_render(void *i, void *scene, void *sensor) {
+    MIH_TRY return ((Box<PathIntegrator> *) i)->p->render(((Box<Scene> *) scene)->p.get(), ((Box<PerspectiveCamera> *) sensor)->p.get()) ? 1 : 0; MIH_CATCH(-1)
+}
+int mih_integrator_counters(void *i, mi_counters *out) { *out = ((Box<PathIntegrator> *) i)->p->counters(); return 0; }
+// Host-side job description (no GPU needed). block_ids / tiles must hold `capacity` entries.
+int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads) {
+    MIH_TRY
+        std::vector<uint32_t> ids, tl;
+        ((Box<PathIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads);
+        if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
+        std::memcpy(block_ids, ids.data(), ids.size() * 4);
+        std::memcpy(tiles, tl.data(), tl.size() * 4);
+        cfg->block_ids = block_ids; cfg->tile_list = tl.empty() ? nullptr : tiles;
+        return 0; MIH_CATCH(-1)
+}
+// Spiral walk (test hook): writes offset.xy, size.xy, block_id per block; returns block count
+int mih_spiral(int w, int h, int off_x, int off_y, int block_size, int32_t *out5, int capacity) {
+    Spiral sp({ w, h }, { off_x, off_y }, (size_t) block_size, 1);
+    int n = (int) sp.block_count();
+    for (int i = 0; i < n && i < capacity; ++i) {
+        Spiral::Block b = sp.next_block();
+        out5[i * 5] = b.offset[0]; out5[i * 5 + 1] = b.offset[1]; out5[i * 5 + 2] = b.size[0]; out5[i * 5 + 3] = b.size[1];
+        out5[i * 5 + 4] = (int32_t) b.block_id;
+    }
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,306 @@
+// miwave host layer — C++17 classes with the shape of Mitsuba 2's plugin API
+// for the path-integrator hot path, sitting on the C ABI of include/miwave.h.
+//
+// Class / method names, argument meaning and error behaviour follow the
+// reference (file:line cited per class) so that a maintainer can put these
+// where the scalar_rgb plugins are today: Scene::ray_intersect / ray_test,
+// PathIntegrator::render, Sampler, Sensor, Film, BSDF and Emitter property
+// parsing. Everything heavy is delegated to libmiwave.so (one mi_ctx per Scene);
+// what stays here is exactly what the reference also does once on the host:
+// Properties parsing, the spiral tile order, camera matrices, filter tables.
+//
+// Errors: std::runtime_error like the reference's Throw() (render() returns
+// false only on cancel/timeout, src/librender/integrator.cpp:178).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+#include <array>
+#include <atomic>
+
+#include "../../include/miwave.h"
+
+namespace miwave {
+
+using Color3f = std::array<float, 3>;
+using Point3f = std::array<float, 3>;
+using Vector3f = std::array<float, 3>;
+
+// ---- Transform4f (include/mitsuba/core/transform.h) ---------------------------------
+// column-major 4x4 + its inverse, composed like the reference (analytic inverses).
+struct Transform4f {
+    float m[16];      // m[c*4 + r]
+    float inv[16];
+    Transform4f();
+    static Transform4f translate(const Vector3f &v);                            // :166-174
+    static Transform4f scale(const Vector3f &v);                                // :176-184
+    static Transform4f perspective(float fov, float near_, float far_);         // :203-219
+    static Transform4f look_at(const Point3f &origin, const Point3f &target, const Vector3f &up); // :241-269
+    Transform4f operator*(const Transform4f &o) const;                          // :58-62
+    Transform4f inverse() const;                                                // :64-72
+    bool has_scale() const;
+};
+
+// ---- Properties (include/mitsuba/core/properties.h) ------------------------------------
+class Properties {
+public:
+    using Value = std::variant<bool, int64_t, float, std::string, Color3f, Transform4f>;
+    Properties() = default;
+    explicit Properties(std::string plugin_name) : m_plugin_name(std::move(plugin_name)) {}
+    const std::string &plugin_name() const { return m_plugin_name; }
+    bool has_property(const std::string &name) const { return m_values.count(name) != 0; }
+    void set_bool(const std::string &n, bool v) { m_values[n] = v; }
+    void set_int(const std::string &n, int64_t v) { m_values[n] = v; }
+    void set_float(const std::string &n, float v) { m_values[n] = v; }
+    void set_string(const std::string &n, const std::string &v) { m_values[n] = v; }
+    void set_color(const std::string &n, const Color3f &v) { m_values[n] = v; }
+    void set_transform(const std::string &n, const Transform4f &v) { m_values[n] = v; }
+    bool bool_(const std::string &n) const;
+    bool bool_(const std::string &n, bool def) const;
+    int64_t int_(const std::string &n) const;
+    int64_t int_(const std::string &n, int64_t def) const;
+    float float_(const std::string &n) const;
+    float float_(const std::string &n, float def) const;
+    std::string string(const std::string &n) const;
+    std::string string(const std::string &n, const std::string &def) const;
+    // Properties::texture(name, default) for constant textures only
+    // (properties.h:307-315; <rgb>/<spectrum value> -> srgb/uniform, xml.cpp:1073-1170)
+    Color3f texture(const std::string &n, float def) const;
+    Color3f texture(const std::string &n) const;
+    Transform4f transform(const std::string &n, const Transform4f &def) const;
+private:
+    std::string m_plugin_name;
+    std::map<std::string, Value> m_values;
+};
+
+// ---- ReconstructionFilter (include/mitsuba/core/rfilter.h, src/libcore/rfilter.cpp) ----
+class ReconstructionFilter {
+public:
+    virtual ~ReconstructionFilter() = default;
+    float radius() const { return m_radius; }
+    uint32_t border_size() const { return m_border_size; }
+    virtual float eval(float x) const = 0;
+    float eval_discretized(float x) const;                     // rfilter.h:62-65
+    const std::vector<float> &values() const { return m_values; }
+protected:
+    void init_discretization();                                // rfilter.cpp:9-20
+    float m_radius = 0.f, m_scale_factor = 0.f;
+    uint32_t m_border_size = 0;
+    std::vector<float> m_values;
+};
+class GaussianFilter final : public ReconstructionFilter {    // src/rfilters/gaussian.cpp:32-47
+public:
+    explicit GaussianFilter(const Properties &props = Properties("gaussian"));
+    float eval(float x) const override;
+private:
+    float m_stddev, m_alpha, m_bias;
+};
+class BoxFilter final : public ReconstructionFilter {         // src/rfilters/box.cpp
+public:
+    explicit BoxFilter(const Properties &props = Properties("box"));
+    float eval(float x) const override;
+};
+
+// ---- Film / HDRFilm (src/librender/film.cpp:7-50, src/films/hdrfilm.cpp) ---------------
+class Film {
+public:
+    explicit Film(const Properties &props = Properties("hdrfilm"));
+    int width() const { return m_size[0]; }
+    int height() const { return m_size[1]; }
+    std::array<int, 2> size() const { return m_size; }
+    std::array<int, 2> crop_size() const { return m_crop_size; }
+    std::array<int, 2> crop_offset() const { return m_crop_offset; }
+    const ReconstructionFilter *reconstruction_filter() const { return m_filter.get(); }
+    void set_reconstruction_filter(std::shared_ptr<ReconstructionFilter> f) { m_filter = std::move(f); }
+    void prepare(const std::vector<std::string> &channels);    // hdrfilm.cpp:190-205
+    // raw XYZAW storage, crop_w*crop_h*5 float32 (hdrfilm.cpp:200-204)
+    std::vector<float> &storage() { return m_storage; }
+    const std::vector<float> &storage() const { return m_storage; }
+    // develop: divide by W, XYZ -> linear sRGB (hdrfilm.cpp:251-322, bitmap.cpp:187-188)
+    std::vector<float> bitmap_rgb() const;
+private:
+    std::array<int, 2> m_size, m_crop_size, m_crop_offset;
+    std::shared_ptr<ReconstructionFilter> m_filter;
+    std::vector<float> m_storage;
+    std::vector<std::string> m_channels;
+};
+
+// ---- Spiral (src/librender/spiral.cpp) ---------------------------------------------------
+class Spiral {
+public:
+    Spiral(std::array<int, 2> size, std::array<int, 2> offset, size_t block_size, size_t passes = 1);
+    size_t block_count() const { return m_block_count; }
+    size_t max_block_size() const { return m_block_size; }
+    void reset();
+    // (offset, size, block_id); size == 0 when exhausted (spiral.cpp:27-72)
+    struct Block { std::array<int, 2> offset, size; size_t block_id; };
+    Block next_block();
+private:
+    enum class Direction { Right = 0, Down, Left, Up };
+    size_t m_block_counter, m_block_count, m_block_size;
+    std::array<int, 2> m_size, m_offset, m_blocks, m_position;
+    Direction m_current_direction;
+    int m_steps_left, m_steps;
+    size_t m_remaining_passes;
+};
+
+// ---- Sampler (include/mitsuba/render/sampler.h, src/samplers/independent.cpp) -------------
+class IndependentSampler {
+public:
+    explicit IndependentSampler(const Properties &props = Properties("independent"));
+    std::shared_ptr<IndependentSampler> clone() const;
+    void seed(uint64_t seed_offset);                           // sampler.cpp:83-96
+    void advance() {}
+    float next_1d();
+    std::array<float, 2> next_2d();
+    size_t sample_count() const { return m_sample_count; }
+    uint64_t base_seed() const { return m_base_seed; }
+private:
+    size_t m_sample_count; uint64_t m_base_seed; uint64_t m_state, m_inc;
+};
+
+// ---- Sensor (src/sensors/perspective.cpp, src/librender/sensor.cpp) ------------------------
+struct Ray3f { Point3f o; Vector3f d; float mint = 0.f, maxt = 0.f; };
+
+class PerspectiveCamera {
+public:
+    explicit PerspectiveCamera(const Properties &props, std::shared_ptr<Film> film,
+                               std::shared_ptr<IndependentSampler> sampler);
+    const std::shared_ptr<Film> &film() const { return m_film; }
+    const std::shared_ptr<IndependentSampler> &sampler() const { return m_sampler; }
+    float near_clip() const { return m_near_clip; }
+    float far_clip() const { return m_far_clip; }
+    float x_fov() const { return m_x_fov; }
+    const Transform4f &world_transform() const { return m_to_world; }
+    const Transform4f &sample_to_camera() const { return m_sample_to_camera; }
+    std::array<float, 2> principal_point_offset() const { return m_pp_offset; }
+    // perspective.cpp:182-216 (position_sample already divided by the crop size)
+    Ray3f sample_ray(const std::array<float, 2> &position_sample) const;
+private:
+    void update_camera_transforms();                           // :118-141
+    std::shared_ptr<Film> m_film;
+    std::shared_ptr<IndependentSampler> m_sampler;
+    Transform4f m_to_world, m_camera_to_sample, m_sample_to_camera;
+    float m_near_clip, m_far_clip, m_x_fov;
+    std::array<float, 2> m_pp_offset;
+};
+float parse_fov(const Properties &props, float aspect);       // src/librender/sensor.cpp:113-167
+
+// ---- BSDF plugins ----------------------------------------------------------------------------
+struct BSDFSample3f { Vector3f wo; float pdf, eta; uint32_t sampled_type; };
+class BSDF {
+public:
+    virtual ~BSDF() = default;
+    uint32_t flags() const;                                    // bsdf.h:417-428
+    // BSDF::sample / eval / pdf in local coordinates (bsdf.h:328-394), scalar semantics
+    std::pair<BSDFSample3f, Color3f> sample(const Vector3f &wi, float sample1, const std::array<float, 2> &sample2) const;
+    Color3f eval(const Vector3f &wi, const Vector3f &wo) const;
+    float pdf(const Vector3f &wi, const Vector3f &wo) const;
+    const mi_bsdf &record() const { return m_rec; }
+protected:
+    mi_bsdf m_rec{};
+};
+class SmoothDiffuse final : public BSDF { public: explicit SmoothDiffuse(const Properties &props); };        // diffuse.cpp:72-76
+class SmoothDielectric final : public BSDF { public: explicit SmoothDielectric(const Properties &props); };  // dielectric.cpp:174-199
+class RoughConductor final : public BSDF { public: explicit RoughConductor(const Properties &props); };      // roughconductor.cpp:146-194
+float lookup_ior(const Properties &props, const std::string &name, const std::string &def);                   // include/mitsuba/render/ior.h
+
+// ---- Emitter / Shape ----------------------------------------------------------------------------
+class AreaLight {                                             // src/emitters/area.cpp:52-60
+public:
+    explicit AreaLight(const Properties &props);
+    Color3f radiance() const { return m_radiance; }
+private:
+    Color3f m_radiance;
+};
+
+class Mesh {                                                  // include/mitsuba/render/mesh.h
+public:
+    Mesh(std::string name, std::vector<float> vertex_positions, std::vector<uint32_t> faces,
+         std::vector<float> vertex_normals = {});
+    uint32_t vertex_count() const { return (uint32_t) (m_positions.size() / 3); }
+    uint32_t face_count() const { return (uint32_t) (m_faces.size() / 3); }
+    uint32_t primitive_count() const { return face_count(); }
+    bool has_vertex_normals() const { return !m_normals.empty(); }
+    const std::vector<float> &vertex_positions_buffer() const { return m_positions; }
+    const std::vector<float> &vertex_normals_buffer() const { return m_normals; }
+    const std::vector<uint32_t> &faces_buffer() const { return m_faces; }
+    void set_bsdf(std::shared_ptr<BSDF> b) { m_bsdf = std::move(b); }
+    void set_emitter(std::shared_ptr<AreaLight> e) { m_emitter = std::move(e); }
+    const std::shared_ptr<BSDF> &bsdf() const { return m_bsdf; }
+    const std::shared_ptr<AreaLight> &emitter() const { return m_emitter; }
+    const std::string &name() const { return m_name; }
+private:
+    std::string m_name;
+    std::vector<float> m_positions, m_normals;
+    std::vector<uint32_t> m_faces;
+    std::shared_ptr<BSDF> m_bsdf;
+    std::shared_ptr<AreaLight> m_emitter;
+};
+
+// ---- Scene (include/mitsuba/render/scene.h:38-161, src/librender/scene.cpp) --------------------
+struct PreliminaryIntersection3f { float t; float u, v; uint32_t prim_index, shape_index; bool is_valid() const; };
+
+class Scene {
+public:
+    Scene();
+    ~Scene();
+    Scene(const Scene &) = delete;
+    void add_shape(std::shared_ptr<Mesh> mesh);               // scene.cpp:33-61
+    // finishes construction: default BSDFs (shape.cpp:75-81), flatten, upload, build accel (scene.cpp:94-97)
+    void build(int device = 0, int bvh_quality = 1);
+    const std::vector<std::shared_ptr<Mesh>> &shapes() const { return m_shapes; }
+    size_t emitter_count() const { return m_emitters.size(); }
+    // Scene::ray_intersect_preliminary / ray_test for one ray or a batch
+    PreliminaryIntersection3f ray_intersect_preliminary(const Ray3f &ray) const;
+    bool ray_test(const Ray3f &ray) const;
+    void ray_intersect_preliminary(const mi_rays_soa &rays, const mi_hits_soa &hits, uint64_t n) const;
+    void ray_test(const mi_rays_soa &rays, float *t_out, uint64_t n) const;
+    mi_ctx *ctx() const { return m_ctx; }
+    const mi_scene_desc &desc() const { return m_desc; }
+private:
+    std::vector<std::shared_ptr<Mesh>> m_shapes;
+    std::vector<float> m_positions, m_normals;
+    std::vector<uint32_t> m_faces;
+    std::vector<mi_shape> m_shape_recs;
+    std::vector<mi_bsdf> m_bsdf_recs;
+    std::vector<mi_emitter> m_emitters;
+    mi_scene_desc m_desc{};
+    mi_ctx *m_ctx = nullptr;
+    bool m_built = false;
+};
+
+// ---- Integrator (include/mitsuba/render/integrator.h, src/librender/integrator.cpp) -------------
+class PathIntegrator {
+public:
+    explicit PathIntegrator(const Properties &props = Properties("path"));   // integrator.cpp:23-38,305-314
+    // SamplingIntegrator::render (integrator.cpp:51-179). Returns !m_stop.
+    bool render(Scene *scene, PerspectiveCamera *sensor);
+    void cancel();                                             // integrator.cpp:43-45
+    int max_depth() const { return m_max_depth; }
+    int rr_depth() const { return m_rr_depth; }
+    uint32_t block_size() const { return m_block_size; }
+    // pixel-tile shard for multi-GPU: this process renders blocks with
+    // (spiral index % world_size) == rank; the film holds the partial sum.
+    void set_shard(uint32_t rank, uint32_t world_size) { m_rank = rank; m_world = world_size; }
+    // fills everything SamplingIntegrator::render derives on the host
+    void make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+                         std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
+                         uint32_t n_threads_hint = 1) const;
+    const mi_counters &counters() const { return m_counters; }
+    void set_profile(bool p) { m_profile = p; }
+private:
+    uint32_t m_block_size; uint32_t m_samples_per_pass; float m_timeout; bool m_hide_emitters;
+    int m_max_depth, m_rr_depth;
+    uint32_t m_rank = 0, m_world = 1;
+    bool m_profile = false;
+    std::atomic<mi_ctx *> m_active_ctx{nullptr};
+    mi_counters m_counters{};
+};
+
+} // namespace miwave

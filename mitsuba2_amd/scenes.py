@@ -1,0 +1,159 @@
+"""Synthetic scenes for parity tests and the benchmark (the reference's data
+submodule is absent): a classic Cornell box as triangles, a
+material-ball scene (rough conductor + dielectric), and the `stairs` mesh of the
+reference's kd-tree tests (src/librender/tests/mesh_generation.py:27-59).
+"""
+import numpy as np
+
+from . import api
+
+WHITE = (0.725, 0.71, 0.68)
+RED = (0.63, 0.065, 0.05)
+GREEN = (0.14, 0.45, 0.091)
+LIGHT_RADIANCE = (17.0, 12.0, 4.0)
+
+
+def _quad(pts, inward_point=None, outward_point=None):
+    """4 corner points -> (vertices[4,3], faces[2,3]); winding chosen so that the geometric
+    normal cross(p1-p0, p2-p0) faces `inward_point` (or away from `outward_point`)."""
+    p = np.asarray(pts, np.float32)
+    n = np.cross(p[1] - p[0], p[2] - p[0])
+    c = p.mean(0)
+    flip = False
+    if inward_point is not None:
+        flip = np.dot(n, np.asarray(inward_point, np.float32) - c) < 0
+    if outward_point is not None:
+        flip = np.dot(n, c - np.asarray(outward_point, np.float32)) < 0
+    if flip:
+        p = p[::-1].copy()
+    return p, np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+
+
+def _merge(parts):
+    vs, fs, base = [], [], 0
+    for v, f in parts:
+        vs.append(v); fs.append(f + base); base += len(v)
+    return np.concatenate(vs), np.concatenate(fs)
+
+
+_ROOM_CENTER = (278.0, 274.4, 279.6)
+_CBOX = dict(
+    floor=[(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)],
+    ceiling=[(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)],
+    back=[(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)],
+    right=[(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)],
+    left=[(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)],
+    # 0.8 below the ceiling so that no light/ceiling triangles are coplanar (closest-hit ties)
+    light=[(343, 548.0, 227), (343, 548.0, 332), (213, 548.0, 332), (213, 548.0, 227)],
+)
+_SHORT = [
+    [(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)],
+    [(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)],
+    [(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)],
+    [(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)],
+    [(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)],
+]
+_TALL = [
+    [(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)],
+    [(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)],
+    [(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)],
+    [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)],
+    [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)],
+]
+
+
+def _block(quads):
+    c = np.mean([np.mean(q, 0) for q in quads], 0)
+    return _merge([_quad(q, outward_point=c) for q in quads])
+
+
+def icosphere(center, radius, level):
+    """Subdivided icosahedron with exact unit vertex normals; 20 * 4**level faces."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    verts = [tuple(x) for x in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = (np.asarray(verts[a]) + np.asarray(verts[b])) * 0.5
+                m /= np.linalg.norm(m)
+                cache[key] = len(verts); verts.append(tuple(m))
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = np.array(nf, np.int64)
+    n = np.asarray(verts, np.float64)
+    p = n * radius + np.asarray(center, np.float64)
+    return p.astype(np.float32), f.astype(np.uint32), n.astype(np.float32)
+
+
+def cornell_box_meshes(diffuse_only=True, ball_level=5):
+    """-> list of api.Mesh. diffuse_only: the classic box (36 triangles, config C2).
+    Otherwise the short block becomes a GGX rough-conductor ball with shading normals
+    and the tall block a dielectric (bk7) ball — the material-ball configuration (C3)."""
+    white = api.BSDF("diffuse", reflectance=WHITE)
+    red = api.BSDF("diffuse", reflectance=RED)
+    green = api.BSDF("diffuse", reflectance=GREEN)
+    meshes = []
+    for name, bsdf in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        v, f = _quad(_CBOX[name], inward_point=_ROOM_CENTER)
+        meshes.append(api.Mesh(name, v, f, bsdf=bsdf))
+    v, f = _quad(_CBOX["light"], inward_point=_ROOM_CENTER)
+    meshes.append(api.Mesh("light", v, f, emitter=api.AreaLight(LIGHT_RADIANCE)))   # default BSDF: diffuse 0
+    if diffuse_only:
+        v, f = _block(_SHORT); meshes.append(api.Mesh("short_block", v, f, bsdf=white))
+        v, f = _block(_TALL); meshes.append(api.Mesh("tall_block", v, f, bsdf=white))
+    else:
+        metal = api.BSDF("roughconductor", distribution="ggx", alpha=0.1,
+                         eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+        glass = api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)
+        v, f, n = icosphere((185.0, 82.5, 169.0), 82.5, ball_level)
+        meshes.append(api.Mesh("metal_ball", v, f, normals=n, bsdf=metal))
+        v, f, n = icosphere((368.0, 110.0, 351.0), 110.0, ball_level)
+        meshes.append(api.Mesh("glass_ball", v, f, normals=n, bsdf=glass))
+    return meshes
+
+
+def cornell_sensor(width, height, spp, seed=0, rfilter="gaussian", **film_kw):
+    film = api.Film(rfilter=rfilter, width=width, height=height, **film_kw)
+    sampler = api.Sampler(sample_count=spp, seed=seed)
+    sensor = api.Sensor(film, sampler, fov=39.3,
+                        to_world=dict(origin=(278, 273, -800), target=(278, 273, 0), up=(0, 1, 0)))
+    return sensor
+
+
+def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_level=5, rfilter="gaussian",
+                **film_kw):
+    """-> (scene, sensor). device < 0 builds only the host-side description."""
+    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level)).build(device)
+    return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
+
+
+def stairs(num_steps):
+    """src/librender/tests/mesh_generation.py:27-59"""
+    size_step = 1.0 / num_steps
+    v = np.zeros((4 * num_steps, 3)); f = np.zeros((4 * num_steps - 2, 3), np.uint32)
+    for i in range(num_steps):
+        h = i * size_step; s1 = i * size_step; s2 = (i + 1) * size_step; k = 4 * i
+        v[k + 0] = [0.0, s1, h]; v[k + 1] = [1.0, s1, h]; v[k + 2] = [0.0, s2, h]; v[k + 3] = [1.0, s2, h]
+        f[k] = [k, k + 1, k + 2]; f[k + 1] = [k + 1, k + 3, k + 2]
+        if i < num_steps - 1:
+            f[k + 2] = [k + 2, k + 3, k + 5]; f[k + 3] = [k + 5, k + 4, k + 2]
+    return v.astype(np.float32), f
+
+
+def random_triangles(n, seed=7, extent=1.0, size=0.05):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (n, 1, 3))
+    v = (c + rng.normal(0, size, (n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    f = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    return v, f

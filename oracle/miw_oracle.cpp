@@ -1,0 +1,674 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Never linked, imported or executed by the
+// product (libmiwave.so / libmiwave_host.so); only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may call it.
+//
+// A CPU restatement of Mitsuba 2's `scalar_rgb` path-tracing hot path: the
+// control flow below follows the reference files line by line (citations on
+// every function); the float32 leaf arithmetic (vector ops, PCG32, warps,
+// triangle test, BSDFs, emitter sampling, filter splat) comes from the product's
+// shared `miw/*.h` headers BY DESIGN: bit-parity between
+// x86-64 and gfx950 is then a property of the two compilers, and those leaf
+// functions are pinned by the reference's own known-answer tests
+// (tests/test_oracle_kat.py: TEA, PCG32 demo vector, dielectric, Fresnel,
+// microfacet, mesh intersection, ImageBlock::put, Spiral, diffuse).
+//
+// What is independent of the product: the render loop (render / render_block /
+// render_sample), the scalar PathIntegrator::sample loop with its carried
+// state, the spiral, brute-force Scene::ray_intersect / ray_test, bordered
+// float32 ImageBlocks merged into the film — i.e. everything the wavefront
+// decomposition re-orders.
+//
+// Parity status: PINNED against every known-answer vector the reference's tests
+// hold for this path; the whole-image result is NOT pinned by the reference (its
+// stored references are statistical and its data submodule is absent; the real
+// binary cannot be built here: ext/enoki, ext/tbb ... are empty) — see DESIGN.md.
+//
+// Denormals: FTZ/DAZ on, like scoped_flush_denormals (integrator.cpp:117).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+#include "../include/miwave.h"
+#include "../mitsuba2_amd/csrc/miw/base.h"
+#include "../mitsuba2_amd/csrc/miw/rng.h"
+#include "../mitsuba2_amd/csrc/miw/warp.h"
+#include "../mitsuba2_amd/csrc/miw/shape.h"
+#include "../mitsuba2_amd/csrc/miw/bsdf.h"
+#include "../mitsuba2_amd/csrc/miw/scene.h"
+#include "../mitsuba2_amd/csrc/miw/film.h"
+
+using namespace miw;
+
+namespace {
+
+struct FtzScope {                       // integrator.cpp:117
+    unsigned csr;
+    FtzScope() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON); }
+    ~FtzScope() { _mm_setcsr(csr); }
+};
+
+// ---- scene in scene order (no acceleration structure: brute force) ------------------------
+struct OScene {
+    std::vector<Tri> tris;              // face order == global primitive id
+    std::vector<float> tri_vn;          // 9 per face or empty
+    std::vector<ShapeRec> shapes;
+    std::vector<BsdfRec> bsdfs;
+    std::vector<EmitterRec> emitters;
+    std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
+    SceneView view{};
+};
+
+bool build_scene(const mi_scene_desc *s, OScene &o) {
+    o.tris.assign(s->face_count, Tri{});
+    o.shapes.resize(s->shape_count);
+    bool any_normals = false;
+    for (uint32_t i = 0; i < s->shape_count; ++i) {
+        const mi_shape &sh = s->shapes[i];
+        o.shapes[i] = ShapeRec{ sh.bsdf, sh.emitter, sh.flags & 1u, 0 };
+        any_normals = any_normals || (sh.flags & 1u);
+        for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris[f].shape = i;
+    }
+    if (any_normals) o.tri_vn.assign((size_t) s->face_count * 9, 0.f);
+    for (uint32_t f = 0; f < s->face_count; ++f) {
+        Tri &t = o.tris[f];
+        for (int k = 0; k < 3; ++k) {
+            uint32_t vi = s->faces[3 * f + k];
+            float *dst = k == 0 ? t.p0 : (k == 1 ? t.p1 : t.p2);
+            std::memcpy(dst, s->vertex_positions + 3 * (size_t) vi, 12);
+            if (any_normals && (o.shapes[t.shape].flags & 1u))
+                std::memcpy(&o.tri_vn[(size_t) f * 9 + 3 * k], s->vertex_normals + 3 * (size_t) vi, 12);
+        }
+        t.prim = f; t.pad = 0;
+    }
+    o.bsdfs.resize(s->bsdf_count);
+    for (uint32_t i = 0; i < s->bsdf_count; ++i) {
+        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags;
+        std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
+    }
+    // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:55-87)
+    bool emit_normals = false;
+    for (uint32_t i = 0; i < s->emitter_count; ++i) {
+        const mi_emitter &e = s->emitters[i];
+        const mi_shape &sh = s->shapes[e.shape];
+        EmitterRec r; std::memset(&r, 0, sizeof r);
+        std::memcpy(r.radiance, e.radiance, 12);
+        r.shape = e.shape; r.tri_first = (uint32_t) o.emit_pmf.size(); r.tri_count = sh.face_count;
+        r.flags = (sh.flags & 1u);
+        emit_normals = emit_normals || r.flags;
+        double sum = 0.0; uint32_t vlo = 0xffffffffu, vhi = 0;
+        for (uint32_t k = 0; k < sh.face_count; ++k) {
+            const Tri &t = o.tris[sh.first_face + k];
+            float area = face_area(ld3(t.p0), ld3(t.p1), ld3(t.p2));
+            o.emit_pmf.push_back(area);
+            sum += (double) area;
+            o.emit_cdf.push_back((float) sum);
+            if (area > 0.f) { if (vlo == 0xffffffffu) vlo = k; vhi = k; }
+            o.emit_tri.insert(o.emit_tri.end(), t.p0, t.p0 + 3);
+            o.emit_tri.insert(o.emit_tri.end(), t.p1, t.p1 + 3);
+            o.emit_tri.insert(o.emit_tri.end(), t.p2, t.p2 + 3);
+            for (int q = 0; q < 9; ++q)
+                o.emit_vnorm.push_back(r.flags ? o.tri_vn[(size_t) (sh.first_face + k) * 9 + q] : 0.f);
+        }
+        if (vlo == 0xffffffffu) return false;
+        r.valid_lo = vlo; r.valid_hi = vhi; r.sum = (float) sum; r.normalization = (float) (1.0 / sum);
+        o.emitters.push_back(r);
+    }
+    SceneView &v = o.view;
+    v.nodes = nullptr; v.node_count = 0;
+    v.tris = o.tris.data(); v.tri_count = (uint32_t) o.tris.size();
+    v.tri_vn = o.tri_vn.empty() ? nullptr : o.tri_vn.data();
+    v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
+    v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
+    v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
+    v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
+    v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
+    return true;
+}
+
+// ---- Scene::ray_intersect / ray_test, observable behaviour -----------------------------------
+// scene_native.inl:23-41 -> kdtree.h:2079-2171: closest accepted triangle; the tie
+// rule (smaller global primitive id) is this code base's definition.
+struct OHit { bool valid; float t, u, v; uint32_t prim; };
+
+OHit ray_intersect_preliminary(const OScene &sc, const Ray &ray) {
+    OHit best{ false, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0xffffffffu };
+    for (uint32_t i = 0; i < sc.tris.size(); ++i) {
+        const Tri &tr = sc.tris[i];
+        float t, u, v;
+        if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) {
+            if (t < best.t || (t == best.t && i < best.prim)) { best.valid = true; best.t = t; best.u = u; best.v = v; best.prim = i; }
+        }
+    }
+    return best;
+}
+bool ray_test(const OScene &sc, const Ray &ray) {
+    for (const Tri &tr : sc.tris) {
+        float t, u, v;
+        if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) return true;
+    }
+    return false;
+}
+// Scene::ray_intersect: scene_native.inl:23-41 + interaction.h:571-596
+bool ray_intersect(const OScene &sc, const Ray &ray, SurfaceInteraction &si) {
+    OHit h = ray_intersect_preliminary(sc, ray);
+    if (!h.valid) { si.t = std::numeric_limits<float>::infinity(); si.wi = -ray.d; return false; }
+    const Tri &tr = sc.tris[h.prim];
+    const float *vn = (sc.shapes[tr.shape].flags & 1u) ? &sc.tri_vn[(size_t) h.prim * 9] : nullptr;
+    compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.t, h.u, h.v, ray.d, si);
+    si.shape = tr.shape; si.prim = h.prim;
+    return true;
+}
+
+// ---- sampler (src/samplers/independent.cpp, src/librender/sampler.cpp) --------------------------
+struct Sampler {
+    PCG32 rng; uint64_t base_seed;
+    void seed(uint64_t seed_offset) { pcg32_seed(rng, base_seed + seed_offset, MIW_PCG32_DEFAULT_STREAM); }  // sampler.cpp:83-96
+    float next_1d() { return pcg32_next_f32(rng); }                                                        // independent.cpp:73-76
+    V2 next_2d() { float f1 = next_1d(), f2 = next_1d(); return v2(f1, f2); }                             // :78-82
+};
+
+// ---- PathIntegrator::sample, src/integrators/path.cpp:100-211 (scalar semantics) -------------------
+struct PathStats { uint64_t segments = 0, shadow_rays = 0; };
+
+void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int rr_depth,
+                 V3 &result_out, bool &valid_ray_out, PathStats &stats) {
+    const SceneView &view = sc.view;
+    float eta = 1.f;                                     // :111
+    float emission_weight = 1.f;                         // :114
+    V3 throughput = v3(1.f), result = v3(0.f);           // :116
+    bool active = true;                                  // MTS_MASKED_FUNCTION, fwd.h:290-294
+
+    SurfaceInteraction si;                               // :120
+    bool si_valid = ray_intersect(sc, ray, si);
+    bool valid_ray = si_valid;                           // :121
+    int32_t emitter = si_valid ? sc.shapes[si.shape].emitter : -1;   // :122, scene.h:243-253 (no environment)
+
+    for (int depth = 1;; ++depth) {
+        if (emitter >= 0) {                              // :126-129
+            if (active)
+                result = result + emission_weight * throughput * emitter_eval(sc.emitters[emitter], si.wi);
+        }
+        active = active && si_valid;                     // :131
+
+        if (depth > rr_depth) {                          // :137-141
+            float q = min_(hmax(throughput) * sqr(eta), .95f);
+            active = (sampler.next_1d() < q) && active;
+            throughput = throughput * rcp(q);
+        }
+
+        if ((uint32_t) depth >= (uint32_t) max_depth || !active)   // :147-149
+            break;
+
+        stats.segments++;
+        const BsdfRec &bsdf = sc.bsdfs[sc.shapes[si.shape].bsdf];   // :154
+        bool active_e = active && (bsdf_flags(bsdf) & BSDF_Smooth) != 0;   // :155
+
+        if (active_e) {                                  // :157-172
+            // Scene::sample_emitter_direction(si, next_2d, test_visibility = true), scene.cpp:164-214
+            DirectionSample ds;
+            V3 emitter_val = sample_emitter_direction(view, si.p, sampler.next_2d(), ds);
+            if (ds.pdf != 0.f) {                         // scene.cpp:200-207
+                Ray shadow;
+                shadow.o = si.p; shadow.d = ds.d;
+                shadow.mint = MIW_RAY_EPSILON * (1.f + hmax(abs3(si.p)));
+                shadow.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON);
+                stats.shadow_rays++;
+                if (ray_test(sc, shadow)) emitter_val = v3(0.f);
+            }
+            active_e = active_e && ds.pdf != 0.f;        // :160
+            V3 wo = to_local(si.sh, ds.d);               // :163
+            V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);    // :164
+            float bpdf = bsdf_pdf(bsdf, si.wi, wo);      // :168
+            float mis = mis_weight(ds.pdf, bpdf);        // :170 (ds.delta is false for area lights)
+            if (active_e)
+                result = result + mis * throughput * bsdf_val * emitter_val;   // :171
+        }
+
+        // :177-178 — argument order as Clang evaluates it: next_1d, then next_2d
+        float sample1 = sampler.next_1d();
+        V2 sample2 = sampler.next_2d();
+        BSDFSample bs;
+        V3 bsdf_val = bsdf_sample(bsdf, si.wi, sample1, sample2, bs);
+
+        throughput = throughput * bsdf_val;              // :181
+        active = active && !all_zero(throughput);        // :182
+        if (!active) break;                              // :183-184
+
+        eta *= bs.eta;                                   // :186
+
+        // :189-190, interaction.h:58-61
+        Ray next;
+        next.o = si.p; next.d = to_world(si.sh, bs.wo);
+        next.mint = (1.f + hmax(abs3(si.p))) * MIW_RAY_EPSILON;
+        next.maxt = std::numeric_limits<float>::infinity();
+        SurfaceInteraction si_bsdf;
+        bool si_bsdf_valid = ray_intersect(sc, next, si_bsdf);
+
+        // :194-205
+        emitter = si_bsdf_valid ? sc.shapes[si_bsdf.shape].emitter : -1;
+        if (emitter >= 0) {
+            // DirectionSample3f ds(si_bsdf, si), records.h:167-173
+            V3 d = si_bsdf.p - si.p;
+            float dist = norm(d);
+            d = d / dist;
+            float emitter_pdf = 0.f;
+            if (!(bs.sampled_type & BSDF_Delta))
+                emitter_pdf = pdf_emitter_direction(view, (uint32_t) emitter, d, dist, si_bsdf.sh.n);
+            emission_weight = mis_weight(bs.pdf, emitter_pdf);
+        }
+        si = si_bsdf; si_valid = si_bsdf_valid;          // :207
+    }
+    result_out = result; valid_ray_out = valid_ray;
+}
+
+// ---- ImageBlock (src/librender/imageblock.cpp) ---------------------------------------------------
+struct ImageBlock {
+    int off_x = 0, off_y = 0, w = 0, h = 0, border = 0;
+    std::vector<float> data;            // (w + 2b) * (h + 2b) * 5
+    std::vector<double> data64;         // same layout, exact-sum twin (parity instrument)
+    void set(int ox, int oy, int w_, int h_, int b, bool with64) {
+        off_x = ox; off_y = oy; w = w_; h = h_; border = b;
+        data.assign((size_t) (w + 2 * b) * (h + 2 * b) * 5, 0.f);
+        if (with64) data64.assign(data.size(), 0.0); else data64.clear();
+    }
+};
+
+// imageblock.cpp:79-172 — restated on its own (NOT via miw/film.h) so that the
+// shared splat helper is checked against it.
+void block_put(ImageBlock &b, const FilmRec &f, V2 pos_, const float *value) {
+    const int C = 5;
+    bool is_valid = true;
+    for (int k = 0; k < C; ++k) is_valid = is_valid && value[k] >= -1e-5f;
+    for (int k = 0; k < C; ++k) is_valid = is_valid && std::isfinite(value[k]);
+    if (!is_valid) return;
+    float filter_radius = f.radius;
+    int size_x = b.w + 2 * b.border, size_y = b.h + 2 * b.border;
+    float pos_x = pos_.x - ((float) (b.off_x - b.border) + .5f),
+          pos_y = pos_.y - ((float) (b.off_y - b.border) + .5f);
+    if (filter_radius > 0.5f + MIW_RAY_EPSILON) {
+        int lo_x = std::max((int) std::ceil(pos_x - filter_radius), 0),
+            lo_y = std::max((int) std::ceil(pos_y - filter_radius), 0);
+        int hi_x = std::min((int) std::floor(pos_x + filter_radius), size_x - 1),
+            hi_y = std::min((int) std::floor(pos_y + filter_radius), size_y - 1);
+        int n = (int) std::ceil((f.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
+        float base_x = (float) lo_x - pos_x, base_y = (float) lo_y - pos_y;
+        float weights_x[16], weights_y[16];
+        for (int i = 0; i < n; ++i) {
+            float px = base_x + (float) i, py = base_y + (float) i;
+            int ix = std::min((int) std::fabs(px * f.scale_factor), MIW_FILTER_RESOLUTION),
+                iy = std::min((int) std::fabs(py * f.scale_factor), MIW_FILTER_RESOLUTION);
+            weights_x[i] = f.lut[ix]; weights_y[i] = f.lut[iy];
+        }
+        for (int yr = 0; yr < n; ++yr) {
+            int y = lo_y + yr;
+            bool enabled = y <= hi_y;
+            for (int xr = 0; xr < n; ++xr) {
+                int x = lo_x + xr;
+                size_t offset = (size_t) C * ((size_t) y * size_x + x);
+                float weight = weights_y[yr] * weights_x[xr];
+                enabled = enabled && x <= hi_x;
+                if (enabled)
+                    for (int k = 0; k < C; ++k) {
+                        float term = value[k] * weight;
+                        b.data[offset + k] += term;
+                        if (!b.data64.empty()) b.data64[offset + k] += (double) term;
+                    }
+            }
+        }
+    } else {
+        int lo_x = (int) std::ceil(pos_x - .5f), lo_y = (int) std::ceil(pos_y - .5f);
+        if (lo_x >= 0 && lo_y >= 0 && lo_x < size_x && lo_y < size_y) {
+            size_t offset = (size_t) C * ((size_t) lo_y * size_x + lo_x);
+            for (int k = 0; k < C; ++k) {
+                b.data[offset + k] += value[k];
+                if (!b.data64.empty()) b.data64[offset + k] += (double) value[k];
+            }
+        }
+    }
+}
+
+// ImageBlock::put(block) into the borderless film (imageblock.cpp:49-77, bitmap.h:657-712)
+void film_put(const ImageBlock &b, int crop_x, int crop_y, int crop_w, int crop_h, float *film, double *film64) {
+    int sw = b.w + 2 * b.border, sh = b.h + 2 * b.border;
+    for (int y = 0; y < sh; ++y) {
+        int fy = y + b.off_y - b.border - crop_y;
+        if (fy < 0 || fy >= crop_h) continue;
+        for (int x = 0; x < sw; ++x) {
+            int fx = x + b.off_x - b.border - crop_x;
+            if (fx < 0 || fx >= crop_w) continue;
+            size_t src = ((size_t) y * sw + x) * 5, dst = ((size_t) fy * crop_w + fx) * 5;
+            for (int k = 0; k < 5; ++k) {
+                if (film) film[dst + k] += b.data[src + k];
+                if (film64) film64[dst + k] += b.data64[src + k];
+            }
+        }
+    }
+}
+
+// ---- Spiral (src/librender/spiral.cpp) — own restatement --------------------------------------------
+struct SpiralBlock { int off_x, off_y, w, h; uint32_t id; };
+std::vector<SpiralBlock> spiral_blocks(int size_x, int size_y, int off_x, int off_y, int bs) {
+    int blocks_x = (int) std::ceil((float) size_x / (float) bs), blocks_y = (int) std::ceil((float) size_y / (float) bs);
+    int count = blocks_x * blocks_y;
+    std::vector<SpiralBlock> out;
+    int px = blocks_x / 2, py = blocks_y / 2, dir = 0, steps_left = 1, steps = 1;   // reset(), :19-25
+    for (int counter = 0; counter < count;) {
+        SpiralBlock b;
+        b.id = (uint32_t) counter;                        // :41 with one pass
+        int ox = px * bs, oy = py * bs;
+        b.w = std::min(bs, size_x - ox); b.h = std::min(bs, size_y - oy);
+        b.off_x = ox + off_x; b.off_y = oy + off_y;
+        out.push_back(b);
+        ++counter;
+        if (counter != count) {
+            do {                                          // :51-69
+                switch (dir) { case 0: ++px; break; case 1: ++py; break; case 2: --px; break; default: --py; break; }
+                if (--steps_left == 0) {
+                    dir = (dir + 1) % 4;
+                    if (dir == 2 || dir == 0) ++steps;
+                    steps_left = steps;
+                }
+            } while (px < 0 || py < 0 || px >= blocks_x || py >= blocks_y);
+        }
+    }
+    return out;
+}
+
+void fill_records(const mi_render_cfg *cfg, SensorRec &sensor, FilmRec &film) {
+    std::memcpy(sensor.sample_to_camera, cfg->sample_to_camera, 64);
+    std::memcpy(sensor.to_world, cfg->to_world, 64);
+    sensor.near_clip = cfg->near_clip; sensor.far_clip = cfg->far_clip;
+    sensor.pp_offset[0] = cfg->principal_point_offset[0]; sensor.pp_offset[1] = cfg->principal_point_offset[1];
+    film.crop_w = cfg->crop_w; film.crop_h = cfg->crop_h; film.crop_x = cfg->crop_x; film.crop_y = cfg->crop_y;
+    film.block_size = cfg->block_size; film.border = cfg->filter_border; film.radius = cfg->filter_radius;
+    film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
+    std::memcpy(film.lut, cfg->filter_lut, sizeof film.lut);
+}
+
+} // namespace
+
+extern "C" {
+
+struct orc_stats { uint64_t samples, segments, shadow_rays; double seconds; };
+
+// SamplingIntegrator::render (src/librender/integrator.cpp:51-139) on `n_threads`
+// std::threads pulling spiral blocks. film32: crop_w*crop_h*5 float (reference
+// semantics: float32 bordered blocks merged in block-id order); film64 (may be
+// NULL): the same samples summed in double — the exact-sum instrument the device
+// film is compared against bit for bit. `only_blocks`/`n_only`: optional subset
+// of block ids to render (bounded CPU-baseline sample); NULL = all.
+int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film32, double *film64,
+               int n_threads, const uint32_t *only_blocks, uint32_t n_only, orc_stats *stats_out) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    SensorRec sensor; FilmRec film;
+    fill_records(cfg, sensor, film);
+    const int bs = cfg->block_size;
+    std::vector<SpiralBlock> blocks = spiral_blocks(cfg->crop_w, cfg->crop_h, cfg->crop_x, cfg->crop_y, bs);
+    // the caller's block-id table must agree with this spiral (host logic cross-check)
+    {
+        int nbx = (cfg->crop_w + bs - 1) / bs;
+        if (cfg->block_ids)
+            for (const SpiralBlock &b : blocks) {
+                int bx = (b.off_x - cfg->crop_x) / bs, by = (b.off_y - cfg->crop_y) / bs;
+                if (cfg->block_ids[by * nbx + bx] != b.id) return -2;
+            }
+    }
+    std::vector<uint32_t> todo;
+    if (only_blocks) todo.assign(only_blocks, only_blocks + n_only);
+    else if (cfg->tile_list) {
+        int nbx = (cfg->crop_w + bs - 1) / bs;
+        std::map<uint32_t, uint32_t> rm_to_id;
+        for (const SpiralBlock &b : blocks) rm_to_id[(uint32_t) (((b.off_y - cfg->crop_y) / bs) * nbx + (b.off_x - cfg->crop_x) / bs)] = b.id;
+        for (uint32_t i = 0; i < cfg->tile_count; ++i) todo.push_back(rm_to_id[cfg->tile_list[i]]);
+        std::sort(todo.begin(), todo.end());
+    } else for (const SpiralBlock &b : blocks) todo.push_back(b.id);
+
+    size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
+    if (film32) std::memset(film32, 0, film_n * sizeof(float));
+    if (film64) std::memset(film64, 0, film_n * sizeof(double));
+
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<size_t> next{0};
+    std::mutex mutex;
+    std::map<size_t, ImageBlock> ready;    // finished blocks waiting for their turn
+    size_t next_merge = 0;
+    std::atomic<uint64_t> total_samples{0}, total_segments{0}, total_shadow{0};
+    if (n_threads < 1) n_threads = 1;
+
+    auto worker = [&]() {
+        FtzScope ftz;                                         // :117
+        Sampler sampler; sampler.base_seed = cfg->base_seed;  // sampler->clone(), :113
+        PathStats st; uint64_t samples = 0;
+        for (;;) {
+            size_t job = next.fetch_add(1);
+            if (job >= todo.size()) break;
+            const SpiralBlock &blk = blocks[todo[job]];
+            ImageBlock block;                                 // :114-116: bordered block
+            block.set(blk.off_x, blk.off_y, blk.w, blk.h, cfg->filter_border, film64 != nullptr);
+            // render_block, :181-209 (scalar branch)
+            uint32_t pixel_count = (uint32_t) (bs * bs);
+            for (uint32_t i = 0; i < pixel_count; ++i) {
+                sampler.seed((uint64_t) blk.id * pixel_count + i);                 // :198
+                uint32_t px, py; morton_decode2(i, px, py);                         // :200
+                if ((int) px >= blk.w || (int) py >= blk.h) continue;               // :201-202
+                float pos_x = (float) (px + (uint32_t) blk.off_x), pos_y = (float) (py + (uint32_t) blk.off_y);   // :204
+                for (uint32_t j = 0; j < cfg->spp; ++j) {
+                    // render_sample, :233-288
+                    V2 jit = sampler.next_2d();
+                    V2 position_sample = v2(pos_x + jit.x, pos_y + jit.y);          // :242
+                    (void) sampler.next_1d();                                       // :252 wavelength sample
+                    V2 adjusted = v2((position_sample.x - (float) cfg->crop_x) / (float) cfg->crop_w,
+                                     (position_sample.y - (float) cfg->crop_y) / (float) cfg->crop_h);   // :254-256
+                    Ray ray = sensor_sample_ray(sensor, adjusted);                  // :258
+                    V3 L; bool valid;
+                    path_sample(sc, sampler, ray, cfg->max_depth, cfg->rr_depth, L, valid, st);   // :264
+                    V3 xyz = srgb_to_xyz(L);                                        // :272-273
+                    float aovs[5] = { xyz.x, xyz.y, xyz.z, valid ? 1.f : 0.f, 1.f };   // :279-283
+                    block_put(block, film, position_sample, aovs);                  // :285
+                    ++samples;                                                      // sampler->advance(), :287
+                }
+            }
+            // film->put(block), :130 — merged in block-id order so that the float32
+            // film is deterministic (the reference's order is thread-timing dependent,
+            // independent.cpp:36-40)
+            std::lock_guard<std::mutex> lock(mutex);
+            ready.emplace(job, std::move(block));
+            while (!ready.empty() && ready.begin()->first == next_merge) {
+                film_put(ready.begin()->second, cfg->crop_x, cfg->crop_y, cfg->crop_w, cfg->crop_h, film32, film64);
+                ready.erase(ready.begin());
+                ++next_merge;
+            }
+        }
+        total_samples += samples; total_segments += st.segments; total_shadow += st.shadow_rays;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (stats_out) {
+        stats_out->samples = total_samples; stats_out->segments = total_segments; stats_out->shadow_rays = total_shadow;
+        stats_out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+// Scene::ray_intersect_preliminary / ray_test by brute force (the definition the BVH must match)
+int orc_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_soa *h, uint64_t n, int any_hit) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    FtzScope ftz;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray ray; ray.o = v3(r->ox[i], r->oy[i], r->oz[i]); ray.d = v3(r->dx[i], r->dy[i], r->dz[i]);
+        ray.mint = r->mint[i]; ray.maxt = r->maxt[i];
+        if (any_hit) {
+            h->t[i] = ray_test(sc, ray) ? 0.f : std::numeric_limits<float>::infinity();
+        } else {
+            OHit o = ray_intersect_preliminary(sc, ray);
+            h->t[i] = o.valid ? o.t : std::numeric_limits<float>::infinity();
+            if (h->u) h->u[i] = o.u;
+            if (h->v) h->v[i] = o.v;
+            if (h->prim) h->prim[i] = o.valid ? o.prim : 0xffffffffu;
+            if (h->shape) h->shape[i] = o.valid ? sc.tris[o.prim].shape : 0xffffffffu;
+        }
+    }
+    return 0;
+}
+
+// Full SurfaceInteraction for one ray: out = t, p.xyz, n.xyz, sh_n.xyz, sh_s.xyz, sh_t.xyz, wi.xyz, uv (21)
+int orc_ray_intersect_full(const mi_scene_desc *scene, const float *ray8, float *out21) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    FtzScope ftz;
+    Ray ray; ray.o = v3(ray8[0], ray8[1], ray8[2]); ray.d = v3(ray8[3], ray8[4], ray8[5]); ray.mint = ray8[6]; ray.maxt = ray8[7];
+    SurfaceInteraction si; std::memset(&si, 0, sizeof si);
+    bool ok = ray_intersect(sc, ray, si);
+    float *o = out21;
+    o[0] = si.t; o[1] = si.p.x; o[2] = si.p.y; o[3] = si.p.z; o[4] = si.n.x; o[5] = si.n.y; o[6] = si.n.z;
+    o[7] = si.sh.n.x; o[8] = si.sh.n.y; o[9] = si.sh.n.z; o[10] = si.sh.s.x; o[11] = si.sh.s.y; o[12] = si.sh.s.z;
+    o[13] = si.sh.t.x; o[14] = si.sh.t.y; o[15] = si.sh.t.z; o[16] = si.wi.x; o[17] = si.wi.y; o[18] = si.wi.z;
+    o[19] = si.uv.x; o[20] = si.uv.y;
+    return ok ? 1 : 0;
+}
+
+// ---- known-answer entry points -------------------------------------------------------------------
+float  orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_float32(v0, v1, rounds); }
+double orc_tea_float64(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_float64(v0, v1, rounds); }
+uint32_t orc_tea_32(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_32(v0, v1, rounds); }
+void orc_pcg32_u32(uint64_t initstate, uint64_t initseq, uint32_t *out, int n) {
+    PCG32 r; pcg32_seed(r, initstate, initseq);
+    for (int i = 0; i < n; ++i) out[i] = pcg32_next_u32(r);
+}
+void orc_pcg32_f32(uint64_t initstate, uint64_t initseq, float *out, int n) {
+    PCG32 r; pcg32_seed(r, initstate, initseq);
+    for (int i = 0; i < n; ++i) out[i] = pcg32_next_f32(r);
+}
+void orc_morton_decode(uint32_t i, uint32_t *xy) { morton_decode2(i, xy[0], xy[1]); }
+void orc_fresnel(float cos_theta_i, float eta, float *out4) { FtzScope f; fresnel(cos_theta_i, eta, out4[0], out4[1], out4[2], out4[3]); }
+float orc_fresnel_conductor(float cos_theta_i, float eta_r, float eta_i) { FtzScope f; return fresnel_conductor(cos_theta_i, eta_r, eta_i); }
+// microfacet: op 0 eval(m) 1 pdf(wi,m) 2 smith_g1(v=wi,m) 3 sample(wi,u) -> m.xyz,pdf
+void orc_microfacet(int op, uint32_t type, float au, float av, int sample_visible, const float *wi, const float *m_or_u, float *out) {
+    FtzScope f;
+    Microfacet d = microfacet_make(type, au, av, sample_visible != 0);
+    V3 w = v3(wi[0], wi[1], wi[2]);
+    switch (op) {
+        case 0: out[0] = mf_eval(d, v3(m_or_u[0], m_or_u[1], m_or_u[2])); break;
+        case 1: out[0] = mf_pdf(d, w, v3(m_or_u[0], m_or_u[1], m_or_u[2])); break;
+        case 2: out[0] = mf_smith_g1(d, w, v3(m_or_u[0], m_or_u[1], m_or_u[2])); break;
+        default: { V3 m; float pdf; mf_sample(d, w, v2(m_or_u[0], m_or_u[1]), m, pdf); out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf; }
+    }
+}
+// Mesh::ray_intersect_triangle: tri9 = p0,p1,p2 ; ray8 ; out = hit, t, u, v
+void orc_ray_triangle(const float *tri9, const float *ray8, float *out4) {
+    FtzScope f;
+    float t, u, v;
+    bool hit = ray_intersect_triangle(ld3(tri9), ld3(tri9 + 3), ld3(tri9 + 6), v3(ray8[0], ray8[1], ray8[2]),
+                                      v3(ray8[3], ray8[4], ray8[5]), ray8[6], ray8[7], t, u, v);
+    out4[0] = hit ? 1.f : 0.f; out4[1] = t; out4[2] = u; out4[3] = v;
+}
+// ImageBlock::put for n samples into a fresh bordered block; out = (w+2b)*(h+2b)*5 floats
+int orc_imageblock_put(const mi_render_cfg *cfg, int off_x, int off_y, int w, int h, int border,
+                       const float *pos_xy, const float *values5, int n, float *out) {
+    FtzScope f;
+    SensorRec sensor; FilmRec film; fill_records(cfg, sensor, film);
+    ImageBlock b; b.set(off_x, off_y, w, h, border, false);
+    for (int i = 0; i < n; ++i) block_put(b, film, v2(pos_xy[2 * i], pos_xy[2 * i + 1]), values5 + 5 * i);
+    std::memcpy(out, b.data.data(), b.data.size() * sizeof(float));
+    return (int) b.data.size();
+}
+// the shared splat helper (miw/film.h) over the same samples, into a film-sized f64 buffer
+void orc_film_splat_shared(const mi_render_cfg *cfg, const float *pos_xy, const float *values5, int n, double *film64) {
+    FtzScope f;
+    SensorRec sensor; FilmRec film; fill_records(cfg, sensor, film);
+    for (int i = 0; i < n; ++i) {
+        int px = (int) std::floor(pos_xy[2 * i]), py = (int) std::floor(pos_xy[2 * i + 1]);
+        film_splat(film, px, py, v2(pos_xy[2 * i], pos_xy[2 * i + 1]), values5 + 5 * i,
+                   [&](int texel, int k, float v) { film64[(size_t) texel * 5 + k] += (double) v; });
+    }
+}
+int orc_spiral(int w, int h, int off_x, int off_y, int bs, int32_t *out5, int capacity) {
+    std::vector<SpiralBlock> b = spiral_blocks(w, h, off_x, off_y, bs);
+    for (size_t i = 0; i < b.size() && (int) i < capacity; ++i) {
+        out5[i * 5] = b[i].off_x; out5[i * 5 + 1] = b[i].off_y; out5[i * 5 + 2] = b[i].w; out5[i * 5 + 3] = b[i].h; out5[i * 5 + 4] = (int32_t) b[i].id;
+    }
+    return (int) b.size();
+}
+void orc_coordinate_system(const float *n, float *st6) {
+    FtzScope f; V3 s, t; coordinate_system(v3(n[0], n[1], n[2]), s, t);
+    st6[0] = s.x; st6[1] = s.y; st6[2] = s.z; st6[3] = t.x; st6[4] = t.y; st6[5] = t.z;
+}
+void orc_warp(int op, const float *u2, float *out) {
+    FtzScope f;
+    V2 u = v2(u2[0], u2[1]);
+    switch (op) {
+        case 0: { V2 p = square_to_uniform_disk_concentric(u); out[0] = p.x; out[1] = p.y; } break;
+        case 1: { V3 p = square_to_cosine_hemisphere(u); out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = square_to_cosine_hemisphere_pdf(p); } break;
+        default: { V2 p = square_to_uniform_triangle(u); out[0] = p.x; out[1] = p.y; }
+    }
+}
+
+// Mirror of the device-side mi_eval: same ops, same layouts, evaluated on the CPU.
+int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const float *in, int is, float *out, int os, uint64_t n) {
+    FtzScope ftz;
+    OScene sc; bool have_scene = false;
+    if (scene) { if (!build_scene(scene, sc)) return -1; have_scene = true; }
+    SensorRec sensor; FilmRec film;
+    if (cfg) fill_records(cfg, sensor, film);
+    for (uint64_t i = 0; i < n; ++i) {
+        const float *a = in + i * (uint64_t) is; float *o = out + i * (uint64_t) os;
+        switch (op) {
+            case MI_EVAL_PCG32: {
+                PCG32 r; pcg32_seed(r, (uint64_t) f2u(a[0]) | ((uint64_t) f2u(a[1]) << 32), MIW_PCG32_DEFAULT_STREAM);
+                for (int k = 0; k < 8; ++k) o[k] = pcg32_next_f32(r);
+            } break;
+            case MI_EVAL_SINCOS: sincos_(a[0], o[0], o[1]); break;
+            case MI_EVAL_COSINE_HEMISPHERE: {
+                V3 w = square_to_cosine_hemisphere(v2(a[0], a[1]));
+                o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = square_to_cosine_hemisphere_pdf(w);
+            } break;
+            case MI_EVAL_BSDF: {
+                if (!have_scene) return -1;
+                const BsdfRec &b = sc.bsdfs[f2u(a[0])];
+                V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
+                BSDFSample bs; V3 w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs);
+                o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
+                o[6] = w.x; o[7] = w.y; o[8] = w.z;
+                V3 e = bsdf_eval(b, wi, wo); o[9] = e.x; o[10] = e.y; o[11] = e.z;
+                o[12] = bsdf_pdf(b, wi, wo);
+            } break;
+            case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
+            case MI_EVAL_CAMERA_RAY: {
+                if (!cfg) return -1;
+                V2 adj = v2((a[0] - (float) film.crop_x) / (float) film.crop_w, (a[1] - (float) film.crop_y) / (float) film.crop_h);
+                Ray r = sensor_sample_ray(sensor, adj);
+                o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.mint; o[7] = r.maxt;
+            } break;
+            case MI_EVAL_EMITTER_SAMPLE: {
+                if (!have_scene) return -1;
+                DirectionSample ds; V3 s = sample_emitter_direction(sc.view, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds);
+                o[0] = ds.d.x; o[1] = ds.d.y; o[2] = ds.d.z; o[3] = ds.dist; o[4] = ds.pdf;
+                o[5] = s.x; o[6] = s.y; o[7] = s.z; o[8] = ds.p.x; o[9] = ds.p.y; o[10] = ds.p.z;
+                o[11] = ds.n.x; o[12] = ds.n.y; o[13] = ds.n.z;
+            } break;
+            case MI_EVAL_FP_SEMANTICS: {
+                float x = a[0], y = a[1], z = a[2];
+                o[0] = x + y; o[1] = x * y; o[2] = x / y; o[3] = __builtin_sqrtf(abs_(x));
+                o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
+            } break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,133 @@
+"""ctypes binding of the CPU checker (oracle/_build/libmiw_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the mitsuba2_amd package.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from mitsuba2_amd._capi import (mi_hits_soa, mi_rays_soa, mi_render_cfg, mi_scene_desc, c_float_p, c_double_p,  # noqa: E402
+                                c_u32_p, c_i32_p, MI_EVAL_STRIDES)
+
+_lib = None
+
+
+class orc_stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64), ("seconds", C.c_double)]
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.L = lib
+        L = lib
+        vp = C.c_void_p
+        L.orc_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_float_p, c_double_p, C.c_int,
+                                 c_u32_p, C.c_uint32, C.POINTER(orc_stats)]
+        L.orc_render.restype = C.c_int
+        L.orc_trace.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64, C.c_int]
+        L.orc_trace.restype = C.c_int
+        L.orc_ray_intersect_full.argtypes = [C.POINTER(mi_scene_desc), c_float_p, c_float_p]
+        L.orc_ray_intersect_full.restype = C.c_int
+        L.emu_trace.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
+                                C.c_int, C.c_int, c_u32_p]
+        L.emu_trace.restype = C.c_int
+        L.emu_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_double_p, C.POINTER(C.c_uint64)]
+        L.emu_render.restype = C.c_int
+        L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.orc_tea_float32.restype = C.c_float
+        L.orc_tea_float64.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.orc_tea_float64.restype = C.c_double
+        L.orc_tea_32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.orc_tea_32.restype = C.c_uint32
+        L.orc_pcg32_u32.argtypes = [C.c_uint64, C.c_uint64, c_u32_p, C.c_int]
+        L.orc_pcg32_f32.argtypes = [C.c_uint64, C.c_uint64, c_float_p, C.c_int]
+        L.orc_morton_decode.argtypes = [C.c_uint32, c_u32_p]
+        L.orc_fresnel.argtypes = [C.c_float, C.c_float, c_float_p]
+        L.orc_fresnel_conductor.argtypes = [C.c_float, C.c_float, C.c_float]; L.orc_fresnel_conductor.restype = C.c_float
+        L.orc_microfacet.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_int, c_float_p, c_float_p, c_float_p]
+        L.orc_ray_triangle.argtypes = [c_float_p, c_float_p, c_float_p]
+        L.orc_imageblock_put.argtypes = [C.POINTER(mi_render_cfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p,
+                                         c_float_p, C.c_int, c_float_p]
+        L.orc_imageblock_put.restype = C.c_int
+        L.orc_film_splat_shared.argtypes = [C.POINTER(mi_render_cfg), c_float_p, c_float_p, C.c_int, c_double_p]
+        L.orc_spiral.argtypes = [C.c_int] * 5 + [c_i32_p, C.c_int]; L.orc_spiral.restype = C.c_int
+        L.orc_coordinate_system.argtypes = [c_float_p, c_float_p]
+        L.orc_warp.argtypes = [C.c_int, c_float_p, c_float_p]
+        L.orc_eval.argtypes = [C.c_int, C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_float_p, C.c_int, c_float_p,
+                               C.c_int, C.c_uint64]
+        L.orc_eval.restype = C.c_int
+
+    # ---- renders ----
+    def render(self, desc, job, threads=1, want_f64=True, only_blocks=None):
+        cfg = job.cfg
+        n = cfg.crop_w * cfg.crop_h * 5
+        f32 = np.zeros(n, np.float32)
+        f64 = np.zeros(n, np.float64) if want_f64 else None
+        st = orc_stats()
+        ob = None if only_blocks is None else np.ascontiguousarray(only_blocks, np.uint32)
+        rc = self.L.orc_render(desc, C.byref(cfg), _fp(f32), None if f64 is None else f64.ctypes.data_as(c_double_p),
+                               threads, None if ob is None else ob.ctypes.data_as(c_u32_p), 0 if ob is None else len(ob),
+                               C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_render failed: %d" % rc)
+        shape = (cfg.crop_h, cfg.crop_w, 5)
+        return f32.reshape(shape), None if f64 is None else f64.reshape(shape), st
+
+    def emu_render(self, desc, job):
+        cfg = job.cfg
+        n = cfg.crop_w * cfg.crop_h * 5
+        f64 = np.zeros(n, np.float64)
+        stats = (C.c_uint64 * 4)()
+        rc = self.L.emu_render(desc, C.byref(cfg), f64.ctypes.data_as(c_double_p), stats)
+        if rc != 0:
+            raise RuntimeError("emu_render failed: %d" % rc)
+        return f64.reshape(cfg.crop_h, cfg.crop_w, 5), list(stats)
+
+    def _trace(self, fn, desc, o, d, mint, maxt, any_hit, *extra):
+        from mitsuba2_amd.api import _rays_struct, _hits_struct
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        h, out = _hits_struct(n)
+        rc = fn(desc, C.byref(r), C.byref(h), n, int(any_hit), *extra)
+        if rc != 0:
+            raise RuntimeError("trace failed: %d" % rc)
+        return out
+
+    def trace(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False):
+        return self._trace(self.L.orc_trace, desc, o, d, mint, maxt, any_hit)
+
+    def emu_trace(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4):
+        stats = (C.c_uint32 * 3)()
+        out = self._trace(self.L.emu_trace, desc, o, d, mint, maxt, any_hit, max_leaf, stats)
+        out["bvh"] = list(stats)
+        return out
+
+    def ray_intersect_full(self, desc, ray8):
+        r = np.ascontiguousarray(ray8, np.float32); out = np.zeros(21, np.float32)
+        ok = self.L.orc_ray_intersect_full(desc, _fp(r), _fp(out))
+        return ok, out
+
+    def eval(self, op, inputs, desc=None, cfg=None):
+        i_s, o_s = MI_EVAL_STRIDES[op]
+        a = np.ascontiguousarray(inputs, np.float32).reshape(-1, i_s)
+        out = np.zeros((len(a), o_s), np.float32)
+        rc = self.L.orc_eval(op, desc, C.byref(cfg) if cfg is not None else None, _fp(a), i_s, _fp(out), o_s, len(a))
+        if rc != 0:
+            raise RuntimeError("orc_eval failed")
+        return out
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "_build", "libmiw_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError(path + " missing: python -m mitsuba2_amd.build --oracle")
+        _lib = Oracle(C.CDLL(path))
+    return _lib

@@ -1,0 +1,40 @@
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running")
+
+
+@pytest.fixture(scope="session")
+def native():
+    """Build (if stale) and load the product libraries + the CPU checker."""
+    from mitsuba2_amd import build
+    build.build_all(oracle=True)
+    from mitsuba2_amd import api
+    api.host_lib()
+    return api
+
+
+@pytest.fixture(scope="session")
+def oracle(native):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    return oracle_py.load()
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
