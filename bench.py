@@ -1,0 +1,160 @@
+"""Headline benchmark: Msamples/s of the path-integrator hot path on the Cornell box,
+1920x1080 @ 512 spp, diffuse BSDFs (BASELINE.json configs[1]), N GPUs of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--width --height --spp]
+
+A "step" is one complete render of the workload (scene + BVH already resident in
+HBM; the timed region is mi_render + the film reduce). For N > 1 launch with
+torch.distributed.run, one rank per GPU: pixel tiles (spiral blocks) are sharded
+round-robin over ranks, each rank splats into a private full-size
+float64 film and one RCCL reduce(sum) to rank 0 closes the step.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(dominant kernel, HIP-event timed inside the library on its own stream) and
+`cpu_baseline` (the scalar_rgb oracle on the host cores, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic bytes per path segment per kernel (sum = 280 B)
+B_SHADE = 196.0              # state R+W 96, hit R 16, ext ray W 28, shadow ray+contribution W 44, contribution R 12
+B_TRACE_CLOSEST = 44.0       # ray R 28, hit W 16
+B_TRACE_ANY = 40.0           # shadow ray R 32, visibility W+R 8
+B_SPLAT = 320.0              # per finished sample: 4x4 texels x 5 channels x 4 B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from mitsuba2_amd import api, scenes, _capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: mitsuba2_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    W, H, SPP = args.width, args.height, args.spp
+    scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=True, device=-1)
+    dev = api.Device(local_rank)
+    dev.upload(scene.desc())                                 # scene + BVH resident before timing
+    integ = api.PathIntegrator()
+    integ.set_shard(rank, world)
+    job = integ.render_job(sensor)
+    cfg = job.cfg
+    cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
+    film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    dev.check(dev.L.mi_set_stream(dev.ctx, C.c_void_p(stream.cuda_stream)))
+
+    def step():
+        st = dev.L.mi_render(dev.ctx, C.byref(cfg), C.c_void_p(film.data_ptr()))
+        dev.check(st)
+        if world > 1:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    agg = dict(ms_shade=0.0, ms_tc=0.0, ms_ta=0.0, ms_film=0.0, ms_init=0.0, n_shade=0, n_tc=0, n_ta=0, segments=0, samples=0,
+               shadow=0, iters=0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        c = dev.counters()
+        agg["ms_shade"] += c.ms_shade; agg["ms_tc"] += c.ms_trace_closest; agg["ms_ta"] += c.ms_trace_any
+        agg["ms_film"] += c.ms_resolve; agg["ms_init"] += c.ms_init
+        agg["n_shade"] += c.n_shade; agg["n_tc"] += c.n_trace_closest; agg["n_ta"] += c.n_trace_any
+        agg["segments"] += c.segments; agg["samples"] += c.samples; agg["shadow"] += c.shadow_rays; agg["iters"] += c.iterations
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = float(W) * H * SPP * args.steps
+        value = total_samples / elapsed / 1e6
+        s_bar = agg["segments"] / max(agg["samples"], 1)
+        # dominant kernel by summed HIP-event time (rank 0's shard)
+        kernels = {
+            "k_shade": (agg["ms_shade"], agg["n_shade"], B_SHADE * agg["segments"] + B_SPLAT * agg["samples"]),
+            "k_trace<closest>": (agg["ms_tc"], agg["n_tc"], B_TRACE_CLOSEST * agg["segments"]),
+            "k_trace<any>": (agg["ms_ta"], agg["n_ta"], B_TRACE_ANY * agg["shadow"]),
+        }
+        roofline = None
+        if not args.no_profile and agg["n_shade"]:
+            name = max(kernels, key=lambda k: kernels[k][0])
+            ms, n, alg_bytes = kernels[name]
+            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            b_alg = 280.0 * s_bar + 320.0
+            roofline = {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
+                "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items()},
+                                  k_film_assemble=round(agg["ms_film"], 3), k_init_lanes=round(agg["ms_init"], 3)),
+                "segments_per_sample": s_bar,
+                "pipeline_alg_bytes_per_sample": b_alg,
+                "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),
+            }
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            O = oracle_py.load()
+            cores = os.cpu_count() or 1
+            nblocks = 8                                      # bounded sample: the 8 centre-most spiral blocks, full spp
+            one = api.PathIntegrator().render_job(sensor)
+            _, _, st = O.render(scene.desc(), one, threads=cores, want_f64=False, only_blocks=np.arange(nblocks, dtype=np.uint32))
+            cpu = {"value": st.samples / st.seconds / 1e6, "unit": "Msamples/sec", "cores": cores, "kind": "port",
+                   "sample": "first %d spiral blocks (32x32 px) of the same %dx%d@%dspp job, %d samples, %.1f s" %
+                             (nblocks, W, H, SPP, st.samples, st.seconds)}
+        out = {
+            "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
+                                   "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" % (W, H, SPP),
+                       "parallelism": "tile-shard x%d + RCCL film reduce" % world if world > 1 else "single GPU",
+                       "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

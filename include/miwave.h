@@ -118,7 +118,13 @@ typedef struct {
     int32_t filter_border;
     /* output: crop_w*crop_h*5 values X,Y,Z,A,W (integrator.cpp:71-72)             */
     int32_t film_on_device;                   /* 0: host pointer, 1: device pointer      */
-    int32_t film_f64;                         /* 0: float32 film, 1: float64 accumulators*/
+    int32_t film_f64;                         /* 0: float32 film, 1: float64 values      */
+    /* how ImageBlock::put is realised:
+     * 1 = sample log + ordered gather: float32 sums in the reference's order
+     *     (bit-identical film; needs spp * lanes * 24 B of HBM),
+     * 2 = float64 atomics straight into the film (order-free, ~1e-16 noise),
+     * 0 = auto: 1 if the log fits in free device memory, else 2               */
+    int32_t film_mode;
     int32_t profile;                          /* 1: time every launch with HIP events    */
     float timeout_s;                          /* <= 0: none (integrator.cpp:34)          */
 } mi_render_cfg;
@@ -135,6 +141,7 @@ typedef struct {
     uint64_t n_trace_closest, n_trace_any, n_shade;
     double ms_bvh_build;
     uint32_t bvh_nodes, bvh_tris, bvh_depth;
+    uint32_t film_mode;        /* 1 = ordered gather, 2 = float64 atomics (last render)   */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */
@@ -151,7 +158,11 @@ mi_status mi_set_stream(mi_ctx *ctx, void *hip_stream);
  * (Mesh::build_pmf, src/librender/mesh.cpp:285-312) */
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 /* Scene::accel_init_cpu (src/librender/scene_native.inl:3-10): build the BVH.
- * quality 0 = LBVH built on the device, 1 = binned SAH built on the host */
+ * quality 0 = LBVH built on the device, 1 = binned SAH built on the host.
+ * Scenes of <= 64 triangles are traced by a brute-force sweep over LDS-resident
+ * triangle packets instead of the tree; OR in MI_BVH_FORCE_TREE to walk the tree
+ * anyway (tests). */
+enum { MI_BVH_FORCE_TREE = 0x10 };
 mi_status mi_bvh_build(mi_ctx *ctx, int32_t quality);
 
 /* Scene::ray_intersect_preliminary (any_hit = 0) / Scene::ray_test (any_hit = 1),

@@ -53,7 +53,8 @@ class mi_render_cfg(C.Structure):
                 ("sample_to_camera", C.c_float * 16), ("to_world", C.c_float * 16),
                 ("near_clip", C.c_float), ("far_clip", C.c_float), ("principal_point_offset", C.c_float * 2),
                 ("filter_lut", C.c_float * 32), ("filter_radius", C.c_float), ("filter_border", C.c_int32),
-                ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("profile", C.c_int32),
+                ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("film_mode", C.c_int32),
+                ("profile", C.c_int32),
                 ("timeout_s", C.c_float)]
 
 
@@ -64,7 +65,7 @@ class mi_counters(C.Structure):
                 ("ms_init", C.c_double), ("ms_resolve", C.c_double),
                 ("n_trace_closest", C.c_uint64), ("n_trace_any", C.c_uint64), ("n_shade", C.c_uint64),
                 ("ms_bvh_build", C.c_double), ("bvh_nodes", C.c_uint32), ("bvh_tris", C.c_uint32),
-                ("bvh_depth", C.c_uint32)]
+                ("bvh_depth", C.c_uint32), ("film_mode", C.c_uint32)]
 
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4

@@ -331,9 +331,10 @@ class Device:
         self.check(self.L.mi_trace(self.ctx, C.byref(r), C.byref(h), n, int(any_hit)))
         return out
 
-    def render(self, job, f64=False, profile=False):
+    def render(self, job, f64=False, profile=False, film_mode=0):
+        """film_mode 0 auto / 1 sample log + ordered gather (float32, reference order) / 2 float64 atomics"""
         cfg = job.cfg
-        cfg.film_on_device = 0; cfg.film_f64 = int(f64); cfg.profile = int(profile)
+        cfg.film_on_device = 0; cfg.film_f64 = int(f64); cfg.profile = int(profile); cfg.film_mode = film_mode
         n = cfg.crop_w * cfg.crop_h * 5
         film = np.zeros(n, np.float64 if f64 else np.float32)
         st = self.L.mi_render(self.ctx, C.byref(cfg), film.ctypes.data_as(C.c_void_p))

@@ -65,6 +65,10 @@ MIW_HD float lerp_(float a, float b, float t) { return fmadd(b, t, fnmadd(a, t, 
 
 struct V2 { float x, y; };
 struct V3 { float x, y, z; };
+// 16- / 8-byte queue words (one dwordx4 / dwordx2 per lane)
+struct alignas(16) F4 { float x, y, z, w; };
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+struct alignas(8)  F2 { float x, y; };
 
 MIW_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 MIW_HD V3 v3(float s) { return v3(s, s, s); }

@@ -30,10 +30,6 @@
 
 namespace miw {
 
-struct alignas(16) F4 { float x, y, z, w; };
-struct alignas(16) U4 { uint32_t x, y, z, w; };
-struct alignas(8)  F2 { float x, y; };
-
 // lane flag word (st.z)
 enum : uint32_t {
     LF_DEPTH_MASK  = 0x0fffu,
@@ -61,6 +57,9 @@ struct LaneQueues {
     F4 *sh_d;      // d.xyz, maxt
     F4 *sh_c;      // pending contribution rgb
     uint32_t *sh_vis; // 1 = unoccluded (written by the any-hit trace)
+    // finished-sample log (24 B/sample), [sample j][lane]: what ImageBlock::put received
+    F2 *log_pos;   // position_sample (x = NaN: sample rejected by imageblock.cpp:85-109)
+    F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
 };
 
 struct RenderParams {
@@ -110,13 +109,34 @@ MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L
 }
 
 // integrator.cpp:264-287 — convert, splat, advance
-template <typename Add>
-MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, Add add) {
+// `sink(pixel, sample_idx, position_sample, aovs)` stands for block->put(position_sample, aovs), :285
+template <typename Sink>
+MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, Sink sink) {
+    (void) P;
     V3 xyz = srgb_to_xyz(L.res);                         // :272-273 (ray_weight == 1 in RGB)
     float aovs[5] = { xyz.x, xyz.y, xyz.z, (L.flags & LF_VALID_RAY) ? 1.f : 0.f, 1.f };
-    film_splat(P.film, (int) (pixel & 0xffffu), (int) (pixel >> 16), L.pos, aovs, add);
+    sink(pixel, L.sample_idx, L.pos, aovs);
     L.sample_idx++;                                      // :287
 }
+
+// Sink 1: splat immediately into float64 accumulators (atomics on the device)
+template <typename Add> struct SplatSink {
+    const FilmRec *film; Add add;
+    MIW_HD void operator()(uint32_t pixel, uint32_t, V2 pos, const float *aovs) const {
+        film_splat(*film, (int) (pixel & 0xffffu), (int) (pixel >> 16), pos, aovs, add);
+    }
+};
+// Sink 2: append to the lane's sample log; the film is assembled afterwards by the
+// ordered gather (miw/film_gather.h), in the reference's float32 accumulation order.
+struct LogSink {
+    F2 *log_pos; F4 *log_val; uint32_t lane, n_lanes;
+    MIW_HD void operator()(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) const {
+        size_t i = (size_t) sample_idx * n_lanes + lane;
+        F2 p; p.x = sample_is_valid(aovs) ? pos.x : __builtin_nanf(""); p.y = pos.y;
+        F4 v; v.x = aovs[0]; v.y = aovs[1]; v.z = aovs[2]; v.w = aovs[3];
+        log_pos[i] = p; log_val[i] = v;
+    }
+};
 
 MIW_HD void lane_load(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
     U4 st = Q.st[lane];
@@ -171,9 +191,9 @@ MIW_HD void lane_init_unused(const LaneQueues &Q, uint32_t lane) {
 
 // Stage 2: one iteration of the depth loop for one lane.
 // Returns true while the lane still has work (not DONE).
-template <typename Add>
+template <typename Sink>
 MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
-                       uint32_t lane, Counters *cnt_local, Add add) {
+                       uint32_t lane, Counters *cnt_local, Sink sink) {
     LaneRegs L;
     lane_load(Q, lane, L);
     if (L.flags & LF_DONE) return false;
@@ -299,7 +319,7 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
     bool store_pos = false;
     if (finished) {
         // ---- splat, advance, regenerate (integrator.cpp:264-287) ----
-        lane_finish_sample(P, pixel, L, add);
+        lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
         lane_begin_sample(P, pixel, L);

@@ -26,6 +26,24 @@ struct Tri {
 
 MIW_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
 
+// mesh.h:194-226 from the edge vectors on (e1 = p1 - p0, e2 = p2 - p0: storing them
+// is bit-identical to recomputing them — one correctly rounded subtraction each).
+MIW_HD bool ray_intersect_triangle_edges(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float mint, float maxt,
+                                         float &t_out, float &u_out, float &v_out) {
+    V3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    bool active = u >= 0.f && u <= 1.f;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    active = active && v >= 0.f && u + v <= 1.f;
+    float t = dot(e2, qvec) * inv_det;
+    active = active && t >= mint && t <= maxt;
+    t_out = t; u_out = u; v_out = v;
+    return active;
+}
+
 // mesh.h:194-226. Returns true on a hit inside [mint, maxt].
 MIW_HD bool ray_intersect_triangle(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, float maxt,
                                    float &t_out, float &u_out, float &v_out) {

@@ -33,6 +33,7 @@
 #include "miw/film.h"
 #include "miw/bvh.h"
 #include "miw/path.h"
+#include "miw/film_gather.h"
 #include "bvh_build.h"
 
 using namespace miw;
@@ -42,6 +43,8 @@ static_assert(sizeof(Tri) == 48, "Tri must be 48 bytes");
 static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layout");
 
 #define MIW_BLOCK 256
+#define MIW_CNT_SHARDS 1024        /* power of two */
+#define MIW_BRUTE_MAX_TRIS 64       /* <= this many triangles: LDS brute-force sweep instead of the BVH */
 
 // ---------------------------------------------------------------------------------------
 // device helpers
@@ -50,9 +53,27 @@ static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layou
 struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t nodes_staged;  // first `nodes_staged` BVH nodes (breadth-first = top of tree)
     uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
+    uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets only, no BVH walk
 };
 
+// Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
+struct TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
+static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
+
 __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
+    if (cfg.brute) {
+        TriPacket *dst = reinterpret_cast<TriPacket *>(smem);
+        for (uint32_t i = threadIdx.x; i < sc.tri_count; i += blockDim.x) {
+            const Tri &t = sc.tris[i];
+            V3 p0 = ld3(t.p0), e1 = ld3(t.p1) - p0, e2 = ld3(t.p2) - p0;
+            TriPacket k;
+            k.p0[0] = p0.x; k.p0[1] = p0.y; k.p0[2] = p0.z; k.e1[0] = e1.x; k.e1[1] = e1.y; k.e1[2] = e1.z;
+            k.e2[0] = e2.x; k.e2[1] = e2.y; k.e2[2] = e2.z; k.prim = t.prim; k.pad[0] = k.pad[1] = 0;
+            dst[i] = k;
+        }
+        __syncthreads();
+        return;
+    }
     const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
     uint32_t n16 = cfg.nodes_staged * (sizeof(BvhNode) / 16);
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) smem[i] = src_n[i];
@@ -66,6 +87,25 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
 template <bool AnyHit>
 __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                           V3 o, V3 d, float mint, float maxt, Hit &h) {
+    if (cfg.brute) {
+        // Every lane sweeps every packet: wave-uniform LDS addresses (broadcast reads, no bank
+        // conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
+        const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+        h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
+        bool any = false;
+        for (uint32_t i = 0; i < sc.tri_count; ++i) {
+            const TriPacket &k = pk[i];
+            float t, u, v;
+            bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
+            if (AnyHit) {
+                any = any || hit;
+            } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
+                h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim;
+            }
+        }
+        if (AnyHit) { if (any) { h.t = 0.f; h.tri = 0; } return any; }
+        return h.tri != MIW_MISS;
+    }
     RayPrep r = ray_prepare(o, d, mint, maxt);
     const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
     const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
@@ -152,22 +192,34 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-__global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt) {
+template <bool UseLog>
+__global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+                                                       uint32_t count_active) {
     uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
     if (lane < P.n_lanes) {
-        FilmAdd add; add.accum = accum;
-        // a lane that had a shadow ray queued must clear it if it queues none now
-        bool alive = lane_shade(P, sc, Q, lane, &local, add);
-        local.active_lanes = alive ? 1 : 0;
+        bool alive;
+        if (UseLog) {
+            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.n_lanes = P.n_lanes;
+            alive = lane_shade(P, sc, Q, lane, &local, sink);
+        } else {
+            FilmAdd add; add.accum = accum;
+            SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
+            alive = lane_shade(P, sc, Q, lane, &local, sink);
+        }
+        local.active_lanes = (alive && count_active) ? 1 : 0;
     }
+    // Statistics: wave-level reduce, then one atomic per wave into one of
+    // MIW_CNT_SHARDS counter records (same-address device atomics serialise at
+    // ~12 ns each — 131k waves on one word would cost more than the shading).
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples),
                        c = wave_sum(local.shadow_rays), d = wave_sum(local.active_lanes);
     if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(&cnt->segments, a);
-        if (b) atomicAdd(&cnt->samples, b);
-        if (c) atomicAdd(&cnt->shadow_rays, c);
-        if (d) atomicAdd(&cnt->active_lanes, d);
+        Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
+        if (a) atomicAdd(&shard->segments, a);
+        if (b) atomicAdd(&shard->samples, b);
+        if (c) atomicAdd(&shard->shadow_rays, c);
+        if (d) atomicAdd(&shard->active_lanes, d);
     }
 }
 
@@ -175,6 +227,24 @@ __global__ void k_film_resolve(const double *accum, float *out32, double *out64,
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (out64) out64[i] = accum[i]; else out32[i] = (float) accum[i];
+}
+
+// Ordered film assembly (miw/film_gather.h): one work item per film texel. The
+// 8x8 texel tile of a wavefront keeps its source lanes (Morton-contiguous log
+// columns) hot in L1/L2.
+__global__ __launch_bounds__(MIW_BLOCK) void k_film_gather(FilmRec F, GatherArgs G, float *out32, double *out64) {
+    // 256 threads = a 16x16 texel tile, Morton order inside the tile
+    uint32_t tiles_x = ((uint32_t) F.crop_w + 15u) / 16u;
+    uint32_t tile = blockIdx.x, mx, my;
+    morton_decode2(threadIdx.x, mx, my);
+    int fx = (int) ((tile % tiles_x) * 16u + mx), fy = (int) ((tile / tiles_x) * 16u + my);
+    if (fx >= F.crop_w || fy >= F.crop_h) return;
+    float v[MIW_FILM_CHANNELS];
+    film_gather_texel(F, G, fx, fy, v);
+    size_t o = ((size_t) fy * F.crop_w + fx) * MIW_FILM_CHANNELS;
+    for (int k = 0; k < MIW_FILM_CHANNELS; ++k) {
+        if (out64) out64[o + k] = (double) v[k]; else out32[o + k] = v[k];
+    }
 }
 
 struct SoaRays { const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt; };
@@ -289,8 +359,9 @@ struct mi_ctx {
     // render state
     DevBuf<F4> q_tp, q_res, q_ray_o, q_ray_d, q_hit, q_sh_d, q_sh_c;
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
-    DevBuf<double> d_accum; DevBuf<float> d_film32;
-    DevBuf<uint32_t> d_block_ids, d_tile_list;
+    DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
+    DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;
+    DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile;
     DevBuf<Counters> d_cnt;
     Counters *h_cnt = nullptr;          // pinned
 
@@ -329,7 +400,7 @@ mi_status mi_create(int32_t device, mi_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) { g_global_error = "hipSetDevice failed"; return MI_ERR_DEVICE; }
     mi_ctx *c = new mi_ctx();
     c->device = device;
-    if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters)) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
+    if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters) * MIW_CNT_SHARDS) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
     *out = c;
     return MI_OK;
 }
@@ -342,7 +413,8 @@ void mi_destroy(mi_ctx *c) {
     c->d_emitters.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
-    c->d_accum.release(); c->d_film32.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    c->d_accum.release(); c->d_out.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
@@ -468,6 +540,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (!c) return MI_ERR_INVALID;
     if (!c->have_scene) return fail(c, MI_ERR_STATE, "mi_bvh_build: no scene uploaded");
+    const bool force_tree = (quality & MI_BVH_FORCE_TREE) != 0;
+    quality &= ~MI_BVH_FORCE_TREE;
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
     // quality 0 (device LBVH) falls back to the host SAH builder this round
@@ -498,9 +572,16 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
     size_t all = r.nodes.size() * sizeof(BvhNode) + r.tris.size() * sizeof(Tri);
-    if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
-    else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
-    c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
+    c->lds_cfg.brute = 0;
+    if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS) {
+        // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
+        c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
+        c->lds_bytes = v.tri_count * sizeof(TriPacket);
+    } else {
+        if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
+        else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
+        c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
+    }
 
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = r.depth;
@@ -594,9 +675,31 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     HIP_TRY(c, c->q_ray_d.resize(nl)); HIP_TRY(c, c->q_hit.resize(nl)); HIP_TRY(c, c->q_sh_d.resize(nl));
     HIP_TRY(c, c->q_sh_c.resize(nl)); HIP_TRY(c, c->q_st.resize(nl)); HIP_TRY(c, c->q_pos.resize(nl));
     HIP_TRY(c, c->q_pixel.resize(nl)); HIP_TRY(c, c->q_sh_vis.resize(nl));
-    HIP_TRY(c, c->d_accum.resize(film_n)); HIP_TRY(c, c->d_cnt.resize(1));
-    HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, sizeof(Counters), s));
+    HIP_TRY(c, c->d_cnt.resize(MIW_CNT_SHARDS));
+    HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, sizeof(Counters) * MIW_CNT_SHARDS, s));
+
+    // film mode: sample log + ordered gather if the log fits, else float64 atomics
+    int film_mode = cfg->film_mode;
+    if (film_mode < 0 || film_mode > 2) return fail(c, MI_ERR_INVALID, "render: film_mode must be 0, 1 or 2");
+    const size_t log_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
+    if (film_mode != 2) {
+        size_t need = log_entries * (sizeof(F2) + sizeof(F4));
+        size_t have = c->q_log_pos.n * sizeof(F2) + c->q_log_val.n * sizeof(F4), free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        bool fits = need <= have || need <= (size_t) ((double) (free_b + have) * 0.8);
+        if (!fits) {
+            if (film_mode == 1) return fail(c, MI_ERR_INVALID, "render: sample log needs %zu MiB, only %zu MiB free", need >> 20, free_b >> 20);
+            film_mode = 2;
+        } else film_mode = 1;
+    }
+    if (film_mode == 1) {
+        if (c->q_log_pos.n < log_entries) { c->q_log_pos.release(); c->q_log_val.release(); }
+        HIP_TRY(c, c->q_log_pos.resize(log_entries)); HIP_TRY(c, c->q_log_val.resize(log_entries));
+    } else {
+        HIP_TRY(c, c->d_accum.resize(film_n));
+        HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
+    }
+    c->counters.film_mode = (uint32_t) film_mode;
     HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
     HIP_TRY(c, hipMemcpyAsync(c->d_block_ids.p, cfg->block_ids, cfg->block_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (cfg->tile_list && n_tiles) {
@@ -608,6 +711,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.tp = c->q_tp.p; Q.res = c->q_res.p; Q.st = c->q_st.p; Q.pos = c->q_pos.p; Q.pixel = c->q_pixel.p;
     Q.ray_o = c->q_ray_o.p; Q.ray_d = c->q_ray_d.p; Q.hit = c->q_hit.p;
     Q.sh_d = c->q_sh_d.p; Q.sh_c = c->q_sh_c.p; Q.sh_vis = c->q_sh_vis.p;
+    Q.log_pos = film_mode == 1 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 ? c->q_log_val.p : nullptr;
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -659,6 +763,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 
         const int check_every = 16;
         bool first = true;
+        unsigned long long active_prev = 0;
         for (;;) {
             for (int it = 0; it < check_every; ++it) {
                 if (!first) {
@@ -667,44 +772,63 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 }
                 MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, n_lanes, c->lds_cfg));
                 K.n_trace_closest++;
-                if (it == check_every - 1)
-                    HIP_TRY(c, hipMemsetAsync(&c->d_cnt.p->active_lanes, 0, sizeof(unsigned long long), s));
-                MIW_TIMED(2, hipLaunchKernelGGL(k_shade, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p));
+                const uint32_t count_active = it == check_every - 1 ? 1u : 0u;
+                if (film_mode == 1)
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, count_active));
+                else
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, count_active));
                 K.n_shade++; K.iterations++;
                 first = false;
             }
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, sizeof(Counters) * MIW_CNT_SHARDS, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             if (cfg->profile) drain_stamps();
-            if (c->h_cnt->active_lanes == 0) break;
+            Counters sum; sum.segments = sum.samples = sum.shadow_rays = sum.active_lanes = 0;
+            for (int i = 0; i < MIW_CNT_SHARDS; ++i) {
+                sum.segments += c->h_cnt[i].segments; sum.samples += c->h_cnt[i].samples;
+                sum.shadow_rays += c->h_cnt[i].shadow_rays; sum.active_lanes += c->h_cnt[i].active_lanes;
+            }
+            K.samples = sum.samples; K.segments = sum.segments; K.shadow_rays = sum.shadow_rays;
+            // active_lanes accumulates over the counting launches: the last one's share is the delta
+            unsigned long long active_now = sum.active_lanes - active_prev;
+            active_prev = sum.active_lanes;
+            if (active_now == 0) break;
             if (c->cancel.load()) { result = MI_ERR_CANCELLED; break; }
             if (cfg->timeout_s > 0.f &&
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > cfg->timeout_s) {
                 result = MI_ERR_CANCELLED; break;
             }
         }
-        K.samples = c->h_cnt->samples; K.segments = c->h_cnt->segments; K.shadow_rays = c->h_cnt->shadow_rays;
     }
 
-    // develop: accumulators -> caller's film
+    // film assembly -> caller's buffer (device pointer, or staged through d_out for a host pointer)
     {
-        dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
+        const size_t elem = cfg->film_f64 ? sizeof(double) : sizeof(float);
         void *dst = film;
-        bool staged = !cfg->film_on_device;
-        if (staged) {
-            if (cfg->film_f64) dst = nullptr; else { HIP_TRY(c, c->d_film32.resize(film_n)); dst = c->d_film32.p; }
-        }
-        if (cfg->film_f64) {
-            if (staged) {
-                HIP_TRY(c, hipMemcpyAsync(film, c->d_accum.p, film_n * sizeof(double), hipMemcpyDeviceToHost, s));
-            } else {
-                MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, (float *) nullptr, (double *) dst, film_n));
-            }
+        const bool staged = !cfg->film_on_device;
+        if (staged) { HIP_TRY(c, c->d_out.resize(film_n * elem)); dst = c->d_out.p; }
+        float *dst32 = cfg->film_f64 ? nullptr : (float *) dst;
+        double *dst64 = cfg->film_f64 ? (double *) dst : nullptr;
+        if (film_mode == 1) {
+            // block -> tile map of this shard
+            std::vector<int32_t> block_tile(cfg->block_count, -1);
+            for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
+            HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
+            HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            GatherArgs G;
+            G.log_pos = c->q_log_pos.p; G.log_val = c->q_log_val.p; G.st = c->q_st.p; G.n_lanes = n_lanes;
+            G.block_ids = c->d_block_ids.p; G.block_tile = c->d_block_tile.p;
+            G.blocks_x = blocks_x; G.blocks_y = blocks_y; G.bs2_log2 = bs2_log2;
+            uint32_t tiles = (((uint32_t) cfg->crop_w + 15u) / 16u) * (((uint32_t) cfg->crop_h + 15u) / 16u);
+            MIW_TIMED(4, hipLaunchKernelGGL(k_film_gather, dim3(tiles), dim3(MIW_BLOCK), 0, s, P.film, G, dst32, dst64));
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(s));            // block_tile (host vector) must outlive the copy
         } else {
-            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, (float *) dst, (double *) nullptr, film_n));
-            if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_film32.p, film_n * sizeof(float), hipMemcpyDeviceToHost, s));
+            dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
+            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, dst32, dst64, film_n));
         }
+        if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_out.p, film_n * elem, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(s));
         if (cfg->profile) drain_stamps();

@@ -23,7 +23,7 @@
 // stored references are statistical and its data submodule is absent; the real
 // binary cannot be built here: ext/enoki, ext/tbb ... are empty) — see DESIGN.md.
 //
-// Denormals: FTZ/DAZ on, like scoped_flush_denormals (integrator.cpp:117).
+// Denormals: preserved (plain IEEE) on both sides — see FtzScope below.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -51,9 +51,16 @@ using namespace miw;
 
 namespace {
 
-struct FtzScope {                       // integrator.cpp:117
+// Float environment of every oracle thread: IEEE-754 round-to-nearest with
+// denormals PRESERVED (FTZ/DAZ forced off, whatever the caller's MXCSR says).
+// The reference flushes denormals on the CPU (scoped_flush_denormals,
+// integrator.cpp:117) as a speed measure; x86 FTZ/DAZ and gfx950's flush mode do
+// not agree on denormal pass-through (min/max/select), so both sides of this
+// code base run plain IEEE instead — results differ from a flushing build only
+// for |x| < 1.2e-38.
+struct FtzScope {
     unsigned csr;
-    FtzScope() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON); }
+    FtzScope() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_OFF); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_OFF); }
     ~FtzScope() { _mm_setcsr(csr); }
 };
 

@@ -14,6 +14,7 @@
 
 #include "../include/miwave.h"
 #include "../mitsuba2_amd/csrc/miw/path.h"
+#include "../mitsuba2_amd/csrc/miw/film_gather.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 
@@ -94,7 +95,8 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
     return true;
 }
-struct Ftz { unsigned csr; Ftz() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON); } ~Ftz() { _mm_setcsr(csr); } };
+// plain IEEE float environment (denormals preserved), see miw_oracle.cpp FtzScope
+struct Ftz { unsigned csr; Ftz() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_OFF); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_OFF); } ~Ftz() { _mm_setcsr(csr); } };
 }
 
 extern "C" {
@@ -121,8 +123,11 @@ int emu_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_so
     return 0;
 }
 
-// the wavefront render loop of mi_render, stage by stage, on the CPU. film64: crop_w*crop_h*5 doubles.
-int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *film64, uint64_t *stats4 /* samples, segments, shadow, iterations */) {
+// the wavefront render loop of mi_render, stage by stage, on the CPU.
+// film64: crop_w*crop_h*5 doubles (film_mode 2: immediate splat, exact sum);
+// film32 (may be NULL): crop_w*crop_h*5 floats (film_mode 1: sample log + ordered gather).
+int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *film64, float *film32,
+               uint64_t *stats4 /* samples, segments, shadow, iterations */) {
     EmuScene sc; if (!emu_build(scene, sc, 4)) return -1;
     Ftz ftz;
     RenderParams P; std::memset(&P, 0, sizeof P);
@@ -145,6 +150,9 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     std::vector<U4> st(n_lanes); std::vector<F2> pos(n_lanes); std::vector<uint32_t> pixel(n_lanes), sh_vis(n_lanes);
     LaneQueues Q; Q.tp = tp.data(); Q.res = res.data(); Q.st = st.data(); Q.pos = pos.data(); Q.pixel = pixel.data();
     Q.ray_o = ray_o.data(); Q.ray_d = ray_d.data(); Q.hit = hit.data(); Q.sh_d = sh_d.data(); Q.sh_c = sh_c.data(); Q.sh_vis = sh_vis.data();
+    std::vector<F2> log_pos; std::vector<F4> log_val;
+    if (film32) { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
+    Q.log_pos = log_pos.data(); Q.log_val = log_val.data();
     size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
     std::memset(film64, 0, film_n * sizeof(double));
 
@@ -180,10 +188,30 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri); hit[lane] = r;
         }
         uint64_t active = 0;
-        for (uint32_t lane = 0; lane < n_lanes; ++lane)        // k_shade
-            active += lane_shade(P, sc.view, Q, lane, &cnt, add) ? 1 : 0;
+        for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
+            SplatSink<decltype(add)> splat{ &P.film, add };
+            LogSink log{ Q.log_pos, Q.log_val, lane, n_lanes };
+            bool do_log = film32 != nullptr;
+            auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
+                splat(pixel, sample_idx, pos, aovs);
+                if (do_log) log(pixel, sample_idx, pos, aovs);
+            };
+            active += lane_shade(P, sc.view, Q, lane, &cnt, sink) ? 1 : 0;
+        }
         ++iterations;
         if (active == 0) break;
+    }
+    if (film32) {                                              // k_film_gather
+        std::vector<int32_t> block_tile(cfg->block_count, -1);
+        for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
+        GatherArgs G; G.log_pos = log_pos.data(); G.log_val = log_val.data(); G.st = st.data(); G.n_lanes = n_lanes;
+        G.block_ids = cfg->block_ids; G.block_tile = block_tile.data();
+        G.blocks_x = blocks_x; G.blocks_y = (cfg->crop_h + bs - 1) / bs;
+        uint32_t l2 = 0; while ((1u << l2) < bs2) ++l2;
+        G.bs2_log2 = l2;
+        for (int fy = 0; fy < cfg->crop_h; ++fy)
+            for (int fx = 0; fx < cfg->crop_w; ++fx)
+                film_gather_texel(P.film, G, fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5);
     }
     if (stats4) { stats4[0] = cnt.samples; stats4[1] = cnt.segments; stats4[2] = cnt.shadow_rays; stats4[3] = iterations; }
     return 0;
