@@ -145,10 +145,19 @@ MIW_HD float mf_pdf(const Microfacet &d, V3 wi, V3 m) {
 MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &pdf_out) {
     if (!d.sample_visible) {
         float sin_phi, cos_phi, cos_theta, cos_theta_2, alpha_2, pdf;
-        // isotropic azimuth (:240-243); the anisotropic branch needs tan() and is
-        // rejected at scene upload for sample_visible=false.
-        sincos_((2.f * MIW_PI) * sample.y, sin_phi, cos_phi);
-        alpha_2 = d.alpha_u * d.alpha_u;
+        if (d.alpha_u == d.alpha_v) {                     // :240-243
+            sincos_((2.f * MIW_PI) * sample.y, sin_phi, cos_phi);
+            alpha_2 = d.alpha_u * d.alpha_u;
+        } else {                                          // :244-255 (tan = sin/cos of the shared sincos)
+            float s, c;
+            sincos_((2.f * MIW_PI) * sample.y, s, c);
+            float ratio = d.alpha_v / d.alpha_u,
+                  tmp   = ratio * (s / c);
+            cos_phi = rsqrt(fmadd(tmp, tmp, 1.f));
+            cos_phi = mulsign(cos_phi, abs_(sample.y - .5f) - .25f);
+            sin_phi = cos_phi * tmp;
+            alpha_2 = rcp(sqr(cos_phi / d.alpha_u) + sqr(sin_phi / d.alpha_v));
+        }
         float tan_theta_m_2 = alpha_2 * sample.x / (1.f - sample.x);
         cos_theta = rsqrt(1.f + tan_theta_m_2);
         cos_theta_2 = sqr(cos_theta);

@@ -481,8 +481,6 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         if (b.type == MI_BSDF_ROUGHCONDUCTOR) {
             if (!(b.flags & MI_BSDF_FLAG_GGX))
                 return fail(c, MI_ERR_INVALID, "bsdf %u: roughconductor distribution 'beckmann' is not implemented on the device; use 'ggx'", i);
-            if (!(b.flags & MI_BSDF_FLAG_SAMPLE_VISIBLE) && b.params[0] != b.params[1])
-                return fail(c, MI_ERR_INVALID, "bsdf %u: anisotropic roughconductor needs sample_visible=true", i);
         }
         BsdfRec r; r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
         c->bsdfs[i] = r;

@@ -1,0 +1,470 @@
+"""Pinning the CPU oracle (and with it the shared leaf arithmetic) against every
+known-answer vector the reference's own tests hold for the path-integrator hot path
+(SURVEY.md §8c). Each test cites the reference test it restates. CPU only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from mitsuba2_amd._capi import c_float_p, c_u32_p, c_i32_p, c_double_p
+
+
+def fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+# ---- src/libcore/tests/test_random.py:6-28 -----------------------------------------------------
+def test_tea_float32_exact(oracle):
+    L = oracle.L
+    kat = {(1, 1): 0.5424730777740479, (1, 2): 0.5079904794692993, (1, 3): 0.4171961545944214,
+           (1, 4): 0.008385419845581055, (1, 5): 0.8085528612136841, (2, 1): 0.6939879655838013,
+           (3, 1): 0.6978365182876587, (4, 1): 0.4897364377975464}
+    for (a, b), v in kat.items():
+        assert L.orc_tea_float32(a, b, 4) == np.float32(v)
+
+
+def test_tea_float64_exact(oracle):
+    L = oracle.L
+    kat = {(1, 1): 0.5424730799533735, (1, 2): 0.5079905082233922, (1, 3): 0.4171962610608142,
+           (1, 4): 0.008385529523330604, (1, 5): 0.80855288317879, (2, 1): 0.6939880404156831,
+           (3, 1): 0.6978365636630994, (4, 1): 0.48973647949223253}
+    for (a, b), v in kat.items():
+        assert L.orc_tea_float64(a, b, 4) == v
+
+
+# ---- PCG32: enoki::PCG32 is not vendored; pinned by O'Neill's public pcg32-demo vector ------------
+def test_pcg32_demo_vector(oracle):
+    out = np.zeros(6, np.uint32)
+    oracle.L.orc_pcg32_u32(42, 54, out.ctypes.data_as(c_u32_p), 6)
+    assert [hex(x) for x in out] == ["0xa15c02b7", "0x7b47f409", "0xba1d3330", "0x83d2f293", "0xbfa4784b", "0xcbed606e"]
+
+
+def test_pcg32_float_is_23_bit_uniform(oracle):
+    u = np.zeros(4096, np.uint32); f = np.zeros(4096, np.float32)
+    oracle.L.orc_pcg32_u32(7, 11, u.ctypes.data_as(c_u32_p), 4096)
+    oracle.L.orc_pcg32_f32(7, 11, fp(f), 4096)
+    expect = ((u >> 9) | 0x3f800000).view(np.float32) - np.float32(1.0)
+    assert np.array_equal(f, expect) and f.min() >= 0 and f.max() < 1
+
+
+# src/samplers/tests/test_independent.py:28-33 — the sampler is the default-seeded PCG32 stream
+def test_independent_sampler_is_default_pcg32(native, oracle):
+    s = native.Sampler()
+    ref = np.zeros(64, np.float32)
+    oracle.L.orc_pcg32_f32(0x853c49e6748fea9b, 0xda3e39cb94b95bdb, fp(ref), 64)
+    assert [s.next_1d() for _ in range(64)] == list(ref)
+    # seed(k) == PCG32(initstate = base_seed + k, default stream)   (sampler.cpp:83-96)
+    s2 = native.Sampler(seed=5); s2.seed(1000)
+    oracle.L.orc_pcg32_f32(1005, 0xda3e39cb94b95bdb, fp(ref), 64)
+    assert [s2.next_1d() for _ in range(64)] == list(ref)
+
+
+def test_morton_decode(oracle):
+    xy = np.zeros(2, np.uint32)
+    seen = set()
+    for i in range(1024):
+        oracle.L.orc_morton_decode(i, xy.ctypes.data_as(c_u32_p))
+        x, y = int(xy[0]), int(xy[1])
+        code = 0
+        for b in range(5):
+            code |= ((x >> b) & 1) << (2 * b) | ((y >> b) & 1) << (2 * b + 1)
+        assert code == i and x < 32 and y < 32
+        seen.add((x, y))
+    assert len(seen) == 1024
+    oracle.L.orc_morton_decode(0b1110, xy.ctypes.data_as(c_u32_p))
+    assert tuple(xy) == (2, 3)
+
+
+# ---- src/librender/tests/test_fresnel.py:7-40 --------------------------------------------------------
+def _fresnel(oracle, c, eta):
+    out = np.zeros(4, np.float32)
+    oracle.L.orc_fresnel(C.c_float(c), C.c_float(eta), fp(out))
+    return out
+
+
+def test_fresnel_spot_checks(oracle):
+    ct_crit = -math.sqrt(1 - 1 / 1.5 ** 2)
+    ok = lambda a, b: np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert ok(_fresnel(oracle, 1, 1.5), (0.04, -1, 1.5, 1 / 1.5))
+    assert ok(_fresnel(oracle, -1, 1.5), (0.04, 1, 1 / 1.5, 1.5))
+    assert ok(_fresnel(oracle, 1, 1 / 1.5), (0.04, -1, 1 / 1.5, 1.5))
+    assert ok(_fresnel(oracle, -1, 1 / 1.5), (0.04, 1, 1.5, 1 / 1.5))
+    assert ok(_fresnel(oracle, 0, 1.5), (1, ct_crit, 1.5, 1 / 1.5))
+    assert ok(_fresnel(oracle, 0, 1 / 1.5), (1, 0, 1 / 1.5, 1.5))
+    c45 = math.cos(math.radians(45))
+    F, ct, _, scale = _fresnel(oracle, c45, 1.5)
+    assert ok(ct, -math.cos(math.radians(28.1255057020557)))
+    assert ok(F, 0.5 * (0.09201336304552442 ** 2 + 0.3033370452904235 ** 2))
+    assert ok((scale * math.sqrt(1 - c45 ** 2)) ** 2 + ct ** 2, 1)
+    F, ct, _, _ = _fresnel(oracle, c45, 1 / 1.5)
+    assert ok(F, 1) and ok(ct, 0)
+    c10 = math.cos(math.radians(10))
+    F, ct, _, scale = _fresnel(oracle, c10, 1 / 1.5)
+    assert ok(ct, -math.cos(math.radians(15.098086605159006)))
+    assert ok(F, 0.5 * (0.19046797197779405 ** 2 + 0.20949431963852014 ** 2))
+
+
+def test_fresnel_index_matched_and_conductor(oracle):
+    # test_fresnel.py:53-60: eta = 1 -> F = 0, cos_theta_t = -cos_theta_i
+    for c in np.linspace(-1, 1, 20):
+        F, ct, _, _ = _fresnel(oracle, c, 1.0)
+        assert F == 0 and abs(ct + c) < 5e-7
+    # test_fresnel.py:63-76: conductor == dielectric for a real IOR
+    oracle.L.orc_fresnel_conductor.argtypes = [C.c_float] * 3
+    for eta in (1.5, 1 / 1.5):
+        for c in np.cos(np.linspace(0, math.pi / 2, 20)):
+            r = _fresnel(oracle, c, eta)[0]
+            r2 = oracle.L.orc_fresnel_conductor(c, eta, 0.0)
+            assert abs(r - r2) < 2e-6
+
+
+# ---- src/bsdfs/tests/test_dielectric.py:35-174 (TransportMode::Radiance rows) ---------------------------
+def _example_dielectric(native):
+    return native.BSDF("dielectric", specular_reflectance=0.3, specular_transmittance=0.6, int_ior=1.5, ext_ior=1.0)
+
+
+def test_dielectric_sample(native):
+    b = _example_dielectric(native)
+    DeltaReflection, DeltaTransmission = 0x20, 0x40
+    r = b.sample([0, 0, 1], 0.0, [0, 0])
+    assert np.allclose(r["weight"], [0.3] * 3) and np.isclose(r["pdf"], 0.04) and r["eta"] == 1.0
+    assert np.allclose(r["wo"], [0, 0, 1]) and r["sampled_type"] == DeltaReflection
+    r = b.sample([0, 0, 1], 0.05, [0, 0])
+    assert np.allclose(r["weight"], [0.6 / 1.5 ** 2] * 3) and np.isclose(r["pdf"], 1 - 0.04) and np.isclose(r["eta"], 1.5)
+    assert np.allclose(r["wo"], [0, 0, -1]) and r["sampled_type"] == DeltaTransmission
+    # test03_sample_reverse
+    r = b.sample([0, 0, -1], 0.0, [0, 0])
+    assert np.allclose(r["weight"], [0.3] * 3) and np.isclose(r["pdf"], 0.04) and np.allclose(r["wo"], [0, 0, -1])
+    r = b.sample([0, 0, -1], 0.05, [0, 0])
+    assert np.allclose(r["weight"], [0.6 * 1.5 ** 2] * 3) and np.isclose(r["eta"], 1 / 1.5) and np.allclose(r["wo"], [0, 0, 1])
+    e, p = b.eval_pdf([0, 0, 1], [0, 0, 1])
+    assert np.all(e == 0) and p == 0                      # dielectric.cpp:312-320
+
+
+def test_dielectric_spot_check_80_degrees(native):
+    b = _example_dielectric(native)
+    a = math.radians(80)
+    wi = [math.sin(a), 0, math.cos(a)]
+    r = b.sample(wi, 0.0, [0, 0])
+    assert np.isclose(r["pdf"], 0.387704354691473, rtol=1e-5) and np.allclose(r["wo"], [-math.sin(a), 0, math.cos(a)], atol=1e-6)
+    r = b.sample(wi, 1.0, [0, 0])
+    a2 = math.radians(41.03641052520335)
+    assert np.isclose(r["pdf"], 1 - 0.387704354691473, rtol=1e-5)
+    assert np.allclose(r["wo"], [-math.sin(a2), 0, -math.cos(a2)], atol=1e-6)
+    r2 = b.sample(r["wo"], 1.0, [0, 0])
+    assert np.isclose(r2["pdf"], 1 - 0.387704354691473, rtol=1e-5) and np.allclose(r2["wo"], wi, atol=1e-6)
+
+
+def test_dielectric_rejects_negative_ior(native):
+    with pytest.raises(RuntimeError):
+        native.BSDF("dielectric", int_ior=-0.5)
+
+
+# ---- src/bsdfs/tests/test_diffuse.py:16-38 ------------------------------------------------------------------
+def test_diffuse_eval_pdf(native):
+    b = native.BSDF("diffuse")
+    assert b.flags() == 0x2                               # DiffuseReflection
+    for i in range(20):
+        th = i / 19.0 * (math.pi / 2)
+        wo = [math.sin(th), 0, math.cos(th)]
+        e, p = b.eval_pdf([0, 0, 1], wo)
+        assert np.isclose(p, max(wo[2], 0) / math.pi, atol=1e-7) and np.isclose(e[0], 0.5 * max(wo[2], 0) / math.pi, atol=1e-7)
+    e, p = b.eval_pdf([0, 0, -1], [0, 0, 1])
+    assert np.all(e == 0) and p == 0                      # FrontSide only
+
+
+def test_diffuse_sample_is_cosine_weighted(native):
+    b = native.BSDF("diffuse", reflectance=(0.2, 0.4, 0.6))
+    rng = np.random.default_rng(0)
+    zs = []
+    for _ in range(2000):
+        r = b.sample([0.3, 0.1, 0.9], rng.random(), rng.random(2))
+        assert np.allclose(r["weight"], [0.2, 0.4, 0.6]) and np.isclose(r["pdf"], r["wo"][2] / math.pi, rtol=1e-6)
+        assert abs(np.linalg.norm(r["wo"]) - 1) < 1e-5
+        zs.append(r["wo"][2])
+    assert abs(np.mean(zs) - 2 / 3) < 0.02                # E[cos] = 2/3 for cosine-weighted
+
+
+# ---- src/librender/tests/test_microfacet.py:209-313 (GGX rows) ---------------------------------------------------
+def _mf(oracle, op, au, av, sv, wi, x):
+    wi = np.asarray(wi, np.float32); x = np.asarray(x, np.float32); out = np.zeros(4, np.float32)
+    oracle.L.orc_microfacet(op, 1, C.c_float(au), C.c_float(av), int(sv), fp(wi), fp(x), fp(out))
+    return out
+
+
+def test_ggx_smith_g1(oracle):
+    steps = 20
+    theta = np.linspace(math.pi / 3, math.pi / 2, steps)
+    v = np.stack([np.zeros(steps) * np.sin(theta), np.sin(theta), np.cos(theta)], 1)      # phi = pi/2
+    v[:, 0] = np.cos(math.pi / 2) * np.sin(theta)
+    ref_aniso = [9.4031686e-01, 9.3310797e-01, 9.2485082e-01, 9.1534841e-01, 9.0435863e-01, 8.9158219e-01, 8.7664890e-01,
+                 8.5909742e-01, 8.3835226e-01, 8.1369340e-01, 7.8421932e-01, 7.4880326e-01, 7.0604056e-01, 6.5419233e-01,
+                 5.9112519e-01, 5.1425743e-01, 4.2051861e-01, 3.0633566e-01, 1.6765384e-01, 1.0861372e-06]
+    ref_iso = [9.9261039e-01, 9.9160647e-01, 9.9042398e-01, 9.8901933e-01, 9.8733366e-01, 9.8528832e-01, 9.8277503e-01,
+               9.7964239e-01, 9.7567332e-01, 9.7054905e-01, 9.6378750e-01, 9.5463598e-01, 9.4187391e-01, 9.2344058e-01,
+               8.9569420e-01, 8.5189372e-01, 7.7902949e-01, 6.5144652e-01, 4.1989169e-01, 3.2584082e-06]
+    got_a = [_mf(oracle, 2, 0.1, 0.3, False, v[i], [0, 0, 1])[0] for i in range(steps)]
+    got_i = [_mf(oracle, 2, 0.1, 0.1, False, v[i], [0, 0, 1])[0] for i in range(steps)]
+    assert np.allclose(got_a, ref_aniso, rtol=1e-5, atol=1e-5) and np.allclose(got_i, ref_iso, rtol=1e-5, atol=1e-5)
+    theta = math.pi / 2 * 0.98
+    phi = np.linspace(0, 2 * math.pi, steps)
+    ref = [0.46130955, 0.36801264, 0.26822716, 0.21645154, 0.19341162, 0.18922243, 0.20219423, 0.23769052, 0.31108665,
+           0.43013984, 0.43013984, 0.31108665, 0.23769052, 0.20219423, 0.18922243, 0.19341162, 0.21645154, 0.26822716,
+           0.36801264, 0.46130955]
+    got = [_mf(oracle, 2, 0.1, 0.3, False, [math.cos(p) * math.sin(theta), math.sin(p) * math.sin(theta), math.cos(theta)],
+               [0, 0, 1])[0] for p in phi]
+    assert np.allclose(got, ref, rtol=2e-5, atol=1e-5)
+    got = [_mf(oracle, 2, 0.1, 0.1, False, [math.cos(p) * math.sin(theta), math.sin(p) * math.sin(theta), math.cos(theta)],
+               [0, 0, 1])[0] for p in phi]
+    assert np.allclose(got, 0.46130955, rtol=2e-5)
+
+
+def test_ggx_sample_table(oracle):
+    """test05_sample_ggx: anisotropic GGX (0.1, 0.3), sample_visible = false, vs Mitsuba 0.6 data."""
+    u = np.linspace(0, 1, 6)
+    u1, u2 = np.meshgrid(u, u)
+    ref_m = np.array([[0, 0, 1], [4.99384739e-02, 1.30972797e-08, 9.98752296e-01], [8.13788623e-02, 2.13430980e-08, 9.96683240e-01],
+                      [1.21566132e-01, 3.18829443e-08, 9.92583334e-01], [1.96116075e-01, 5.14350340e-08, 9.80580688e-01],
+                      [1, 2.62268316e-07, 0], [0, 0, 1], [1.52942007e-02, 1.41212299e-01, 9.89861190e-01],
+                      [2.45656986e-02, 2.26816610e-01, 9.73627627e-01], [3.57053429e-02, 3.29669625e-01, 9.43420947e-01],
+                      [5.36015145e-02, 4.94906068e-01, 8.67291689e-01], [1.07676744e-01, 9.94185984e-01, 0]])
+    ref_pdf = np.array([10.61032867, 6.81609201, 3.85797882, 1.73599267, 0.45013079, 0., 10.61032867, 7.00141668, 4.13859272,
+                        2.02177191, 0.65056872, 0.])
+    for k in range(12):
+        r = _mf(oracle, 3, 0.1, 0.3, False, [0, 0, 1], [u1.ravel()[k], u2.ravel()[k]])
+        if k % 6 == 5:
+            continue                                      # u1 = 1: cos_theta = 0, direction undefined up to rounding
+        assert np.allclose(r[:3], ref_m[k], atol=5e-4), k
+        assert np.isclose(r[3], ref_pdf[k], atol=1e-3), k
+
+
+def test_ggx_eval_normalisation_and_visible_sampling(oracle):
+    """D(m) cos integrates to 1; the visible-normal sampler's pdf matches D*G1*|wi.m|/cos (microfacet.h:300-303)."""
+    n = 200
+    th = (np.arange(n) + 0.5) / n * (math.pi / 2); ph = (np.arange(2 * n) + 0.5) / (2 * n) * 2 * math.pi
+    T, P = np.meshgrid(th, ph)
+    acc = 0.0
+    for t, p in zip(T.ravel()[::7], P.ravel()[::7]):
+        m = [math.sin(t) * math.cos(p), math.sin(t) * math.sin(p), math.cos(t)]
+        acc += _mf(oracle, 0, 0.5, 0.5, True, [0, 0, 1], m)[0] * math.cos(t) * math.sin(t)
+    acc *= (math.pi / 2 / n) * (2 * math.pi / (2 * n)) * 7
+    assert abs(acc - 1) < 0.02
+    rng = np.random.default_rng(1)
+    wi = np.array([0.6, 0.0, 0.8], np.float32)
+    for _ in range(200):
+        r = _mf(oracle, 3, 0.3, 0.3, True, wi, rng.random(2))
+        m = r[:3]
+        assert abs(np.linalg.norm(m) - 1) < 1e-5 and m[2] > 0
+        assert np.isclose(r[3], _mf(oracle, 1, 0.3, 0.3, True, wi, m)[0], rtol=1e-5)
+
+
+# ---- src/librender/tests/test_mesh.py:257-299 -------------------------------------------------------------------------
+def test_mesh_ray_intersect_triangle(oracle):
+    # rectangle.obj is absent (data submodule); these two triangles of the [-1,1]^2 quad are the
+    # unique ones consistent with the test's prim_uv values (0.35, 0.3) / (0.3, 0.35).
+    tris = [np.array([-1, 1, 0, 1, -1, 0, -1, -1, 0], np.float32), np.array([1, -1, 0, 1, 1, 0, -1, 1, 0], np.float32)]
+    out = np.zeros(4, np.float32)
+    oracle.L.orc_ray_triangle(fp(tris[0]), fp(np.array([-0.3, -0.3, -10, 0, 0, 1, 0, np.inf], np.float32)), fp(out))
+    assert out[0] == 1 and np.isclose(out[1], 10) and np.allclose(out[2:], [0.35, 0.3])
+    oracle.L.orc_ray_triangle(fp(tris[1]), fp(np.array([0.3, 0.3, -10, 0, 0, 1, 0, np.inf], np.float32)), fp(out))
+    assert out[0] == 1 and np.isclose(out[1], 10) and np.allclose(out[2:], [0.3, 0.35])
+    # no backface culling, interval test (mesh.h:210-217)
+    oracle.L.orc_ray_triangle(fp(tris[0]), fp(np.array([-0.3, -0.3, 10, 0, 0, -1, 0, np.inf], np.float32)), fp(out))
+    assert out[0] == 1
+    oracle.L.orc_ray_triangle(fp(tris[0]), fp(np.array([-0.3, -0.3, -10, 0, 0, 1, 0, 9.9], np.float32)), fp(out))
+    assert out[0] == 0
+    oracle.L.orc_ray_triangle(fp(tris[0]), fp(np.array([-0.3, -0.3, -10, 0, 0, 1, 10.1, np.inf], np.float32)), fp(out))
+    assert out[0] == 0
+    oracle.L.orc_ray_triangle(fp(tris[0]), fp(np.array([0.3, 0.3, -10, 0, 0, 1, 0, np.inf], np.float32)), fp(out))
+    assert out[0] == 0
+
+
+def test_surface_interaction_fields(native, oracle):
+    """interaction.h:571-596 + mesh.cpp:449-545: p from barycentrics, unit normals, orthonormal frame, wi local."""
+    from mitsuba2_amd import api
+    v = np.array([[-1, 1, 0], [1, -1, 0], [-1, -1, 0]], np.float32)
+    scene = api.Scene([api.Mesh("t", v, [[0, 1, 2]])]).build(-1)
+    ok, si = oracle.ray_intersect_full(scene.desc(), [-0.3, -0.3, -10, 0, 0, 1, 0, np.inf])
+    assert ok == 1 and np.isclose(si[0], 10) and np.allclose(si[1:4], [-0.3, -0.3, 0], atol=1e-6)
+    n, sh_n, s, t, wi = si[4:7], si[7:10], si[10:13], si[13:16], si[16:19]
+    assert np.allclose(np.abs(n), [0, 0, 1]) and np.allclose(n, sh_n)
+    assert abs(np.dot(s, t)) < 1e-6 and abs(np.dot(s, n)) < 1e-6 and np.allclose(np.cross(sh_n, s), t, atol=1e-6)
+    assert np.isclose(wi[2], np.dot([0, 0, -1], n)) and np.allclose(si[19:21], [0.35, 0.3])
+    ok, si = oracle.ray_intersect_full(scene.desc(), [5, 5, -10, 0, 0, 1, 0, np.inf])
+    assert ok == 0 and np.isinf(si[0]) and np.allclose(si[16:19], [0, 0, -1])     # scene_native.inl:34-38
+
+
+# ---- src/librender/tests/test_kdtrees.py:26-59 (stairs) on the CPU ----------------------------------------------------------
+def test_stairs_bvh_equals_brute_force_equals_formula(native, oracle):
+    from mitsuba2_amd import scenes, api
+    n_steps = 20
+    v, f = scenes.stairs(n_steps)
+    scene = api.Scene([api.Mesh("stairs", v, f)]).build(-1)
+    n = 64; inv_n = 1.0 / (n - 1)
+    xs, ys = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    o = np.stack([xs.ravel() * inv_n, ys.ravel() * inv_n, np.full(xs.size, 2.0)], 1).astype(np.float32)
+    d = np.tile(np.array([0, 0, -1], np.float32), (len(o), 1))
+    naive = oracle.trace(scene.desc(), o, d, 0.0, 100.0)
+    for max_leaf in (1, 4, 16):
+        tree = oracle.emu_trace(scene.desc(), o, d, 0.0, 100.0, max_leaf=max_leaf)
+        assert np.array_equal(tree["prim"], naive["prim"]) and np.array_equal(tree["t"].view(np.uint32), naive["t"].view(np.uint32))
+        assert tree["bvh"][2] <= 62
+    expected = 2.0 - np.floor((ys.ravel() * inv_n) * n_steps) / n_steps
+    assert np.allclose(naive["t"], expected, atol=1e-6)
+    shadow = oracle.emu_trace(scene.desc(), o, d, 0.0, 100.0, any_hit=True)
+    assert np.all(shadow["t"] == 0)
+
+
+def test_bvh_equals_brute_force_random_soup(native, oracle):
+    from mitsuba2_amd import scenes, api
+    v, f = scenes.random_triangles(1500, seed=3)
+    scene = api.Scene([api.Mesh("soup", v, f)]).build(-1)
+    rng = np.random.default_rng(4)
+    n = 3000
+    o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50, 0] = 0; d[50:100, 1] = 0; d[100:120] = [0, 0, 1]         # axis-parallel rays
+    a = oracle.trace(scene.desc(), o, d, 1e-4, np.inf); b = oracle.emu_trace(scene.desc(), o, d, 1e-4, np.inf)
+    assert np.array_equal(a["prim"], b["prim"]) and (a["prim"] != 0xffffffff).mean() > 0.1
+    hit = a["prim"] != 0xffffffff
+    for k in ("t", "u", "v"):
+        assert np.array_equal(a[k][hit].view(np.uint32), b[k][hit].view(np.uint32))
+    a = oracle.trace(scene.desc(), o, d, 1e-4, 0.5, any_hit=True); b = oracle.emu_trace(scene.desc(), o, d, 1e-4, 0.5, any_hit=True)
+    assert np.array_equal(a["t"], b["t"])
+
+
+def test_closest_hit_tie_break_is_smallest_prim(native, oracle):
+    """Two coplanar coincident triangles: the smaller global primitive id wins (this code base's definition)."""
+    from mitsuba2_amd import api
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    v = np.concatenate([tri, tri, tri + [0, 0, 1]]); f = np.arange(9, dtype=np.uint32).reshape(3, 3)
+    scene = api.Scene([api.Mesh("dup", v, f)]).build(-1)
+    o = np.array([[0.2, 0.2, -1.0]], np.float32); d = np.array([[0, 0, 1.0]], np.float32)
+    assert oracle.trace(scene.desc(), o, d)["prim"][0] == 0 and oracle.emu_trace(scene.desc(), o, d, max_leaf=1)["prim"][0] == 0
+
+
+# ---- src/librender/tests/test_imageblock.py:146-220 ------------------------------------------------------------------------------
+def _film_job(native, w, h, **kw):
+    from mitsuba2_amd import scenes
+    sensor = scenes.cornell_sensor(w, h, 1, **kw)
+    return sensor, native.PathIntegrator(block_size=32).render_job(sensor)
+
+
+def test_imageblock_put_gaussian_vs_reference_loop(native, oracle):
+    sensor, job = _film_job(native, 12, 12)
+    cfg = job.cfg
+    lut = np.array(list(cfg.filter_lut))
+    radius, border = 2, cfg.filter_border
+    assert cfg.filter_radius == 2.0 and border == 2
+
+    def eval_discretized(x):
+        return lut[min(int(abs(x * (31 / cfg.filter_radius))), 31)]
+    positions = np.array([[5, 6], [0, 1], [5, 6], [1, 11], [11, 11], [0, 1], [2, 5], [4, 1], [0, 11], [5, 4]], np.float64)
+    positions += np.random.default_rng(0).uniform(0, 0.95, positions.shape)
+    positions = positions.astype(np.float32)
+    n = len(positions)
+    values = np.concatenate([np.arange(n * 3).reshape(n, 3), np.ones((n, 2))], 1).astype(np.float32)
+    ref = np.zeros((12 + 2 * border, 12 + 2 * border, 5))
+    for i in range(n):
+        pos = positions[i].astype(np.float64) - 0.5 + border
+        lo = np.ceil(pos - radius).astype(int); hi = np.floor(pos + radius).astype(int)
+        for dy in range(lo[1], hi[1] + 1):
+            for dx in range(lo[0], hi[0] + 1):
+                if dx < 0 or dy < 0 or dx >= ref.shape[1] or dy >= ref.shape[0]:
+                    continue
+                w = eval_discretized(dx - pos[0]) * eval_discretized(dy - pos[1])
+                ref[dy, dx] += w * values[i]
+    out = np.zeros(ref.size, np.float32)
+    got = oracle.L.orc_imageblock_put(C.byref(cfg), 0, 0, 12, 12, border, fp(positions), fp(values), n, fp(out))
+    assert got == ref.size
+    assert np.allclose(out.reshape(ref.shape), ref, atol=1e-5)
+    # the product's shared splat helper (miw/film.h), clipped to the film, must agree with the block interior
+    film64 = np.zeros(12 * 12 * 5)
+    oracle.L.orc_film_splat_shared(C.byref(cfg), fp(positions), fp(values), n, film64.ctypes.data_as(c_double_p))
+    assert np.allclose(film64.reshape(12, 12, 5), ref[border:-border, border:-border], atol=1e-5)
+
+
+def test_gaussian_filter_table(native):
+    """src/rfilters/gaussian.cpp:32-47 + src/libcore/rfilter.cpp:9-20"""
+    sensor, job = _film_job(native, 8, 8)
+    lut = np.array(list(job.cfg.filter_lut), np.float64)
+    alpha, radius = -1.0 / (2 * 0.25), 2.0
+    bias = math.exp(alpha * radius * radius)
+    expect = [max(0.0, math.exp(alpha * (radius * i / 31) ** 2) - bias) for i in range(31)] + [0.0]
+    assert np.allclose(lut, expect, atol=1e-7) and lut[31] == 0 and job.cfg.filter_border == 2
+    sensor, job = _film_job(native, 8, 8, rfilter="box")
+    assert job.cfg.filter_border == 0 and abs(job.cfg.filter_radius - 0.5) < 1e-3 and list(job.cfg.filter_lut)[:31] == [1.0] * 31
+
+
+# ---- src/librender/tests/test_spiral.py:49-80 -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["host", "oracle"])
+def test_spiral(native, oracle, which):
+    def blocks(w, h, bs=32, off=(0, 0)):
+        if which == "host":
+            return native.spiral(w, h, bs, off)
+        n = ((w + bs - 1) // bs) * ((h + bs - 1) // bs)
+        out = np.zeros((n, 5), np.int32)
+        assert oracle.L.orc_spiral(w, h, off[0], off[1], bs, out.ctypes.data_as(c_i32_p), n) == n
+        return out
+    b = blocks(15, 12)                                    # test02_small_film
+    assert len(b) == 1 and list(b[0]) == [0, 0, 15, 12, 0]
+    b = blocks(318, 322)                                  # test03_normal_film
+    assert len(b) == 110
+    c, w = np.array([160, 160]), 32
+    expected = [c, c + [w, 0], c + [w, w], c + [0, w], c + [-w, w], c + [-w, 0], c + [-w, -w], c + [0, -w], c + [w, -w],
+                c + [2 * w, -w], c + [2 * w, 0], c + [2 * w, w]]
+    for i, e in enumerate(expected):
+        assert list(b[i][:2]) == list(e) and list(b[i][2:4]) == [32, 32] and b[i][4] == i
+    # every block exactly once, ids 0..n-1, edge blocks clipped
+    assert sorted(b[:, 4]) == list(range(110))
+    assert len({(x, y) for x, y in b[:, :2]}) == 110
+    assert b[:, 2].min() == 318 - 9 * 32 and b[:, 3].min() == 322 - 10 * 32
+    b = blocks(64, 64, 32, (5, 7))                        # crop offset is added to block offsets (spiral.cpp:45)
+    assert sorted(map(tuple, b[:, :2])) == [(5, 7), (5, 39), (37, 7), (37, 39)]
+
+
+def test_host_and_oracle_spiral_agree(native, oracle):
+    for w, h, bs in [(1920, 1080, 32), (256, 256, 32), (77, 45, 16), (33, 1, 32)]:
+        a = native.spiral(w, h, bs)
+        out = np.zeros_like(a)
+        oracle.L.orc_spiral(w, h, 0, 0, bs, out.ctypes.data_as(c_i32_p), len(a))
+        assert np.array_equal(a, out)
+
+
+# ---- src/sensors/tests/test_perspective.py --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("origin", [[1.0, 0.0, 1.5], [1.0, 4.0, 1.5]])
+@pytest.mark.parametrize("direction", [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+def test_perspective_sample_ray(native, origin, direction):
+    from mitsuba2_amd import api
+    film = api.Film(width=512, height=256); sampler = api.Sampler()
+    t = [origin[i] + direction[i] for i in range(3)]
+    for fov in (34.0, 80.0):
+        cam = api.Sensor(film, sampler, fov=fov, near_clip=1.0, far_clip=35.0, to_world=dict(origin=origin, target=t, up=(0, 1, 0)))
+        r = cam.sample_ray(0.5, 0.5)
+        assert np.allclose(r[0:3], origin) and np.allclose(r[3:6], direction, atol=1e-6)
+        assert np.isclose(r[6], 1.0, rtol=1e-6) and np.isclose(r[7], 35.0, rtol=1e-5)
+        # test04_fov_axis: the edge of the film along x is fov/2 away from the optical axis
+        for x in (0.0, 1.0):
+            r = cam.sample_ray(x, 0.5)
+            ang = math.degrees(math.acos(np.clip(np.dot(r[3:6], direction), -1, 1)))
+            assert abs(ang - fov / 2) < 1e-3
+            assert np.isclose(r[6], 1.0 / math.cos(math.radians(fov / 2)), rtol=1e-5)   # mint = near / d.z
+
+
+def test_parse_fov_and_errors(native):
+    from mitsuba2_amd import api
+    film = api.Film(width=512, height=256); sampler = api.Sampler()
+    cam = api.Sensor(film, sampler, fov=40.0, fov_axis="y")
+    assert np.isclose(cam.x_fov(), math.degrees(2 * math.atan(math.tan(math.radians(20)) * 2)), rtol=1e-6)
+    cam = api.Sensor(film, sampler)                        # default focal_length 50mm, diagonal (sensor.cpp:132-147)
+    diag = 2 * math.degrees(math.atan(math.sqrt(36 * 36 + 24 * 24) / 100))
+    width = 2 * math.tan(math.radians(diag) / 2) / math.sqrt(1 + 1 / 4)
+    assert np.isclose(cam.x_fov(), math.degrees(2 * math.atan(width / 2)), rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        api.Sensor(film, sampler, fov=40.0, focal_length="50mm")
+    with pytest.raises(RuntimeError):
+        api.Sensor(film, sampler, fov=40.0, near_clip=5.0, far_clip=1.0)
+    with pytest.raises(RuntimeError):
+        api.Sensor(film, sampler, fov=200.0)
