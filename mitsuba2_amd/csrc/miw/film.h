@@ -48,21 +48,13 @@ MIW_HD bool sample_is_valid(const float *value) {
     return ok;
 }
 
-// Calls add(texel_index, channel, value) for every texel the sample touches,
-// in the reference's loop order (:148-161). `px,py` = integer pixel the sample
-// belongs to (selects the spiral block), `pos` = position_sample.
+// ImageBlock::put into ONE bordered block (offset off_x/off_y, clipped size bw x bh):
+// calls add(block_texel, channel, value) with block_texel = y * (bw + 2*border) + x,
+// for every texel the sample touches, in the reference's loop order (:148-161).
+// The caller has already validated the sample (sample_is_valid).
 template <typename Add>
-MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *value, Add add) {
-    if (!sample_is_valid(value)) return;
-
-    // block this pixel lives in (spiral.cpp:43-45): offset, clipped size
-    int bx = ((px - f.crop_x) / f.block_size) * f.block_size,
-        by = ((py - f.crop_y) / f.block_size) * f.block_size;
-    int bw = f.crop_w - bx < f.block_size ? f.crop_w - bx : f.block_size,
-        bh = f.crop_h - by < f.block_size ? f.crop_h - by : f.block_size;
-    int off_x = bx + f.crop_x, off_y = by + f.crop_y;
+MIW_HD void block_splat(const FilmRec &f, int off_x, int off_y, int bw, int bh, V2 pos_, const float *value, Add add) {
     int size_x = bw + 2 * f.border, size_y = bh + 2 * f.border;
-
     // :114  pos = pos_ - (m_offset - m_border_size + .5f)
     float posx = pos_.x - ((float) (off_x - f.border) + .5f),
           posy = pos_.y - ((float) (off_y - f.border) + .5f);
@@ -85,15 +77,12 @@ MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *v
         for (int yr = 0; yr < n; ++yr) {
             int y = lo_y + yr;
             bool enabled = y <= hi_y;
-            // block texel -> film texel (imageblock.cpp:49-77)
-            int fy = y + by - f.border;
             for (int xr = 0; xr < n; ++xr) {
                 int x = lo_x + xr;
                 float weight = wy[yr] * wx[xr];
                 enabled = enabled && x <= hi_x;
-                int fx = x + bx - f.border;
-                if (enabled && fx >= 0 && fx < f.crop_w && fy >= 0 && fy < f.crop_h) {
-                    int texel = fy * f.crop_w + fx;
+                if (enabled) {
+                    int texel = y * size_x + x;
                     for (int k = 0; k < MIW_FILM_CHANNELS; ++k)
                         add(texel, k, value[k] * weight);
                 }
@@ -102,14 +91,34 @@ MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *v
     } else {                                             // box filter, :163-170
         int lo_x = ceil2int(posx - .5f), lo_y = ceil2int(posy - .5f);
         if (lo_x >= 0 && lo_y >= 0 && lo_x < size_x && lo_y < size_y) {
-            int fx = lo_x + bx - f.border, fy = lo_y + by - f.border;
-            if (fx >= 0 && fx < f.crop_w && fy >= 0 && fy < f.crop_h) {
-                int texel = fy * f.crop_w + fx;
-                for (int k = 0; k < MIW_FILM_CHANNELS; ++k)
-                    add(texel, k, value[k]);
-            }
+            int texel = lo_y * size_x + lo_x;
+            for (int k = 0; k < MIW_FILM_CHANNELS; ++k)
+                add(texel, k, value[k]);
         }
     }
+}
+
+// The spiral block a pixel belongs to (spiral.cpp:43-45): bordered-block origin and clipped size
+MIW_HD void block_of_pixel(const FilmRec &f, int px, int py, int &bx, int &by, int &bw, int &bh) {
+    bx = ((px - f.crop_x) / f.block_size) * f.block_size;
+    by = ((py - f.crop_y) / f.block_size) * f.block_size;
+    bw = f.crop_w - bx < f.block_size ? f.crop_w - bx : f.block_size;
+    bh = f.crop_h - by < f.block_size ? f.crop_h - by : f.block_size;
+}
+
+// ImageBlock::put followed by Film::put (imageblock.cpp:49-77, out-of-film border texels
+// clipped): add(film_texel, channel, value). `px,py` = the pixel the sample belongs to.
+template <typename Add>
+MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *value, Add add) {
+    if (!sample_is_valid(value)) return;
+    int bx, by, bw, bh;
+    block_of_pixel(f, px, py, bx, by, bw, bh);
+    const int size_x = bw + 2 * f.border;
+    block_splat(f, bx + f.crop_x, by + f.crop_y, bw, bh, pos_, value, [&](int texel, int k, float v) {
+        int x = texel % size_x, y = texel / size_x;
+        int fx = x + bx - f.border, fy = y + by - f.border;
+        if (fx >= 0 && fx < f.crop_w && fy >= 0 && fy < f.crop_h) add(fy * f.crop_w + fx, k, v);
+    });
 }
 
 } // namespace miw

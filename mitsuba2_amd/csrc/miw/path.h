@@ -57,7 +57,7 @@ struct LaneQueues {
     F4 *sh_d;      // d.xyz, maxt
     F4 *sh_c;      // pending contribution rgb
     uint32_t *sh_vis; // 1 = unoccluded (written by the any-hit trace)
-    // finished-sample log (24 B/sample), [sample j][lane]: what ImageBlock::put received
+    // finished-sample log (24 B/sample), [lane][sample j]: what ImageBlock::put received
     F2 *log_pos;   // position_sample (x = NaN: sample rejected by imageblock.cpp:85-109)
     F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
 };
@@ -129,9 +129,9 @@ template <typename Add> struct SplatSink {
 // Sink 2: append to the lane's sample log; the film is assembled afterwards by the
 // ordered gather (miw/film_gather.h), in the reference's float32 accumulation order.
 struct LogSink {
-    F2 *log_pos; F4 *log_val; uint32_t lane, n_lanes;
+    F2 *log_pos; F4 *log_val; uint32_t lane, spp;        // [lane][sample]: one contiguous run per pixel
     MIW_HD void operator()(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) const {
-        size_t i = (size_t) sample_idx * n_lanes + lane;
+        size_t i = (size_t) lane * spp + sample_idx;
         F2 p; p.x = sample_is_valid(aovs) ? pos.x : __builtin_nanf(""); p.y = pos.y;
         F4 v; v.x = aovs[0]; v.y = aovs[1]; v.z = aovs[2]; v.w = aovs[3];
         log_pos[i] = p; log_val[i] = v;
@@ -148,7 +148,7 @@ MIW_HD void lane_load_path(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
     F4 a = Q.tp[lane], b = Q.res[lane];
     L.tp = v3(a.x, a.y, a.z); L.eta = a.w;
     L.res = v3(b.x, b.y, b.z); L.prev_pdf = b.w;
-    F2 p = Q.pos[lane]; L.pos = v2(p.x, p.y);
+    L.pos = v2(0.f, 0.f);            // position_sample is fetched only when the sample is splatted
 }
 MIW_HD void lane_store(const LaneQueues &Q, uint32_t lane, const LaneRegs &L, bool store_pos) {
     U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
@@ -198,7 +198,6 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
     lane_load(Q, lane, L);
     if (L.flags & LF_DONE) return false;
     lane_load_path(Q, lane, L);
-    const uint32_t pixel = Q.pixel[lane];
     const bool had_shadow = (L.flags & LF_HAS_SHADOW) != 0;
 
     // (k-1)'s emitter-sampling contribution, now that its shadow ray is resolved
@@ -217,8 +216,8 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
         F4 h = Q.hit[lane];
         const uint32_t tri_idx = f2u(h.w);
         const bool valid = tri_idx != MIW_MISS;
-        F4 ro = Q.ray_o[lane], rd = Q.ray_d[lane];
-        V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
+        F4 rd = Q.ray_d[lane];
+        V3 ray_d = v3(rd.x, rd.y, rd.z);
 
         SurfaceInteraction si;
         uint32_t bsdf_index = 0;
@@ -240,7 +239,8 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
                 float emitter_pdf = 0.f;
                 if (!(L.flags & LF_PREV_DELTA)) {
                     // DirectionSample3f ds(si_bsdf, si), records.h:167-173
-                    V3 d = si.p - ray_o;
+                    F4 ro = Q.ray_o[lane];               // previous vertex: only this MIS term needs it
+                    V3 d = si.p - v3(ro.x, ro.y, ro.z);
                     float dist = norm(d);
                     d = d / dist;
                     emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, si.sh.n);
@@ -319,6 +319,8 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
     bool store_pos = false;
     if (finished) {
         // ---- splat, advance, regenerate (integrator.cpp:264-287) ----
+        const uint32_t pixel = Q.pixel[lane];
+        F2 ps = Q.pos[lane]; L.pos = v2(ps.x, ps.y);
         lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;

@@ -57,7 +57,7 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
 };
 
 // Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
-struct TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
+struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
 static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 
 __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     if (lane < P.n_lanes) {
         bool alive;
         if (UseLog) {
-            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.n_lanes = P.n_lanes;
+            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
             alive = lane_shade(P, sc, Q, lane, &local, sink);
         } else {
             FilmAdd add; add.accum = accum;
@@ -229,18 +229,129 @@ __global__ void k_film_resolve(const double *accum, float *out32, double *out64,
     if (out64) out64[i] = accum[i]; else out32[i] = (float) accum[i];
 }
 
-// Ordered film assembly (miw/film_gather.h): one work item per film texel. The
-// 8x8 texel tile of a wavefront keeps its source lanes (Morton-contiguous log
-// columns) hot in L1/L2.
-__global__ __launch_bounds__(MIW_BLOCK) void k_film_gather(FilmRec F, GatherArgs G, float *out32, double *out64) {
-    // 256 threads = a 16x16 texel tile, Morton order inside the tile
-    uint32_t tiles_x = ((uint32_t) F.crop_w + 15u) / 16u;
-    uint32_t tile = blockIdx.x, mx, my;
-    morton_decode2(threadIdx.x, mx, my);
-    int fx = (int) ((tile % tiles_x) * 16u + mx), fy = (int) ((tile / tiles_x) * 16u + my);
+// Ordered film assembly, step 1 (miw/film_gather.h): the bordered ImageBlock of every spiral block
+// is rebuilt by TEXEL PATCHES — one wavefront owns an 8x8 patch of block texels, one texel per lane,
+// the five channel sums live in registers. The wave walks the block's pixels in Morton order
+// (render_block's order, integrator.cpp:196-203), skips those whose filter footprint cannot reach
+// the patch, and replays each remaining pixel's sample run front to back: 64 samples are fetched with
+// one coalesced load (lane i = sample i; the log is [lane][sample]), the owning lane derives what
+// ImageBlock::put derives once per sample (lo, clipped extent, the discretised x/y weights,
+// imageblock.cpp:114-146) and parks the weights in LDS, then the samples are broadcast one by one
+// (v_readlane) and each lane adds value*wy*wx to its texel iff the footprint covers it (:148-161).
+// Every texel therefore sees exactly the reference's sequence of float32 additions; there are no
+// atomics and no cross-lane accumulation, and the dependent chain per texel is register-only.
+#define MIW_FP_SIDE 8                  /* patch = 8 x 8 texels = one wavefront */
+#define MIW_FP_MAXN 8                  /* filter footprint is at most 8 x 8 (radius <= 4) */
+struct PatchArgs { uint32_t patches_x, patches_y; int32_t reach; };
+
+template <bool wide>
+__global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles) {
+    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
+    __shared__ float s_w[64 * 2 * MIW_FP_MAXN];              // per staged sample: wx[8], wy[8]
+    const uint32_t l = threadIdx.x;
+    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
+    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
+    const int tx = ptx0 + (int) (l & 7u), ty = pty0 + (int) (l >> 3);
+    if (l < 32) s_lut[l] = F.lut[l];
+    __syncthreads();
+
+    // pixels (block-local) whose samples can reach this patch
+    int x0 = ptx0 - F.border - PA.reach, x1 = ptx0 + MIW_FP_SIDE - 1 - F.border + PA.reach,
+        y0 = pty0 - F.border - PA.reach, y1 = pty0 + MIW_FP_SIDE - 1 - F.border + PA.reach;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > g.bw - 1) x1 = g.bw - 1;
+    if (y1 > g.bh - 1) y1 = g.bh - 1;
+
+    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
+    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
+    if (n > MIW_FP_MAXN) n = MIW_FP_MAXN;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+    const uint32_t bs2 = 1u << A.bs2_log2;
+
+    for (uint32_t q = 0; q < bs2; ++q) {                     // wave-uniform scan in Morton order
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        if ((int) x < x0 || (int) x > x1 || (int) y < y0 || (int) y > y1) continue;
+        const uint32_t lane = (tile << A.bs2_log2) + q;
+        const uint32_t count = (uint32_t) __builtin_amdgcn_readfirstlane((int) A.st[lane].w);
+        const F2 *lp = A.log_pos + (size_t) lane * A.spp; const F4 *lv = A.log_val + (size_t) lane * A.spp;
+        for (uint32_t j0 = 0; j0 < count; j0 += 64) {
+            const uint32_t m = count - j0 < 64u ? count - j0 : 64u;
+            // ---- stage: lane i owns sample j0 + i ----
+            F2 p; p.x = __builtin_nanf(""); p.y = 0.f;
+            F4 v; v.x = v.y = v.z = v.w = 0.f;
+            if (l < m) { p = lp[j0 + l]; v = lv[j0 + l]; }
+            int lo_x = 0, lo_y = 0, nx = 0, ny = 0;
+            float wx[MIW_FP_MAXN], wy[MIW_FP_MAXN];
+            for (int i = 0; i < MIW_FP_MAXN; ++i) wx[i] = wy[i] = 0.f;
+            if (p.x == p.x) {                                // not a rejected sample (imageblock.cpp:98-108)
+                const float posx = p.x - kx, posy = p.y - ky;                        // :114
+                if (wide) {
+                    lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
+                    if (lo_x < 0) lo_x = 0;
+                    if (lo_y < 0) lo_y = 0;
+                    int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
+                    if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
+                    if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
+                    const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
+                    for (int i = 0; i < MIW_FP_MAXN; ++i) {
+                        if (i < n) {
+                            int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
+                                iy = (int) abs_((base_y + (float) i) * F.scale_factor);
+                            if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
+                            if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
+                            wx[i] = s_lut[ix]; wy[i] = s_lut[iy];
+                        }
+                    }
+                    nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;   // texels enabled by `y <= hi_y`, `x <= hi_x`
+                    if (nx > n) nx = n;
+                    if (ny > n) ny = n;
+                    if (nx < 0) nx = 0;
+                    if (ny < 0) ny = 0;
+                } else {                                     // box filter, :163-170: one texel, weight 1
+                    lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
+                    const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
+                    nx = ny = in ? 1 : 0; wx[0] = wy[0] = 1.f;
+                    if (!in) lo_x = lo_y = 0;
+                }
+            }
+            __syncthreads();                                 // previous chunk's weights fully consumed
+            for (int i = 0; i < MIW_FP_MAXN; ++i) { s_w[l * 16 + i] = wx[i]; s_w[l * 16 + 8 + i] = wy[i]; }
+            __syncthreads();
+            const int pk_lo = lo_x | (lo_y << 16), pk_n = nx | (ny << 8);
+            // ---- replay: this pixel's samples back to back ----
+            for (uint32_t s = 0; s < m; ++s) {
+                const int slo = __builtin_amdgcn_readlane(pk_lo, (int) s), sn = __builtin_amdgcn_readlane(pk_n, (int) s);
+                const int xr = tx - (slo & 0xffff), yr = ty - (slo >> 16);
+                const bool hit = (uint32_t) xr < (uint32_t) (sn & 0xff) && (uint32_t) yr < (uint32_t) (sn >> 8);
+                const float w = s_w[s * 16 + 8 + (yr & 7)] * s_w[s * 16 + (xr & 7)];          // wy * wx, :155
+                const float vx = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.x), (int) s)),
+                            vy = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.y), (int) s)),
+                            vz = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.z), (int) s)),
+                            va = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.w), (int) s));
+                if (hit) {
+                    if (wide) { acc0 += vx * w; acc1 += vy * w; acc2 += vz * w; acc3 += va * w; acc4 += 1.f * w; }
+                    else      { acc0 += vx;     acc1 += vy;     acc2 += vz;     acc3 += va;     acc4 += 1.f; }
+                }
+            }
+        }
+    }
+    if (tx < g.size_x && ty < g.size_y) {
+        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
+    }
+}
+
+// step 2: every film texel sums the block tiles covering it, ascending block id
+__global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64) {
+    int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;
     if (fx >= F.crop_w || fy >= F.crop_h) return;
     float v[MIW_FILM_CHANNELS];
-    film_gather_texel(F, G, fx, fy, v);
+    film_merge_texel(F, A, tiles, fx, fy, v);
     size_t o = ((size_t) fy * F.crop_w + fx) * MIW_FILM_CHANNELS;
     for (int k = 0; k < MIW_FILM_CHANNELS; ++k) {
         if (out64) out64[o + k] = (double) v[k]; else out32[o + k] = v[k];
@@ -361,7 +472,7 @@ struct mi_ctx {
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
     DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;
-    DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile;
+    DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
     DevBuf<Counters> d_cnt;
     Counters *h_cnt = nullptr;          // pinned
 
@@ -414,7 +525,7 @@ void mi_destroy(mi_ctx *c) {
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
-    c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release();
+    c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
@@ -814,12 +925,26 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
             HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
             HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            GatherArgs G;
-            G.log_pos = c->q_log_pos.p; G.log_val = c->q_log_val.p; G.st = c->q_st.p; G.n_lanes = n_lanes;
-            G.block_ids = c->d_block_ids.p; G.block_tile = c->d_block_tile.p;
-            G.blocks_x = blocks_x; G.blocks_y = blocks_y; G.bs2_log2 = bs2_log2;
-            uint32_t tiles = (((uint32_t) cfg->crop_w + 15u) / 16u) * (((uint32_t) cfg->crop_h + 15u) / 16u);
-            MIW_TIMED(4, hipLaunchKernelGGL(k_film_gather, dim3(tiles), dim3(MIW_BLOCK), 0, s, P.film, G, dst32, dst64));
+            BlockReplayArgs A;
+            A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
+            A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
+            A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
+            A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
+            const uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
+            A.tile_stride = side * side * MIW_FILM_CHANNELS;
+            HIP_TRY(c, c->d_tiles.resize((size_t) std::max<uint32_t>(n_tiles, 1) * A.tile_stride));
+            if (n_tiles) {
+                PatchArgs PA;
+                PA.patches_x = PA.patches_y = (side + MIW_FP_SIDE - 1) / MIW_FP_SIDE;
+                PA.reach = (int32_t) floorf(cfg->filter_radius + .5f);
+                const dim3 fgrid(n_tiles * PA.patches_x * PA.patches_y);
+                if (cfg->filter_radius > 0.5f + MIW_RAY_EPSILON)
+                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
+                else
+                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<false>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
+            }
+            MIW_TIMED(5, hipLaunchKernelGGL(k_film_merge, dim3(((uint32_t) cfg->crop_w + 255u) / 256u, (uint32_t) cfg->crop_h), dim3(256), 0, s,
+                                            P.film, A, c->d_tiles.p, dst32, dst64));
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(s));            // block_tile (host vector) must outlive the copy
         } else {

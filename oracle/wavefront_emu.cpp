@@ -190,7 +190,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         uint64_t active = 0;
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
-            LogSink log{ Q.log_pos, Q.log_val, lane, n_lanes };
+            LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);
@@ -201,17 +201,21 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         ++iterations;
         if (active == 0) break;
     }
-    if (film32) {                                              // k_film_gather
+    if (film32) {                                              // k_film_blocks + k_film_merge
         std::vector<int32_t> block_tile(cfg->block_count, -1);
         for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
-        GatherArgs G; G.log_pos = log_pos.data(); G.log_val = log_val.data(); G.st = st.data(); G.n_lanes = n_lanes;
-        G.block_ids = cfg->block_ids; G.block_tile = block_tile.data();
-        G.blocks_x = blocks_x; G.blocks_y = (cfg->crop_h + bs - 1) / bs;
+        BlockReplayArgs A; A.log_pos = log_pos.data(); A.log_val = log_val.data(); A.st = st.data(); A.spp = cfg->spp;
+        A.block_ids = cfg->block_ids; A.block_tile = block_tile.data(); A.tile_list = cfg->tile_list;
+        A.blocks_x = blocks_x; A.blocks_y = (cfg->crop_h + bs - 1) / bs;
         uint32_t l2 = 0; while ((1u << l2) < bs2) ++l2;
-        G.bs2_log2 = l2;
+        A.bs2_log2 = l2;
+        uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
+        A.tile_stride = side * side * MIW_FILM_CHANNELS;
+        std::vector<float> tiles((size_t) n_tiles * A.tile_stride, 0.f);
+        for (uint32_t t = 0; t < n_tiles; ++t) film_block_replay(P.film, A, t, tiles.data() + (size_t) t * A.tile_stride);
         for (int fy = 0; fy < cfg->crop_h; ++fy)
             for (int fx = 0; fx < cfg->crop_w; ++fx)
-                film_gather_texel(P.film, G, fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5);
+                film_merge_texel(P.film, A, tiles.data(), fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5);
     }
     if (stats4) { stats4[0] = cnt.samples; stats4[1] = cnt.segments; stats4[2] = cnt.shadow_rays; stats4[3] = iterations; }
     return 0;
