@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
+    ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
+    ap.add_argument("--samples-per-launch", type=int, default=0, help="resident plan: samples each pixel advances per launch")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,6 +69,7 @@ def main():
     job = integ.render_job(sensor)
     cfg = job.cfg
     cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
+    cfg.plan = args.plan; cfg.samples_per_launch = args.samples_per_launch
     film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     dev.check(dev.L.mi_set_stream(dev.ctx, C.c_void_p(stream.cuda_stream)))
@@ -86,7 +89,7 @@ def main():
         step()
     sync()
     agg = dict(ms_shade=0.0, ms_tc=0.0, ms_ta=0.0, ms_film=0.0, ms_init=0.0, n_shade=0, n_tc=0, n_ta=0, segments=0, samples=0,
-               shadow=0, iters=0)
+               shadow=0, iters=0, ms_path=0.0, n_path=0, ms_fb=0.0, ms_fm=0.0, n_film=0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -95,6 +98,8 @@ def main():
         agg["ms_film"] += c.ms_resolve; agg["ms_init"] += c.ms_init
         agg["n_shade"] += c.n_shade; agg["n_tc"] += c.n_trace_closest; agg["n_ta"] += c.n_trace_any
         agg["segments"] += c.segments; agg["samples"] += c.samples; agg["shadow"] += c.shadow_rays; agg["iters"] += c.iterations
+        agg["ms_path"] += c.ms_path; agg["n_path"] += c.n_path; agg["ms_fb"] += c.ms_film_blocks; agg["ms_fm"] += c.ms_film_merge
+        agg["n_film"] += 1
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -111,9 +116,13 @@ def main():
             "k_shade": (agg["ms_shade"], agg["n_shade"], B_SHADE * agg["segments"] + B_SPLAT * agg["samples"]),
             "k_trace<closest>": (agg["ms_tc"], agg["n_tc"], B_TRACE_CLOSEST * agg["segments"]),
             "k_trace<any>": (agg["ms_ta"], agg["n_ta"], B_TRACE_ANY * agg["shadow"]),
+            # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
+            "k_path_resident": (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
+            # ordered film replay: reads the 24 B/sample log once, writes the block tiles
+            "k_film_blocks": (agg["ms_fb"], agg["n_film"], 24.0 * agg["samples"]),
         }
         roofline = None
-        if not args.no_profile and agg["n_shade"]:
+        if not args.no_profile and (agg["n_shade"] or agg["n_path"]):
             name = max(kernels, key=lambda k: kernels[k][0])
             ms, n, alg_bytes = kernels[name]
             achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -122,8 +131,8 @@ def main():
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
-                "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items()},
-                                  k_film_assemble=round(agg["ms_film"], 3), k_init_lanes=round(agg["ms_init"], 3)),
+                "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
+                                  k_film_merge=round(agg["ms_fm"], 3), k_init=round(agg["ms_init"], 3)),
                 "segments_per_sample": s_bar,
                 "pipeline_alg_bytes_per_sample": b_alg,
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),
@@ -147,6 +156,7 @@ def main():
             "config": {"workload": "Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                    "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" % (W, H, SPP),
                        "parallelism": "tile-shard x%d + RCCL film reduce" % world if world > 1 else "single GPU",
+                       "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -127,6 +127,14 @@ typedef struct {
     int32_t film_mode;
     int32_t profile;                          /* 1: time every launch with HIP events    */
     float timeout_s;                          /* <= 0: none (integrator.cpp:34)          */
+    /* execution plan of the sample loop (same arithmetic, same film, either way):
+     * 1 = wavefront: SoA ray / hit / shadow queues in HBM, one kernel per stage
+     *     (trace closest, shade, trace any) per depth-loop iteration,
+     * 2 = resident: the whole depth loop of a pixel runs in registers, geometry in LDS
+     *     (or read through L2), the pixel is advanced `samples_per_launch` samples per launch,
+     * 0 = auto: 2 when the geometry is LDS-resident, else 1                          */
+    int32_t plan;
+    int32_t samples_per_launch;               /* plan 2: <= 0 = default (32)             */
 } mi_render_cfg;
 
 typedef struct {
@@ -142,6 +150,10 @@ typedef struct {
     double ms_bvh_build;
     uint32_t bvh_nodes, bvh_tris, bvh_depth;
     uint32_t film_mode;        /* 1 = ordered gather, 2 = float64 atomics (last render)   */
+    uint32_t plan;             /* 1 = wavefront, 2 = resident (last render)               */
+    double ms_path;            /* plan 2: HIP-event time of the k_path_resident launches  */
+    uint64_t n_path;
+    double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -55,7 +55,7 @@ class mi_render_cfg(C.Structure):
                 ("filter_lut", C.c_float * 32), ("filter_radius", C.c_float), ("filter_border", C.c_int32),
                 ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("film_mode", C.c_int32),
                 ("profile", C.c_int32),
-                ("timeout_s", C.c_float)]
+                ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32)]
 
 
 class mi_counters(C.Structure):
@@ -65,7 +65,9 @@ class mi_counters(C.Structure):
                 ("ms_init", C.c_double), ("ms_resolve", C.c_double),
                 ("n_trace_closest", C.c_uint64), ("n_trace_any", C.c_uint64), ("n_shade", C.c_uint64),
                 ("ms_bvh_build", C.c_double), ("bvh_nodes", C.c_uint32), ("bvh_tris", C.c_uint32),
-                ("bvh_depth", C.c_uint32), ("film_mode", C.c_uint32)]
+                ("bvh_depth", C.c_uint32), ("film_mode", C.c_uint32), ("plan", C.c_uint32),
+                ("ms_path", C.c_double), ("n_path", C.c_uint64),
+                ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double)]
 
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
@@ -140,6 +142,7 @@ def load_host_lib():
         "mih_sensor_sample_ray": (i32, [vp, f, f, c_float_p]), "mih_sensor_x_fov": (f, [vp]),
         "mih_integrator_create": (vp, [vp]), "mih_integrator_destroy": (None, [vp]),
         "mih_integrator_set_shard": (None, [vp, u32, u32]), "mih_integrator_set_profile": (None, [vp, i32]),
+        "mih_integrator_set_plan": (None, [vp, i32]),
         "mih_integrator_cancel": (None, [vp]), "mih_integrator_render": (i32, [vp, vp, vp]),
         "mih_integrator_counters": (i32, [vp, C.POINTER(mi_counters)]),
         "mih_make_render_cfg": (i32, [vp, vp, C.POINTER(mi_render_cfg), c_u32_p, c_u32_p, u32, u32]),

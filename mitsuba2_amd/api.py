@@ -274,6 +274,10 @@ class PathIntegrator:
     def set_profile(self, on=True):
         host_lib().mih_integrator_set_profile(self.h, int(on))
 
+    def set_plan(self, plan):
+        """0 auto / 1 wavefront (HBM queues) / 2 resident (registers + LDS)"""
+        host_lib().mih_integrator_set_plan(self.h, int(plan))
+
     def render(self, scene, sensor):
         """SamplingIntegrator::render -> True (finished) / False (cancelled, timeout)"""
         r = host_lib().mih_integrator_render(self.h, scene.h, sensor.h)
@@ -331,10 +335,15 @@ class Device:
         self.check(self.L.mi_trace(self.ctx, C.byref(r), C.byref(h), n, int(any_hit)))
         return out
 
-    def render(self, job, f64=False, profile=False, film_mode=0):
-        """film_mode 0 auto / 1 sample log + ordered gather (float32, reference order) / 2 float64 atomics"""
+    def render(self, job, f64=False, profile=False, film_mode=0, plan=None, samples_per_launch=None):
+        """film_mode 0 auto / 1 sample log + ordered gather (float32, reference order) / 2 float64 atomics;
+        plan 0 auto / 1 wavefront (HBM queues) / 2 resident (registers + LDS)"""
         cfg = job.cfg
         cfg.film_on_device = 0; cfg.film_f64 = int(f64); cfg.profile = int(profile); cfg.film_mode = film_mode
+        if plan is not None:
+            cfg.plan = int(plan)
+        if samples_per_launch is not None:
+            cfg.samples_per_launch = int(samples_per_launch)
         n = cfg.crop_w * cfg.crop_h * 5
         film = np.zeros(n, np.float64 if f64 else np.float32)
         st = self.L.mi_render(self.ctx, C.byref(cfg), film.ctypes.data_as(C.c_void_p))

@@ -91,8 +91,8 @@ struct LaneRegs {
     Ray ray;
 };
 
-MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L) {
-    if (L.sample_idx >= P.spp) {                         // pixel finished: retire the lane
+MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, uint32_t sample_end) {
+    if (L.sample_idx >= sample_end) {                    // pixel finished (or end of this pass): retire the lane
         L.flags = LF_DONE;
         L.ray.o = L.ray.d = v3(0.f); L.ray.mint = 0.f; L.ray.maxt = -1.f;   // maxt < 0: no ray queued
         return;
@@ -173,7 +173,7 @@ MIW_HD void lane_init(const RenderParams &P, const LaneQueues &Q, uint32_t lane,
     L.sample_idx = 0; L.flags = 0;
     L.tp = v3(1.f); L.res = v3(0.f); L.eta = 1.f; L.prev_pdf = 0.f; L.pos = v2(0.f, 0.f);
     L.ray.o = L.ray.d = v3(0.f); L.ray.mint = 0.f; L.ray.maxt = -1.f;
-    lane_begin_sample(P, pixel, L);
+    lane_begin_sample(P, pixel, L, P.spp);
     lane_store(Q, lane, L, true);
     lane_clear_shadow(Q, lane);
     Q.sh_vis[lane] = 0;
@@ -189,7 +189,113 @@ MIW_HD void lane_init_unused(const LaneQueues &Q, uint32_t lane) {
     Q.sh_vis[lane] = 0;
 }
 
-// Stage 2: one iteration of the depth loop for one lane.
+// What one depth-loop iteration hands to the shadow stage (scene.cpp:203-207):
+// origin and mint are the extension ray's (L.ray.o, L.ray.mint).
+struct ShadowOut { bool has; V3 d; float maxt; V3 c; };
+
+enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
+       STEP_FINISHED = 1,        // the camera sample is complete
+       STEP_DEAD_PENDING = 2 };  // complete once the shadow ray in `sh` is resolved
+
+// One iteration of PathIntegrator::sample's depth loop (path.cpp:124-208) on register
+// state. `L.ray.d` is the direction of the ray that produced hit record `h`;
+// `prev_o()` returns its origin (the previous vertex; fetched lazily — only the
+// emitter-hit MIS term needs it). Leaves the extension ray in L.ray (maxt < 0: none).
+// Shared by every execution plan: the HBM-queue wavefront kernels (lane_shade below),
+// the register-resident kernel (k_path_resident) and the CPU checker.
+template <typename PrevO>
+MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
+                     ShadowOut &sh, Counters *cnt_local) {
+    sh.has = false;
+    const uint32_t depth = L.flags & LF_DEPTH_MASK;
+    const uint32_t tri_idx = f2u(h.w);
+    const bool valid = tri_idx != MIW_MISS;
+    const V3 ray_d = L.ray.d;
+
+    SurfaceInteraction si;
+    uint32_t bsdf_index = 0;
+    int32_t emitter = -1;                            // scene.h:243-253 (no environment emitter)
+    if (valid) {
+        const Tri &tr = sc.tris[tri_idx];
+        const ShapeRec &shape = sc.shapes[tr.shape];
+        const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
+        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+        si.shape = tr.shape; si.prim = tr.prim;
+        emitter = shape.emitter; bsdf_index = shape.bsdf;
+    }
+    if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
+
+    // ---- intersection with emitters, path.cpp:126-129 ----
+    if (emitter >= 0) {
+        float emission_weight = 1.f;                 // :109
+        if (depth > 1) {                             // :194-205, evaluated lazily
+            float emitter_pdf = 0.f;
+            if (!(L.flags & LF_PREV_DELTA)) {
+                // DirectionSample3f ds(si_bsdf, si), records.h:167-173
+                V3 d = si.p - prev_o();
+                float dist = norm(d);
+                d = d / dist;
+                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, si.sh.n);
+            }
+            emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
+        }
+        L.res = L.res + emission_weight * L.tp * emitter_eval(sc.emitters[emitter], si.wi);
+    }
+
+    bool active = valid;                             // :131
+
+    // ---- Russian roulette, :137-141 (the draw happens even for dead paths) ----
+    if ((int32_t) depth > P.rr_depth) {
+        float q = min_(hmax(L.tp) * sqr(L.eta), .95f);
+        active = (next_1d(L.rng) < q) && active;
+        L.tp = L.tp * rcp(q);
+    }
+
+    // ---- termination, :147-149 ----
+    if (depth >= (uint32_t) P.max_depth || !active) return STEP_FINISHED;
+
+    if (cnt_local) cnt_local->segments++;
+    const BsdfRec &bsdf = sc.bsdfs[bsdf_index];
+    const uint32_t bflags = bsdf_flags(bsdf);
+    L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
+    L.ray.d = v3(0.f); L.ray.maxt = -1.f;
+
+    // ---- emitter sampling, :155-172 ----
+    if (bflags & BSDF_Smooth) {
+        DirectionSample ds;
+        V3 emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds);
+        if (ds.pdf != 0.f) {
+            V3 wo = to_local(si.sh, ds.d);
+            V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);
+            float bpdf = bsdf_pdf(bsdf, si.wi, wo);
+            float mis = mis_weight(ds.pdf, bpdf);
+            V3 c = mis * L.tp * bsdf_val * emitter_val;
+            if (!all_zero(c)) {
+                // shadow ray, scene.cpp:203-205
+                sh.has = true; sh.d = ds.d; sh.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON); sh.c = c;
+                if (cnt_local) cnt_local->shadow_rays++;
+            }
+        }
+    }
+
+    // ---- BSDF sampling, :177-186 (Clang order: next_1d, then next_2d) ----
+    float s1 = next_1d(L.rng);
+    V2 s2 = next_2d(L.rng);
+    BSDFSample bs;
+    V3 bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs);
+    L.tp = L.tp * bsdf_val;
+    if (all_zero(L.tp))                              // :182-184
+        return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;
+    L.eta *= bs.eta;                                 // :186
+    L.ray.d = to_world(si.sh, bs.wo);                // :189, interaction.h:58-61
+    L.ray.maxt = MIW_INFINITY;
+    L.prev_pdf = bs.pdf;
+    L.flags = (L.flags & ~(LF_DEPTH_MASK | LF_PREV_DELTA)) | ((depth + 1) & LF_DEPTH_MASK)
+            | ((bs.sampled_type & BSDF_Delta) ? LF_PREV_DELTA : 0u) | LF_RAY_ACTIVE;
+    return STEP_CONTINUE;
+}
+
+// Stage 2 of the HBM-queue plan: one iteration of the depth loop for one lane.
 // Returns true while the lane still has work (not DONE).
 template <typename Sink>
 MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
@@ -212,108 +318,21 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
     if (L.flags & LF_DEAD_PENDING) {
         finished = true;
     } else {
-        const uint32_t depth = L.flags & LF_DEPTH_MASK;
-        F4 h = Q.hit[lane];
-        const uint32_t tri_idx = f2u(h.w);
-        const bool valid = tri_idx != MIW_MISS;
         F4 rd = Q.ray_d[lane];
-        V3 ray_d = v3(rd.x, rd.y, rd.z);
-
-        SurfaceInteraction si;
-        uint32_t bsdf_index = 0;
-        int32_t emitter = -1;                            // scene.h:243-253 (no environment emitter)
-        if (valid) {
-            const Tri &tr = sc.tris[tri_idx];
-            const ShapeRec &shape = sc.shapes[tr.shape];
-            const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
-            si.shape = tr.shape; si.prim = tr.prim;
-            emitter = shape.emitter; bsdf_index = shape.bsdf;
+        L.ray.d = v3(rd.x, rd.y, rd.z);
+        ShadowOut sh;
+        const int r = path_step(P, sc, L, Q.hit[lane],
+                                [&]() { F4 ro = Q.ray_o[lane]; return v3(ro.x, ro.y, ro.z); }, sh, cnt_local);
+        if (sh.has) {
+            F4 sd; sd.x = sh.d.x; sd.y = sh.d.y; sd.z = sh.d.z; sd.w = sh.maxt;
+            Q.sh_d[lane] = sd;
+            F4 sc4; sc4.x = sh.c.x; sc4.y = sh.c.y; sc4.z = sh.c.z; sc4.w = 0.f;
+            Q.sh_c[lane] = sc4;
+            L.flags |= LF_HAS_SHADOW;
         }
-        if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
-
-        // ---- intersection with emitters, path.cpp:126-129 ----
-        if (emitter >= 0) {
-            float emission_weight = 1.f;                 // :109
-            if (depth > 1) {                             // :194-205, evaluated lazily
-                float emitter_pdf = 0.f;
-                if (!(L.flags & LF_PREV_DELTA)) {
-                    // DirectionSample3f ds(si_bsdf, si), records.h:167-173
-                    F4 ro = Q.ray_o[lane];               // previous vertex: only this MIS term needs it
-                    V3 d = si.p - v3(ro.x, ro.y, ro.z);
-                    float dist = norm(d);
-                    d = d / dist;
-                    emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, si.sh.n);
-                }
-                emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
-            }
-            L.res = L.res + emission_weight * L.tp * emitter_eval(sc.emitters[emitter], si.wi);
-        }
-
-        bool active = valid;                             // :131
-
-        // ---- Russian roulette, :137-141 (the draw happens even for dead paths) ----
-        if ((int32_t) depth > P.rr_depth) {
-            float q = min_(hmax(L.tp) * sqr(L.eta), .95f);
-            active = (next_1d(L.rng) < q) && active;
-            L.tp = L.tp * rcp(q);
-        }
-
-        // ---- termination, :147-149 ----
-        if (depth >= (uint32_t) P.max_depth || !active) {
-            finished = true;
-        } else {
-            if (cnt_local) cnt_local->segments++;
-            const BsdfRec &bsdf = sc.bsdfs[bsdf_index];
-            const uint32_t bflags = bsdf_flags(bsdf);
-            L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
-            L.ray.d = v3(0.f); L.ray.maxt = -1.f;
-
-            // ---- emitter sampling, :155-172 ----
-            if (bflags & BSDF_Smooth) {
-                DirectionSample ds;
-                V3 emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds);
-                if (ds.pdf != 0.f) {
-                    V3 wo = to_local(si.sh, ds.d);
-                    V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);
-                    float bpdf = bsdf_pdf(bsdf, si.wi, wo);
-                    float mis = mis_weight(ds.pdf, bpdf);
-                    V3 c = mis * L.tp * bsdf_val * emitter_val;
-                    if (!all_zero(c)) {
-                        // shadow ray, scene.cpp:203-205
-                        F4 sd; sd.x = ds.d.x; sd.y = ds.d.y; sd.z = ds.d.z;
-                        sd.w = ds.dist * (1.f - MIW_SHADOW_EPSILON);
-                        Q.sh_d[lane] = sd;
-                        F4 sc4; sc4.x = c.x; sc4.y = c.y; sc4.z = c.z; sc4.w = 0.f;
-                        Q.sh_c[lane] = sc4;
-                        L.flags |= LF_HAS_SHADOW;
-                        if (cnt_local) cnt_local->shadow_rays++;
-                    }
-                }
-            }
-
-            // ---- BSDF sampling, :177-186 (Clang order: next_1d, then next_2d) ----
-            float s1 = next_1d(L.rng);
-            V2 s2 = next_2d(L.rng);
-            BSDFSample bs;
-            V3 bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs);
-            L.tp = L.tp * bsdf_val;
-            if (all_zero(L.tp)) {                        // :182-184
-                if (L.flags & LF_HAS_SHADOW) {
-                    // the sample ends once its last shadow ray has been resolved
-                    L.flags = (L.flags & ~LF_RAY_ACTIVE) | LF_DEAD_PENDING;
-                } else {
-                    finished = true;
-                }
-            } else {
-                L.eta *= bs.eta;                         // :186
-                L.ray.d = to_world(si.sh, bs.wo);        // :189, interaction.h:58-61
-                L.ray.maxt = MIW_INFINITY;
-                L.prev_pdf = bs.pdf;
-                L.flags = (L.flags & ~(LF_DEPTH_MASK | LF_PREV_DELTA)) | ((depth + 1) & LF_DEPTH_MASK)
-                        | ((bs.sampled_type & BSDF_Delta) ? LF_PREV_DELTA : 0u) | LF_RAY_ACTIVE;
-            }
-        }
+        if (r == STEP_FINISHED) finished = true;
+        else if (r == STEP_DEAD_PENDING)             // the sample ends once its last shadow ray is resolved
+            L.flags = (L.flags & ~LF_RAY_ACTIVE) | LF_DEAD_PENDING;
     }
 
     bool store_pos = false;
@@ -324,12 +343,53 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
         lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
-        lane_begin_sample(P, pixel, L);
+        lane_begin_sample(P, pixel, L, P.spp);
         store_pos = true;
     }
     lane_store(Q, lane, L, store_pos);
     if (had_shadow && !(L.flags & LF_HAS_SHADOW)) lane_clear_shadow(Q, lane);
     return !(L.flags & LF_DONE);
+}
+
+// The register-resident plan: a run of one pixel's sample loop (render_block's inner
+// loops, integrator.cpp:196-209) with every Scene::ray_intersect / ray_test call made
+// in place: `closest(o, d, mint, maxt) -> F4 hit record`, `occluded(o, d, mint, maxt) -> bool`.
+// A pixel's only state between two camera samples is its PCG32 state and its sample
+// counter (st: state lo, hi, flags, index), so a pixel can be advanced in passes:
+// this call runs samples [st.w, sample_end) and returns the updated st word.
+// The float additions into `result` happen in the reference's order by construction
+// (emission term, then the emitter-sampling term of the same vertex, path.cpp:126-172).
+template <typename Closest, typename Occluded, typename Sink>
+MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
+                       Closest closest, Occluded occluded, Sink sink, Counters *cnt_local) {
+    LaneRegs L;
+    L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
+    L.rng.inc = MIW_PCG32_SCALAR_INC;
+    L.sample_idx = st.w; L.flags = 0;
+    lane_begin_sample(P, pixel, L, sample_end);
+    while (!(L.flags & LF_DONE)) {
+        const V3 o = L.ray.o;
+        F4 h = closest(o, L.ray.d, L.ray.mint, L.ray.maxt);
+        ShadowOut sh;
+        const int r = path_step(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
+        if (sh.has && !occluded(L.ray.o, sh.d, L.ray.mint, sh.maxt)) L.res = L.res + sh.c;
+        if (r != STEP_CONTINUE) {
+            lane_finish_sample(P, pixel, L, sink);
+            if (cnt_local) cnt_local->samples++;
+            L.flags = 0;
+            lane_begin_sample(P, pixel, L, sample_end);
+        }
+    }
+    st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
+    st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;
+    return st;
+}
+
+// Seed word of a fresh lane (sampler.cpp:83-96 via integrator.cpp:198)
+MIW_HD U4 lane_seed_state(uint64_t seed) {
+    PCG32 r; pcg32_seed(r, seed, MIW_PCG32_DEFAULT_STREAM);
+    U4 st; st.x = (uint32_t) r.state; st.y = (uint32_t) (r.state >> 32); st.z = 0; st.w = 0;
+    return st;
 }
 
 } // namespace miw

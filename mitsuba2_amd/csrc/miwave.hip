@@ -223,6 +223,73 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     }
 }
 
+// ---- the resident plan -----------------------------------------------------------------
+// k_init_pixels: pixel <-> lane map and PCG32 seeding only (a pixel carries nothing else
+// between two camera samples).
+__global__ __launch_bounds__(MIW_BLOCK) void k_init_pixels(RenderParams P, U4 *st_out, uint32_t *pixel_out, InitArgs A) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= P.n_lanes) return;
+    uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
+    uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
+    uint32_t x, y;
+    morton_decode2(i, x, y);                                   // integrator.cpp:200
+    int32_t bw = P.film.crop_w - (int32_t) (bx * A.bs), bh = P.film.crop_h - (int32_t) (by * A.bs);
+    if (bw > (int32_t) A.bs) bw = (int32_t) A.bs;
+    if (bh > (int32_t) A.bs) bh = (int32_t) A.bs;
+    if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
+        U4 st; st.x = st.y = 0; st.z = LF_DONE; st.w = 0;
+        st_out[lane] = st; pixel_out[lane] = 0;
+        return;
+    }
+    uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
+    pixel_out[lane] = px | (py << 16);
+    st_out[lane] = lane_seed_state(A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i);   // :198
+}
+
+// k_path_resident: one thread = one pixel, advanced from its current sample to `sample_end`.
+// Path state, ray, hit record and the pending emitter contribution never leave registers;
+// the geometry is swept / walked in LDS (trace_one); HBM sees 20 B of pixel state per launch
+// and the 24 B/sample log (or the film atomics).
+template <bool UseLog>
+__global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+                                                               TraceLds cfg, uint32_t sample_end) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    if (lane < P.n_lanes) {
+        U4 st = Q.st[lane];
+        if (!(st.z & LF_DONE)) {
+            const uint32_t pixel = Q.pixel[lane];
+            auto closest = [&](V3 o, V3 d, float mint, float maxt) {
+                Hit h; F4 r;
+                if (maxt < 0.f) { r.x = MIW_INFINITY; r.y = r.z = 0.f; r.w = u2f(MIW_MISS); return r; }
+                trace_one<false>(sc, cfg, smem, o, d, mint, maxt, h);
+                r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
+                return r;
+            };
+            auto occluded = [&](V3 o, V3 d, float mint, float maxt) { Hit h; return trace_one<true>(sc, cfg, smem, o, d, mint, maxt, h); };
+            if (UseLog) {
+                LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
+                st = pixel_render(P, sc, pixel, st, sample_end, closest, occluded, sink, &local);
+            } else {
+                FilmAdd add; add.accum = accum;
+                SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
+                st = pixel_render(P, sc, pixel, st, sample_end, closest, occluded, sink, &local);
+            }
+            Q.st[lane] = st;
+        }
+    }
+    unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
+    if ((threadIdx.x & 63) == 0) {
+        Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
+        if (a) atomicAdd(&shard->segments, a);
+        if (b) atomicAdd(&shard->samples, b);
+        if (c) atomicAdd(&shard->shadow_rays, c);
+    }
+}
+
 __global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -779,11 +846,20 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     auto wall0 = std::chrono::steady_clock::now();
     c->cancel.store(0);
 
+    // execution plan
+    int plan = cfg->plan;
+    if (plan < 0 || plan > 2) return fail(c, MI_ERR_INVALID, "render: plan must be 0, 1 or 2");
+    const bool lds_resident = c->lds_cfg.brute || (c->lds_cfg.nodes_staged >= c->view.node_count && c->lds_cfg.tris_staged >= c->view.tri_count);
+    if (plan == 0) plan = lds_resident ? 2 : 1;
+    c->counters.plan = (uint32_t) plan;
+
     size_t nl = std::max<uint32_t>(n_lanes, 1);
-    HIP_TRY(c, c->q_tp.resize(nl)); HIP_TRY(c, c->q_res.resize(nl)); HIP_TRY(c, c->q_ray_o.resize(nl));
-    HIP_TRY(c, c->q_ray_d.resize(nl)); HIP_TRY(c, c->q_hit.resize(nl)); HIP_TRY(c, c->q_sh_d.resize(nl));
-    HIP_TRY(c, c->q_sh_c.resize(nl)); HIP_TRY(c, c->q_st.resize(nl)); HIP_TRY(c, c->q_pos.resize(nl));
-    HIP_TRY(c, c->q_pixel.resize(nl)); HIP_TRY(c, c->q_sh_vis.resize(nl));
+    HIP_TRY(c, c->q_st.resize(nl)); HIP_TRY(c, c->q_pixel.resize(nl));
+    if (plan == 1) {
+        HIP_TRY(c, c->q_tp.resize(nl)); HIP_TRY(c, c->q_res.resize(nl)); HIP_TRY(c, c->q_ray_o.resize(nl));
+        HIP_TRY(c, c->q_ray_d.resize(nl)); HIP_TRY(c, c->q_hit.resize(nl)); HIP_TRY(c, c->q_sh_d.resize(nl));
+        HIP_TRY(c, c->q_sh_c.resize(nl)); HIP_TRY(c, c->q_pos.resize(nl)); HIP_TRY(c, c->q_sh_vis.resize(nl));
+    }
     HIP_TRY(c, c->d_cnt.resize(MIW_CNT_SHARDS));
     HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, sizeof(Counters) * MIW_CNT_SHARDS, s));
 
@@ -824,8 +900,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
-    K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = 0;
+    K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = 0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0;
 
     // event pool for per-launch timing
     struct Stamp { int cls; size_t e0, e1; };
@@ -849,6 +925,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 case 1: K.ms_trace_any += ms; break;
                 case 2: K.ms_shade += ms; break;
                 case 3: K.ms_init += ms; break;
+                case 6: K.ms_path += ms; break;
+                case 4: K.ms_film_blocks += ms; K.ms_resolve += ms; break;
+                case 5: K.ms_film_merge += ms; K.ms_resolve += ms; break;
                 default: K.ms_resolve += ms; break;
             }
         }
@@ -863,7 +942,52 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     } while (0)
 
     mi_status result = MI_OK;
-    if (n_lanes > 0) {
+    auto read_counters = [&](Counters &sum) -> mi_status {
+        HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, sizeof(Counters) * MIW_CNT_SHARDS, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        sum.segments = sum.samples = sum.shadow_rays = sum.active_lanes = 0;
+        for (int i = 0; i < MIW_CNT_SHARDS; ++i) {
+            sum.segments += c->h_cnt[i].segments; sum.samples += c->h_cnt[i].samples;
+            sum.shadow_rays += c->h_cnt[i].shadow_rays; sum.active_lanes += c->h_cnt[i].active_lanes;
+        }
+        K.samples = sum.samples; K.segments = sum.segments; K.shadow_rays = sum.shadow_rays;
+        return MI_OK;
+    };
+    auto out_of_time = [&]() {
+        return cfg->timeout_s > 0.f &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > cfg->timeout_s;
+    };
+    if (n_lanes > 0 && plan == 2) {
+        // ---- resident plan: every pixel advances `per_launch` samples per launch ----
+        dim3 grid((n_lanes + MIW_BLOCK - 1) / MIW_BLOCK), block(MIW_BLOCK);
+        InitArgs A; A.block_ids = c->d_block_ids.p; A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
+        A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
+        MIW_TIMED(3, hipLaunchKernelGGL(k_init_pixels, grid, block, 0, s, P, c->q_st.p, c->q_pixel.p, A));
+        HIP_TRY(c, hipGetLastError());
+        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 32u;
+        const uint32_t sync_every = 8;
+        uint32_t launches = 0;
+        for (uint32_t done = 0; done < cfg->spp; ) {
+            const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
+            if (film_mode == 1)
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, grid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end));
+            else
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end));
+            K.n_path++; K.iterations++;
+            done = end;
+            if (++launches % sync_every == 0 && done < cfg->spp) {
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipStreamSynchronize(s));
+                if (cfg->profile) drain_stamps();
+                if (c->cancel.load() || out_of_time()) { result = MI_ERR_CANCELLED; break; }
+            }
+        }
+        HIP_TRY(c, hipGetLastError());
+        Counters sum;
+        mi_status rs = read_counters(sum);
+        if (rs != MI_OK) return rs;
+        if (cfg->profile) drain_stamps();
+    } else if (n_lanes > 0) {
         dim3 grid((n_lanes + MIW_BLOCK - 1) / MIW_BLOCK), block(MIW_BLOCK);
         InitArgs A; A.block_ids = c->d_block_ids.p; A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
@@ -890,24 +1014,16 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 first = false;
             }
             HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, sizeof(Counters) * MIW_CNT_SHARDS, hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            Counters sum;
+            mi_status rs = read_counters(sum);
+            if (rs != MI_OK) return rs;
             if (cfg->profile) drain_stamps();
-            Counters sum; sum.segments = sum.samples = sum.shadow_rays = sum.active_lanes = 0;
-            for (int i = 0; i < MIW_CNT_SHARDS; ++i) {
-                sum.segments += c->h_cnt[i].segments; sum.samples += c->h_cnt[i].samples;
-                sum.shadow_rays += c->h_cnt[i].shadow_rays; sum.active_lanes += c->h_cnt[i].active_lanes;
-            }
-            K.samples = sum.samples; K.segments = sum.segments; K.shadow_rays = sum.shadow_rays;
             // active_lanes accumulates over the counting launches: the last one's share is the delta
             unsigned long long active_now = sum.active_lanes - active_prev;
             active_prev = sum.active_lanes;
             if (active_now == 0) break;
             if (c->cancel.load()) { result = MI_ERR_CANCELLED; break; }
-            if (cfg->timeout_s > 0.f &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > cfg->timeout_s) {
-                result = MI_ERR_CANCELLED; break;
-            }
+            if (out_of_time()) { result = MI_ERR_CANCELLED; break; }
         }
     }
 

@@ -640,6 +640,7 @@ void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_
     for (int i = 0; i < 32; ++i) cfg.filter_lut[i] = rf->values()[i];
     cfg.filter_radius = rf->radius(); cfg.filter_border = (int32_t) rf->border_size();
     cfg.timeout_s = m_timeout; cfg.profile = m_profile ? 1 : 0;
+    cfg.plan = m_plan;
 }
 
 bool PathIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
@@ -801,6 +802,7 @@ void *mih_integrator_create(void *props) {
 void mih_integrator_destroy(void *i) { delete (Box<PathIntegrator> *) i; }
 void mih_integrator_set_shard(void *i, uint32_t rank, uint32_t world) { ((Box<PathIntegrator> *) i)->p->set_shard(rank, world); }
 void mih_integrator_set_profile(void *i, int on) { ((Box<PathIntegrator> *) i)->p->set_profile(on != 0); }
+void mih_integrator_set_plan(void *i, int plan) { ((Box<PathIntegrator> *) i)->p->set_plan(plan); }
 void mih_integrator_cancel(void *i) { ((Box<PathIntegrator> *) i)->p->cancel(); }
 // 1 = finished, 0 = cancelled / timed out, -1 = error
 int mih_integrator_render(void *i, void *scene, void *sensor) {

@@ -294,11 +294,14 @@ public:
                          uint32_t n_threads_hint = 1) const;
     const mi_counters &counters() const { return m_counters; }
     void set_profile(bool p) { m_profile = p; }
+    // execution plan of the device sample loop (mi_render_cfg::plan): 0 auto, 1 wavefront, 2 resident
+    void set_plan(int plan) { m_plan = plan; }
 private:
     uint32_t m_block_size; uint32_t m_samples_per_pass; float m_timeout; bool m_hide_emitters;
     int m_max_depth, m_rr_depth;
     uint32_t m_rank = 0, m_world = 1;
     bool m_profile = false;
+    int m_plan = 0;
     std::atomic<mi_ctx *> m_active_ctx{nullptr};
     mi_counters m_counters{};
 };

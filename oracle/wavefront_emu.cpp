@@ -173,6 +173,41 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     auto add = [film64](int texel, int k, float v) { film64[(size_t) texel * 5 + k] += (double) v; };
     Counters cnt; std::memset(&cnt, 0, sizeof cnt);
     uint64_t iterations = 0;
+    if (cfg->plan == 2) {
+        // the resident plan (k_init_pixels + k_path_resident): every pixel advanced
+        // `samples_per_launch` samples per pass, state between passes = st word only
+        for (uint32_t lane = 0; lane < n_lanes; ++lane) {
+            if (st[lane].z & LF_DONE) { st[lane].x = st[lane].y = st[lane].w = 0; continue; }
+            uint32_t tile = lane / bs2, i = lane % bs2;
+            uint32_t b = cfg->tile_list ? cfg->tile_list[tile] : tile;
+            st[lane] = lane_seed_state(cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
+        }
+        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 32u;
+        auto closest = [&](V3 o, V3 d, float mint, float maxt) {
+            Hit h; RayPrep rp = ray_prepare(o, d, mint, maxt);
+            bvh_intersect<false>(node_at, tri_at, rp, h);
+            F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri); return r;
+        };
+        auto occluded = [&](V3 o, V3 d, float mint, float maxt) {
+            Hit h; RayPrep rp = ray_prepare(o, d, mint, maxt);
+            return bvh_intersect<true>(node_at, tri_at, rp, h);
+        };
+        for (uint32_t done = 0; done < cfg->spp; ) {
+            const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
+            for (uint32_t lane = 0; lane < n_lanes; ++lane) {
+                if (st[lane].z & LF_DONE) continue;
+                SplatSink<decltype(add)> splat{ &P.film, add };
+                LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp };
+                bool do_log = film32 != nullptr;
+                auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
+                    splat(pixel, sample_idx, pos, aovs);
+                    if (do_log) log(pixel, sample_idx, pos, aovs);
+                };
+                st[lane] = pixel_render(P, sc.view, pixel[lane], st[lane], end, closest, occluded, sink, &cnt);
+            }
+            done = end; ++iterations;
+        }
+    } else
     for (;;) {
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_trace<any>
             F4 d = sh_d[lane]; if (d.w < 0.f) continue;

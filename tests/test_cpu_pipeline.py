@@ -37,6 +37,22 @@ def test_wavefront_stages_equal_scalar_path_integrator(native, oracle, diffuse_o
     assert st.segments / st.samples > 2.0 and np.isfinite(o32).all() and o32[..., 4].min() > 0
 
 
+@pytest.mark.parametrize("per_launch", [1, 4, 5, 64])
+def test_resident_plan_equals_scalar_path_integrator(native, oracle, per_launch):
+    """pixel_render (the resident plan's per-pixel sample loop), advanced in passes of `per_launch`
+    samples with only the PCG32 state carried between passes, == the scalar oracle, bit for bit."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(40, 36, 10, diffuse_only=False, device=-1, ball_level=1)
+    job = native.PathIntegrator().render_job(sensor)
+    job.cfg.plan = 2; job.cfg.samples_per_launch = per_launch
+    o32, o64, st = oracle.render(scene.desc(), job, threads=4)
+    e64, e32, est = oracle.emu_render(scene.desc(), job)
+    assert est[0] == st.samples == 40 * 36 * 10 and est[1] == st.segments
+    assert est[3] == -(-10 // per_launch)                           # launches
+    assert np.array_equal(e32, o32)
+    assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
+
+
 @pytest.mark.parametrize("kw", [dict(max_depth=1), dict(max_depth=2), dict(max_depth=3, rr_depth=1), dict(rr_depth=2)])
 def test_depth_and_rr_variants(native, oracle, kw):
     from mitsuba2_amd import scenes

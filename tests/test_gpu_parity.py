@@ -168,13 +168,18 @@ def _render_both(native, oracle, dev, scene, sensor, **integ_kw):
     job = integ.render_job(sensor)
     dev.upload(scene.desc())
     o32, o64, ost = oracle.render(scene.desc(), job, threads=8)
-    g32, st = dev.render(job)                      # auto -> sample log + ordered gather
-    assert st == 0 and dev.counters().film_mode == 1
-    assert dev.counters().samples == ost.samples and dev.counters().segments == ost.segments
-    assert np.array_equal(g32, o32), "ordered-gather film is not bit-identical: rel L2 %g" % rel_l2(g32, o32)
-    g64, st = dev.render(job, f64=True, film_mode=2)
-    assert st == 0 and dev.counters().film_mode == 2
-    cnt = dev.counters()
+    g64 = cnt = None
+    for plan, spl in ((1, 0), (2, 0), (2, 3)):     # wavefront (HBM queues) / resident / resident in 3-sample passes
+        g32, st = dev.render(job, plan=plan, samples_per_launch=spl)   # film auto -> sample log + ordered gather
+        c = dev.counters()
+        assert st == 0 and c.film_mode == 1 and c.plan == plan
+        assert c.samples == ost.samples and c.segments == ost.segments
+        assert np.array_equal(g32, o32), "plan %d: ordered-gather film is not bit-identical: rel L2 %g" % (plan, rel_l2(g32, o32))
+        g64p, st = dev.render(job, f64=True, film_mode=2, plan=plan, samples_per_launch=spl)
+        assert st == 0 and dev.counters().film_mode == 2 and dev.counters().plan == plan
+        if g64 is not None:                        # float64 atomics: order-free to float32 precision
+            assert np.array_equal(g64p.astype(np.float32), g64.astype(np.float32))
+        g64, cnt = g64p, dev.counters()
     return g64, o32, o64, cnt, ost
 
 
