@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "matball"],
+                    help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
+                         "dielectric balls, 41k triangles; quoted at 1024 spp)")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
     ap.add_argument("--samples-per-launch", type=int, default=0, help="resident plan: samples each pixel advances per launch")
     args = ap.parse_args()
@@ -61,7 +64,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     W, H, SPP = args.width, args.height, args.spp
-    scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=True, device=-1)
+    scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
     dev = api.Device(local_rank)
     dev.upload(scene.desc())                                 # scene + BVH resident before timing
     integ = api.PathIntegrator()
@@ -153,8 +156,11 @@ def main():
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
-                                   "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" % (W, H, SPP),
+            "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
+                                    "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
+                                    "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, 40972 "
+                                    "triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
+                                    "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
                        "parallelism": "tile-shard x%d + RCCL film reduce" % world if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},

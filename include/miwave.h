@@ -204,7 +204,8 @@ enum {
     MI_EVAL_FRESNEL = 4,          /* in: cos_theta_i, eta                out: r,cos_t,eta_it,eta_ti */
     MI_EVAL_CAMERA_RAY = 5,       /* in: x,y (film sample)               out: o.xyz,d.xyz,mint,maxt */
     MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2                 out: d.xyz,dist,pdf,spec.rgb,p.xyz,n.xyz (14) */
-    MI_EVAL_FP_SEMANTICS = 7      /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
+    MI_EVAL_FP_SEMANTICS = 7,     /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
+    MI_EVAL_SPECIAL = 8           /* in: x                               out: exp, log, erf, erfinv (miw/special.h)   */
 };
 mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
                   const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);

@@ -72,8 +72,8 @@ class mi_counters(C.Structure):
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
 MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
-               FP_SEMANTICS=7)
-MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8)}
+               FP_SEMANTICS=7, SPECIAL=8)
+MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8), 8: (1, 4)}
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
 MI_SYMBOLS = ["mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",

@@ -8,6 +8,7 @@
 #pragma once
 #include "base.h"
 #include "warp.h"
+#include "special.h"
 #include "shape.h"
 
 namespace miw {
@@ -97,13 +98,18 @@ MIW_HD Microfacet microfacet_make(uint32_t type, float au, float av, bool sv) {
     return d;
 }
 
-// :184-202 — only GGX is evaluated on device this round; Beckmann needs exp()
+// :184-202
 MIW_HD float mf_eval(const Microfacet &d, V3 m) {
     float alpha_uv = d.alpha_u * d.alpha_v,
           cos_theta = m.z,
+          cos_theta_2 = sqr(cos_theta),
           result;
-    result = rcp(MIW_PI * alpha_uv *
-                 sqr(sqr(m.x / d.alpha_u) + sqr(m.y / d.alpha_v) + sqr(m.z)));
+    if (d.type == MF_BECKMANN)
+        result = exp_(-(sqr(m.x / d.alpha_u) + sqr(m.y / d.alpha_v)) / cos_theta_2)
+                 / (MIW_PI * alpha_uv * sqr(cos_theta_2));
+    else
+        result = rcp(MIW_PI * alpha_uv *
+                     sqr(sqr(m.x / d.alpha_u) + sqr(m.y / d.alpha_v) + sqr(m.z)));
     return (result * cos_theta > 1e-20f) ? result : 0.f;
 }
 
@@ -112,7 +118,13 @@ MIW_HD float mf_smith_g1(const Microfacet &d, V3 v, V3 m) {
     float xy_alpha_2 = sqr(d.alpha_u * v.x) + sqr(d.alpha_v * v.y),
           tan_theta_alpha_2 = xy_alpha_2 / sqr(v.z),
           result;
-    result = 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
+    if (d.type == MF_BECKMANN) {
+        float a = rsqrt(tan_theta_alpha_2), a_sqr = sqr(a);
+        result = a >= 1.6f ? 1.f
+                           : (3.535f * a + 2.181f * a_sqr) / (1.f + 2.276f * a + 2.577f * a_sqr);
+    } else {
+        result = 2.f / (1.f + __builtin_sqrtf(1.f + tan_theta_alpha_2));
+    }
     if (xy_alpha_2 == 0.f) result = 1.f;
     if (dot(v, m) * v.z <= 0.f) result = 0.f;
     return result;
@@ -121,9 +133,25 @@ MIW_HD float mf_G(const Microfacet &d, V3 wi, V3 wo, V3 m) {      // :319-321
     return mf_smith_g1(d, wi, m) * mf_smith_g1(d, wo, m);
 }
 
-// :358-411, GGX branch :396-410
-MIW_HD V2 mf_sample_visible_11(float cos_theta_i, V2 sample) {
-    V2 p = square_to_uniform_disk_concentric(sample);
+// :358-411
+MIW_HD V2 mf_sample_visible_11(uint32_t type, float cos_theta_i, V2 sample) {
+    if (type == MF_BECKMANN) {                                     // :359-395
+        float tan_theta_i = safe_sqrt(fnmadd(cos_theta_i, cos_theta_i, 1.f)) / cos_theta_i;
+        float cot_theta_i = rcp(tan_theta_i);
+        float maxval = erf_(cot_theta_i);
+        sample.x = max_(min_(sample.x, 1.f - 1e-6f), 1e-6f);
+        sample.y = max_(min_(sample.y, 1.f - 1e-6f), 1e-6f);
+        float x = maxval - (maxval + 1.f) * erf_(__builtin_sqrtf(-log_(sample.x)));
+        sample.x *= 1.f + maxval + MIW_INV_SQRT_PI * tan_theta_i * exp_(-sqr(cot_theta_i));
+        for (int i = 0; i < 3; ++i) {                              // three Newton iterations
+            float slope = erfinv_(x),
+                  value = 1.f + x + MIW_INV_SQRT_PI * tan_theta_i * exp_(-sqr(slope)) - sample.x,
+                  derivative = 1.f - slope * tan_theta_i;
+            x -= value / derivative;
+        }
+        return v2(erfinv_(x), erfinv_(fmsub(2.f, sample.y, 1.f)));
+    }
+    V2 p = square_to_uniform_disk_concentric(sample);              // :396-410
     float s = .5f * (1.f + cos_theta_i);
     p.y = lerp_(safe_sqrt(1.f - sqr(p.x)), p.y, s);
     float x = p.x, y = p.y,
@@ -158,12 +186,19 @@ MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &p
             sin_phi = cos_phi * tmp;
             alpha_2 = rcp(sqr(cos_phi / d.alpha_u) + sqr(sin_phi / d.alpha_v));
         }
-        float tan_theta_m_2 = alpha_2 * sample.x / (1.f - sample.x);
-        cos_theta = rsqrt(1.f + tan_theta_m_2);
-        cos_theta_2 = sqr(cos_theta);
-        float temp = 1.f + tan_theta_m_2 / alpha_2,
-              cos_theta_3 = max_(cos_theta_2 * cos_theta, 1e-20f);
-        pdf = rcp(MIW_PI * d.alpha_u * d.alpha_v * cos_theta_3 * sqr(temp));
+        if (d.type == MF_BECKMANN) {                      // :258-266
+            cos_theta = rsqrt(fnmadd(alpha_2, log_(1.f - sample.x), 1.f));
+            cos_theta_2 = sqr(cos_theta);
+            float cos_theta_3 = max_(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = (1.f - sample.x) / (MIW_PI * d.alpha_u * d.alpha_v * cos_theta_3);
+        } else {                                          // :267-277
+            float tan_theta_m_2 = alpha_2 * sample.x / (1.f - sample.x);
+            cos_theta = rsqrt(1.f + tan_theta_m_2);
+            cos_theta_2 = sqr(cos_theta);
+            float temp = 1.f + tan_theta_m_2 / alpha_2,
+                  cos_theta_3 = max_(cos_theta_2 * cos_theta, 1e-20f);
+            pdf = rcp(MIW_PI * d.alpha_u * d.alpha_v * cos_theta_3 * sqr(temp));
+        }
         float sin_theta = __builtin_sqrtf(1.f - cos_theta_2);
         m_out = v3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
         pdf_out = pdf;
@@ -172,7 +207,7 @@ MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &p
         V3 wi_p = normalize(v3(d.alpha_u * wi.x, d.alpha_v * wi.y, wi.z));   // step 1
         sincos_phi(wi_p, sin_phi, cos_phi);
         cos_theta = wi_p.z;
-        V2 slope = mf_sample_visible_11(cos_theta, sample);                  // step 2
+        V2 slope = mf_sample_visible_11(d.type, cos_theta, sample);                  // step 2
         slope = v2(fmsub(cos_phi, slope.x, sin_phi * slope.y) * d.alpha_u,   // step 3
                    fmadd(sin_phi, slope.x, cos_phi * slope.y) * d.alpha_v);
         V3 m = normalize(v3(-slope.x, -slope.y, 1.f));                       // step 4

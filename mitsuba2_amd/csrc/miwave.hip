@@ -27,6 +27,7 @@
 #include "miw/base.h"
 #include "miw/rng.h"
 #include "miw/warp.h"
+#include "miw/special.h"
 #include "miw/shape.h"
 #include "miw/bsdf.h"
 #include "miw/scene.h"
@@ -486,6 +487,7 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             o[0] = x + y; o[1] = x * y; o[2] = x / y; o[3] = __builtin_sqrtf(abs_(x));
             o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
         } break;
+        case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
     }
 }
 
@@ -656,10 +658,6 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         const mi_bsdf &b = s->bsdfs[i];
         if (b.type > MI_BSDF_ROUGHCONDUCTOR) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
-        if (b.type == MI_BSDF_ROUGHCONDUCTOR) {
-            if (!(b.flags & MI_BSDF_FLAG_GGX))
-                return fail(c, MI_ERR_INVALID, "bsdf %u: roughconductor distribution 'beckmann' is not implemented on the device; use 'ggx'", i);
-        }
         BsdfRec r; r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
         c->bsdfs[i] = r;
     }

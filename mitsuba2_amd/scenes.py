@@ -96,7 +96,7 @@ def icosphere(center, radius, level):
     return p.astype(np.float32), f.astype(np.uint32), n.astype(np.float32)
 
 
-def cornell_box_meshes(diffuse_only=True, ball_level=5):
+def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None):
     """-> list of api.Mesh. diffuse_only: the classic box (36 triangles, config C2).
     Otherwise the short block becomes a GGX rough-conductor ball with shading normals
     and the tall block a dielectric (bk7) ball — the material-ball configuration (C3)."""
@@ -113,8 +113,11 @@ def cornell_box_meshes(diffuse_only=True, ball_level=5):
         v, f = _block(_SHORT); meshes.append(api.Mesh("short_block", v, f, bsdf=white))
         v, f = _block(_TALL); meshes.append(api.Mesh("tall_block", v, f, bsdf=white))
     else:
-        metal = api.BSDF("roughconductor", distribution="ggx", alpha=0.1,
-                         eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+        mkw = dict(distribution="ggx", alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+        mkw.update(metal or {})
+        if "alpha_u" in mkw:
+            mkw.pop("alpha", None)
+        metal = api.BSDF("roughconductor", **mkw)
         glass = api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)
         v, f, n = icosphere((185.0, 82.5, 169.0), 82.5, ball_level)
         meshes.append(api.Mesh("metal_ball", v, f, normals=n, bsdf=metal))
@@ -132,9 +135,10 @@ def cornell_sensor(width, height, spp, seed=0, rfilter="gaussian", **film_kw):
 
 
 def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_level=5, rfilter="gaussian",
-                **film_kw):
-    """-> (scene, sensor). device < 0 builds only the host-side description."""
-    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level)).build(device)
+                metal=None, **film_kw):
+    """-> (scene, sensor). device < 0 builds only the host-side description.
+    `metal`: property overrides of the rough-conductor ball (e.g. dict(distribution="beckmann"))."""
+    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level, metal)).build(device)
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 

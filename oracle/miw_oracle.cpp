@@ -42,6 +42,7 @@
 #include "../mitsuba2_amd/csrc/miw/base.h"
 #include "../mitsuba2_amd/csrc/miw/rng.h"
 #include "../mitsuba2_amd/csrc/miw/warp.h"
+#include "../mitsuba2_amd/csrc/miw/special.h"
 #include "../mitsuba2_amd/csrc/miw/shape.h"
 #include "../mitsuba2_amd/csrc/miw/bsdf.h"
 #include "../mitsuba2_amd/csrc/miw/scene.h"
@@ -575,6 +576,11 @@ void orc_microfacet(int op, uint32_t type, float au, float av, int sample_visibl
         default: { V3 m; float pdf; mf_sample(d, w, v2(m_or_u[0], m_or_u[1]), m, pdf); out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf; }
     }
 }
+// special.h restatements: out4 = exp, log, erf, erfinv of x
+void orc_special(float x, float *out4) {
+    FtzScope f;
+    out4[0] = exp_(x); out4[1] = log_(x); out4[2] = erf_(x); out4[3] = erfinv_(x);
+}
 // Mesh::ray_intersect_triangle: tri9 = p0,p1,p2 ; ray8 ; out = hit, t, u, v
 void orc_ray_triangle(const float *tri9, const float *ray8, float *out4) {
     FtzScope f;
@@ -672,6 +678,7 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 o[0] = x + y; o[1] = x * y; o[2] = x / y; o[3] = __builtin_sqrtf(abs_(x));
                 o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
             } break;
+            case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
             default: return -1;
         }
     }

