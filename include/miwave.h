@@ -174,7 +174,8 @@ mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
  * Scenes of <= 64 triangles are traced by a brute-force sweep over LDS-resident
  * triangle packets instead of the tree; OR in MI_BVH_FORCE_TREE to walk the tree
  * anyway (tests). */
-enum { MI_BVH_FORCE_TREE = 0x10 };
+enum { MI_BVH_FORCE_TREE = 0x10,       /* walk the tree even for <= 64 triangles                  */
+       MI_BVH_NO_LEAF_FILTER = 0x20 };  /* resident plan: sweep every triangle, no leaf-box filter (tests) */
 mi_status mi_bvh_build(mi_ctx *ctx, int32_t quality);
 
 /* Scene::ray_intersect_preliminary (any_hit = 0) / Scene::ray_test (any_hit = 1),

@@ -353,32 +353,43 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
 
 // The register-resident plan: a run of one pixel's sample loop (render_block's inner
 // loops, integrator.cpp:196-209) with every Scene::ray_intersect / ray_test call made
-// in place: `closest(o, d, mint, maxt) -> F4 hit record`, `occluded(o, d, mint, maxt) -> bool`.
+// in place. The two scene queries of one depth-loop iteration are issued TOGETHER, one
+// iteration late for the shadow ray: the shadow ray of vertex k (scene.cpp:203-207) and
+// the extension ray leaving vertex k (path.cpp:189) share their origin and mint, so
+//   trace2(o, mint, dE, maxtE, hasE, dS, maxtS, hasS) -> (F4 hit record of E, bool S occluded)
+// resolves both in one pass over the geometry. The float additions into `result` keep
+// the reference's order: emitter-sampling term of vertex k (path.cpp:171), then the
+// emission term of vertex k+1 (:126-129) — exactly what the HBM-queue plan does.
 // A pixel's only state between two camera samples is its PCG32 state and its sample
 // counter (st: state lo, hi, flags, index), so a pixel can be advanced in passes:
 // this call runs samples [st.w, sample_end) and returns the updated st word.
-// The float additions into `result` happen in the reference's order by construction
-// (emission term, then the emitter-sampling term of the same vertex, path.cpp:126-172).
-template <typename Closest, typename Occluded, typename Sink>
+template <typename Trace2, typename Sink>
 MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
-                       Closest closest, Occluded occluded, Sink sink, Counters *cnt_local) {
+                       Trace2 trace2, Sink sink, Counters *cnt_local) {
     LaneRegs L;
     L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
     L.rng.inc = MIW_PCG32_SCALAR_INC;
     L.sample_idx = st.w; L.flags = 0;
     lane_begin_sample(P, pixel, L, sample_end);
+    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = v3(0.f);
+    bool dead_pending = false;
     while (!(L.flags & LF_DONE)) {
         const V3 o = L.ray.o;
-        F4 h = closest(o, L.ray.d, L.ray.mint, L.ray.maxt);
-        ShadowOut sh;
-        const int r = path_step(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
-        if (sh.has && !occluded(L.ray.o, sh.d, L.ray.mint, sh.maxt)) L.res = L.res + sh.c;
-        if (r != STEP_CONTINUE) {
-            lane_finish_sample(P, pixel, L, sink);
-            if (cnt_local) cnt_local->samples++;
-            L.flags = 0;
-            lane_begin_sample(P, pixel, L, sample_end);
+        F4 h; bool occluded = false;
+        trace2(o, L.ray.mint, L.ray.d, L.ray.maxt, !dead_pending, sh.d, sh.maxt, sh.has, h, occluded);
+        if (sh.has && !occluded) L.res = L.res + sh.c;              // path.cpp:171 of the previous vertex
+        sh.has = false;
+        int r = STEP_FINISHED;
+        if (!dead_pending) {
+            r = path_step(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
+            if (r == STEP_DEAD_PENDING) { dead_pending = true; continue; }   // one more pass for its shadow ray
+            if (r == STEP_CONTINUE) continue;
         }
+        dead_pending = false;
+        lane_finish_sample(P, pixel, L, sink);
+        if (cnt_local) cnt_local->samples++;
+        L.flags = 0;
+        lane_begin_sample(P, pixel, L, sample_end);
     }
     st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
     st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;

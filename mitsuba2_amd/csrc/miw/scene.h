@@ -52,6 +52,7 @@ struct SceneView {
     const float *emit_tri;                          // 9 floats per emitter face
     const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
     const float *emit_pmf, *emit_cdf;
+    const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
 };
 
 struct DirectionSample { V3 p, n, d; float dist, pdf; uint32_t emitter; };

@@ -54,8 +54,13 @@ static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layou
 struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t nodes_staged;  // first `nodes_staged` BVH nodes (breadth-first = top of tree)
     uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
-    uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets only, no BVH walk
+    uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets (+ leaf boxes), no BVH walk
+    uint32_t leaves;        // brute: number of LeafBox records staged behind the packets
 };
+
+// Padded bounding box of one BVH leaf (<= 4 consecutive triangles in leaf order), 32 B = 2 x b128.
+struct alignas(16) LeafBox { float lo[3]; uint32_t first; float hi[3]; uint32_t count; };
+static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 
 // Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
 struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
@@ -72,6 +77,10 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
             k.e2[0] = e2.x; k.e2[1] = e2.y; k.e2[2] = e2.z; k.prim = t.prim; k.pad[0] = k.pad[1] = 0;
             dst[i] = k;
         }
+        // leaf boxes of the SAH tree behind the packets (k_path_resident's candidate filter)
+        uint4 *dst_b = smem + sc.tri_count * (sizeof(TriPacket) / 16);
+        const uint4 *src_b = reinterpret_cast<const uint4 *>(sc.leaf_boxes);
+        for (uint32_t i = threadIdx.x; i < cfg.leaves * (sizeof(LeafBox) / 16); i += blockDim.x) dst_b[i] = src_b[i];
         __syncthreads();
         return;
     }
@@ -125,6 +134,58 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
         return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
     }
+}
+
+// The resident plan's paired query: extension ray E and shadow ray S leave the same vertex
+// (same origin, same mint). Tiny scenes (packets in LDS) are resolved in two phases:
+//   1. a wave-uniform pass over the SAH leaves' padded boxes (broadcast LDS reads, the
+//      conservative slab test of bvh.h — a triangle Moeller-Trumbore accepts is never culled)
+//      leaves every lane two 64-bit candidate masks, one bit per triangle;
+//   2. every lane pops its own candidates (E's first, then S's) and runs the exact
+//      Moeller-Trumbore test on that packet (per-lane LDS address). The wave iterates
+//      max-over-lanes(candidates) times instead of 2 x tri_count.
+// Results are those of the full sweep: closest hit with ties to the smaller primitive id,
+// "any triangle passes" for S.
+__device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
+                                       V3 o, float mint, V3 dE, float maxtE, bool hasE,
+                                       V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
+    Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
+    bool occ = false;
+    if (cfg.brute && cfg.leaves) {
+        const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+        const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
+        const RayPrep rE = ray_prepare(o, dE, mint, maxtE), rS = ray_prepare(o, dS, mint, maxtS);
+        unsigned long long mE = 0, mS = 0;
+        for (uint32_t i = 0; i < cfg.leaves; ++i) {
+            const LeafBox &b = lb[i];                              // wave-uniform address
+            const unsigned long long bits = (b.count >= 64u ? ~0ull : ((1ull << b.count) - 1ull)) << b.first;
+            float tn;
+            if (box_test(b.lo, b.hi, rE, maxtE, tn)) mE |= bits;
+            if (box_test(b.lo, b.hi, rS, maxtS, tn)) mS |= bits;
+        }
+        if (!hasE) mE = 0;
+        if (!hasS) mS = 0;
+        while ((mE | mS) != 0ull) {
+            const bool useE = mE != 0ull;
+            const unsigned long long m = useE ? mE : mS;
+            const uint32_t i = (uint32_t) __ffsll((long long) m) - 1u;
+            if (useE) mE = m & (m - 1ull); else mS = m & (m - 1ull);
+            const TriPacket &k = pk[i];
+            const V3 d = useE ? dE : dS;
+            const float maxt = useE ? maxtE : maxtS;
+            float t, u, v;
+            const bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
+            if (hit) {
+                if (!useE) { occ = true; mS = 0ull; }
+                else if (t < h.t || (t == h.t && k.prim < h.prim)) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
+            }
+        }
+    } else {
+        if (hasE) trace_one<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_one<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+    }
+    hit_out.x = h.t; hit_out.y = h.u; hit_out.z = h.v; hit_out.w = u2f(h.tri);
+    occ_out = occ;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -263,21 +324,16 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, Sce
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
             const uint32_t pixel = Q.pixel[lane];
-            auto closest = [&](V3 o, V3 d, float mint, float maxt) {
-                Hit h; F4 r;
-                if (maxt < 0.f) { r.x = MIW_INFINITY; r.y = r.z = 0.f; r.w = u2f(MIW_MISS); return r; }
-                trace_one<false>(sc, cfg, smem, o, d, mint, maxt, h);
-                r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
-                return r;
+            auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
+                trace2(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
             };
-            auto occluded = [&](V3 o, V3 d, float mint, float maxt) { Hit h; return trace_one<true>(sc, cfg, smem, o, d, mint, maxt, h); };
             if (UseLog) {
                 LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
-                st = pixel_render(P, sc, pixel, st, sample_end, closest, occluded, sink, &local);
+                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
             } else {
                 FilmAdd add; add.accum = accum;
                 SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
-                st = pixel_render(P, sc, pixel, st, sample_end, closest, occluded, sink, &local);
+                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
             }
             Q.st[lane] = st;
         }
@@ -533,6 +589,7 @@ struct mi_ctx {
     DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
+    DevBuf<LeafBox> d_leaf_boxes;
     SceneView view{};
     TraceLds lds_cfg{}; size_t lds_bytes = 0;
 
@@ -590,7 +647,7 @@ void mi_destroy(mi_ctx *c) {
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
     c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_bsdfs.release();
-    c->d_emitters.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
@@ -715,7 +772,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (!c) return MI_ERR_INVALID;
     if (!c->have_scene) return fail(c, MI_ERR_STATE, "mi_bvh_build: no scene uploaded");
     const bool force_tree = (quality & MI_BVH_FORCE_TREE) != 0;
-    quality &= ~MI_BVH_FORCE_TREE;
+    const int32_t quality_flags = quality;
+    quality &= ~(MI_BVH_FORCE_TREE | MI_BVH_NO_LEAF_FILTER);
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
     // quality 0 (device LBVH) falls back to the host SAH builder this round
@@ -746,11 +804,24 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
     size_t all = r.nodes.size() * sizeof(BvhNode) + r.tris.size() * sizeof(Tri);
-    c->lds_cfg.brute = 0;
+    c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; v.leaf_boxes = nullptr;
     if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
-        c->lds_bytes = v.tri_count * sizeof(TriPacket);
+        // the SAH leaves (padded boxes, <= 4 triangles each) become the resident plan's candidate filter
+        std::vector<LeafBox> leaves;
+        auto add_leaf = [&](const float *lo, const float *hi, int32_t child) {
+            if (child >= 0 || !(lo[0] <= hi[0])) return;          // inner node, or absent child (inverted box)
+            const uint32_t code = (uint32_t) ~child;
+            LeafBox b; memcpy(b.lo, lo, 12); memcpy(b.hi, hi, 12); b.first = code >> 4; b.count = (code & 15u) + 1u;
+            leaves.push_back(b);
+        };
+        for (const BvhNode &n : r.nodes) { add_leaf(n.lo0, n.hi0, n.child0); add_leaf(n.lo1, n.hi1, n.child1); }
+        HIP_TRY(c, c->d_leaf_boxes.upload(leaves, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        v.leaf_boxes = c->d_leaf_boxes.p;
+        c->lds_cfg.leaves = (quality_flags & MI_BVH_NO_LEAF_FILTER) ? 0u : (uint32_t) leaves.size();
+        c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox);
     } else {
         if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
         else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }

@@ -183,14 +183,12 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             st[lane] = lane_seed_state(cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
         }
         const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 32u;
-        auto closest = [&](V3 o, V3 d, float mint, float maxt) {
-            Hit h; RayPrep rp = ray_prepare(o, d, mint, maxt);
-            bvh_intersect<false>(node_at, tri_at, rp, h);
-            F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri); return r;
-        };
-        auto occluded = [&](V3 o, V3 d, float mint, float maxt) {
-            Hit h; RayPrep rp = ray_prepare(o, d, mint, maxt);
-            return bvh_intersect<true>(node_at, tri_at, rp, h);
+        auto trace2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
+            Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS;
+            if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h); }
+            hE.x = h.t; hE.y = h.u; hE.z = h.v; hE.w = u2f(h.tri);
+            occS = false;
+            if (hasS) { Hit hs; RayPrep rp = ray_prepare(o, dS, mint, maxtS); occS = bvh_intersect<true>(node_at, tri_at, rp, hs); }
         };
         for (uint32_t done = 0; done < cfg->spp; ) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
@@ -203,7 +201,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                     splat(pixel, sample_idx, pos, aovs);
                     if (do_log) log(pixel, sample_idx, pos, aovs);
                 };
-                st[lane] = pixel_render(P, sc.view, pixel[lane], st[lane], end, closest, occluded, sink, &cnt);
+                st[lane] = pixel_render(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt);
             }
             done = end; ++iterations;
         }
