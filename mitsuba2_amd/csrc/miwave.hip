@@ -15,6 +15,7 @@
 // workgroup; traversal is stackless (miw/bvh.h).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
 #include <string>
@@ -45,6 +46,7 @@ static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layou
 
 #define MIW_BLOCK 256
 #define MIW_CNT_SHARDS 1024        /* power of two */
+#define MIW_BRUTE_MAX_LEAF 2        /* triangles per leaf box of the resident plan's candidate filter */
 #define MIW_BRUTE_MAX_TRIS 64       /* <= this many triangles: LDS brute-force sweep instead of the BVH */
 
 // ---------------------------------------------------------------------------------------
@@ -146,6 +148,34 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
 //      max-over-lanes(candidates) times instead of 2 x tri_count.
 // Results are those of the full sweep: closest hit with ties to the smaller primitive id,
 // "any triangle passes" for S.
+// Candidate filter of trace2: the slab test of bvh.h re-expressed for speed — v_rcp_f32 for
+// 1/d, t = fma(plane, inv_d, -o*inv_d), hardware min/max (v_min3/v_max3) — it only has to stay
+// CONSERVATIVE, not bit-reproducible: leaf boxes are padded by 1e-5 x the scene extent
+// (bvh_build.h), five orders of magnitude above the rounding differences between the two forms,
+// and every accepted candidate is then decided by the exact Moeller-Trumbore test.
+struct FastRay { V3 inv_d, neg_o_inv_d; float mint; };
+__device__ __forceinline__ FastRay fast_ray(V3 o, V3 d, float mint) {
+    FastRay r;
+    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
+          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
+          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
+    r.inv_d = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
+    r.mint = mint;
+    return r;
+}
+__device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, const FastRay &r, float tmax_wide) {
+    float t0x = __builtin_fmaf(lo[0], r.inv_d.x, r.neg_o_inv_d.x), t1x = __builtin_fmaf(hi[0], r.inv_d.x, r.neg_o_inv_d.x),
+          t0y = __builtin_fmaf(lo[1], r.inv_d.y, r.neg_o_inv_d.y), t1y = __builtin_fmaf(hi[1], r.inv_d.y, r.neg_o_inv_d.y),
+          t0z = __builtin_fmaf(lo[2], r.inv_d.z, r.neg_o_inv_d.z), t1z = __builtin_fmaf(hi[2], r.inv_d.z, r.neg_o_inv_d.z);
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    // widened like bvh.h's box_test, plus an absolute slack for the fma-form rounding near the origin
+    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
+    return tn <= tf && tn <= tmax_wide;
+}
+
 __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                        V3 o, float mint, V3 dE, float maxtE, bool hasE,
                                        V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
@@ -154,14 +184,14 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
     if (cfg.brute && cfg.leaves) {
         const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
         const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
-        const RayPrep rE = ray_prepare(o, dE, mint, maxtE), rS = ray_prepare(o, dS, mint, maxtS);
+        const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
+        const float wideE = __builtin_fmaf(abs_(maxtE), 2e-6f, maxtE), wideS = __builtin_fmaf(abs_(maxtS), 2e-6f, maxtS);
         unsigned long long mE = 0, mS = 0;
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
             const unsigned long long bits = (b.count >= 64u ? ~0ull : ((1ull << b.count) - 1ull)) << b.first;
-            float tn;
-            if (box_test(b.lo, b.hi, rE, maxtE, tn)) mE |= bits;
-            if (box_test(b.lo, b.hi, rS, maxtS, tn)) mS |= bits;
+            if (box_test_fast(b.lo, b.hi, rE, wideE)) mE |= bits;
+            if (box_test_fast(b.lo, b.hi, rS, wideS)) mS |= bits;
         }
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
@@ -447,19 +477,29 @@ __global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A
             for (int i = 0; i < MIW_FP_MAXN; ++i) { s_w[l * 16 + i] = wx[i]; s_w[l * 16 + 8 + i] = wy[i]; }
             __syncthreads();
             const int pk_lo = lo_x | (lo_y << 16), pk_n = nx | (ny << 8);
-            // ---- replay: this pixel's samples back to back ----
-            for (uint32_t s = 0; s < m; ++s) {
-                const int slo = __builtin_amdgcn_readlane(pk_lo, (int) s), sn = __builtin_amdgcn_readlane(pk_n, (int) s);
-                const int xr = tx - (slo & 0xffff), yr = ty - (slo >> 16);
-                const bool hit = (uint32_t) xr < (uint32_t) (sn & 0xff) && (uint32_t) yr < (uint32_t) (sn >> 8);
-                const float w = s_w[s * 16 + 8 + (yr & 7)] * s_w[s * 16 + (xr & 7)];          // wy * wx, :155
-                const float vx = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.x), (int) s)),
-                            vy = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.y), (int) s)),
-                            vz = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.z), (int) s)),
-                            va = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.w), (int) s));
-                if (hit) {
-                    if (wide) { acc0 += vx * w; acc1 += vy * w; acc2 += vz * w; acc3 += va * w; acc4 += 1.f * w; }
-                    else      { acc0 += vx;     acc1 += vy;     acc2 += vz;     acc3 += va;     acc4 += 1.f; }
+            // ---- replay: this pixel's samples back to back, four per trip ----
+            // Lanes the footprint does not cover add value * 0 (= +-0: leaves a finite sum unchanged), which
+            // keeps the trip branch-free; staged slots >= m carry nx = ny = 0 and value 0.
+            const uint32_t m4 = (m + 3u) & ~3u;
+            for (uint32_t s0 = 0; s0 < m4; s0 += 4) {
+                float w[4], vx[4], vy[4], vz[4], va[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sl = (int) (s0 + k);
+                    const int slo = __builtin_amdgcn_readlane(pk_lo, sl), sn = __builtin_amdgcn_readlane(pk_n, sl);
+                    const int xr = tx - (slo & 0xffff), yr = ty - (slo >> 16);
+                    const bool hit = (uint32_t) xr < (uint32_t) (sn & 0xff) && (uint32_t) yr < (uint32_t) (sn >> 8);
+                    const float wk = s_w[sl * 16 + 8 + (yr & 7)] * s_w[sl * 16 + (xr & 7)];            // wy * wx, :155
+                    w[k] = hit ? wk : 0.f;
+                    vx[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.x), sl));
+                    vy[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.y), sl));
+                    vz[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.z), sl));
+                    va[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.w), sl));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (wide) { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += 1.f * w[k]; }
+                    else      { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += w[k]; }
                 }
             }
         }
@@ -777,7 +817,10 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
     // quality 0 (device LBVH) falls back to the host SAH builder this round
-    BvhBuildResult r = bvh_build_sah(c->tris_in);
+    // tiny scenes are swept through their SAH leaves' boxes (trace2): leaf size tuned for that filter
+    uint32_t max_leaf = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree ? MIW_BRUTE_MAX_LEAF : 4u;
+    if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) atoi(e);
+    BvhBuildResult r = bvh_build_sah(c->tris_in, -1.f, max_leaf);
     if (r.depth > MIW_BVH_MAX_DEPTH) return fail(c, MI_ERR_INVALID, "BVH depth %u exceeds the traversal trail", r.depth);
     std::vector<float> vn;
     if (!c->tri_vn_in.empty()) {
