@@ -45,7 +45,8 @@ def main():
                     help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
                          "dielectric balls, 41k triangles; quoted at 1024 spp)")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
-    ap.add_argument("--samples-per-launch", type=int, default=0, help="resident plan: samples each pixel advances per launch")
+    ap.add_argument("--samples-per-launch", type=int, default=-1,
+                    help="resident plan: samples each pixel advances per launch (-1 = all spp in one launch, 0 = library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,7 +73,7 @@ def main():
     job = integ.render_job(sensor)
     cfg = job.cfg
     cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
-    cfg.plan = args.plan; cfg.samples_per_launch = args.samples_per_launch
+    cfg.plan = args.plan; cfg.samples_per_launch = SPP if args.samples_per_launch < 0 else args.samples_per_launch
     film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     dev.check(dev.L.mi_set_stream(dev.ctx, C.c_void_p(stream.cuda_stream)))

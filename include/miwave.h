@@ -122,7 +122,8 @@ typedef struct {
     /* how ImageBlock::put is realised:
      * 1 = sample log + ordered gather: float32 sums in the reference's order
      *     (bit-identical film; needs spp * lanes * 24 B of HBM),
-     * 2 = float64 atomics straight into the film (order-free, ~1e-16 noise),
+     * 2 = float64 sums, order-free to float32 precision (resident plan: per-workgroup
+     *     LDS tiles flushed once per launch; wavefront plan: atomics straight into the film),
      * 0 = auto: 1 if the log fits in free device memory, else 2               */
     int32_t film_mode;
     int32_t profile;                          /* 1: time every launch with HIP events    */
@@ -134,7 +135,7 @@ typedef struct {
      *     (or read through L2), the pixel is advanced `samples_per_launch` samples per launch,
      * 0 = auto: 2 when the geometry is LDS-resident, else 1                          */
     int32_t plan;
-    int32_t samples_per_launch;               /* plan 2: <= 0 = default (32)             */
+    int32_t samples_per_launch;               /* plan 2: <= 0 = default (128)            */
 } mi_render_cfg;
 
 typedef struct {

@@ -107,9 +107,10 @@ MIW_HD void block_of_pixel(const FilmRec &f, int px, int py, int &bx, int &by, i
 }
 
 // ImageBlock::put followed by Film::put (imageblock.cpp:49-77, out-of-film border texels
-// clipped): add(film_texel, channel, value). `px,py` = the pixel the sample belongs to.
-template <typename Add>
-MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *value, Add add) {
+// clipped): add_xy(fx, fy, channel, value) with crop-relative film coordinates.
+// `px,py` = the pixel the sample belongs to.
+template <typename AddXY>
+MIW_HD void film_splat_xy(const FilmRec &f, int px, int py, V2 pos_, const float *value, AddXY add_xy) {
     if (!sample_is_valid(value)) return;
     int bx, by, bw, bh;
     block_of_pixel(f, px, py, bx, by, bw, bh);
@@ -117,8 +118,14 @@ MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *v
     block_splat(f, bx + f.crop_x, by + f.crop_y, bw, bh, pos_, value, [&](int texel, int k, float v) {
         int x = texel % size_x, y = texel / size_x;
         int fx = x + bx - f.border, fy = y + by - f.border;
-        if (fx >= 0 && fx < f.crop_w && fy >= 0 && fy < f.crop_h) add(fy * f.crop_w + fx, k, v);
+        if (fx >= 0 && fx < f.crop_w && fy >= 0 && fy < f.crop_h) add_xy(fx, fy, k, v);
     });
+}
+// same, add(film_texel, channel, value)
+template <typename Add>
+MIW_HD void film_splat(const FilmRec &f, int px, int py, V2 pos_, const float *value, Add add) {
+    const int w = f.crop_w;
+    film_splat_xy(f, px, py, pos_, value, [&](int fx, int fy, int k, float v) { add(fy * w + fx, k, v); });
 }
 
 } // namespace miw

@@ -126,6 +126,13 @@ template <typename Add> struct SplatSink {
         film_splat(*film, (int) (pixel & 0xffffu), (int) (pixel >> 16), pos, aovs, add);
     }
 };
+// Sink 1b: splat through add_xy(fx, fy, channel, value) (workgroup-local film tile on the device)
+template <typename AddXY> struct SplatXYSink {
+    const FilmRec *film; AddXY add;
+    MIW_HD void operator()(uint32_t pixel, uint32_t, V2 pos, const float *aovs) const {
+        film_splat_xy(*film, (int) (pixel & 0xffffu), (int) (pixel >> 16), pos, aovs, add);
+    }
+};
 // Sink 2: append to the lane's sample log; the film is assembled afterwards by the
 // ordered gather (miw/film_gather.h), in the reference's float32 accumulation order.
 struct LogSink {

@@ -279,6 +279,19 @@ struct FilmAdd {
     }
 };
 
+// Workgroup-local film tile (resident plan, film_mode 2): the 256 lanes of a workgroup are one
+// Morton-contiguous 16 x 16 pixel quad of a spiral block, so everything they splat lands in the
+// (16 + 2*border)^2 texels around it. The tile is accumulated in LDS with float64 adds (ds_add_f64:
+// the sum is order-free to float32 precision) and flushed to the film accumulators once per launch.
+struct TileAdd {
+    double *tile; int x0, y0, side;     // tile origin in crop-relative film coordinates
+    __device__ __forceinline__ void operator()(int fx, int fy, int k, float v) const {
+        const int tx = fx - x0, ty = fy - y0;
+        if ((unsigned) tx < (unsigned) side && (unsigned) ty < (unsigned) side)
+            unsafeAtomicAdd(tile + (ty * side + tx) * MIW_FILM_CHANNELS + k, (double) v);
+    }
+};
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -343,12 +356,32 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_init_pixels(RenderParams P, U4 *s
 // Path state, ray, hit record and the pending emitter contribution never leave registers;
 // the geometry is swept / walked in LDS (trace_one); HBM sees 20 B of pixel state per launch
 // and the 24 B/sample log (or the film atomics).
+struct TileArgs {               // film_mode 2 in the resident plan; side == 0: splat straight into `accum`
+    const uint32_t *tile_list; uint32_t blocks_x, bs, bs2_log2;
+    uint32_t side;              // 16 + 2 * margin, margin = max(filter border, floor(radius + .5))
+    uint32_t geom16;            // uint4 slots of dynamic LDS in front of the tile
+};
+
 template <bool UseLog>
 __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
-                                                               TraceLds cfg, uint32_t sample_end) {
+                                                               TraceLds cfg, uint32_t sample_end, TileArgs T) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    // workgroup film tile
+    double *tile = reinterpret_cast<double *>(smem + T.geom16);
+    int tile_x0 = 0, tile_y0 = 0;
+    if (!UseLog && T.side) {
+        const uint32_t lane0 = blockIdx.x * blockDim.x, t = lane0 >> T.bs2_log2, q0 = lane0 & ((1u << T.bs2_log2) - 1u);
+        const uint32_t b = T.tile_list ? T.tile_list[t] : t;
+        uint32_t qx, qy;
+        morton_decode2(q0, qx, qy);
+        const int margin = (int) (T.side - 16u) / 2;
+        tile_x0 = (int) ((b % T.blocks_x) * T.bs + qx) - margin;
+        tile_y0 = (int) ((b / T.blocks_x) * T.bs + qy) - margin;
+        for (uint32_t i = threadIdx.x; i < T.side * T.side * MIW_FILM_CHANNELS; i += blockDim.x) tile[i] = 0.0;
+        __syncthreads();
+    }
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
     if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
@@ -360,12 +393,27 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, Sce
             if (UseLog) {
                 LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
                 st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
+            } else if (T.side) {
+                TileAdd add; add.tile = tile; add.x0 = tile_x0; add.y0 = tile_y0; add.side = (int) T.side;
+                SplatXYSink<TileAdd> sink; sink.film = &P.film; sink.add = add;
+                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
             } else {
                 FilmAdd add; add.accum = accum;
                 SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
                 st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
             }
             Q.st[lane] = st;
+        }
+    }
+    if (!UseLog && T.side) {                                     // flush the tile: one f64 atomic per touched slot
+        __syncthreads();
+        const int n = (int) (T.side * T.side);
+        for (int i = (int) threadIdx.x; i < n * MIW_FILM_CHANNELS; i += (int) blockDim.x) {
+            const double v = tile[i];
+            if (v == 0.0) continue;
+            const int texel = i / MIW_FILM_CHANNELS, k = i - texel * MIW_FILM_CHANNELS;
+            const int fx = tile_x0 + texel % (int) T.side, fy = tile_y0 + texel / (int) T.side;
+            unsafeAtomicAdd(accum + ((size_t) fy * P.film.crop_w + fx) * MIW_FILM_CHANNELS + k, v);
         }
     }
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
@@ -1076,15 +1124,26 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
         MIW_TIMED(3, hipLaunchKernelGGL(k_init_pixels, grid, block, 0, s, P, c->q_st.p, c->q_pixel.p, A));
         HIP_TRY(c, hipGetLastError());
-        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 32u;
+        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
+        // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
+        TileArgs TA; memset(&TA, 0, sizeof TA);
+        size_t tile_bytes = 0;
+        if (film_mode == 2 && bs >= 16) {
+            TA.tile_list = A.tile_list; TA.blocks_x = blocks_x; TA.bs = bs; TA.bs2_log2 = bs2_log2;
+            TA.side = 16u + 2u * std::max<uint32_t>((uint32_t) cfg->filter_border, (uint32_t) floorf(cfg->filter_radius + .5f));
+            TA.geom16 = (uint32_t) ((c->lds_bytes + 15) / 16);
+            tile_bytes = (size_t) TA.geom16 * 16 - c->lds_bytes + (size_t) TA.side * TA.side * MIW_FILM_CHANNELS * sizeof(double);
+            if (c->lds_bytes + tile_bytes > 64 * 1024)
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+        }
         const uint32_t sync_every = 8;
         uint32_t launches = 0;
         for (uint32_t done = 0; done < cfg->spp; ) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
             if (film_mode == 1)
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, grid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end));
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, grid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA));
             else
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end));
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA));
             K.n_path++; K.iterations++;
             done = end;
             if (++launches % sync_every == 0 && done < cfg->spp) {

@@ -182,7 +182,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             uint32_t b = cfg->tile_list ? cfg->tile_list[tile] : tile;
             st[lane] = lane_seed_state(cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
         }
-        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 32u;
+        const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
         auto trace2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
             Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS;
             if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h); }
