@@ -68,6 +68,17 @@ typedef struct {          /* area light, src/emitters/area.cpp                  
     float radiance[3];
 } mi_emitter;
 
+typedef struct {          /* environment map, src/emitters/envmap.cpp (one per scene)     */
+    const float *rgba;    /* width * height * 4 linear RGBA floats, row 0 = +Y pole (bitmap->convert(RGBA, Float32)) */
+    uint32_t width, height;                /* >= 2 x 2                                   */
+    float scale;                           /* `scale` property                            */
+    float to_world[16];                    /* `to_world`, column-major 4x4 (rotation part is used) */
+    float bsphere_radius;                  /* scene->bbox().bounding_sphere().radius (set_scene, envmap.cpp:128-132
+                                              applies the (1 + RayEpsilon) enlargement itself)  */
+    uint32_t emitter_index;                /* position among the scene's emitters (Scene::m_emitters order,
+                                              scene.cpp:38-60): area emitters at or after it shift up by one */
+} mi_envmap;
+
 typedef struct {
     const float    *vertex_positions;  /* 3 * vertex_count                               */
     const float    *vertex_normals;    /* 3 * vertex_count, or NULL                      */
@@ -77,6 +88,7 @@ typedef struct {
     const mi_shape   *shapes;   uint32_t shape_count;
     const mi_bsdf    *bsdfs;    uint32_t bsdf_count;
     const mi_emitter *emitters; uint32_t emitter_count;
+    const mi_envmap  *envmap;          /* or NULL                                        */
 } mi_scene_desc;
 
 /* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */
@@ -207,7 +219,10 @@ enum {
     MI_EVAL_CAMERA_RAY = 5,       /* in: x,y (film sample)               out: o.xyz,d.xyz,mint,maxt */
     MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2                 out: d.xyz,dist,pdf,spec.rgb,p.xyz,n.xyz (14) */
     MI_EVAL_FP_SEMANTICS = 7,     /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
-    MI_EVAL_SPECIAL = 8           /* in: x                               out: exp, log, erf, erfinv (miw/special.h)   */
+    MI_EVAL_SPECIAL = 8,          /* in: x                               out: exp, log, erf, erfinv (miw/special.h)   */
+    MI_EVAL_ENVMAP = 9,           /* in: d.xyz (world), ref.xyz, u1, u2 (8)
+                                     out: eval.rgb, pdf_direction, sample{d.xyz, dist, pdf, spec.rgb} (12)          */
+    MI_EVAL_INVTRIG = 10          /* in: y, x                            out: atan2(y,x), acos(x), asin(x) (3)       */
 };
 mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
                   const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);

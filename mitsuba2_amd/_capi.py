@@ -28,12 +28,18 @@ class mi_emitter(C.Structure):
     _fields_ = [("shape", C.c_uint32), ("radiance", C.c_float * 3)]
 
 
+class mi_envmap(C.Structure):
+    _fields_ = [("rgba", c_float_p), ("width", C.c_uint32), ("height", C.c_uint32), ("scale", C.c_float),
+                ("to_world", C.c_float * 16), ("bsphere_radius", C.c_float), ("emitter_index", C.c_uint32)]
+
+
 class mi_scene_desc(C.Structure):
     _fields_ = [("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_count", C.c_uint32),
                 ("faces", c_u32_p), ("face_count", C.c_uint32),
                 ("shapes", C.POINTER(mi_shape)), ("shape_count", C.c_uint32),
                 ("bsdfs", C.POINTER(mi_bsdf)), ("bsdf_count", C.c_uint32),
-                ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32)]
+                ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32),
+                ("envmap", C.POINTER(mi_envmap))]
 
 
 class mi_rays_soa(C.Structure):
@@ -72,8 +78,8 @@ class mi_counters(C.Structure):
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
 MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
-               FP_SEMANTICS=7, SPECIAL=8)
-MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8), 8: (1, 4)}
+               FP_SEMANTICS=7, SPECIAL=8, ENVMAP=9, INVTRIG=10)
+MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8), 8: (1, 4), 9: (8, 12), 10: (2, 3)}
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
 MI_SYMBOLS = ["mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
@@ -128,6 +134,8 @@ def load_host_lib():
         "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),
         "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p]), "mih_mesh_destroy": (None, [vp]),
         "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),
+        "mih_envmap_create": (vp, [vp, u32, u32, c_float_p]), "mih_envmap_destroy": (None, [vp]),
+        "mih_scene_add_envmap": (i32, [vp, vp]),
         "mih_scene_create": (vp, []), "mih_scene_destroy": (None, [vp]),
         "mih_scene_add_shape": (i32, [vp, vp]), "mih_scene_build": (i32, [vp, i32, i32]),
         "mih_scene_desc": (C.POINTER(mi_scene_desc), [vp]), "mih_scene_ctx": (vp, [vp]),

@@ -117,6 +117,7 @@ class AreaLight:
 
 class Mesh:
     def __init__(self, name, vertices, faces, normals=None, bsdf=None, emitter=None):
+        self.name = name
         self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         self.faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
         self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
@@ -153,13 +154,42 @@ def _hits_struct(n):
     return h, dict(t=t, u=u, v=v, prim=prim, shape=shape)
 
 
+class EnvMap:
+    """<emitter type="envmap"> (src/emitters/envmap.cpp): `rgb` = H x W x 3 (or x 4) linear float pixels in
+    lat-long layout, row 0 = +Y pole; properties `scale`, `to_world`."""
+
+    def __init__(self, rgb, **kw):
+        a = np.asarray(rgb, np.float32)
+        if a.ndim != 3 or a.shape[2] not in (3, 4):
+            raise ValueError("EnvMap: expected an H x W x 3|4 array")
+        if a.shape[2] == 3:
+            a = np.concatenate([a, np.ones(a.shape[:2] + (1,), np.float32)], 2)
+        self.rgba = np.ascontiguousarray(a, np.float32)
+        self._p = Properties("envmap", **kw)
+        self.h = host_lib().mih_envmap_create(self._p.h, a.shape[1], a.shape[0], _fp(self.rgba))
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_envmap_destroy(self.h); self.h = None
+
+
 class Scene:
-    def __init__(self, shapes):
+    def __init__(self, shapes, envmap=None, envmap_after=None):
+        """`envmap`: an EnvMap child; `envmap_after` = number of shapes listed before it in the scene
+        (default: after all shapes) — fixes its position in the emitter order (scene.cpp:38-60)."""
         self.shapes = list(shapes)
+        self.envmap = envmap
         self.h = host_lib().mih_scene_create()
-        for s in self.shapes:
+        pos = len(self.shapes) if envmap_after is None else envmap_after
+        for i, s in enumerate(self.shapes):
+            if envmap is not None and i == pos and host_lib().mih_scene_add_envmap(self.h, envmap.h) != 0:
+                raise RuntimeError(_err())
             if host_lib().mih_scene_add_shape(self.h, s.h) != 0:
                 raise RuntimeError(_err())
+        if envmap is not None and pos >= len(self.shapes) and host_lib().mih_scene_add_envmap(self.h, envmap.h) != 0:
+            raise RuntimeError(_err())
         self.device = None
 
     def build(self, device=0, bvh_quality=1):

@@ -230,6 +230,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         si.shape = tr.shape; si.prim = tr.prim;
         emitter = shape.emitter; bsdf_index = shape.bsdf;
     }
+    else if (sc.env) emitter = (int32_t) sc.env->emitter_index;   // a miss sees the environment, scene.h:248-249
     if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
 
     // ---- intersection with emitters, path.cpp:126-129 ----
@@ -238,15 +239,20 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         if (depth > 1) {                             // :194-205, evaluated lazily
             float emitter_pdf = 0.f;
             if (!(L.flags & LF_PREV_DELTA)) {
-                // DirectionSample3f ds(si_bsdf, si), records.h:167-173
-                V3 d = si.p - prev_o();
-                float dist = norm(d);
-                d = d / dist;
-                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, si.sh.n);
+                // DirectionSample3f ds(si_bsdf, si), records.h:167-173 (d = -wi = ray.d for a miss)
+                V3 d = ray_d; float dist = 0.f; V3 n = v3(0.f);
+                if (valid) {
+                    d = si.p - prev_o();
+                    dist = norm(d);
+                    d = d / dist;
+                    n = si.sh.n;
+                }
+                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, n);
             }
             emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
         }
-        L.res = L.res + emission_weight * L.tp * emitter_eval(sc.emitters[emitter], si.wi);
+        V3 radiance = valid ? emitter_eval(sc.emitters[emitter], si.wi) : env_eval(*sc.env, ray_d);
+        L.res = L.res + emission_weight * L.tp * radiance;
     }
 
     bool active = valid;                             // :131

@@ -7,6 +7,7 @@
 #include "base.h"
 #include "shape.h"
 #include "bsdf.h"
+#include "envmap.h"
 
 namespace miw {
 
@@ -39,8 +40,9 @@ struct EmitterRec {
     uint32_t valid_lo, valid_hi;
     float sum, normalization;
     uint32_t flags;      // bit0: emit_vnorm valid for this emitter
-    uint32_t pad;
+    uint32_t type;       // 0: area light on `shape`; 1: the environment map (SceneView::env)
 };
+enum : uint32_t { EMITTER_AREA = 0, EMITTER_ENVMAP = 1 };
 
 struct SceneView {
     const BvhNode *nodes;   uint32_t node_count;
@@ -52,6 +54,7 @@ struct SceneView {
     const float *emit_tri;                          // 9 floats per emitter face
     const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
     const float *emit_pmf, *emit_cdf;
+    const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
 };
 
@@ -87,20 +90,26 @@ MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, Dir
         sample.x = (sample.x - (float) index * emitter_pdf) * n;
     }
     const EmitterRec &e = sc.emitters[index];
-    MeshSampler mesh = emitter_mesh(sc, e);
-    // Shape::sample_direction, shape.cpp:292-309
-    PositionSample ps = mesh_sample_position(mesh, sample);
-    ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf; ds.emitter = index;
-    ds.d = ds.p - ref_p;
-    float dist_squared = squared_norm(ds.d);
-    ds.dist = __builtin_sqrtf(dist_squared);
-    ds.d = ds.d / ds.dist;
-    float dp = abs_dot(ds.d, ds.n);
-    ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
-    // AreaLight::sample_direction, area.cpp:131-136,165
-    bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
-    V3 spec = v3(e.radiance[0], e.radiance[1], e.radiance[2]) / ds.pdf;
-    if (!active) spec = v3(0.f);
+    V3 spec;
+    ds.emitter = index;
+    if (e.type == EMITTER_ENVMAP) {
+        spec = env_sample_direction(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
+    } else {
+        MeshSampler mesh = emitter_mesh(sc, e);
+        // Shape::sample_direction, shape.cpp:292-309
+        PositionSample ps = mesh_sample_position(mesh, sample);
+        ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf;
+        ds.d = ds.p - ref_p;
+        float dist_squared = squared_norm(ds.d);
+        ds.dist = __builtin_sqrtf(dist_squared);
+        ds.d = ds.d / ds.dist;
+        float dp = abs_dot(ds.d, ds.n);
+        ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        // AreaLight::sample_direction, area.cpp:131-136,165
+        bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
+        spec = v3(e.radiance[0], e.radiance[1], e.radiance[2]) / ds.pdf;
+        if (!active) spec = v3(0.f);
+    }
     if (sc.emitter_count > 1) {                        // scene.cpp:195-197
         ds.pdf *= emitter_pdf;
         spec = spec * rcp(emitter_pdf);
@@ -112,12 +121,17 @@ MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, Dir
 // `ds_d`, `ds_dist`, `ds_n` come from DirectionSample(si_bsdf, si) (records.h:167-173).
 MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n) {
     const EmitterRec &e = sc.emitters[emitter];
-    float dp = dot(ds_d, ds_n);
-    bool active = dp < 0.f;
-    float pdf = e.normalization,
-          adp = abs_dot(ds_d, ds_n);
-    pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
-    float value = active ? pdf : 0.f;
+    float value;
+    if (e.type == EMITTER_ENVMAP) {
+        value = env_pdf_direction(*sc.env, ds_d);
+    } else {
+        float dp = dot(ds_d, ds_n);
+        bool active = dp < 0.f;
+        float pdf = e.normalization,
+              adp = abs_dot(ds_d, ds_n);
+        pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
+        value = active ? pdf : 0.f;
+    }
     if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);
     return value;
 }

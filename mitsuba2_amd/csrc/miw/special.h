@@ -11,6 +11,9 @@
 //                <= 1 ulp over the normal range;
 //   erf_       : Cephes ndtrf.c erff / erfcf scheme (x*P(x^2) for |x| < 1,
 //                1 - exp(-x^2)/x * Q(1/x^2) beyond), max rel. error 3.8e-7;
+//   atan2_, acos_ : Cephes atanf / asinf / acosf (range reduction + odd minimax
+//                polynomials), <= 2 ulp; used by the environment map's lat-long
+//                lookup (src/emitters/envmap.cpp:140-142);
 //   erfinv_    : M. Giles, "Approximating the erfinv function" (GPU Computing
 //                Gems 2010), single-precision variant, max rel. error 2.8e-7.
 // Accuracy figures are measured against scipy.special (tests/test_oracle_kat.py);
@@ -144,5 +147,56 @@ MIW_HD float erfinv_(float x) {
     }
     return p * x;
 }
+
+// ---- inverse trigonometric functions (environment map lookups) ---------------------------
+MIW_HD float atan_(float x) {
+    float a = abs_(x), y;
+    if (!(a == a)) return x;
+    if (a > 2.414213562373095f)       { y = 1.5707963267948966f; a = -(1.f / a); }          // > tan(3 pi / 8)
+    else if (a > 0.4142135623730950f) { y = 0.7853981633974483f; a = (a - 1.f) / (a + 1.f); }  // > tan(pi / 8)
+    else y = 0.f;
+    float z = a * a;
+    float p = 8.05374449538e-2f;
+    p = fmadd(p, z, -1.38776856032e-1f);
+    p = fmadd(p, z, 1.99777106478e-1f);
+    p = fmadd(p, z, -3.33329491539e-1f);
+    y = y + fmadd(p * z, a, a);
+    return mulsign(y, x);
+}
+
+MIW_HD float atan2_(float y, float x) {
+    if (!(x == x) || !(y == y)) return x + y;
+    if (x == 0.f) {
+        if (y == 0.f) return (f2u(x) & 0x80000000u) ? mulsign(MIW_PI, y) : y;      // atan2(+-0, -0) = +-pi, (+-0, +0) = +-0
+        return mulsign(1.5707963267948966f, y);
+    }
+    if (y == 0.f) return x > 0.f ? y : mulsign(MIW_PI, y);
+    float w = x < 0.f ? mulsign(MIW_PI, y) : 0.f;
+    return w + atan_(y / x);
+}
+
+MIW_HD float asin_(float x) {
+    float a = abs_(x), z, r;
+    if (a > 1.f) return __builtin_nanf("");
+    bool big = a > 0.5f;
+    if (big) { z = 0.5f * (1.f - a); r = __builtin_sqrtf(z); }
+    else     { r = a; z = a * a; }
+    float p = 4.2163199048e-2f;
+    p = fmadd(p, z, 2.4181311049e-2f);
+    p = fmadd(p, z, 4.5470025998e-2f);
+    p = fmadd(p, z, 7.4953002686e-2f);
+    p = fmadd(p, z, 1.6666752422e-1f);
+    float v = fmadd(p * z, r, r);
+    if (big) v = 1.5707963267948966f - (v + v);
+    return mulsign(v, x);
+}
+
+MIW_HD float acos_(float x) {
+    if (x < -1.f || x > 1.f) return __builtin_nanf("");
+    if (x < -0.5f) return MIW_PI - 2.f * asin_(__builtin_sqrtf(0.5f * (1.f + x)));
+    if (x > 0.5f)  return 2.f * asin_(__builtin_sqrtf(0.5f * (1.f - x)));
+    return 1.5707963267948966f - asin_(x);
+}
+MIW_HD float safe_acos(float x) { return acos_(clamp_(x, -1.f, 1.f)); }
 
 } // namespace miw

@@ -37,6 +37,7 @@
 #include "miw/path.h"
 #include "miw/film_gather.h"
 #include "bvh_build.h"
+#include "envmap_build.h"
 
 using namespace miw;
 
@@ -632,6 +633,16 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
         } break;
         case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
+        case MI_EVAL_ENVMAP: {
+            if (!sc.env) break;
+            V3 d = v3(a[0], a[1], a[2]);
+            V3 e = env_eval(*sc.env, d); o[0] = e.x; o[1] = e.y; o[2] = e.z;
+            o[3] = env_pdf_direction(*sc.env, d);
+            V3 sd, sp, sn; float dist, pdf;
+            V3 spec = env_sample_direction(*sc.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
+            o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
+        } break;
+        case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
     }
 }
 
@@ -678,6 +689,8 @@ struct mi_ctx {
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes;
+    DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
+    bool have_env = false;
     SceneView view{};
     TraceLds lds_cfg{}; size_t lds_bytes = 0;
 
@@ -735,7 +748,7 @@ void mi_destroy(mi_ctx *c) {
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
     c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_bsdfs.release();
-    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
@@ -774,13 +787,17 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         const mi_shape &sh = s->shapes[i];
         if (sh.bsdf >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "shape %u: bsdf index out of range", i);
         if (sh.emitter >= (int32_t) s->emitter_count) return fail(c, MI_ERR_INVALID, "shape %u: emitter index out of range", i);
+        if (s->envmap && s->envmap->emitter_index > s->emitter_count) return fail(c, MI_ERR_INVALID, "envmap: emitter_index out of range");
         if ((uint64_t) sh.first_face + sh.face_count > s->face_count) return fail(c, MI_ERR_INVALID, "shape %u: face range out of bounds", i);
         if ((sh.flags & MI_SHAPE_HAS_NORMALS) && !s->vertex_normals) return fail(c, MI_ERR_INVALID, "shape %u: HAS_NORMALS without vertex_normals", i);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) {
             if (face_shape[f] != 0xffffffffu) return fail(c, MI_ERR_INVALID, "face %u belongs to two shapes", f);
             face_shape[f] = i;
         }
-        ShapeRec r; r.bsdf = sh.bsdf; r.emitter = sh.emitter; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
+        // emitter ids index the combined list: the environment map sits at envmap->emitter_index
+        int32_t emitter_id = sh.emitter;
+        if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
+        ShapeRec r; r.bsdf = sh.bsdf; r.emitter = emitter_id; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
         c->shapes[i] = r;
         any_normals = any_normals || (r.flags & 1u);
     }
@@ -809,7 +826,9 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
     c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
     bool any_emit_normals = false;
+    auto push_env = [&]() { EmitterRec r; memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; c->emitters.push_back(r); };
     for (uint32_t i = 0; i < s->emitter_count; ++i) {
+        if (s->envmap && s->envmap->emitter_index == i) push_env();
         const mi_emitter &e = s->emitters[i];
         if (e.shape >= s->shape_count) return fail(c, MI_ERR_INVALID, "emitter %u: shape index out of range", i);
         const mi_shape &sh = s->shapes[e.shape];
@@ -841,8 +860,21 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         c->emitters.push_back(r);
     }
     if (!any_emit_normals) c->emit_vnorm.clear();
+    if (s->envmap && s->envmap->emitter_index >= s->emitter_count) push_env();
 
     HIP_TRY(c, hipSetDevice(c->device));
+    c->have_env = false;
+    if (s->envmap) {
+        EnvmapTables t = envmap_build(*s->envmap);
+        if (!t.ok) return fail(c, MI_ERR_INVALID, "envmap: needs >= 2x2 texels, a non-zero luminance sum and an invertible to_world");
+        HIP_TRY(c, c->d_env_data.upload(t.data, c->stream));
+        HIP_TRY(c, c->d_env_levels.upload(t.levels, c->stream));
+        t.rec.data = c->d_env_data.p; t.rec.levels = c->d_env_levels.p;
+        std::vector<EnvmapRec> one(1, t.rec);
+        HIP_TRY(c, c->d_env.upload(one, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->have_env = true;
+    }
     HIP_TRY(c, c->d_shapes.upload(c->shapes, c->stream));
     HIP_TRY(c, c->d_bsdfs.upload(c->bsdfs, c->stream));
     HIP_TRY(c, c->d_emitters.upload(c->emitters, c->stream));
@@ -891,6 +923,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();
     v.emit_tri = c->d_emit_tri.p; v.emit_vnorm = c->emit_vnorm.empty() ? nullptr : c->d_emit_vnorm.p;
     v.emit_pmf = c->d_emit_pmf.p; v.emit_cdf = c->d_emit_cdf.p;
+    v.env = c->have_env ? c->d_env.p : nullptr;
 
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
@@ -1259,7 +1292,7 @@ mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *
         mi_status st = fill_params(c, cfg, P);
         if (st != MI_OK) return st;
     }
-    if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE) && !c->have_bvh)
+    if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE || op == MI_EVAL_ENVMAP) && !c->have_bvh)
         return fail(c, MI_ERR_STATE, "mi_eval: scene required");
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> din, dout;

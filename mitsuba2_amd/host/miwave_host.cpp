@@ -472,6 +472,18 @@ AreaLight::AreaLight(const Properties &props) {
     m_radiance = props.texture("radiance", 1.f);               // area.cpp:55 (D65(1) ~ white in RGB mode)
 }
 
+EnvironmentMapEmitter::EnvironmentMapEmitter(const Properties &props) {
+    m_scale = props.float_("scale", 1.f);                      // envmap.cpp:124
+    m_to_world = props.transform("to_world", Transform4f());
+    if (props.has_property("filename"))
+        Throw("envmap: image file I/O is outside this layer; pass the linear RGBA float pixels with set_bitmap()");
+}
+void EnvironmentMapEmitter::set_bitmap(uint32_t width, uint32_t height, const float *rgba) {
+    if (width < 2 || height < 2 || !rgba) Throw("envmap: the bitmap must be at least 2x2");
+    m_width = width; m_height = height;
+    m_data.assign(rgba, rgba + (size_t) width * height * 4);
+}
+
 // ============================================================================================
 // Mesh / Scene
 // ============================================================================================
@@ -489,6 +501,11 @@ Scene::~Scene() { if (m_ctx) mi_destroy(m_ctx); }
 void Scene::add_shape(std::shared_ptr<Mesh> mesh) {
     if (m_built) Throw("Scene: cannot add shapes after build()");
     m_shapes.push_back(std::move(mesh));
+}
+void Scene::add_emitter(std::shared_ptr<EnvironmentMapEmitter> env) {
+    if (m_built) Throw("Scene: cannot add emitters after build()");
+    if (m_env) Throw("Only one environment emitter can be specified per scene.");   // scene.cpp:48-49
+    m_env = std::move(env); m_env_after_shapes = m_shapes.size();
 }
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
                     std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
@@ -538,6 +555,25 @@ void Scene::build(int device, int bvh_quality) {
     m_desc.shapes = m_shape_recs.data(); m_desc.shape_count = (uint32_t) m_shape_recs.size();
     m_desc.bsdfs = m_bsdf_recs.data(); m_desc.bsdf_count = (uint32_t) m_bsdf_recs.size();
     m_desc.emitters = m_emitters.data(); m_desc.emitter_count = (uint32_t) m_emitters.size();
+    m_desc.envmap = nullptr;
+    if (m_env) {
+        if (m_env->data().empty()) Throw("envmap: no bitmap set");
+        m_env_rec.rgba = m_env->data().data(); m_env_rec.width = m_env->width(); m_env_rec.height = m_env->height();
+        m_env_rec.scale = m_env->scale();
+        std::memcpy(m_env_rec.to_world, m_env->world_transform().m, 64);
+        // emitter order (scene.cpp:38-60): area lights of the shapes added before the envmap come first
+        uint32_t before = 0;
+        for (size_t i = 0; i < m_env_after_shapes && i < m_shapes.size(); ++i) if (m_shapes[i]->emitter()) ++before;
+        m_env_rec.emitter_index = before;
+        // scene->bbox().bounding_sphere() (bbox.h:329-332): centre of the bbox, distance to its max corner
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = 0; i < m_positions.size(); i += 3)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], m_positions[i + a]); hi[a] = std::max(hi[a], m_positions[i + a]); }
+        float c[3], d2 = 0.f;
+        for (int a = 0; a < 3; ++a) { c[a] = (lo[a] + hi[a]) * .5f; float d = c[a] - hi[a]; d2 += d * d; }
+        m_env_rec.bsphere_radius = std::sqrt(d2);
+        m_desc.envmap = &m_env_rec;
+    }
     m_built = true;
     if (device < 0) return;                                    // flatten only (host-side tests)
     if (!m_ctx) {
@@ -737,6 +773,14 @@ void mih_mesh_destroy(void *m) { delete (Box<Mesh> *) m; }
 void mih_mesh_set_bsdf(void *m, void *b) { ((Box<Mesh> *) m)->p->set_bsdf(((Box<BSDF> *) b)->p); }
 void mih_mesh_set_emitter(void *m, void *e) { ((Box<Mesh> *) m)->p->set_emitter(((Box<AreaLight> *) e)->p); }
 
+void *mih_envmap_create(void *props, uint32_t w, uint32_t h, const float *rgba) {
+    MIH_TRY
+        auto e = std::make_shared<EnvironmentMapEmitter>(*(Properties *) props);
+        e->set_bitmap(w, h, rgba);
+        return new Box<EnvironmentMapEmitter>{ e }; MIH_CATCH(nullptr)
+}
+void mih_envmap_destroy(void *e) { delete (Box<EnvironmentMapEmitter> *) e; }
+int mih_scene_add_envmap(void *s, void *e) { MIH_TRY ((Box<Scene> *) s)->p->add_emitter(((Box<EnvironmentMapEmitter> *) e)->p); return 0; MIH_CATCH(-1) }
 void *mih_scene_create() { return new Box<Scene>{ std::make_shared<Scene>() }; }
 void mih_scene_destroy(void *s) { delete (Box<Scene> *) s; }
 int mih_scene_add_shape(void *s, void *m) { MIH_TRY ((Box<Scene> *) s)->p->add_shape(((Box<Mesh> *) m)->p); return 0; MIH_CATCH(-1) }

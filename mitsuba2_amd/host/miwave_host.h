@@ -219,6 +219,24 @@ private:
     Color3f m_radiance;
 };
 
+// src/emitters/envmap.cpp. The reference loads `filename` through Bitmap (out of scope here: no
+// image I/O on the path); the linear RGBA float32 pixels it would hold after
+// bitmap->convert(RGBA, Float32) (:71-75) are handed over with set_bitmap().
+class EnvironmentMapEmitter {
+public:
+    explicit EnvironmentMapEmitter(const Properties &props);  // `scale` (:124), `to_world` (endpoint.cpp)
+    void set_bitmap(uint32_t width, uint32_t height, const float *rgba);
+    uint32_t width() const { return m_width; }
+    uint32_t height() const { return m_height; }
+    float scale() const { return m_scale; }
+    const Transform4f &world_transform() const { return m_to_world; }
+    const std::vector<float> &data() const { return m_data; }
+private:
+    float m_scale; Transform4f m_to_world;
+    uint32_t m_width = 0, m_height = 0;
+    std::vector<float> m_data;
+};
+
 class Mesh {                                                  // include/mitsuba/render/mesh.h
 public:
     Mesh(std::string name, std::vector<float> vertex_positions, std::vector<uint32_t> faces,
@@ -252,6 +270,10 @@ public:
     ~Scene();
     Scene(const Scene &) = delete;
     void add_shape(std::shared_ptr<Mesh> mesh);               // scene.cpp:33-61
+    // an <emitter type="envmap"> child: takes its place in the emitter order after the shapes added
+    // so far; "Only one environment emitter can be specified per scene." (scene.cpp:47-50)
+    void add_emitter(std::shared_ptr<EnvironmentMapEmitter> env);
+    const EnvironmentMapEmitter *environment() const { return m_env.get(); }   // scene.h:150-151
     // finishes construction: default BSDFs (shape.cpp:75-81), flatten, upload, build accel (scene.cpp:94-97)
     void build(int device = 0, int bvh_quality = 1);
     const std::vector<std::shared_ptr<Mesh>> &shapes() const { return m_shapes; }
@@ -270,6 +292,7 @@ private:
     std::vector<mi_shape> m_shape_recs;
     std::vector<mi_bsdf> m_bsdf_recs;
     std::vector<mi_emitter> m_emitters;
+    std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;
     bool m_built = false;

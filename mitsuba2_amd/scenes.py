@@ -142,6 +142,34 @@ def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_le
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 
+def sky_envmap(width=64, height=32, seed=1):
+    """Synthetic lat-long HDR sky (the reference's data submodule is absent): vertical sky
+    gradient, warm horizon band, dark ground, a sun blob and a little seeded noise. -> H x W x 3 float32."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(height, dtype=np.float64) + 0.0) / (height - 1)          # 0 = +Y pole
+    u = np.arange(width, dtype=np.float64) / (width - 1)
+    U, V = np.meshgrid(u, v)
+    sky = np.stack([0.25 + 0.3 * V, 0.45 + 0.3 * V, 0.9 - 0.2 * V], 2)
+    horizon = np.exp(-((V - 0.5) / 0.06) ** 2)[..., None] * np.array([0.9, 0.6, 0.3])
+    ground = np.array([0.12, 0.10, 0.08])
+    img = np.where((V < 0.5)[..., None], sky + horizon, ground + 0.3 * horizon)
+    sun = np.exp(-(((U - 0.3) / 0.03) ** 2 + ((V - 0.28) / 0.04) ** 2))[..., None] * np.array([60.0, 52.0, 40.0])
+    img = img + sun + 0.02 * rng.random((height, width, 3))
+    return img.astype(np.float32)
+
+
+def open_box(width, height, spp, seed=0, device=0, with_area_light=True, envmap_after=None, env_scale=1.0,
+             env_size=(64, 32), ball_level=1, rfilter="gaussian", **film_kw):
+    """Cornell box without its ceiling under the synthetic sky: area light + environment map (the emitter mix
+    of config C4), rough-conductor and dielectric balls. -> (scene, sensor)."""
+    meshes = [m for m in cornell_box_meshes(False, ball_level) if m.name not in ("ceiling",) and
+              (with_area_light or m.name != "light")]
+    env = api.EnvMap(sky_envmap(env_size[0], env_size[1]), scale=env_scale,
+                     to_world=dict(origin=(0, 0, 0), target=(0.3, 0.1, 1.0), up=(0, 1, 0)))
+    scene = api.Scene(meshes, envmap=env, envmap_after=envmap_after).build(device)
+    return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
+
+
 def stairs(num_steps):
     """src/librender/tests/mesh_generation.py:27-59"""
     size_step = 1.0 / num_steps

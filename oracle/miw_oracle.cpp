@@ -47,6 +47,7 @@
 #include "../mitsuba2_amd/csrc/miw/bsdf.h"
 #include "../mitsuba2_amd/csrc/miw/scene.h"
 #include "../mitsuba2_amd/csrc/miw/film.h"
+#include "../mitsuba2_amd/csrc/envmap_build.h"
 
 using namespace miw;
 
@@ -73,6 +74,7 @@ struct OScene {
     std::vector<BsdfRec> bsdfs;
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
+    EnvmapTables env;                   // environment emitter (scene.cpp:47-51) or !ok
     SceneView view{};
 };
 
@@ -82,7 +84,9 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     bool any_normals = false;
     for (uint32_t i = 0; i < s->shape_count; ++i) {
         const mi_shape &sh = s->shapes[i];
-        o.shapes[i] = ShapeRec{ sh.bsdf, sh.emitter, sh.flags & 1u, 0 };
+        int32_t emitter_id = sh.emitter;            // Scene::m_emitters order: the envmap sits at envmap->emitter_index
+        if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
+        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & 1u, 0 };
         any_normals = any_normals || (sh.flags & 1u);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris[f].shape = i;
     }
@@ -105,7 +109,9 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:55-87)
     bool emit_normals = false;
+    auto push_env = [&]() { EmitterRec r; std::memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; o.emitters.push_back(r); };
     for (uint32_t i = 0; i < s->emitter_count; ++i) {
+        if (s->envmap && s->envmap->emitter_index == i) push_env();
         const mi_emitter &e = s->emitters[i];
         const mi_shape &sh = s->shapes[e.shape];
         EmitterRec r; std::memset(&r, 0, sizeof r);
@@ -131,7 +137,15 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         r.valid_lo = vlo; r.valid_hi = vhi; r.sum = (float) sum; r.normalization = (float) (1.0 / sum);
         o.emitters.push_back(r);
     }
+    if (s->envmap && s->envmap->emitter_index >= s->emitter_count) push_env();
+    if (s->envmap) {
+        o.env = envmap_build(*s->envmap);
+        if (!o.env.ok) return false;
+        o.env.rec.data = o.env.data.data(); o.env.rec.levels = o.env.levels.data();
+    }
     SceneView &v = o.view;
+    v.env = s->envmap ? &o.env.rec : nullptr;
+    v.leaf_boxes = nullptr;
     v.nodes = nullptr; v.node_count = 0;
     v.tris = o.tris.data(); v.tri_count = (uint32_t) o.tris.size();
     v.tri_vn = o.tri_vn.empty() ? nullptr : o.tri_vn.data();
@@ -199,12 +213,18 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int
     SurfaceInteraction si;                               // :120
     bool si_valid = ray_intersect(sc, ray, si);
     bool valid_ray = si_valid;                           // :121
-    int32_t emitter = si_valid ? sc.shapes[si.shape].emitter : -1;   // :122, scene.h:243-253 (no environment)
+    const int32_t env_id = view.env ? (int32_t) view.env->emitter_index : -1;
+    // :122, scene.h:243-253: a miss returns scene->environment()
+    int32_t emitter = si_valid ? sc.shapes[si.shape].emitter : env_id;
+    V3 miss_d = ray.d;                                   // -si.wi of an invalid interaction (interaction.h:591)
 
     for (int depth = 1;; ++depth) {
         if (emitter >= 0) {                              // :126-129
-            if (active)
-                result = result + emission_weight * throughput * emitter_eval(sc.emitters[emitter], si.wi);
+            if (active) {
+                V3 radiance = si_valid ? emitter_eval(sc.emitters[emitter], si.wi)      // area.cpp:63-71
+                                       : env_eval(*view.env, miss_d);                    // envmap.cpp:134-146
+                result = result + emission_weight * throughput * radiance;
+            }
         }
         active = active && si_valid;                     // :131
 
@@ -263,15 +283,20 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int
         bool si_bsdf_valid = ray_intersect(sc, next, si_bsdf);
 
         // :194-205
-        emitter = si_bsdf_valid ? sc.shapes[si_bsdf.shape].emitter : -1;
+        emitter = si_bsdf_valid ? sc.shapes[si_bsdf.shape].emitter : env_id;
+        miss_d = next.d;
         if (emitter >= 0) {
-            // DirectionSample3f ds(si_bsdf, si), records.h:167-173
-            V3 d = si_bsdf.p - si.p;
-            float dist = norm(d);
-            d = d / dist;
+            // DirectionSample3f ds(si_bsdf, si), records.h:167-173: d = -wi (= ray.d) for environment emitters
+            V3 d = next.d; float dist = 0.f; V3 n = v3(0.f);
+            if (si_bsdf_valid) {
+                d = si_bsdf.p - si.p;
+                dist = norm(d);
+                d = d / dist;
+                n = si_bsdf.sh.n;
+            }
             float emitter_pdf = 0.f;
             if (!(bs.sampled_type & BSDF_Delta))
-                emitter_pdf = pdf_emitter_direction(view, (uint32_t) emitter, d, dist, si_bsdf.sh.n);
+                emitter_pdf = pdf_emitter_direction(view, (uint32_t) emitter, d, dist, n);
             emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }
         si = si_bsdf; si_valid = si_bsdf_valid;          // :207
@@ -576,6 +601,24 @@ void orc_microfacet(int op, uint32_t type, float au, float av, int sample_visibl
         default: { V3 m; float pdf; mf_sample(d, w, v2(m_or_u[0], m_or_u[1]), m, pdf); out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf; }
     }
 }
+// Hierarchical2D<Float, 0> over caller data (w x h floats): op 0 = sample(xy) -> x, y, pdf ; op 1 = eval(xy) -> pdf
+int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *xy, float *out3) {
+    FtzScope f;
+    // reuse the envmap table builder on a grey bitmap whose luminance * sin(theta) equals `data` is not possible in
+    // general (sin(theta) = 0 at the poles), so the hierarchy is built here directly from `data`
+    // exactly as envmap_build does for its luminance array.
+    std::vector<float> rgba((size_t) w * h * 4, 1.f);
+    mi_envmap e; std::memset(&e, 0, sizeof e);
+    e.rgba = rgba.data(); e.width = w; e.height = h; e.scale = 1.f;
+    for (int i = 0; i < 4; ++i) e.to_world[i * 5] = 1.f;
+    e.bsphere_radius = 1.f;
+    EnvmapTables t = envmap_build_from_density(e, data);
+    if (!t.ok) return -1;
+    t.rec.data = t.data.data(); t.rec.levels = t.levels.data();
+    if (op == 0) { float pdf; V2 r = hier2d_sample(t.rec, v2(xy[0], xy[1]), pdf); out3[0] = r.x; out3[1] = r.y; out3[2] = pdf; }
+    else out3[0] = hier2d_eval(t.rec, v2(xy[0], xy[1]));
+    return 0;
+}
 // special.h restatements: out4 = exp, log, erf, erfinv of x
 void orc_special(float x, float *out4) {
     FtzScope f;
@@ -679,6 +722,16 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
             } break;
             case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
+            case MI_EVAL_ENVMAP: {
+                if (!have_scene || !sc.view.env) return -1;
+                V3 d = v3(a[0], a[1], a[2]);
+                V3 e = env_eval(*sc.view.env, d); o[0] = e.x; o[1] = e.y; o[2] = e.z;
+                o[3] = env_pdf_direction(*sc.view.env, d);
+                V3 sd, sp, sn; float dist, pdf;
+                V3 spec = env_sample_direction(*sc.view.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
+                o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
+        } break;
+                case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
             default: return -1;
         }
     }

@@ -54,6 +54,7 @@ class Oracle:
         L.orc_microfacet.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_int, c_float_p, c_float_p, c_float_p]
         L.orc_ray_triangle.argtypes = [c_float_p, c_float_p, c_float_p]
         L.orc_special.argtypes = [C.c_float, c_float_p]
+        L.orc_hier2d.argtypes = [c_float_p, C.c_uint32, C.c_uint32, C.c_int, c_float_p, c_float_p]; L.orc_hier2d.restype = C.c_int
         L.orc_imageblock_put.argtypes = [C.POINTER(mi_render_cfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p,
                                          c_float_p, C.c_int, c_float_p]
         L.orc_imageblock_put.restype = C.c_int

@@ -17,6 +17,7 @@
 #include "../mitsuba2_amd/csrc/miw/film_gather.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
+#include "../mitsuba2_amd/csrc/envmap_build.h"
 
 using namespace miw;
 
@@ -26,6 +27,7 @@ struct EmuScene {
     std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     BvhBuildResult bvh; std::vector<float> vn_leaf;
+    EnvmapTables env;
     SceneView view{};
 };
 
@@ -35,7 +37,9 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     bool any_normals = false;
     for (uint32_t i = 0; i < s->shape_count; ++i) {
         const mi_shape &sh = s->shapes[i];
-        o.shapes[i] = ShapeRec{ sh.bsdf, sh.emitter, sh.flags & 1u, 0 };
+        int32_t emitter_id = sh.emitter;
+        if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
+        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & 1u, 0 };
         any_normals = any_normals || (sh.flags & 1u);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris_in[f].shape = i;
     }
@@ -57,7 +61,9 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
     }
     bool emit_normals = false;
+    auto push_env = [&]() { EmitterRec r; std::memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; o.emitters.push_back(r); };
     for (uint32_t i = 0; i < s->emitter_count; ++i) {
+        if (s->envmap && s->envmap->emitter_index == i) push_env();
         const mi_emitter &e = s->emitters[i];
         const mi_shape &sh = s->shapes[e.shape];
         EmitterRec r; std::memset(&r, 0, sizeof r);
@@ -79,6 +85,12 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         r.valid_lo = vlo; r.valid_hi = vhi; r.sum = (float) sum; r.normalization = (float) (1.0 / sum);
         o.emitters.push_back(r);
     }
+    if (s->envmap && s->envmap->emitter_index >= s->emitter_count) push_env();
+    if (s->envmap) {
+        o.env = envmap_build(*s->envmap);
+        if (!o.env.ok) return false;
+        o.env.rec.data = o.env.data.data(); o.env.rec.levels = o.env.levels.data();
+    }
     o.bvh = bvh_build_sah(o.tris_in, -1.f, (uint32_t) max_leaf);
     if (!o.vn_in.empty()) {
         o.vn_leaf.resize(o.vn_in.size());
@@ -93,6 +105,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
+    v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr;
     return true;
 }
 // plain IEEE float environment (denormals preserved), see miw_oracle.cpp FtzScope

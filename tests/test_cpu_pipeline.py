@@ -52,6 +52,27 @@ def test_rough_conductor_variants(native, oracle, metal):
     assert not np.array_equal(g32, o32)                             # the variant really changes the image
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(with_area_light=False), dict(envmap_after=0), dict(env_scale=0.25)])
+def test_environment_map_scene(native, oracle, kw):
+    """Environment emitter (src/emitters/envmap.cpp): misses see the map (scene.h:248-249), it is sampled through
+    the hierarchical warp with MIS against BSDF sampling, alone or mixed with an area light, at either position
+    in the emitter order — wavefront stages and the resident sample loop both == the scalar oracle."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.open_box(40, 32, 6, device=-1, **kw)
+    job, o32, o64, st, e64, e32, est = _both(native, oracle, scene, sensor)
+    assert est[1] == st.segments and np.array_equal(e32, o32) and np.isfinite(o32).all()
+    assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
+    job.cfg.plan = 2
+    r64, r32, rst = oracle.emu_render(scene.desc(), job)
+    assert rst[1] == st.segments and np.array_equal(r32, o32)
+    top = o32[:8, :, 1] / o32[:8, :, 4]                             # rays leaving through the open top see sky
+    assert top.mean() > 0.05
+    if kw.get("env_scale"):
+        full, _ = scenes.open_box(40, 32, 6, device=-1)
+        f32, _, _ = oracle.render(full.desc(), native.PathIntegrator().render_job(sensor), threads=4)
+        assert not np.array_equal(f32, o32)
+
+
 @pytest.mark.parametrize("per_launch", [1, 4, 5, 64])
 def test_resident_plan_equals_scalar_path_integrator(native, oracle, per_launch):
     """pixel_render (the resident plan's per-pixel sample loop), advanced in passes of `per_launch`

@@ -575,3 +575,64 @@ def test_parse_fov_and_errors(native):
         api.Sensor(film, sampler, fov=40.0, near_clip=5.0, far_clip=1.0)
     with pytest.raises(RuntimeError):
         api.Sensor(film, sampler, fov=200.0)
+
+
+# ---- src/libcore/tests/test_distr_2d.py:8-47 (Hierarchical2D0 spot checks vs Mathematica) -----------------------
+def _h2d(oracle, data, op, xy):
+    d = np.ascontiguousarray(data, np.float32); out = np.zeros(3, np.float32)
+    rc = oracle.L.orc_hier2d(fp(d), d.shape[1], d.shape[0], op, fp(np.asarray(xy, np.float32)), fp(out))
+    assert rc == 0
+    return out
+
+
+def _bilinear_to_square(v00, v10, v01, v11, s):
+    """include/mitsuba/core/warp.h:368-426 in float64 (the reference test computes its expectations with it)"""
+    def lerp(a, b, t): return a + (b - a) * t
+    def lin2int(v0, v1, x): return x * ((2 - x) * v0 + x * v1) / (v0 + v1) if abs(v0 - v1) > 1e-4 * (v0 + v1) else x
+    r0, r1 = v00 + v10, v01 + v11
+    c0, c1 = lerp(v00, v01, s[1]), lerp(v10, v11, s[1])
+    pdf = lerp(c0, c1, s[0])
+    return [lin2int(c0, c1, s[0]), lin2int(r0, r1, s[1])], pdf
+
+
+def test_hierarchical2d_spot_checks(oracle):
+    ref = np.array([[1, 2, 5], [9, 7, 2]], np.float32)            # mismatched X/Y resolution, odd number of columns
+    intg = np.array([19, 16]) / 35
+    a = lambda x, y: np.allclose(x, y, atol=1e-6)
+    assert a(_h2d(oracle, ref, 0, [0, 0]), [0, 0, 8.0 / 35.0])
+    assert a(_h2d(oracle, ref, 0, [1, 1]), [1, 1, 16.0 / 35.0])
+    assert a(_h2d(oracle, ref, 0, [intg[0], 0]), [0.5, 0, 16.0 / 35.0])
+    s, pdf = _bilinear_to_square(1, 2, 9, 7, [0.4, 0.3])
+    s[0] *= intg[0]; pdf *= 8.0 / 35.0
+    assert a(_h2d(oracle, ref, 0, s), [0.2, 0.3, pdf]) and a(_h2d(oracle, ref, 1, [0.2, 0.3])[0], pdf)
+    s, pdf = _bilinear_to_square(2, 5, 7, 2, [0.4, 0.3])
+    s[0] = s[0] * intg[1] + intg[0]; pdf *= 8.0 / 35.0
+    assert a(_h2d(oracle, ref, 0, s), [0.7, 0.3, pdf]) and a(_h2d(oracle, ref, 1, [0.7, 0.3])[0], pdf)
+
+
+def test_hierarchical2d_sample_matches_its_density(oracle):
+    """forward warp + eval are consistent on a random 7 x 5 grid: returned pdf == eval(position), positions in [0,1]^2,
+    and the warp is a bijection of strata (histogram of warped stratified samples ~ integral of the density)."""
+    rng = np.random.default_rng(5)
+    data = (rng.random((5, 7)) * 10).astype(np.float32)
+    n = 64
+    hist = np.zeros((4, 6))
+    for i in range(n):
+        for j in range(n):
+            r = _h2d(oracle, data, 0, [(i + 0.5) / n, (j + 0.5) / n])
+            assert 0 <= r[0] <= 1 and 0 <= r[1] <= 1
+            assert np.isclose(r[2], _h2d(oracle, data, 1, r[:2])[0], rtol=2e-4)
+            hist[min(int(r[1] * 4), 3), min(int(r[0] * 6), 5)] += 1
+    avg = (data[:-1, :-1] + data[:-1, 1:] + data[1:, :-1] + data[1:, 1:]) / 4
+    assert np.allclose(hist / n ** 2, avg / avg.sum(), atol=4e-3)
+
+
+def test_inverse_trig_accuracy(oracle):
+    x = np.linspace(-1, 1, 4001).astype(np.float32)
+    y = np.random.default_rng(2).uniform(-3, 3, 4001).astype(np.float32)
+    got = oracle.eval(10, np.stack([y, x], 1))
+    assert np.max(np.abs(got[:, 0] - np.arctan2(y.astype(np.float64), x.astype(np.float64)))) < 4e-7
+    assert np.max(np.abs(got[:, 1] - np.arccos(x.astype(np.float64)))) < 4e-7
+    assert np.max(np.abs(got[:, 2] - np.arcsin(x.astype(np.float64)))) < 3e-7
+    sp = oracle.eval(10, np.array([[0.0, -1.0], [-0.0, -1.0], [0.0, 1.0], [1.0, 0.0], [-1.0, 0.0]], np.float32))[:, 0]
+    assert np.allclose(sp, [np.pi, -np.pi, 0.0, np.pi / 2, -np.pi / 2], atol=1e-7)
