@@ -145,7 +145,7 @@ typedef struct {
      *     (trace closest, shade, trace any) per depth-loop iteration,
      * 2 = resident: the whole depth loop of a pixel runs in registers, geometry in LDS
      *     (or read through L2), the pixel is advanced `samples_per_launch` samples per launch,
-     * 0 = auto: 2 when the geometry is LDS-resident, else 1                          */
+     * 0 = auto: 2 when the geometry is LDS-resident or the tree fits the LDS-stack walk, else 1 */
     int32_t plan;
     int32_t samples_per_launch;               /* plan 2: <= 0 = default (128)            */
 } mi_render_cfg;

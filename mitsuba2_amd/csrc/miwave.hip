@@ -59,6 +59,8 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
     uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets (+ leaf boxes), no BVH walk
     uint32_t leaves;        // brute: number of LeafBox records staged behind the packets
+    uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
+    uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
 };
 
 // Padded bounding box of one BVH leaf (<= 4 consecutive triangles in leaf order), 32 B = 2 x b128.
@@ -95,6 +97,82 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
     uint4 *dst_t = smem + n16;
     for (uint32_t i = threadIdx.x; i < t16; i += blockDim.x) dst_t[i] = src_t[i];
     __syncthreads();
+}
+
+// Candidate-box test shared by the tiny-scene filter (trace2) and the stack traversal below: the slab
+// test of bvh.h re-expressed for speed — v_rcp_f32 for 1/d, t = fma(plane, inv_d, -o*inv_d), hardware
+// min/max (v_min3/v_max3). It only has to stay CONSERVATIVE, not bit-reproducible: boxes are padded by
+// 1e-5 x the scene extent (bvh_build.h), orders of magnitude above the rounding differences between the
+// two forms, and every hit is decided by the exact Moeller-Trumbore test.
+struct FastRay { V3 inv_d, neg_o_inv_d; float mint; };
+__device__ __forceinline__ FastRay fast_ray(V3 o, V3 d, float mint) {
+    FastRay r;
+    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
+          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
+          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
+    r.inv_d = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
+    r.mint = mint;
+    return r;
+}
+__device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, const FastRay &r, float tmax_wide, float &tn_out) {
+    float t0x = __builtin_fmaf(lo[0], r.inv_d.x, r.neg_o_inv_d.x), t1x = __builtin_fmaf(hi[0], r.inv_d.x, r.neg_o_inv_d.x),
+          t0y = __builtin_fmaf(lo[1], r.inv_d.y, r.neg_o_inv_d.y), t1y = __builtin_fmaf(hi[1], r.inv_d.y, r.neg_o_inv_d.y),
+          t0z = __builtin_fmaf(lo[2], r.inv_d.z, r.neg_o_inv_d.z), t1z = __builtin_fmaf(hi[2], r.inv_d.z, r.neg_o_inv_d.z);
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    // widened like bvh.h's box_test, plus slack for the fma-form rounding
+    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
+    tn_out = tn;
+    return tn <= tf && tn <= tmax_wide;
+}
+__device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t), 2e-6f, t); }
+
+// Stack traversal of the BVH2 for scenes that do not fit LDS: the per-lane stack lives in LDS
+// (entry-major, one dword per lane per entry: conflict-free), the top of the tree is read from LDS
+// and the rest through L1/L2. Same observable result as bvh_intersect (== brute force, ties to the
+// smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
+// trail walk of bvh.h runs.
+#define MIW_STACK_ENTRIES 32
+template <bool AnyHit, typename NodeAt, typename TriAt>
+__device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
+                                                    V3 o, V3 d, float mint, float maxt, Hit &best) {
+    best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+    const FastRay r = fast_ray(o, d, mint);
+    float tmax = maxt;
+    int32_t cur = 0, sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode &n = node_at(cur);
+            float tn0, tn1;
+            const float wide = widen(tmax);
+            const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
+            const int32_t c0 = n.child0, c1 = n.child1;
+            if (h0 && h1) {
+                const bool second_first = tn1 < tn0;
+                stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
+                cur = second_first ? c1 : c0;
+                continue;
+            }
+            if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
+        } else {
+            const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const Tri &tr = tri_at(first + i);
+                float t, u, v;
+                if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), o, d, mint, maxt, t, u, v)) {
+                    if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
+                    if (t < best.t || (t == best.t && tr.prim < best.prim)) {
+                        best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
+                        tmax = t;
+                    }
+                }
+            }
+        }
+        if (sp == 0) return best.tri != MIW_MISS;
+        --sp; cur = stack[sp * MIW_BLOCK];
+    }
 }
 
 template <bool AnyHit>
@@ -135,6 +213,10 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
             return (uint32_t) i < ns ? lnodes[i] : gnodes[i];
         };
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
+        if (cfg.stack) {
+            int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
+            return bvh_intersect_stack<AnyHit>(node_at, tri_at, stack, o, d, mint, maxt, h);
+        }
         return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
     }
 }
@@ -149,34 +231,6 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
 //      max-over-lanes(candidates) times instead of 2 x tri_count.
 // Results are those of the full sweep: closest hit with ties to the smaller primitive id,
 // "any triangle passes" for S.
-// Candidate filter of trace2: the slab test of bvh.h re-expressed for speed — v_rcp_f32 for
-// 1/d, t = fma(plane, inv_d, -o*inv_d), hardware min/max (v_min3/v_max3) — it only has to stay
-// CONSERVATIVE, not bit-reproducible: leaf boxes are padded by 1e-5 x the scene extent
-// (bvh_build.h), five orders of magnitude above the rounding differences between the two forms,
-// and every accepted candidate is then decided by the exact Moeller-Trumbore test.
-struct FastRay { V3 inv_d, neg_o_inv_d; float mint; };
-__device__ __forceinline__ FastRay fast_ray(V3 o, V3 d, float mint) {
-    FastRay r;
-    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
-          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
-          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
-    r.inv_d = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
-    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
-    r.mint = mint;
-    return r;
-}
-__device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, const FastRay &r, float tmax_wide) {
-    float t0x = __builtin_fmaf(lo[0], r.inv_d.x, r.neg_o_inv_d.x), t1x = __builtin_fmaf(hi[0], r.inv_d.x, r.neg_o_inv_d.x),
-          t0y = __builtin_fmaf(lo[1], r.inv_d.y, r.neg_o_inv_d.y), t1y = __builtin_fmaf(hi[1], r.inv_d.y, r.neg_o_inv_d.y),
-          t0z = __builtin_fmaf(lo[2], r.inv_d.z, r.neg_o_inv_d.z), t1z = __builtin_fmaf(hi[2], r.inv_d.z, r.neg_o_inv_d.z);
-    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
-    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-    // widened like bvh.h's box_test, plus an absolute slack for the fma-form rounding near the origin
-    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
-    return tn <= tf && tn <= tmax_wide;
-}
-
 __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                        V3 o, float mint, V3 dE, float maxtE, bool hasE,
                                        V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
@@ -186,13 +240,14 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
         const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
         const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
-        const float wideE = __builtin_fmaf(abs_(maxtE), 2e-6f, maxtE), wideS = __builtin_fmaf(abs_(maxtS), 2e-6f, maxtS);
+        const float wideE = widen(maxtE), wideS = widen(maxtS);
         unsigned long long mE = 0, mS = 0;
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
             const unsigned long long bits = (b.count >= 64u ? ~0ull : ((1ull << b.count) - 1ull)) << b.first;
-            if (box_test_fast(b.lo, b.hi, rE, wideE)) mE |= bits;
-            if (box_test_fast(b.lo, b.hi, rS, wideS)) mS |= bits;
+            float tn;
+            if (box_test_fast(b.lo, b.hi, rE, wideE, tn)) mE |= bits;
+            if (box_test_fast(b.lo, b.hi, rS, wideS, tn)) mS |= bits;
         }
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
@@ -928,7 +983,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
     size_t all = r.nodes.size() * sizeof(BvhNode) + r.tris.size() * sizeof(Tri);
-    c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; v.leaf_boxes = nullptr;
+    c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr;
     if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
@@ -950,6 +1005,11 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
         else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
         c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
+        c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0;
+        if (all > 16 * 1024 && r.depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK")) {
+            c->lds_cfg.stack = 1; c->lds_cfg.stack16 = (uint32_t) (c->lds_bytes / 16);
+            c->lds_bytes += (size_t) MIW_STACK_ENTRIES * MIW_BLOCK * sizeof(int32_t);
+        }
     }
 
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1043,7 +1103,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     int plan = cfg->plan;
     if (plan < 0 || plan > 2) return fail(c, MI_ERR_INVALID, "render: plan must be 0, 1 or 2");
     const bool lds_resident = c->lds_cfg.brute || (c->lds_cfg.nodes_staged >= c->view.node_count && c->lds_cfg.tris_staged >= c->view.tri_count);
-    if (plan == 0) plan = lds_resident ? 2 : 1;
+    // measured on MI355X: the resident plan wins whenever the scene query runs out of LDS
+    // (packets / staged tree) or with the LDS-stack walk; the queue plan remains for the stackless fallback
+    if (plan == 0) plan = (lds_resident || c->lds_cfg.stack) ? 2 : 1;
     c->counters.plan = (uint32_t) plan;
 
     size_t nl = std::max<uint32_t>(n_lanes, 1);
