@@ -309,13 +309,15 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
 }
 
 // Stage 2 of the HBM-queue plan: one iteration of the depth loop for one lane.
-// Returns true while the lane still has work (not DONE).
+// Returns the lane's new flag word: LF_DONE clear = the lane still has work; LF_RAY_ACTIVE = an
+// extension / primary ray is queued; LF_HAS_SHADOW = a shadow ray is queued; LF_DEAD_PENDING = the
+// sample only waits for that shadow ray (the device builds the next iteration's work lists from these).
 template <typename Sink>
-MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
-                       uint32_t lane, Counters *cnt_local, Sink sink) {
+MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
+                           uint32_t lane, Counters *cnt_local, Sink sink) {
     LaneRegs L;
     lane_load(Q, lane, L);
-    if (L.flags & LF_DONE) return false;
+    if (L.flags & LF_DONE) return LF_DONE;
     lane_load_path(Q, lane, L);
     const bool had_shadow = (L.flags & LF_HAS_SHADOW) != 0;
 
@@ -361,7 +363,7 @@ MIW_HD bool lane_shade(const RenderParams &P, const SceneView &sc, const LaneQue
     }
     lane_store(Q, lane, L, store_pos);
     if (had_shadow && !(L.flags & LF_HAS_SHADOW)) lane_clear_shadow(Q, lane);
-    return !(L.flags & LF_DONE);
+    return L.flags;
 }
 
 // The register-resident plan: a run of one pixel's sample loop (render_block's inner

@@ -278,6 +278,33 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
 // kernels
 // ---------------------------------------------------------------------------------------
 
+// ---- wavefront plan: stream compaction and material sorting -----------------------------
+// The stage kernels do not sweep all lanes: every workgroup consumes a dense list of the lane ids
+// (of its own 256-lane slice) that need the stage, and appends the lanes that need the next stage
+// to that stage's list. Appending is a wavefront-level ballot + popcount prefix sum with one LDS
+// atomic per wave per list — no global atomics (same-address device atomics serialise at ~12 ns),
+// no memsets: a workgroup owns segment [g*256, g*256+256) of every list and publishes its counts when
+// it finishes. Lists are double-buffered by iteration parity. k_trace<closest> files every traced
+// lane under the BSDF type of the surface it hit, so k_shade walks the lists type by type: a
+// wavefront shades one material (at most three wavefronts per workgroup straddle a boundary), idle
+// wavefronts retire at once. Lane state stays lane-indexed (SoA of 16-byte fields), so list order
+// never changes a result.
+enum { WL_E = 0, WL_S = 1, WL_SHADE0 = 2, WL_KEYS = 4, WL_LISTS = 6 };   // shade keys: bsdf type 0..2, 3 = no surface
+struct WorkLists {
+    uint32_t *list[WL_LISTS];     // n_lanes entries each, segmented per workgroup
+    uint32_t *count;              // [workgroup][WL_LISTS]
+};
+
+__device__ __forceinline__ void wave_append(bool pred, uint32_t *segment, uint32_t *lds_counter, uint32_t value) {
+    const unsigned long long b = __ballot(pred);
+    if (b == 0ull) return;                                     // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(lds_counter, (uint32_t) __popcll(b));
+    base = (uint32_t) __shfl((int) base, (int) leader, 64);
+    if (pred) segment[base + (uint32_t) __popcll(b & ((1ull << lane) - 1ull))] = value;
+}
+
 struct InitArgs {
     const uint32_t *block_ids;    // per block (row-major grid)
     const uint32_t *tile_list;    // or nullptr
@@ -286,9 +313,8 @@ struct InitArgs {
     uint64_t base_seed;
 };
 
-__global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQueues Q, uint32_t *pixel_out, InitArgs A) {
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= P.n_lanes) return;
+// -> true when the lane starts with a camera ray queued
+__device__ __forceinline__ bool init_one_lane(const RenderParams &P, const LaneQueues &Q, uint32_t *pixel_out, const InitArgs &A, uint32_t lane) {
     uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
     uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
     uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
@@ -300,31 +326,60 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQu
     if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
         pixel_out[lane] = 0;
         lane_init_unused(Q, lane);
-        return;
+        return false;
     }
     uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
     uint32_t pixel = px | (py << 16);
     pixel_out[lane] = pixel;
     uint64_t seed = A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i;   // :198
     lane_init(P, Q, lane, pixel, seed);
+    return P.spp > 0;
+}
+
+__global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQueues Q, uint32_t *pixel_out, InitArgs A, WorkLists W) {
+    __shared__ uint32_t s_cnt[WL_LISTS];
+    if (threadIdx.x < WL_LISTS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    bool has_ray = false;
+    if (lane < P.n_lanes) has_ray = init_one_lane(P, Q, pixel_out, A, lane);
+    wave_append(has_ray, W.list[WL_E] + blockIdx.x * MIW_BLOCK, &s_cnt[WL_E], lane);
+    __syncthreads();
+    if (threadIdx.x < WL_LISTS) W.count[blockIdx.x * WL_LISTS + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
 template <bool AnyHit>
-__global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q, uint32_t n_lanes, TraceLds cfg) {
+__global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q, TraceLds cfg, WorkLists io) {
     extern __shared__ uint4 smem[];
-    stage_to_lds(sc, cfg, smem);
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= n_lanes) return;
-    F4 d = AnyHit ? Q.sh_d[lane] : Q.ray_d[lane];
-    if (d.w < 0.f) return;                                     // no ray queued for this lane
-    F4 o = Q.ray_o[lane];
-    Hit h;
-    bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, h);
-    if (AnyHit) {
-        Q.sh_vis[lane] = hit ? 0u : 1u;
-    } else {
-        F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
-        Q.hit[lane] = r;
+    __shared__ uint32_t s_cnt[WL_KEYS];
+    const uint32_t seg = blockIdx.x * MIW_BLOCK, *cnt = io.count + blockIdx.x * WL_LISTS;
+    const uint32_t n = cnt[AnyHit ? WL_S : WL_E];
+    if (AnyHit && n == 0) return;                              // nothing to test in this slice (uniform)
+    // the "no surface" list already holds the lanes k_shade parked there (samples waiting for a shadow ray)
+    if (!AnyHit && threadIdx.x < WL_KEYS) s_cnt[threadIdx.x] = threadIdx.x == WL_KEYS - 1 ? cnt[WL_SHADE0 + WL_KEYS - 1] : 0u;
+    stage_to_lds(sc, cfg, smem);                               // ends with __syncthreads()
+    const bool mine = threadIdx.x < n;
+    uint32_t lane = 0, key = WL_KEYS - 1;
+    if (mine) {
+        lane = io.list[AnyHit ? WL_S : WL_E][seg + threadIdx.x];
+        F4 d = AnyHit ? Q.sh_d[lane] : Q.ray_d[lane];
+        F4 o = Q.ray_o[lane];
+        Hit h;
+        bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, h);
+        if (AnyHit) {
+            Q.sh_vis[lane] = hit ? 0u : 1u;
+        } else {
+            F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
+            Q.hit[lane] = r;
+            if (hit) key = sc.bsdfs[sc.shapes[sc.tris[h.tri].shape].bsdf].type;    // material sort key
+        }
+    }
+    if (!AnyHit) {
+#pragma unroll
+        for (uint32_t k = 0; k < WL_KEYS; ++k)
+            wave_append(mine && key == k, io.list[WL_SHADE0 + k] + seg, &s_cnt[k], lane);
+        __syncthreads();
+        if (threadIdx.x < WL_KEYS) io.count[blockIdx.x * WL_LISTS + WL_SHADE0 + threadIdx.x] = s_cnt[threadIdx.x];
     }
 }
 
@@ -355,21 +410,42 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 template <bool UseLog>
 __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
-                                                       uint32_t count_active) {
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+                                                       uint32_t count_active, WorkLists in, WorkLists out) {
+    __shared__ uint32_t s_cnt[WL_LISTS];
+    if (threadIdx.x < WL_LISTS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t seg = blockIdx.x * MIW_BLOCK, *cnt_in = in.count + blockIdx.x * WL_LISTS;
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
-    if (lane < P.n_lanes) {
-        bool alive;
+    // this workgroup's four material lists, back to back
+    uint32_t lane = 0; bool mine = false;
+    {
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < WL_KEYS; ++k) {
+            const uint32_t n = cnt_in[WL_SHADE0 + k];
+            if (!mine && threadIdx.x - base < n) { lane = in.list[WL_SHADE0 + k][seg + threadIdx.x - base]; mine = true; }
+            base += n;
+        }
+    }
+    uint32_t flags = LF_DONE;
+    if (mine) {
         if (UseLog) {
             LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
-            alive = lane_shade(P, sc, Q, lane, &local, sink);
+            flags = lane_shade(P, sc, Q, lane, &local, sink);
         } else {
             FilmAdd add; add.accum = accum;
             SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
-            alive = lane_shade(P, sc, Q, lane, &local, sink);
+            flags = lane_shade(P, sc, Q, lane, &local, sink);
         }
-        local.active_lanes = (alive && count_active) ? 1 : 0;
+        local.active_lanes = (!(flags & LF_DONE) && count_active) ? 1 : 0;
     }
+    // next iteration's work: rays to trace, shadow rays to test, samples that only wait for a shadow ray
+    const bool alive = mine && !(flags & LF_DONE);
+    wave_append(alive && (flags & LF_RAY_ACTIVE), out.list[WL_E] + seg, &s_cnt[WL_E], lane);
+    wave_append(alive && (flags & LF_HAS_SHADOW), out.list[WL_S] + seg, &s_cnt[WL_S], lane);
+    wave_append(alive && (flags & LF_DEAD_PENDING), out.list[WL_SHADE0 + WL_KEYS - 1] + seg, &s_cnt[WL_SHADE0 + WL_KEYS - 1], lane);
+    __syncthreads();
+    if (threadIdx.x < WL_LISTS) out.count[blockIdx.x * WL_LISTS + threadIdx.x] = s_cnt[threadIdx.x];
     // Statistics: wave-level reduce, then one atomic per wave into one of
     // MIW_CNT_SHARDS counter records (same-address device atomics serialise at
     // ~12 ns each — 131k waves on one word would cost more than the shading).
@@ -754,6 +830,7 @@ struct mi_ctx {
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
     DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;
+    DevBuf<uint32_t> d_lists, d_list_counts;    // wavefront plan: 2 parities x WL_LISTS lists / counters
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
     DevBuf<Counters> d_cnt;
     Counters *h_cnt = nullptr;          // pinned
@@ -806,7 +883,7 @@ void mi_destroy(mi_ctx *c) {
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
-    c->d_accum.release(); c->d_out.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    c->d_accum.release(); c->d_out.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
     c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
@@ -1257,25 +1334,37 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         dim3 grid((n_lanes + MIW_BLOCK - 1) / MIW_BLOCK), block(MIW_BLOCK);
         InitArgs A; A.block_ids = c->d_block_ids.p; A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
-        MIW_TIMED(3, hipLaunchKernelGGL(k_init_lanes, grid, block, 0, s, P, Q, c->q_pixel.p, A));
+        // work lists (stream compaction + material sorting), double-buffered by iteration parity
+        const size_t n_wg = grid.x, seg_lanes = n_wg * MIW_BLOCK;
+        HIP_TRY(c, c->d_lists.resize((size_t) 2 * WL_LISTS * seg_lanes));
+        HIP_TRY(c, c->d_list_counts.resize(2 * WL_LISTS * n_wg));
+        HIP_TRY(c, hipMemsetAsync(c->d_list_counts.p, 0, 2 * WL_LISTS * n_wg * sizeof(uint32_t), s));
+        WorkLists WL[2];
+        for (int p = 0; p < 2; ++p) {
+            for (int l = 0; l < WL_LISTS; ++l) WL[p].list[l] = c->d_lists.p + ((size_t) p * WL_LISTS + l) * seg_lanes;
+            WL[p].count = c->d_list_counts.p + (size_t) p * WL_LISTS * n_wg;
+        }
+        MIW_TIMED(3, hipLaunchKernelGGL(k_init_lanes, grid, block, 0, s, P, Q, c->q_pixel.p, A, WL[0]));
         HIP_TRY(c, hipGetLastError());
 
         const int check_every = 16;
         bool first = true;
         unsigned long long active_prev = 0;
+        uint32_t parity = 0;
         for (;;) {
-            for (int it = 0; it < check_every; ++it) {
+            for (int it = 0; it < check_every; ++it, parity ^= 1u) {
+                const WorkLists &cur = WL[parity], &nxt = WL[parity ^ 1u];
                 if (!first) {
-                    MIW_TIMED(1, hipLaunchKernelGGL(k_trace<true>, grid, block, c->lds_bytes, s, c->view, Q, n_lanes, c->lds_cfg));
+                    MIW_TIMED(1, hipLaunchKernelGGL(k_trace<true>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
                     K.n_trace_any++;
                 }
-                MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, n_lanes, c->lds_cfg));
+                MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
                 K.n_trace_closest++;
                 const uint32_t count_active = it == check_every - 1 ? 1u : 0u;
                 if (film_mode == 1)
-                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, count_active));
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, count_active, cur, nxt));
                 else
-                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, count_active));
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, count_active, cur, nxt));
                 K.n_shade++; K.iterations++;
                 first = false;
             }

@@ -242,7 +242,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                 splat(pixel, sample_idx, pos, aovs);
                 if (do_log) log(pixel, sample_idx, pos, aovs);
             };
-            active += lane_shade(P, sc.view, Q, lane, &cnt, sink) ? 1 : 0;
+            active += (lane_shade(P, sc.view, Q, lane, &cnt, sink) & LF_DONE) ? 0 : 1;
         }
         ++iterations;
         if (active == 0) break;
