@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--scene", default="cornell", choices=["cornell", "matball"],
                     help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
                          "dielectric balls, 41k triangles; quoted at 1024 spp)")
+    ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
     ap.add_argument("--samples-per-launch", type=int, default=-1,
                     help="resident plan: samples each pixel advances per launch (-1 = all spp in one launch, 0 = library default)")
@@ -67,7 +68,8 @@ def main():
     W, H, SPP = args.width, args.height, args.spp
     scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
     dev = api.Device(local_rank)
-    dev.upload(scene.desc())                                 # scene + BVH resident before timing
+    dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
+    bvh = dev.counters()
     integ = api.PathIntegrator()
     integ.set_shard(rank, world)
     job = integ.render_job(sensor)
@@ -162,6 +164,8 @@ def main():
                                     "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, 40972 "
                                     "triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
+                       "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 3),
+                               "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
                        "parallelism": "tile-shard x%d + RCCL film reduce" % world if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},

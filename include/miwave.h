@@ -167,6 +167,8 @@ typedef struct {
     double ms_path;            /* plan 2: HIP-event time of the k_path_resident launches  */
     uint64_t n_path;
     double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
+    uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran the device LBVH builder    */
+    uint32_t pad_;
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */
@@ -183,7 +185,8 @@ mi_status mi_set_stream(mi_ctx *ctx, void *hip_stream);
  * (Mesh::build_pmf, src/librender/mesh.cpp:285-312) */
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 /* Scene::accel_init_cpu (src/librender/scene_native.inl:3-10): build the BVH.
- * quality 0 = LBVH built on the device, 1 = binned SAH built on the host.
+ * quality 0 = LBVH built on the device (Morton sort + Karras radix tree + bottom-up fit),
+ * 1 = binned SAH built on the host (better trees; the default of the host layer).
  * Scenes of <= 64 triangles are traced by a brute-force sweep over LDS-resident
  * triangle packets instead of the tree; OR in MI_BVH_FORCE_TREE to walk the tree
  * anyway (tests). */

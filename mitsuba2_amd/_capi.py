@@ -73,7 +73,8 @@ class mi_counters(C.Structure):
                 ("ms_bvh_build", C.c_double), ("bvh_nodes", C.c_uint32), ("bvh_tris", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("film_mode", C.c_uint32), ("plan", C.c_uint32),
                 ("ms_path", C.c_double), ("n_path", C.c_uint64),
-                ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double)]
+                ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double),
+                ("bvh_on_device", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4

@@ -38,6 +38,7 @@
 #include "miw/film_gather.h"
 #include "bvh_build.h"
 #include "envmap_build.h"
+#include "lbvh_device.h"
 
 using namespace miw;
 
@@ -1028,28 +1029,81 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     quality &= ~(MI_BVH_FORCE_TREE | MI_BVH_NO_LEAF_FILTER);
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
-    // quality 0 (device LBVH) falls back to the host SAH builder this round
-    // tiny scenes are swept through their SAH leaves' boxes (trace2): leaf size tuned for that filter
-    uint32_t max_leaf = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree ? MIW_BRUTE_MAX_LEAF : 4u;
-    if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) atoi(e);
-    BvhBuildResult r = bvh_build_sah(c->tris_in, -1.f, max_leaf);
-    if (r.depth > MIW_BVH_MAX_DEPTH) return fail(c, MI_ERR_INVALID, "BVH depth %u exceeds the traversal trail", r.depth);
-    std::vector<float> vn;
-    if (!c->tri_vn_in.empty()) {
-        vn.resize(c->tri_vn_in.size());
-        for (size_t i = 0; i < r.order.size(); ++i)
-            memcpy(&vn[i * 9], &c->tri_vn_in[(size_t) r.order[i] * 9], 36);
-    }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, c->d_nodes.upload(r.nodes, c->stream));
-    HIP_TRY(c, c->d_tris.upload(r.tris, c->stream));
-    HIP_TRY(c, c->d_tri_vn.upload(vn, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BvhBuildResult r;                       // host SAH result (nodes kept for the tiny-scene leaf filter)
+    uint32_t node_count = 0, tri_count = (uint32_t) c->tris_in.size(), depth = 0;
+    bool built_on_device = false;
+    const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree;
+    if (quality == 0 && !tiny && tri_count >= 2) {
+        // ---- device LBVH (lbvh_device.h) ----
+        hipStream_t s = c->stream;
+        const int n = (int) tri_count;
+        DevBuf<Tri> d_in; DevBuf<float> d_vn_in; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_bounds, d_arrivals, d_height;
+        DevBuf<LbvhBox> d_boxes; DevBuf<LbvhLinks> d_inner; DevBuf<int32_t> d_leaf_parent; DevBuf<unsigned char> d_tmp;
+        auto free_tmp = [&]() { d_in.release(); d_vn_in.release(); d_keys.release(); d_keys_sorted.release(); d_bounds.release();
+                                d_arrivals.release(); d_height.release(); d_boxes.release(); d_inner.release(); d_leaf_parent.release(); d_tmp.release(); };
+        HIP_TRY(c, d_in.upload(c->tris_in, s));
+        if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_in.upload(c->tri_vn_in, s));
+        HIP_TRY(c, d_keys.resize(n)); HIP_TRY(c, d_keys_sorted.resize(n)); HIP_TRY(c, d_bounds.resize(6));
+        HIP_TRY(c, d_arrivals.resize(n)); HIP_TRY(c, d_height.resize(n)); HIP_TRY(c, d_boxes.resize((size_t) 2 * n));
+        HIP_TRY(c, d_inner.resize(n)); HIP_TRY(c, d_leaf_parent.resize(n));
+        HIP_TRY(c, c->d_nodes.resize(n)); HIP_TRY(c, c->d_tris.resize(n));
+        if (!c->tri_vn_in.empty()) HIP_TRY(c, c->d_tri_vn.resize((size_t) n * 9));
+        const uint32_t init_bounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+        HIP_TRY(c, hipMemcpyAsync(d_bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(d_arrivals.p, 0, (size_t) n * sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemsetAsync(d_height.p, 0, (size_t) n * sizeof(uint32_t), s));
+        const dim3 blk(256), grd((unsigned) ((n + 255) / 256));
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<unsigned>(grd.x, 1024u)), blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p);
+        hipLaunchKernelGGL(k_lbvh_morton, grd, blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p, d_keys.p);
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+        HIP_TRY(c, d_tmp.resize(tmp_bytes + 16));
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+        // box padding (bvh.h): 1e-5 x the largest |coordinate|
+        uint32_t hb[6];
+        HIP_TRY(c, hipMemcpyAsync(hb, d_bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        float m = 0.f;
+        for (int k = 0; k < 6; ++k) { uint32_t o = hb[k]; float f = u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); m = std::max(m, std::fabs(f)); }
+        const float pad = std::max(1e-5f * m, 1e-30f);
+        hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
+                           (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
+        hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p);
+        hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_inner.p, d_leaf_parent.p, n, d_boxes.p, d_arrivals.p, d_height.p);
+        hipLaunchKernelGGL(k_lbvh_emit, grd, blk, 0, s, d_inner.p, d_boxes.p, n, c->d_nodes.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        free_tmp();
+        node_count = (uint32_t) (n - 1);
+        built_on_device = depth <= MIW_BVH_MAX_DEPTH;     // deeper (many coincident centroids): take the SAH builder
+    }
+    std::vector<float> vn;
+    if (!built_on_device) {
+        // ---- host binned SAH (bvh_build.h) ----
+        // tiny scenes are swept through their SAH leaves' boxes (trace2): leaf size tuned for that filter
+        uint32_t max_leaf = tiny ? MIW_BRUTE_MAX_LEAF : 4u;
+        if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) atoi(e);
+        r = bvh_build_sah(c->tris_in, -1.f, max_leaf);
+        if (r.depth > MIW_BVH_MAX_DEPTH) return fail(c, MI_ERR_INVALID, "BVH depth %u exceeds the traversal trail", r.depth);
+        if (!c->tri_vn_in.empty()) {
+            vn.resize(c->tri_vn_in.size());
+            for (size_t i = 0; i < r.order.size(); ++i)
+                memcpy(&vn[i * 9], &c->tri_vn_in[(size_t) r.order[i] * 9], 36);
+        }
+        HIP_TRY(c, c->d_nodes.upload(r.nodes, c->stream));
+        HIP_TRY(c, c->d_tris.upload(r.tris, c->stream));
+        HIP_TRY(c, c->d_tri_vn.upload(vn, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        node_count = (uint32_t) r.nodes.size(); tri_count = (uint32_t) r.tris.size(); depth = r.depth;
+    }
+    c->counters.bvh_on_device = built_on_device ? 1u : 0u;
 
     SceneView &v = c->view;
-    v.nodes = c->d_nodes.p; v.node_count = (uint32_t) r.nodes.size();
-    v.tris = c->d_tris.p; v.tri_count = (uint32_t) r.tris.size();
-    v.tri_vn = vn.empty() ? nullptr : c->d_tri_vn.p;
+    v.nodes = c->d_nodes.p; v.node_count = node_count;
+    v.tris = c->d_tris.p; v.tri_count = tri_count;
+    v.tri_vn = c->tri_vn_in.empty() ? nullptr : c->d_tri_vn.p;
     v.shapes = c->d_shapes.p; v.shape_count = (uint32_t) c->shapes.size();
     v.bsdfs = c->d_bsdfs.p; v.bsdf_count = (uint32_t) c->bsdfs.size();
     v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();
@@ -1059,7 +1113,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
 
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
-    size_t all = r.nodes.size() * sizeof(BvhNode) + r.tris.size() * sizeof(Tri);
+    size_t all = (size_t) node_count * sizeof(BvhNode) + (size_t) tri_count * sizeof(Tri);
     c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr;
     if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
@@ -1083,14 +1137,14 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
         c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
         c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0;
-        if (all > 16 * 1024 && r.depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK")) {
+        if (all > 16 * 1024 && depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK")) {
             c->lds_cfg.stack = 1; c->lds_cfg.stack16 = (uint32_t) (c->lds_bytes / 16);
             c->lds_bytes += (size_t) MIW_STACK_ENTRIES * MIW_BLOCK * sizeof(int32_t);
         }
     }
 
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = r.depth;
+    c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = depth;
     c->have_bvh = true;
     return MI_OK;
 }
