@@ -45,6 +45,15 @@ enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2 }
 enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2 };
 enum { MI_SHAPE_HAS_NORMALS = 1 };
 
+/* A spectrum-valued plugin parameter (what src/libcore/xml.cpp:1073-1170 turns an <rgb> / <spectrum>
+ * tag into). scalar_rgb library: only MI_TEX_RGB. scalar_spectral library (libmiwave_spectral.so):
+ *   MI_TEX_UNIFORM   v[0] = value                              (src/spectra/uniform.cpp)
+ *   MI_TEX_SRGB      v[0..2] = srgb_model_fetch coefficients   (src/spectra/srgb.cpp)
+ *   MI_TEX_D65       v[0] = scale / 10568                      (src/spectra/d65.cpp)
+ *   MI_TEX_SRGB_D65  v[0..2] = coefficients, v[3] = d65 scale / 10568 (src/spectra/srgb_d65.cpp) */
+enum { MI_TEX_RGB = 0, MI_TEX_UNIFORM = 1, MI_TEX_SRGB = 2, MI_TEX_D65 = 3, MI_TEX_SRGB_D65 = 4 };
+typedef struct { uint32_t type; float v[4]; } mi_texture;
+
 typedef struct {
     uint32_t type;        /* MI_BSDF_*                                                   */
     uint32_t flags;       /* roughconductor: MI_BSDF_FLAG_*                              */
@@ -54,6 +63,12 @@ typedef struct {
      * roughconductor (src/bsdfs/roughconductor.cpp:146-194): [0] alpha_u, [1] alpha_v,
      *                                              [2..4] eta, [5..7] k, [8..10] specular_reflectance */
     float params[14];
+    /* scalar_spectral (and optionally scalar_rgb: used when tex[0].type != MI_TEX_RGB or params carry no colour):
+     * diffuse: tex[0] reflectance; dielectric: tex[0] specular_reflectance, tex[1] specular_transmittance;
+     * roughconductor: tex[0] eta, tex[1] k, tex[2] specular_reflectance. The scalar_rgb library derives
+     * these from params[] itself. */
+    mi_texture tex[3];
+    uint32_t pad;
 } mi_bsdf;
 
 typedef struct {
@@ -65,7 +80,8 @@ typedef struct {
 
 typedef struct {          /* area light, src/emitters/area.cpp                            */
     uint32_t shape;       /* the shape it is attached to                                 */
-    float radiance[3];
+    float radiance[3];    /* scalar_rgb                                                  */
+    mi_texture radiance_tex;   /* scalar_spectral: MI_TEX_SRGB_D65 (<rgb>) or MI_TEX_D65 (<spectrum value>, default) */
 } mi_emitter;
 
 typedef struct {          /* environment map, src/emitters/envmap.cpp (one per scene)     */
@@ -173,6 +189,9 @@ typedef struct {
 
 /* ---- entry points -------------------------------------------------------------------- */
 
+/* 3 for the scalar_rgb library, 4 for the scalar_spectral library (channels of a Spectrum) */
+int32_t mi_spectrum_channels(void);
+
 /* number of visible HIP devices */
 mi_status mi_device_count(int32_t *count);
 /* create a context on `device`; *out is NULL on failure */
@@ -216,16 +235,18 @@ enum {
     MI_EVAL_PCG32 = 0,            /* in: seed lo, seed hi (as bits)      out: 8 floats   */
     MI_EVAL_SINCOS = 1,           /* in: x                               out: sin, cos   */
     MI_EVAL_COSINE_HEMISPHERE = 2,/* in: u1,u2                           out: wo.xyz,pdf */
-    MI_EVAL_BSDF = 3,             /* in: bsdf idx, wi.xyz, s1, s2x, s2y, wo.xyz (10)
-                                     out: sample{wo.xyz,pdf,eta,type,w.rgb} eval.rgb pdf (13) */
+    MI_EVAL_BSDF = 3,             /* in: bsdf idx, wi.xyz, s1, s2x, s2y, wo.xyz (10) [+ wavelengths[4] in the spectral library]
+                                     out: sample{wo.xyz,pdf,eta,type}, weight[N], eval[N], pdf (7 + 2N; N = mi_spectrum_channels) */
     MI_EVAL_FRESNEL = 4,          /* in: cos_theta_i, eta                out: r,cos_t,eta_it,eta_ti */
     MI_EVAL_CAMERA_RAY = 5,       /* in: x,y (film sample)               out: o.xyz,d.xyz,mint,maxt */
-    MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2                 out: d.xyz,dist,pdf,spec.rgb,p.xyz,n.xyz (14) */
+    MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2 [+ wavelengths[4]] out: d.xyz,dist,pdf,p.xyz,n.xyz,value[N] (11 + N) */
     MI_EVAL_FP_SEMANTICS = 7,     /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
     MI_EVAL_SPECIAL = 8,          /* in: x                               out: exp, log, erf, erfinv (miw/special.h)   */
     MI_EVAL_ENVMAP = 9,           /* in: d.xyz (world), ref.xyz, u1, u2 (8)
                                      out: eval.rgb, pdf_direction, sample{d.xyz, dist, pdf, spec.rgb} (12)          */
-    MI_EVAL_INVTRIG = 10          /* in: y, x                            out: atan2(y,x), acos(x), asin(x) (3)       */
+    MI_EVAL_INVTRIG = 10,         /* in: y, x                            out: atan2(y,x), acos(x), asin(x) (3)       */
+    MI_EVAL_SPECTRUM = 11         /* spectral library only. in: wavelength sample, c0,c1,c2, d65 scale (5)
+                                     out: wavelengths[4], weights[4], srgb[4], srgb_d65[4], xyz of weight*srgb_d65 (19) */
 };
 mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
                   const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);

@@ -15,8 +15,13 @@ c_u32_p = C.POINTER(C.c_uint32)
 c_i32_p = C.POINTER(C.c_int32)
 
 
+class mi_texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("v", C.c_float * 4)]
+
+
 class mi_bsdf(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("params", C.c_float * 14)]
+    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("params", C.c_float * 14),
+                ("tex", mi_texture * 3), ("pad", C.c_uint32)]
 
 
 class mi_shape(C.Structure):
@@ -25,7 +30,7 @@ class mi_shape(C.Structure):
 
 
 class mi_emitter(C.Structure):
-    _fields_ = [("shape", C.c_uint32), ("radiance", C.c_float * 3)]
+    _fields_ = [("shape", C.c_uint32), ("radiance", C.c_float * 3), ("radiance_tex", mi_texture)]
 
 
 class mi_envmap(C.Structure):
@@ -83,8 +88,23 @@ MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA
 MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8), 8: (1, 4), 9: (8, 12), 10: (2, 3)}
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
-MI_SYMBOLS = ["mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
+MI_SYMBOLS = ["mi_spectrum_channels", "mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
               "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval"]
+
+
+VARIANT_SUFFIX = {"scalar_rgb": "", "scalar_spectral": "_spectral"}
+
+
+def eval_strides(op, channels=3):
+    """(input stride, output stride) of a mi_eval op for a library with `channels` spectrum channels"""
+    extra = 4 if channels == 4 else 0
+    if op == 3:
+        return 10 + extra, 7 + 2 * channels
+    if op == 6:
+        return 5 + extra, 11 + channels
+    if op == 11:
+        return 5, 19
+    return MI_EVAL_STRIDES[op]
 
 
 def _load(name):
@@ -93,11 +113,12 @@ def _load(name):
         raise ImportError(
             "%s is missing: build the native libraries first (python -m mitsuba2_amd.build). "
             "mitsuba2_amd has no CPU fallback." % path)
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return C.CDLL(path)          # RTLD_LOCAL: both variants export the same symbol names
 
 
-def load_device_lib():
-    lib = _load("libmiwave.so")
+def load_device_lib(variant="scalar_rgb"):
+    lib = _load("libmiwave%s.so" % VARIANT_SUFFIX[variant])
+    lib.mi_spectrum_channels.argtypes = []; lib.mi_spectrum_channels.restype = C.c_int32
     vp = C.c_void_p
     lib.mi_device_count.argtypes = [c_i32_p]; lib.mi_device_count.restype = C.c_int32
     lib.mi_create.argtypes = [C.c_int32, C.POINTER(vp)]; lib.mi_create.restype = C.c_int32
@@ -117,12 +138,11 @@ def load_device_lib():
     return lib
 
 
-def load_host_lib():
-    load_device_lib()
-    lib = _load("libmiwave_host.so")
+def load_host_lib(variant="scalar_rgb"):
+    lib = _load("libmiwave_host%s.so" % VARIANT_SUFFIX[variant])
     vp, cp, f, i32, u32, u64 = C.c_void_p, C.c_char_p, C.c_float, C.c_int32, C.c_uint32, C.c_uint64
     sig = {
-        "mih_last_error": (cp, []),
+        "mih_last_error": (cp, []), "mih_spectrum_channels": (i32, []), "mih_set_srgb_model": (i32, [cp]),
         "mih_props_create": (vp, [cp]), "mih_props_destroy": (None, [vp]),
         "mih_props_set_float": (None, [vp, cp, f]), "mih_props_set_int": (None, [vp, cp, C.c_int64]),
         "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),

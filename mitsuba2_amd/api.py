@@ -12,22 +12,40 @@ import numpy as np
 from . import _capi
 from ._capi import (mi_counters, mi_hits_soa, mi_rays_soa, mi_render_cfg, mi_scene_desc, c_float_p, c_u32_p)
 
-_host = None
-_dev = None
+_variant = "scalar_rgb"
+_host = {}
+_dev = {}
+
+
+def set_variant(name):
+    """mitsuba.set_variant(): 'scalar_rgb' (default) or 'scalar_spectral'. Like in the reference, objects
+    belong to the variant they were created under (each variant is its own pair of native libraries)."""
+    global _variant
+    if name not in _capi.VARIANT_SUFFIX:
+        raise ValueError("unknown variant %r (scalar_rgb, scalar_spectral)" % (name,))
+    _variant = name
+
+
+def variant():
+    return _variant
 
 
 def host_lib():
-    global _host
-    if _host is None:
-        _host = _capi.load_host_lib()
-    return _host
+    if _variant not in _host:
+        _host[_variant] = _capi.load_host_lib(_variant)
+    return _host[_variant]
 
 
 def device_lib():
-    global _dev
-    if _dev is None:
-        _dev = _capi.load_device_lib()
-    return _dev
+    if _variant not in _dev:
+        _dev[_variant] = _capi.load_device_lib(_variant)
+    return _dev[_variant]
+
+
+def set_srgb_model(path):
+    """scalar_spectral: where the reference's data/srgb.coeff lives (src/librender/srgb.cpp:20-27)"""
+    if host_lib().mih_set_srgb_model(str(path).encode()) != 0:
+        raise RuntimeError(_err())
 
 
 def _err():
@@ -387,7 +405,7 @@ class Device:
         return c
 
     def eval(self, op, inputs, cfg=None):
-        i_s, o_s = _capi.MI_EVAL_STRIDES[op]
+        i_s, o_s = _capi.eval_strides(op, self.L.mi_spectrum_channels())
         a = np.ascontiguousarray(inputs, np.float32).reshape(-1, i_s)
         out = np.zeros((len(a), o_s), np.float32)
         self.check(self.L.mi_eval(self.ctx, op, C.byref(cfg) if cfg is not None else None, _fp(a), i_s, _fp(out), o_s,

@@ -3,11 +3,14 @@
     python -m mitsuba2_amd.build            # product libraries (hipcc, g++)
     python -m mitsuba2_amd.build --oracle   # + the CPU checker under oracle/_build
 
+Like the reference, one build = one variant: everything below exists twice, scalar_rgb (no suffix)
+and scalar_spectral (suffix _spectral, compiled with -DMIW_SPECTRAL=1: 4-wavelength Spectrum).
 Product:
-  mitsuba2_amd/lib/libmiwave.so       gfx950 kernels + C ABI (include/miwave.h)        [hipcc]
-  mitsuba2_amd/lib/libmiwave_host.so  C++17 host classes + ctypes facade               [g++]
+  mitsuba2_amd/lib/libmiwave[_spectral].so       gfx950 kernels + C ABI (include/miwave.h)        [hipcc]
+  mitsuba2_amd/lib/libmiwave_host[_spectral].so  C++17 host classes + ctypes facade               [g++]
 Checker (test infrastructure, never loaded by the package):
-  oracle/_build/libmiw_oracle.so      scalar_rgb restatement + CPU wavefront emulator  [g++]
+  oracle/_build/libmiw_oracle[_spectral].so      scalar restatement + CPU wavefront emulator      [g++]
+  oracle/_ref/                                   built from the reference's own ext/rgb2spec sources (see build_oracle_ref)
 
 Float flags are part of the parity contract (miw/base.h): no contraction, no
 fast-math, correctly rounded div/sqrt (hipcc default), denormals preserved on
@@ -52,42 +55,79 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_device(force=False):
+VARIANTS = {"scalar_rgb": ("", []), "scalar_spectral": ("_spectral", ["-DMIW_SPECTRAL=1"])}
+
+
+def build_device(force=False, variant="scalar_rgb"):
     os.makedirs(LIB, exist_ok=True)
-    out = os.path.join(LIB, "libmiwave.so")
+    suffix, defs = VARIANTS[variant]
+    out = os.path.join(LIB, "libmiwave%s.so" % suffix)
     src = os.path.join(PKG, "csrc", "miwave.hip")
     deps = _headers(os.path.join(PKG, "csrc")) + [os.path.join(ROOT, "include", "miwave.h")]
     if force or _newer(out, deps):
-        _run([HIPCC] + HIP_FLAGS + [src, "-o", out])
+        _run([HIPCC] + HIP_FLAGS + defs + [src, "-o", out])
     return out
 
 
-def build_host(force=False):
+def build_host(force=False, variant="scalar_rgb"):
     os.makedirs(LIB, exist_ok=True)
-    out = os.path.join(LIB, "libmiwave_host.so")
+    suffix, defs = VARIANTS[variant]
+    out = os.path.join(LIB, "libmiwave_host%s.so" % suffix)
     src = os.path.join(PKG, "host", "miwave_host.cpp")
     deps = _headers(os.path.join(PKG, "host")) + _headers(os.path.join(PKG, "csrc", "miw")) + \
-        [os.path.join(ROOT, "include", "miwave.h"), os.path.join(LIB, "libmiwave.so")]
+        [os.path.join(ROOT, "include", "miwave.h"), os.path.join(LIB, "libmiwave%s.so" % suffix)]
     if force or _newer(out, deps):
-        _run([CXX] + CXX_FLAGS + [src, "-o", out, "-L" + LIB, "-lmiwave", "-Wl,-rpath,$ORIGIN"])
+        _run([CXX] + CXX_FLAGS + defs + [src, "-o", out, "-L" + LIB, "-lmiwave%s" % suffix, "-Wl,-rpath,$ORIGIN"])
     return out
 
 
-def build_oracle(force=False):
+def build_oracle(force=False, variant="scalar_rgb"):
     os.makedirs(ORACLE_BUILD, exist_ok=True)
-    out = os.path.join(ORACLE_BUILD, "libmiw_oracle.so")
+    suffix, defs = VARIANTS[variant]
+    out = os.path.join(ORACLE_BUILD, "libmiw_oracle%s.so" % suffix)
     srcs = [os.path.join(ROOT, "oracle", "miw_oracle.cpp"), os.path.join(ROOT, "oracle", "wavefront_emu.cpp")]
     deps = srcs + _headers(os.path.join(PKG, "csrc")) + [os.path.join(ROOT, "include", "miwave.h")]
     if force or _newer(out, deps):
-        _run([CXX] + CXX_FLAGS + srcs + ["-o", out, "-lpthread"])
+        _run([CXX] + CXX_FLAGS + defs + srcs + ["-o", out, "-lpthread"])
     return out
 
 
+REFERENCE = os.environ.get("MIWAVE_REFERENCE", "/root/reference")
+ORACLE_REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def build_oracle_ref(force=False):
+    """oracle/_ref: what can be built of the real reference, from its sources where they lie
+    (ext/rgb2spec is self-contained C/C++; the renderer itself needs the empty ext/ submodules):
+      rgb2spec_opt        the reference's spectral-upsampling optimiser  (ext/rgb2spec/rgb2spec_opt.cpp)
+      srgb.coeff          its output `rgb2spec_opt 64 srgb.coeff` = the reference's data/srgb.coeff
+                          (ext/rgb2spec/CMakeLists.txt:47-52); ~50 s single-threaded, built once
+      librgb2spec_ref.so  rgb2spec_fetch / rgb2spec_load (ext/rgb2spec/rgb2spec.c), to check the host layer's fetch
+    Only present where /root/reference is (this container); the GPU box uses the files that travel with the repo."""
+    src_dir = os.path.join(REFERENCE, "ext", "rgb2spec")
+    if not os.path.isdir(src_dir):
+        return None
+    os.makedirs(ORACLE_REF, exist_ok=True)
+    opt = os.path.join(ORACLE_REF, "rgb2spec_opt")
+    coeff = os.path.join(ORACLE_REF, "srgb.coeff")
+    lib = os.path.join(ORACLE_REF, "librgb2spec_ref.so")
+    if force or not os.path.exists(opt):
+        _run([CXX, "-O2", "-std=c++11", os.path.join(src_dir, "rgb2spec_opt.cpp"), "-o", opt])
+    if force or not os.path.exists(coeff):
+        _run([opt, "64", coeff])
+    if force or not os.path.exists(lib):
+        _run(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I" + src_dir, os.path.join(src_dir, "rgb2spec.c"), "-o", lib, "-lm"])
+    return coeff
+
+
 def build_all(oracle=True, force=False):
-    build_device(force)
-    build_host(force)
+    for variant in VARIANTS:
+        build_device(force, variant)
+        build_host(force, variant)
+        if oracle:
+            build_oracle(force, variant)
     if oracle:
-        build_oracle(force)
+        build_oracle_ref(False)
 
 
 if __name__ == "__main__":

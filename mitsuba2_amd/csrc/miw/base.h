@@ -109,6 +109,31 @@ MIW_HD V3 fmsub3(V3 a, float b, V3 c) {
 
 MIW_HD float squared_norm2(V2 p) { return fmadd(p.y, p.y, p.x * p.x); }
 
+// ---- Spectrum type of the compiled variant (include/mitsuba/core/spectrum.h) ---------
+// Like the reference, one build = one variant: scalar_rgb carries Color3f (Spec == V3),
+// scalar_spectral carries Spectrum<Float, 4> (MIW_SPECTRAL, 4 wavelengths per sample).
+#if !defined(MIW_SPECTRAL)
+#  define MIW_SPECTRAL 0
+#endif
+#if MIW_SPECTRAL
+#  define MIW_SPEC_N 4
+struct Spec { float c[4]; };
+MIW_HD Spec spec(float s) { Spec r; r.c[0] = r.c[1] = r.c[2] = r.c[3] = s; return r; }
+MIW_HD Spec operator+(Spec a, Spec b) { Spec r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+MIW_HD Spec operator*(Spec a, Spec b) { Spec r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * b.c[i]; return r; }
+MIW_HD Spec operator*(Spec a, float s) { Spec r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * s; return r; }
+MIW_HD Spec operator*(float s, Spec a) { Spec r; for (int i = 0; i < 4; ++i) r.c[i] = s * a.c[i]; return r; }
+MIW_HD Spec operator/(Spec a, float s) { float q = rcp(s); Spec r; for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * q; return r; }
+MIW_HD float hmax(Spec a) { return max_(max_(max_(a.c[0], a.c[1]), a.c[2]), a.c[3]); }
+MIW_HD bool all_zero(Spec a) { return a.c[0] == 0.f && a.c[1] == 0.f && a.c[2] == 0.f && a.c[3] == 0.f; }
+struct Wavelengths { float l[4]; };
+#else
+#  define MIW_SPEC_N 3
+typedef V3 Spec;
+MIW_HD Spec spec(float s) { return v3(s); }
+struct Wavelengths { };
+#endif
+
 // ---- Frame (include/mitsuba/core/frame.h:25-37) -------------------------------
 struct Frame { V3 s, t, n; };
 

@@ -9,6 +9,7 @@
 #include "base.h"
 #include "warp.h"
 #include "special.h"
+#include "spectrum.h"
 #include "shape.h"
 
 namespace miw {
@@ -24,13 +25,15 @@ enum : uint32_t {
 enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2 };
 enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
 
-// 64-byte material record (host fills it from the plugin's Properties)
-//   diffuse:        p[0..2] reflectance
-//   dielectric:     p[0] eta (= int_ior/ext_ior), p[1..3] specular_reflectance,
-//                   p[4..6] specular_transmittance
-//   roughconductor: p[0] alpha_u, p[1] alpha_v, p[2..4] eta, p[5..7] k,
-//                   p[8..10] specular_reflectance; flags bit0 = GGX, bit1 = sample_visible
-struct BsdfRec { uint32_t type, flags; float p[14]; };
+// 128-byte material record (host fills it from the plugin's Properties). Scalars in p[], the
+// plugin's spectrum-valued parameters as texture records (spectrum.h):
+//   diffuse:        tex[0] reflectance
+//   dielectric:     p[0] eta (= int_ior/ext_ior), tex[0] specular_reflectance, tex[1] specular_transmittance
+//   roughconductor: p[0] alpha_u, p[1] alpha_v, tex[0] eta, tex[1] k, tex[2] specular_reflectance;
+//                   flags bit0 = GGX, bit1 = sample_visible
+// (scalar_rgb callers may fill only p[] in the legacy layout — diffuse p[0..2]; dielectric p[1..3],
+//  p[4..6]; roughconductor p[2..4], p[5..7], p[8..10] — the uploader derives the TEX_RGB records.)
+struct BsdfRec { uint32_t type, flags; float p[14]; TexRec tex[3]; uint32_t pad; };
 
 struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
 
@@ -217,20 +220,20 @@ MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &p
 }
 
 // ---- SmoothDiffuse (diffuse.cpp) ------------------------------------------------
-MIW_HD V3 diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs) {
+MIW_HD Spec diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
     float cos_theta_i = wi.z;
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
-    if (!(cos_theta_i > 0.f)) return v3(0.f);                        // :88-91
+    if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :88-91
     bs.wo = square_to_cosine_hemisphere(sample2);
     bs.pdf = square_to_cosine_hemisphere_pdf(bs.wo);
     bs.eta = 1.f;
     bs.sampled_type = BSDF_DiffuseReflection;
-    return (bs.pdf > 0.f) ? v3(b.p[0], b.p[1], b.p[2]) : v3(0.f);    // :101
+    return (bs.pdf > 0.f) ? tex_eval(b.tex[0], wl) : spec(0.f);      // :101
 }
-MIW_HD V3 diffuse_eval(const BsdfRec &b, V3 wi, V3 wo) {
+MIW_HD Spec diffuse_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
-    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return v3(0.f);
-    return v3(b.p[0], b.p[1], b.p[2]) * MIW_INV_PI * cos_theta_o;    // :116-117
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
+    return tex_eval(b.tex[0], wl) * MIW_INV_PI * cos_theta_o;        // :116-117
 }
 MIW_HD float diffuse_pdf(V3 wi, V3 wo) {
     float pdf = square_to_cosine_hemisphere_pdf(wo);
@@ -238,7 +241,7 @@ MIW_HD float diffuse_pdf(V3 wi, V3 wo) {
 }
 
 // ---- SmoothDielectric (dielectric.cpp:201-310, unpolarized branch :289-307) -------
-MIW_HD V3 dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &bs) {
+MIW_HD Spec dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &bs, const Wavelengths &wl) {
     float cos_theta_i = wi.z;
     float r_i, cos_theta_t, eta_it, eta_ti;
     fresnel(cos_theta_i, b.p[0], r_i, cos_theta_t, eta_it, eta_ti);
@@ -248,10 +251,10 @@ MIW_HD V3 dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &
     bs.sampled_type = selected_r ? BSDF_DeltaReflection : BSDF_DeltaTransmission;
     bs.wo = selected_r ? reflect(wi) : refract(wi, cos_theta_t, eta_ti);
     bs.eta = selected_r ? 1.f : eta_it;
-    V3 weight = v3(1.f);                                             // :290
-    if (selected_r) weight = weight * v3(b.p[1], b.p[2], b.p[3]);    // :296-297
+    Spec weight = spec(1.f);                                         // :290
+    if (selected_r) weight = weight * tex_eval(b.tex[0], wl);        // :296-297
     else {
-        weight = weight * v3(b.p[4], b.p[5], b.p[6]);                // :299-300
+        weight = weight * tex_eval(b.tex[1], wl);                    // :299-300
         weight = weight * sqr(eta_ti);                               // :302-307 (Radiance mode)
     }
     return weight;
@@ -261,16 +264,20 @@ MIW_HD V3 dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &
 MIW_HD Microfacet rc_distr(const BsdfRec &b) {
     return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[1], (b.flags & 2u) != 0);
 }
-MIW_HD V3 rc_fresnel(const BsdfRec &b, float c) {
-    return v3(fresnel_conductor(c, b.p[2], b.p[5]),
-              fresnel_conductor(c, b.p[3], b.p[6]),
-              fresnel_conductor(c, b.p[4], b.p[7]));
+MIW_HD Spec rc_fresnel(const BsdfRec &b, float c, const Wavelengths &wl) {
+    Spec eta = tex_eval(b.tex[0], wl), k = tex_eval(b.tex[1], wl), r;
+#if MIW_SPECTRAL
+    for (int i = 0; i < 4; ++i) r.c[i] = fresnel_conductor(c, eta.c[i], k.c[i]);
+#else
+    r = v3(fresnel_conductor(c, eta.x, k.x), fresnel_conductor(c, eta.y, k.y), fresnel_conductor(c, eta.z, k.z));
+#endif
+    return r;
 }
 // :196-275
-MIW_HD V3 roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs) {
+MIW_HD Spec roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     float cos_theta_i = wi.z;
-    if (!(cos_theta_i > 0.f)) return v3(0.f);
+    if (!(cos_theta_i > 0.f)) return spec(0.f);
     Microfacet distr = rc_distr(b);
     V3 m;
     mf_sample(distr, wi, sample2, m, bs.pdf);
@@ -282,23 +289,23 @@ MIW_HD V3 roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample 
     if (distr.sample_visible) weight = mf_smith_g1(distr, bs.wo, m);
     else weight = mf_G(distr, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
     bs.pdf /= 4.f * dot(bs.wo, m);
-    V3 F = rc_fresnel(b, dot(wi, m));
-    V3 w = v3(weight) * v3(b.p[8], b.p[9], b.p[10]);
-    return active ? F * w : v3(0.f);
+    Spec F = rc_fresnel(b, dot(wi, m), wl);
+    Spec w = spec(weight) * tex_eval(b.tex[2], wl);
+    return active ? F * w : spec(0.f);
 }
 // :277-345
-MIW_HD V3 roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo) {
+MIW_HD Spec roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
-    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return v3(0.f);
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
     V3 H = normalize(wo + wi);
     Microfacet distr = rc_distr(b);
     float D = mf_eval(distr, H);
     bool active = D != 0.f;
     float G = mf_G(distr, wi, wo, H);
     float res = D * G / (4.f * wi.z);
-    V3 F = rc_fresnel(b, dot(wi, H));
-    V3 result = v3(res) * v3(b.p[8], b.p[9], b.p[10]);
-    return active ? F * result : v3(0.f);
+    Spec F = rc_fresnel(b, dot(wi, H), wl);
+    Spec result = spec(res) * tex_eval(b.tex[2], wl);
+    return active ? F * result : spec(0.f);
 }
 // :347-382
 MIW_HD float roughconductor_pdf(const BsdfRec &b, V3 wi, V3 wo) {
@@ -317,18 +324,18 @@ MIW_HD float roughconductor_pdf(const BsdfRec &b, V3 wi, V3 wo) {
 
 // ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
-MIW_HD V3 bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs) {
+MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
     switch (b.type) {
-        case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs);
-        case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs);
-        default:                   return roughconductor_sample(b, wi, sample2, bs);
+        case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, wl);
+        case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, wl);
+        default:                   return roughconductor_sample(b, wi, sample2, bs, wl);
     }
 }
-MIW_HD V3 bsdf_eval(const BsdfRec &b, V3 wi, V3 wo) {
+MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
     switch (b.type) {
-        case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo);
-        case BSDF_TYPE_DIELECTRIC: return v3(0.f);                   // dielectric.cpp:312-315
-        default:                   return roughconductor_eval(b, wi, wo);
+        case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, wl);
+        case BSDF_TYPE_DIELECTRIC: return spec(0.f);                 // dielectric.cpp:312-315
+        default:                   return roughconductor_eval(b, wi, wo, wl);
     }
 }
 MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {

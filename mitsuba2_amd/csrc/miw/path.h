@@ -86,9 +86,10 @@ MIW_HD V2 next_2d(PCG32 &r) { float a = pcg32_next_f32(r); float b = pcg32_next_
 struct LaneRegs {
     PCG32 rng;
     uint32_t flags, sample_idx;
-    V3 tp, res; float eta, prev_pdf;
+    Spec tp, res; float eta, prev_pdf;
     V2 pos;
     Ray ray;
+    Wavelengths wl; Spec ray_weight;     // sample_wavelength (spectrum.h:305-314); unused words in RGB builds
 };
 
 MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, uint32_t sample_end) {
@@ -100,11 +101,16 @@ MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L
     float px = (float) (pixel & 0xffffu), py = (float) (pixel >> 16);
     V2 j = next_2d(L.rng);                               // :242
     L.pos = v2(px + j.x, py + j.y);
-    (void) next_1d(L.rng);                               // :252 wavelength sample, always drawn
+    const float wavelength_sample = next_1d(L.rng);     // :252 wavelength sample, always drawn
+#if MIW_SPECTRAL
+    sample_wavelengths(wavelength_sample, L.wl, L.ray_weight);   // perspective.cpp:191-192
+#else
+    (void) wavelength_sample; L.ray_weight = spec(1.f);
+#endif
     V2 adj = v2((L.pos.x - (float) P.film.crop_x) / (float) P.film.crop_w,    // :254-256
                 (L.pos.y - (float) P.film.crop_y) / (float) P.film.crop_h);
     L.ray = sensor_sample_ray(P.sensor, adj);            // :258
-    L.tp = v3(1.f); L.res = v3(0.f); L.eta = 1.f; L.prev_pdf = 0.f;   // path.cpp:111-116
+    L.tp = spec(1.f); L.res = spec(0.f); L.eta = 1.f; L.prev_pdf = 0.f;   // path.cpp:111-116
     L.flags = 1u | LF_RAY_ACTIVE;                        // depth = 1
 }
 
@@ -113,7 +119,11 @@ MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L
 template <typename Sink>
 MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, Sink sink) {
     (void) P;
+#if MIW_SPECTRAL
+    V3 xyz = spectrum_to_xyz(L.ray_weight * L.res, L.wl);   // :266-271
+#else
     V3 xyz = srgb_to_xyz(L.res);                         // :272-273 (ray_weight == 1 in RGB)
+#endif
     float aovs[5] = { xyz.x, xyz.y, xyz.z, (L.flags & LF_VALID_RAY) ? 1.f : 0.f, 1.f };
     sink(pixel, L.sample_idx, L.pos, aovs);
     L.sample_idx++;                                      // :287
@@ -151,6 +161,7 @@ MIW_HD void lane_load(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
     L.rng.inc = MIW_PCG32_SCALAR_INC;
     L.flags = st.z; L.sample_idx = st.w;
 }
+#if !MIW_SPECTRAL   // the HBM-queue plan carries RGB path state (16-byte fields); spectral builds run the resident plan
 MIW_HD void lane_load_path(const LaneQueues &Q, uint32_t lane, LaneRegs &L) {
     F4 a = Q.tp[lane], b = Q.res[lane];
     L.tp = v3(a.x, a.y, a.z); L.eta = a.w;
@@ -195,10 +206,11 @@ MIW_HD void lane_init_unused(const LaneQueues &Q, uint32_t lane) {
     lane_clear_shadow(Q, lane);
     Q.sh_vis[lane] = 0;
 }
+#endif   // !MIW_SPECTRAL
 
 // What one depth-loop iteration hands to the shadow stage (scene.cpp:203-207):
 // origin and mint are the extension ray's (L.ray.o, L.ray.mint).
-struct ShadowOut { bool has; V3 d; float maxt; V3 c; };
+struct ShadowOut { bool has; V3 d; float maxt; Spec c; };
 
 enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
        STEP_FINISHED = 1,        // the camera sample is complete
@@ -251,7 +263,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
             }
             emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
         }
-        V3 radiance = valid ? emitter_eval(sc.emitters[emitter], si.wi) : env_eval(*sc.env, ray_d);
+        Spec radiance = valid ? emitter_eval(sc.emitters[emitter], si.wi, L.wl) : env_eval_spec(*sc.env, ray_d);
         L.res = L.res + emission_weight * L.tp * radiance;
     }
 
@@ -276,13 +288,13 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     // ---- emitter sampling, :155-172 ----
     if (bflags & BSDF_Smooth) {
         DirectionSample ds;
-        V3 emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds);
+        Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
-            V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);
+            Spec bsdf_val = bsdf_eval(bsdf, si.wi, wo, L.wl);
             float bpdf = bsdf_pdf(bsdf, si.wi, wo);
             float mis = mis_weight(ds.pdf, bpdf);
-            V3 c = mis * L.tp * bsdf_val * emitter_val;
+            Spec c = mis * L.tp * bsdf_val * emitter_val;
             if (!all_zero(c)) {
                 // shadow ray, scene.cpp:203-205
                 sh.has = true; sh.d = ds.d; sh.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON); sh.c = c;
@@ -295,7 +307,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    V3 bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs);
+    Spec bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs, L.wl);
     L.tp = L.tp * bsdf_val;
     if (all_zero(L.tp))                              // :182-184
         return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;
@@ -308,6 +320,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     return STEP_CONTINUE;
 }
 
+#if !MIW_SPECTRAL
 // Stage 2 of the HBM-queue plan: one iteration of the depth loop for one lane.
 // Returns the lane's new flag word: LF_DONE clear = the lane still has work; LF_RAY_ACTIVE = an
 // extension / primary ray is queued; LF_HAS_SHADOW = a shadow ray is queued; LF_DEAD_PENDING = the
@@ -365,6 +378,7 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
     if (had_shadow && !(L.flags & LF_HAS_SHADOW)) lane_clear_shadow(Q, lane);
     return L.flags;
 }
+#endif   // !MIW_SPECTRAL
 
 // The register-resident plan: a run of one pixel's sample loop (render_block's inner
 // loops, integrator.cpp:196-209) with every Scene::ray_intersect / ray_test call made
@@ -386,7 +400,7 @@ MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixe
     L.rng.inc = MIW_PCG32_SCALAR_INC;
     L.sample_idx = st.w; L.flags = 0;
     lane_begin_sample(P, pixel, L, sample_end);
-    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = v3(0.f);
+    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
     bool dead_pending = false;
     while (!(L.flags & LF_DONE)) {
         const V3 o = L.ray.o;

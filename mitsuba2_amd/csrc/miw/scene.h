@@ -33,7 +33,7 @@ struct ShapeRec {
 };
 
 struct EmitterRec {
-    float radiance[3];
+    TexRec radiance;     // area.cpp:55 `radiance` (srgb_d65 / d65 texture in spectral builds, RGB otherwise)
     uint32_t shape;
     uint32_t tri_first;  // first face of this emitter in emit_tri / emit_pmf / emit_cdf
     uint32_t tri_count;
@@ -72,13 +72,27 @@ MIW_HD MeshSampler emitter_mesh(const SceneView &sc, const EmitterRec &e) {
     return m;
 }
 
+// The environment map is an RGB-build feature this round (its spectral branch upsamples every texel
+// through srgb_model_fetch, envmap.cpp:104-110): spectral scenes carrying one are rejected at upload.
+#if MIW_SPECTRAL
+MIW_HD Spec env_sample_direction_spec(const EnvmapRec &, V3, V2, V3 &d, float &dist, float &pdf, V3 &p, V3 &n) {
+    d = p = n = v3(0.f); dist = 0.f; pdf = 0.f; return spec(0.f);
+}
+MIW_HD Spec env_eval_spec(const EnvmapRec &, V3) { return spec(0.f); }
+#else
+MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d, float &dist, float &pdf, V3 &p, V3 &n) {
+    return env_sample_direction(e, ref_p, sample, d, dist, pdf, p, n);
+}
+MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d) { return env_eval(e, d); }
+#endif
+
 // scene.cpp:164-200 + area.cpp:121-166 + shape.cpp:292-309, *without* the
 // visibility test (the shadow ray is a separate wavefront stage). Returns the
 // unoccluded emitter value; `ds.pdf == 0` means "no sample" (path.cpp:160).
-MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds) {
+MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
     if (sc.emitter_count == 0) {                       // scene.cpp:208-211
         ds.p = ds.n = ds.d = v3(0.f); ds.dist = 0.f; ds.pdf = 0.f; ds.emitter = 0;
-        return v3(0.f);
+        return spec(0.f);
     }
     uint32_t index = 0;
     float emitter_pdf = 1.f;
@@ -90,10 +104,10 @@ MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, Dir
         sample.x = (sample.x - (float) index * emitter_pdf) * n;
     }
     const EmitterRec &e = sc.emitters[index];
-    V3 spec;
+    Spec value;
     ds.emitter = index;
     if (e.type == EMITTER_ENVMAP) {
-        spec = env_sample_direction(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
+        value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
     } else {
         MeshSampler mesh = emitter_mesh(sc, e);
         // Shape::sample_direction, shape.cpp:292-309
@@ -107,14 +121,14 @@ MIW_HD V3 sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, Dir
         ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
         // AreaLight::sample_direction, area.cpp:131-136,165
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
-        spec = v3(e.radiance[0], e.radiance[1], e.radiance[2]) / ds.pdf;
-        if (!active) spec = v3(0.f);
+        value = tex_eval(e.radiance, wl) / ds.pdf;
+        if (!active) value = spec(0.f);
     }
     if (sc.emitter_count > 1) {                        // scene.cpp:195-197
         ds.pdf *= emitter_pdf;
-        spec = spec * rcp(emitter_pdf);
+        value = value * rcp(emitter_pdf);
     }
-    return spec;
+    return value;
 }
 
 // scene.cpp:216-231 + area.cpp:168-187 + shape.cpp:311-323.
@@ -137,9 +151,10 @@ MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_
 }
 
 // AreaLight::eval, area.cpp:63-71
-MIW_HD V3 emitter_eval(const EmitterRec &e, V3 wi) {
-    return wi.z > 0.f ? v3(e.radiance[0], e.radiance[1], e.radiance[2]) : v3(0.f);
+MIW_HD Spec emitter_eval(const EmitterRec &e, V3 wi, const Wavelengths &wl) {
+    return wi.z > 0.f ? tex_eval(e.radiance, wl) : spec(0.f);
 }
+
 
 // path.cpp:223-227
 MIW_HD float mis_weight(float pdf_a, float pdf_b) {

@@ -44,7 +44,8 @@ using namespace miw;
 
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
 static_assert(sizeof(Tri) == 48, "Tri must be 48 bytes");
-static_assert(sizeof(BsdfRec) == 64 && sizeof(mi_bsdf) == 64, "bsdf record layout");
+static_assert(sizeof(BsdfRec) == 128 && sizeof(mi_bsdf) == 128, "bsdf record layout");
+static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 
 #define MIW_BLOCK 256
 #define MIW_CNT_SHARDS 1024        /* power of two */
@@ -314,6 +315,7 @@ struct InitArgs {
     uint64_t base_seed;
 };
 
+#if !MIW_SPECTRAL   // HBM-queue plan: RGB builds only (path.h)
 // -> true when the lane starts with a camera ray queued
 __device__ __forceinline__ bool init_one_lane(const RenderParams &P, const LaneQueues &Q, uint32_t *pixel_out, const InitArgs &A, uint32_t lane) {
     uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQu
     __syncthreads();
     if (threadIdx.x < WL_LISTS) W.count[blockIdx.x * WL_LISTS + threadIdx.x] = s_cnt[threadIdx.x];
 }
+#endif
 
 template <bool AnyHit>
 __global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q, TraceLds cfg, WorkLists io) {
@@ -409,6 +412,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+#if !MIW_SPECTRAL
 template <bool UseLog>
 __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                        uint32_t count_active, WorkLists in, WorkLists out) {
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
         if (d) atomicAdd(&shard->active_lanes, d);
     }
 }
+#endif   // !MIW_SPECTRAL
 
 // ---- the resident plan -----------------------------------------------------------------
 // k_init_pixels: pixel <-> lane map and PCG32 seeding only (a pixel carries nothing else
@@ -737,14 +742,19 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             V3 w = square_to_cosine_hemisphere(v2(a[0], a[1]));
             o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = square_to_cosine_hemisphere_pdf(w);
         } break;
-        case MI_EVAL_BSDF: {
+        case MI_EVAL_BSDF: {      // spectral builds: in[10..13] = wavelengths; colour outputs have MIW_SPEC_N channels
             const BsdfRec &b = sc.bsdfs[f2u(a[0])];
             V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
-            BSDFSample bs; V3 w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs);
+            Wavelengths wl;
+#if MIW_SPECTRAL
+            for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
+#endif
+            BSDFSample bs; Spec w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
             o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-            o[6] = w.x; o[7] = w.y; o[8] = w.z;
-            V3 e = bsdf_eval(b, wi, wo); o[9] = e.x; o[10] = e.y; o[11] = e.z;
-            o[12] = bsdf_pdf(b, wi, wo);
+            Spec e = bsdf_eval(b, wi, wo, wl);
+            const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
+            for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
+            o[6 + 2 * MIW_SPEC_N] = bsdf_pdf(b, wi, wo);
         } break;
         case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
         case MI_EVAL_CAMERA_RAY: {
@@ -753,11 +763,16 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             Ray r = sensor_sample_ray(P.sensor, adj);
             o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.mint; o[7] = r.maxt;
         } break;
-        case MI_EVAL_EMITTER_SAMPLE: {
-            DirectionSample ds; V3 s = sample_emitter_direction(sc, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds);
+        case MI_EVAL_EMITTER_SAMPLE: {   // spectral builds: in[5..8] = wavelengths
+            Wavelengths wl;
+#if MIW_SPECTRAL
+            for (int k = 0; k < 4; ++k) wl.l[k] = a[5 + k];
+#endif
+            DirectionSample ds; Spec s = sample_emitter_direction(sc, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds, wl);
             o[0] = ds.d.x; o[1] = ds.d.y; o[2] = ds.d.z; o[3] = ds.dist; o[4] = ds.pdf;
-            o[5] = s.x; o[6] = s.y; o[7] = s.z; o[8] = ds.p.x; o[9] = ds.p.y; o[10] = ds.p.z;
-            o[11] = ds.n.x; o[12] = ds.n.y; o[13] = ds.n.z;
+            o[5] = ds.p.x; o[6] = ds.p.y; o[7] = ds.p.z; o[8] = ds.n.x; o[9] = ds.n.y; o[10] = ds.n.z;
+            const float *sf = reinterpret_cast<const float *>(&s);
+            for (int k = 0; k < MIW_SPEC_N; ++k) o[11 + k] = sf[k];
         } break;
         case MI_EVAL_FP_SEMANTICS: {
             float x = a[0], y = a[1], z = a[2];
@@ -765,6 +780,7 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
         } break;
         case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
+#if !MIW_SPECTRAL
         case MI_EVAL_ENVMAP: {
             if (!sc.env) break;
             V3 d = v3(a[0], a[1], a[2]);
@@ -774,6 +790,18 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             V3 spec = env_sample_direction(*sc.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
             o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
         } break;
+#else
+        case MI_EVAL_SPECTRUM: {         // in: wavelength sample, c0, c1, c2 (srgb coefficients), d65 scale
+            Wavelengths wl; Spec wt;
+            sample_wavelengths(a[0], wl, wt);
+            TexRec t; t.type = TEX_SRGB_D65; t.v[0] = a[1]; t.v[1] = a[2]; t.v[2] = a[3]; t.v[3] = a[4];
+            Spec sd = tex_eval(t, wl);
+            t.type = TEX_SRGB; Spec sr = tex_eval(t, wl);
+            for (int k = 0; k < 4; ++k) { o[k] = wl.l[k]; o[4 + k] = wt.c[k]; o[8 + k] = sr.c[k]; o[12 + k] = sd.c[k]; }
+            V3 xyz = spectrum_to_xyz(wt * sd, wl);
+            o[16] = xyz.x; o[17] = xyz.y; o[18] = xyz.z;
+        } break;
+#endif
         case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
     }
 }
@@ -852,6 +880,8 @@ static mi_status fail(mi_ctx *c, mi_status code, const char *fmt, ...) {
 static thread_local std::string g_global_error;
 
 extern "C" {
+
+int32_t mi_spectrum_channels(void) { return MIW_SPEC_N; }
 
 mi_status mi_device_count(int32_t *count) {
     if (!count) return MI_ERR_INVALID;
@@ -953,7 +983,24 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         const mi_bsdf &b = s->bsdfs[i];
         if (b.type > MI_BSDF_ROUGHCONDUCTOR) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
-        BsdfRec r; r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
+        BsdfRec r; memset(&r, 0, sizeof r);
+        r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
+#if MIW_SPECTRAL
+        for (int k = 0; k < (int) b.type + 1; ++k) {           // slots in use: diffuse 1, dielectric 2, roughconductor 3
+            if (b.tex[k].type == MI_TEX_RGB || b.tex[k].type > MI_TEX_SRGB_D65)
+                return fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: the scalar_spectral library needs a spectral texture record", i, k);
+            memcpy(&r.tex[k], &b.tex[k], sizeof(TexRec));
+        }
+#else
+        {   // legacy RGB layout of params[] -> texture records
+            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            for (int k = 0; k < 3; ++k) {
+                r.tex[k].type = TEX_RGB;
+                if (off[b.type][k] >= 0) memcpy(r.tex[k].v, b.params + off[b.type][k], 12);
+                if (b.tex[k].type != MI_TEX_RGB) return fail(c, MI_ERR_INVALID, "bsdf %u: spectral texture record passed to the scalar_rgb library", i);
+            }
+        }
+#endif
         c->bsdfs[i] = r;
     }
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
@@ -968,7 +1015,13 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         if (sh.emitter != (int32_t) i) return fail(c, MI_ERR_INVALID, "emitter %u: shape %u does not point back to it", i, e.shape);
         if (sh.face_count == 0) return fail(c, MI_ERR_INVALID, "emitter %u: cannot create sampling table for an empty mesh", i);
         EmitterRec r; memset(&r, 0, sizeof r);
-        memcpy(r.radiance, e.radiance, 12);
+#if MIW_SPECTRAL
+        if (e.radiance_tex.type != MI_TEX_D65 && e.radiance_tex.type != MI_TEX_SRGB_D65 && e.radiance_tex.type != MI_TEX_UNIFORM)
+            return fail(c, MI_ERR_INVALID, "emitter %u: the scalar_spectral library needs a spectral radiance record", i);
+        memcpy(&r.radiance, &e.radiance_tex, sizeof(TexRec));
+#else
+        r.radiance.type = TEX_RGB; memcpy(r.radiance.v, e.radiance, 12);
+#endif
         r.shape = e.shape; r.tri_first = (uint32_t) c->emit_pmf.size(); r.tri_count = sh.face_count;
         r.flags = (sh.flags & MI_SHAPE_HAS_NORMALS) ? 1u : 0u;
         any_emit_normals = any_emit_normals || r.flags;
@@ -997,6 +1050,9 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 
     HIP_TRY(c, hipSetDevice(c->device));
     c->have_env = false;
+#if MIW_SPECTRAL
+    if (s->envmap) return fail(c, MI_ERR_INVALID, "envmap: not available in the scalar_spectral library this round");
+#endif
     if (s->envmap) {
         EnvmapTables t = envmap_build(*s->envmap);
         if (!t.ok) return fail(c, MI_ERR_INVALID, "envmap: needs >= 2x2 texels, a non-zero luminance sum and an invertible to_world");
@@ -1237,6 +1293,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // measured on MI355X: the resident plan wins whenever the scene query runs out of LDS
     // (packets / staged tree) or with the LDS-stack walk; the queue plan remains for the stackless fallback
     if (plan == 0) plan = (lds_resident || c->lds_cfg.stack) ? 2 : 1;
+#if MIW_SPECTRAL
+    if (cfg->plan == 1) return fail(c, MI_ERR_INVALID, "render: the scalar_spectral library runs the resident plan only (plan 0 or 2)");
+    plan = 2;
+#endif
     c->counters.plan = (uint32_t) plan;
 
     size_t nl = std::max<uint32_t>(n_lanes, 1);
@@ -1384,7 +1444,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
         if (cfg->profile) drain_stamps();
-    } else if (n_lanes > 0) {
+    }
+#if !MIW_SPECTRAL
+    else if (n_lanes > 0) {
         dim3 grid((n_lanes + MIW_BLOCK - 1) / MIW_BLOCK), block(MIW_BLOCK);
         InitArgs A; A.block_ids = c->d_block_ids.p; A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
@@ -1435,6 +1497,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             if (out_of_time()) { result = MI_ERR_CANCELLED; break; }
         }
     }
+#endif
 
     // film assembly -> caller's buffer (device pointer, or staged through d_out for a host pointer)
     {

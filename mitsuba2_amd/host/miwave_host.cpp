@@ -6,6 +6,9 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
 
 #include "../csrc/miw/base.h"
 #include "../csrc/miw/rng.h"
@@ -159,6 +162,98 @@ Color3f Properties::texture(const std::string &n) const {
 Color3f Properties::texture(const std::string &n, float def) const {
     return has_property(n) ? texture(n) : Color3f{ def, def, def };
 }
+// ---- sRGB upsampling model -------------------------------------------------------------------
+int spectrum_channels() { return MIW_SPEC_N; }
+namespace {
+struct SRGBModel { uint32_t res = 0; std::vector<float> scale, data; };
+std::mutex g_model_mutex; std::string g_model_path; SRGBModel g_model;
+const SRGBModel &srgb_model() {
+    std::lock_guard<std::mutex> lock(g_model_mutex);
+    if (g_model.res) return g_model;
+    std::string path = g_model_path;
+    if (path.empty()) if (const char *e = std::getenv("MIWAVE_SRGB_COEFF")) path = e;
+    if (path.empty()) Throw("Could not load sRGB-to-spectrum upsampling model ('data/srgb.coeff'): set MIWAVE_SRGB_COEFF");
+    FILE *f = std::fopen(path.c_str(), "rb");                  // rgb2spec_load, rgb2spec.c:13-47
+    char header[4]; uint32_t res = 0;
+    if (!f || std::fread(header, 4, 1, f) != 1 || std::memcmp(header, "SPEC", 4) != 0 || std::fread(&res, 4, 1, f) != 1 || res < 2) {
+        if (f) std::fclose(f);
+        Throw("Could not load sRGB-to-spectrum upsampling model ('" + path + "')");
+    }
+    SRGBModel m; m.res = res; m.scale.resize(res); m.data.resize((size_t) res * res * res * 9);
+    bool ok = std::fread(m.scale.data(), 4, res, f) == res && std::fread(m.data.data(), 4, m.data.size(), f) == m.data.size();
+    std::fclose(f);
+    if (!ok) Throw("Could not load sRGB-to-spectrum upsampling model ('" + path + "'): truncated file");
+    g_model = std::move(m);
+    return g_model;
+}
+}
+void set_srgb_model_path(const std::string &path) { std::lock_guard<std::mutex> lock(g_model_mutex); g_model_path = path; g_model = SRGBModel(); }
+
+// srgb.cpp:28-39 + rgb2spec_fetch (rgb2spec.c:76-124): table addressed by the largest component,
+// trilinear interpolation of the three sigmoid-polynomial coefficients
+std::array<float, 3> srgb_model_fetch(const Color3f &c) {
+    const float inf = std::numeric_limits<float>::infinity();
+    if (c[0] == 0.f && c[1] == 0.f && c[2] == 0.f) return { 0.f, 0.f, -inf };
+    if (c[0] == 1.f && c[1] == 1.f && c[2] == 1.f) return { 0.f, 0.f, inf };
+    const SRGBModel &m = srgb_model();
+    const int res = (int) m.res;
+    float rgb[3];
+    for (int j = 0; j < 3; ++j) rgb[j] = std::max(std::min(c[j], 1.f), 0.f);
+    int i = 0;
+    for (int j = 1; j < 3; ++j) if (rgb[j] >= rgb[i]) i = j;
+    const float z = rgb[i], sc = (float) (res - 1) / z, x = rgb[(i + 1) % 3] * sc, y = rgb[(i + 2) % 3] * sc;
+    const uint32_t xi = std::min((uint32_t) x, (uint32_t) (res - 2)), yi = std::min((uint32_t) y, (uint32_t) (res - 2));
+    int left = 0, last = res - 2, size = last;                 // rgb2spec_find_interval
+    while (size > 0) {
+        int half = size >> 1, middle = left + half + 1;
+        if (m.scale[middle] <= z) { left = middle; size -= half + 1; } else size = half;
+    }
+    const uint32_t zi = (uint32_t) std::min(left, last);
+    size_t offset = ((((size_t) i * res + zi) * res + yi) * res + xi) * 3;
+    const size_t dx = 3, dy = 3 * (size_t) res, dz = 3 * (size_t) res * res;
+    const float x1 = x - (float) xi, x0 = 1.f - x1, y1 = y - (float) yi, y0 = 1.f - y1,
+                z1 = (z - m.scale[zi]) / (m.scale[zi + 1] - m.scale[zi]), z0 = 1.f - z1;
+    std::array<float, 3> out;
+    const float *d = m.data.data();
+    for (int j = 0; j < 3; ++j, ++offset)
+        out[j] = ((d[offset] * x0 + d[offset + dx] * x1) * y0 + (d[offset + dy] * x0 + d[offset + dy + dx] * x1) * y1) * z0 +
+                 ((d[offset + dz] * x0 + d[offset + dz + dx] * x1) * y0 + (d[offset + dz + dy] * x0 + d[offset + dz + dy + dx] * x1) * y1) * z1;
+    return out;
+}
+
+mi_texture Properties::texture_record(const std::string &n, float def, bool within_emitter, bool unbounded) const {
+    mi_texture t{};
+    bool is_color = false; Color3f color{ def, def, def }; float value = def;
+    if (has_property(n)) {
+        if (const Color3f *v = prop_get<Color3f>(m_values, n)) { is_color = true; color = *v; }
+        else if (const float *v = prop_get<float>(m_values, n)) { value = *v; color = { *v, *v, *v }; }
+        else Throw("The property \"" + n + "\" has the wrong type (expected <rgb> or <float>; only constant textures are supported).");
+    }
+#if MIW_SPECTRAL
+    if (is_color) {
+        if (within_emitter) {                                  // srgb_d65.cpp:33-47
+            float scale = std::max(color[0], std::max(color[1], color[2])) * 2.f;
+            if (scale != 0.f) { float r = 1.f / scale; color = { color[0] * r, color[1] * r, color[2] * r }; }
+            auto cf = srgb_model_fetch(color);
+            t.type = MI_TEX_SRGB_D65; t.v[0] = cf[0]; t.v[1] = cf[1]; t.v[2] = cf[2];
+            t.v[3] = (1.f * scale) * (1.f / 10568.f);          // d65.cpp:61-62 with scale = props.scale * scale
+        } else {                                               // srgb.cpp:27-35
+            if (!unbounded) for (float v : color) if (v < 0.f || v > 1.f)
+                Throw("Invalid RGB reflectance value, must be in the range [0, 1]!");
+            auto cf = srgb_model_fetch(color);
+            t.type = MI_TEX_SRGB; t.v[0] = cf[0]; t.v[1] = cf[1]; t.v[2] = cf[2];
+        }
+    } else if (within_emitter) { t.type = MI_TEX_D65; t.v[0] = value * (1.f / 10568.f); }   // xml.cpp:1097-1099
+    else { t.type = MI_TEX_UNIFORM; t.v[0] = value; }
+#else
+    (void) within_emitter; (void) value;
+    if (is_color && !within_emitter && !unbounded) for (float v : color) if (v < 0.f || v > 1.f)
+        Throw("Invalid RGB reflectance value, must be in the range [0, 1]!");
+    t.type = MI_TEX_RGB; t.v[0] = color[0]; t.v[1] = color[1]; t.v[2] = color[2];
+#endif
+    return t;
+}
+
 Transform4f Properties::transform(const std::string &n, const Transform4f &def) const {
     if (!has_property(n)) return def;
     const Transform4f *v = prop_get<Transform4f>(m_values, n);
@@ -403,16 +498,23 @@ float lookup_ior(const Properties &props, const std::string &name, const std::st
 
 static const miw::BsdfRec &as_rec(const mi_bsdf &b) { return *reinterpret_cast<const miw::BsdfRec *>(&b); }
 uint32_t BSDF::flags() const { return miw::bsdf_flags(as_rec(m_rec)); }
+#if MIW_SPECTRAL
+std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &, float, const std::array<float, 2> &) const {
+    Throw("BSDF::sample on the host is a scalar_rgb test helper");
+}
+Color3f BSDF::eval(const Vector3f &, const Vector3f &) const { Throw("BSDF::eval on the host is a scalar_rgb test helper"); }
+#else
 std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &wi, float s1, const std::array<float, 2> &s2) const {
     miw::BSDFSample bs;
-    miw::V3 w = miw::bsdf_sample(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), s1, miw::v2(s2[0], s2[1]), bs);
+    miw::V3 w = miw::bsdf_sample(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), s1, miw::v2(s2[0], s2[1]), bs, miw::Wavelengths());
     BSDFSample3f o; o.wo = { bs.wo.x, bs.wo.y, bs.wo.z }; o.pdf = bs.pdf; o.eta = bs.eta; o.sampled_type = bs.sampled_type;
     return { o, Color3f{ w.x, w.y, w.z } };
 }
 Color3f BSDF::eval(const Vector3f &wi, const Vector3f &wo) const {
-    miw::V3 v = miw::bsdf_eval(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]));
+    miw::V3 v = miw::bsdf_eval(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]), miw::Wavelengths());
     return { v.x, v.y, v.z };
 }
+#endif
 float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
     return miw::bsdf_pdf(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]));
 }
@@ -425,6 +527,7 @@ SmoothDiffuse::SmoothDiffuse(const Properties &props) {
     check_reflectance(r, "reflectance");
     m_rec.type = MI_BSDF_DIFFUSE; m_rec.flags = 0;
     m_rec.params[0] = r[0]; m_rec.params[1] = r[1]; m_rec.params[2] = r[2];
+    m_rec.tex[0] = props.texture_record("reflectance", .5f, false, false);
 }
 SmoothDielectric::SmoothDielectric(const Properties &props) {
     float int_ior = lookup_ior(props, "int_ior", "bk7"), ext_ior = lookup_ior(props, "ext_ior", "air");
@@ -434,6 +537,8 @@ SmoothDielectric::SmoothDielectric(const Properties &props) {
     m_rec.type = MI_BSDF_DIELECTRIC; m_rec.flags = 0;
     m_rec.params[0] = int_ior / ext_ior;
     for (int i = 0; i < 3; ++i) { m_rec.params[1 + i] = sr[i]; m_rec.params[4 + i] = stt[i]; }
+    m_rec.tex[0] = props.texture_record("specular_reflectance", 1.f, false, false);
+    m_rec.tex[1] = props.texture_record("specular_transmittance", 1.f, false, false);
 }
 RoughConductor::RoughConductor(const Properties &props) {
     std::string material = props.string("material", "none");
@@ -466,10 +571,14 @@ RoughConductor::RoughConductor(const Properties &props) {
     m_rec.type = MI_BSDF_ROUGHCONDUCTOR; m_rec.flags = flags;
     m_rec.params[0] = au; m_rec.params[1] = av;
     for (int i = 0; i < 3; ++i) { m_rec.params[2 + i] = eta[i]; m_rec.params[5 + i] = k[i]; m_rec.params[8 + i] = sr[i]; }
+    m_rec.tex[0] = props.texture_record("eta", 0.f, false, true);    // xml.cpp is_unbounded_spectrum: eta, k
+    m_rec.tex[1] = props.texture_record("k", 1.f, false, true);
+    m_rec.tex[2] = props.texture_record("specular_reflectance", 1.f, false, false);
 }
 
 AreaLight::AreaLight(const Properties &props) {
     m_radiance = props.texture("radiance", 1.f);               // area.cpp:55 (D65(1) ~ white in RGB mode)
+    m_radiance_tex = props.texture_record("radiance", 1.f, true, false);
 }
 
 EnvironmentMapEmitter::EnvironmentMapEmitter(const Properties &props) {
@@ -538,6 +647,7 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
             s.emitter = (int32_t) erecs.size();
             mi_emitter e{}; e.shape = (uint32_t) srecs.size();
             Color3f r = m->emitter()->radiance(); e.radiance[0] = r[0]; e.radiance[1] = r[1]; e.radiance[2] = r[2];
+            e.radiance_tex = m->emitter()->radiance_texture();
             erecs.push_back(e);
         }
         s.flags = m->has_vertex_normals() ? MI_SHAPE_HAS_NORMALS : 0;
@@ -773,6 +883,8 @@ void mih_mesh_destroy(void *m) { delete (Box<Mesh> *) m; }
 void mih_mesh_set_bsdf(void *m, void *b) { ((Box<Mesh> *) m)->p->set_bsdf(((Box<BSDF> *) b)->p); }
 void mih_mesh_set_emitter(void *m, void *e) { ((Box<Mesh> *) m)->p->set_emitter(((Box<AreaLight> *) e)->p); }
 
+int mih_spectrum_channels() { return spectrum_channels(); }
+int mih_set_srgb_model(const char *path) { MIH_TRY set_srgb_model_path(path ? path : ""); return 0; MIH_CATCH(-1) }
 void *mih_envmap_create(void *props, uint32_t w, uint32_t h, const float *rgba) {
     MIH_TRY
         auto e = std::make_shared<EnvironmentMapEmitter>(*(Properties *) props);

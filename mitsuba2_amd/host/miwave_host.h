@@ -73,10 +73,24 @@ public:
     Color3f texture(const std::string &n, float def) const;
     Color3f texture(const std::string &n) const;
     Transform4f transform(const std::string &n, const Transform4f &def) const;
+    // The texture object an <rgb> / <spectrum value> property expands to in the compiled variant
+    // (src/libcore/xml.cpp:1073-1100): srgb / srgb_d65 / uniform / d65, as a C-ABI record.
+    // `within_emitter`: the property belongs to an emitter; `unbounded`: xml.cpp's is_unbounded_spectrum
+    // names (eta, k, int_ior, ext_ior) skip the [0, 1] reflectance check (src/spectra/srgb.cpp:30-31).
+    mi_texture texture_record(const std::string &n, float def, bool within_emitter, bool unbounded) const;
 private:
     std::string m_plugin_name;
     std::map<std::string, Value> m_values;
 };
+
+// ---- sRGB -> spectrum upsampling model (src/librender/srgb.cpp:14-42, ext/rgb2spec/rgb2spec.c) ----
+// scalar_spectral only. The coefficient table `data/srgb.coeff` is an artefact of the reference's
+// build (rgb2spec_opt 64 srgb.coeff, ext/rgb2spec/CMakeLists.txt:47-52); point the layer at it with
+// set_srgb_model_path() or the MIWAVE_SRGB_COEFF environment variable.
+void set_srgb_model_path(const std::string &path);
+std::array<float, 3> srgb_model_fetch(const Color3f &c);
+// 3 = scalar_rgb, 4 = scalar_spectral build of this layer
+int spectrum_channels();
 
 // ---- ReconstructionFilter (include/mitsuba/core/rfilter.h, src/libcore/rfilter.cpp) ----
 class ReconstructionFilter {
@@ -215,8 +229,9 @@ class AreaLight {                                             // src/emitters/ar
 public:
     explicit AreaLight(const Properties &props);
     Color3f radiance() const { return m_radiance; }
+    const mi_texture &radiance_texture() const { return m_radiance_tex; }   // srgb_d65 / d65 in spectral builds
 private:
-    Color3f m_radiance;
+    Color3f m_radiance; mi_texture m_radiance_tex{};
 };
 
 // src/emitters/envmap.cpp. The reference loads `filename` through Bitmap (out of scope here: no

@@ -104,8 +104,20 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
+        std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
         o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags;
         std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
+#if MIW_SPECTRAL
+        std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
+#else
+        {   // legacy RGB layout of params[] (include/miwave.h) -> texture records
+            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            for (int k = 0; k < 3; ++k) {
+                o.bsdfs[i].tex[k].type = TEX_RGB;
+                if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
+            }
+        }
+#endif
     }
     // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:55-87)
     bool emit_normals = false;
@@ -115,7 +127,11 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         const mi_emitter &e = s->emitters[i];
         const mi_shape &sh = s->shapes[e.shape];
         EmitterRec r; std::memset(&r, 0, sizeof r);
-        std::memcpy(r.radiance, e.radiance, 12);
+#if MIW_SPECTRAL
+        std::memcpy(&r.radiance, &e.radiance_tex, sizeof(TexRec));
+#else
+        r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
+#endif
         r.shape = e.shape; r.tri_first = (uint32_t) o.emit_pmf.size(); r.tri_count = sh.face_count;
         r.flags = (sh.flags & 1u);
         emit_normals = emit_normals || r.flags;
@@ -202,12 +218,12 @@ struct Sampler {
 // ---- PathIntegrator::sample, src/integrators/path.cpp:100-211 (scalar semantics) -------------------
 struct PathStats { uint64_t segments = 0, shadow_rays = 0; };
 
-void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int rr_depth,
-                 V3 &result_out, bool &valid_ray_out, PathStats &stats) {
+void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths &wl, int max_depth, int rr_depth,
+                 Spec &result_out, bool &valid_ray_out, PathStats &stats) {
     const SceneView &view = sc.view;
     float eta = 1.f;                                     // :111
     float emission_weight = 1.f;                         // :114
-    V3 throughput = v3(1.f), result = v3(0.f);           // :116
+    Spec throughput = spec(1.f), result = spec(0.f);     // :116
     bool active = true;                                  // MTS_MASKED_FUNCTION, fwd.h:290-294
 
     SurfaceInteraction si;                               // :120
@@ -221,8 +237,8 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int
     for (int depth = 1;; ++depth) {
         if (emitter >= 0) {                              // :126-129
             if (active) {
-                V3 radiance = si_valid ? emitter_eval(sc.emitters[emitter], si.wi)      // area.cpp:63-71
-                                       : env_eval(*view.env, miss_d);                    // envmap.cpp:134-146
+                Spec radiance = si_valid ? emitter_eval(sc.emitters[emitter], si.wi, wl)  // area.cpp:63-71
+                                         : env_eval_spec(*view.env, miss_d);             // envmap.cpp:134-146
                 result = result + emission_weight * throughput * radiance;
             }
         }
@@ -244,18 +260,18 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int
         if (active_e) {                                  // :157-172
             // Scene::sample_emitter_direction(si, next_2d, test_visibility = true), scene.cpp:164-214
             DirectionSample ds;
-            V3 emitter_val = sample_emitter_direction(view, si.p, sampler.next_2d(), ds);
+            Spec emitter_val = sample_emitter_direction(view, si.p, sampler.next_2d(), ds, wl);
             if (ds.pdf != 0.f) {                         // scene.cpp:200-207
                 Ray shadow;
                 shadow.o = si.p; shadow.d = ds.d;
                 shadow.mint = MIW_RAY_EPSILON * (1.f + hmax(abs3(si.p)));
                 shadow.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON);
                 stats.shadow_rays++;
-                if (ray_test(sc, shadow)) emitter_val = v3(0.f);
+                if (ray_test(sc, shadow)) emitter_val = spec(0.f);
             }
             active_e = active_e && ds.pdf != 0.f;        // :160
             V3 wo = to_local(si.sh, ds.d);               // :163
-            V3 bsdf_val = bsdf_eval(bsdf, si.wi, wo);    // :164
+            Spec bsdf_val = bsdf_eval(bsdf, si.wi, wo, wl);   // :164
             float bpdf = bsdf_pdf(bsdf, si.wi, wo);      // :168
             float mis = mis_weight(ds.pdf, bpdf);        // :170 (ds.delta is false for area lights)
             if (active_e)
@@ -266,7 +282,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, int max_depth, int
         float sample1 = sampler.next_1d();
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        V3 bsdf_val = bsdf_sample(bsdf, si.wi, sample1, sample2, bs);
+        Spec bsdf_val = bsdf_sample(bsdf, si.wi, sample1, sample2, bs, wl);
 
         throughput = throughput * bsdf_val;              // :181
         active = active && !all_zero(throughput);        // :182
@@ -500,13 +516,23 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
                     // render_sample, :233-288
                     V2 jit = sampler.next_2d();
                     V2 position_sample = v2(pos_x + jit.x, pos_y + jit.y);          // :242
-                    (void) sampler.next_1d();                                       // :252 wavelength sample
+                    float wavelength_sample = sampler.next_1d();                    // :252
                     V2 adjusted = v2((position_sample.x - (float) cfg->crop_x) / (float) cfg->crop_w,
                                      (position_sample.y - (float) cfg->crop_y) / (float) cfg->crop_h);   // :254-256
                     Ray ray = sensor_sample_ray(sensor, adjusted);                  // :258
-                    V3 L; bool valid;
-                    path_sample(sc, sampler, ray, cfg->max_depth, cfg->rr_depth, L, valid, st);   // :264
+                    Wavelengths wl; Spec ray_weight;
+#if MIW_SPECTRAL
+                    sample_wavelengths(wavelength_sample, wl, ray_weight);          // perspective.cpp:191-192, spectrum.h:305-314
+#else
+                    (void) wavelength_sample; ray_weight = spec(1.f);
+#endif
+                    Spec L; bool valid;
+                    path_sample(sc, sampler, ray, wl, cfg->max_depth, cfg->rr_depth, L, valid, st);   // :264
+#if MIW_SPECTRAL
+                    V3 xyz = spectrum_to_xyz(ray_weight * L, wl);                   // :266-271
+#else
                     V3 xyz = srgb_to_xyz(L);                                        // :272-273
+#endif
                     float aovs[5] = { xyz.x, xyz.y, xyz.z, valid ? 1.f : 0.f, 1.f };   // :279-283
                     block_put(block, film, position_sample, aovs);                  // :285
                     ++samples;                                                      // sampler->advance(), :287
@@ -619,6 +645,20 @@ int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *x
     else out3[0] = hier2d_eval(t.rec, v2(xy[0], xy[1]));
     return 0;
 }
+#if MIW_SPECTRAL
+// spectrum.h restatements for the known-answer tests (src/librender/tests/test_spectra.py):
+// op 0: cie1931_xyz(in[0]) -> xyz ; 1: d65 (scale in[0]) at in[1] ; 2: sample_wavelengths(in[0]) -> wl[4], weight[4]
+// op 3: texture record {type = in[0] bits, v = in[1..4]} at wavelengths in[5..8] -> 4 values
+void orc_spectral(int op, const float *in, float *out) {
+    FtzScope f;
+    if (op == 0) { V3 v = cie1931_xyz(in[0]); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+    else if (op == 1) out[0] = d65_eval(in[0], in[1]);
+    else if (op == 2) { Wavelengths wl; Spec w; sample_wavelengths(in[0], wl, w); for (int i = 0; i < 4; ++i) { out[i] = wl.l[i]; out[4 + i] = w.c[i]; } }
+    else { TexRec t; t.type = f2u(in[0]); for (int i = 0; i < 4; ++i) t.v[i] = in[1 + i];
+           Wavelengths wl; for (int i = 0; i < 4; ++i) wl.l[i] = in[5 + i];
+           Spec r = tex_eval(t, wl); for (int i = 0; i < 4; ++i) out[i] = r.c[i]; }
+}
+#endif
 // special.h restatements: out4 = exp, log, erf, erfinv of x
 void orc_special(float x, float *out4) {
     FtzScope f;
@@ -696,11 +736,16 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 if (!have_scene) return -1;
                 const BsdfRec &b = sc.bsdfs[f2u(a[0])];
                 V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
-                BSDFSample bs; V3 w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs);
+                Wavelengths wl;
+#if MIW_SPECTRAL
+                for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
+#endif
+                BSDFSample bs; Spec w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
                 o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-                o[6] = w.x; o[7] = w.y; o[8] = w.z;
-                V3 e = bsdf_eval(b, wi, wo); o[9] = e.x; o[10] = e.y; o[11] = e.z;
-                o[12] = bsdf_pdf(b, wi, wo);
+                Spec e = bsdf_eval(b, wi, wo, wl);
+                const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
+                for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
+                o[6 + 2 * MIW_SPEC_N] = bsdf_pdf(b, wi, wo);
             } break;
             case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
             case MI_EVAL_CAMERA_RAY: {
@@ -711,10 +756,15 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
             } break;
             case MI_EVAL_EMITTER_SAMPLE: {
                 if (!have_scene) return -1;
-                DirectionSample ds; V3 s = sample_emitter_direction(sc.view, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds);
+                Wavelengths wl;
+#if MIW_SPECTRAL
+                for (int k = 0; k < 4; ++k) wl.l[k] = a[5 + k];
+#endif
+                DirectionSample ds; Spec sv = sample_emitter_direction(sc.view, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds, wl);
                 o[0] = ds.d.x; o[1] = ds.d.y; o[2] = ds.d.z; o[3] = ds.dist; o[4] = ds.pdf;
-                o[5] = s.x; o[6] = s.y; o[7] = s.z; o[8] = ds.p.x; o[9] = ds.p.y; o[10] = ds.p.z;
-                o[11] = ds.n.x; o[12] = ds.n.y; o[13] = ds.n.z;
+                o[5] = ds.p.x; o[6] = ds.p.y; o[7] = ds.p.z; o[8] = ds.n.x; o[9] = ds.n.y; o[10] = ds.n.z;
+                const float *sf = reinterpret_cast<const float *>(&sv);
+                for (int k = 0; k < MIW_SPEC_N; ++k) o[11 + k] = sf[k];
             } break;
             case MI_EVAL_FP_SEMANTICS: {
                 float x = a[0], y = a[1], z = a[2];
@@ -722,6 +772,7 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
             } break;
             case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
+#if !MIW_SPECTRAL
             case MI_EVAL_ENVMAP: {
                 if (!have_scene || !sc.view.env) return -1;
                 V3 d = v3(a[0], a[1], a[2]);
@@ -731,7 +782,19 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 V3 spec = env_sample_direction(*sc.view.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
                 o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
         } break;
-                case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
+    #else
+            case MI_EVAL_SPECTRUM: {
+                Wavelengths wl; Spec wt;
+                sample_wavelengths(a[0], wl, wt);
+                TexRec t; t.type = TEX_SRGB_D65; t.v[0] = a[1]; t.v[1] = a[2]; t.v[2] = a[3]; t.v[3] = a[4];
+                Spec sd = tex_eval(t, wl);
+                t.type = TEX_SRGB; Spec sr = tex_eval(t, wl);
+                for (int k = 0; k < 4; ++k) { o[k] = wl.l[k]; o[4 + k] = wt.c[k]; o[8 + k] = sr.c[k]; o[12 + k] = sd.c[k]; }
+                V3 xyz = spectrum_to_xyz(wt * sd, wl);
+                o[16] = xyz.x; o[17] = xyz.y; o[18] = xyz.z;
+            } break;
+#endif
+            case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
             default: return -1;
         }
     }

@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from mitsuba2_amd._capi import (mi_hits_soa, mi_rays_soa, mi_render_cfg, mi_scene_desc, c_float_p, c_double_p,  # noqa: E402
-                                c_u32_p, c_i32_p, MI_EVAL_STRIDES)
+                                c_u32_p, c_i32_p, MI_EVAL_STRIDES, VARIANT_SUFFIX, eval_strides)
 
-_lib = None
+_libs = {}
 
 
 class orc_stats(C.Structure):
@@ -27,8 +27,9 @@ def _fp(a):
 
 
 class Oracle:
-    def __init__(self, lib):
+    def __init__(self, lib, channels=3):
         self.L = lib
+        self.channels = channels
         L = lib
         vp = C.c_void_p
         L.orc_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_float_p, c_double_p, C.c_int,
@@ -54,6 +55,8 @@ class Oracle:
         L.orc_microfacet.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_float, C.c_int, c_float_p, c_float_p, c_float_p]
         L.orc_ray_triangle.argtypes = [c_float_p, c_float_p, c_float_p]
         L.orc_special.argtypes = [C.c_float, c_float_p]
+        if channels == 4:
+            L.orc_spectral.argtypes = [C.c_int, c_float_p, c_float_p]
         L.orc_hier2d.argtypes = [c_float_p, C.c_uint32, C.c_uint32, C.c_int, c_float_p, c_float_p]; L.orc_hier2d.restype = C.c_int
         L.orc_imageblock_put.argtypes = [C.POINTER(mi_render_cfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p,
                                          c_float_p, C.c_int, c_float_p]
@@ -117,7 +120,7 @@ class Oracle:
         return ok, out
 
     def eval(self, op, inputs, desc=None, cfg=None):
-        i_s, o_s = MI_EVAL_STRIDES[op]
+        i_s, o_s = eval_strides(op, self.channels)
         a = np.ascontiguousarray(inputs, np.float32).reshape(-1, i_s)
         out = np.zeros((len(a), o_s), np.float32)
         rc = self.L.orc_eval(op, desc, C.byref(cfg) if cfg is not None else None, _fp(a), i_s, _fp(out), o_s, len(a))
@@ -126,11 +129,10 @@ class Oracle:
         return out
 
 
-def load():
-    global _lib
-    if _lib is None:
-        path = os.path.join(ROOT, "oracle", "_build", "libmiw_oracle.so")
+def load(variant="scalar_rgb"):
+    if variant not in _libs:
+        path = os.path.join(ROOT, "oracle", "_build", "libmiw_oracle%s.so" % VARIANT_SUFFIX[variant])
         if not os.path.exists(path):
             raise ImportError(path + " missing: python -m mitsuba2_amd.build --oracle")
-        _lib = Oracle(C.CDLL(path))
-    return _lib
+        _libs[variant] = Oracle(C.CDLL(path), 4 if variant == "scalar_spectral" else 3)
+    return _libs[variant]

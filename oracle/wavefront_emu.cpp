@@ -57,8 +57,20 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     }
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
+        std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
         o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags;
         std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
+#if MIW_SPECTRAL
+        std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
+#else
+        {
+            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            for (int k = 0; k < 3; ++k) {
+                o.bsdfs[i].tex[k].type = TEX_RGB;
+                if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
+            }
+        }
+#endif
     }
     bool emit_normals = false;
     auto push_env = [&]() { EmitterRec r; std::memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; o.emitters.push_back(r); };
@@ -67,7 +79,11 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         const mi_emitter &e = s->emitters[i];
         const mi_shape &sh = s->shapes[e.shape];
         EmitterRec r; std::memset(&r, 0, sizeof r);
-        std::memcpy(r.radiance, e.radiance, 12);
+#if MIW_SPECTRAL
+        std::memcpy(&r.radiance, &e.radiance_tex, sizeof(TexRec));
+#else
+        r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
+#endif
         r.shape = e.shape; r.tri_first = (uint32_t) o.emit_pmf.size(); r.tri_count = sh.face_count; r.flags = sh.flags & 1u;
         emit_normals = emit_normals || r.flags;
         double sum = 0.0; uint32_t vlo = 0xffffffffu, vhi = 0;
@@ -175,10 +191,17 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         uint32_t bx = b % blocks_x, by = b / blocks_x, x, y;
         morton_decode2(i, x, y);
         int bw = std::min<int>(bs, cfg->crop_w - (int) (bx * bs)), bh = std::min<int>(bs, cfg->crop_h - (int) (by * bs));
+#if MIW_SPECTRAL   // spectral builds run the resident plan only: a lane is its st word (k_init_pixels)
+        if ((int) x >= bw || (int) y >= bh) { pixel[lane] = 0; U4 d; d.x = d.y = d.w = 0; d.z = LF_DONE; st[lane] = d; continue; }
+        uint32_t px = (uint32_t) cfg->crop_x + bx * bs + x, py = (uint32_t) cfg->crop_y + by * bs + y;
+        pixel[lane] = px | (py << 16);
+        st[lane] = lane_seed_state(cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
+#else
         if ((int) x >= bw || (int) y >= bh) { pixel[lane] = 0; lane_init_unused(Q, lane); continue; }
         uint32_t px = (uint32_t) cfg->crop_x + bx * bs + x, py = (uint32_t) cfg->crop_y + by * bs + y;
         pixel[lane] = px | (py << 16);
         lane_init(P, Q, lane, pixel[lane], cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
+#endif
     }
     const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris;
     auto node_at = [nodes](int32_t i) -> const BvhNode & { return nodes[i]; };
@@ -219,6 +242,9 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             done = end; ++iterations;
         }
     } else
+#if MIW_SPECTRAL
+    return -2;                                                 // the HBM-queue plan carries RGB path state
+#else
     for (;;) {
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_trace<any>
             F4 d = sh_d[lane]; if (d.w < 0.f) continue;
@@ -247,6 +273,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         ++iterations;
         if (active == 0) break;
     }
+#endif
     if (film32) {                                              // k_film_blocks + k_film_merge
         std::vector<int32_t> block_tile(cfg->block_count, -1);
         for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;

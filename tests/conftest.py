@@ -38,3 +38,24 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+SRGB_COEFF = os.path.join(ROOT, "oracle", "_ref", "srgb.coeff")
+
+
+@pytest.fixture()
+def spectral(native):
+    """Switches the host layer to the scalar_spectral variant for one test (mitsuba.set_variant)."""
+    if not os.path.exists(SRGB_COEFF):
+        pytest.skip("oracle/_ref/srgb.coeff missing (built from the reference's ext/rgb2spec by mitsuba2_amd.build)")
+    native.set_variant("scalar_spectral")
+    native.set_srgb_model(SRGB_COEFF)
+    yield native
+    native.set_variant("scalar_rgb")
+
+
+@pytest.fixture(scope="session")
+def oracle_spectral(native):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    return oracle_py.load("scalar_spectral")
