@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--scene", default="cornell", choices=["cornell", "matball"],
                     help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
                          "dielectric balls, 41k triangles; quoted at 1024 spp)")
+    ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
+                    help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs oracle/_ref/srgb.coeff or "
+                         "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
     ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
     ap.add_argument("--samples-per-launch", type=int, default=-1,
@@ -66,6 +69,10 @@ def main():
     torch.cuda.set_device(local_rank)
 
     W, H, SPP = args.width, args.height, args.spp
+    if args.variant != "scalar_rgb":
+        api.set_variant(args.variant)
+        if not os.environ.get("MIWAVE_SRGB_COEFF"):
+            api.set_srgb_model(os.path.join(ROOT, "oracle", "_ref", "srgb.coeff"))   # a data file the reference's build makes
     scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
     dev = api.Device(local_rank)
     dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
@@ -133,9 +140,19 @@ def main():
             ms, n, alg_bytes = kernels[name]
             achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             b_alg = 280.0 * s_bar + 320.0
+            # measured HBM bytes per launch of that kernel (rocprofv3 PMC passes, committed under profiles/)
+            traffic = None
+            try:
+                key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, dev.counters().plan,
+                                                                 dev.counters().film_mode, cfg.samples_per_launch)
+                entry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get(name)
+                if entry and world == 1:
+                    traffic = entry["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roofline = {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
                 "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
                                   k_film_merge=round(agg["ms_fm"], 3), k_init=round(agg["ms_init"], 3)),
@@ -147,7 +164,7 @@ def main():
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py
-            O = oracle_py.load()
+            O = oracle_py.load(args.variant)
             cores = os.cpu_count() or 1
             nblocks = 8                                      # bounded sample: the 8 centre-most spiral blocks, full spp
             one = api.PathIntegrator().render_job(sensor)
@@ -159,6 +176,7 @@ def main():
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "variant": args.variant,
             "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                     "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
                                     "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, 40972 "
