@@ -392,17 +392,34 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 // A pixel's only state between two camera samples is its PCG32 state and its sample
 // counter (st: state lo, hi, flags, index), so a pixel can be advanced in passes:
 // this call runs samples [st.w, sample_end) and returns the updated st word.
-template <typename Trace2, typename Sink>
-MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
-                       Trace2 trace2, Sink sink, Counters *cnt_local) {
+// `work` feeds the loop: fetch(pixel, st) hands out the next pixel of this lane (false: none left),
+// store(st) publishes a pixel's state when its run is over, put(...) is block->put(). A lane that
+// finishes a pixel fetches the next one INSIDE the iteration loop, so the other lanes of its wavefront
+// never wait for it (the device feeds lanes from one shared queue; the CPU checker hands out one pixel).
+template <typename Work, typename Trace2>
+MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
+                                Trace2 trace2, Counters *cnt_local) {
     LaneRegs L;
-    L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
-    L.rng.inc = MIW_PCG32_SCALAR_INC;
-    L.sample_idx = st.w; L.flags = 0;
-    lane_begin_sample(P, pixel, L, sample_end);
+    L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
+    uint32_t pixel = 0;
+    bool have = false, dead_pending = false;
     ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
-    bool dead_pending = false;
-    while (!(L.flags & LF_DONE)) {
+    auto sink = [&work](uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { work.put(px, sample_idx, pos, aovs); };
+    for (;;) {
+        if (L.flags & LF_DONE) {
+            if (have) {
+                U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
+                st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;
+                work.store(st);
+            }
+            U4 st;
+            have = work.fetch(pixel, st);
+            if (!have) break;
+            L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
+            L.sample_idx = st.w; L.flags = 0;
+            lane_begin_sample(P, pixel, L, sample_end);
+            continue;
+        }
         const V3 o = L.ray.o;
         F4 h; bool occluded = false;
         trace2(o, L.ray.mint, L.ray.d, L.ray.maxt, !dead_pending, sh.d, sh.maxt, sh.has, h, occluded);
@@ -420,9 +437,20 @@ MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixe
         L.flags = 0;
         lane_begin_sample(P, pixel, L, sample_end);
     }
-    st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
-    st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;
-    return st;
+}
+
+// One pixel, samples [st.w, sample_end): returns the updated st word.
+template <typename Trace2, typename Sink>
+MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
+                       Trace2 trace2, Sink sink, Counters *cnt_local) {
+    struct OnePixel {
+        uint32_t pixel; U4 st; bool taken; Sink sink;
+        MIW_HD bool fetch(uint32_t &px, U4 &s) { if (taken) return false; taken = true; px = pixel; s = st; return true; }
+        MIW_HD void store(U4 s) { st = s; }
+        MIW_HD void put(uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { sink(px, sample_idx, pos, aovs); }
+    } work{ pixel, st, false, sink };
+    pixel_stream_render(P, sc, sample_end, work, trace2, cnt_local);
+    return work.st;
 }
 
 // Seed word of a fresh lane (sampler.cpp:83-96 via integrator.cpp:198)

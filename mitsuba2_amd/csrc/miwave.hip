@@ -253,20 +253,20 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         }
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
-        while ((mE | mS) != 0ull) {
-            const bool useE = mE != 0ull;
-            const unsigned long long m = useE ? mE : mS;
-            const uint32_t i = (uint32_t) __ffsll((long long) m) - 1u;
-            if (useE) mE = m & (m - 1ull); else mS = m & (m - 1ull);
+        while (mE != 0ull) {                                   // closest hit of E over its candidates
+            const uint32_t i = (uint32_t) __ffsll((long long) mE) - 1u;
+            mE &= mE - 1ull;
             const TriPacket &k = pk[i];
-            const V3 d = useE ? dE : dS;
-            const float maxt = useE ? maxtE : maxtS;
             float t, u, v;
-            const bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
-            if (hit) {
-                if (!useE) { occ = true; mS = 0ull; }
-                else if (t < h.t || (t == h.t && k.prim < h.prim)) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
-            }
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
+                (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
+        }
+        while (mS != 0ull) {                                   // any hit of S
+            const uint32_t i = (uint32_t) __ffsll((long long) mS) - 1u;
+            mS &= mS - 1ull;
+            const TriPacket &k = pk[i];
+            float t, u, v;
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) { occ = true; mS = 0ull; }
         }
     } else {
         if (hasE) trace_one<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
@@ -500,9 +500,38 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
     uint32_t geom16;            // uint4 slots of dynamic LDS in front of the tile
 };
 
+// Log mode feeds the lanes from ONE shared pixel queue (`next_pixel`): a lane that finishes its pixel takes
+// the next unclaimed one inside the iteration loop (wavefront-aggregated: ballot + one atomic per wave per
+// refill), so no lane waits for the slowest pixel of its wavefront and the launch drains evenly. The grid is
+// sized to the machine; workgroups that start late find the queue empty and retire.
+struct QueueWork {
+    const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane;
+    __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
+        for (;;) {
+            // claim: ballot over the lanes asking, one atomic for all of them
+            const unsigned long long b = __ballot(1);
+            const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+            uint32_t base = 0;
+            if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
+            base = (uint32_t) __shfl((int) base, (int) leader, 64);
+            lane = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
+            if (lane >= n_lanes) return false;
+            st = Q->st[lane];
+            if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
+            pixel = Q->pixel[lane];
+            return true;
+        }
+    }
+    __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
+    __device__ __forceinline__ void put(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) {
+        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp;
+        sink(0u, sample_idx, pos, aovs);
+    }
+};
+
 template <bool UseLog>
 __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
-                                                               TraceLds cfg, uint32_t sample_end, TileArgs T) {
+                                                               TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,17 +550,17 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, Sce
         __syncthreads();
     }
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
-    if (lane < P.n_lanes) {
+    auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
+        trace2(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
+    };
+    if (UseLog) {
+        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
+        pixel_stream_render(P, sc, sample_end, work, tr2, &local);
+    } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
             const uint32_t pixel = Q.pixel[lane];
-            auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
-                trace2(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
-            };
-            if (UseLog) {
-                LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
-                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
-            } else if (T.side) {
+            if (T.side) {
                 TileAdd add; add.tile = tile; add.x0 = tile_x0; add.y0 = tile_y0; add.side = (int) T.side;
                 SplatXYSink<TileAdd> sink; sink.film = &P.film; sink.add = add;
                 st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
@@ -859,6 +888,7 @@ struct mi_ctx {
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
     DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;
+    DevBuf<uint32_t> d_next_pixel; int cu_count = 256;
     DevBuf<uint32_t> d_lists, d_list_counts;    // wavefront plan: 2 parities x WL_LISTS lists / counters
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
     DevBuf<Counters> d_cnt;
@@ -901,6 +931,7 @@ mi_status mi_create(int32_t device, mi_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) { g_global_error = "hipSetDevice failed"; return MI_ERR_DEVICE; }
     mi_ctx *c = new mi_ctx();
     c->device = device;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters) * MIW_CNT_SHARDS) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
     *out = c;
     return MI_OK;
@@ -914,7 +945,7 @@ void mi_destroy(mi_ctx *c) {
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
-    c->d_accum.release(); c->d_out.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
     c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
@@ -1410,6 +1441,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
         MIW_TIMED(3, hipLaunchKernelGGL(k_init_pixels, grid, block, 0, s, P, c->q_st.p, c->q_pixel.p, A));
         HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, c->d_next_pixel.resize(1));
         const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
         // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
         TileArgs TA; memset(&TA, 0, sizeof TA);
@@ -1426,10 +1458,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         uint32_t launches = 0;
         for (uint32_t done = 0; done < cfg->spp; ) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
-            if (film_mode == 1)
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, grid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA));
-            else
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA));
+            if (film_mode == 1) {
+                // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
+                HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
+                const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+            } else
+                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             K.n_path++; K.iterations++;
             done = end;
             if (++launches % sync_every == 0 && done < cfg->spp) {
