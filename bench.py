@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "matball"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "matball", "interior"],
                     help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
                          "dielectric balls, 41k triangles; quoted at 1024 spp)")
     ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
@@ -73,7 +73,10 @@ def main():
         api.set_variant(args.variant)
         if not os.environ.get("MIWAVE_SRGB_COEFF"):
             api.set_srgb_model(os.path.join(ROOT, "oracle", "_ref", "srgb.coeff"))   # a data file the reference's build makes
-    scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
+    if args.scene == "interior":     # BASELINE configs[3] class: ~0.9 M triangles, area light + environment map
+        scene, sensor = scenes.interior_scene(W, H, SPP, device=-1)
+    else:
+        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
     dev = api.Device(local_rank)
     dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
     bvh = dev.counters()
@@ -179,6 +182,9 @@ def main():
             "variant": args.variant,
             "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                     "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
+                                    "procedural interior (911 362 triangles: displaced wall grids + 200 icospheres, diffuse / GGX / "
+                                    "Beckmann conductors / dielectric), area light + 1024x512 environment map, %dx%d @ %d spp, path "
+                                    "integrator max_depth=-1 rr_depth=5" if args.scene == "interior" else
                                     "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, 40972 "
                                     "triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),

@@ -170,6 +170,62 @@ def open_box(width, height, spp, seed=0, device=0, with_area_light=True, envmap_
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 
+def _displaced_grid(corners, n, amp, rng, inward_point):
+    """n x n quad grid over the bilinear patch `corners` (4 points), vertices displaced along the patch normal by
+    seeded noise of amplitude `amp`; winding facing `inward_point`. -> (vertices, faces)"""
+    c = np.asarray(corners, np.float64)
+    u = np.linspace(0, 1, n + 1)
+    U, V = np.meshgrid(u, u)
+    P = ((1 - U)[..., None] * (1 - V)[..., None] * c[0] + U[..., None] * (1 - V)[..., None] * c[1] +
+         U[..., None] * V[..., None] * c[2] + (1 - U)[..., None] * V[..., None] * c[3])
+    nrm = np.cross(c[1] - c[0], c[3] - c[0]); nrm /= np.linalg.norm(nrm)
+    if np.dot(nrm, np.asarray(inward_point, np.float64) - c.mean(0)) < 0:
+        nrm = -nrm
+    bump = amp * (0.5 * np.sin(9 * np.pi * U) * np.cos(7 * np.pi * V) + 0.5 * (rng.random(U.shape) - 0.5))
+    bump[0, :] = bump[-1, :] = 0; bump[:, 0] = bump[:, -1] = 0              # keep the seams closed
+    P = P + bump[..., None] * nrm
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    a, b, cc, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+    f = np.concatenate([np.stack([a, b, cc], 1), np.stack([a, cc, d], 1)])
+    v = P.reshape(-1, 3)
+    tn = np.cross(v[f[0, 1]] - v[f[0, 0]], v[f[0, 2]] - v[f[0, 0]])
+    if np.dot(tn, nrm) < 0:
+        f = f[:, ::-1]
+    return v.astype(np.float32), f.astype(np.uint32)
+
+
+def interior_scene(width, height, spp, grid=256, n_clutter=200, clutter_level=3, seed=1234, device=0, env_size=(1024, 512),
+                   rfilter="gaussian", **film_kw):
+    """BASELINE config 4 class: a procedurally generated ~1 M-triangle interior — the Cornell
+    room without its ceiling, every wall a displaced `grid` x `grid` mesh, `n_clutter` icospheres (diffuse / GGX
+    conductor / dielectric, shading normals) scattered by a fixed-seed generator, one area light and the synthetic
+    lat-long sky. grid=256, n_clutter=200, clutter_level=3 -> 655 360 + 256 000 + 2 = 911 362 triangles."""
+    rng = np.random.default_rng(seed)
+    white = api.BSDF("diffuse", reflectance=WHITE); red = api.BSDF("diffuse", reflectance=RED)
+    green = api.BSDF("diffuse", reflectance=GREEN)
+    meshes = []
+    for name, bsdf in (("floor", white), ("back", white), ("right", green), ("left", red)):
+        v, f = _displaced_grid(_CBOX[name], grid, 6.0, rng, _ROOM_CENTER)
+        meshes.append(api.Mesh(name, v, f, bsdf=bsdf))
+    v, f = _displaced_grid([(556, 548.8, -200), (0, 548.8, -200), (0, 548.8, 0), (556, 548.8, 0)], grid, 4.0, rng, (278, 0, -100))
+    meshes.append(api.Mesh("awning", v, f, bsdf=white))
+    v, f = _quad(_CBOX["light"], inward_point=_ROOM_CENTER)
+    meshes.append(api.Mesh("light", v, f, emitter=api.AreaLight(LIGHT_RADIANCE)))
+    mats = [white, red, green,
+            api.BSDF("roughconductor", distribution="ggx", alpha=0.15, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14)),
+            api.BSDF("roughconductor", distribution="beckmann", alpha=0.3, eta=(1.66, 0.88, 0.52), k=(9.2, 6.3, 4.8)),
+            api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)]
+    for i in range(n_clutter):
+        r = float(rng.uniform(8, 28))
+        c = (float(rng.uniform(40, 510)), r + float(rng.uniform(0, 260)) * float(rng.random() < 0.3), float(rng.uniform(40, 520)))
+        v, f, n = icosphere(c, r, clutter_level)
+        meshes.append(api.Mesh("clutter%d" % i, v, f, normals=n, bsdf=mats[i % len(mats)]))
+    env = api.EnvMap(sky_envmap(env_size[0], env_size[1]), scale=1.0,
+                     to_world=dict(origin=(0, 0, 0), target=(0.3, 0.1, 1.0), up=(0, 1, 0)))
+    scene = api.Scene(meshes, envmap=env).build(device)
+    return scene, cornell_sensor(width, height, spp, seed=0, rfilter=rfilter, **film_kw)
+
+
 def stairs(num_steps):
     """src/librender/tests/mesh_generation.py:27-59"""
     size_step = 1.0 / num_steps
