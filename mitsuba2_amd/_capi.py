@@ -154,6 +154,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),
         "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),
         "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p]), "mih_mesh_destroy": (None, [vp]),
+        "mih_mesh_load": (vp, [i32, vp]), "mih_mesh_recompute_normals": (i32, [vp]),
+        "mih_mesh_counts": (None, [vp, c_u32_p, c_u32_p, c_i32_p]), "mih_mesh_copy": (None, [vp, c_float_p, c_u32_p, c_float_p]),
         "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),
         "mih_envmap_create": (vp, [vp, u32, u32, c_float_p]), "mih_envmap_destroy": (None, [vp]),
         "mih_scene_add_envmap": (i32, [vp, vp]),

@@ -150,6 +150,40 @@ class Mesh:
         if emitter is not None:
             host_lib().mih_mesh_set_emitter(self.h, emitter.h)
 
+    @classmethod
+    def load(cls, filename, bsdf=None, emitter=None, **kw):
+        """<shape type="obj"|"ply"> (src/shapes/obj.cpp, ply.cpp): properties face_normals, flip_tex_coords, to_world"""
+        kind = {".obj": 0, ".ply": 1}.get(str(filename)[-4:].lower())
+        if kind is None:
+            raise ValueError("Mesh.load: expected a .obj or .ply file")
+        props = Properties("obj" if kind == 0 else "ply", filename=str(filename), **kw)
+        h = host_lib().mih_mesh_load(kind, props.h)
+        if not h:
+            raise RuntimeError(_err())
+        self = cls.__new__(cls)
+        self.h, self.name = h, str(filename)
+        self._sync()
+        self.bsdf, self.emitter = bsdf, emitter
+        if bsdf is not None:
+            host_lib().mih_mesh_set_bsdf(self.h, bsdf.h)
+        if emitter is not None:
+            host_lib().mih_mesh_set_emitter(self.h, emitter.h)
+        return self
+
+    def _sync(self):
+        nv, nf, hn = C.c_uint32(), C.c_uint32(), C.c_int32()
+        host_lib().mih_mesh_counts(self.h, C.byref(nv), C.byref(nf), C.byref(hn))
+        self.vertices = np.zeros((nv.value, 3), np.float32); self.faces = np.zeros((nf.value, 3), np.uint32)
+        self.normals = np.zeros((nv.value, 3), np.float32) if hn.value else None
+        host_lib().mih_mesh_copy(self.h, _fp(self.vertices), self.faces.ctypes.data_as(c_u32_p),
+                                 None if self.normals is None else _fp(self.normals))
+
+    def recompute_vertex_normals(self):
+        """Mesh::recompute_vertex_normals (src/librender/mesh.cpp:200-246)"""
+        if host_lib().mih_mesh_recompute_normals(self.h) != 0:
+            raise RuntimeError(_err())
+        self._sync()
+
     def __del__(self):
         if getattr(self, "h", None):
             host_lib().mih_mesh_destroy(self.h); self.h = None

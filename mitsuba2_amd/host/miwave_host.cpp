@@ -14,6 +14,8 @@
 #include "../csrc/miw/rng.h"
 #include "../csrc/miw/bsdf.h"
 #include "../csrc/miw/scene.h"
+#include "../csrc/miw/special.h"
+#include <cctype>
 
 namespace miwave {
 
@@ -603,6 +605,247 @@ Mesh::Mesh(std::string name, std::vector<float> p, std::vector<uint32_t> f, std:
     for (uint32_t i : m_faces) if (i >= vertex_count()) Throw("Mesh: face references a vertex out of range");
 }
 
+// enoki unit_angle(a, b) for unit vectors: 2 asin(|b -+ a| / 2), robust near 0 and pi
+static float unit_angle(miw::V3 a, miw::V3 b) {
+    float dot_uv = miw::dot(a, b);
+    miw::V3 t = dot_uv >= 0.f ? b - a : b + a;
+    float temp = 2.f * miw::asin_(.5f * miw::norm(t));
+    return dot_uv >= 0.f ? temp : MIW_PI - temp;
+}
+void Mesh::recompute_vertex_normals() {
+    const uint32_t nv = vertex_count(), nf = face_count();
+    std::vector<miw::V3> acc(nv, miw::v3(0.f));
+    auto P = [&](uint32_t i) { return miw::v3(m_positions[3 * i], m_positions[3 * i + 1], m_positions[3 * i + 2]); };
+    for (uint32_t f = 0; f < nf; ++f) {
+        const uint32_t fi[3] = { m_faces[3 * f], m_faces[3 * f + 1], m_faces[3 * f + 2] };
+        miw::V3 v[3] = { P(fi[0]), P(fi[1]), P(fi[2]) };
+        miw::V3 side_0 = v[1] - v[0], side_1 = v[2] - v[0];
+        miw::V3 n = miw::cross(side_0, side_1);
+        float length_sqr = miw::squared_norm(n);
+        if (length_sqr > 0.f) {
+            n = n * miw::rsqrt(length_sqr);
+            const miw::V3 s1[3] = { side_0, v[2] - v[1], v[0] - v[2] }, s2[3] = { side_1, v[0] - v[1], v[1] - v[2] };
+            for (int j = 0; j < 3; ++j)
+                acc[fi[j]] = acc[fi[j]] + n * unit_angle(miw::normalize(s1[j]), miw::normalize(s2[j]));
+        }
+    }
+    m_normals.assign((size_t) nv * 3, 0.f);
+    for (uint32_t i = 0; i < nv; ++i) {
+        miw::V3 n = acc[i];
+        float length = miw::norm(n);
+        if (length != 0.f) n = n / length; else n = miw::v3(1.f, 0.f, 0.f);    // "some bogus value", mesh.cpp:243
+        m_normals[3 * i] = n.x; m_normals[3 * i + 1] = n.y; m_normals[3 * i + 2] = n.z;
+    }
+}
+
+// ---- obj / ply ---------------------------------------------------------------------------------
+namespace {
+std::string read_file(const std::string &path, const char *what) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) Throw(std::string("Error while loading ") + what + " file \"" + path + "\": file not found");
+    std::string data;
+    char buf[1 << 16]; size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    std::fclose(f);
+    return data;
+}
+std::string base_name(const std::string &path) { size_t p = path.find_last_of("/\\"); return p == std::string::npos ? path : path.substr(p + 1); }
+miw::V3 xf_normal(const Transform4f &t, miw::V3 n) {            // Transform::transform_affine(Normal): inverse transpose
+    const float *m = t.inv;
+    return miw::v3(m[0] * n.x + m[1] * n.y + m[2] * n.z, m[4] * n.x + m[5] * n.y + m[6] * n.z, m[8] * n.x + m[9] * n.y + m[10] * n.z);
+}
+struct Key3 { uint32_t k[3]; bool operator<(const Key3 &o) const { return std::lexicographical_compare(k, k + 3, o.k, o.k + 3); } };
+}
+
+std::shared_ptr<Mesh> load_obj(const Properties &props) {
+    const bool flip_tex_coords = props.bool_("flip_tex_coords", true), face_normals = props.bool_("face_normals", false);
+    const Transform4f to_world = props.transform("to_world", Transform4f());
+    const std::string path = props.string("filename"), name = base_name(path);
+    const std::string data = read_file(path, "OBJ");
+    auto fail = [&](const std::string &d) { Throw("Error while loading OBJ file \"" + name + "\": " + d); };
+    std::vector<miw::V3> vertices, normals; std::vector<std::array<float, 2>> texcoords;
+    std::vector<uint32_t> faces; std::vector<Key3> keys;        // keys[id] = (v, vt, vn) of output vertex id
+    std::map<Key3, uint32_t> vertex_map;
+    size_t pos = 0;
+    while (pos < data.size()) {
+        size_t eol = data.find('\n', pos);
+        if (eol == std::string::npos) eol = data.size();
+        if (eol - pos >= 1024) fail("file contains an excessively long line!");
+        std::string line = data.substr(pos, eol - pos);
+        pos = eol + 1;
+        const char *cur = line.c_str();
+        while (*cur == ' ' || *cur == '\t' || *cur == '\r') ++cur;
+        bool parse_error = false;
+        auto read_floats = [&](int n, float *out) { for (int i = 0; i < n; ++i) { char *end; out[i] = std::strtof(cur, &end); parse_error |= end == cur; cur = end; } };
+        if (cur[0] == 'v' && (cur[1] == ' ' || cur[1] == '\t')) {
+            float p[3]; cur += 2; read_floats(3, p);
+            miw::V3 w = miw::xf_point_affine(to_world.m, miw::v3(p[0], p[1], p[2]));
+            if (!std::isfinite(w.x) || !std::isfinite(w.y) || !std::isfinite(w.z)) fail("mesh contains invalid vertex position data");
+            vertices.push_back(w);
+        } else if (cur[0] == 'v' && cur[1] == 'n' && (cur[2] == ' ' || cur[2] == '\t')) {
+            float p[3]; cur += 3; read_floats(3, p);
+            miw::V3 n = miw::normalize(xf_normal(to_world, miw::v3(p[0], p[1], p[2])));
+            if (!std::isfinite(n.x) || !std::isfinite(n.y) || !std::isfinite(n.z)) fail("mesh contains invalid vertex normal data");
+            normals.push_back(n);
+        } else if (cur[0] == 'v' && cur[1] == 't' && (cur[2] == ' ' || cur[2] == '\t')) {
+            float p[2]; cur += 3; read_floats(2, p);
+            if (flip_tex_coords) p[1] = 1.f - p[1];
+            texcoords.push_back({ p[0], p[1] });
+        } else if (cur[0] == 'f' && (cur[1] == ' ' || cur[1] == '\t')) {
+            cur += 2;
+            size_t vertex_index = 0, type_index = 0;
+            Key3 key{ { 0, 0, 0 } }; uint32_t tri[3] = { 0, 0, 0 };
+            while (true) {
+                char *next2;
+                uint32_t value = (uint32_t) std::strtoul(cur, &next2, 10);
+                if (cur == next2) break;
+                if (type_index < 3) key.k[type_index] = value; else { parse_error = true; break; }
+                while (*next2 == '/') { type_index++; next2++; }
+                if (*next2 == ' ' || *next2 == '\t' || *next2 == '\0' || *next2 == '\r') {
+                    type_index = 0;
+                    if ((size_t) key.k[0] - 1 >= vertices.size()) fail("reference to invalid vertex " + std::to_string(key.k[0]) + "!");
+                    auto it = vertex_map.find(key);
+                    uint32_t id;
+                    if (it != vertex_map.end()) id = it->second;
+                    else { id = (uint32_t) keys.size(); vertex_map.emplace(key, id); keys.push_back(key); }
+                    if (vertex_index < 3) tri[vertex_index] = id; else { tri[1] = tri[2]; tri[2] = id; }   // polygon fan
+                    vertex_index++;
+                    if (vertex_index >= 3) faces.insert(faces.end(), tri, tri + 3);
+                    key = Key3{ { 0, 0, 0 } };
+                }
+                cur = next2;
+            }
+        }
+        if (parse_error) fail("could not parse line \"" + line + "\"");
+    }
+    const size_t nv = keys.size();
+    std::vector<float> P(nv * 3), N;
+    const bool keep_normals = !face_normals;
+    if (keep_normals && !normals.empty()) N.assign(nv * 3, 0.f);
+    for (size_t id = 0; id < nv; ++id) {
+        const Key3 &k = keys[id];
+        const miw::V3 &v = vertices[k.k[0] - 1];
+        P[3 * id] = v.x; P[3 * id + 1] = v.y; P[3 * id + 2] = v.z;
+        if (k.k[1] && (size_t) k.k[1] - 1 >= texcoords.size()) fail("reference to invalid texture coordinate " + std::to_string(k.k[1]) + "!");
+        if (keep_normals && k.k[2]) {
+            if ((size_t) k.k[2] - 1 >= normals.size()) fail("reference to invalid normal " + std::to_string(k.k[2]) + "!");
+            const miw::V3 &n = normals[k.k[2] - 1];
+            N[3 * id] = n.x; N[3 * id + 1] = n.y; N[3 * id + 2] = n.z;
+        }
+    }
+    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(faces), std::move(N));
+    if (keep_normals && normals.empty()) mesh->recompute_vertex_normals();      // obj.cpp:339-341
+    return mesh;
+}
+
+std::shared_ptr<Mesh> load_ply(const Properties &props) {
+    const bool face_normals = props.bool_("face_normals", false);
+    const Transform4f to_world = props.transform("to_world", Transform4f());
+    const std::string path = props.string("filename"), name = base_name(path);
+    const std::string data = read_file(path, "PLY");
+    auto fail = [&](const std::string &d) { Throw("Error while loading PLY file \"" + name + "\": " + d); };
+    struct Prop { std::string name, type, count_type; bool list = false; };
+    struct Elem { std::string name; size_t count = 0; std::vector<Prop> props; };
+    std::vector<Elem> elems; std::string format;
+    size_t pos = 0; bool header_done = false, tag = false;
+    auto next_line = [&]() { size_t e = data.find('\n', pos); if (e == std::string::npos) fail("invalid PLY header"); std::string l = data.substr(pos, e - pos); pos = e + 1; if (!l.empty() && l.back() == '\r') l.pop_back(); return l; };
+    auto split = [](const std::string &l) { std::vector<std::string> t; size_t i = 0; while (i < l.size()) { while (i < l.size() && (l[i] == ' ' || l[i] == '\t')) ++i; size_t j = i; while (j < l.size() && l[j] != ' ' && l[j] != '\t') ++j; if (j > i) t.push_back(l.substr(i, j - i)); i = j; } return t; };
+    while (!header_done) {
+        auto t = split(next_line());
+        if (t.empty()) continue;
+        if (t[0] == "ply") tag = true;
+        else if (t[0] == "format" && t.size() >= 3) { format = t[1]; if (t[2] != "1.0") fail("PLY file has unknown version"); }
+        else if (t[0] == "comment" || t[0] == "obj_info") {}
+        else if (t[0] == "element" && t.size() == 3) { Elem e; e.name = t[1]; e.count = (size_t) std::strtoull(t[2].c_str(), nullptr, 10); elems.push_back(e); }
+        else if (t[0] == "property" && !elems.empty()) {
+            Prop p;
+            if (t.size() == 5 && t[1] == "list") { p.list = true; p.count_type = t[2]; p.type = t[3]; p.name = t[4]; }
+            else if (t.size() == 3) { p.type = t[1]; p.name = t[2]; }
+            else fail("invalid PLY header: could not parse a property line");
+            elems.back().props.push_back(p);
+        } else if (t[0] == "end_header") header_done = true;
+        else fail("invalid PLY header: unknown token \"" + t[0] + "\"");
+    }
+    if (!tag) fail("invalid PLY header: missing \"ply\" tag");
+    const bool ascii = format == "ascii", le = format == "binary_little_endian", be = format == "binary_big_endian";
+    if (!ascii && !le && !be) fail("invalid PLY header: unknown format");
+    auto type_size = [&](const std::string &t) -> int {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        fail("invalid PLY header: unknown format type \"" + t + "\""); return 0; };
+    auto read_num = [&](const std::string &t) -> double {          // one scalar of PLY type t at `pos`
+        if (ascii) {
+            while (pos < data.size() && std::isspace((unsigned char) data[pos])) ++pos;
+            char *end; double v = std::strtod(data.c_str() + pos, &end);
+            if (end == data.c_str() + pos) fail("could not parse the body");
+            pos = (size_t) (end - data.c_str());
+            return v;
+        }
+        const int sz = type_size(t);
+        if (pos + sz > data.size()) fail("file is truncated");
+        unsigned char b[8];
+        for (int i = 0; i < sz; ++i) b[i] = (unsigned char) data[pos + (be ? sz - 1 - i : i)];
+        pos += sz;
+        if (t == "char" || t == "int8") return (double) (int8_t) b[0];
+        if (t == "uchar" || t == "uint8") return (double) b[0];
+        if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, b, 2); return v; }
+        if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, b, 2); return v; }
+        if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, b, 4); return v; }
+        if (t == "uint" || t == "uint32") { uint32_t v; std::memcpy(&v, b, 4); return v; }
+        if (t == "float" || t == "float32") { float v; std::memcpy(&v, b, 4); return v; }
+        double v; std::memcpy(&v, b, 8); return v;
+    };
+    std::vector<float> P, N; std::vector<uint32_t> F; bool has_normals = false;
+    for (const Elem &el : elems) {
+        if (el.name == "vertex") {
+            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
+            for (size_t i = 0; i < el.props.size(); ++i) {
+                const std::string &n = el.props[i].name;
+                if (n == "x") ix = (int) i; else if (n == "y") iy = (int) i; else if (n == "z") iz = (int) i;
+                else if (n == "nx") inx = (int) i; else if (n == "ny") iny = (int) i; else if (n == "nz") inz = (int) i;
+                if (el.props[i].list) fail("vertex element with a list property");
+            }
+            if (ix < 0 || iy < 0 || iz < 0) fail("vertex coordinates missing");
+            has_normals = inx >= 0 && iny >= 0 && inz >= 0 && !face_normals;
+            P.resize(el.count * 3); if (has_normals) N.resize(el.count * 3);
+            std::vector<double> row(el.props.size());
+            for (size_t v = 0; v < el.count; ++v) {
+                for (size_t i = 0; i < el.props.size(); ++i) row[i] = read_num(el.props[i].type);
+                miw::V3 p = miw::xf_point_affine(to_world.m, miw::v3((float) row[ix], (float) row[iy], (float) row[iz]));
+                P[3 * v] = p.x; P[3 * v + 1] = p.y; P[3 * v + 2] = p.z;
+                if (has_normals) {
+                    miw::V3 n = miw::normalize(xf_normal(to_world, miw::v3((float) row[inx], (float) row[iny], (float) row[inz])));
+                    N[3 * v] = n.x; N[3 * v + 1] = n.y; N[3 * v + 2] = n.z;
+                }
+            }
+        } else if (el.name == "face") {
+            F.reserve(el.count * 3);
+            for (size_t f = 0; f < el.count; ++f)
+                for (const Prop &p : el.props) {
+                    if (p.list) {
+                        const int cnt = (int) read_num(p.count_type);
+                        const bool indices = p.name == "vertex_index" || p.name == "vertex_indices";
+                        if (indices && cnt != 3) fail("incompatible contents -- is this a triangle mesh?");   // ply.cpp:339
+                        for (int k = 0; k < cnt; ++k) { double v = read_num(p.type); if (indices) F.push_back((uint32_t) v); }
+                    } else (void) read_num(p.type);
+                }
+        } else {                                                  // unknown element: skipped (ply.cpp:364-366)
+            for (size_t k = 0; k < el.count; ++k)
+                for (const Prop &p : el.props) {
+                    if (p.list) { const int cnt = (int) read_num(p.count_type); for (int q = 0; q < cnt; ++q) (void) read_num(p.type); }
+                    else (void) read_num(p.type);
+                }
+        }
+    }
+    if (ascii) while (pos < data.size() && std::isspace((unsigned char) data[pos])) ++pos;
+    if (pos != data.size()) fail("invalid file -- trailing content");
+    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(F), std::move(N));
+    if (!face_normals && !has_normals) mesh->recompute_vertex_normals();        // ply.cpp:378-383
+    return mesh;
+}
+
 bool PreliminaryIntersection3f::is_valid() const { return t != std::numeric_limits<float>::infinity(); }
 
 Scene::Scene() {}
@@ -878,6 +1121,20 @@ void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uin
         std::vector<uint32_t> f(faces, faces + 3 * (size_t) nf);
         std::vector<float> n; if (normals) n.assign(normals, normals + 3 * (size_t) nv);
         return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n)) }; MIH_CATCH(nullptr)
+}
+// kind 0 = obj, 1 = ply (the `obj` / `ply` shape plugins; props: filename, face_normals, flip_tex_coords, to_world)
+void *mih_mesh_load(int kind, void *props) {
+    MIH_TRY return new Box<Mesh>{ kind == 0 ? load_obj(*(Properties *) props) : load_ply(*(Properties *) props) }; MIH_CATCH(nullptr)
+}
+int mih_mesh_recompute_normals(void *m) { MIH_TRY ((Box<Mesh> *) m)->p->recompute_vertex_normals(); return 0; MIH_CATCH(-1) }
+void mih_mesh_counts(void *m, uint32_t *nv, uint32_t *nf, int *has_normals) {
+    const Mesh &me = *((Box<Mesh> *) m)->p; *nv = me.vertex_count(); *nf = me.face_count(); *has_normals = me.has_vertex_normals() ? 1 : 0;
+}
+void mih_mesh_copy(void *m, float *pos, uint32_t *faces, float *normals) {
+    const Mesh &me = *((Box<Mesh> *) m)->p;
+    if (pos) std::memcpy(pos, me.vertex_positions_buffer().data(), me.vertex_positions_buffer().size() * 4);
+    if (faces) std::memcpy(faces, me.faces_buffer().data(), me.faces_buffer().size() * 4);
+    if (normals && me.has_vertex_normals()) std::memcpy(normals, me.vertex_normals_buffer().data(), me.vertex_normals_buffer().size() * 4);
 }
 void mih_mesh_destroy(void *m) { delete (Box<Mesh> *) m; }
 void mih_mesh_set_bsdf(void *m, void *b) { ((Box<Mesh> *) m)->p->set_bsdf(((Box<BSDF> *) b)->p); }

@@ -263,6 +263,10 @@ public:
     const std::vector<float> &vertex_positions_buffer() const { return m_positions; }
     const std::vector<float> &vertex_normals_buffer() const { return m_normals; }
     const std::vector<uint32_t> &faces_buffer() const { return m_faces; }
+    // Mesh::recompute_vertex_normals (src/librender/mesh.cpp:200-246): angle-weighted face normals
+    // (Thuermer & Wuethrich 1998); creates the normal buffer if the mesh has none
+    void recompute_vertex_normals();
+    void discard_vertex_normals() { m_normals.clear(); }       // `face_normals = true` (m_disable_vertex_normals)
     void set_bsdf(std::shared_ptr<BSDF> b) { m_bsdf = std::move(b); }
     void set_emitter(std::shared_ptr<AreaLight> e) { m_emitter = std::move(e); }
     const std::shared_ptr<BSDF> &bsdf() const { return m_bsdf; }
@@ -275,6 +279,11 @@ private:
     std::shared_ptr<BSDF> m_bsdf;
     std::shared_ptr<AreaLight> m_emitter;
 };
+
+// Mesh file loaders: the `obj` and `ply` shape plugins.
+// Properties: filename, face_normals (false), to_world (identity); obj: flip_tex_coords (true).
+std::shared_ptr<Mesh> load_obj(const Properties &props);      // src/shapes/obj.cpp:95-345
+std::shared_ptr<Mesh> load_ply(const Properties &props);      // src/shapes/ply.cpp (ascii / binary_little_endian / big_endian)
 
 // ---- Scene (include/mitsuba/render/scene.h:38-161, src/librender/scene.cpp) --------------------
 struct PreliminaryIntersection3f { float t; float u, v; uint32_t prim_index, shape_index; bool is_valid() const; };

@@ -1,0 +1,113 @@
+"""the `obj` / `ply` shape plugins and Mesh::recompute_vertex_normals in the host layer."""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_normal_weighting_scheme(native):
+    """src/librender/tests/test_mesh.py:79-106 (test04): angle-weighted vertex normals"""
+    a, b = 1.0, 0.5
+    v = np.array([[0, 0, 0], [-a, 1, 0], [a, 1, 0], [-b, 0, 1], [b, 0, 1]], np.float32)
+    f = np.array([[0, 1, 2], [0, 3, 4]], np.uint32)
+    m = native.Mesh("MyMesh", v, f)
+    m.recompute_vertex_normals()
+    n0 = np.array([0.0, 0.0, -1.0]); n1 = np.array([0.0, 1.0, 0.0])
+    n2 = n0 * (math.pi / 2.0) + n1 * math.acos(3.0 / 5.0); n2 /= np.linalg.norm(n2)
+    assert np.allclose(m.normals, np.vstack([n2, n0, n0, n1, n1]), atol=5e-4)
+
+
+def test_obj_loader(native, tmp_path):
+    """src/shapes/obj.cpp: v / vt / vn / f with all index forms, quad fan, vertex de-duplication in order of first
+    use, flipped v texture coordinate, computed normals when the file has none, face_normals, to_world, errors."""
+    p = tmp_path / "quad.obj"
+    p.write_text("# unit quad in z = 0, counter-clockwise\n"
+                 "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                 "f 1/1 2/2 3/3 4/4\n")
+    m = native.Mesh.load(p)
+    assert m.vertices.shape == (4, 3) and m.faces.tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert np.allclose(m.normals, [[0, 0, 1]] * 4)                  # no vn in the file: recompute_vertex_normals (:339-341)
+    assert native.Mesh.load(p, face_normals=True).normals is None   # m_disable_vertex_normals
+    p2 = tmp_path / "tri.obj"
+    p2.write_text("v 0 0 0\nv 2 0 0\nv 0 2 0\nvn 0 0 1\nvn 0 1 0\n"
+                  "f 1//1 2//1 3//1\nf 3//2 2//2 1//2\nf 1//1 2//1 3//1\n")
+    m2 = native.Mesh.load(p2, to_world=dict(origin=(0, 0, 0), target=(0, 0, 1), up=(0, 1, 0)))
+    # (position, normal) pairs: 3 with normal 1, 3 with normal 2, the last face reuses the first three ids
+    assert len(m2.vertices) == 6 and m2.faces.tolist() == [[0, 1, 2], [3, 4, 5], [0, 1, 2]]
+    assert np.allclose(np.linalg.norm(m2.normals, axis=1), 1)
+    bad = tmp_path / "bad.obj"; bad.write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(RuntimeError, match="invalid vertex"):
+        native.Mesh.load(bad)
+    with pytest.raises(RuntimeError, match="file not found"):
+        native.Mesh.load(tmp_path / "missing.obj")
+
+
+def _write_ply(path, v, f, fmt, normals=None):
+    header = ["ply", "format %s 1.0" % fmt, "comment made by tests", "element vertex %d" % len(v),
+              "property float x", "property float y", "property float z"]
+    if normals is not None:
+        header += ["property float nx", "property float ny", "property float nz"]
+    header += ["element face %d" % len(f), "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(header) + "\n").encode())
+        e = ">" if fmt == "binary_big_endian" else "<"
+        rows = v if normals is None else np.concatenate([v, normals], 1)
+        if fmt == "ascii":
+            for r in rows:
+                fh.write((" ".join(repr(float(x)) for x in r) + "\n").encode())
+            for t in f:
+                fh.write(("3 %d %d %d\n" % tuple(t)).encode())
+        else:
+            for r in rows:
+                fh.write(struct.pack(e + "%df" % len(r), *[float(x) for x in r]))
+            for t in f:
+                fh.write(struct.pack(e + "B3i", 3, *[int(x) for x in t]))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_loader_round_trip(native, tmp_path, fmt):
+    """src/shapes/ply.cpp: every encoding, stored vs computed normals, and a rendered mesh that came from a file."""
+    from mitsuba2_amd import scenes
+    v, f, n = scenes.icosphere((0.5, 0.25, -1.0), 2.0, 2)
+    p = tmp_path / "ball.ply"
+    _write_ply(p, v, f, fmt, normals=n)
+    m = native.Mesh.load(p)
+    assert np.array_equal(m.vertices, v) and np.array_equal(m.faces, f) and np.allclose(m.normals, n, atol=1e-6)
+    _write_ply(p, v, f, fmt)
+    m = native.Mesh.load(p)
+    assert np.allclose(m.normals, n, atol=2e-2)                     # computed normals of a sphere ~ radial
+    if fmt == "ascii":
+        q = tmp_path / "quad.ply"
+        q.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                     "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+        with pytest.raises(RuntimeError, match="triangle mesh"):
+            native.Mesh.load(q)
+
+
+def test_loaded_mesh_renders_like_the_in_memory_mesh(native, oracle, tmp_path):
+    """A scene built from an OBJ file renders like the same scene built from arrays: same faces in the same order
+    (=> same primitive ids); the loader re-normalises `vn` (obj.cpp:185), so shading normals differ in the last bits."""
+    from mitsuba2_amd import scenes
+    v, f, n = scenes.icosphere((185.0, 82.5, 169.0), 82.5, 1)
+    p = tmp_path / "ball.obj"
+    with open(p, "w") as fh:
+        for a in v:
+            fh.write("v %r %r %r\n" % tuple(float(x) for x in a))
+        for a in n:
+            fh.write("vn %r %r %r\n" % tuple(float(x) for x in a))
+        for t in f:
+            fh.write("f %d//%d %d//%d %d//%d\n" % tuple(int(x) + 1 for x in np.repeat(t, 2)))
+    metal = dict(distribution="ggx", alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+    films = []
+    for from_file in (False, True):
+        base = [m for m in scenes.cornell_box_meshes(True) if m.name not in ("short_block",)]
+        ball = native.Mesh.load(p, bsdf=native.BSDF("roughconductor", **metal)) if from_file else \
+            native.Mesh("ball", v, f, normals=n, bsdf=native.BSDF("roughconductor", **metal))
+        scene = native.Scene(base + [ball]).build(-1)
+        sensor = scenes.cornell_sensor(40, 32, 4)
+        job = native.PathIntegrator().render_job(sensor)
+        films.append(oracle.render(scene.desc(), job, threads=4, want_f64=False)[0])
+    assert np.allclose(films[0], films[1], rtol=2e-3, atol=1e-5) and films[0][..., 1].max() > 0
+    assert (films[0] == films[1]).mean() > 0.5
