@@ -166,6 +166,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_scene_ray_test": (i32, [vp, C.POINTER(mi_rays_soa), c_float_p, u64]),
         "mih_film_create": (vp, [vp]), "mih_film_destroy": (None, [vp]),
         "mih_film_set_filter": (i32, [vp, cp, vp]),
+        "mih_film_develop": (cp, [vp, cp]), "mih_film_set_data": (i32, [vp, c_float_p, u64]),
+        "mih_film_crop_size": (None, [vp, c_i32_p, c_i32_p]),
         "mih_film_data": (c_float_p, [vp, C.POINTER(u64)]), "mih_film_develop_rgb": (i32, [vp, c_float_p]),
         "mih_sampler_create": (vp, [vp]), "mih_sampler_destroy": (None, [vp]),
         "mih_sampler_seed": (None, [vp, u64]), "mih_sampler_next_1d": (f, [vp]),

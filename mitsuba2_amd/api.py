@@ -287,6 +287,32 @@ class Film:
             if host_lib().mih_film_set_filter(self.h, rfilter.encode(), None) != 0:
                 raise RuntimeError(_err())
 
+    def crop_size(self):
+        w, h = C.c_int32(), C.c_int32()
+        host_lib().mih_film_crop_size(self.h, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def set_data(self, xyzaw):
+        """fill the film's X, Y, Z, A, W storage (what mi_render writes)"""
+        a = np.ascontiguousarray(xyzaw, np.float32)
+        if host_lib().mih_film_set_data(self.h, _fp(a), a.size) != 0:
+            raise RuntimeError(_err())
+
+    def develop(self):
+        """HDRFilm::bitmap(): W-normalised XYZ -> linear sRGB, H x W x 3 (hdrfilm.cpp:251-322)"""
+        w, h = self.crop_size()
+        out = np.zeros((h, w, 3), np.float32)
+        if host_lib().mih_film_develop_rgb(self.h, _fp(out)) != 0:
+            raise RuntimeError(_err())
+        return out
+
+    def develop_to(self, filename):
+        """HDRFilm::set_destination_file + develop (hdrfilm.cpp:213-217,327-345) -> path of the file written"""
+        r = host_lib().mih_film_develop(self.h, str(filename).encode())
+        if not r:
+            raise RuntimeError(_err())
+        return r.decode()
+
     def data(self, shape):
         n = C.c_uint64()
         p = host_lib().mih_film_data(self.h, C.byref(n))

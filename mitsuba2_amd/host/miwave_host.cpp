@@ -19,6 +19,8 @@
 
 namespace miwave {
 
+static std::string to_lower(std::string s) { for (char &c : s) c = (char) std::tolower(c); return s; }
+
 [[noreturn]] static void Throw(const std::string &msg) { throw std::runtime_error(msg); }
 
 // ============================================================================================
@@ -304,6 +306,17 @@ Film::Film(const Properties &props) {
         m_crop_offset[0] + m_crop_size[0] > m_size[0] || m_crop_offset[1] + m_crop_size[1] > m_size[1])
         Throw("Invalid crop window specification!");
     m_filter = std::make_shared<GaussianFilter>();             // film.cpp:45-49
+    // hdrfilm.cpp:95-180: output format properties
+    m_file_format = to_lower(props.string("file_format", "openexr"));
+    m_pixel_format = to_lower(props.string("pixel_format", "rgb"));
+    m_component_format = to_lower(props.string("component_format", "float16"));
+    if (m_file_format != "openexr" && m_file_format != "exr" && m_file_format != "pfm")
+        Throw("The \"file_format\" parameter must either be equal to \"openexr\" or \"pfm\" in this layer (\"rgbe\" is not provided). Found " + m_file_format + ".");
+    if (m_pixel_format != "rgb" && m_pixel_format != "rgba")
+        Throw("The \"pixel_format\" parameter must either be equal to \"rgb\" or \"rgba\" in this layer. Found " + m_pixel_format + ".");
+    if (m_component_format != "float16" && m_component_format != "float32")
+        Throw("The \"component_format\" parameter must either be equal to \"float16\" or \"float32\". Found " + m_component_format + " instead.");
+    if (m_file_format == "pfm") { m_pixel_format = "rgb"; m_component_format = "float32"; }      // :170-180
 }
 void Film::prepare(const std::vector<std::string> &channels) {
     m_channels = channels;
@@ -319,6 +332,90 @@ std::vector<float> Film::bitmap_rgb() const {
         rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
     }
     return rgb;
+}
+
+// float32 -> IEEE half, round to nearest even (what Bitmap::convert does for component_format float16)
+static uint16_t float_to_half(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t) (sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));   // inf / nan
+    if (x >= 0x477ff000u) return (uint16_t) (sign | 0x7c00u);                                       // overflow -> inf
+    if (x < 0x33000001u) return (uint16_t) sign;                                                    // underflow -> 0
+    int e = (int) (x >> 23) - 127 + 15; uint32_t m = x & 0x7fffffu;
+    if (e <= 0) {                                              // subnormal half
+        m |= 0x800000u; int shift = 14 - e;
+        uint32_t h = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t) (sign | h);
+    }
+    uint32_t h = ((uint32_t) e << 10) | (m >> 13), rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t) (sign | h);
+}
+
+std::string Film::develop() const {
+    if (m_dest_file.empty()) Throw("Destination file not specified, cannot develop.");
+    const bool exr = m_file_format == "openexr" || m_file_format == "exr";
+    const bool rgba = m_pixel_format == "rgba";
+    std::string path = m_dest_file; const std::string ext = exr ? ".exr" : ".pfm";
+    size_t dot = path.find_last_of('.'), slash = path.find_last_of("/\\");
+    if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) path = path.substr(0, dot);
+    path += ext;
+    const int W = m_crop_size[0], H = m_crop_size[1];
+    std::vector<float> rgb = bitmap_rgb();
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) Throw("Could not open \"" + path + "\" for writing");
+    if (!exr) {                                                // PFM: "PF", bottom-to-top scanlines, little endian
+        std::fprintf(f, "PF\n%d %d\n-1.0\n", W, H);
+        for (int y = H - 1; y >= 0; --y) std::fwrite(&rgb[(size_t) y * W * 3], 4, (size_t) W * 3, f);
+        std::fclose(f);
+        return path;
+    }
+    // OpenEXR 2, single-part scanline image, no compression
+    const bool half = m_component_format != "float32";
+    const int nch = rgba ? 4 : 3; const char *names = rgba ? "ABGR" : "BGR";      // channels are stored alphabetically
+    std::vector<unsigned char> hdr;
+    auto put = [&](const void *p, size_t n) { hdr.insert(hdr.end(), (const unsigned char *) p, (const unsigned char *) p + n); };
+    auto put_str = [&](const char *s) { put(s, std::strlen(s) + 1); };
+    auto put_i32 = [&](int32_t v) { put(&v, 4); };
+    auto put_f32 = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { put_str(name); put_str(type); put_i32(size); };
+    const uint32_t magic = 20000630u, version = 2u;
+    put(&magic, 4); put(&version, 4);
+    attr("channels", "chlist", nch * 18 + 1);
+    for (int c = 0; c < nch; ++c) { char nm[2] = { names[c], 0 }; put_str(nm); put_i32(half ? 1 : 2); unsigned char z[4] = { 0, 0, 0, 0 }; put(z, 4); put_i32(1); put_i32(1); }
+    { unsigned char z = 0; put(&z, 1); }
+    attr("compression", "compression", 1); { unsigned char z = 0; put(&z, 1); }
+    attr("dataWindow", "box2i", 16); put_i32(0); put_i32(0); put_i32(W - 1); put_i32(H - 1);
+    attr("displayWindow", "box2i", 16); put_i32(0); put_i32(0); put_i32(W - 1); put_i32(H - 1);
+    attr("lineOrder", "lineOrder", 1); { unsigned char z = 0; put(&z, 1); }
+    attr("pixelAspectRatio", "float", 4); put_f32(1.f);
+    attr("screenWindowCenter", "v2f", 8); put_f32(0.f); put_f32(0.f);
+    attr("screenWindowWidth", "float", 4); put_f32(1.f);
+    { unsigned char z = 0; put(&z, 1); }
+    const size_t bpc = half ? 2 : 4, line_bytes = (size_t) W * nch * bpc;
+    std::fwrite(hdr.data(), 1, hdr.size(), f);
+    uint64_t offset = hdr.size() + (uint64_t) H * 8;
+    for (int y = 0; y < H; ++y) { std::fwrite(&offset, 8, 1, f); offset += 8 + line_bytes; }
+    std::vector<unsigned char> line(line_bytes);
+    for (int y = 0; y < H; ++y) {
+        int32_t yy = y, sz = (int32_t) line_bytes;
+        std::fwrite(&yy, 4, 1, f); std::fwrite(&sz, 4, 1, f);
+        for (int c = 0; c < nch; ++c) {
+            const char ch = names[c];
+            for (int x = 0; x < W; ++x) {
+                const size_t i = (size_t) y * W + x;
+                float v;
+                if (ch == 'A') { const float *p = &m_storage[i * 5]; v = p[4] != 0.f ? p[3] / p[4] : 0.f; }
+                else v = rgb[i * 3 + (ch == 'R' ? 0 : ch == 'G' ? 1 : 2)];
+                unsigned char *dst = &line[((size_t) c * W + x) * bpc];
+                if (half) { uint16_t h = float_to_half(v); std::memcpy(dst, &h, 2); } else std::memcpy(dst, &v, 4);
+            }
+        }
+        std::fwrite(line.data(), 1, line_bytes, f);
+    }
+    std::fclose(f);
+    return path;
 }
 
 // ============================================================================================
@@ -396,7 +493,6 @@ std::array<float, 2> IndependentSampler::next_2d() { float a = next_1d(), b = ne
 // ============================================================================================
 // Sensor
 // ============================================================================================
-static std::string to_lower(std::string s) { for (char &c : s) c = (char) std::tolower(c); return s; }
 static float rad_to_deg(float v) { return v * (180.f / MIW_PI); }
 static float deg_to_rad(float v) { return v * (MIW_PI / 180.f); }
 
@@ -1181,6 +1277,23 @@ const float *mih_film_data(void *f, uint64_t *count) {
     auto &s = ((Box<Film> *) f)->p->storage();
     if (count) *count = s.size();
     return s.data();
+}
+int mih_film_set_data(void *f, const float *xyzaw, uint64_t count) {
+    MIH_TRY
+        Film &film = *((Box<Film> *) f)->p;
+        film.prepare({ "X", "Y", "Z", "A", "W" });
+        if (count != film.storage().size()) Throw("film data size mismatch");
+        std::memcpy(film.storage().data(), xyzaw, count * sizeof(float));
+        return 0; MIH_CATCH(-1)
+}
+void mih_film_crop_size(void *f, int *w, int *h) { auto cs = ((Box<Film> *) f)->p->crop_size(); *w = cs[0]; *h = cs[1]; }
+static thread_local std::string g_develop_path;
+const char *mih_film_develop(void *f, const char *filename) {
+    MIH_TRY
+        Film &film = *((Box<Film> *) f)->p;
+        if (filename) film.set_destination_file(filename);
+        g_develop_path = film.develop();
+        return g_develop_path.c_str(); MIH_CATCH(nullptr)
 }
 int mih_film_develop_rgb(void *f, float *out) {
     MIH_TRY auto rgb = ((Box<Film> *) f)->p->bitmap_rgb(); std::memcpy(out, rgb.data(), rgb.size() * 4); return 0; MIH_CATCH(-1)

@@ -137,8 +137,14 @@ public:
     const std::vector<float> &storage() const { return m_storage; }
     // develop: divide by W, XYZ -> linear sRGB (hdrfilm.cpp:251-322, bitmap.cpp:187-188)
     std::vector<float> bitmap_rgb() const;
+    // HDRFilm::set_destination_file / develop (hdrfilm.cpp:213-217,327-345): writes bitmap() in `file_format`
+    // ("openexr" (default) / "pfm"; "rgbe" is not provided), `pixel_format` rgb or rgba, `component_format`
+    // float16 (default for OpenEXR) / float32; the extension is replaced by the format's proper one.
+    void set_destination_file(const std::string &filename) { m_dest_file = filename; }
+    std::string develop() const;                               // -> the path written
 private:
     std::array<int, 2> m_size, m_crop_size, m_crop_offset;
+    std::string m_dest_file, m_file_format = "openexr", m_pixel_format = "rgb", m_component_format = "float16";
     std::shared_ptr<ReconstructionFilter> m_filter;
     std::vector<float> m_storage;
     std::vector<std::string> m_channels;
