@@ -159,6 +159,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),
         "mih_envmap_create": (vp, [vp, u32, u32, c_float_p]), "mih_envmap_destroy": (None, [vp]),
         "mih_scene_add_envmap": (i32, [vp, vp]),
+        "mih_load_xml": (i32, [cp, i32, cp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mih_scene_create": (vp, []), "mih_scene_destroy": (None, [vp]),
         "mih_scene_add_shape": (i32, [vp, vp]), "mih_scene_build": (i32, [vp, i32, i32]),
         "mih_scene_desc": (C.POINTER(mi_scene_desc), [vp]), "mih_scene_ctx": (vp, [vp]),

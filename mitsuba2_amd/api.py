@@ -362,6 +362,38 @@ class Sensor:
             host_lib().mih_sensor_destroy(self.h); self.h = None
 
 
+def _wrap(cls, handle, **attrs):
+    obj = cls.__new__(cls)
+    obj.h = handle
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+def _load_xml(text_or_path, is_file, params):
+    hs = [C.c_void_p() for _ in range(5)]
+    ps = "\n".join("%s=%s" % (k, v) for k, v in params.items())
+    if host_lib().mih_load_xml(str(text_or_path).encode(), int(is_file), ps.encode(), *[C.byref(h) for h in hs]) != 0:
+        raise RuntimeError(_err())
+    scene = _wrap(Scene, hs[0], shapes=[], envmap=None, device=None)
+    sensor = None
+    if hs[1]:
+        sensor = _wrap(Sensor, hs[1], film=_wrap(Film, hs[2]), sampler=_wrap(Sampler, hs[3]))
+    return scene, sensor, _wrap(PathIntegrator, hs[4])
+
+
+def load_string(xml, **params):
+    """mitsuba.core.xml.load_string for the subset of host/miwave_host.h (scene, shape obj/ply/rectangle, bsdf, ref,
+    area emitter, perspective sensor + hdrfilm + independent sampler + rfilter, path integrator, $parameters).
+    -> (scene, sensor or None, integrator); call scene.build(device) before rendering."""
+    return _load_xml(xml, False, params)
+
+
+def load_file(path, **params):
+    """mitsuba.core.xml.load_file (same subset); relative mesh file names resolve against the scene file's directory."""
+    return _load_xml(path, True, params)
+
+
 class RenderJob:
     """The host-side job description (mi_render_cfg + its tables), kept alive together."""
 

@@ -41,6 +41,8 @@ struct Transform4f {
     static Transform4f scale(const Vector3f &v);                                // :176-184
     static Transform4f perspective(float fov, float near_, float far_);         // :203-219
     static Transform4f look_at(const Point3f &origin, const Point3f &target, const Vector3f &up); // :241-269
+    static Transform4f rotate(const Vector3f &axis, float angle_degrees);       // :175-178
+    static Transform4f from_matrix(const float *row_major16);                   // <matrix value="..."/>
     Transform4f operator*(const Transform4f &o) const;                          // :58-62
     Transform4f inverse() const;                                                // :64-72
     bool has_scale() const;
@@ -358,5 +360,21 @@ private:
     std::atomic<mi_ctx *> m_active_ctx{nullptr};
     mi_counters m_counters{};
 };
+
+// ---- XML scene front-end, a subset (src/libcore/xml.cpp) --------------------------
+// <scene>, <default>, $parameters (also from `params`), <shape type="obj|ply|rectangle">, <bsdf> (inline, or
+// top-level with id + <ref id=.../>), <emitter type="area|envmap">, <sensor type="perspective"> with <film>,
+// <sampler>, <rfilter> children, <integrator type="path">; values <float> <integer> <boolean> <string> <rgb>
+// <spectrum value=...>; <transform name="to_world"> of <translate> <scale> <rotate> <lookat> <matrix>.
+// Anything else throws the reference's kind of error ("unexpected ..."/"Plugin ... not found").
+struct LoadedScene {
+    std::shared_ptr<Scene> scene;
+    std::shared_ptr<PerspectiveCamera> sensor;                 // nullptr if the file has none
+    std::shared_ptr<PathIntegrator> integrator;                // default-constructed `path` if the file has none
+    std::vector<std::shared_ptr<Mesh>> shapes;
+};
+LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, std::string> &params = {},
+                            const std::string &base_dir = ".");
+LoadedScene load_xml_file(const std::string &path, const std::map<std::string, std::string> &params = {});
 
 } // namespace miwave

@@ -1,0 +1,109 @@
+"""the XML front-end subset of the host layer (src/libcore/xml.cpp)."""
+import numpy as np
+import pytest
+
+CBOX_XML = """<?xml version="1.0" encoding="utf-8"?>
+<!-- a two-wall Cornell corner written the way Mitsuba 2 scenes are -->
+<scene version="2.0.0">
+    <default name="spp" value="4"/>
+    <default name="res" value="32"/>
+    <integrator type="path">
+        <integer name="max_depth" value="$depth"/>
+        <integer name="rr_depth" value="3"/>
+    </integrator>
+    <sensor type="perspective">
+        <float name="fov" value="39.3"/>
+        <transform name="to_world">
+            <lookat origin="278, 273, -800" target="278, 273, 0" up="0, 1, 0"/>
+        </transform>
+        <sampler type="independent">
+            <integer name="sample_count" value="$spp"/>
+            <integer name="seed" value="7"/>
+        </sampler>
+        <film type="hdrfilm">
+            <integer name="width" value="$res"/>
+            <integer name="height" value="24"/>
+            <string name="component_format" value="float32"/>
+            <rfilter type="box"/>
+        </film>
+    </sensor>
+    <bsdf type="diffuse" id="white"><rgb name="reflectance" value="0.725, 0.71, 0.68"/></bsdf>
+    <bsdf type="roughconductor" id="metal">
+        <string name="distribution" value="ggx"/>
+        <float name="alpha" value="0.2"/>
+        <rgb name="eta" value="0.2, 0.92, 1.1"/>
+        <rgb name="k" value="3.9, 2.45, 2.14"/>
+    </bsdf>
+    <shape type="rectangle">                              <!-- floor -->
+        <transform name="to_world">
+            <scale x="278" y="280" z="1"/>
+            <rotate x="1" angle="-90"/>
+            <translate x="278" y="0" z="280"/>
+        </transform>
+        <ref id="white"/>
+    </shape>
+    <shape type="rectangle">                              <!-- back wall -->
+        <transform name="to_world">
+            <scale value="278"/>
+            <rotate y="1" angle="180"/>
+            <translate x="278" y="278" z="559"/>
+        </transform>
+        <ref id="metal"/>
+    </shape>
+    <shape type="obj">
+        <string name="filename" value="light.obj"/>
+        <bsdf type="diffuse"><spectrum name="reflectance" value="0"/></bsdf>
+        <emitter type="area"><rgb name="radiance" value="17, 12, 4"/></emitter>
+    </shape>
+</scene>
+"""
+
+
+def test_xml_scene_equals_the_same_scene_built_by_hand(native, oracle, tmp_path):
+    (tmp_path / "light.obj").write_text("v 343 548 227\nv 343 548 332\nv 213 548 332\nv 213 548 227\nf 4 3 2 1\n")
+    (tmp_path / "corner.xml").write_text(CBOX_XML)
+    scene, sensor, integ = native.load_file(tmp_path / "corner.xml", depth=5)
+    scene.build(-1)
+    d = scene.desc().contents
+    assert d.face_count == 6 and d.shape_count == 3 and d.emitter_count == 1 and d.bsdf_count == 3
+    job = integ.render_job(sensor)
+    assert (job.cfg.crop_w, job.cfg.crop_h, job.cfg.spp, job.cfg.max_depth, job.cfg.rr_depth, job.cfg.base_seed) == (32, 24, 4, 5, 3, 7)
+    assert abs(job.cfg.filter_radius - 0.5) < 1e-3                  # <rfilter type="box"/> (box.cpp: radius 0.5 + eps)
+    x32, _, st = oracle.render(scene.desc(), job, threads=4, want_f64=False)
+    assert st.samples == 32 * 24 * 4 and x32[..., :3].max() > 0
+
+    # the same scene through the classes
+    white = native.BSDF("diffuse", reflectance=(0.725, 0.71, 0.68))
+    metal = native.BSDF("roughconductor", distribution="ggx", alpha=0.2, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+    fl = np.asarray(scene.desc().contents.vertex_positions[:3 * 12], np.float32).reshape(12, 3)      # as transformed by the loader
+    q = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    meshes = [native.Mesh("floor", fl[0:4], q, bsdf=white), native.Mesh("back", fl[4:8], q, bsdf=metal),
+              native.Mesh("light", fl[8:12], q, bsdf=native.BSDF("diffuse", reflectance=0.0), emitter=native.AreaLight((17.0, 12.0, 4.0)))]
+    scene2 = native.Scene(meshes).build(-1)
+    film = native.Film(rfilter="box", width=32, height=24)
+    sensor2 = native.Sensor(film, native.Sampler(sample_count=4, seed=7), fov=39.3,
+                            to_world=dict(origin=(278, 273, -800), target=(278, 273, 0), up=(0, 1, 0)))
+    job2 = native.PathIntegrator(max_depth=5, rr_depth=3).render_job(sensor2)
+    y32, _, _ = oracle.render(scene2.desc(), job2, threads=4, want_f64=False)
+    assert np.array_equal(x32, y32)
+    # the floor really is the y = 0 plane spanning the room, facing up; the wall faces the camera
+    assert np.allclose(fl[0:4, 1], 0, atol=1e-4) and fl[0:4, 0].min() < 1 and fl[0:4, 0].max() > 555
+    n = np.cross(fl[1] - fl[0], fl[2] - fl[0]); assert n[1] > 0
+    nb = np.cross(fl[5] - fl[4], fl[6] - fl[4]); assert nb[2] < 0
+
+
+def test_xml_errors(native, tmp_path):
+    with pytest.raises(RuntimeError, match=r"undefined parameter \"\$depth\""):
+        native.load_string(CBOX_XML)
+    with pytest.raises(RuntimeError, match="not found"):
+        native.load_string('<scene version="2.0.0"><integrator type="volpath"/></scene>')
+    with pytest.raises(RuntimeError, match="unexpected <medium>"):
+        native.load_string('<scene version="2.0.0"><medium type="homogeneous"/></scene>')
+    with pytest.raises(RuntimeError, match="unknown object"):
+        native.load_string('<scene version="2.0.0"><shape type="rectangle"><ref id="nope"/></shape></scene>')
+    with pytest.raises(RuntimeError, match="mismatched closing tag"):
+        native.load_string('<scene version="2.0.0"><shape type="rectangle"></bsdf></scene>')
+    with pytest.raises(RuntimeError, match="true"):
+        native.load_string('<scene version="2.0.0"><shape type="rectangle"><boolean name="flip_normals" value="yes"/></shape></scene>')
+    scene, sensor, integ = native.load_string('<scene version="2.0.0"><shape type="rectangle"/></scene>')
+    assert sensor is None and integ.render_job is not None
