@@ -1467,7 +1467,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             K.n_path++; K.iterations++;
             done = end;
-            if (++launches % sync_every == 0 && done < cfg->spp) {
+            // cancel() / timeout take effect at launch granularity (the reference checks should_stop() per block)
+            if ((++launches % sync_every == 0 || cfg->timeout_s > 0.f || c->cancel.load()) && done < cfg->spp) {
                 HIP_TRY(c, hipGetLastError());
                 HIP_TRY(c, hipStreamSynchronize(s));
                 if (cfg->profile) drain_stamps();

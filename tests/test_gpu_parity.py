@@ -431,3 +431,33 @@ def test_interior_scene_crop_parity(native, oracle, quality):
     assert st == 0 and c.samples == ost.samples == 24 * 16 * 2 and c.segments == ost.segments
     assert np.array_equal(g32, o32)
     d.close()
+
+
+def test_timeout_and_cancel_return_partial_films(native, cbox):
+    """Integrator `timeout` / cancel() (integrator.cpp:34,43-45,143-146,178): render() returns false, the film holds
+    the samples finished so far, and a later render on the same objects is complete again."""
+    import threading
+    import time
+    from mitsuba2_amd import scenes, _capi
+    scene, sensor = scenes.cornell_box(256, 256, 4096, device=-1)
+    d = native.Device(0)
+    d.upload(scene.desc())
+    job = native.PathIntegrator().render_job(sensor)
+    total = 256 * 256 * 4096
+    for plan in (2, 1):
+        job.cfg.timeout_s = 0.05
+        film, st = d.render(job, plan=plan, samples_per_launch=64)
+        c = d.counters()
+        assert st == _capi.MI_ERR_CANCELLED and 0 < c.samples < total and np.isfinite(film).all() and film[..., 4].max() > 0
+        assert b"cancel" in d.L.mi_last_error(d.ctx)
+    job.cfg.timeout_s = 0.0
+    t = threading.Timer(0.05, lambda: d.L.mi_cancel(d.ctx))
+    t0 = time.time(); t.start()
+    film, st = d.render(job, plan=2, samples_per_launch=64)
+    t.join()
+    assert st == _capi.MI_ERR_CANCELLED and 0 < d.counters().samples < total and time.time() - t0 < 5.0
+    small_scene, small_sensor = cbox
+    d.upload(small_scene.desc())
+    film, st = d.render(native.PathIntegrator().render_job(small_sensor))
+    assert st == 0 and d.counters().samples == 128 * 96 * 16
+    d.close()
