@@ -137,6 +137,9 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 // smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
 // trail walk of bvh.h runs.
 #define MIW_STACK_ENTRIES 32
+#ifndef MIW_TREE_WAVES
+#define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
+#endif
 template <bool AnyHit, typename NodeAt, typename TriAt>
 __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
                                                     V3 o, V3 d, float mint, float maxt, Hit &best) {
@@ -233,12 +236,15 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
 //      max-over-lanes(candidates) times instead of 2 x tri_count.
 // Results are those of the full sweep: closest hit with ties to the smaller primitive id,
 // "any triangle passes" for S.
+// `Tiny` selects the code that is compiled in: the two-phase LDS query (tiny scenes) or the tree walks —
+// one kernel per scene class keeps each one's register budget (occupancy) to what it needs.
+template <bool Tiny>
 __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                        V3 o, float mint, V3 dE, float maxtE, bool hasE,
                                        V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
     Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
     bool occ = false;
-    if (cfg.brute && cfg.leaves) {
+    if (Tiny && cfg.leaves) {
         const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
         const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
         const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
@@ -529,8 +535,8 @@ struct QueueWork {
     }
 };
 
-template <bool UseLog>
-__global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+template <bool UseLog, bool Tiny>
+__global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_path_resident(RenderParams P, Sce
     }
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
     auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
-        trace2(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
+        trace2<Tiny>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
@@ -1451,9 +1457,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             TA.side = 16u + 2u * std::max<uint32_t>((uint32_t) cfg->filter_border, (uint32_t) floorf(cfg->filter_radius + .5f));
             TA.geom16 = (uint32_t) ((c->lds_bytes + 15) / 16);
             tile_bytes = (size_t) TA.geom16 * 16 - c->lds_bytes + (size_t) TA.side * TA.side * MIW_FILM_CHANNELS * sizeof(double);
-            if (c->lds_bytes + tile_bytes > 64 * 1024)
-                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+            if (c->lds_bytes + tile_bytes > 64 * 1024) {
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+            }
         }
+        const bool tiny = c->lds_cfg.brute != 0;
         const uint32_t sync_every = 8;
         uint32_t launches = 0;
         for (uint32_t done = 0; done < cfg->spp; ) {
@@ -1462,9 +1471,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<true>, pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
-            } else
-                MIW_TIMED(6, hipLaunchKernelGGL(k_path_resident<false>, grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+                if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else      MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+            } else if (tiny)
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, true>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+            else
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, false>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             K.n_path++; K.iterations++;
             done = end;
             // cancel() / timeout take effect at launch granularity (the reference checks should_stop() per block)
