@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank path on a box with fewer GPUs than ranks, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--shard-of", type=int, default=0, help="testing only (N = 1): render shard 0 of this many — what one rank "
+                    "of an N-GPU run executes; `value` then counts only that shard's samples")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "matball", "interior"],
@@ -87,6 +89,8 @@ def main():
     bvh = dev.counters()
     integ = api.PathIntegrator()
     integ.set_shard(rank, world)
+    if args.shard_of > 1 and world == 1:
+        integ.set_shard(0, args.shard_of)
     job = integ.render_job(sensor)
     cfg = job.cfg
     cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
@@ -130,6 +134,8 @@ def main():
 
     if rank == 0:
         total_samples = float(W) * H * SPP * args.steps
+        if args.shard_of > 1 and world == 1:
+            total_samples = float(agg["samples"])
         value = total_samples / elapsed / 1e6
         s_bar = agg["segments"] / max(agg["samples"], 1)
         # dominant kernel by summed HIP-event time (rank 0's shard)
