@@ -114,7 +114,7 @@ def main():
         step()
     sync()
     agg = dict(ms_shade=0.0, ms_tc=0.0, ms_ta=0.0, ms_film=0.0, ms_init=0.0, n_shade=0, n_tc=0, n_ta=0, segments=0, samples=0,
-               shadow=0, iters=0, ms_path=0.0, n_path=0, ms_fb=0.0, ms_fm=0.0, n_film=0)
+               shadow=0, iters=0, ms_path=0.0, n_path=0, ms_fb=0.0, ms_fm=0.0, ms_fp=0.0, n_film=0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -123,7 +123,7 @@ def main():
         agg["ms_film"] += c.ms_resolve; agg["ms_init"] += c.ms_init
         agg["n_shade"] += c.n_shade; agg["n_tc"] += c.n_trace_closest; agg["n_ta"] += c.n_trace_any
         agg["segments"] += c.segments; agg["samples"] += c.samples; agg["shadow"] += c.shadow_rays; agg["iters"] += c.iterations
-        agg["ms_path"] += c.ms_path; agg["n_path"] += c.n_path; agg["ms_fb"] += c.ms_film_blocks; agg["ms_fm"] += c.ms_film_merge
+        agg["ms_path"] += c.ms_path; agg["n_path"] += c.n_path; agg["ms_fb"] += c.ms_film_blocks; agg["ms_fm"] += c.ms_film_merge; agg["ms_fp"] += c.ms_film_pack
         agg["n_film"] += 1
     sync()
     elapsed = time.perf_counter() - t0
@@ -169,7 +169,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
                 "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
-                                  k_film_merge=round(agg["ms_fm"], 3), k_init=round(agg["ms_init"], 3)),
+                                  k_film_merge=round(agg["ms_fm"], 3), k_film_pack=round(agg["ms_fp"], 3), k_init=round(agg["ms_init"], 3)),
                 "segments_per_sample": s_bar,
                 "pipeline_alg_bytes_per_sample": b_alg,
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),

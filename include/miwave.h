@@ -185,6 +185,7 @@ typedef struct {
     double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
     uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran the device LBVH builder    */
     uint32_t pad_;
+    double ms_film_pack;       /* film_mode 1: k_film_pack (sample records + footprint boxes), part of ms_resolve */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

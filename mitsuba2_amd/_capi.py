@@ -79,7 +79,7 @@ class mi_counters(C.Structure):
                 ("bvh_depth", C.c_uint32), ("film_mode", C.c_uint32), ("plan", C.c_uint32),
                 ("ms_path", C.c_double), ("n_path", C.c_uint64),
                 ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double),
-                ("bvh_on_device", C.c_uint32), ("pad_", C.c_uint32)]
+                ("bvh_on_device", C.c_uint32), ("pad_", C.c_uint32), ("ms_film_pack", C.c_double)]
 
 
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4

@@ -731,6 +731,218 @@ __global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A
     }
 }
 
+// ---- fast form of step 1 for filters whose footprint is at most 4 x 4 texels (radius <= 2: box, tent,
+// gaussian, mitchell, catmullrom) and blocks of at most 127 bordered texels a side ----
+//
+// k_film_blocks spends one wave-iteration of all 64 texel lanes on every sample of every pixel in reach of
+// the 8x8 patch (144 pixels for 64 texels), although a sample touches 16 texels: 6 % of the lane-iterations add
+// anything. The fast form splits the work in two:
+//   k_film_pack   once per SAMPLE: everything ImageBlock::put derives from the position alone (lo, the clipped
+//                 extent, the discretised weight indices, imageblock.cpp:114-146) is packed into the 8 bytes the
+//                 position occupied in the log: per axis lo (7 bits) | extent (3) | 4 x LUT index (5 each).
+//                 The same pass records, per pixel, the union of its samples' footprints (block texels).
+//   k_film_groups once per (texel GROUP, sample): a wavefront still owns an 8x8 patch, one texel per lane,
+//                 accumulators in registers, but its lanes form independent groups of GW x GH texels. Each
+//                 group walks ITS OWN Morton-ordered list of the pixels whose footprint union overlaps the
+//                 group (25 pixels for a 2x2 group instead of 144), so one wave-iteration serves 64 / (GW*GH)
+//                 (group, sample) pairs; a lane decodes the packed record with a handful of integer ops.
+//                 Sample runs are staged through LDS with coalesced loads, 16 samples per group at a time.
+// Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order,
+// each pixel's samples front to back), so the tiles are bit-identical to k_film_blocks'.
+#define MIW_PK_LO_BITS 7
+#define MIW_PK_MAX_SIDE 127
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+
+// one wavefront per pixel (lane i = samples i, i + 64, ...); boxes[lane] = min lo_x | max hi_x << 8 | min lo_y << 16 | max hi_y << 24
+template <bool wide>
+__global__ __launch_bounds__(256) void k_film_pack(FilmRec F, BlockReplayArgs A, uint32_t n_lanes, uint32_t *boxes) {
+    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+    if (lane >= n_lanes) return;
+    const uint32_t tile = lane >> A.bs2_log2, q = lane & ((1u << A.bs2_log2) - 1u);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    uint32_t x, y;
+    morton_decode2(q, x, y);
+    uint32_t count = A.st[lane].w;
+    if ((int) x >= g.bw || (int) y >= g.bh) count = 0;
+    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
+    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
+    if (n > 4) n = 4;
+    uint2 *recs = reinterpret_cast<uint2 *>(const_cast<F2 *>(A.log_pos)) + (size_t) lane * A.spp;
+    uint32_t min_x = 127u, max_x = 0u, min_y = 127u, max_y = 0u;
+    for (uint32_t j = l; j < count; j += 64u) {
+        const F2 p = A.log_pos[(size_t) lane * A.spp + j];
+        uint32_t w0 = 0u, w1 = 0u;
+        if (p.x == p.x) {                                    // not a rejected sample (imageblock.cpp:98-108)
+            const float posx = p.x - kx, posy = p.y - ky;                            // :114
+            int lo_x, lo_y, nx, ny;
+            if (wide) {
+                lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
+                if (lo_x < 0) lo_x = 0;
+                if (lo_y < 0) lo_y = 0;
+                int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
+                if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
+                if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
+                nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;
+                if (nx > n) nx = n;
+                if (ny > n) ny = n;
+                if (nx < 0) nx = 0;
+                if (ny < 0) ny = 0;
+                const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n) {
+                        int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
+                            iy = (int) abs_((base_y + (float) i) * F.scale_factor);
+                        if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
+                        if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
+                        w0 |= (uint32_t) ix << (10 + 5 * i); w1 |= (uint32_t) iy << (10 + 5 * i);
+                    }
+                }
+            } else {                                         // box filter, :163-170: one texel, weight 1
+                lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
+                const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
+                nx = ny = in ? 1 : 0;
+                if (!in) lo_x = lo_y = 0;
+            }
+            if (nx == 0 || ny == 0) { nx = ny = 0; lo_x = lo_y = 0; w0 = w1 = 0u; }
+            else {
+                min_x = min(min_x, (uint32_t) lo_x); max_x = max(max_x, (uint32_t) (lo_x + nx - 1));
+                min_y = min(min_y, (uint32_t) lo_y); max_y = max(max_y, (uint32_t) (lo_y + ny - 1));
+            }
+            w0 |= (uint32_t) lo_x | ((uint32_t) nx << MIW_PK_LO_BITS);
+            w1 |= (uint32_t) lo_y | ((uint32_t) ny << MIW_PK_LO_BITS);
+        }
+        recs[j] = make_uint2(w0, w1);
+    }
+    min_x = wave_min_u32(min_x); max_x = wave_max_u32(max_x); min_y = wave_min_u32(min_y); max_y = wave_max_u32(max_y);
+    if (l == 0) boxes[lane] = min_x | (max_x << 8) | (min_y << 16) | (max_y << 24);
+}
+
+#define MIW_FG_CHUNK 16                /* samples per group staged per trip */
+template <int GW, int GH, bool wide>
+__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, const uint32_t *boxes, float *tiles) {
+    constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group, groups, groups per patch row
+    constexpr int LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
+    static_assert(PASSES >= 1, "group too large");
+    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
+    __shared__ unsigned short s_list[NG][LCAP];
+    __shared__ uint32_t s_m[NG];
+    __shared__ uint2 s_rec[NG][MIW_FG_CHUNK + 1];
+    __shared__ float4 s_val[NG][MIW_FG_CHUNK + 1];
+    const uint32_t l = threadIdx.x;
+    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
+    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
+    const uint32_t h = l / GL, li = l % GL;
+    const int tx = ptx0 + (int) (h % GPX) * GW + (int) (li % GW), ty = pty0 + (int) (h / GPX) * GH + (int) (li / GW);
+    if (l < MIW_FILTER_RESOLUTION + 1) s_lut[l] = F.lut[l];
+
+    // ---- per group: the pixels whose footprint union overlaps the group, in Morton order ----
+    const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
+    uint32_t fill[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) fill[i] = 0;
+    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
+        const uint32_t q = q0 + l;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        uint32_t box = 127u | (127u << 16);                  // empty
+        if (q < bs2 && (int) x < g.bw && (int) y < g.bh) box = boxes[lane0 + q];
+        const int bx0 = (int) (box & 255u), bx1 = (int) ((box >> 8) & 255u), by0 = (int) ((box >> 16) & 255u), by1 = (int) (box >> 24);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int gx0 = ptx0 + (i % GPX) * GW, gy0 = pty0 + (i / GPX) * GH;
+            // window of k_film_blocks (bounds the list) and the exact footprint test
+            const bool in = (int) x >= gx0 - F.border - PA.reach && (int) x <= gx0 + GW - 1 - F.border + PA.reach &&
+                            (int) y >= gy0 - F.border - PA.reach && (int) y <= gy0 + GH - 1 - F.border + PA.reach &&
+                            bx0 <= gx0 + GW - 1 && bx1 >= gx0 && by0 <= gy0 + GH - 1 && by1 >= gy0;
+            const unsigned long long m = __ballot(in);
+            if (in) {
+                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
+                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
+            }
+            fill[i] += (uint32_t) __popcll(m);
+        }
+    }
+    uint32_t max_m = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
+        if (l == 0) s_m[i] = m;
+        max_m = m > max_m ? m : max_m;
+    }
+    __syncthreads();
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+    const uint2 *recs = reinterpret_cast<const uint2 *>(A.log_pos);
+    const uint32_t my_m = s_m[h];
+    for (uint32_t k = 0; k < max_m; ++k) {
+        // staging rows of this step: pass i loads group i * 4 + l / 16, sample l % 16
+        size_t row[PASSES]; uint32_t cnt[PASSES];
+        uint32_t step_max = 0;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
+            cnt[i] = 0; row[i] = 0;
+            if (k < s_m[hs]) {
+                const uint32_t lane = lane0 + s_list[hs][k];
+                cnt[i] = A.st[lane].w; row[i] = (size_t) lane * A.spp;
+            }
+            step_max = cnt[i] > step_max ? cnt[i] : step_max;
+        }
+        step_max = wave_max_u32(step_max);
+        (void) my_m;
+        // the next chunk's loads are in flight while the current one is replayed
+        const uint32_t jj = l & 15u;
+        uint2 nr[PASSES]; float4 nv[PASSES];
+        auto fetch = [&](uint32_t j0) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                nr[i] = make_uint2(0u, 0u); nv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + jj < cnt[i]) {
+                    nr[i] = recs[row[i] + j0 + jj];
+                    const F4 t = A.log_val[row[i] + j0 + jj];
+                    nv[i] = make_float4(t.x, t.y, t.z, t.w);
+                }
+            }
+        };
+        fetch(0);
+        for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
+                s_rec[hs][jj] = nr[i]; s_val[hs][jj] = nv[i];
+            }
+            if (j0 + MIW_FG_CHUNK < step_max) fetch(j0 + MIW_FG_CHUNK);
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < MIW_FG_CHUNK; ++s) {
+                const uint2 r = s_rec[h][s];
+                const float4 v = s_val[h][s];
+                const int xr = tx - (int) (r.x & 127u), yr = ty - (int) (r.y & 127u);
+                const bool hit = (uint32_t) xr < ((r.x >> MIW_PK_LO_BITS) & 7u) && (uint32_t) yr < ((r.y >> MIW_PK_LO_BITS) & 7u);
+                float w = 1.f;
+                if (wide) w = s_lut[(r.y >> (10 + 5 * (yr & 3))) & 31u] * s_lut[(r.x >> (10 + 5 * (xr & 3))) & 31u];   // wy * wx, :155
+                if (hit) { acc0 += v.x * w; acc1 += v.y * w; acc2 += v.z * w; acc3 += v.w * w; acc4 += w; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tx < g.size_x && ty < g.size_y) {
+        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
+    }
+}
+
 // step 2: every film texel sums the block tiles covering it, ascending block id
 __global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64) {
     int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;
@@ -893,7 +1105,7 @@ struct mi_ctx {
     DevBuf<F4> q_tp, q_res, q_ray_o, q_ray_d, q_hit, q_sh_d, q_sh_c;
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
-    DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;
+    DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val; DevBuf<uint32_t> d_boxes;
     DevBuf<uint32_t> d_next_pixel; int cu_count = 256;
     DevBuf<uint32_t> d_lists, d_list_counts;    // wavefront plan: 2 parities x WL_LISTS lists / counters
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
@@ -952,7 +1164,7 @@ void mi_destroy(mi_ctx *c) {
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
-    c->q_log_pos.release(); c->q_log_val.release(); c->d_block_tile.release(); c->d_tiles.release();
+    c->q_log_pos.release(); c->q_log_val.release(); c->d_boxes.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
@@ -1383,7 +1595,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
-    K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = 0;
+    K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
     K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0;
 
     // event pool for per-launch timing
@@ -1411,6 +1623,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 case 6: K.ms_path += ms; break;
                 case 4: K.ms_film_blocks += ms; K.ms_resolve += ms; break;
                 case 5: K.ms_film_merge += ms; K.ms_resolve += ms; break;
+                case 7: K.ms_film_pack += ms; K.ms_resolve += ms; break;
                 default: K.ms_resolve += ms; break;
             }
         }
@@ -1574,7 +1787,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 PA.patches_x = PA.patches_y = (side + MIW_FP_SIDE - 1) / MIW_FP_SIDE;
                 PA.reach = (int32_t) floorf(cfg->filter_radius + .5f);
                 const dim3 fgrid(n_tiles * PA.patches_x * PA.patches_y);
-                if (cfg->filter_radius > 0.5f + MIW_RAY_EPSILON)
+                const bool wide = cfg->filter_radius > 0.5f + MIW_RAY_EPSILON;
+                // footprints of at most 4 x 4 texels: packed records + per-group pixel lists (k_film_pack / k_film_groups)
+                // group shape: 2x2 reads 6.25 sample rows per texel (HBM-bound, 50 ms on C2), 4x4 spends 0.77 wave-iterations
+                // per sample (VALU-bound, 45 ms); 4x2 balances the two (41 ms). MIW_FILM_GROUP = 0 | 2 | 3 | 4 overrides.
+                int group = 3;
+                if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
+                const bool packed = group > 0 && side <= MIW_PK_MAX_SIDE && PA.reach <= 2 &&
+                                    (!wide || ceil2int((cfg->filter_radius - 2.f * MIW_RAY_EPSILON) * 2.f) <= 4);
+                if (packed) {
+                    HIP_TRY(c, c->d_boxes.resize(nl));
+                    const dim3 kgrid((unsigned) ((n_lanes + 3) / 4));
+                    if (wide) MIW_TIMED(7, hipLaunchKernelGGL(k_film_pack<true>, kgrid, dim3(256), 0, s, P.film, A, (uint32_t) n_lanes, c->d_boxes.p));
+                    else      MIW_TIMED(7, hipLaunchKernelGGL(k_film_pack<false>, kgrid, dim3(256), 0, s, P.film, A, (uint32_t) n_lanes, c->d_boxes.p));
+#define MIW_FG_LAUNCH(GW, GH) \
+                    do { if (wide) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH, true>), fgrid, dim3(64), 0, s, P.film, A, PA, c->d_boxes.p, c->d_tiles.p)); \
+                         else      MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH, false>), fgrid, dim3(64), 0, s, P.film, A, PA, c->d_boxes.p, c->d_tiles.p)); } while (0)
+                    if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 3) MIW_FG_LAUNCH(4, 2); else MIW_FG_LAUNCH(2, 2);
+#undef MIW_FG_LAUNCH
+                } else if (wide)
                     MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
                 else
                     MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<false>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
