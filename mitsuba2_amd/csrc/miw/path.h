@@ -396,6 +396,9 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 // store(st) publishes a pixel's state when its run is over, put(...) is block->put(). A lane that
 // finishes a pixel fetches the next one INSIDE the iteration loop, so the other lanes of its wavefront
 // never wait for it (the device feeds lanes from one shared queue; the CPU checker hands out one pixel).
+#ifndef MIW_SECTION
+#define MIW_SECTION(i) do { } while (0)      /* section clock of debug builds (miwave.hip) */
+#endif
 template <typename Work, typename Trace2>
 MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                 Trace2 trace2, Counters *cnt_local) {
@@ -418,8 +421,10 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
             L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
             L.sample_idx = st.w; L.flags = 0;
             lane_begin_sample(P, pixel, L, sample_end);
+            MIW_SECTION(0);
             continue;
         }
+        MIW_SECTION(0);
         const V3 o = L.ray.o;
         F4 h; bool occluded = false;
         trace2(o, L.ray.mint, L.ray.d, L.ray.maxt, !dead_pending, sh.d, sh.maxt, sh.has, h, occluded);
@@ -428,6 +433,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
         int r = STEP_FINISHED;
         if (!dead_pending) {
             r = path_step(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
+            MIW_SECTION(4);
             if (r == STEP_DEAD_PENDING) { dead_pending = true; continue; }   // one more pass for its shadow ray
             if (r == STEP_CONTINUE) continue;
         }
@@ -436,6 +442,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
         lane_begin_sample(P, pixel, L, sample_end);
+        MIW_SECTION(5);
     }
 }
 

@@ -25,6 +25,16 @@
 #include <algorithm>
 
 #include "../../include/miwave.h"
+// Section clock (debug builds, -DMIW_SECTION_PROFILE=1): wall cycles per wavefront between markers, summed
+// into g_sections and printed by mi_render when MIW_DEBUG is set. Not compiled into the product library.
+#if defined(MIW_SECTION_PROFILE)
+__device__ unsigned long long g_sections[16];
+#endif
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsigned long long b[4][16]; return &b[threadIdx.x >> 6][0]; }
+#define MIW_SECTION(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); unsigned long long *b_ = miw_sec_buf(); \
+        if ((threadIdx.x & 63u) == (unsigned) __ffsll((long long) __ballot(1)) - 1u) { b_[i] += now_ - b_[15]; b_[15] = now_; } } while (0)
+#endif
 #include "miw/base.h"
 #include "miw/rng.h"
 #include "miw/warp.h"
@@ -259,6 +269,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         }
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
+        MIW_SECTION(1);
         while (mE != 0ull) {                                   // closest hit of E over its candidates
             const uint32_t i = (uint32_t) __ffsll((long long) mE) - 1u;
             mE &= mE - 1ull;
@@ -267,6 +278,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
             if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
                 (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
         }
+        MIW_SECTION(2);
         while (mS != 0ull) {                                   // any hit of S
             const uint32_t i = (uint32_t) __ffsll((long long) mS) - 1u;
             mS &= mS - 1ull;
@@ -274,6 +286,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
             float t, u, v;
             if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) { occ = true; mS = 0ull; }
         }
+        MIW_SECTION(3);
     } else {
         if (hasE) trace_one<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
         if (hasS) { Hit hs; occ = trace_one<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
@@ -540,6 +553,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
+#endif
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     // workgroup film tile
     double *tile = reinterpret_cast<double *>(smem + T.geom16);
@@ -595,6 +611,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
         if (a) atomicAdd(&shard->segments, a);
         if (b) atomicAdd(&shard->samples, b);
         if (c) atomicAdd(&shard->shadow_rays, c);
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) if (b_[i]) atomicAdd(&g_sections[i], b_[i]); }
+#endif
     }
 }
 
@@ -1704,6 +1723,19 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         Counters sum;
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
+#if defined(MIW_SECTION_PROFILE)
+        if (getenv("MIW_DEBUG")) {
+            unsigned long long sec[16];
+            if (hipMemcpyFromSymbol(sec, HIP_SYMBOL(g_sections), sizeof sec) == hipSuccess) {
+                static const char *names[6] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin" };
+                unsigned long long tot = 0;
+                for (int i = 0; i < 6; ++i) tot += sec[i];
+                for (int i = 0; i < 6; ++i) fprintf(stderr, "[miwave] section %-13s %6.2f %%\n", names[i], 100.0 * (double) sec[i] / (double) std::max<unsigned long long>(tot, 1));
+                memset(sec, 0, sizeof sec);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_sections), sec, sizeof sec);
+            }
+        }
+#endif
         if (cfg->profile) drain_stamps();
     }
 #if !MIW_SPECTRAL
