@@ -252,6 +252,13 @@ enum {
 mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
                   const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);
 
+/* Exhaustive device self-checks of leaf arithmetic whose device form differs from the host form.
+ * MI_SELFTEST_RCP: miw::rcp (v_rcp_f32 + one Newton step inside [2^-126, 2^126), IEEE division elsewhere)
+ * against the correctly rounded 1.f / x for all 2^32 float bit patterns. *mismatches = inputs whose bits differ
+ * (NaN results count as equal). */
+enum { MI_SELFTEST_RCP = 0 };
+mi_status mi_selftest(mi_ctx *ctx, int32_t which, uint64_t *mismatches);
+
 #ifdef __cplusplus
 }
 #endif

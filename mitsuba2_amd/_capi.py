@@ -89,7 +89,7 @@ MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
 MI_SYMBOLS = ["mi_spectrum_channels", "mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
-              "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval"]
+              "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval", "mi_selftest"]
 
 
 VARIANT_SUFFIX = {"scalar_rgb": "", "scalar_spectral": "_spectral"}
@@ -135,6 +135,7 @@ def load_device_lib(variant="scalar_rgb"):
     lib.mi_eval.argtypes = [vp, C.c_int32, C.POINTER(mi_render_cfg), c_float_p, C.c_int32, c_float_p, C.c_int32,
                             C.c_uint64]
     lib.mi_eval.restype = C.c_int32
+    lib.mi_selftest.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64)]; lib.mi_selftest.restype = C.c_int32
     return lib
 
 

@@ -504,6 +504,12 @@ class Device:
                                   len(a)))
         return out
 
+    def selftest(self, which=0):
+        """mi_selftest: number of inputs on which a device-specific leaf form differs from the IEEE form"""
+        bad = C.c_uint64(0)
+        self.check(self.L.mi_selftest(self.ctx, int(which), C.byref(bad)))
+        return int(bad.value)
+
     def close(self):
         if self.ctx:
             self.L.mi_destroy(self.ctx); self.ctx = C.c_void_p()

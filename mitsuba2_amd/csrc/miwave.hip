@@ -75,8 +75,8 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
 };
 
-// Padded bounding box of one BVH leaf (<= 4 consecutive triangles in leaf order), 32 B = 2 x b128.
-struct alignas(16) LeafBox { float lo[3]; uint32_t first; float hi[3]; uint32_t count; };
+// Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
+struct alignas(16) LeafBox { float lo[3]; uint32_t mask_lo; float hi[3]; uint32_t mask_hi; };   // mask: one bit per triangle of the leaf (leaf order)
 static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 
 // Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
@@ -190,28 +190,31 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
     }
 }
 
+// Tiny scenes without a candidate filter: every lane sweeps every packet — wave-uniform LDS addresses
+// (broadcast reads, no bank conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
+template <bool AnyHit>
+__device__ __forceinline__ bool trace_brute(const SceneView &sc, const uint4 *smem, V3 o, V3 d, float mint, float maxt, Hit &h) {
+    const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+    h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
+    bool any = false;
+    for (uint32_t i = 0; i < sc.tri_count; ++i) {
+        const TriPacket &k = pk[i];
+        float t, u, v;
+        bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
+        if (AnyHit) {
+            any = any || hit;
+        } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
+            h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim;
+        }
+    }
+    if (AnyHit) { if (any) { h.t = 0.f; h.tri = 0; } return any; }
+    return h.tri != MIW_MISS;
+}
+
 template <bool AnyHit>
 __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                           V3 o, V3 d, float mint, float maxt, Hit &h) {
-    if (cfg.brute) {
-        // Every lane sweeps every packet: wave-uniform LDS addresses (broadcast reads, no bank
-        // conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
-        const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
-        h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
-        bool any = false;
-        for (uint32_t i = 0; i < sc.tri_count; ++i) {
-            const TriPacket &k = pk[i];
-            float t, u, v;
-            bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
-            if (AnyHit) {
-                any = any || hit;
-            } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
-                h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim;
-            }
-        }
-        if (AnyHit) { if (any) { h.t = 0.f; h.tri = 0; } return any; }
-        return h.tri != MIW_MISS;
-    }
+    if (cfg.brute) return trace_brute<AnyHit>(sc, smem, o, d, mint, maxt, h);
     RayPrep r = ray_prepare(o, d, mint, maxt);
     const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
     const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
@@ -248,21 +251,26 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
 // "any triangle passes" for S.
 // `Tiny` selects the code that is compiled in: the two-phase LDS query (tiny scenes) or the tree walks —
 // one kernel per scene class keeps each one's register budget (occupancy) to what it needs.
-template <bool Tiny>
+template <int Tiny>
 __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                        V3 o, float mint, V3 dE, float maxtE, bool hasE,
                                        V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
     Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
     bool occ = false;
     if (Tiny && cfg.leaves) {
+        // candidate masks: 32 bits when the scene has <= 32 triangles (Tiny == 2), else 64
+        using Mask = typename std::conditional<Tiny == 2, uint32_t, unsigned long long>::type;
+        auto lowest = [](Mask m) -> uint32_t {
+            return Tiny == 2 ? (uint32_t) __ffs((int) (uint32_t) m) - 1u : (uint32_t) __ffsll((long long) m) - 1u;
+        };
         const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
         const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
         const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
         const float wideE = widen(maxtE), wideS = widen(maxtS);
-        unsigned long long mE = 0, mS = 0;
+        Mask mE = 0, mS = 0;
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
-            const unsigned long long bits = (b.count >= 64u ? ~0ull : ((1ull << b.count) - 1ull)) << b.first;
+            const Mask bits = Tiny == 2 ? (Mask) b.mask_lo : (Mask) (b.mask_lo | ((unsigned long long) b.mask_hi << 32));
             float tn;
             if (box_test_fast(b.lo, b.hi, rE, wideE, tn)) mE |= bits;
             if (box_test_fast(b.lo, b.hi, rS, wideS, tn)) mS |= bits;
@@ -270,23 +278,26 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
         MIW_SECTION(1);
-        while (mE != 0ull) {                                   // closest hit of E over its candidates
-            const uint32_t i = (uint32_t) __ffsll((long long) mE) - 1u;
-            mE &= mE - 1ull;
+        while (mE != 0) {                                      // closest hit of E over its candidates
+            const uint32_t i = lowest(mE);
+            mE &= mE - 1;
             const TriPacket &k = pk[i];
             float t, u, v;
             if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
                 (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
         }
         MIW_SECTION(2);
-        while (mS != 0ull) {                                   // any hit of S
-            const uint32_t i = (uint32_t) __ffsll((long long) mS) - 1u;
-            mS &= mS - 1ull;
+        while (mS != 0) {                                      // any hit of S
+            const uint32_t i = lowest(mS);
+            mS &= mS - 1;
             const TriPacket &k = pk[i];
             float t, u, v;
-            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) { occ = true; mS = 0ull; }
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) { occ = true; mS = 0; }
         }
         MIW_SECTION(3);
+    } else if (Tiny) {                                         // tiny scene, filter switched off (MI_BVH_NO_LEAF_FILTER)
+        if (hasE) trace_brute<false>(sc, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_brute<true>(sc, smem, o, dS, mint, maxtS, hs); }
     } else {
         if (hasE) trace_one<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
         if (hasS) { Hit hs; occ = trace_one<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
@@ -548,7 +559,7 @@ struct QueueWork {
     }
 };
 
-template <bool UseLog, bool Tiny>
+template <bool UseLog, int Tiny>
 __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -1447,7 +1458,9 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         auto add_leaf = [&](const float *lo, const float *hi, int32_t child) {
             if (child >= 0 || !(lo[0] <= hi[0])) return;          // inner node, or absent child (inverted box)
             const uint32_t code = (uint32_t) ~child;
-            LeafBox b; memcpy(b.lo, lo, 12); memcpy(b.hi, hi, 12); b.first = code >> 4; b.count = (code & 15u) + 1u;
+            const uint32_t first = code >> 4, count = (code & 15u) + 1u;
+            const unsigned long long bits = (count >= 64u ? ~0ull : ((1ull << count) - 1ull)) << first;
+            LeafBox b; memcpy(b.lo, lo, 12); memcpy(b.hi, hi, 12); b.mask_lo = (uint32_t) bits; b.mask_hi = (uint32_t) (bits >> 32);
             leaves.push_back(b);
         };
         for (const BvhNode &n : r.nodes) { add_leaf(n.lo0, n.hi0, n.child0); add_leaf(n.lo1, n.hi1, n.child1); }
@@ -1690,8 +1703,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             TA.geom16 = (uint32_t) ((c->lds_bytes + 15) / 16);
             tile_bytes = (size_t) TA.geom16 * 16 - c->lds_bytes + (size_t) TA.side * TA.side * MIW_FILM_CHANNELS * sizeof(double);
             if (c->lds_bytes + tile_bytes > 64 * 1024) {
-                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
-                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
             }
         }
         const bool tiny = c->lds_cfg.brute != 0;
@@ -1703,12 +1716,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
-                if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
-                else      MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                if (tiny && c->view.tri_count <= 32u)   // 32-bit candidate masks
+                          MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 2>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else      MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
             } else if (tiny)
-                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, true>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             else
-                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, false>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 0>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             K.n_path++; K.iterations++;
             done = end;
             // cancel() / timeout take effect at launch granularity (the reference checks should_stop() per block)
@@ -1883,6 +1898,37 @@ mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * os * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     din.release(); dout.release();
+    return MI_OK;
+}
+
+// ---- mi_selftest -------------------------------------------------------------------------
+__global__ void k_selftest_rcp(unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = u2f((uint32_t) i);
+        volatile float one = 1.f;                               // keeps the division a division
+        const float ref = one / x, got = miw::rcp(x);
+        if (f2u(ref) != f2u(got) && !(ref != ref && got != got)) ++bad;
+    }
+    bad = wave_sum(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
+mi_status mi_selftest(mi_ctx *c, int32_t which, uint64_t *mismatches) {
+    if (!c || !mismatches) return MI_ERR_INVALID;
+    if (which != MI_SELFTEST_RCP) return fail(c, MI_ERR_INVALID, "mi_selftest: unknown test %d", which);
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<unsigned long long> d;
+    HIP_TRY(c, d.resize(1));
+    HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, c->stream, d.p);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, d.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mismatches = h;
+    d.release();
     return MI_OK;
 }
 

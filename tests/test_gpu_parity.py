@@ -45,6 +45,12 @@ def _rays_for(sensor, w, h, n, seed=1):
     return rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7]
 
 
+def test_rcp_exhaustive(native, dev):
+    """miw::rcp on the device (v_rcp_f32 + one Newton step inside [2^-126, 2^126), IEEE division elsewhere)
+    must be the correctly rounded 1/x for all 2^32 float bit patterns (base.h)."""
+    assert dev.selftest(0) == 0
+
+
 def test_fp_semantics_match_host(native, oracle, dev):
     """+,*,/,sqrt,fma,rcp,min,max incl. denormal / inf / signed-zero inputs: identical bits."""
     rng = np.random.default_rng(3)
