@@ -21,7 +21,7 @@ class mi_texture(C.Structure):
 
 class mi_bsdf(C.Structure):
     _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("params", C.c_float * 14),
-                ("tex", mi_texture * 3), ("pad", C.c_uint32)]
+                ("tex", mi_texture * 3), ("back", C.c_uint32)]
 
 
 class mi_shape(C.Structure):
@@ -149,7 +149,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),
         "mih_props_set_color": (None, [vp, cp, f, f, f]),
         "mih_props_set_lookat": (None, [vp, cp, c_float_p, c_float_p, c_float_p]),
-        "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]),
+        "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]), "mih_bsdf_create_twosided": (vp, [vp, vp]),
+        "mih_fresnel_diffuse_reflectance": (C.c_float, [C.c_float]),
         "mih_bsdf_record": (i32, [vp, C.POINTER(mi_bsdf)]), "mih_bsdf_flags": (u32, [vp]),
         "mih_bsdf_sample": (i32, [vp, c_float_p, f, c_float_p, c_float_p]),
         "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),

@@ -121,6 +121,19 @@ class BSDF:
             host_lib().mih_bsdf_destroy(self.h); self.h = None
 
 
+class TwoSided(BSDF):
+    """<bsdf type="twosided">: `front` on both sides, or `front` / `back` (src/bsdfs/twosided.cpp)"""
+    def __init__(self, front, back=None):
+        self._front, self._back = front, back            # keep the nested handles alive
+        self.h = host_lib().mih_bsdf_create_twosided(front.h, back.h if back is not None else None)
+        if not self.h:
+            raise RuntimeError(_err())
+
+
+def fresnel_diffuse_reflectance(eta):
+    return float(host_lib().mih_fresnel_diffuse_reflectance(float(eta)))
+
+
 class AreaLight:
     def __init__(self, radiance):
         self._p = Properties("area", radiance=tuple(radiance))

@@ -1,8 +1,10 @@
 // BSDF kernels on the path: smooth diffuse, smooth dielectric, rough conductor
-// (GGX / Beckmann microfacet with visible-normal sampling), plus Fresnel terms.
+// (GGX / Beckmann microfacet with visible-normal sampling), smooth conductor, smooth plastic,
+// the two-sided adapter, plus Fresnel terms.
 //
 // Follows: src/bsdfs/diffuse.cpp:78-135, src/bsdfs/dielectric.cpp:201-320,
-// src/bsdfs/roughconductor.cpp:196-382, include/mitsuba/render/microfacet.h:184-418,
+// src/bsdfs/roughconductor.cpp:196-382, src/bsdfs/conductor.cpp:202-261, src/bsdfs/plastic.cpp:176-301,
+// src/bsdfs/twosided.cpp:94-172, include/mitsuba/render/microfacet.h:184-418,
 // include/mitsuba/render/fresnel.h:34-116,275-294.
 // Unpolarized RGB only (the scalar_rgb variant); TransportMode::Radiance.
 #pragma once
@@ -22,7 +24,11 @@ enum : uint32_t {
     BSDF_Delta  = 0x00001 | 0x00020 | 0x00040,
 };
 
-enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2 };
+enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2,
+                  BSDF_TYPE_CONDUCTOR = 3, BSDF_TYPE_PLASTIC = 4, BSDF_TYPE_COUNT = 5 };
+// record flag bits: 0-1 belong to the type (roughconductor: GGX, sample_visible; plastic: nonlinear, has
+// specular_reflectance); bit 8 marks a record wrapped by the twosided adapter, whose back side is record `back`
+enum : uint32_t { BSDF_REC_TWOSIDED = 0x100u };
 enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
 
 // 128-byte material record (host fills it from the plugin's Properties). Scalars in p[], the
@@ -31,16 +37,30 @@ enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
 //   dielectric:     p[0] eta (= int_ior/ext_ior), tex[0] specular_reflectance, tex[1] specular_transmittance
 //   roughconductor: p[0] alpha_u, p[1] alpha_v, tex[0] eta, tex[1] k, tex[2] specular_reflectance;
 //                   flags bit0 = GGX, bit1 = sample_visible
+//   conductor:      tex[0] eta, tex[1] k, tex[2] specular_reflectance
+//   plastic:        p[0] eta, p[1] 1/eta^2, p[2] fdr_int, p[3] specular_sampling_weight (plastic.cpp:163-174),
+//                   tex[0] diffuse_reflectance, tex[1] specular_reflectance; flags bit0 = nonlinear,
+//                   bit1 = specular_reflectance given
+//   twosided:       the FRONT record with BSDF_REC_TWOSIDED set; `back` = table index of the back side's record
 // (scalar_rgb callers may fill only p[] in the legacy layout — diffuse p[0..2]; dielectric p[1..3],
 //  p[4..6]; roughconductor p[2..4], p[5..7], p[8..10] — the uploader derives the TEX_RGB records.)
-struct BsdfRec { uint32_t type, flags; float p[14]; TexRec tex[3]; uint32_t pad; };
+struct BsdfRec { uint32_t type, flags; float p[14]; TexRec tex[3]; uint32_t back; };
 
 struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
 
+// texture slots a record of this type reads
+MIW_HD uint32_t bsdf_tex_slots(uint32_t type) {
+    return type == BSDF_TYPE_DIFFUSE ? 1u : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_PLASTIC) ? 2u : 3u;
+}
+
 MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
-    return b.type == BSDF_TYPE_DIFFUSE ? BSDF_DiffuseReflection
-         : b.type == BSDF_TYPE_DIELECTRIC ? (BSDF_DeltaReflection | BSDF_DeltaTransmission)
-         : BSDF_GlossyReflection;
+    switch (b.type) {
+        case BSDF_TYPE_DIFFUSE:    return BSDF_DiffuseReflection;
+        case BSDF_TYPE_DIELECTRIC: return BSDF_DeltaReflection | BSDF_DeltaTransmission;
+        case BSDF_TYPE_CONDUCTOR:  return BSDF_DeltaReflection;                          // conductor.cpp:202
+        case BSDF_TYPE_PLASTIC:    return BSDF_DeltaReflection | BSDF_DiffuseReflection; // plastic.cpp:156-158
+        default:                   return BSDF_GlossyReflection;
+    }
 }
 
 // ---- Fresnel ---------------------------------------------------------------------
@@ -322,12 +342,100 @@ MIW_HD float roughconductor_pdf(const BsdfRec &b, V3 wi, V3 wo) {
     return result;
 }
 
+// ---- SmoothConductor (conductor.cpp:217-261, unpolarized branch :253-255) ---------------
+MIW_HD Spec conductor_sample(const BsdfRec &b, V3 wi, BSDFSample &bs, const Wavelengths &wl) {
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    float cos_theta_i = wi.z;
+    if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :223-229
+    bs.sampled_type = BSDF_DeltaReflection;
+    bs.wo = reflect(wi);
+    bs.eta = 1.f;
+    bs.pdf = 1.f;
+    return tex_eval(b.tex[2], wl) * rc_fresnel(b, cos_theta_i, wl);   // :254
+}
+
+// ---- SmoothPlastic (plastic.cpp) ---------------------------------------------------------
+MIW_HD float plastic_fresnel(float cos_theta, float eta) {
+    float r, ct, a, c;
+    fresnel(cos_theta, eta, r, ct, a, c);
+    return r;
+}
+// diff = diffuse_reflectance / (1 - (nonlinear ? diff * fdr_int : fdr_int)), :237-238, :264-265
+MIW_HD Spec plastic_diffuse(const BsdfRec &b, const Wavelengths &wl) {
+    Spec value = tex_eval(b.tex[0], wl);
+    const float fdr_int = b.p[2];
+    if (b.flags & 1u) {
+#if MIW_SPECTRAL
+        for (int i = 0; i < 4; ++i) value.c[i] = value.c[i] / (1.f - value.c[i] * fdr_int);
+#else
+        value = v3(value.x / (1.f - value.x * fdr_int), value.y / (1.f - value.y * fdr_int), value.z / (1.f - value.z * fdr_int));
+#endif
+    } else {
+        const float den = 1.f - fdr_int;
+#if MIW_SPECTRAL
+        for (int i = 0; i < 4; ++i) value.c[i] = value.c[i] / den;
+#else
+        value = v3(value.x / den, value.y / den, value.z / den);
+#endif
+    }
+    return value;
+}
+// :176-244 (all components enabled: the path integrator's BSDFContext)
+MIW_HD Spec plastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    float cos_theta_i = wi.z;
+    if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :187-193
+    const float eta = b.p[0], inv_eta_2 = b.p[1], ssw = b.p[3];
+    float f_i = plastic_fresnel(cos_theta_i, eta),
+          prob_specular = f_i * ssw,
+          prob_diffuse = (1.f - f_i) * (1.f - ssw);
+    prob_specular = prob_specular / (prob_specular + prob_diffuse);  // :203
+    prob_diffuse = 1.f - prob_specular;
+    bs.eta = 1.f;
+    if (sample1 < prob_specular) {                                   // :207, :213-224
+        bs.wo = reflect(wi);
+        bs.pdf = prob_specular;
+        bs.sampled_type = BSDF_DeltaReflection;
+        Spec value = spec(f_i / bs.pdf);
+        if (b.flags & 2u) value = value * tex_eval(b.tex[1], wl);
+        return value;
+    }
+    bs.wo = square_to_cosine_hemisphere(sample2);                    // :226-241
+    bs.pdf = prob_diffuse * square_to_cosine_hemisphere_pdf(bs.wo);
+    bs.sampled_type = BSDF_DiffuseReflection;
+    float f_o = plastic_fresnel(bs.wo.z, eta);
+    Spec value = plastic_diffuse(b, wl);
+    return value * (inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse);
+}
+// :246-270
+MIW_HD Spec plastic_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
+    const float eta = b.p[0], inv_eta_2 = b.p[1];
+    float f_i = plastic_fresnel(cos_theta_i, eta), f_o = plastic_fresnel(cos_theta_o, eta);
+    Spec diff = plastic_diffuse(b, wl);
+    return diff * (square_to_cosine_hemisphere_pdf(wo) * inv_eta_2 * (1.f - f_i) * (1.f - f_o));
+}
+// :272-298
+MIW_HD float plastic_pdf(const BsdfRec &b, V3 wi, V3 wo) {
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return 0.f;
+    const float eta = b.p[0], ssw = b.p[3];
+    float f_i = plastic_fresnel(cos_theta_i, eta),
+          prob_specular = f_i * ssw,
+          prob_diffuse = (1.f - f_i) * (1.f - ssw);
+    prob_diffuse = prob_diffuse / (prob_specular + prob_diffuse);
+    return square_to_cosine_hemisphere_pdf(wo) * prob_diffuse;
+}
+
 // ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
 MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, wl);
         case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, wl);
+        case BSDF_TYPE_CONDUCTOR:  return conductor_sample(b, wi, bs, wl);
+        case BSDF_TYPE_PLASTIC:    return plastic_sample(b, wi, sample1, sample2, bs, wl);
         default:                   return roughconductor_sample(b, wi, sample2, bs, wl);
     }
 }
@@ -335,6 +443,8 @@ MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, wl);
         case BSDF_TYPE_DIELECTRIC: return spec(0.f);                 // dielectric.cpp:312-315
+        case BSDF_TYPE_CONDUCTOR:  return spec(0.f);                 // conductor.cpp:263-266
+        case BSDF_TYPE_PLASTIC:    return plastic_eval(b, wi, wo, wl);
         default:                   return roughconductor_eval(b, wi, wo, wl);
     }
 }
@@ -342,8 +452,41 @@ MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_pdf(wi, wo);
         case BSDF_TYPE_DIELECTRIC: return 0.f;                       // dielectric.cpp:317-320
+        case BSDF_TYPE_CONDUCTOR:  return 0.f;                       // conductor.cpp:268-271
+        case BSDF_TYPE_PLASTIC:    return plastic_pdf(b, wi, wo);
         default:                   return roughconductor_pdf(b, wi, wo);
     }
+}
+
+// ---- TwoSidedBRDF (twosided.cpp) -------------------------------------------------------
+// A shape's BSDF as the integrator sees it: the record itself, or — for a twosided record — the front
+// record when cos(theta_i) > 0, the back record with wi (and wo) mirrored when cos(theta_i) < 0 (:105-124),
+// nothing when cos(theta_i) == 0. `flags` is BSDF::flags() of the plugin (twosided: both sides, :76-86).
+struct BsdfSide { const BsdfRec *b; bool flip, none; uint32_t flags; };
+MIW_HD BsdfSide bsdf_side(const BsdfRec *table, uint32_t index, V3 wi) {
+    BsdfSide s; s.b = table + index; s.flip = false; s.none = false; s.flags = bsdf_flags(*s.b);
+    if (s.b->flags & BSDF_REC_TWOSIDED) {
+        const BsdfRec *back = table + s.b->back;
+        s.flags |= bsdf_flags(*back);
+        if (wi.z < 0.f) { s.flip = true; s.b = back; }
+        else if (!(wi.z > 0.f)) s.none = true;
+    }
+    return s;
+}
+MIW_HD V3 bsdf_mirror(V3 w) { return v3(w.x, w.y, w.z * -1.f); }      // `wi.z() *= -1.f`
+MIW_HD Spec bsdf_side_sample(const BsdfSide &s, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+    if (s.none) { bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0; return spec(0.f); }
+    Spec v = bsdf_sample(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, wl);
+    if (s.flip) bs.wo.z *= -1.f;                                     // :121
+    return v;
+}
+MIW_HD Spec bsdf_side_eval(const BsdfSide &s, V3 wi, V3 wo, const Wavelengths &wl) {
+    if (s.none) return spec(0.f);
+    return s.flip ? bsdf_eval(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), wl) : bsdf_eval(*s.b, wi, wo, wl);
+}
+MIW_HD float bsdf_side_pdf(const BsdfSide &s, V3 wi, V3 wo) {
+    if (s.none) return 0.f;
+    return s.flip ? bsdf_pdf(*s.b, bsdf_mirror(wi), bsdf_mirror(wo)) : bsdf_pdf(*s.b, wi, wo);
 }
 
 } // namespace miw

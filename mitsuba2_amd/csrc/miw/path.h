@@ -222,7 +222,10 @@ enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
 // emitter-hit MIS term needs it). Leaves the extension ray in L.ray (maxt < 0: none).
 // Shared by every execution plan: the HBM-queue wavefront kernels (lane_shade below),
 // the register-resident kernel (k_path_resident) and the CPU checker.
-template <typename PrevO>
+// `Mats` names the BSDF plugins the scene uses, so that a kernel compiled for MATS_DIFFUSE (every shape one-sided
+// smooth diffuse: BASELINE config 2) carries no dispatch and none of the other plugins' code; MATS_ALL is the table.
+enum { MATS_ALL = 0, MATS_DIFFUSE = 1 };
+template <int Mats = MATS_ALL, typename PrevO>
 MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
                      ShadowOut &sh, Counters *cnt_local) {
     sh.has = false;
@@ -280,8 +283,10 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     if (depth >= (uint32_t) P.max_depth || !active) return STEP_FINISHED;
 
     if (cnt_local) cnt_local->segments++;
-    const BsdfRec &bsdf = sc.bsdfs[bsdf_index];
-    const uint32_t bflags = bsdf_flags(bsdf);
+    BsdfSide bsdf;                                                   // si.bsdf(ray), incl. the twosided adapter
+    if (Mats == MATS_DIFFUSE) { bsdf.b = sc.bsdfs + bsdf_index; bsdf.flip = bsdf.none = false; bsdf.flags = BSDF_DiffuseReflection; }
+    else bsdf = bsdf_side(sc.bsdfs, bsdf_index, si.wi);
+    const uint32_t bflags = bsdf.flags;
     L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
     L.ray.d = v3(0.f); L.ray.maxt = -1.f;
 
@@ -291,8 +296,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
-            Spec bsdf_val = bsdf_eval(bsdf, si.wi, wo, L.wl);
-            float bpdf = bsdf_pdf(bsdf, si.wi, wo);
+            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, L.wl) : bsdf_side_eval(bsdf, si.wi, wo, L.wl);
+            float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf(bsdf, si.wi, wo);
             float mis = mis_weight(ds.pdf, bpdf);
             Spec c = mis * L.tp * bsdf_val * emitter_val;
             if (!all_zero(c)) {
@@ -307,7 +312,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    Spec bsdf_val = bsdf_sample(bsdf, si.wi, s1, s2, bs, L.wl);
+    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, L.wl) : bsdf_side_sample(bsdf, si.wi, s1, s2, bs, L.wl);
     L.tp = L.tp * bsdf_val;
     if (all_zero(L.tp))                              // :182-184
         return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;
@@ -399,7 +404,7 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 #ifndef MIW_SECTION
 #define MIW_SECTION(i) do { } while (0)      /* section clock of debug builds (miwave.hip) */
 #endif
-template <typename Work, typename Trace2>
+template <int Mats = MATS_ALL, typename Work, typename Trace2>
 MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                 Trace2 trace2, Counters *cnt_local) {
     LaneRegs L;
@@ -432,7 +437,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
         sh.has = false;
         int r = STEP_FINISHED;
         if (!dead_pending) {
-            r = path_step(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
+            r = path_step<Mats>(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
             MIW_SECTION(4);
             if (r == STEP_DEAD_PENDING) { dead_pending = true; continue; }   // one more pass for its shadow ray
             if (r == STEP_CONTINUE) continue;

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q,
         } else {
             F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
             Q.hit[lane] = r;
-            if (hit) key = sc.bsdfs[sc.shapes[sc.tris[h.tri].shape].bsdf].type;    // material sort key
+            if (hit) { key = sc.bsdfs[sc.shapes[sc.tris[h.tri].shape].bsdf].type; if (key > 2u) key = 2u; }   // material sort key (conductor / plastic share the rough conductor's list)
         }
     }
     if (!AnyHit) {
@@ -559,7 +559,7 @@ struct QueueWork {
     }
 };
 
-template <bool UseLog, int Tiny>
+template <bool UseLog, int Tiny, int Mats = MATS_ALL>
 __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
-        pixel_stream_render(P, sc, sample_end, work, tr2, &local);
+        pixel_stream_render<Mats>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
@@ -1020,18 +1020,19 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = square_to_cosine_hemisphere_pdf(w);
         } break;
         case MI_EVAL_BSDF: {      // spectral builds: in[10..13] = wavelengths; colour outputs have MIW_SPEC_N channels
-            const BsdfRec &b = sc.bsdfs[f2u(a[0])];
+            const uint32_t b_index = f2u(a[0]);
             V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
             Wavelengths wl;
 #if MIW_SPECTRAL
             for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
 #endif
-            BSDFSample bs; Spec w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
+            const BsdfSide b = bsdf_side(sc.bsdfs, b_index, wi);
+            BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
             o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-            Spec e = bsdf_eval(b, wi, wo, wl);
+            Spec e = bsdf_side_eval(b, wi, wo, wl);
             const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
             for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
-            o[6 + 2 * MIW_SPEC_N] = bsdf_pdf(b, wi, wo);
+            o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo);
         } break;
         case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
         case MI_EVAL_CAMERA_RAY: {
@@ -1116,7 +1117,7 @@ struct mi_ctx {
     std::vector<Tri> tris_in;
     std::vector<float> tri_vn_in;       // 9 per tri or empty
     std::vector<ShapeRec> shapes;
-    std::vector<BsdfRec> bsdfs;
+    std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     bool have_scene = false, have_bvh = false;
@@ -1261,18 +1262,27 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     c->bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         const mi_bsdf &b = s->bsdfs[i];
-        if (b.type > MI_BSDF_ROUGHCONDUCTOR) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
+        if (b.type >= BSDF_TYPE_COUNT) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
         BsdfRec r; memset(&r, 0, sizeof r);
         r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
+        if (b.flags & MI_BSDF_FLAG_TWOSIDED) {                 // twosided.cpp:62-92
+            if (b.back >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "bsdf %u: back-side record %u out of range", i, b.back);
+            const uint32_t tr = BSDF_DeltaTransmission;
+            BsdfRec probe; memset(&probe, 0, sizeof probe);
+            probe.type = b.type; const uint32_t f0 = bsdf_flags(probe);
+            probe.type = s->bsdfs[b.back].type; const uint32_t f1 = probe.type < BSDF_TYPE_COUNT ? bsdf_flags(probe) : 0u;
+            if ((f0 | f1) & tr) return fail(c, MI_ERR_INVALID, "bsdf %u: only materials without a transmission component can be nested", i);
+            r.back = b.back;
+        }
 #if MIW_SPECTRAL
-        for (int k = 0; k < (int) b.type + 1; ++k) {           // slots in use: diffuse 1, dielectric 2, roughconductor 3
+        for (int k = 0; k < (int) bsdf_tex_slots(b.type); ++k) {
             if (b.tex[k].type == MI_TEX_RGB || b.tex[k].type > MI_TEX_SRGB_D65)
                 return fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: the scalar_spectral library needs a spectral texture record", i, k);
             memcpy(&r.tex[k], &b.tex[k], sizeof(TexRec));
         }
 #else
         {   // legacy RGB layout of params[] -> texture records
-            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            const int off[5][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 } };
             for (int k = 0; k < 3; ++k) {
                 r.tex[k].type = TEX_RGB;
                 if (off[b.type][k] >= 0) memcpy(r.tex[k].v, b.params + off[b.type][k], 12);
@@ -1282,6 +1292,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 #endif
         c->bsdfs[i] = r;
     }
+    c->diffuse_only = true;
+    for (const BsdfRec &r : c->bsdfs) if (r.type != BSDF_TYPE_DIFFUSE || (r.flags & BSDF_REC_TWOSIDED)) c->diffuse_only = false;
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
     c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
     bool any_emit_normals = false;
@@ -1716,10 +1728,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
-                if (tiny && c->view.tri_count <= 32u)   // 32-bit candidate masks
-                          MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 2>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
-                else if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
-                else      MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
+                // kernel variants: 32-bit candidate masks up to 32 triangles; no BSDF dispatch when every shape is plain diffuse
+                if (tiny && c->view.tri_count <= 32u) { if (c->diffuse_only) MIW_PATH_LAUNCH(2, MATS_DIFFUSE); else MIW_PATH_LAUNCH(2, MATS_ALL); }
+                else if (tiny)                        { if (c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE); else MIW_PATH_LAUNCH(1, MATS_ALL); }
+                else MIW_PATH_LAUNCH(0, MATS_ALL);
+#undef MIW_PATH_LAUNCH
             } else if (tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             else

@@ -258,6 +258,33 @@ mi_texture Properties::texture_record(const std::string &n, float def, bool with
     return t;
 }
 
+// Texture::mean() of the constant texture a property resolves to: uniform.cpp (value), srgb.cpp:52-57
+// (RGB: hmean of the colour; spectral: hmean of the model over 16 wavelengths, srgb.h:26-35).
+float Properties::texture_mean(const std::string &n, float def) const {
+    if (has_property(n)) {
+        if (const Color3f *v = prop_get<Color3f>(m_values, n)) {
+#if MIW_SPECTRAL
+            auto c = srgb_model_fetch(*v);
+            const float step = (830.f - 360.f) / 15.f;
+            float sum = 0.f;
+            for (int i = 0; i < 16; ++i) {
+                float lambda = std::fma((float) i, step, 360.f);
+                float x = std::fma(std::fma(c[0], lambda, c[1]), lambda, c[2]);
+                float r = std::isinf(c[2]) ? std::fma(c[2] < 0.f ? -1.f : 1.f, .5f, .5f)
+                                           : std::max(0.f, std::fma(.5f * x, 1.f / std::sqrt(std::fma(x, x, 1.f)), .5f));
+                sum += r;
+            }
+            return sum * (1.f / 16.f);
+#else
+            return (((*v)[0] + (*v)[1]) + (*v)[2]) * (1.f / 3.f);
+#endif
+        }
+        if (const float *v = prop_get<float>(m_values, n)) return *v;
+        Throw("The property \"" + n + "\" has the wrong type (expected <rgb> or <float>; only constant textures are supported).");
+    }
+    return def;
+}
+
 Transform4f Properties::transform(const std::string &n, const Transform4f &def) const {
     if (!has_property(n)) return def;
     const Transform4f *v = prop_get<Transform4f>(m_values, n);
@@ -595,7 +622,18 @@ float lookup_ior(const Properties &props, const std::string &name, const std::st
 }
 
 static const miw::BsdfRec &as_rec(const mi_bsdf &b) { return *reinterpret_cast<const miw::BsdfRec *>(&b); }
-uint32_t BSDF::flags() const { return miw::bsdf_flags(as_rec(m_rec)); }
+uint32_t BSDF::flags() const {
+    uint32_t f = miw::bsdf_flags(as_rec(m_rec));
+    if (m_back) f |= miw::bsdf_flags(as_rec(m_back->record()));    // twosided.cpp:76-86
+    return f;
+}
+// the plugin as the integrator sees it: a two-record table {front, back} for the twosided adapter
+namespace { struct SideTable { miw::BsdfRec t[2]; };
+SideTable side_table(const mi_bsdf &rec, const std::shared_ptr<BSDF> &back) {
+    SideTable s; s.t[0] = as_rec(rec); s.t[1] = back ? as_rec(back->record()) : as_rec(rec);
+    s.t[0].back = 1; s.t[1].flags &= ~(uint32_t) MI_BSDF_FLAG_TWOSIDED;
+    return s;
+} }
 #if MIW_SPECTRAL
 std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &, float, const std::array<float, 2> &) const {
     Throw("BSDF::sample on the host is a scalar_rgb test helper");
@@ -604,17 +642,23 @@ Color3f BSDF::eval(const Vector3f &, const Vector3f &) const { Throw("BSDF::eval
 #else
 std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &wi, float s1, const std::array<float, 2> &s2) const {
     miw::BSDFSample bs;
-    miw::V3 w = miw::bsdf_sample(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), s1, miw::v2(s2[0], s2[1]), bs, miw::Wavelengths());
+    const SideTable tab = side_table(m_rec, m_back);
+    const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
+    miw::V3 w = miw::bsdf_side_sample(miw::bsdf_side(tab.t, 0, wi_), wi_, s1, miw::v2(s2[0], s2[1]), bs, miw::Wavelengths());
     BSDFSample3f o; o.wo = { bs.wo.x, bs.wo.y, bs.wo.z }; o.pdf = bs.pdf; o.eta = bs.eta; o.sampled_type = bs.sampled_type;
     return { o, Color3f{ w.x, w.y, w.z } };
 }
 Color3f BSDF::eval(const Vector3f &wi, const Vector3f &wo) const {
-    miw::V3 v = miw::bsdf_eval(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]), miw::Wavelengths());
+    const SideTable tab = side_table(m_rec, m_back);
+    const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
+    miw::V3 v = miw::bsdf_side_eval(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]), miw::Wavelengths());
     return { v.x, v.y, v.z };
 }
 #endif
 float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
-    return miw::bsdf_pdf(as_rec(m_rec), miw::v3(wi[0], wi[1], wi[2]), miw::v3(wo[0], wo[1], wo[2]));
+    const SideTable tab = side_table(m_rec, m_back);
+    const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
+    return miw::bsdf_side_pdf(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]));
 }
 
 static void check_reflectance(const Color3f &c, const char *what) {  // src/spectra/srgb.cpp:30-31
@@ -672,6 +716,64 @@ RoughConductor::RoughConductor(const Properties &props) {
     m_rec.tex[0] = props.texture_record("eta", 0.f, false, true);    // xml.cpp is_unbounded_spectrum: eta, k
     m_rec.tex[1] = props.texture_record("k", 1.f, false, true);
     m_rec.tex[2] = props.texture_record("specular_reflectance", 1.f, false, false);
+}
+
+SmoothConductor::SmoothConductor(const Properties &props) {
+    std::string material = props.string("material", "none");
+    Color3f eta, k;
+    if (props.has_property("eta") || material == "none") {       // conductor.cpp:207-211
+        eta = props.texture("eta", 0.f); k = props.texture("k", 1.f);
+        if (material != "none") Throw("Should specify either (eta, k) or material, not both.");
+    } else {
+        Throw("complex_ior_from_file: the IOR data files are not available; specify 'eta' and 'k' explicitly.");
+    }
+    Color3f sr = props.texture("specular_reflectance", 1.f);
+    check_reflectance(sr, "specular_reflectance");
+    m_rec.type = MI_BSDF_CONDUCTOR; m_rec.flags = 0;
+    for (int i = 0; i < 3; ++i) { m_rec.params[2 + i] = eta[i]; m_rec.params[5 + i] = k[i]; m_rec.params[8 + i] = sr[i]; }
+    m_rec.tex[0] = props.texture_record("eta", 0.f, false, true);
+    m_rec.tex[1] = props.texture_record("k", 1.f, false, true);
+    m_rec.tex[2] = props.texture_record("specular_reflectance", 1.f, false, false);
+}
+// fresnel.h:327-361
+float fresnel_diffuse_reflectance(float eta) {
+    if (eta < 1.f)
+        return -1.4399f * (eta * eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
+    float inv_eta = 1.f / eta, inv_eta_2 = inv_eta * inv_eta, inv_eta_3 = inv_eta_2 * inv_eta,
+          inv_eta_4 = inv_eta_3 * inv_eta, inv_eta_5 = inv_eta_4 * inv_eta;
+    return 0.919317f - 3.4793f * inv_eta + 6.75335f * inv_eta_2 - 7.80989f * inv_eta_3 + 4.98554f * inv_eta_4 - 1.36881f * inv_eta_5;
+}
+SmoothPlastic::SmoothPlastic(const Properties &props) {
+    float int_ior = lookup_ior(props, "int_ior", "polypropylene"), ext_ior = lookup_ior(props, "ext_ior", "air");
+    if (int_ior < 0.f || ext_ior < 0.f) Throw("The interior and exterior indices of refraction must be positive!");
+    const float eta = int_ior / ext_ior;
+    Color3f dr = props.texture("diffuse_reflectance", .5f);
+    check_reflectance(dr, "diffuse_reflectance");
+    const bool has_spec = props.has_property("specular_reflectance");
+    Color3f sr = props.texture("specular_reflectance", 1.f);
+    if (has_spec) check_reflectance(sr, "specular_reflectance");
+    // parameters_changed(), plastic.cpp:163-174
+    const float d_mean = props.texture_mean("diffuse_reflectance", .5f),
+                s_mean = has_spec ? props.texture_mean("specular_reflectance", 1.f) : 1.f;
+    m_rec.type = MI_BSDF_PLASTIC;
+    m_rec.flags = (props.bool_("nonlinear", false) ? MI_BSDF_FLAG_NONLINEAR : 0) | (has_spec ? MI_BSDF_FLAG_HAS_SPECULAR : 0);
+    m_rec.params[0] = eta;
+    m_rec.params[1] = 1.f / (eta * eta);
+    m_rec.params[2] = fresnel_diffuse_reflectance(1.f / eta);
+    m_rec.params[3] = s_mean / (d_mean + s_mean);
+    for (int i = 0; i < 3; ++i) { m_rec.params[4 + i] = dr[i]; m_rec.params[7 + i] = sr[i]; }
+    m_rec.tex[0] = props.texture_record("diffuse_reflectance", .5f, false, false);
+    m_rec.tex[1] = props.texture_record("specular_reflectance", 1.f, false, false);
+}
+TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back) {
+    if (!front) Throw("A nested one-sided material is required!");
+    if (front->twosided() || (back && back->twosided())) Throw("twosided: nested twosided materials are not supported");
+    if (!back) back = front;
+    if ((front->flags() | back->flags()) & miw::BSDF_DeltaTransmission)
+        Throw("Only materials without a transmission component can be nested!");
+    m_rec = front->record();
+    m_rec.flags |= MI_BSDF_FLAG_TWOSIDED;
+    m_back = back;
 }
 
 AreaLight::AreaLight(const Properties &props) {
@@ -955,6 +1057,11 @@ void Scene::add_emitter(std::shared_ptr<EnvironmentMapEmitter> env) {
     if (m_env) Throw("Only one environment emitter can be specified per scene.");   // scene.cpp:48-49
     m_env = std::move(env); m_env_after_shapes = m_shapes.size();
 }
+// front and back of a twosided BSDF are the same material (twosided.cpp:72-73)
+static bool miw_same_record(const mi_bsdf &back, const mi_bsdf &front_twosided) {
+    mi_bsdf f = front_twosided; f.flags &= ~(uint32_t) MI_BSDF_FLAG_TWOSIDED;
+    return std::memcmp(&back, &f, sizeof f) == 0;
+}
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
                     std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
                     std::vector<mi_emitter> &erecs) {
@@ -979,7 +1086,20 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
             m->set_bsdf(b);
         }
         auto it = bsdf_index.find(b.get());
-        if (it == bsdf_index.end()) { it = bsdf_index.emplace(b.get(), (uint32_t) brecs.size()).first; brecs.push_back(b->record()); }
+        if (it == bsdf_index.end()) {
+            it = bsdf_index.emplace(b.get(), (uint32_t) brecs.size()).first;
+            brecs.push_back(b->record());
+            if (b->twosided()) {                                   // the back side's record follows (or is the front's own)
+                const uint32_t self = it->second;
+                const BSDF *back = b->back().get();
+                if (miw_same_record(back->record(), b->record())) brecs[self].back = self;
+                else {
+                    auto jt = bsdf_index.find(back);
+                    if (jt == bsdf_index.end()) { jt = bsdf_index.emplace(back, (uint32_t) brecs.size()).first; brecs.push_back(back->record()); }
+                    brecs[self].back = jt->second;
+                }
+            }
+        }
         s.bsdf = it->second;
         s.emitter = -1;
         if (m->emitter()) {
@@ -1305,13 +1425,30 @@ std::shared_ptr<BSDF> make_bsdf(const Properties &p) {
     if (t == "diffuse") return std::make_shared<SmoothDiffuse>(p);
     if (t == "dielectric") return std::make_shared<SmoothDielectric>(p);
     if (t == "roughconductor") return std::make_shared<RoughConductor>(p);
+    if (t == "conductor") return std::make_shared<SmoothConductor>(p);
+    if (t == "plastic") return std::make_shared<SmoothPlastic>(p);
     Throw("Plugin \"" + t + "\" not found!");
 }
 std::shared_ptr<BSDF> parse_bsdf(XmlCtx &cx, const XmlNode &n) {
     Properties p(cx.get(n, "type"));
     auto objs = parse_properties(cx, n, p);
-    if (!objs.empty()) Throw("Error while loading XML: unexpected <" + objs[0]->tag + "> inside <bsdf>");
-    auto b = make_bsdf(p);
+    std::shared_ptr<BSDF> b;
+    if (p.plugin_name() == "twosided") {                       // nested <bsdf> / <ref> children, twosided.cpp:63-73
+        std::vector<std::shared_ptr<BSDF>> nested;
+        for (const XmlNode *c : objs) {
+            if (c->tag == "bsdf") nested.push_back(parse_bsdf(cx, *c));
+            else if (c->tag == "ref") {
+                auto it = cx.bsdfs.find(cx.get(*c, "id"));
+                if (it == cx.bsdfs.end()) Throw("Error while loading XML: reference to unknown object \"" + cx.get(*c, "id") + "\"");
+                nested.push_back(it->second);
+            } else Throw("Error while loading XML: unexpected <" + c->tag + "> inside <bsdf>");
+        }
+        if (nested.size() > 2) Throw("At most two nested BSDFs can be specified!");
+        b = std::make_shared<TwoSidedBRDF>(nested.empty() ? nullptr : nested[0], nested.size() == 2 ? nested[1] : nullptr);
+    } else {
+        if (!objs.empty()) Throw("Error while loading XML: unexpected <" + objs[0]->tag + "> inside <bsdf>");
+        b = make_bsdf(p);
+    }
     if (n.attr.count("id")) cx.bsdfs[cx.get(n, "id")] = b;
     return b;
 }
@@ -1438,9 +1575,18 @@ void *mih_bsdf_create(void *props) {
         if (p.plugin_name() == "diffuse") b = std::make_shared<SmoothDiffuse>(p);
         else if (p.plugin_name() == "dielectric") b = std::make_shared<SmoothDielectric>(p);
         else if (p.plugin_name() == "roughconductor") b = std::make_shared<RoughConductor>(p);
+        else if (p.plugin_name() == "conductor") b = std::make_shared<SmoothConductor>(p);
+        else if (p.plugin_name() == "plastic") b = std::make_shared<SmoothPlastic>(p);
         else throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
         return new Box<BSDF>{ b }; MIH_CATCH(nullptr)
 }
+// <bsdf type="twosided">: front (and optionally back) are BSDF handles; the result is a new handle
+void *mih_bsdf_create_twosided(void *front, void *back) {
+    MIH_TRY
+        std::shared_ptr<BSDF> f = front ? ((Box<BSDF> *) front)->p : nullptr, b = back ? ((Box<BSDF> *) back)->p : nullptr;
+        return new Box<BSDF>{ std::make_shared<TwoSidedBRDF>(f, b) }; MIH_CATCH(nullptr)
+}
+float mih_fresnel_diffuse_reflectance(float eta) { return fresnel_diffuse_reflectance(eta); }
 void mih_bsdf_destroy(void *b) { delete (Box<BSDF> *) b; }
 int mih_bsdf_record(void *b, mi_bsdf *out) { *out = ((Box<BSDF> *) b)->p->record(); return 0; }
 uint32_t mih_bsdf_flags(void *b) { return ((Box<BSDF> *) b)->p->flags(); }

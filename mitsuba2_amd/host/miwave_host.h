@@ -74,6 +74,7 @@ public:
     // (properties.h:307-315; <rgb>/<spectrum value> -> srgb/uniform, xml.cpp:1073-1170)
     Color3f texture(const std::string &n, float def) const;
     Color3f texture(const std::string &n) const;
+    float texture_mean(const std::string &n, float def) const;   // Texture::mean() of that constant texture
     Transform4f transform(const std::string &n, const Transform4f &def) const;
     // The texture object an <rgb> / <spectrum value> property expands to in the compiled variant
     // (src/libcore/xml.cpp:1073-1100): srgb / srgb_d65 / uniform / d65, as a C-ABI record.
@@ -224,12 +225,21 @@ public:
     Color3f eval(const Vector3f &wi, const Vector3f &wo) const;
     float pdf(const Vector3f &wi, const Vector3f &wo) const;
     const mi_bsdf &record() const { return m_rec; }
+    // twosided adapter: the nested back-side BSDF (nullptr: not twosided; == this: same BSDF on both sides)
+    const std::shared_ptr<BSDF> &back() const { return m_back; }
+    bool twosided() const { return (m_rec.flags & MI_BSDF_FLAG_TWOSIDED) != 0; }
 protected:
     mi_bsdf m_rec{};
+    std::shared_ptr<BSDF> m_back;
 };
 class SmoothDiffuse final : public BSDF { public: explicit SmoothDiffuse(const Properties &props); };        // diffuse.cpp:72-76
 class SmoothDielectric final : public BSDF { public: explicit SmoothDielectric(const Properties &props); };  // dielectric.cpp:174-199
 class RoughConductor final : public BSDF { public: explicit RoughConductor(const Properties &props); };      // roughconductor.cpp:146-194
+class SmoothConductor final : public BSDF { public: explicit SmoothConductor(const Properties &props); };    // conductor.cpp:201-215
+class SmoothPlastic final : public BSDF { public: explicit SmoothPlastic(const Properties &props); };        // plastic.cpp:135-174
+// twosided.cpp:62-92: wraps one nested BRDF (both sides) or two (front, back); nested BSDFs must not transmit
+class TwoSidedBRDF final : public BSDF { public: explicit TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back = nullptr); };
+float fresnel_diffuse_reflectance(float eta);                                                                 // fresnel.h:327-361
 float lookup_ior(const Properties &props, const std::string &name, const std::string &def);                   // include/mitsuba/render/ior.h
 
 // ---- Emitter / Shape ----------------------------------------------------------------------------

@@ -142,6 +142,40 @@ def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_le
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 
+def plugin_box_meshes():
+    """Cornell box dressed with the smooth conductor, smooth plastic and twosided plugins: plastic floor
+    (nonlinear) and back wall, a copper-like smooth conductor short block, the tall block replaced by a
+    free-standing panel (one quad, seen from both sides) with a twosided material — red diffuse front, rough
+    conductor back — and a second panel whose single twosided diffuse serves both sides."""
+    white = api.BSDF("diffuse", reflectance=WHITE)
+    red = api.BSDF("diffuse", reflectance=RED)
+    green = api.BSDF("diffuse", reflectance=GREEN)
+    floor = api.BSDF("plastic", diffuse_reflectance=(0.3, 0.45, 0.7), int_ior=1.49, ext_ior=1.000277, nonlinear=True)
+    back = api.BSDF("plastic", diffuse_reflectance=WHITE, specular_reflectance=(0.9, 0.8, 0.7))
+    copper = api.BSDF("conductor", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), specular_reflectance=(0.95, 0.95, 0.95))
+    rough = api.BSDF("roughconductor", distribution="ggx", alpha=0.25, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+    panel = api.TwoSided(red, rough)
+    both = api.TwoSided(api.BSDF("diffuse", reflectance=(0.2, 0.7, 0.3)))
+    meshes = []
+    for name, bsdf in (("floor", floor), ("ceiling", white), ("back", back), ("right", green), ("left", red)):
+        v, f = _quad(_CBOX[name], inward_point=_ROOM_CENTER)
+        meshes.append(api.Mesh(name, v, f, bsdf=bsdf))
+    v, f = _quad(_CBOX["light"], inward_point=_ROOM_CENTER)
+    meshes.append(api.Mesh("light", v, f, emitter=api.AreaLight(LIGHT_RADIANCE)))
+    v, f = _block(_SHORT); meshes.append(api.Mesh("short_block", v, f, bsdf=copper))
+    quad = np.array([(300.0, 0.0, 420.0), (470.0, 0.0, 300.0), (470.0, 330.0, 300.0), (300.0, 330.0, 420.0)], np.float32)
+    meshes.append(api.Mesh("panel", quad, np.array([(0, 1, 2), (0, 2, 3)], np.uint32), bsdf=panel))
+    quad2 = np.array([(60.0, 0.0, 330.0), (150.0, 0.0, 460.0), (150.0, 220.0, 460.0), (60.0, 220.0, 330.0)], np.float32)
+    meshes.append(api.Mesh("panel2", quad2, np.array([(0, 1, 2), (0, 2, 3)], np.uint32), bsdf=both))
+    return meshes
+
+
+def plugin_box(width, height, spp, seed=0, device=0, rfilter="gaussian", **film_kw):
+    """-> (scene, sensor): the conductor / plastic / twosided test scene (plugin_box_meshes)"""
+    scene = api.Scene(plugin_box_meshes()).build(device)
+    return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
+
+
 def sky_envmap(width=64, height=32, seed=1):
     """Synthetic lat-long HDR sky (the reference's data submodule is absent): vertical sky
     gradient, warm horizon band, dark ground, a sun blob and a little seeded noise. -> H x W x 3 float32."""

@@ -105,13 +105,13 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
-        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags;
+        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags; o.bsdfs[i].back = s->bsdfs[i].back;
         std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
 #if MIW_SPECTRAL
         std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
 #else
         {   // legacy RGB layout of params[] (include/miwave.h) -> texture records
-            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            const int off[5][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 } };
             for (int k = 0; k < 3; ++k) {
                 o.bsdfs[i].tex[k].type = TEX_RGB;
                 if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
@@ -254,8 +254,9 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
             break;
 
         stats.segments++;
-        const BsdfRec &bsdf = sc.bsdfs[sc.shapes[si.shape].bsdf];   // :154
-        bool active_e = active && (bsdf_flags(bsdf) & BSDF_Smooth) != 0;   // :155
+        // :154 si.bsdf(ray); a twosided plugin resolves to its front / back record here (twosided.cpp:105-124)
+        const BsdfSide bsdf = bsdf_side(sc.bsdfs.data(), sc.shapes[si.shape].bsdf, si.wi);
+        bool active_e = active && (bsdf.flags & BSDF_Smooth) != 0;   // :155
 
         if (active_e) {                                  // :157-172
             // Scene::sample_emitter_direction(si, next_2d, test_visibility = true), scene.cpp:164-214
@@ -271,8 +272,8 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
             }
             active_e = active_e && ds.pdf != 0.f;        // :160
             V3 wo = to_local(si.sh, ds.d);               // :163
-            Spec bsdf_val = bsdf_eval(bsdf, si.wi, wo, wl);   // :164
-            float bpdf = bsdf_pdf(bsdf, si.wi, wo);      // :168
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, wl);   // :164
+            float bpdf = bsdf_side_pdf(bsdf, si.wi, wo);      // :168
             float mis = mis_weight(ds.pdf, bpdf);        // :170 (ds.delta is false for area lights)
             if (active_e)
                 result = result + mis * throughput * bsdf_val * emitter_val;   // :171
@@ -282,7 +283,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
         float sample1 = sampler.next_1d();
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        Spec bsdf_val = bsdf_sample(bsdf, si.wi, sample1, sample2, bs, wl);
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, wl);
 
         throughput = throughput * bsdf_val;              // :181
         active = active && !all_zero(throughput);        // :182
@@ -734,18 +735,19 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
             } break;
             case MI_EVAL_BSDF: {
                 if (!have_scene) return -1;
-                const BsdfRec &b = sc.bsdfs[f2u(a[0])];
+                const uint32_t b_index = f2u(a[0]);
                 V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
                 Wavelengths wl;
 #if MIW_SPECTRAL
                 for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
 #endif
-                BSDFSample bs; Spec w = bsdf_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
+                const BsdfSide b = bsdf_side(sc.bsdfs.data(), b_index, wi);
+                BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
                 o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-                Spec e = bsdf_eval(b, wi, wo, wl);
+                Spec e = bsdf_side_eval(b, wi, wo, wl);
                 const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
                 for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
-                o[6 + 2 * MIW_SPEC_N] = bsdf_pdf(b, wi, wo);
+                o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo);
             } break;
             case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
             case MI_EVAL_CAMERA_RAY: {

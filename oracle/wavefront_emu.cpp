@@ -58,13 +58,13 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
-        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags;
+        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags; o.bsdfs[i].back = s->bsdfs[i].back;
         std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
 #if MIW_SPECTRAL
         std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
 #else
         {
-            const int off[3][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 } };
+            const int off[5][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 } };
             for (int k = 0; k < 3; ++k) {
                 o.bsdfs[i].tex[k].type = TEX_RGB;
                 if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
