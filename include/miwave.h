@@ -171,6 +171,10 @@ typedef struct {
      * 0 = auto: 2 when the geometry is LDS-resident or the tree fits the LDS-stack walk, else 1 */
     int32_t plan;
     int32_t samples_per_launch;               /* plan 2: <= 0 = default (128)            */
+    /* 1: `film` already holds earlier passes (samples_per_pass < sample_count, integrator.cpp:75-86: the blocks
+     * of pass p carry ids p * block_count + counter, spiral.cpp:41); this pass's block tiles are added onto it,
+     * after the ids already in it. 0: the film is overwritten. */
+    int32_t accumulate;
 } mi_render_cfg;
 
 typedef struct {

@@ -66,7 +66,7 @@ class mi_render_cfg(C.Structure):
                 ("filter_lut", C.c_float * 32), ("filter_radius", C.c_float), ("filter_border", C.c_int32),
                 ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("film_mode", C.c_int32),
                 ("profile", C.c_int32),
-                ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32)]
+                ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32), ("accumulate", C.c_int32)]
 
 
 class mi_counters(C.Structure):
@@ -182,6 +182,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_integrator_cancel": (None, [vp]), "mih_integrator_render": (i32, [vp, vp, vp]),
         "mih_integrator_counters": (i32, [vp, C.POINTER(mi_counters)]),
         "mih_make_render_cfg": (i32, [vp, vp, C.POINTER(mi_render_cfg), c_u32_p, c_u32_p, u32, u32]),
+        "mih_make_render_cfg_pass": (i32, [vp, vp, C.POINTER(mi_render_cfg), c_u32_p, c_u32_p, u32, u32, u32]),
+        "mih_integrator_pass_count": (i32, [vp, vp]),
         "mih_spiral": (i32, [i32, i32, i32, i32, i32, c_i32_p, i32]),
     }
     for name, (res, args) in sig.items():

@@ -443,11 +443,19 @@ class PathIntegrator:
         host_lib().mih_integrator_counters(self.h, C.byref(c))
         return c
 
-    def render_job(self, sensor, n_threads=1, capacity=1 << 16):
+    def pass_count(self, sensor):
+        """sample_count / samples_per_pass (integrator.cpp:75-86)"""
+        n = host_lib().mih_integrator_pass_count(self.h, sensor.h)
+        if n < 0:
+            raise RuntimeError(_err())
+        return n
+
+    def render_job(self, sensor, n_threads=1, capacity=1 << 16, pass_index=0):
+        """The job of pass `pass_index` (ascending block-id offset; passes after the first accumulate onto the film)"""
         cfg = mi_render_cfg()
         block_ids = np.zeros(capacity, np.uint32); tiles = np.zeros(capacity, np.uint32)
-        if host_lib().mih_make_render_cfg(self.h, sensor.h, C.byref(cfg), block_ids.ctypes.data_as(c_u32_p),
-                                          tiles.ctypes.data_as(c_u32_p), capacity, n_threads) != 0:
+        if host_lib().mih_make_render_cfg_pass(self.h, sensor.h, C.byref(cfg), block_ids.ctypes.data_as(c_u32_p),
+                                               tiles.ctypes.data_as(c_u32_p), capacity, n_threads, pass_index) != 0:
             raise RuntimeError(_err())
         return RenderJob(cfg, block_ids, tiles)
 
@@ -488,9 +496,10 @@ class Device:
         self.check(self.L.mi_trace(self.ctx, C.byref(r), C.byref(h), n, int(any_hit)))
         return out
 
-    def render(self, job, f64=False, profile=False, film_mode=0, plan=None, samples_per_launch=None):
+    def render(self, job, f64=False, profile=False, film_mode=0, plan=None, samples_per_launch=None, onto=None):
         """film_mode 0 auto / 1 sample log + ordered gather (float32, reference order) / 2 float64 atomics;
-        plan 0 auto / 1 wavefront (HBM queues) / 2 resident (registers + LDS)"""
+        plan 0 auto / 1 wavefront (HBM queues) / 2 resident (registers + LDS);
+        onto: the film of the earlier passes when job.cfg.accumulate is set (a copy is accumulated onto)"""
         cfg = job.cfg
         cfg.film_on_device = 0; cfg.film_f64 = int(f64); cfg.profile = int(profile); cfg.film_mode = film_mode
         if plan is not None:
@@ -499,6 +508,8 @@ class Device:
             cfg.samples_per_launch = int(samples_per_launch)
         n = cfg.crop_w * cfg.crop_h * 5
         film = np.zeros(n, np.float64 if f64 else np.float32)
+        if cfg.accumulate:
+            film[:] = np.asarray(onto).reshape(-1)
         st = self.L.mi_render(self.ctx, C.byref(cfg), film.ctypes.data_as(C.c_void_p))
         if st not in (0, _capi.MI_ERR_CANCELLED):
             self.check(st)

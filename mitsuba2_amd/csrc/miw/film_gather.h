@@ -75,9 +75,11 @@ MIW_HD void film_block_replay(const FilmRec &f, const BlockReplayArgs &a, uint32
 }
 
 // Step 2: film texel (fx, fy), crop-relative -> out[5]; `tiles` = block tiles written by step 1.
-MIW_HD void film_merge_texel(const FilmRec &f, const BlockReplayArgs &a, const float *tiles, int fx, int fy, float *out) {
+// `accumulate`: out[] already holds the texel of earlier passes (their block ids are smaller) and is added onto.
+MIW_HD void film_merge_texel(const FilmRec &f, const BlockReplayArgs &a, const float *tiles, int fx, int fy, float *out,
+                             bool accumulate = false) {
     const int bs = f.block_size;
-    for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = 0.f;
+    if (!accumulate) for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = 0.f;
     // blocks whose bordered area contains the texel: at most 2 x 2
     int bx_lo = (fx - f.border) / bs, bx_hi = (fx + f.border) / bs,
         by_lo = (fy - f.border) / bs, by_hi = (fy + f.border) / bs;

@@ -628,10 +628,11 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
     }
 }
 
-__global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n) {
+__global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n, int accumulate) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (out64) out64[i] = accum[i]; else out32[i] = (float) accum[i];
+    if (out64) out64[i] = accumulate ? out64[i] + accum[i] : accum[i];
+    else out32[i] = accumulate ? (float) ((double) out32[i] + accum[i]) : (float) accum[i];
 }
 
 // Ordered film assembly, step 1 (miw/film_gather.h): the bordered ImageBlock of every spiral block
@@ -974,12 +975,13 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
 }
 
 // step 2: every film texel sums the block tiles covering it, ascending block id
-__global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64) {
+__global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64, int accumulate) {
     int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;
     if (fx >= F.crop_w || fy >= F.crop_h) return;
     float v[MIW_FILM_CHANNELS];
-    film_merge_texel(F, A, tiles, fx, fy, v);
     size_t o = ((size_t) fy * F.crop_w + fx) * MIW_FILM_CHANNELS;
+    if (accumulate) for (int k = 0; k < MIW_FILM_CHANNELS; ++k) v[k] = out64 ? (float) out64[o + k] : out32[o + k];
+    film_merge_texel(F, A, tiles, fx, fy, v, accumulate != 0);
     for (int k = 0; k < MIW_FILM_CHANNELS; ++k) {
         if (out64) out64[o + k] = (double) v[k]; else out32[o + k] = v[k];
     }
@@ -1826,7 +1828,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         const size_t elem = cfg->film_f64 ? sizeof(double) : sizeof(float);
         void *dst = film;
         const bool staged = !cfg->film_on_device;
-        if (staged) { HIP_TRY(c, c->d_out.resize(film_n * elem)); dst = c->d_out.p; }
+        if (staged) {
+            HIP_TRY(c, c->d_out.resize(film_n * elem)); dst = c->d_out.p;
+            if (cfg->accumulate) HIP_TRY(c, hipMemcpyAsync(c->d_out.p, film, film_n * elem, hipMemcpyHostToDevice, s));
+        }
         float *dst32 = cfg->film_f64 ? nullptr : (float *) dst;
         double *dst64 = cfg->film_f64 ? (double *) dst : nullptr;
         if (film_mode == 1) {
@@ -1872,12 +1877,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<false>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
             }
             MIW_TIMED(5, hipLaunchKernelGGL(k_film_merge, dim3(((uint32_t) cfg->crop_w + 255u) / 256u, (uint32_t) cfg->crop_h), dim3(256), 0, s,
-                                            P.film, A, c->d_tiles.p, dst32, dst64));
+                                            P.film, A, c->d_tiles.p, dst32, dst64, cfg->accumulate));
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(s));            // block_tile (host vector) must outlive the copy
         } else {
             dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
-            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, dst32, dst64, film_n));
+            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, dst32, dst64, film_n, cfg->accumulate));
         }
         if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_out.p, film_n * elem, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipGetLastError());

@@ -1194,18 +1194,26 @@ PathIntegrator::PathIntegrator(const Properties &props) {
 }
 void PathIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
 
+// integrator.cpp:75-86
+static size_t samples_per_pass_of(uint32_t samples_per_pass, size_t total_spp) {
+    size_t spp_pass = (samples_per_pass == (uint32_t) -1) ? total_spp : std::min((size_t) samples_per_pass, total_spp);
+    if (spp_pass == 0 || (total_spp % spp_pass) != 0)
+        Throw("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(spp_pass) + ").");
+    return spp_pass;
+}
+uint32_t PathIntegrator::pass_count(const PerspectiveCamera *sensor) const {
+    size_t total_spp = sensor->sampler()->sample_count();
+    return (uint32_t) (total_spp / samples_per_pass_of(m_samples_per_pass, total_spp));
+}
 void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
                                      std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
-                                     uint32_t n_threads) const {
+                                     uint32_t n_threads, uint32_t pass) const {
     std::memset(&cfg, 0, sizeof cfg);
     const Film *film = sensor->film().get();
     auto cs = film->crop_size(); auto co = film->crop_offset();
     size_t total_spp = sensor->sampler()->sample_count();
-    size_t spp_pass = (m_samples_per_pass == (uint32_t) -1) ? total_spp : std::min((size_t) m_samples_per_pass, total_spp);
-    if (spp_pass == 0 || (total_spp % spp_pass) != 0)
-        Throw("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(spp_pass) + ").");
-    if (spp_pass != total_spp)
-        Throw("samples_per_pass < sample_count is not supported: a pixel's PCG32 stream is consumed in one pass.");
+    size_t spp_pass = samples_per_pass_of(m_samples_per_pass, total_spp);
+    if (pass >= total_spp / spp_pass) Throw("make_render_cfg: pass index out of range");
     // block size, integrator.cpp:88-97 (MTS_BLOCK_SIZE = 32, spiral.h:9-10)
     uint32_t bs = m_block_size;
     if (bs == 0) {
@@ -1217,7 +1225,8 @@ void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_
         }
     }
     cfg.crop_x = co[0]; cfg.crop_y = co[1]; cfg.crop_w = cs[0]; cfg.crop_h = cs[1];
-    cfg.spp = (uint32_t) total_spp; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+    cfg.spp = (uint32_t) spp_pass; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+    cfg.accumulate = pass > 0 ? 1 : 0;
     cfg.base_seed = sensor->sampler()->base_seed();
     cfg.block_size = (int32_t) bs;
     // spiral visitation order -> block id per row-major block (spiral.cpp)
@@ -1228,7 +1237,7 @@ void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_
     for (size_t i = 0; i < spiral.block_count(); ++i) {
         Spiral::Block b = spiral.next_block();
         uint32_t bx = (uint32_t) (b.offset[0] - co[0]) / bs, by = (uint32_t) (b.offset[1] - co[1]) / bs;
-        block_ids[by * nbx + bx] = (uint32_t) b.block_id;
+        block_ids[by * nbx + bx] = (uint32_t) (b.block_id + (size_t) pass * spiral.block_count());   // spiral.cpp:41
         by_id[b.block_id] = by * nbx + bx;
     }
     tiles.clear();
@@ -1253,14 +1262,23 @@ bool PathIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
     if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
     Film *film = sensor->film().get();
     film->prepare({ "X", "Y", "Z", "A", "W" });                // integrator.cpp:67-73
-    mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
-    make_render_cfg(sensor, cfg, block_ids, tiles);
-    m_active_ctx.store(scene->ctx());
-    mi_status st = mi_render(scene->ctx(), &cfg, film->storage().data());
-    m_active_ctx.store(nullptr);
-    mi_get_counters(scene->ctx(), &m_counters);
-    if (st == MI_ERR_CANCELLED) return false;
-    if (st != MI_OK) Throw(std::string("mi_render: ") + mi_last_error(scene->ctx()));
+    const uint32_t passes = pass_count(sensor);
+    mi_counters total{};
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
+        make_render_cfg(sensor, cfg, block_ids, tiles, 1, pass);
+        m_active_ctx.store(scene->ctx());
+        mi_status st = mi_render(scene->ctx(), &cfg, film->storage().data());
+        m_active_ctx.store(nullptr);
+        mi_get_counters(scene->ctx(), &m_counters);
+        if (pass > 0) {                                        // work counters add up over the passes
+            m_counters.samples += total.samples; m_counters.segments += total.segments; m_counters.shadow_rays += total.shadow_rays;
+            m_counters.iterations += total.iterations; m_counters.ms_render += total.ms_render;
+        }
+        total = m_counters;
+        if (st == MI_ERR_CANCELLED) return false;
+        if (st != MI_OK) Throw(std::string("mi_render: ") + mi_last_error(scene->ctx()));
+    }
     return true;
 }
 
@@ -1763,6 +1781,20 @@ int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *blo
         std::memcpy(tiles, tl.data(), tl.size() * 4);
         cfg->block_ids = block_ids; cfg->tile_list = tl.empty() ? nullptr : tiles;
         return 0; MIH_CATCH(-1)
+}
+int mih_make_render_cfg_pass(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads, uint32_t pass) {
+    MIH_TRY
+        std::vector<uint32_t> ids, tl;
+        ((Box<PathIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads, pass);
+        if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
+        std::memcpy(block_ids, ids.data(), ids.size() * 4);
+        std::memcpy(tiles, tl.data(), tl.size() * 4);
+        cfg->block_ids = block_ids; cfg->tile_list = tl.empty() ? nullptr : tiles;
+        return 0; MIH_CATCH(-1)
+}
+int mih_integrator_pass_count(void *i, void *sensor) {
+    MIH_TRY
+        return (int) ((Box<PathIntegrator> *) i)->p->pass_count(((Box<PerspectiveCamera> *) sensor)->p.get()); MIH_CATCH(-1)
 }
 // Spiral walk (test hook): writes offset.xy, size.xy, block_id per block; returns block count
 int mih_spiral(int w, int h, int off_x, int off_y, int block_size, int32_t *out5, int capacity) {

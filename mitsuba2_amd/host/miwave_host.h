@@ -354,9 +354,14 @@ public:
     // (spiral index % world_size) == rank; the film holds the partial sum.
     void set_shard(uint32_t rank, uint32_t world_size) { m_rank = rank; m_world = world_size; }
     // fills everything SamplingIntegrator::render derives on the host
+    // for pass `pass` of pass_count(sensor) (samples_per_pass < sample_count, integrator.cpp:75-86). Passes are
+    // numbered by ascending block-id offset: pass p's blocks carry ids p * block_count + spiral counter
+    // (spiral.cpp:41), the film adds block tiles in ascending id, so render() runs p = 0, 1, ... and every pass
+    // after the first accumulates onto the film (mi_render_cfg::accumulate).
     void make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
                          std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
-                         uint32_t n_threads_hint = 1) const;
+                         uint32_t n_threads_hint = 1, uint32_t pass = 0) const;
+    uint32_t pass_count(const PerspectiveCamera *sensor) const;
     const mi_counters &counters() const { return m_counters; }
     void set_profile(bool p) { m_profile = p; }
     // execution plan of the device sample loop (mi_render_cfg::plan): 0 auto, 1 wavefront, 2 resident

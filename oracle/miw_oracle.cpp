@@ -465,14 +465,20 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
     fill_records(cfg, sensor, film);
     const int bs = cfg->block_size;
     std::vector<SpiralBlock> blocks = spiral_blocks(cfg->crop_w, cfg->crop_h, cfg->crop_x, cfg->crop_y, bs);
-    // the caller's block-id table must agree with this spiral (host logic cross-check)
+    // the caller's block-id table must agree with this spiral (host logic cross-check); with several passes
+    // (samples_per_pass < sample_count) the ids of a pass are shifted by a multiple of the block count, spiral.cpp:41
+    uint32_t id_offset = 0;
     {
         int nbx = (cfg->crop_w + bs - 1) / bs;
-        if (cfg->block_ids)
+        if (cfg->block_ids && !blocks.empty()) {
+            const SpiralBlock &b0 = blocks[0];
+            id_offset = cfg->block_ids[((b0.off_y - cfg->crop_y) / bs) * nbx + (b0.off_x - cfg->crop_x) / bs] - b0.id;
+            if (id_offset % (uint32_t) blocks.size() != 0) return -2;
             for (const SpiralBlock &b : blocks) {
                 int bx = (b.off_x - cfg->crop_x) / bs, by = (b.off_y - cfg->crop_y) / bs;
-                if (cfg->block_ids[by * nbx + bx] != b.id) return -2;
+                if (cfg->block_ids[by * nbx + bx] != b.id + id_offset) return -2;
             }
+        }
     }
     std::vector<uint32_t> todo;
     if (only_blocks) todo.assign(only_blocks, only_blocks + n_only);
@@ -485,8 +491,10 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
     } else for (const SpiralBlock &b : blocks) todo.push_back(b.id);
 
     size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
-    if (film32) std::memset(film32, 0, film_n * sizeof(float));
-    if (film64) std::memset(film64, 0, film_n * sizeof(double));
+    if (!cfg->accumulate) {                                  // earlier passes (smaller block ids) stay in the film
+        if (film32) std::memset(film32, 0, film_n * sizeof(float));
+        if (film64) std::memset(film64, 0, film_n * sizeof(double));
+    }
 
     auto t0 = std::chrono::steady_clock::now();
     std::atomic<size_t> next{0};
@@ -509,7 +517,7 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
             // render_block, :181-209 (scalar branch)
             uint32_t pixel_count = (uint32_t) (bs * bs);
             for (uint32_t i = 0; i < pixel_count; ++i) {
-                sampler.seed((uint64_t) blk.id * pixel_count + i);                 // :198
+                sampler.seed((uint64_t) (blk.id + id_offset) * pixel_count + i);   // :198
                 uint32_t px, py; morton_decode2(i, px, py);                         // :200
                 if ((int) px >= blk.w || (int) py >= blk.h) continue;               // :201-202
                 float pos_x = (float) (px + (uint32_t) blk.off_x), pos_y = (float) (py + (uint32_t) blk.off_y);   // :204

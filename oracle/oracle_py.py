@@ -70,11 +70,16 @@ class Oracle:
         L.orc_eval.restype = C.c_int
 
     # ---- renders ----
-    def render(self, desc, job, threads=1, want_f64=True, only_blocks=None):
+    def render(self, desc, job, threads=1, want_f64=True, only_blocks=None, onto=None):
+        """onto = (f32, f64) films of the earlier passes when job.cfg.accumulate is set"""
         cfg = job.cfg
         n = cfg.crop_w * cfg.crop_h * 5
         f32 = np.zeros(n, np.float32)
         f64 = np.zeros(n, np.float64) if want_f64 else None
+        if cfg.accumulate:
+            f32[:] = np.asarray(onto[0]).reshape(-1)
+            if f64 is not None:
+                f64[:] = np.asarray(onto[1]).reshape(-1)
         st = orc_stats()
         ob = None if only_blocks is None else np.ascontiguousarray(only_blocks, np.uint32)
         rc = self.L.orc_render(desc, C.byref(cfg), _fp(f32), None if f64 is None else f64.ctypes.data_as(c_double_p),
@@ -85,10 +90,13 @@ class Oracle:
         shape = (cfg.crop_h, cfg.crop_w, 5)
         return f32.reshape(shape), None if f64 is None else f64.reshape(shape), st
 
-    def emu_render(self, desc, job):
+    def emu_render(self, desc, job, onto=None):
+        """onto = (f64, f32) films of the earlier passes when job.cfg.accumulate is set"""
         cfg = job.cfg
         n = cfg.crop_w * cfg.crop_h * 5
         f64 = np.zeros(n, np.float64); f32 = np.zeros(n, np.float32)
+        if cfg.accumulate:
+            f64[:] = np.asarray(onto[0]).reshape(-1); f32[:] = np.asarray(onto[1]).reshape(-1)
         stats = (C.c_uint64 * 4)()
         rc = self.L.emu_render(desc, C.byref(cfg), f64.ctypes.data_as(c_double_p), _fp(f32), stats)
         if rc != 0:

@@ -183,7 +183,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     if (film32) { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
     Q.log_pos = log_pos.data(); Q.log_val = log_val.data();
     size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
-    std::memset(film64, 0, film_n * sizeof(double));
+    if (!cfg->accumulate) std::memset(film64, 0, film_n * sizeof(double));
 
     for (uint32_t lane = 0; lane < n_lanes; ++lane) {          // k_init_lanes
         uint32_t tile = lane / bs2, i = lane % bs2;
@@ -288,7 +288,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         for (uint32_t t = 0; t < n_tiles; ++t) film_block_replay(P.film, A, t, tiles.data() + (size_t) t * A.tile_stride);
         for (int fy = 0; fy < cfg->crop_h; ++fy)
             for (int fx = 0; fx < cfg->crop_w; ++fx)
-                film_merge_texel(P.film, A, tiles.data(), fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5);
+                film_merge_texel(P.film, A, tiles.data(), fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5, cfg->accumulate != 0);
     }
     if (stats4) { stats4[0] = cnt.samples; stats4[1] = cnt.segments; stats4[2] = cnt.shadow_rays; stats4[3] = iterations; }
     return 0;

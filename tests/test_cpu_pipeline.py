@@ -89,6 +89,36 @@ def test_resident_plan_equals_scalar_path_integrator(native, oracle, per_launch)
     assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
 
 
+def test_samples_per_pass(native, oracle):
+    """samples_per_pass < sample_count (integrator.cpp:75-86): every pass re-seeds the pixels from its own block ids
+    (spiral.cpp:41: counter + pass * block_count) and adds its blocks onto the film after the ids already there."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(40, 36, 6, device=-1)
+    integ = native.PathIntegrator(samples_per_pass=2)
+    assert integ.pass_count(sensor) == 3
+    one = native.PathIntegrator().render_job(sensor)
+    assert one.cfg.spp == 6 and one.cfg.accumulate == 0
+    nblocks = one.cfg.block_count
+    o32 = o64 = e32 = e64 = None
+    segments = 0
+    for p in range(3):
+        job = integ.render_job(sensor, pass_index=p)
+        assert job.cfg.spp == 2 and job.cfg.accumulate == (1 if p else 0) and job.cfg.block_count == nblocks
+        assert np.array_equal(job.block_ids[:nblocks], one.block_ids[:nblocks] + p * nblocks)
+        o32, o64, st = oracle.render(scene.desc(), job, threads=4, onto=(o32, o64))
+        e64, e32, est = oracle.emu_render(scene.desc(), job, onto=(e64, e32))
+        assert est[1] == st.segments and np.array_equal(e32, o32)
+        assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
+        segments += st.segments
+    w1 = oracle.render(scene.desc(), integ.render_job(sensor, pass_index=0), threads=4)[0][..., 4]
+    assert abs(o32[..., 4].sum() / (3 * w1.sum()) - 1) < 0.02      # three passes' worth of filter weights
+    s32, _, sst = oracle.render(scene.desc(), one, threads=4)       # the single-pass render: other seeds, same estimator
+    assert not np.array_equal(s32, o32)
+    assert abs(o32[..., 1].sum() / s32[..., 1].sum() - 1) < 0.1 and abs(segments / sst.segments - 1) < 0.05
+    with pytest.raises(RuntimeError, match="multiple of samples_per_pass"):
+        native.PathIntegrator(samples_per_pass=4).render_job(sensor)
+
+
 @pytest.mark.parametrize("kw", [dict(max_depth=1), dict(max_depth=2), dict(max_depth=3, rr_depth=1), dict(rr_depth=2)])
 def test_depth_and_rr_variants(native, oracle, kw):
     from mitsuba2_amd import scenes

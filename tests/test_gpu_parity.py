@@ -265,6 +265,31 @@ def test_render_float32_film_and_host_classes(native, oracle, cbox):
     assert c.samples == 96 * 64 * 8 and c.bvh_tris == 32
 
 
+def test_render_samples_per_pass(native, oracle, dev):
+    """samples_per_pass < sample_count (integrator.cpp:75-86) through the host classes: three passes of 2 spp, each
+    seeded from its own block ids and accumulated onto the film (mi_render_cfg::accumulate) == the oracle run the
+    same way, bit for bit, in both film modes and both plans."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(96, 64, 6, device=0)
+    integ = native.PathIntegrator(samples_per_pass=2)
+    assert integ.pass_count(sensor) == 3 and integ.render(scene, sensor) is True
+    film = sensor.film.data((64, 96, 5)).copy()
+    assert integ.counters().samples == 96 * 64 * 6
+    dev.upload(scene.desc())
+    o32 = o64 = None
+    g = {(plan, fm): None for plan in (1, 2) for fm in (1, 2)}
+    for p in range(3):
+        job = integ.render_job(sensor, pass_index=p)
+        o32, o64, _ = oracle.render(scene.desc(), job, threads=8, onto=(o32, o64))
+        for (plan, fm) in g:
+            g[(plan, fm)], st = dev.render(job, plan=plan, film_mode=fm, f64=(fm == 2), onto=g[(plan, fm)])
+            assert st == 0
+    assert np.array_equal(film, o32)
+    for plan in (1, 2):
+        assert np.array_equal(g[(plan, 1)], o32)
+        assert np.allclose(g[(plan, 2)], o64, rtol=1e-12, atol=0)
+
+
 def test_render_materials_parity(native, oracle, dev):
     """Config C3-class: GGX rough conductor + dielectric balls with shading normals."""
     from mitsuba2_amd import scenes
