@@ -45,7 +45,9 @@ enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2, 
 enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2,            /* roughconductor */
        MI_BSDF_FLAG_NONLINEAR = 1, MI_BSDF_FLAG_HAS_SPECULAR = 2,          /* plastic */
        MI_BSDF_FLAG_TWOSIDED = 0x100 };                                    /* any type: wrapped by <bsdf type="twosided"> */
-enum { MI_SHAPE_HAS_NORMALS = 1 };
+enum { MI_SHAPE_HAS_NORMALS = 1,
+       MI_SHAPE_RECTANGLE = 2 };   /* analytic rectangle (src/shapes/rectangle.cpp): face_count == 1 — the shape's single
+                                      primitive, id first_face; its faces[] entry is ignored — geometry in `rectangles` */
 
 /* A spectrum-valued plugin parameter (what src/libcore/xml.cpp:1073-1170 turns an <rgb> / <spectrum>
  * tag into). scalar_rgb library: only MI_TEX_RGB. scalar_spectral library (libmiwave_spectral.so):
@@ -102,6 +104,13 @@ typedef struct {          /* environment map, src/emitters/envmap.cpp (one per s
                                               scene.cpp:38-60): area emitters at or after it shift up by one */
 } mi_envmap;
 
+/* Rectangle(props): [-1, 1]^2 in the z = 0 plane of object space, normal +z, placed by to_world
+ * (flip_normals already folded in, rectangle.cpp:78-80). Matrices 4x4 column-major: m_to_world and its inverse. */
+typedef struct {
+    uint32_t shape;                        /* index into shapes (which carries MI_SHAPE_RECTANGLE) */
+    float to_world[16], to_object[16];
+} mi_rectangle;
+
 typedef struct {
     const float    *vertex_positions;  /* 3 * vertex_count                               */
     const float    *vertex_normals;    /* 3 * vertex_count, or NULL                      */
@@ -112,6 +121,7 @@ typedef struct {
     const mi_bsdf    *bsdfs;    uint32_t bsdf_count;
     const mi_emitter *emitters; uint32_t emitter_count;
     const mi_envmap  *envmap;          /* or NULL                                        */
+    const mi_rectangle *rectangles; uint32_t rectangle_count;   /* one per MI_SHAPE_RECTANGLE shape, or NULL / 0 */
 } mi_scene_desc;
 
 /* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */

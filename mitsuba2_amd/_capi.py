@@ -38,13 +38,18 @@ class mi_envmap(C.Structure):
                 ("to_world", C.c_float * 16), ("bsphere_radius", C.c_float), ("emitter_index", C.c_uint32)]
 
 
+class mi_rectangle(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
+
+
 class mi_scene_desc(C.Structure):
     _fields_ = [("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_count", C.c_uint32),
                 ("faces", c_u32_p), ("face_count", C.c_uint32),
                 ("shapes", C.POINTER(mi_shape)), ("shape_count", C.c_uint32),
                 ("bsdfs", C.POINTER(mi_bsdf)), ("bsdf_count", C.c_uint32),
                 ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32),
-                ("envmap", C.POINTER(mi_envmap))]
+                ("envmap", C.POINTER(mi_envmap)),
+                ("rectangles", C.POINTER(mi_rectangle)), ("rectangle_count", C.c_uint32)]
 
 
 class mi_rays_soa(C.Structure):
@@ -149,6 +154,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),
         "mih_props_set_color": (None, [vp, cp, f, f, f]),
         "mih_props_set_lookat": (None, [vp, cp, c_float_p, c_float_p, c_float_p]),
+        "mih_props_set_matrix": (None, [vp, cp, c_float_p]), "mih_rectangle_create": (vp, [vp]),
         "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]), "mih_bsdf_create_twosided": (vp, [vp, vp]),
         "mih_fresnel_diffuse_reflectance": (C.c_float, [C.c_float]),
         "mih_bsdf_record": (i32, [vp, C.POINTER(mi_bsdf)]), "mih_bsdf_flags": (u32, [vp]),

@@ -58,7 +58,7 @@ def _fp(a):
 
 class Properties:
     """Properties(plugin_name, **values): float / int / bool / str / 3-tuple (rgb) values;
-    `to_world=dict(origin=, target=, up=)` becomes a look-at transform."""
+    `to_world=dict(origin=, target=, up=)` becomes a look-at transform, a 4x4 numpy array a <matrix>."""
 
     def __init__(self, plugin, **kw):
         L = host_lib()
@@ -73,6 +73,9 @@ class Properties:
                 L.mih_props_set_float(self.h, n, v)
             elif isinstance(v, str):
                 L.mih_props_set_string(self.h, n, v.encode())
+            elif isinstance(v, np.ndarray) and v.shape == (4, 4):
+                m = np.ascontiguousarray(v, np.float32)
+                L.mih_props_set_matrix(self.h, n, _fp(m))
             elif isinstance(v, dict):
                 o = np.asarray(v["origin"], np.float32); t = np.asarray(v["target"], np.float32)
                 u = np.asarray(v.get("up", (0, 1, 0)), np.float32)
@@ -134,6 +137,16 @@ def fresnel_diffuse_reflectance(eta):
     return float(host_lib().mih_fresnel_diffuse_reflectance(float(eta)))
 
 
+def quad_to_world(corner, edge_u, edge_v):
+    """4x4 to_world that maps the rectangle plugin's [-1, 1]^2 onto the parallelogram corner + s * edge_u + t * edge_v
+    (s, t in [0, 1]); +z maps to normalize(edge_u x edge_v)."""
+    c = np.asarray(corner, np.float64); u = np.asarray(edge_u, np.float64) / 2; v = np.asarray(edge_v, np.float64) / 2
+    n = np.cross(u, v); n /= np.linalg.norm(n)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = u, v, n, c + u + v
+    return m.astype(np.float32)
+
+
 class AreaLight:
     def __init__(self, radiance):
         self._p = Properties("area", radiance=tuple(radiance))
@@ -175,6 +188,27 @@ class Mesh:
             raise RuntimeError(_err())
         self = cls.__new__(cls)
         self.h, self.name = h, str(filename)
+        self._sync()
+        self.bsdf, self.emitter = bsdf, emitter
+        if bsdf is not None:
+            host_lib().mih_mesh_set_bsdf(self.h, bsdf.h)
+        if emitter is not None:
+            host_lib().mih_mesh_set_emitter(self.h, emitter.h)
+        return self
+
+    @classmethod
+    def rectangle(cls, to_world=None, flip_normals=False, bsdf=None, emitter=None, name="rectangle"):
+        """<shape type="rectangle"> (src/shapes/rectangle.cpp): the analytic [-1, 1]^2 quad in z = 0 placed by the 4x4
+        `to_world` — one primitive, intersected and sampled analytically (not two triangles)."""
+        kw = dict(flip_normals=bool(flip_normals))
+        if to_world is not None:
+            kw["to_world"] = np.asarray(to_world, np.float32).reshape(4, 4)
+        props = Properties("rectangle", **kw)
+        h = host_lib().mih_rectangle_create(props.h)
+        if not h:
+            raise RuntimeError(_err())
+        self = cls.__new__(cls)
+        self.h, self.name = h, name
         self._sync()
         self.bsdf, self.emitter = bsdf, emitter
         if bsdf is not None:

@@ -225,7 +225,8 @@ enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
 // `Mats` names the BSDF plugins the scene uses, so that a kernel compiled for MATS_DIFFUSE (every shape one-sided
 // smooth diffuse: BASELINE config 2) carries no dispatch and none of the other plugins' code; MATS_ALL is the table.
 enum { MATS_ALL = 0, MATS_DIFFUSE = 1 };
-template <int Mats = MATS_ALL, typename PrevO>
+// `Analytic` = false compiles the analytic-shape branch out (scenes the caller knows to be triangles only).
+template <int Mats = MATS_ALL, bool Analytic = true, typename PrevO>
 MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
                      ShadowOut &sh, Counters *cnt_local) {
     sh.has = false;
@@ -240,8 +241,12 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     if (valid) {
         const Tri &tr = sc.tris[tri_idx];
         const ShapeRec &shape = sc.shapes[tr.shape];
-        const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+        if (Analytic && tr.pad) {                        // analytic rectangle: its own compute_surface_interaction
+            compute_surface_interaction_rect(sc.rects[tr.pad - 1u], h.x, h.y, h.z, prev_o(), ray_d, si);
+        } else {
+            const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
+            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+        }
         si.shape = tr.shape; si.prim = tr.prim;
         emitter = shape.emitter; bsdf_index = shape.bsdf;
     }
@@ -404,7 +409,7 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 #ifndef MIW_SECTION
 #define MIW_SECTION(i) do { } while (0)      /* section clock of debug builds (miwave.hip) */
 #endif
-template <int Mats = MATS_ALL, typename Work, typename Trace2>
+template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2>
 MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                 Trace2 trace2, Counters *cnt_local) {
     LaneRegs L;
@@ -437,7 +442,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
         sh.has = false;
         int r = STEP_FINISHED;
         if (!dead_pending) {
-            r = path_step<Mats>(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
+            r = path_step<Mats, Analytic>(P, sc, L, h, [o]() { return o; }, sh, cnt_local);
             MIW_SECTION(4);
             if (r == STEP_DEAD_PENDING) { dead_pending = true; continue; }   // one more pass for its shadow ray
             if (r == STEP_CONTINUE) continue;

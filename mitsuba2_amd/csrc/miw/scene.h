@@ -39,7 +39,8 @@ struct EmitterRec {
     uint32_t tri_count;
     uint32_t valid_lo, valid_hi;
     float sum, normalization;
-    uint32_t flags;      // bit0: emit_vnorm valid for this emitter
+    uint32_t flags;      // bit0: emit_vnorm valid for this emitter; bit1: the shape is analytic rectangle `tri_first`
+                         // (no face tables; normalization = its 1 / surface area)
     uint32_t type;       // 0: area light on `shape`; 1: the environment map (SceneView::env)
 };
 enum : uint32_t { EMITTER_AREA = 0, EMITTER_ENVMAP = 1 };
@@ -55,6 +56,7 @@ struct SceneView {
     const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
     const float *emit_pmf, *emit_cdf;
     const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
+    const RectRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
 };
 
@@ -109,9 +111,9 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
     if (e.type == EMITTER_ENVMAP) {
         value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
     } else {
-        MeshSampler mesh = emitter_mesh(sc, e);
         // Shape::sample_direction, shape.cpp:292-309
-        PositionSample ps = mesh_sample_position(mesh, sample);
+        PositionSample ps = (e.flags & 2u) ? rect_sample_position(sc.rects[e.tri_first], sample)
+                                           : mesh_sample_position(emitter_mesh(sc, e), sample);
         ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf;
         ds.d = ds.p - ref_p;
         float dist_squared = squared_norm(ds.d);

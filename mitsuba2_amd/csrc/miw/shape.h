@@ -21,7 +21,17 @@ struct Tri {
     float p0[3], p1[3], p2[3];
     uint32_t shape;      // index into the shape table
     uint32_t prim;       // global primitive id (scene order) — closest-hit tie break
-    uint32_t pad;
+    uint32_t pad;        // 0: a mesh triangle. k > 0: one of the two bounding triangles of analytic rectangle k - 1
+                         // (RectRec table): the BVH builders see ordinary triangles, the leaf test runs the
+                         // rectangle's own intersection routine (both halves give the same answer)
+};
+
+// Analytic rectangle (src/shapes/rectangle.cpp): [-1, 1]^2 in z = 0 of object space. 4x4 matrices column-major.
+struct RectRec {
+    float to_world[16], to_object[16];
+    float n[3], inv_area;         // m_frame.n, m_inv_surface_area (update(), :86-96)
+    float dp_du[3]; uint32_t shape;
+    float dp_dv[3]; uint32_t prim;
 };
 
 MIW_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
@@ -62,6 +72,23 @@ MIW_HD bool ray_intersect_triangle(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, 
     return active;
 }
 
+// Rectangle::ray_intersect_preliminary / ray_test, rectangle.cpp:139-173 (u, v = prim_uv = local x, y)
+MIW_HD bool ray_intersect_rectangle(const RectRec &r, V3 o, V3 d, float mint, float maxt,
+                                    float &t_out, float &u_out, float &v_out) {
+    V3 ol = xf_point_affine(r.to_object, o), dl = xf_vector(r.to_object, d);   // m_to_object.transform_affine(ray_)
+    float t = -ol.z * rcp(dl.z);                                                 // -ray.o.z() * ray.d_rcp.z()
+    V3 local = v3(fmadd(dl.x, t, ol.x), fmadd(dl.y, t, ol.y), fmadd(dl.z, t, ol.z));   // ray(t)
+    t_out = t; u_out = local.x; v_out = local.y;
+    return t >= mint && t <= maxt && abs_(local.x) <= 1.f && abs_(local.y) <= 1.f;
+}
+// the leaf test of every scene query: Mesh::ray_intersect_triangle or the analytic shape's own routine
+// (kdtree.h:2362-2391 intersect_prim)
+MIW_HD bool prim_intersect(const Tri &tr, const RectRec *rects, V3 o, V3 d, float mint, float maxt,
+                           float &t, float &u, float &v) {
+    if (tr.pad) return ray_intersect_rectangle(rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
+    return ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), o, d, mint, maxt, t, u, v);
+}
+
 // What the shading stage needs of a SurfaceInteraction3f (interaction.h).
 struct SurfaceInteraction {
     float t;
@@ -97,6 +124,19 @@ MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
     si.wi = to_local(si.sh, -ray_d);                   // interaction.h:591
 }
 
+// Rectangle::compute_surface_interaction, rectangle.cpp:175-208 + interaction.h:571-596
+MIW_HD void compute_surface_interaction_rect(const RectRec &r, float t, float u, float v, V3 ray_o, V3 ray_d,
+                                             SurfaceInteraction &si) {
+    si.t = t;
+    si.p = v3(fmadd(ray_d.x, t, ray_o.x), fmadd(ray_d.y, t, ray_o.y), fmadd(ray_d.z, t, ray_o.z));   // ray(pi.t), :196
+    si.n = ld3(r.n); si.sh.n = si.n;                   // :198-199
+    V3 dp_du = ld3(r.dp_du);                           // :200
+    si.uv = v2(fmadd(u, .5f, .5f), fmadd(v, .5f, .5f));   // :202-203
+    si.sh.s = normalize(fnmadd3(si.sh.n, dot(si.sh.n, dp_du), dp_du));   // initialize_sh_frame, interaction.h:153-156
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = to_local(si.sh, -ray_d);                   // interaction.h:591
+}
+
 // interaction.h:58-61 — (1 + hmax(abs(p))) * RayEpsilon
 MIW_HD float spawn_mint(V3 p) { return (1.f + hmax(abs3(p))) * MIW_RAY_EPSILON; }
 
@@ -125,6 +165,14 @@ MIW_HD uint32_t distr_sample(const MeshSampler &m, float value) {
 }
 
 struct PositionSample { V3 p, n; V2 uv; float pdf; };
+
+// Rectangle::sample_position, rectangle.cpp:111-125
+MIW_HD PositionSample rect_sample_position(const RectRec &r, V2 sample) {
+    PositionSample ps;
+    ps.p = xf_point_affine(r.to_world, v3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
+    ps.n = ld3(r.n); ps.pdf = r.inv_area; ps.uv = sample;
+    return ps;
+}
 
 // mesh.cpp:352-397
 MIW_HD PositionSample mesh_sample_position(const MeshSampler &m, V2 sample) {

@@ -45,6 +45,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "miw/film.h"
 #include "miw/bvh.h"
 #include "miw/path.h"
+#include "rect_build.h"
 #include "miw/film_gather.h"
 #include "bvh_build.h"
 #include "envmap_build.h"
@@ -152,7 +153,7 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 #endif
 template <bool AnyHit, typename NodeAt, typename TriAt>
 __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
-                                                    V3 o, V3 d, float mint, float maxt, Hit &best) {
+                                                    V3 o, V3 d, float mint, float maxt, Hit &best, const RectRec *rects) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     const FastRay r = fast_ray(o, d, mint);
     float tmax = maxt;
@@ -176,7 +177,7 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
             for (uint32_t i = 0; i < count; ++i) {
                 const Tri &tr = tri_at(first + i);
                 float t, u, v;
-                if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), o, d, mint, maxt, t, u, v)) {
+                if (prim_intersect(tr, rects, o, d, mint, maxt, t, u, v)) {
                     if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
                     if (t < best.t || (t == best.t && tr.prim < best.prim)) {
                         best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
@@ -224,7 +225,7 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         // whole scene is LDS resident: pure ds_read traversal
         auto node_at = [lnodes](int32_t i) -> const BvhNode & { return lnodes[i]; };
         auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, sc.rects);
     } else {
         uint32_t ns = cfg.nodes_staged;
         auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
@@ -233,9 +234,9 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
         if (cfg.stack) {
             int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
-            return bvh_intersect_stack<AnyHit>(node_at, tri_at, stack, o, d, mint, maxt, h);
+            return bvh_intersect_stack<AnyHit>(node_at, tri_at, stack, o, d, mint, maxt, h, sc.rects);
         }
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h);
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, sc.rects);
     }
 }
 
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
-        pixel_stream_render<Mats>(P, sc, sample_end, work, tr2, &local);
+        pixel_stream_render<Mats, Tiny == 0>(P, sc, sample_end, work, tr2, &local);   // packet scenes hold triangles only
     } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
@@ -1119,6 +1120,7 @@ struct mi_ctx {
     std::vector<Tri> tris_in;
     std::vector<float> tri_vn_in;       // 9 per tri or empty
     std::vector<ShapeRec> shapes;
+    std::vector<RectRec> rects;                 // analytic rectangles
     std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
@@ -1126,7 +1128,7 @@ struct mi_ctx {
 
     // device scene
     DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
-    DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters;
+    DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<RectRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes;
     DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
@@ -1192,7 +1194,7 @@ void mi_destroy(mi_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
-    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_bsdfs.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
@@ -1243,14 +1245,39 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         int32_t emitter_id = sh.emitter;
         if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
         ShapeRec r; r.bsdf = sh.bsdf; r.emitter = emitter_id; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
+        if (sh.flags & MI_SHAPE_RECTANGLE) {
+            if (sh.face_count != 1) return fail(c, MI_ERR_INVALID, "shape %u: an analytic rectangle is one primitive (face_count == 1)", i);
+            if (sh.flags & MI_SHAPE_HAS_NORMALS) return fail(c, MI_ERR_INVALID, "shape %u: a rectangle has no vertex normals", i);
+        }
         c->shapes[i] = r;
         any_normals = any_normals || (r.flags & 1u);
     }
+    // analytic rectangles: record + two bounding triangles (the second one appended behind the faces)
+    c->rects.clear();
+    std::vector<int32_t> shape_rect(s->shape_count, -1);
+    for (uint32_t k = 0; k < s->rectangle_count; ++k) {
+        const mi_rectangle &q = s->rectangles[k];
+        if (q.shape >= s->shape_count || !(s->shapes[q.shape].flags & MI_SHAPE_RECTANGLE) || shape_rect[q.shape] >= 0)
+            return fail(c, MI_ERR_INVALID, "rectangle %u: shape %u is not a (single) MI_SHAPE_RECTANGLE shape", k, q.shape);
+        shape_rect[q.shape] = (int32_t) k;
+        c->rects.push_back(rect_record(q.to_world, q.to_object, q.shape, s->shapes[q.shape].first_face));
+        if (!(c->rects.back().inv_area > 0.f) || !isfinite_(c->rects.back().inv_area))
+            return fail(c, MI_ERR_INVALID, "rectangle %u: degenerate to_world", k);
+    }
+    for (uint32_t i = 0; i < s->shape_count; ++i)
+        if ((s->shapes[i].flags & MI_SHAPE_RECTANGLE) && shape_rect[i] < 0) return fail(c, MI_ERR_INVALID, "shape %u: no mi_rectangle record", i);
+    c->tris_in.resize((size_t) s->face_count + c->rects.size());
     c->tri_vn_in.clear();
-    if (any_normals) c->tri_vn_in.assign((size_t) s->face_count * 9, 0.f);
+    if (any_normals) c->tri_vn_in.assign(c->tris_in.size() * 9, 0.f);
     for (uint32_t f = 0; f < s->face_count; ++f) {
         if (face_shape[f] == 0xffffffffu) return fail(c, MI_ERR_INVALID, "face %u belongs to no shape", f);
         Tri &t = c->tris_in[f];
+        if (shape_rect[face_shape[f]] >= 0) {                  // the rectangle's primitive slot: its two bounding triangles
+            Tri two[2];
+            rect_bounding_tris(c->rects[shape_rect[face_shape[f]]], (uint32_t) shape_rect[face_shape[f]], two);
+            t = two[0]; c->tris_in[(size_t) s->face_count + shape_rect[face_shape[f]]] = two[1];
+            continue;
+        }
         for (int k = 0; k < 3; ++k) {
             uint32_t vi = s->faces[3 * f + k];
             if (vi >= s->vertex_count) return fail(c, MI_ERR_INVALID, "face %u: vertex index out of range", f);
@@ -1315,6 +1342,13 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 #else
         r.radiance.type = TEX_RGB; memcpy(r.radiance.v, e.radiance, 12);
 #endif
+        if (shape_rect[e.shape] >= 0) {                        // area light on an analytic rectangle: no face tables
+            const RectRec &q = c->rects[shape_rect[e.shape]];
+            r.shape = e.shape; r.tri_first = (uint32_t) shape_rect[e.shape]; r.tri_count = 0; r.flags = 2u;
+            r.valid_lo = r.valid_hi = 0; r.normalization = q.inv_area; r.sum = rcp(q.inv_area);
+            c->emitters.push_back(r);
+            continue;
+        }
         r.shape = e.shape; r.tri_first = (uint32_t) c->emit_pmf.size(); r.tri_count = sh.face_count;
         r.flags = (sh.flags & MI_SHAPE_HAS_NORMALS) ? 1u : 0u;
         any_emit_normals = any_emit_normals || r.flags;
@@ -1358,6 +1392,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         c->have_env = true;
     }
     HIP_TRY(c, c->d_shapes.upload(c->shapes, c->stream));
+    HIP_TRY(c, c->d_rects.upload(c->rects, c->stream));
     HIP_TRY(c, c->d_bsdfs.upload(c->bsdfs, c->stream));
     HIP_TRY(c, c->d_emitters.upload(c->emitters, c->stream));
     HIP_TRY(c, c->d_emit_tri.upload(c->emit_tri, c->stream));
@@ -1382,7 +1417,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     BvhBuildResult r;                       // host SAH result (nodes kept for the tiny-scene leaf filter)
     uint32_t node_count = 0, tri_count = (uint32_t) c->tris_in.size(), depth = 0;
     bool built_on_device = false;
-    const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree;
+    const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree && c->rects.empty();   // packets are triangles only
     if (quality == 0 && !tiny && tri_count >= 2) {
         // ---- device LBVH (lbvh_device.h) ----
         hipStream_t s = c->stream;
@@ -1459,12 +1494,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.emit_tri = c->d_emit_tri.p; v.emit_vnorm = c->emit_vnorm.empty() ? nullptr : c->d_emit_vnorm.p;
     v.emit_pmf = c->d_emit_pmf.p; v.emit_cdf = c->d_emit_cdf.p;
     v.env = c->have_env ? c->d_env.p : nullptr;
+    v.rects = c->rects.empty() ? nullptr : c->d_rects.p; v.rect_count = (uint32_t) c->rects.size();
 
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
     size_t all = (size_t) node_count * sizeof(BvhNode) + (size_t) tri_count * sizeof(Tri);
     c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr;
-    if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS) {
+    if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS && c->rects.empty()) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
         // the SAH leaves (padded boxes, <= 4 triangles each) become the resident plan's candidate filter

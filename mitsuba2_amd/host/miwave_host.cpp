@@ -1062,10 +1062,20 @@ static bool miw_same_record(const mi_bsdf &back, const mi_bsdf &front_twosided) 
     mi_bsdf f = front_twosided; f.flags &= ~(uint32_t) MI_BSDF_FLAG_TWOSIDED;
     return std::memcmp(&back, &f, sizeof f) == 0;
 }
+std::shared_ptr<Mesh> make_rectangle(const Properties &props) {
+    Transform4f tw = props.transform("to_world", Transform4f());
+    if (props.bool_("flip_normals", false)) tw = tw * Transform4f::scale({ 1.f, 1.f, -1.f });   // rectangle.cpp:78-80
+    const float c[4][2] = { { -1, -1 }, { 1, -1 }, { 1, 1 }, { -1, 1 } };                       // bbox(), :98-105
+    std::vector<float> P;
+    for (auto &q : c) { miw::V3 w = miw::xf_point_affine(tw.m, miw::v3(q[0], q[1], 0.f)); P.insert(P.end(), { w.x, w.y, w.z }); }
+    auto mesh = std::make_shared<Mesh>("rectangle", std::move(P), std::vector<uint32_t>{ 0, 1, 2 });
+    mesh->m_rectangle = true; mesh->m_rect_to_world = tw;
+    return mesh;
+}
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
                     std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
-                    std::vector<mi_emitter> &erecs) {
-    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear();
+                    std::vector<mi_emitter> &erecs, std::vector<mi_rectangle> &rrecs) {
+    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear();
     bool any_normals = false;
     for (auto &m : shapes) any_normals = any_normals || m->has_vertex_normals();
     std::map<const BSDF *, uint32_t> bsdf_index;
@@ -1111,12 +1121,19 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
         }
         s.flags = m->has_vertex_normals() ? MI_SHAPE_HAS_NORMALS : 0;
         s.first_face = fbase; s.face_count = m->face_count();
+        if (m->is_rectangle()) {
+            s.flags |= MI_SHAPE_RECTANGLE;
+            mi_rectangle r{}; r.shape = (uint32_t) srecs.size();
+            std::memcpy(r.to_world, m->rectangle_to_world().m, 64); std::memcpy(r.to_object, m->rectangle_to_world().inv, 64);
+            rrecs.push_back(r);
+        }
         srecs.push_back(s);
     }
 }
 void Scene::build(int device, int bvh_quality) {
     if (m_shapes.empty()) Throw("Scene: no shapes");
-    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters);
+    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs);
+    m_desc.rectangles = m_rect_recs.empty() ? nullptr : m_rect_recs.data(); m_desc.rectangle_count = (uint32_t) m_rect_recs.size();
     m_desc.vertex_positions = m_positions.data();
     m_desc.vertex_normals = m_normals.empty() ? nullptr : m_normals.data();
     m_desc.vertex_count = (uint32_t) (m_positions.size() / 3);
@@ -1527,13 +1544,8 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
             if (p.plugin_name() == "obj" || p.plugin_name() == "ply") {
                 p.set_string("filename", resolve(cx, p.string("filename")));
                 mesh = p.plugin_name() == "obj" ? load_obj(p) : load_ply(p);
-            } else if (p.plugin_name() == "rectangle") {          // rectangle.cpp:73-92: [-1, 1]^2 in z = 0, normal +z — entered as two triangles
-                Transform4f tw = p.transform("to_world", Transform4f());
-                if (p.bool_("flip_normals", false)) tw = tw * Transform4f::scale({ 1.f, 1.f, -1.f });
-                const float c[4][2] = { { -1, -1 }, { 1, -1 }, { 1, 1 }, { -1, 1 } };
-                std::vector<float> P;
-                for (auto &q : c) { miw::V3 w = miw::xf_point_affine(tw.m, miw::v3(q[0], q[1], 0.f)); P.insert(P.end(), { w.x, w.y, w.z }); }
-                mesh = std::make_shared<Mesh>("rectangle", std::move(P), std::vector<uint32_t>{ 0, 1, 2, 0, 2, 3 });
+            } else if (p.plugin_name() == "rectangle") {
+                mesh = make_rectangle(p);
             } else Throw("Plugin \"" + p.plugin_name() + "\" not found!");
             for (const XmlNode *c : objs) {
                 if (c->tag == "bsdf") mesh->set_bsdf(parse_bsdf(cx, *c));
@@ -1581,6 +1593,8 @@ void mih_props_set_int(void *p, const char *n, int64_t v) { ((Properties *) p)->
 void mih_props_set_bool(void *p, const char *n, int v) { ((Properties *) p)->set_bool(n, v != 0); }
 void mih_props_set_string(void *p, const char *n, const char *v) { ((Properties *) p)->set_string(n, v); }
 void mih_props_set_color(void *p, const char *n, float r, float g, float b) { ((Properties *) p)->set_color(n, Color3f{ r, g, b }); }
+// 4x4 row-major matrix (what <matrix value="..."/> holds, xml.cpp)
+void mih_props_set_matrix(void *p, const char *n, const float *row_major16) { ((Properties *) p)->set_transform(n, Transform4f::from_matrix(row_major16)); }
 void mih_props_set_lookat(void *p, const char *n, const float *origin, const float *target, const float *up) {
     ((Properties *) p)->set_transform(n, Transform4f::look_at({ origin[0], origin[1], origin[2] },
                                                               { target[0], target[1], target[2] }, { up[0], up[1], up[2] }));
@@ -1639,6 +1653,9 @@ void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uin
         std::vector<uint32_t> f(faces, faces + 3 * (size_t) nf);
         std::vector<float> n; if (normals) n.assign(normals, normals + 3 * (size_t) nv);
         return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n)) }; MIH_CATCH(nullptr)
+}
+void *mih_rectangle_create(void *props) {                    // the `rectangle` shape plugin (analytic)
+    MIH_TRY return new Box<Mesh>{ make_rectangle(*(Properties *) props) }; MIH_CATCH(nullptr)
 }
 // kind 0 = obj, 1 = ply (the `obj` / `ply` shape plugins; props: filename, face_normals, flip_tex_coords, to_world)
 void *mih_mesh_load(int kind, void *props) {

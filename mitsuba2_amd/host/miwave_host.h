@@ -290,13 +290,22 @@ public:
     const std::shared_ptr<BSDF> &bsdf() const { return m_bsdf; }
     const std::shared_ptr<AreaLight> &emitter() const { return m_emitter; }
     const std::string &name() const { return m_name; }
+    // the analytic `rectangle` shape (make_rectangle): one primitive, intersected / sampled analytically on the
+    // device; its vertex buffer holds the four corners (scene bounds), its single face entry is a placeholder
+    bool is_rectangle() const { return m_rectangle; }
+    const Transform4f &rectangle_to_world() const { return m_rect_to_world; }
 private:
+    friend std::shared_ptr<Mesh> make_rectangle(const Properties &props);
     std::string m_name;
     std::vector<float> m_positions, m_normals;
     std::vector<uint32_t> m_faces;
     std::shared_ptr<BSDF> m_bsdf;
     std::shared_ptr<AreaLight> m_emitter;
+    bool m_rectangle = false; Transform4f m_rect_to_world;
 };
+// The `rectangle` shape plugin (src/shapes/rectangle.cpp:76-84): [-1, 1]^2 in z = 0, normal +z, properties
+// to_world (identity) and flip_normals (false). An analytic primitive — not two triangles.
+std::shared_ptr<Mesh> make_rectangle(const Properties &props);
 
 // Mesh file loaders: the `obj` and `ply` shape plugins.
 // Properties: filename, face_normals (false), to_world (identity); obj: flip_tex_coords (true).
@@ -334,6 +343,7 @@ private:
     std::vector<mi_shape> m_shape_recs;
     std::vector<mi_bsdf> m_bsdf_recs;
     std::vector<mi_emitter> m_emitters;
+    std::vector<mi_rectangle> m_rect_recs;
     std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;

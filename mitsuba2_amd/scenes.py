@@ -176,6 +176,39 @@ def plugin_box(width, height, spp, seed=0, device=0, rfilter="gaussian", **film_
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 
+def _rect(name, corners, inward_point, **kw):
+    """api.Mesh.rectangle over the parallelogram corners[0] + s * (corners[1] - corners[0]) + t * (corners[3] - corners[0]),
+    normal towards `inward_point`"""
+    c = np.asarray(corners, np.float64)
+    u, v = c[1] - c[0], c[3] - c[0]
+    if np.dot(np.cross(u, v), np.asarray(inward_point, np.float64) - c.mean(0)) < 0:
+        u, v = v, u
+    return api.Mesh.rectangle(api.quad_to_world(c[0], u, v), name=name, **kw)
+
+
+def rect_box_meshes():
+    """The Cornell box with analytic rectangles (src/shapes/rectangle.cpp) for the walls and for the area light,
+    triangle meshes for the two blocks, and a free-standing twosided rectangle seen from both sides."""
+    white = api.BSDF("diffuse", reflectance=WHITE)
+    red = api.BSDF("diffuse", reflectance=RED)
+    green = api.BSDF("diffuse", reflectance=GREEN)
+    shapes = []
+    for name, bsdf in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        shapes.append(_rect(name, _CBOX[name], _ROOM_CENTER, bsdf=bsdf))
+    shapes.append(_rect("light", _CBOX["light"], _ROOM_CENTER, emitter=api.AreaLight(LIGHT_RADIANCE)))
+    v, f = _block(_SHORT); shapes.append(api.Mesh("short_block", v, f, bsdf=white))
+    v, f = _block(_TALL); shapes.append(api.Mesh("tall_block", v, f, bsdf=white))
+    panel = api.TwoSided(api.BSDF("diffuse", reflectance=(0.2, 0.3, 0.8)), api.BSDF("diffuse", reflectance=(0.8, 0.7, 0.2)))
+    shapes.append(_rect("panel", [(60, 0, 330), (150, 0, 460), (150, 220, 460), (60, 220, 330)], (0, 100, 600), bsdf=panel))
+    return shapes
+
+
+def rect_box(width, height, spp, seed=0, device=0, rfilter="gaussian", **film_kw):
+    """-> (scene, sensor): analytic rectangles + meshes (rect_box_meshes)"""
+    scene = api.Scene(rect_box_meshes()).build(device)
+    return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
+
+
 def sky_envmap(width=64, height=32, seed=1):
     """Synthetic lat-long HDR sky (the reference's data submodule is absent): vertical sky
     gradient, warm horizon band, dark ground, a sun blob and a little seeded noise. -> H x W x 3 float32."""

@@ -48,6 +48,7 @@
 #include "../mitsuba2_amd/csrc/miw/scene.h"
 #include "../mitsuba2_amd/csrc/miw/film.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
+#include "../mitsuba2_amd/csrc/rect_build.h"
 
 using namespace miw;
 
@@ -68,7 +69,8 @@ struct FtzScope {
 
 // ---- scene in scene order (no acceleration structure: brute force) ------------------------
 struct OScene {
-    std::vector<Tri> tris;              // face order == global primitive id
+    std::vector<Tri> tris;              // face order == global primitive id; pad = k + 1: the slot of analytic rectangle k
+    std::vector<RectRec> rects;         // analytic rectangles (src/shapes/rectangle.cpp)
     std::vector<float> tri_vn;          // 9 per face or empty
     std::vector<ShapeRec> shapes;
     std::vector<BsdfRec> bsdfs;
@@ -91,8 +93,16 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris[f].shape = i;
     }
     if (any_normals) o.tri_vn.assign((size_t) s->face_count * 9, 0.f);
+    o.rects.clear();
+    for (uint32_t k = 0; k < s->rectangle_count; ++k) {        // Rectangle(props) + update(), rectangle.cpp:76-96
+        const mi_rectangle &q = s->rectangles[k];
+        const uint32_t f = s->shapes[q.shape].first_face;
+        o.rects.push_back(rect_record(q.to_world, q.to_object, q.shape, f));
+        o.tris[f].pad = k + 1u; o.tris[f].prim = f;
+    }
     for (uint32_t f = 0; f < s->face_count; ++f) {
         Tri &t = o.tris[f];
+        if (t.pad) continue;                                  // a rectangle's primitive slot
         for (int k = 0; k < 3; ++k) {
             uint32_t vi = s->faces[3 * f + k];
             float *dst = k == 0 ? t.p0 : (k == 1 ? t.p1 : t.p2);
@@ -132,6 +142,13 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
 #else
         r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
 #endif
+        if (sh.flags & MI_SHAPE_RECTANGLE) {                   // Rectangle::sample_position / pdf_position: no tables
+            const uint32_t k = o.tris[sh.first_face].pad - 1u;
+            r.shape = e.shape; r.tri_first = k; r.tri_count = 0; r.flags = 2u;
+            r.normalization = o.rects[k].inv_area; r.sum = rcp(o.rects[k].inv_area);
+            o.emitters.push_back(r);
+            continue;
+        }
         r.shape = e.shape; r.tri_first = (uint32_t) o.emit_pmf.size(); r.tri_count = sh.face_count;
         r.flags = (sh.flags & 1u);
         emit_normals = emit_normals || r.flags;
@@ -161,6 +178,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     SceneView &v = o.view;
     v.env = s->envmap ? &o.env.rec : nullptr;
+    v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
     v.leaf_boxes = nullptr;
     v.nodes = nullptr; v.node_count = 0;
     v.tris = o.tris.data(); v.tri_count = (uint32_t) o.tris.size();
@@ -183,7 +201,8 @@ OHit ray_intersect_preliminary(const OScene &sc, const Ray &ray) {
     for (uint32_t i = 0; i < sc.tris.size(); ++i) {
         const Tri &tr = sc.tris[i];
         float t, u, v;
-        if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) {
+        // kdtree.h:2362-2391 intersect_prim: the mesh's triangle test or the shape's own ray_intersect_preliminary
+        if (prim_intersect(tr, sc.rects.data(), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) {
             if (t < best.t || (t == best.t && i < best.prim)) { best.valid = true; best.t = t; best.u = u; best.v = v; best.prim = i; }
         }
     }
@@ -192,7 +211,7 @@ OHit ray_intersect_preliminary(const OScene &sc, const Ray &ray) {
 bool ray_test(const OScene &sc, const Ray &ray) {
     for (const Tri &tr : sc.tris) {
         float t, u, v;
-        if (ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) return true;
+        if (prim_intersect(tr, sc.rects.data(), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) return true;
     }
     return false;
 }
@@ -201,8 +220,12 @@ bool ray_intersect(const OScene &sc, const Ray &ray, SurfaceInteraction &si) {
     OHit h = ray_intersect_preliminary(sc, ray);
     if (!h.valid) { si.t = std::numeric_limits<float>::infinity(); si.wi = -ray.d; return false; }
     const Tri &tr = sc.tris[h.prim];
-    const float *vn = (sc.shapes[tr.shape].flags & 1u) ? &sc.tri_vn[(size_t) h.prim * 9] : nullptr;
-    compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.t, h.u, h.v, ray.d, si);
+    if (tr.pad) {                                          // Rectangle::compute_surface_interaction, rectangle.cpp:175-208
+        compute_surface_interaction_rect(sc.rects[tr.pad - 1u], h.t, h.u, h.v, ray.o, ray.d, si);
+    } else {
+        const float *vn = (sc.shapes[tr.shape].flags & 1u) ? &sc.tri_vn[(size_t) h.prim * 9] : nullptr;
+        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.t, h.u, h.v, ray.d, si);
+    }
     si.shape = tr.shape; si.prim = h.prim;
     return true;
 }

@@ -18,13 +18,14 @@
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
+#include "../mitsuba2_amd/csrc/rect_build.h"
 
 using namespace miw;
 
 namespace {
 struct EmuScene {
     std::vector<Tri> tris_in; std::vector<float> vn_in;
-    std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters;
+    std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters; std::vector<RectRec> rects;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     BvhBuildResult bvh; std::vector<float> vn_leaf;
     EnvmapTables env;
@@ -43,9 +44,21 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         any_normals = any_normals || (sh.flags & 1u);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris_in[f].shape = i;
     }
-    if (any_normals) o.vn_in.assign((size_t) s->face_count * 9, 0.f);
+    // analytic rectangles: record + two bounding triangles (the second one behind the faces), as mi_scene_upload
+    o.rects.clear();
+    o.tris_in.resize((size_t) s->face_count + s->rectangle_count);
+    for (uint32_t k = 0; k < s->rectangle_count; ++k) {
+        const mi_rectangle &q = s->rectangles[k];
+        const uint32_t f = s->shapes[q.shape].first_face;
+        o.rects.push_back(rect_record(q.to_world, q.to_object, q.shape, f));
+        Tri two[2];
+        rect_bounding_tris(o.rects.back(), k, two);
+        o.tris_in[f] = two[0]; o.tris_in[(size_t) s->face_count + k] = two[1];
+    }
+    if (any_normals) o.vn_in.assign(o.tris_in.size() * 9, 0.f);
     for (uint32_t f = 0; f < s->face_count; ++f) {
         Tri &t = o.tris_in[f];
+        if (t.pad) continue;
         for (int k = 0; k < 3; ++k) {
             uint32_t vi = s->faces[3 * f + k];
             float *dst = k == 0 ? t.p0 : (k == 1 ? t.p1 : t.p2);
@@ -84,6 +97,13 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
 #else
         r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
 #endif
+        if (sh.flags & MI_SHAPE_RECTANGLE) {
+            const uint32_t k = o.tris_in[sh.first_face].pad - 1u;
+            r.shape = e.shape; r.tri_first = k; r.tri_count = 0; r.flags = 2u;
+            r.normalization = o.rects[k].inv_area; r.sum = rcp(o.rects[k].inv_area);
+            o.emitters.push_back(r);
+            continue;
+        }
         r.shape = e.shape; r.tri_first = (uint32_t) o.emit_pmf.size(); r.tri_count = sh.face_count; r.flags = sh.flags & 1u;
         emit_normals = emit_normals || r.flags;
         double sum = 0.0; uint32_t vlo = 0xffffffffu, vhi = 0;
@@ -122,6 +142,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
     v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr;
+    v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
     return true;
 }
 // plain IEEE float environment (denormals preserved), see miw_oracle.cpp FtzScope
@@ -136,13 +157,13 @@ int emu_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_so
     EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
     Ftz ftz;
     if (stats3) { stats3[0] = sc.view.node_count; stats3[1] = sc.view.tri_count; stats3[2] = sc.bvh.depth; }
-    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris;
+    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const RectRec *rects = sc.view.rects;
     auto node_at = [nodes](int32_t i) -> const BvhNode & { return nodes[i]; };
     auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
     for (uint64_t i = 0; i < n; ++i) {
         RayPrep rp = ray_prepare(v3(r->ox[i], r->oy[i], r->oz[i]), v3(r->dx[i], r->dy[i], r->dz[i]), r->mint[i], r->maxt[i]);
         Hit hit; bool ok;
-        if (any_hit) ok = bvh_intersect<true>(node_at, tri_at, rp, hit); else ok = bvh_intersect<false>(node_at, tri_at, rp, hit);
+        if (any_hit) ok = bvh_intersect<true>(node_at, tri_at, rp, hit, rects); else ok = bvh_intersect<false>(node_at, tri_at, rp, hit, rects);
         h->t[i] = ok ? hit.t : MIW_INFINITY;
         if (h->u) h->u[i] = hit.u;
         if (h->v) h->v[i] = hit.v;
@@ -203,7 +224,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         lane_init(P, Q, lane, pixel[lane], cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
 #endif
     }
-    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris;
+    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const RectRec *rects = sc.view.rects;
     auto node_at = [nodes](int32_t i) -> const BvhNode & { return nodes[i]; };
     auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
     auto add = [film64](int texel, int k, float v) { film64[(size_t) texel * 5 + k] += (double) v; };
@@ -221,10 +242,10 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
         auto trace2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
             Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS;
-            if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h); }
+            if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h, rects); }
             hE.x = h.t; hE.y = h.u; hE.z = h.v; hE.w = u2f(h.tri);
             occS = false;
-            if (hasS) { Hit hs; RayPrep rp = ray_prepare(o, dS, mint, maxtS); occS = bvh_intersect<true>(node_at, tri_at, rp, hs); }
+            if (hasS) { Hit hs; RayPrep rp = ray_prepare(o, dS, mint, maxtS); occS = bvh_intersect<true>(node_at, tri_at, rp, hs, rects); }
         };
         for (uint32_t done = 0; done < cfg->spp; ) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
@@ -250,13 +271,13 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             F4 d = sh_d[lane]; if (d.w < 0.f) continue;
             F4 o = ray_o[lane]; Hit h;
             RayPrep rp = ray_prepare(v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w);
-            sh_vis[lane] = bvh_intersect<true>(node_at, tri_at, rp, h) ? 0u : 1u;
+            sh_vis[lane] = bvh_intersect<true>(node_at, tri_at, rp, h, rects) ? 0u : 1u;
         }
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_trace<closest>
             F4 d = ray_d[lane]; if (d.w < 0.f) continue;
             F4 o = ray_o[lane]; Hit h;
             RayPrep rp = ray_prepare(v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w);
-            bvh_intersect<false>(node_at, tri_at, rp, h);
+            bvh_intersect<false>(node_at, tri_at, rp, h, rects);
             F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri); hit[lane] = r;
         }
         uint64_t active = 0;

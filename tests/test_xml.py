@@ -65,7 +65,8 @@ def test_xml_scene_equals_the_same_scene_built_by_hand(native, oracle, tmp_path)
     scene, sensor, integ = native.load_file(tmp_path / "corner.xml", depth=5)
     scene.build(-1)
     d = scene.desc().contents
-    assert d.face_count == 6 and d.shape_count == 3 and d.emitter_count == 1 and d.bsdf_count == 3
+    assert d.face_count == 4 and d.shape_count == 3 and d.emitter_count == 1 and d.bsdf_count == 3
+    assert d.rectangle_count == 2                                   # <shape type="rectangle"> is the analytic primitive
     job = integ.render_job(sensor)
     assert (job.cfg.crop_w, job.cfg.crop_h, job.cfg.spp, job.cfg.max_depth, job.cfg.rr_depth, job.cfg.base_seed) == (32, 24, 4, 5, 3, 7)
     assert abs(job.cfg.filter_radius - 0.5) < 1e-3                  # <rfilter type="box"/> (box.cpp: radius 0.5 + eps)
@@ -77,7 +78,8 @@ def test_xml_scene_equals_the_same_scene_built_by_hand(native, oracle, tmp_path)
     metal = native.BSDF("roughconductor", distribution="ggx", alpha=0.2, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
     fl = np.asarray(scene.desc().contents.vertex_positions[:3 * 12], np.float32).reshape(12, 3)      # as transformed by the loader
     q = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
-    meshes = [native.Mesh("floor", fl[0:4], q, bsdf=white), native.Mesh("back", fl[4:8], q, bsdf=metal),
+    tw = [np.array(scene.desc().contents.rectangles[i].to_world[:], np.float32).reshape(4, 4).T for i in range(2)]
+    meshes = [native.Mesh.rectangle(tw[0], bsdf=white), native.Mesh.rectangle(tw[1], bsdf=metal),
               native.Mesh("light", fl[8:12], q, bsdf=native.BSDF("diffuse", reflectance=0.0), emitter=native.AreaLight((17.0, 12.0, 4.0)))]
     scene2 = native.Scene(meshes).build(-1)
     film = native.Film(rfilter="box", width=32, height=24)
