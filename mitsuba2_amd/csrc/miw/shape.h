@@ -83,9 +83,11 @@ MIW_HD bool ray_intersect_rectangle(const RectRec &r, V3 o, V3 d, float mint, fl
 }
 // the leaf test of every scene query: Mesh::ray_intersect_triangle or the analytic shape's own routine
 // (kdtree.h:2362-2391 intersect_prim)
+// (Analytic = false: the caller knows the scene holds triangles only and compiles the branch out)
+template <bool Analytic = true>
 MIW_HD bool prim_intersect(const Tri &tr, const RectRec *rects, V3 o, V3 d, float mint, float maxt,
                            float &t, float &u, float &v) {
-    if (tr.pad) return ray_intersect_rectangle(rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
+    if (Analytic && tr.pad) return ray_intersect_rectangle(rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
     return ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), o, d, mint, maxt, t, u, v);
 }
 

@@ -151,7 +151,7 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 #ifndef MIW_TREE_WAVES
 #define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
 #endif
-template <bool AnyHit, typename NodeAt, typename TriAt>
+template <bool AnyHit, bool Analytic, typename NodeAt, typename TriAt>
 __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
                                                     V3 o, V3 d, float mint, float maxt, Hit &best, const RectRec *rects) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
             for (uint32_t i = 0; i < count; ++i) {
                 const Tri &tr = tri_at(first + i);
                 float t, u, v;
-                if (prim_intersect(tr, rects, o, d, mint, maxt, t, u, v)) {
+                if (prim_intersect<Analytic>(tr, rects, o, d, mint, maxt, t, u, v)) {
                     if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
                     if (t < best.t || (t == best.t && tr.prim < best.prim)) {
                         best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
@@ -212,7 +212,7 @@ __device__ __forceinline__ bool trace_brute(const SceneView &sc, const uint4 *sm
     return h.tri != MIW_MISS;
 }
 
-template <bool AnyHit>
+template <bool AnyHit, bool Analytic = true>
 __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                           V3 o, V3 d, float mint, float maxt, Hit &h) {
     if (cfg.brute) return trace_brute<AnyHit>(sc, smem, o, d, mint, maxt, h);
@@ -234,7 +234,7 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
         if (cfg.stack) {
             int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
-            return bvh_intersect_stack<AnyHit>(node_at, tri_at, stack, o, d, mint, maxt, h, sc.rects);
+            return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, sc.rects);
         }
         return bvh_intersect<AnyHit>(node_at, tri_at, r, h, sc.rects);
     }
@@ -252,7 +252,7 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
 // "any triangle passes" for S.
 // `Tiny` selects the code that is compiled in: the two-phase LDS query (tiny scenes) or the tree walks —
 // one kernel per scene class keeps each one's register budget (occupancy) to what it needs.
-template <int Tiny>
+template <int Tiny, bool Analytic = true>
 __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                        V3 o, float mint, V3 dE, float maxtE, bool hasE,
                                        V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
@@ -300,8 +300,8 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (hasE) trace_brute<false>(sc, smem, o, dE, mint, maxtE, h);
         if (hasS) { Hit hs; occ = trace_brute<true>(sc, smem, o, dS, mint, maxtS, hs); }
     } else {
-        if (hasE) trace_one<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
-        if (hasS) { Hit hs; occ = trace_one<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+        if (hasE) trace_one<false, Analytic>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_one<true, Analytic>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
     }
     hit_out.x = h.t; hit_out.y = h.u; hit_out.z = h.v; hit_out.w = u2f(h.tri);
     occ_out = occ;
@@ -560,7 +560,8 @@ struct QueueWork {
     }
 };
 
-template <bool UseLog, int Tiny, int Mats = MATS_ALL>
+// Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
+template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0)>
 __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -585,11 +586,11 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_r
     }
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
     auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
-        trace2<Tiny>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
+        trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
-        pixel_stream_render<Mats, Tiny == 0>(P, sc, sample_end, work, tr2, &local);   // packet scenes hold triangles only
+        pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
@@ -1766,11 +1767,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
-#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
+#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: 32-bit candidate masks up to 32 triangles; no BSDF dispatch when every shape is plain diffuse
                 if (tiny && c->view.tri_count <= 32u) { if (c->diffuse_only) MIW_PATH_LAUNCH(2, MATS_DIFFUSE); else MIW_PATH_LAUNCH(2, MATS_ALL); }
                 else if (tiny)                        { if (c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE); else MIW_PATH_LAUNCH(1, MATS_ALL); }
-                else MIW_PATH_LAUNCH(0, MATS_ALL);
+                else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_ALL);
+                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
             } else if (tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
