@@ -562,7 +562,7 @@ struct QueueWork {
 
 // Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
 template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0)>
-__global__ __launch_bounds__(MIW_BLOCK, Tiny ? 3 : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+__global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
@@ -1766,11 +1766,20 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             if (film_mode == 1) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
-                const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * 4u));
+                // persistent grid: 4 workgroups per CU. The plain-diffuse packet kernel is compiled for 4 waves per SIMD
+                // (123 VGPRs; +8 % over 3 on C2); when the shard holds fewer than ~1.5 pixels per resident lane it is
+                // launched 3 per CU instead, so that lanes refill from the queue rather than idle behind their
+                // wavefront's longest pixel (8-GPU shard of C2: 46.5 vs 47.3 ms).
+                unsigned wg_per_cu = 4u;
+                if (tiny && c->diffuse_only && (double) n_lanes < 1.5 * (double) c->cu_count * 4.0 * MIW_BLOCK) wg_per_cu = 3u;
+                if (const char *e = getenv("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
+                const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * wg_per_cu));
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
-                // kernel variants: 32-bit candidate masks up to 32 triangles; no BSDF dispatch when every shape is plain diffuse
-                if (tiny && c->view.tri_count <= 32u) { if (c->diffuse_only) MIW_PATH_LAUNCH(2, MATS_DIFFUSE); else MIW_PATH_LAUNCH(2, MATS_ALL); }
-                else if (tiny)                        { if (c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE); else MIW_PATH_LAUNCH(1, MATS_ALL); }
+                // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
+                // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
+                if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
+                else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_ALL);
+                else if (tiny) MIW_PATH_LAUNCH(1, MATS_ALL);
                 else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_ALL);
                 else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
