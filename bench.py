@@ -145,8 +145,9 @@ def main():
             "k_trace<any>": (agg["ms_ta"], agg["n_ta"], B_TRACE_ANY * agg["shadow"]),
             # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
             "k_path_resident": (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
-            # ordered film replay: reads the 24 B/sample log once, writes the block tiles
-            "k_film_blocks": (agg["ms_fb"], agg["n_film"], 24.0 * agg["samples"]),
+            # ordered film replay: reads the 24 B/sample log, writes the block tiles (k_film_groups after k_film_pack
+            # for footprints <= 4x4, else k_film_blocks)
+            ("k_film_groups" if agg["ms_fp"] > 0 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], 24.0 * agg["samples"]),
         }
         roofline = None
         if not args.no_profile and (agg["n_shade"] or agg["n_path"]):
