@@ -41,9 +41,11 @@ enum {
  * [first_face, first_face + face_count): global primitive id == face index,
  * like ShapeKDTree::m_primitive_map (kdtree.h:2335-2353). */
 
-enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2, MI_BSDF_CONDUCTOR = 3, MI_BSDF_PLASTIC = 4 };
+enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2, MI_BSDF_CONDUCTOR = 3, MI_BSDF_PLASTIC = 4,
+       MI_BSDF_ROUGHDIELECTRIC = 5 };
 enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2,            /* roughconductor */
        MI_BSDF_FLAG_NONLINEAR = 1, MI_BSDF_FLAG_HAS_SPECULAR = 2,          /* plastic */
+       MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE = 4, MI_BSDF_FLAG_HAS_SPEC_TRANSMITTANCE = 8,   /* roughdielectric (+ GGX, SAMPLE_VISIBLE) */
        MI_BSDF_FLAG_TWOSIDED = 0x100 };                                    /* any type: wrapped by <bsdf type="twosided"> */
 enum { MI_SHAPE_HAS_NORMALS = 1,
        MI_SHAPE_RECTANGLE = 2 };   /* analytic rectangle (src/shapes/rectangle.cpp): face_count == 1 — the shape's single
@@ -69,12 +71,15 @@ typedef struct {
      * conductor (src/bsdfs/conductor.cpp:201-215):  [2..4] eta, [5..7] k, [8..10] specular_reflectance
      * plastic (src/bsdfs/plastic.cpp:135-174):      [0] eta = int_ior/ext_ior, [1] 1/eta^2, [2] fdr_int,
      *                                              [3] specular_sampling_weight, [4..6] diffuse_reflectance,
-     *                                              [7..9] specular_reflectance (MI_BSDF_FLAG_HAS_SPECULAR) */
+     *                                              [7..9] specular_reflectance (MI_BSDF_FLAG_HAS_SPECULAR)
+     * roughdielectric (src/bsdfs/roughdielectric.cpp:146-201): [0] alpha_u, [1] alpha_v, [2] eta, [3] 1/eta,
+     *                                              [4..6] specular_reflectance, [7..9] specular_transmittance */
     float params[14];
     /* scalar_spectral (and optionally scalar_rgb: used when tex[0].type != MI_TEX_RGB or params carry no colour):
      * diffuse: tex[0] reflectance; dielectric: tex[0] specular_reflectance, tex[1] specular_transmittance;
      * roughconductor / conductor: tex[0] eta, tex[1] k, tex[2] specular_reflectance; plastic: tex[0]
-     * diffuse_reflectance, tex[1] specular_reflectance. The scalar_rgb library derives these from params[] itself. */
+     * diffuse_reflectance, tex[1] specular_reflectance; roughdielectric: tex[0] specular_reflectance, tex[1]
+     * specular_transmittance. The scalar_rgb library derives these from params[] itself. */
     mi_texture tex[3];
     uint32_t back;        /* MI_BSDF_FLAG_TWOSIDED: index of the back side's record (its own index: same BSDF on both
                              sides, src/bsdfs/twosided.cpp:72-73); else 0 */

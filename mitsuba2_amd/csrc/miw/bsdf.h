@@ -18,14 +18,15 @@ namespace miw {
 
 // BSDFFlags subset (include/mitsuba/render/bsdf.h:40-124)
 enum : uint32_t {
-    BSDF_DiffuseReflection = 0x00002, BSDF_GlossyReflection = 0x00008,
+    BSDF_DiffuseReflection = 0x00002, BSDF_GlossyReflection = 0x00008, BSDF_GlossyTransmission = 0x00010,
+    BSDF_Transmission = 0x00004 | 0x00010 | 0x00040,
     BSDF_DeltaReflection   = 0x00020, BSDF_DeltaTransmission = 0x00040,
     BSDF_Smooth = 0x00002 | 0x00004 | 0x00008 | 0x00010,
     BSDF_Delta  = 0x00001 | 0x00020 | 0x00040,
 };
 
 enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2,
-                  BSDF_TYPE_CONDUCTOR = 3, BSDF_TYPE_PLASTIC = 4, BSDF_TYPE_COUNT = 5 };
+                  BSDF_TYPE_CONDUCTOR = 3, BSDF_TYPE_PLASTIC = 4, BSDF_TYPE_ROUGHDIELECTRIC = 5, BSDF_TYPE_COUNT = 6 };
 // record flag bits: 0-1 belong to the type (roughconductor: GGX, sample_visible; plastic: nonlinear, has
 // specular_reflectance); bit 8 marks a record wrapped by the twosided adapter, whose back side is record `back`
 enum : uint32_t { BSDF_REC_TWOSIDED = 0x100u };
@@ -41,6 +42,9 @@ enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
 //   plastic:        p[0] eta, p[1] 1/eta^2, p[2] fdr_int, p[3] specular_sampling_weight (plastic.cpp:163-174),
 //                   tex[0] diffuse_reflectance, tex[1] specular_reflectance; flags bit0 = nonlinear,
 //                   bit1 = specular_reflectance given
+//   roughdielectric: p[0] alpha_u, p[1] alpha_v, p[2] eta, p[3] 1/eta (roughdielectric.cpp:160,200), tex[0]
+//                   specular_reflectance, tex[1] specular_transmittance; flags bit0 = GGX, bit1 = sample_visible,
+//                   bit2 / bit3 = specular_reflectance / specular_transmittance given
 //   twosided:       the FRONT record with BSDF_REC_TWOSIDED set; `back` = table index of the back side's record
 // (scalar_rgb callers may fill only p[] in the legacy layout — diffuse p[0..2]; dielectric p[1..3],
 //  p[4..6]; roughconductor p[2..4], p[5..7], p[8..10] — the uploader derives the TEX_RGB records.)
@@ -50,7 +54,8 @@ struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
 
 // texture slots a record of this type reads
 MIW_HD uint32_t bsdf_tex_slots(uint32_t type) {
-    return type == BSDF_TYPE_DIFFUSE ? 1u : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_PLASTIC) ? 2u : 3u;
+    return type == BSDF_TYPE_DIFFUSE ? 1u
+         : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_PLASTIC || type == BSDF_TYPE_ROUGHDIELECTRIC) ? 2u : 3u;
 }
 
 MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
@@ -59,6 +64,7 @@ MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
         case BSDF_TYPE_DIELECTRIC: return BSDF_DeltaReflection | BSDF_DeltaTransmission;
         case BSDF_TYPE_CONDUCTOR:  return BSDF_DeltaReflection;                          // conductor.cpp:202
         case BSDF_TYPE_PLASTIC:    return BSDF_DeltaReflection | BSDF_DiffuseReflection; // plastic.cpp:156-158
+        case BSDF_TYPE_ROUGHDIELECTRIC: return BSDF_GlossyReflection | BSDF_GlossyTransmission;   // roughdielectric.cpp:189-194
         default:                   return BSDF_GlossyReflection;
     }
 }
@@ -428,6 +434,104 @@ MIW_HD float plastic_pdf(const BsdfRec &b, V3 wi, V3 wo) {
     return square_to_cosine_hemisphere_pdf(wo) * prob_diffuse;
 }
 
+// ---- RoughDielectric (roughdielectric.cpp:204-441; both lobes enabled, TransportMode::Radiance) ------------
+MIW_HD V3 refract(V3 wi, V3 m, float cos_theta_t, float eta_ti) {            // fresnel.h:310-313
+    return fmsub3(m, fmadd(dot(wi, m), eta_ti, cos_theta_t), wi * eta_ti);
+}
+MIW_HD V3 mulsign3(V3 v, float s) { return v3(mulsign(v.x, s), mulsign(v.y, s), mulsign(v.z, s)); }
+MIW_HD Microfacet rd_distr(const BsdfRec &b) {
+    return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[1], (b.flags & 2u) != 0);
+}
+// :204-316
+MIW_HD Spec roughdielectric_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    const float eta = b.p[2];
+    float cos_theta_i = wi.z;
+    bool active = cos_theta_i != 0.f;                                // :219
+    Microfacet distr = rd_distr(b), sample_distr = distr;
+    if (!distr.sample_visible) {                                     // :230-232, microfacet.h:173-176
+        float scale = 1.2f - .2f * __builtin_sqrtf(abs_(cos_theta_i));
+        sample_distr.alpha_u *= scale; sample_distr.alpha_v *= scale;
+    }
+    V3 m;
+    mf_sample(sample_distr, mulsign3(wi, cos_theta_i), sample2, m, bs.pdf);   // :235-237
+    active = active && bs.pdf != 0.f;
+    float F, cos_theta_t, eta_it, eta_ti;
+    fresnel(dot(wi, m), eta, F, cos_theta_t, eta_it, eta_ti);        // :240-241
+    bool selected_r = sample1 <= F && active;                        // :247
+    Spec weight = spec(1.f);
+    bs.pdf *= selected_r ? F : 1.f - F;
+    bool selected_t = !selected_r && active;
+    bs.eta = selected_r ? 1.f : eta_it;                              // :261-265
+    bs.sampled_type = selected_r ? BSDF_GlossyReflection : BSDF_GlossyTransmission;
+    float dwh_dwo = 0.f;
+    if (selected_r) {                                                // :270-279
+        bs.wo = reflect(wi, m);
+        if (b.flags & 4u) weight = weight * tex_eval(b.tex[0], wl);
+        dwh_dwo = rcp(4.f * dot(bs.wo, m));
+    }
+    if (selected_t) {                                                // :282-300
+        bs.wo = refract(wi, m, cos_theta_t, eta_ti);
+        Spec factor = spec(sqr(eta_ti));
+        if (b.flags & 8u) factor = factor * tex_eval(b.tex[1], wl);
+        weight = weight * factor;
+        dwh_dwo = (sqr(bs.eta) * dot(bs.wo, m)) / sqr(dot(wi, m) + bs.eta * dot(bs.wo, m));
+    }
+    if (distr.sample_visible) weight = weight * mf_smith_g1(distr, bs.wo, m);                  // :302-306
+    else weight = weight * (mf_G(distr, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z));
+    bs.pdf *= abs_(dwh_dwo);
+    return active ? weight : spec(0.f);
+}
+// :318-386
+MIW_HD Spec roughdielectric_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+    const float m_eta = b.p[2], m_inv_eta = b.p[3];
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    bool active = cos_theta_i != 0.f;
+    bool reflect_ = cos_theta_i * cos_theta_o > 0.f;
+    float eta = cos_theta_i > 0.f ? m_eta : m_inv_eta, inv_eta = cos_theta_i > 0.f ? m_inv_eta : m_eta;
+    V3 m = normalize(wi + wo * (reflect_ ? 1.f : eta));              // :339
+    m = mulsign3(m, m.z);                                            // :342
+    Microfacet distr = rd_distr(b);
+    float D = mf_eval(distr, m);
+    float F, ct, a, c;
+    fresnel(dot(wi, m), m_eta, F, ct, a, c);
+    float G = mf_G(distr, wi, wo, m);
+    if (!active) return spec(0.f);
+    if (reflect_) {                                                  // :363-370
+        Spec value = spec(F * D * G / (4.f * abs_(cos_theta_i)));
+        if (b.flags & 4u) value = value * tex_eval(b.tex[0], wl);
+        return value;
+    }
+    float scale = sqr(inv_eta);                                      // :376
+    Spec value = spec(abs_((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) /
+                           (cos_theta_i * sqr(dot(wi, m) + eta * dot(wo, m)))));             // :379-381
+    if (b.flags & 8u) value = value * tex_eval(b.tex[1], wl);
+    return value;
+}
+// :388-441
+MIW_HD float roughdielectric_pdf(const BsdfRec &b, V3 wi, V3 wo) {
+    const float m_eta = b.p[2], m_inv_eta = b.p[3];
+    float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    bool active = cos_theta_i != 0.f;
+    bool reflect_ = cos_theta_i * cos_theta_o > 0.f;
+    float eta = cos_theta_i > 0.f ? m_eta : m_inv_eta;
+    V3 m = normalize(wi + wo * (reflect_ ? 1.f : eta));
+    m = mulsign3(m, m.z);
+    active = active && dot(wi, m) * wi.z > 0.f && dot(wo, m) * wo.z > 0.f;     // :415-416
+    float dwh_dwo = reflect_ ? rcp(4.f * dot(wo, m))
+                             : (eta * eta * dot(wo, m)) / sqr(dot(wi, m) + eta * dot(wo, m));   // :419-421
+    Microfacet sample_distr = rd_distr(b);
+    if (!sample_distr.sample_visible) {                              // :434-435
+        float scale = 1.2f - .2f * __builtin_sqrtf(abs_(wi.z));
+        sample_distr.alpha_u *= scale; sample_distr.alpha_v *= scale;
+    }
+    float prob = mf_pdf(sample_distr, mulsign3(wi, wi.z), m);        // :438
+    float F, ct, a, c;
+    fresnel(dot(wi, m), m_eta, F, ct, a, c);
+    prob *= reflect_ ? F : 1.f - F;                                  // :440-443
+    return active ? prob * abs_(dwh_dwo) : 0.f;
+}
+
 // ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
 MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
@@ -436,6 +540,7 @@ MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDF
         case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, wl);
         case BSDF_TYPE_CONDUCTOR:  return conductor_sample(b, wi, bs, wl);
         case BSDF_TYPE_PLASTIC:    return plastic_sample(b, wi, sample1, sample2, bs, wl);
+        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_sample(b, wi, sample1, sample2, bs, wl);
         default:                   return roughconductor_sample(b, wi, sample2, bs, wl);
     }
 }
@@ -445,6 +550,7 @@ MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
         case BSDF_TYPE_DIELECTRIC: return spec(0.f);                 // dielectric.cpp:312-315
         case BSDF_TYPE_CONDUCTOR:  return spec(0.f);                 // conductor.cpp:263-266
         case BSDF_TYPE_PLASTIC:    return plastic_eval(b, wi, wo, wl);
+        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_eval(b, wi, wo, wl);
         default:                   return roughconductor_eval(b, wi, wo, wl);
     }
 }
@@ -454,6 +560,7 @@ MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {
         case BSDF_TYPE_DIELECTRIC: return 0.f;                       // dielectric.cpp:317-320
         case BSDF_TYPE_CONDUCTOR:  return 0.f;                       // conductor.cpp:268-271
         case BSDF_TYPE_PLASTIC:    return plastic_pdf(b, wi, wo);
+        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_pdf(b, wi, wo);
         default:                   return roughconductor_pdf(b, wi, wo);
     }
 }

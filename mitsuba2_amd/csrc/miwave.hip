@@ -1297,7 +1297,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
         if (b.flags & MI_BSDF_FLAG_TWOSIDED) {                 // twosided.cpp:62-92
             if (b.back >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "bsdf %u: back-side record %u out of range", i, b.back);
-            const uint32_t tr = BSDF_DeltaTransmission;
+            const uint32_t tr = BSDF_Transmission;
             BsdfRec probe; memset(&probe, 0, sizeof probe);
             probe.type = b.type; const uint32_t f0 = bsdf_flags(probe);
             probe.type = s->bsdfs[b.back].type; const uint32_t f1 = probe.type < BSDF_TYPE_COUNT ? bsdf_flags(probe) : 0u;
@@ -1312,7 +1312,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         }
 #else
         {   // legacy RGB layout of params[] -> texture records
-            const int off[5][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 } };
+            const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };
             for (int k = 0; k < 3; ++k) {
                 r.tex[k].type = TEX_RGB;
                 if (off[b.type][k] >= 0) memcpy(r.tex[k].v, b.params + off[b.type][k], 12);

@@ -765,11 +765,42 @@ SmoothPlastic::SmoothPlastic(const Properties &props) {
     m_rec.tex[0] = props.texture_record("diffuse_reflectance", .5f, false, false);
     m_rec.tex[1] = props.texture_record("specular_reflectance", 1.f, false, false);
 }
+RoughDielectric::RoughDielectric(const Properties &props) {
+    float int_ior = lookup_ior(props, "int_ior", "bk7"), ext_ior = lookup_ior(props, "ext_ior", "air");
+    if (int_ior < 0.f || ext_ior < 0.f || int_ior == ext_ior)
+        Throw("The interior and exterior indices of refraction must be positive and differ!");   // :155-157
+    const float eta = int_ior / ext_ior;
+    uint32_t flags = 0;
+    if (props.has_property("distribution")) {                  // :162-173 (default: beckmann)
+        std::string distr = to_lower(props.string("distribution"));
+        if (distr == "ggx") flags |= MI_BSDF_FLAG_GGX;
+        else if (distr != "beckmann") Throw("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+    }
+    if (props.bool_("sample_visible", true)) flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
+    float au, av;
+    if (props.has_property("alpha_u") || props.has_property("alpha_v")) {
+        if (!props.has_property("alpha_u") || !props.has_property("alpha_v"))
+            Throw("Microfacet model: both 'alpha_u' and 'alpha_v' must be specified.");
+        if (props.has_property("alpha")) Throw("Microfacet model: please specifyeither 'alpha' or 'alpha_u'/'alpha_v'.");
+        au = props.float_("alpha_u"); av = props.float_("alpha_v");
+    } else {
+        au = av = props.float_("alpha", 0.1f);
+    }
+    const bool has_r = props.has_property("specular_reflectance"), has_t = props.has_property("specular_transmittance");
+    Color3f sr = props.texture("specular_reflectance", 1.f), stt = props.texture("specular_transmittance", 1.f);
+    if (has_r) { check_reflectance(sr, "specular_reflectance"); flags |= MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE; }
+    if (has_t) { check_reflectance(stt, "specular_transmittance"); flags |= MI_BSDF_FLAG_HAS_SPEC_TRANSMITTANCE; }
+    m_rec.type = MI_BSDF_ROUGHDIELECTRIC; m_rec.flags = flags;
+    m_rec.params[0] = au; m_rec.params[1] = av; m_rec.params[2] = eta; m_rec.params[3] = 1.f / eta;   // parameters_changed(), :199-201
+    for (int i = 0; i < 3; ++i) { m_rec.params[4 + i] = sr[i]; m_rec.params[7 + i] = stt[i]; }
+    m_rec.tex[0] = props.texture_record("specular_reflectance", 1.f, false, false);
+    m_rec.tex[1] = props.texture_record("specular_transmittance", 1.f, false, false);
+}
 TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back) {
     if (!front) Throw("A nested one-sided material is required!");
     if (front->twosided() || (back && back->twosided())) Throw("twosided: nested twosided materials are not supported");
     if (!back) back = front;
-    if ((front->flags() | back->flags()) & miw::BSDF_DeltaTransmission)
+    if ((front->flags() | back->flags()) & miw::BSDF_Transmission)
         Throw("Only materials without a transmission component can be nested!");
     m_rec = front->record();
     m_rec.flags |= MI_BSDF_FLAG_TWOSIDED;
@@ -1462,6 +1493,7 @@ std::shared_ptr<BSDF> make_bsdf(const Properties &p) {
     if (t == "roughconductor") return std::make_shared<RoughConductor>(p);
     if (t == "conductor") return std::make_shared<SmoothConductor>(p);
     if (t == "plastic") return std::make_shared<SmoothPlastic>(p);
+    if (t == "roughdielectric") return std::make_shared<RoughDielectric>(p);
     Throw("Plugin \"" + t + "\" not found!");
 }
 std::shared_ptr<BSDF> parse_bsdf(XmlCtx &cx, const XmlNode &n) {
@@ -1609,6 +1641,7 @@ void *mih_bsdf_create(void *props) {
         else if (p.plugin_name() == "roughconductor") b = std::make_shared<RoughConductor>(p);
         else if (p.plugin_name() == "conductor") b = std::make_shared<SmoothConductor>(p);
         else if (p.plugin_name() == "plastic") b = std::make_shared<SmoothPlastic>(p);
+        else if (p.plugin_name() == "roughdielectric") b = std::make_shared<RoughDielectric>(p);
         else throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
         return new Box<BSDF>{ b }; MIH_CATCH(nullptr)
 }

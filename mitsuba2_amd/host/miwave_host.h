@@ -237,6 +237,7 @@ class SmoothDielectric final : public BSDF { public: explicit SmoothDielectric(c
 class RoughConductor final : public BSDF { public: explicit RoughConductor(const Properties &props); };      // roughconductor.cpp:146-194
 class SmoothConductor final : public BSDF { public: explicit SmoothConductor(const Properties &props); };    // conductor.cpp:201-215
 class SmoothPlastic final : public BSDF { public: explicit SmoothPlastic(const Properties &props); };        // plastic.cpp:135-174
+class RoughDielectric final : public BSDF { public: explicit RoughDielectric(const Properties &props); };    // roughdielectric.cpp:146-201
 // twosided.cpp:62-92: wraps one nested BRDF (both sides) or two (front, back); nested BSDFs must not transmit
 class TwoSidedBRDF final : public BSDF { public: explicit TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back = nullptr); };
 float fresnel_diffuse_reflectance(float eta);                                                                 // fresnel.h:327-361

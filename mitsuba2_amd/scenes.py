@@ -96,7 +96,7 @@ def icosphere(center, radius, level):
     return p.astype(np.float32), f.astype(np.uint32), n.astype(np.float32)
 
 
-def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None):
+def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None, glass=None):
     """-> list of api.Mesh. diffuse_only: the classic box (36 triangles, config C2).
     Otherwise the short block becomes a GGX rough-conductor ball with shading normals
     and the tall block a dielectric (bk7) ball — the material-ball configuration (C3)."""
@@ -118,7 +118,11 @@ def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None):
         if "alpha_u" in mkw:
             mkw.pop("alpha", None)
         metal = api.BSDF("roughconductor", **mkw)
-        glass = api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)
+        if glass is None:
+            glass = api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)
+        else:                                             # e.g. dict(plugin="roughdielectric", alpha=0.2, distribution="ggx")
+            gkw = dict(int_ior=1.5046, ext_ior=1.000277); gkw.update(glass)
+            glass = api.BSDF(gkw.pop("plugin", "roughdielectric"), **gkw)
         v, f, n = icosphere((185.0, 82.5, 169.0), 82.5, ball_level)
         meshes.append(api.Mesh("metal_ball", v, f, normals=n, bsdf=metal))
         v, f, n = icosphere((368.0, 110.0, 351.0), 110.0, ball_level)
@@ -135,10 +139,10 @@ def cornell_sensor(width, height, spp, seed=0, rfilter="gaussian", **film_kw):
 
 
 def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_level=5, rfilter="gaussian",
-                metal=None, **film_kw):
+                metal=None, glass=None, **film_kw):
     """-> (scene, sensor). device < 0 builds only the host-side description.
     `metal`: property overrides of the rough-conductor ball (e.g. dict(distribution="beckmann"))."""
-    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level, metal)).build(device)
+    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level, metal, glass)).build(device)
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 

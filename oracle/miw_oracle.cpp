@@ -121,7 +121,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
 #else
         {   // legacy RGB layout of params[] (include/miwave.h) -> texture records
-            const int off[5][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 } };
+            const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };
             for (int k = 0; k < 3; ++k) {
                 o.bsdfs[i].tex[k].type = TEX_RGB;
                 if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
