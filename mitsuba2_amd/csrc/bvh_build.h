@@ -140,18 +140,23 @@ struct Builder {
 
 } // namespace detail
 
-// `pad`: absolute box padding (see bvh.h); pass <0 to derive it from the scene extent.
+// The scene's padding unit: 1e-5 x the largest |coordinate|. A triangle hit counts iff its point lies inside the
+// triangle's bounds grown by ONE unit (shape.h: accept_pad); the BVH boxes are grown by TWO, so that such a hit is
+// never culled whatever the rounding of the slab tests (~1e-7 x the coordinates).
+inline float scene_pad_unit(const std::vector<Tri> &tris) {
+    float m = 0.f;
+    for (const Tri &t : tris)
+        for (int k = 0; k < 3; ++k) {
+            m = std::max(m, std::fabs(t.p0[k])); m = std::max(m, std::fabs(t.p1[k])); m = std::max(m, std::fabs(t.p2[k]));
+        }
+    return std::max(1e-5f * m, 1e-30f);
+}
+
+// `pad`: absolute box padding (see bvh.h); pass <0 to derive it from the scene extent (2 x scene_pad_unit).
 inline BvhBuildResult bvh_build_sah(const std::vector<Tri> &tris, float pad = -1.f, uint32_t max_leaf = 4) {
     BvhBuildResult out;
     if (max_leaf > 16) max_leaf = 16;
-    if (pad < 0.f) {
-        float m = 0.f;
-        for (const Tri &t : tris)
-            for (int k = 0; k < 3; ++k) {
-                m = std::max(m, std::fabs(t.p0[k])); m = std::max(m, std::fabs(t.p1[k])); m = std::max(m, std::fabs(t.p2[k]));
-            }
-        pad = std::max(1e-5f * m, 1e-30f);
-    }
+    if (pad < 0.f) pad = 2.f * scene_pad_unit(tris);
     const float inf = std::numeric_limits<float>::infinity();
     auto set_empty = [&](float *lo, float *hi) { for (int a = 0; a < 3; ++a) { lo[a] = inf; hi[a] = -inf; } };
 

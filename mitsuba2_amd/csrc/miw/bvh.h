@@ -56,7 +56,7 @@ struct Hit { float t, u, v; uint32_t tri; uint32_t prim; };
 // Accessors: NodeAt(i) -> const BvhNode&, TriAt(i) -> const Tri&. The device
 // kernels pass LDS-staged accessors; the CPU checker passes plain arrays.
 template <bool AnyHit, typename NodeAt, typename TriAt>
-MIW_HD bool bvh_intersect(NodeAt node_at, TriAt tri_at, const RayPrep &r, Hit &best, const RectRec *rects = nullptr) {
+MIW_HD bool bvh_intersect(NodeAt node_at, TriAt tri_at, const RayPrep &r, Hit &best, PrimCtx ctx) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     float tmax = r.maxt;           // shrinks to the best t (closest-hit only)
     int32_t cur = 0;
@@ -103,7 +103,7 @@ MIW_HD bool bvh_intersect(NodeAt node_at, TriAt tri_at, const RayPrep &r, Hit &b
             for (uint32_t i = 0; i < count; ++i) {
                 const Tri &tr = tri_at(first + i);
                 float t, u, v;
-                if (prim_intersect(tr, rects, r.o, r.d, r.mint, r.maxt, t, u, v)) {
+                if (prim_intersect(tr, ctx, r.o, r.d, r.mint, r.maxt, t, u, v)) {
                     if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
                     if (t < best.t || (t == best.t && tr.prim < best.prim)) {
                         best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
@@ -120,13 +120,12 @@ MIW_HD bool bvh_intersect(NodeAt node_at, TriAt tri_at, const RayPrep &r, Hit &b
 
 // Brute force over all triangles: the definition the BVH must reproduce.
 template <bool AnyHit, typename TriAt>
-MIW_HD bool brute_intersect(TriAt tri_at, uint32_t tri_count, V3 o, V3 d, float mint, float maxt, Hit &best,
-                            const RectRec *rects = nullptr) {
+MIW_HD bool brute_intersect(TriAt tri_at, uint32_t tri_count, V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     for (uint32_t i = 0; i < tri_count; ++i) {
         const Tri &tr = tri_at(i);
         float t, u, v;
-        if (prim_intersect(tr, rects, o, d, mint, maxt, t, u, v)) {
+        if (prim_intersect(tr, ctx, o, d, mint, maxt, t, u, v)) {
             if (AnyHit) { best.t = 0.f; best.tri = i; best.prim = tr.prim; return true; }
             if (t < best.t || (t == best.t && tr.prim < best.prim)) {
                 best.t = t; best.u = u; best.v = v; best.tri = i; best.prim = tr.prim;

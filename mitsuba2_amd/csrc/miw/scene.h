@@ -57,8 +57,12 @@ struct SceneView {
     const float *emit_pmf, *emit_cdf;
     const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
     const RectRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
+    float accept_pad;                               // shape.h: the bounds rule of every triangle hit
+    const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
 };
+
+MIW_HD PrimCtx prim_ctx(const SceneView &sc) { PrimCtx c; c.rects = sc.rects; c.accept_pad = sc.accept_pad; return c; }
 
 struct DirectionSample { V3 p, n, d; float dist, pdf; uint32_t emitter; };
 

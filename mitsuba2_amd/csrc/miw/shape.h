@@ -81,14 +81,39 @@ MIW_HD bool ray_intersect_rectangle(const RectRec &r, V3 o, V3 d, float mint, fl
     t_out = t; u_out = local.x; v_out = local.y;
     return t >= mint && t <= maxt && abs_(local.x) <= 1.f && abs_(local.y) <= 1.f;
 }
-// the leaf test of every scene query: Mesh::ray_intersect_triangle or the analytic shape's own routine
-// (kdtree.h:2362-2391 intersect_prim)
-// (Analytic = false: the caller knows the scene holds triangles only and compiles the branch out)
+// ---- the accept rule every scene query shares -------------------------------------------------------------
+// Moeller-Trumbore is ill-conditioned for a ray (nearly) inside the triangle's plane: det -> 0, and the t it
+// reports can lie anywhere — typically a shadow or bounce ray leaving a surface at grazing angle "re-hits" the face
+// it starts on at some t > mint although it has long left the face. Whether such a phantom is found then depends
+// on which triangles a query happens to test: brute force tests all of them, a spatial structure (the reference's
+// kd-tree, kdtree.h:2079-2171, like any BVH) only those near the ray. At 10^9 samples that is no longer a
+// thought experiment (1 sample in 1.3*10^8 on the Cornell box), so the rule is made structure-independent: a
+// triangle hit counts iff the point it stands for, o + t*d, lies inside the triangle's bounding box grown by
+// `accept_pad` (1e-5 x the largest |coordinate| of the scene; the BVH boxes are grown by twice that, so a hit
+// that counts is never culled). Brute force, packet sweep, leaf filter and both tree walks then agree by
+// construction; for well-conditioned hits the rule never fires.
+struct PrimCtx { const RectRec *rects; float accept_pad; };
+struct TriBounds { float lo[3], hi[3]; };                  // bounding box of a triangle's vertices, grown by accept_pad
+MIW_HD TriBounds tri_bounds(V3 p0, V3 p1, V3 p2, float pad) {
+    TriBounds b;
+    b.lo[0] = min_(p0.x, min_(p1.x, p2.x)) - pad; b.hi[0] = max_(p0.x, max_(p1.x, p2.x)) + pad;
+    b.lo[1] = min_(p0.y, min_(p1.y, p2.y)) - pad; b.hi[1] = max_(p0.y, max_(p1.y, p2.y)) + pad;
+    b.lo[2] = min_(p0.z, min_(p1.z, p2.z)) - pad; b.hi[2] = max_(p0.z, max_(p1.z, p2.z)) + pad;
+    return b;
+}
+MIW_HD bool hit_in_bounds(const TriBounds &b, V3 o, V3 d, float t) {
+    const float px = fmadd(d.x, t, o.x), py = fmadd(d.y, t, o.y), pz = fmadd(d.z, t, o.z);
+    return px >= b.lo[0] && px <= b.hi[0] && py >= b.lo[1] && py <= b.hi[1] && pz >= b.lo[2] && pz <= b.hi[2];
+}
+// the leaf test: Mesh::ray_intersect_triangle (+ the rule above) or the analytic shape's own routine
+// (kdtree.h:2362-2391 intersect_prim). Analytic = false: the caller knows the scene holds triangles only.
 template <bool Analytic = true>
-MIW_HD bool prim_intersect(const Tri &tr, const RectRec *rects, V3 o, V3 d, float mint, float maxt,
+MIW_HD bool prim_intersect(const Tri &tr, PrimCtx ctx, V3 o, V3 d, float mint, float maxt,
                            float &t, float &u, float &v) {
-    if (Analytic && tr.pad) return ray_intersect_rectangle(rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
-    return ray_intersect_triangle(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), o, d, mint, maxt, t, u, v);
+    if (Analytic && tr.pad) return ray_intersect_rectangle(ctx.rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
+    const V3 p0 = ld3(tr.p0), p1 = ld3(tr.p1), p2 = ld3(tr.p2);
+    return ray_intersect_triangle(p0, p1, p2, o, d, mint, maxt, t, u, v) &&
+           hit_in_bounds(tri_bounds(p0, p1, p2, ctx.accept_pad), o, d, t);
 }
 
 // What the shading stage needs of a SurfaceInteraction3f (interaction.h).

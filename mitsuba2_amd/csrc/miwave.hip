@@ -30,6 +30,10 @@
 #if defined(MIW_SECTION_PROFILE)
 __device__ unsigned long long g_sections[16];
 #endif
+#if defined(MIW_VERIFY_FILTER)
+__device__ unsigned int g_verify_n;
+__device__ float g_verify[16 * 16];
+#endif
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsigned long long b[4][16]; return &b[threadIdx.x >> 6][0]; }
 #define MIW_SECTION(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); unsigned long long *b_ = miw_sec_buf(); \
@@ -99,6 +103,10 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
         uint4 *dst_b = smem + sc.tri_count * (sizeof(TriPacket) / 16);
         const uint4 *src_b = reinterpret_cast<const uint4 *>(sc.leaf_boxes);
         for (uint32_t i = threadIdx.x; i < cfg.leaves * (sizeof(LeafBox) / 16); i += blockDim.x) dst_b[i] = src_b[i];
+        // per-packet vertex bounds grown by accept_pad (shape.h: the accept rule), 24 B each, behind the boxes
+        float *dst_t = reinterpret_cast<float *>(dst_b + cfg.leaves * (sizeof(LeafBox) / 16));
+        const float *src_t = reinterpret_cast<const float *>(sc.tri_bounds);
+        for (uint32_t i = threadIdx.x; i < sc.tri_count * 6u; i += blockDim.x) dst_t[i] = src_t[i];
         __syncthreads();
         return;
     }
@@ -153,7 +161,7 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 #endif
 template <bool AnyHit, bool Analytic, typename NodeAt, typename TriAt>
 __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
-                                                    V3 o, V3 d, float mint, float maxt, Hit &best, const RectRec *rects) {
+                                                    V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     const FastRay r = fast_ray(o, d, mint);
     float tmax = maxt;
@@ -177,7 +185,7 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
             for (uint32_t i = 0; i < count; ++i) {
                 const Tri &tr = tri_at(first + i);
                 float t, u, v;
-                if (prim_intersect<Analytic>(tr, rects, o, d, mint, maxt, t, u, v)) {
+                if (prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v)) {
                     if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
                     if (t < best.t || (t == best.t && tr.prim < best.prim)) {
                         best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
@@ -191,17 +199,23 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
     }
 }
 
+// per-packet vertex bounds of a tiny scene, staged behind the leaf boxes (stage_to_lds)
+__device__ __forceinline__ const TriBounds *packet_bounds(const SceneView &sc, TraceLds cfg, const uint4 *smem) {
+    return reinterpret_cast<const TriBounds *>(smem + sc.tri_count * (sizeof(TriPacket) / 16) + cfg.leaves * (sizeof(LeafBox) / 16));
+}
 // Tiny scenes without a candidate filter: every lane sweeps every packet — wave-uniform LDS addresses
 // (broadcast reads, no bank conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
 template <bool AnyHit>
-__device__ __forceinline__ bool trace_brute(const SceneView &sc, const uint4 *smem, V3 o, V3 d, float mint, float maxt, Hit &h) {
+__device__ __forceinline__ bool trace_brute(const SceneView &sc, TraceLds cfg, const uint4 *smem, V3 o, V3 d, float mint, float maxt, Hit &h) {
     const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+    const TriBounds *tb = packet_bounds(sc, cfg, smem);
     h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
     bool any = false;
     for (uint32_t i = 0; i < sc.tri_count; ++i) {
         const TriPacket &k = pk[i];
         float t, u, v;
-        bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v);
+        bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v) &&
+                   hit_in_bounds(tb[i], o, d, t);
         if (AnyHit) {
             any = any || hit;
         } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
@@ -215,7 +229,7 @@ __device__ __forceinline__ bool trace_brute(const SceneView &sc, const uint4 *sm
 template <bool AnyHit, bool Analytic = true>
 __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
                                           V3 o, V3 d, float mint, float maxt, Hit &h) {
-    if (cfg.brute) return trace_brute<AnyHit>(sc, smem, o, d, mint, maxt, h);
+    if (cfg.brute) return trace_brute<AnyHit>(sc, cfg, smem, o, d, mint, maxt, h);
     RayPrep r = ray_prepare(o, d, mint, maxt);
     const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
     const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
@@ -225,7 +239,7 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         // whole scene is LDS resident: pure ds_read traversal
         auto node_at = [lnodes](int32_t i) -> const BvhNode & { return lnodes[i]; };
         auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, sc.rects);
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
     } else {
         uint32_t ns = cfg.nodes_staged;
         auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
@@ -234,9 +248,9 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
         if (cfg.stack) {
             int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
-            return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, sc.rects);
+            return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, prim_ctx(sc));
         }
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, sc.rects);
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
     }
 }
 
@@ -266,6 +280,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         };
         const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
         const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
+        const TriBounds *tb = packet_bounds(sc, cfg, smem);
         const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
         const float wideE = widen(maxtE), wideS = widen(maxtS);
         Mask mE = 0, mS = 0;
@@ -288,17 +303,44 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
         }
         MIW_SECTION(2);
+        uint32_t s_tri = 0; float s_t = 0.f;
         while (mS != 0) {                                      // any hit of S
             const uint32_t i = lowest(mS);
             mS &= mS - 1;
             const TriPacket &k = pk[i];
             float t, u, v;
-            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) { occ = true; mS = 0; }
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) {
+                occ = true; mS = 0; s_tri = i; s_t = t;
+            }
         }
+        // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
+        // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
+        // through the full sweep with the rule inside, which is what the rule means.
+        if (h.tri != MIW_MISS && !hit_in_bounds(tb[h.tri], o, dE, h.t)) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (occ && !hit_in_bounds(tb[s_tri], o, dS, s_t)) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
         MIW_SECTION(3);
+#if defined(MIW_VERIFY_FILTER)
+        {   // debug builds: every filtered query against the full sweep; mismatching rays go to g_verify
+            Hit hb; bool occ_b = false;
+            if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, hb); else { hb.tri = MIW_MISS; hb.t = MIW_INFINITY; }
+            if (hasS) { Hit hs; occ_b = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+            const bool badE = hasE && (hb.tri != h.tri || f2u(hb.t) != f2u(h.t)), badS = hasS && occ_b != occ;
+            if (badE || badS) {
+                const uint32_t k = atomicAdd(&g_verify_n, 1u);
+                if (k < 16u) {
+                    float *r = g_verify + k * 16;
+                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint;
+                    const V3 d = badE ? dE : dS;
+                    r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = badE ? maxtE : maxtS;
+                    r[8] = badE ? 1.f : 2.f; r[9] = u2f(badE ? hb.tri : (uint32_t) occ_b); r[10] = u2f(badE ? h.tri : (uint32_t) occ);
+                    r[11] = hb.t; r[12] = h.t;
+                }
+            }
+        }
+#endif
     } else if (Tiny) {                                         // tiny scene, filter switched off (MI_BVH_NO_LEAF_FILTER)
-        if (hasE) trace_brute<false>(sc, smem, o, dE, mint, maxtE, h);
-        if (hasS) { Hit hs; occ = trace_brute<true>(sc, smem, o, dS, mint, maxtS, hs); }
+        if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
     } else {
         if (hasE) trace_one<false, Analytic>(sc, cfg, smem, o, dE, mint, maxtE, h);
         if (hasS) { Hit hs; occ = trace_one<true, Analytic>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
@@ -1131,7 +1173,7 @@ struct mi_ctx {
     DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<RectRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
-    DevBuf<LeafBox> d_leaf_boxes;
+    DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds;
     DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
     bool have_env = false;
     SceneView view{};
@@ -1196,7 +1238,7 @@ void mi_destroy(mi_ctx *c) {
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
     c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
-    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
@@ -1445,13 +1487,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
         HIP_TRY(c, d_tmp.resize(tmp_bytes + 16));
         HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
-        // box padding (bvh.h): 1e-5 x the largest |coordinate|
+        // box padding (bvh.h, bvh_build.h: scene_pad_unit): 2e-5 x the largest |coordinate|
         uint32_t hb[6];
         HIP_TRY(c, hipMemcpyAsync(hb, d_bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         float m = 0.f;
         for (int k = 0; k < 6; ++k) { uint32_t o = hb[k]; float f = u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); m = std::max(m, std::fabs(f)); }
-        const float pad = std::max(1e-5f * m, 1e-30f);
+        const float pad = 2.f * std::max(1e-5f * m, 1e-30f);
         hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
                            (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
         hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p);
@@ -1486,6 +1528,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     c->counters.bvh_on_device = built_on_device ? 1u : 0u;
 
     SceneView &v = c->view;
+    v.accept_pad = scene_pad_unit(c->tris_in);                // shape.h: the bounds rule of every triangle hit
+    v.tri_bounds = nullptr;
     v.nodes = c->d_nodes.p; v.node_count = node_count;
     v.tris = c->d_tris.p; v.tri_count = tri_count;
     v.tri_vn = c->tri_vn_in.empty() ? nullptr : c->d_tri_vn.p;
@@ -1519,7 +1563,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         v.leaf_boxes = c->d_leaf_boxes.p;
         c->lds_cfg.leaves = (quality_flags & MI_BVH_NO_LEAF_FILTER) ? 0u : (uint32_t) leaves.size();
-        c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox);
+        std::vector<TriBounds> bounds(v.tri_count);               // per packet (leaf order), staged behind the boxes
+        for (uint32_t i = 0; i < v.tri_count; ++i)
+            bounds[i] = tri_bounds(ld3(r.tris[i].p0), ld3(r.tris[i].p1), ld3(r.tris[i].p2), v.accept_pad);
+        HIP_TRY(c, c->d_tri_bounds.upload(bounds, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        v.tri_bounds = c->d_tri_bounds.p;
+        c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox) + v.tri_count * sizeof(TriBounds);
     } else {
         if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
         else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
@@ -1801,6 +1851,20 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         Counters sum;
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
+#if defined(MIW_VERIFY_FILTER)
+        {
+            unsigned int n = 0; float buf[256];
+            (void) hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_verify_n), sizeof n);
+            (void) hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_verify), sizeof buf);
+            fprintf(stderr, "[miwave] filter verification: %u mismatching queries\n", n);
+            for (unsigned i = 0; i < n && i < 16; ++i) {
+                const float *r = buf + i * 16; uint32_t a, b; memcpy(&a, r + 9, 4); memcpy(&b, r + 10, 4);
+                fprintf(stderr, "  kind %g o=(%.9g %.9g %.9g) mint=%.9g d=(%.9g %.9g %.9g) maxt=%.9g brute=%u filter=%u t_brute=%.9g t_filter=%.9g\n",
+                        r[8], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], a, b, r[11], r[12]);
+            }
+            n = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_verify_n), &n, sizeof n);
+        }
+#endif
 #if defined(MIW_SECTION_PROFILE)
         if (getenv("MIW_DEBUG")) {
             unsigned long long sec[16];

@@ -143,6 +143,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
     v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr;
     v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
+    v.accept_pad = scene_pad_unit(o.tris_in); v.tri_bounds = nullptr;
     return true;
 }
 // plain IEEE float environment (denormals preserved), see miw_oracle.cpp FtzScope
@@ -157,7 +158,7 @@ int emu_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_so
     EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
     Ftz ftz;
     if (stats3) { stats3[0] = sc.view.node_count; stats3[1] = sc.view.tri_count; stats3[2] = sc.bvh.depth; }
-    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const RectRec *rects = sc.view.rects;
+    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const PrimCtx rects = prim_ctx(sc.view);
     auto node_at = [nodes](int32_t i) -> const BvhNode & { return nodes[i]; };
     auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
     for (uint64_t i = 0; i < n; ++i) {
@@ -224,7 +225,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         lane_init(P, Q, lane, pixel[lane], cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
 #endif
     }
-    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const RectRec *rects = sc.view.rects;
+    const BvhNode *nodes = sc.view.nodes; const Tri *tris = sc.view.tris; const PrimCtx rects = prim_ctx(sc.view);
     auto node_at = [nodes](int32_t i) -> const BvhNode & { return nodes[i]; };
     auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
     auto add = [film64](int texel, int k, float v) { film64[(size_t) texel * 5 + k] += (double) v; };

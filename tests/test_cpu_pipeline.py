@@ -89,6 +89,34 @@ def test_resident_plan_equals_scalar_path_integrator(native, oracle, per_launch)
     assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
 
 
+def test_phantom_grazing_hit_is_structure_independent(native, oracle):
+    """A shadow ray found by a 1.3e8-sample render (tools/diag_plans.py): it leaves a side face of the short block at
+    grazing angle, 0.007 below the top edge; Moeller-Trumbore (ill-conditioned: det ~ 1e-4 |e1||e2|) "re-hits" that
+    face at t = 0.035 > mint although the ray left the face's bounds at t = 0.013. Brute force used to report the
+    hit, every spatial structure (leaf filter, both tree walks) to miss it. The accept rule of shape.h (the hit
+    point must lie inside the triangle's bounds grown by accept_pad) makes all of them agree."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(64, 48, 1, device=-1)
+    o = np.array([[110.197144, 164.992737, 233.387756]], np.float32)
+    d = np.array([[0.28888461, 0.953493118, 0.0860041305]], np.float32)
+    mint, maxt = np.float32(0.0209558979), np.float32(401.329437)
+    dsc = scene.desc().contents
+    tri = np.array([[dsc.vertex_positions[3 * dsc.faces[3 * 20 + k] + a] for a in range(3)] for k in range(3)], np.float32)
+    import ctypes as C
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    out = np.zeros(4, np.float32)
+    oracle.L.orc_ray_triangle(fp(np.ascontiguousarray(tri.reshape(-1))), fp(np.concatenate([o[0], d[0], [mint, maxt]]).astype(np.float32)), fp(out))
+    hit, t, u, v = out
+    assert hit and abs(t - 0.0352677) < 1e-5 and u + v > 0.9999          # the raw triangle test accepts the phantom
+    assert (o[0] + t * d[0])[1] > 165.02                                # ... 0.026 above the face's top edge (pad: 0.0056)
+    for any_hit in (False, True):
+        b = oracle.trace(scene.desc(), o, d, mint=mint, maxt=maxt, any_hit=any_hit)
+        for leaf in (2, 4):
+            e = oracle.emu_trace(scene.desc(), o, d, mint=mint, maxt=maxt, any_hit=any_hit, max_leaf=leaf)
+            assert np.array_equal(np.asarray(e["t"]).view(np.uint32), np.asarray(b["t"]).view(np.uint32))
+        assert not np.isfinite(b["t"]).any()                            # unoccluded under the rule
+
+
 def test_samples_per_pass(native, oracle):
     """samples_per_pass < sample_count (integrator.cpp:75-86): every pass re-seeds the pixels from its own block ids
     (spiral.cpp:41: counter + pass * block_count) and adds its blocks onto the film after the ids already there."""
