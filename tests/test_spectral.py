@@ -128,6 +128,28 @@ def test_spectral_resident_plan_equals_scalar_oracle(spectral, oracle_spectral, 
     assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
 
 
+@pytest.mark.parametrize("which", ["plugin_box", "rect_box", "frosted"])
+def test_spectral_plugins_and_rectangles(spectral, oracle_spectral, which):
+    """conductor / plastic / twosided / roughdielectric and the analytic rectangles in the scalar_spectral build: the
+    resident sample loop == the scalar oracle bit for bit; the plastic's sampling weight uses the spectral
+    Texture::mean() (srgb.h:26-35: the sigmoid-polynomial model averaged over 16 wavelengths)."""
+    from mitsuba2_amd import scenes
+    if which == "plugin_box":
+        scene, sensor = scenes.plugin_box(40, 32, 6, device=-1)
+    elif which == "rect_box":
+        scene, sensor = scenes.rect_box(40, 32, 6, device=-1)
+    else:
+        scene, sensor = scenes.cornell_box(40, 32, 6, diffuse_only=False, device=-1, ball_level=1,
+                                           glass=dict(alpha=0.2, distribution="ggx"))
+    job, o32, o64, st, e64, e32, est = _both(spectral, oracle_spectral, scene, sensor)
+    assert est[1] == st.segments and np.array_equal(e32, o32) and np.isfinite(o32).all()
+    if which == "plugin_box":
+        d = scene.desc().contents
+        pl = [d.bsdfs[i] for i in range(d.bsdf_count) if d.bsdfs[i].type == 4]
+        assert len(pl) == 2 and all(r.tex[0].type == 2 for r in pl)          # MI_TEX_SRGB records
+        assert all(0.3 < r.params[3] < 0.8 for r in pl)                       # s_mean / (d_mean + s_mean)
+
+
 def test_spectral_render_agrees_with_rgb_render(native, spectral, oracle_spectral, oracle):
     """Upsampling RGB to spectra and integrating back against the CIE observer must land near the RGB render
     (same geometry, same sampler): means of X, Y, Z within a few percent."""
@@ -195,4 +217,11 @@ def test_gpu_spectral_render_parity(spectral, oracle_spectral, diffuse_only):
     job.cfg.plan = 1
     film = np.zeros(job.cfg.crop_w * job.cfg.crop_h * 5, np.float32)
     assert d.L.mi_render(d.ctx, C.byref(job.cfg), film.ctypes.data_as(C.c_void_p)) == -1      # queue plan: RGB builds only
+    if not diffuse_only:                                            # the (f)-4 plugins and analytic rectangles, spectral build
+        for sc_, se_ in (scenes.plugin_box(64, 48, 6, device=-1), scenes.rect_box(64, 48, 6, device=-1)):
+            j2 = spectral.PathIntegrator().render_job(se_)
+            r32, _, rst = oracle_spectral.render(sc_.desc(), j2, threads=8, want_f64=False)
+            d.upload(sc_.desc())
+            q32, st = d.render(j2)
+            assert st == 0 and d.counters().segments == rst.segments and np.array_equal(q32, r32)
     d.close()

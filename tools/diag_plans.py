@@ -1,3 +1,9 @@
+"""Diagnostic (GPU box): render the Cornell box at W x H x SPP with the resident plan and with the HBM-queue wavefront
+plan and report every texel where the two float32 films differ. This is the tool that found the phantom
+Moeller-Trumbore hits described in DESIGN.md section 2 (one sample in 1.3e8).
+
+    python tools/diag_plans.py 1920 1080 64
+"""
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 from mitsuba2_amd import api as native, scenes
