@@ -176,12 +176,12 @@ def main():
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),
             }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py
             O = oracle_py.load(args.variant)
             cores = os.cpu_count() or 1
-            nblocks = 8                                      # bounded sample: the 8 centre-most spiral blocks, full spp
+            nblocks = max(8, cores)                          # bounded sample: one centre-most spiral block per host thread, full spp
             one = api.PathIntegrator().render_job(sensor)
             _, _, st = O.render(scene.desc(), one, threads=cores, want_f64=False, only_blocks=np.arange(nblocks, dtype=np.uint32))
             cpu = {"value": st.samples / st.seconds / 1e6, "unit": "Msamples/sec", "cores": cores, "kind": "port",
