@@ -1297,6 +1297,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     }
     // analytic rectangles: record + two bounding triangles (the second one appended behind the faces)
     c->rects.clear();
+    if (s->rectangle_count && !s->rectangles) return fail(c, MI_ERR_INVALID, "scene: rectangle_count without rectangles");
     std::vector<int32_t> shape_rect(s->shape_count, -1);
     for (uint32_t k = 0; k < s->rectangle_count; ++k) {
         const mi_rectangle &q = s->rectangles[k];

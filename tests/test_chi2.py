@@ -9,7 +9,7 @@ import pytest
 from scipy import stats
 
 SIGNIFICANCE = 0.01
-N_TESTS = 16                                   # Sidak correction over the tests of this module
+N_TESTS = 19                                   # Sidak correction over the tests of this module
 
 
 def _dir(phi, z):
@@ -125,3 +125,64 @@ def test_chi2_roughdielectric(native, oracle, kw, wi):
 def _bsdf_chi2_res(native, oracle, plugin, wi, res, n=600000, **kw):
     fine = res[0] > 64
     return _bsdf_chi2(native, oracle, plugin, wi, n=n, res=res, ires=16, **kw)     # quadrature error << sampling noise
+
+
+# ---- emitter sampling (scene.cpp:164-231, area.cpp:121-187, shape.cpp:292-323, rectangle.cpp:111-130, envmap.cpp) ----
+
+_TO_Y = np.array([[1, 0, 0], [0, 0, 1], [0, 1, 0]], np.float64)         # harness frame (polar axis z) <-> scene (+y up)
+
+
+@pytest.mark.parametrize("analytic", [False, True])
+def test_chi2_area_light_sampling(native, oracle, analytic):
+    """Scene::sample_emitter_direction on a quad area light — a two-triangle mesh (area CDF + triangle warp) or the
+    analytic rectangle (uniform in object space) — against the closed-form solid-angle density (1 / area) r^2 / |cos|
+    of a uniformly sampled quad, from a reference point below it."""
+    from mitsuba2_amd import scenes
+    corners = np.array(scenes._CBOX["light"], np.float64)              # y = 548, x in [213, 343], z in [227, 332]
+    light = native.AreaLight((17.0, 12.0, 4.0))
+    if analytic:
+        shape = scenes._rect("light", corners, (278, 0, 280), emitter=light)
+    else:
+        v, f = scenes._quad(corners, inward_point=(278, 0, 280))
+        shape = native.Mesh("light", v, f, emitter=light)
+    scene = native.Scene([shape]).build(-1)
+    ref = np.array([250.0, 300.0, 260.0])
+    n = 400000
+    rng = np.random.default_rng(4)
+    inp = np.zeros((n, 5), np.float32); inp[:, 0:3] = ref; inp[:, 3:5] = rng.random((n, 2))
+    out = oracle.eval(6, inp, scene.desc())
+    d_s, pdf_s, val = out[:, 0:3].astype(np.float64), out[:, 4], out[:, 11:14]
+    assert (pdf_s > 0).all() and np.allclose(val * pdf_s[:, None], (17.0, 12.0, 4.0), rtol=1e-4)
+    x0, x1, zz0, zz1, yl = 213.0, 343.0, 227.0, 332.0, 548.0
+    area = (x1 - x0) * (zz1 - zz0)
+
+    def pdf(dirs_h):                                                   # harness frame -> scene frame
+        d = dirs_h.astype(np.float64) @ _TO_Y.T
+        t = (yl - ref[1]) / np.where(d[:, 1] > 1e-9, d[:, 1], np.inf)
+        p = ref + d * t[:, None]
+        inside = (d[:, 1] > 1e-9) & (p[:, 0] >= x0) & (p[:, 0] <= x1) & (p[:, 2] >= zz0) & (p[:, 2] <= zz1)
+        return np.where(inside, (1 / area) * t * t / np.maximum(d[:, 1], 1e-9), 0.0)
+    sel = rng.integers(0, n, 2000)
+    assert np.allclose(pdf(d_s[sel] @ _TO_Y), pdf_s[sel], rtol=2e-4)   # the sampled pdf is that density
+    p, stat, dof, mass, frac = chi2_sphere(d_s @ _TO_Y, pdf, n, res=(96, 96), ires=12, z_range=(0.85, 1.0))
+    assert p > _threshold() and abs(mass - 1) < 3e-3 and frac == 1.0, (p, stat, dof, mass, frac)
+
+
+def test_chi2_envmap_sampling(native, oracle):
+    """EnvironmentMapEmitter::sample_direction through the hierarchical warp (envmap.cpp:157-190, distr_2d.h) against
+    its own pdf_direction (:192-208) over the whole sphere"""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.open_box(16, 16, 1, device=-1, with_area_light=False, env_size=(64, 32))
+    n = 600000
+    rng = np.random.default_rng(9)
+    inp = np.zeros((n, 8), np.float32); inp[:, 0:3] = (0, 0, 1); inp[:, 3:6] = (278, 200, 280); inp[:, 6:8] = rng.random((n, 2))
+    out = oracle.eval(9, inp, scene.desc())
+    d_s, pdf_s = out[:, 4:7].astype(np.float64), out[:, 8]
+
+    def pdf(dirs):
+        q = np.zeros((len(dirs), 8), np.float32); q[:, 0:3] = dirs; q[:, 3:6] = (278, 200, 280)
+        return oracle.eval(9, q, scene.desc())[:, 3]
+    sel = rng.integers(0, n, 2000)
+    assert np.allclose(pdf(d_s[sel].astype(np.float32)), pdf_s[sel], rtol=2e-3)
+    p, stat, dof, mass, frac = chi2_sphere(d_s, pdf, n, res=(128, 96), ires=8)
+    assert p > _threshold() and abs(mass - 1) < 5e-3, (p, stat, dof, mass, frac)

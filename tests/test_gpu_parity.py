@@ -392,6 +392,19 @@ def test_errors_are_loud(native, dev):
         native.PathIntegrator(rr_depth=0)
     with pytest.raises(RuntimeError):
         native.BSDF("roughplastic")
+    # malformed descriptions of the newer record types are refused by mi_scene_upload with a message
+    from mitsuba2_amd import scenes
+    d3 = native.Device(0)
+    for breaker, msg in ((lambda d: setattr(d.bsdfs[0], "type", 99), b"unknown type"),
+                         (lambda d: (setattr(d.bsdfs[0], "flags", 0x100), setattr(d.bsdfs[0], "back", 77)), b"back-side record"),
+                         (lambda d: setattr(d, "rectangle_count", 0), b"no mi_rectangle record"),
+                         (lambda d: setattr(d.rectangles[0], "shape", 7), b"is not a (single) MI_SHAPE_RECTANGLE shape")):
+        scene = native.Scene(scenes.rect_box_meshes()).build(-1)
+        desc = scene.desc().contents
+        breaker(desc)
+        st = d3.L.mi_scene_upload(d3.ctx, scene.desc())
+        assert st == _capi.MI_ERR_INVALID and msg in d3.L.mi_last_error(d3.ctx), (msg, d3.L.mi_last_error(d3.ctx))
+    d3.close()
 
 
 def test_forced_tree_walk_on_cornell(native, oracle, cbox):
