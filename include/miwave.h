@@ -48,7 +48,8 @@ enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2,            /* roug
        MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE = 4, MI_BSDF_FLAG_HAS_SPEC_TRANSMITTANCE = 8,   /* roughdielectric (+ GGX, SAMPLE_VISIBLE) */
        MI_BSDF_FLAG_TWOSIDED = 0x100 };                                    /* any type: wrapped by <bsdf type="twosided"> */
 enum { MI_SHAPE_HAS_NORMALS = 1,
-       MI_SHAPE_RECTANGLE = 2 };   /* analytic rectangle (src/shapes/rectangle.cpp): face_count == 1 — the shape's single
+       MI_SHAPE_RECTANGLE = 2,
+       MI_SHAPE_SPHERE = 4 };      /* analytic sphere (src/shapes/sphere.cpp): like MI_SHAPE_RECTANGLE, geometry in `spheres` */   /* analytic rectangle (src/shapes/rectangle.cpp): face_count == 1 — the shape's single
                                       primitive, id first_face; its faces[] entry is ignored — geometry in `rectangles` */
 
 /* A spectrum-valued plugin parameter (what src/libcore/xml.cpp:1073-1170 turns an <rgb> / <spectrum>
@@ -116,6 +117,15 @@ typedef struct {
     float to_world[16], to_object[16];
 } mi_rectangle;
 
+/* Sphere(props) after update() (src/shapes/sphere.cpp:96-131): center and radius extracted from to_world, to_world
+ * rebuilt from them (uniform scale, rotation, translation), its inverse, flip_normals. */
+typedef struct {
+    uint32_t shape;                        /* index into shapes (which carries MI_SHAPE_SPHERE) */
+    float center[3], radius;
+    uint32_t flip_normals;
+    float to_world[16], to_object[16];
+} mi_sphere;
+
 typedef struct {
     const float    *vertex_positions;  /* 3 * vertex_count                               */
     const float    *vertex_normals;    /* 3 * vertex_count, or NULL                      */
@@ -127,6 +137,7 @@ typedef struct {
     const mi_emitter *emitters; uint32_t emitter_count;
     const mi_envmap  *envmap;          /* or NULL                                        */
     const mi_rectangle *rectangles; uint32_t rectangle_count;   /* one per MI_SHAPE_RECTANGLE shape, or NULL / 0 */
+    const mi_sphere *spheres; uint32_t sphere_count;            /* one per MI_SHAPE_SPHERE shape, or NULL / 0    */
 } mi_scene_desc;
 
 /* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */

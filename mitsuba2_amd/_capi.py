@@ -42,6 +42,11 @@ class mi_rectangle(C.Structure):
     _fields_ = [("shape", C.c_uint32), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
 
 
+class mi_sphere(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("center", C.c_float * 3), ("radius", C.c_float), ("flip_normals", C.c_uint32),
+                ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
+
+
 class mi_scene_desc(C.Structure):
     _fields_ = [("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_count", C.c_uint32),
                 ("faces", c_u32_p), ("face_count", C.c_uint32),
@@ -49,7 +54,8 @@ class mi_scene_desc(C.Structure):
                 ("bsdfs", C.POINTER(mi_bsdf)), ("bsdf_count", C.c_uint32),
                 ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32),
                 ("envmap", C.POINTER(mi_envmap)),
-                ("rectangles", C.POINTER(mi_rectangle)), ("rectangle_count", C.c_uint32)]
+                ("rectangles", C.POINTER(mi_rectangle)), ("rectangle_count", C.c_uint32),
+                ("spheres", C.POINTER(mi_sphere)), ("sphere_count", C.c_uint32)]
 
 
 class mi_rays_soa(C.Structure):
@@ -154,7 +160,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),
         "mih_props_set_color": (None, [vp, cp, f, f, f]),
         "mih_props_set_lookat": (None, [vp, cp, c_float_p, c_float_p, c_float_p]),
-        "mih_props_set_matrix": (None, [vp, cp, c_float_p]), "mih_rectangle_create": (vp, [vp]),
+        "mih_props_set_matrix": (None, [vp, cp, c_float_p]), "mih_rectangle_create": (vp, [vp]), "mih_sphere_create": (vp, [vp]),
         "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]), "mih_bsdf_create_twosided": (vp, [vp, vp]),
         "mih_fresnel_diffuse_reflectance": (C.c_float, [C.c_float]),
         "mih_bsdf_record": (i32, [vp, C.POINTER(mi_bsdf)]), "mih_bsdf_flags": (u32, [vp]),

@@ -217,6 +217,26 @@ class Mesh:
             host_lib().mih_mesh_set_emitter(self.h, emitter.h)
         return self
 
+    @classmethod
+    def sphere(cls, center=(0, 0, 0), radius=1.0, to_world=None, flip_normals=False, bsdf=None, emitter=None, name="sphere"):
+        """<shape type="sphere"> (src/shapes/sphere.cpp): the analytic sphere — one primitive"""
+        kw = dict(center=tuple(float(x) for x in center), radius=float(radius), flip_normals=bool(flip_normals))
+        if to_world is not None:
+            kw["to_world"] = np.asarray(to_world, np.float32).reshape(4, 4)
+        props = Properties("sphere", **kw)
+        h = host_lib().mih_sphere_create(props.h)
+        if not h:
+            raise RuntimeError(_err())
+        self = cls.__new__(cls)
+        self.h, self.name = h, name
+        self._sync()
+        self.bsdf, self.emitter = bsdf, emitter
+        if bsdf is not None:
+            host_lib().mih_mesh_set_bsdf(self.h, bsdf.h)
+        if emitter is not None:
+            host_lib().mih_mesh_set_emitter(self.h, emitter.h)
+        return self
+
     def _sync(self):
         nv, nf, hn = C.c_uint32(), C.c_uint32(), C.c_int32()
         host_lib().mih_mesh_counts(self.h, C.byref(nv), C.byref(nf), C.byref(hn))

@@ -241,8 +241,10 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     if (valid) {
         const Tri &tr = sc.tris[tri_idx];
         const ShapeRec &shape = sc.shapes[tr.shape];
-        if (Analytic && tr.pad) {                        // analytic rectangle: its own compute_surface_interaction
-            compute_surface_interaction_rect(sc.rects[tr.pad - 1u], h.x, h.y, h.z, prev_o(), ray_d, si);
+        if (Analytic && tr.pad) {                        // analytic shape: its own compute_surface_interaction
+            const RectRec &a = sc.rects[tr.pad - 1u];
+            if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.x, prev_o(), ray_d, si);
+            else compute_surface_interaction_rect(a, h.x, h.y, h.z, prev_o(), ray_d, si);
         } else {
             const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
             compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
@@ -260,14 +262,15 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
             float emitter_pdf = 0.f;
             if (!(L.flags & LF_PREV_DELTA)) {
                 // DirectionSample3f ds(si_bsdf, si), records.h:167-173 (d = -wi = ray.d for a miss)
-                V3 d = ray_d; float dist = 0.f; V3 n = v3(0.f);
+                V3 d = ray_d; float dist = 0.f; V3 n = v3(0.f), ref_p = v3(0.f);
                 if (valid) {
-                    d = si.p - prev_o();
+                    ref_p = prev_o();
+                    d = si.p - ref_p;
                     dist = norm(d);
                     d = d / dist;
                     n = si.sh.n;
                 }
-                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, n);
+                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, n, ref_p);
             }
             emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
         }

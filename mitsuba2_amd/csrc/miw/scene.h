@@ -78,6 +78,65 @@ MIW_HD MeshSampler emitter_mesh(const SceneView &sc, const EmitterRec &e) {
     return m;
 }
 
+// ---- Sphere as an emitter shape: sphere.cpp:146-275 -----------------------------------------------------------
+// warp.h:255-260 (circ(z) = sqrt(1 - z^2), frozen as safe_sqrt(fnmadd(z, z, 1)))
+MIW_HD V3 square_to_uniform_sphere(V2 sample) {
+    float z = fnmadd(2.f, sample.y, 1.f), r = safe_sqrt(fnmadd(z, z, 1.f)), s, c;
+    sincos_((2.f * MIW_PI) * sample.x, s, c);
+    return v3(r * c, r * s, z);
+}
+// Sphere::sample_direction (:169-246): uniform over the cone the sphere subtends from outside, over the surface from
+// inside. Fills ds.p, ds.n, ds.d, ds.dist, ds.pdf.
+MIW_HD void sphere_sample_direction(const RectRec &r, V3 ref_p, V2 sample, DirectionSample &ds) {
+    const V3 center = ld3(r.n);
+    const float radius = r.radius;
+    V3 dc_v = center - ref_p;
+    float dc_2 = squared_norm(dc_v);
+    float radius_adj = radius * (r.flip ? (1.f + MIW_RAY_EPSILON) : (1.f - MIW_RAY_EPSILON));
+    if (dc_2 > sqr(radius_adj)) {                          // :181-221
+        float inv_dc = rsqrt(dc_2),
+              sin_theta_max = radius * inv_dc,
+              sin_theta_max_2 = sqr(sin_theta_max),
+              inv_sin_theta_max = rcp(sin_theta_max),
+              cos_theta_max = safe_sqrt(1.f - sin_theta_max_2);
+        float sin_theta_2 = sin_theta_max_2 > 0.00068523f ? 1.f - sqr(fmadd(cos_theta_max - 1.f, sample.x, 1.f))
+                                                          : sin_theta_max_2 * sample.x,
+              cos_theta = safe_sqrt(1.f - sin_theta_2);
+        float cos_alpha = sin_theta_2 * inv_sin_theta_max + cos_theta * safe_sqrt(fnmadd(sin_theta_2, sqr(inv_sin_theta_max), 1.f)),
+              sin_alpha = safe_sqrt(fnmadd(cos_alpha, cos_alpha, 1.f));
+        float sin_phi, cos_phi;
+        sincos_(sample.y * (2.f * MIW_PI), sin_phi, cos_phi);
+        Frame f; f.n = dc_v * -inv_dc;                     // Frame3f(dc_v * -inv_dc)
+        coordinate_system(f.n, f.s, f.t);
+        V3 d = to_world(f, v3(cos_phi * sin_alpha, sin_phi * sin_alpha, cos_alpha));
+        ds.p = v3(fmadd(d.x, radius, center.x), fmadd(d.y, radius, center.y), fmadd(d.z, radius, center.z));
+        ds.n = d;
+        ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = __builtin_sqrtf(dist2);
+        ds.d = ds.d / ds.dist;
+        ds.pdf = (.5f * MIW_INV_PI) / (1.f - cos_theta_max);   // square_to_uniform_cone_pdf, warp.h:481-490
+        if (ds.dist == 0.f) ds.pdf = 0.f;
+    } else {                                               // :224-236
+        V3 d = square_to_uniform_sphere(sample);
+        ds.p = v3(fmadd(d.x, radius, center.x), fmadd(d.y, radius, center.y), fmadd(d.z, radius, center.z));
+        ds.n = d;
+        ds.d = ds.p - ref_p;
+        float dist2 = squared_norm(ds.d);
+        ds.dist = __builtin_sqrtf(dist2);
+        ds.d = ds.d / ds.dist;
+        ds.pdf = r.inv_area * dist2 / abs_dot(ds.d, ds.n);
+    }
+    if (r.flip) ds.n = -ds.n;                              // :243-244
+}
+// Sphere::pdf_direction, :248-262
+MIW_HD float sphere_pdf_direction(const RectRec &r, V3 ref_p, V3 ds_d, float ds_dist, V3 ds_n) {
+    float sin_alpha = r.radius * rcp(norm(ld3(r.n) - ref_p)),
+          cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
+    return sin_alpha < (1.f - MIW_EPSILON) ? (.5f * MIW_INV_PI) / (1.f - cos_alpha)       // math::OneMinusEpsilon
+                                           : r.inv_area * sqr(ds_dist) / abs_dot(ds_d, ds_n);
+}
+
 // The environment map is an RGB-build feature this round (its spectral branch upsamples every texel
 // through srgb_model_fetch, envmap.cpp:104-110): spectral scenes carrying one are rejected at upload.
 #if MIW_SPECTRAL
@@ -115,16 +174,20 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
     if (e.type == EMITTER_ENVMAP) {
         value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
     } else {
-        // Shape::sample_direction, shape.cpp:292-309
-        PositionSample ps = (e.flags & 2u) ? rect_sample_position(sc.rects[e.tri_first], sample)
-                                           : mesh_sample_position(emitter_mesh(sc, e), sample);
-        ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf;
-        ds.d = ds.p - ref_p;
-        float dist_squared = squared_norm(ds.d);
-        ds.dist = __builtin_sqrtf(dist_squared);
-        ds.d = ds.d / ds.dist;
-        float dp = abs_dot(ds.d, ds.n);
-        ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
+            sphere_sample_direction(sc.rects[e.tri_first], ref_p, sample, ds);      // the sphere's own sample_direction
+        } else {
+            // Shape::sample_direction, shape.cpp:292-309
+            PositionSample ps = (e.flags & 2u) ? rect_sample_position(sc.rects[e.tri_first], sample)
+                                               : mesh_sample_position(emitter_mesh(sc, e), sample);
+            ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf;
+            ds.d = ds.p - ref_p;
+            float dist_squared = squared_norm(ds.d);
+            ds.dist = __builtin_sqrtf(dist_squared);
+            ds.d = ds.d / ds.dist;
+            float dp = abs_dot(ds.d, ds.n);
+            ds.pdf *= (dp != 0.f) ? dist_squared / dp : 0.f;
+        }
         // AreaLight::sample_direction, area.cpp:131-136,165
         bool active = dot(ds.d, ds.n) < 0.f && ds.pdf != 0.f;
         value = tex_eval(e.radiance, wl) / ds.pdf;
@@ -139,7 +202,8 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
 
 // scene.cpp:216-231 + area.cpp:168-187 + shape.cpp:311-323.
 // `ds_d`, `ds_dist`, `ds_n` come from DirectionSample(si_bsdf, si) (records.h:167-173).
-MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n) {
+// `ref_p` = it.p, the point the direction leaves from (only the sphere's pdf_direction needs it).
+MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
     const EmitterRec &e = sc.emitters[emitter];
     float value;
     if (e.type == EMITTER_ENVMAP) {
@@ -147,9 +211,14 @@ MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_
     } else {
         float dp = dot(ds_d, ds_n);
         bool active = dp < 0.f;
-        float pdf = e.normalization,
-              adp = abs_dot(ds_d, ds_n);
-        pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
+        float pdf;
+        if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
+            pdf = sphere_pdf_direction(sc.rects[e.tri_first], ref_p, ds_d, ds_dist, ds_n);
+        } else {
+            pdf = e.normalization;
+            float adp = abs_dot(ds_d, ds_n);
+            pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
+        }
         value = active ? pdf : 0.f;
     }
     if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);

@@ -9,6 +9,7 @@
 #pragma once
 #include "base.h"
 #include "warp.h"
+#include "special.h"
 
 namespace miw {
 
@@ -26,12 +27,17 @@ struct Tri {
                          // rectangle's own intersection routine (both halves give the same answer)
 };
 
-// Analytic rectangle (src/shapes/rectangle.cpp): [-1, 1]^2 in z = 0 of object space. 4x4 matrices column-major.
+// Analytic shapes. kind 0 = rectangle (src/shapes/rectangle.cpp): [-1, 1]^2 in z = 0 of object space;
+// kind 1 = sphere (src/shapes/sphere.cpp). 4x4 matrices column-major.
+enum : uint32_t { ANALYTIC_RECTANGLE = 0, ANALYTIC_SPHERE = 1 };
 struct RectRec {
     float to_world[16], to_object[16];
-    float n[3], inv_area;         // m_frame.n, m_inv_surface_area (update(), :86-96)
+    float n[3], inv_area;         // rectangle: m_frame.n; sphere: m_center. m_inv_surface_area
     float dp_du[3]; uint32_t shape;
     float dp_dv[3]; uint32_t prim;
+    uint32_t kind; float radius;  // sphere: m_radius
+    uint32_t flip;                // sphere: m_flip_normals
+    uint32_t pad_;
 };
 
 MIW_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
@@ -105,12 +111,52 @@ MIW_HD bool hit_in_bounds(const TriBounds &b, V3 o, V3 d, float t) {
     const float px = fmadd(d.x, t, o.x), py = fmadd(d.y, t, o.y), pz = fmadd(d.z, t, o.z);
     return px >= b.lo[0] && px <= b.hi[0] && py >= b.lo[1] && py <= b.hi[1] && pz >= b.lo[2] && pz <= b.hi[2];
 }
+// ---- Sphere (src/shapes/sphere.cpp) --------------------------------------------------------------------------
+// math::solve_quadratic in double precision (include/mitsuba/core/math.h:371-413), as the scalar variants run it
+MIW_HD bool solve_quadratic_d(double a, double b, double c, double &x0, double &x1) {
+    const bool linear_case = a == 0.0, valid_linear = linear_case && b != 0.0;
+    x0 = x1 = -c / b;
+    const double discrim = __builtin_fma(b, b, -(4.0 * a * c));
+    const bool valid_quadratic = !linear_case && discrim >= 0.0;
+    if (valid_quadratic) {
+        const double sqrt_discrim = __builtin_sqrt(discrim);
+        const double temp = -0.5 * (b + __builtin_copysign(sqrt_discrim, b));
+        const double x0p = temp / a, x1p = c / temp;
+        x0 = x1p < x0p ? x1p : x0p;                       // min / max, std semantics
+        x1 = x0p < x1p ? x1p : x0p;
+    }
+    return valid_linear || valid_quadratic;
+}
+// Sphere::ray_intersect_preliminary / ray_test, sphere.cpp:281-336 (u = v = 0: the sphere reports no prim_uv)
+MIW_HD bool ray_intersect_sphere(const RectRec &r, V3 o_, V3 d_, float mint_, float maxt_,
+                                 float &t_out, float &u_out, float &v_out) {
+    const double mint = (double) mint_, maxt = (double) maxt_;
+    const double ox = (double) o_.x - (double) r.n[0], oy = (double) o_.y - (double) r.n[1], oz = (double) o_.z - (double) r.n[2];
+    const double dx = d_.x, dy = d_.y, dz = d_.z;
+    // squared_norm / dot: enoki fma chains, fma(z, z, fma(y, y, x * x))
+    const double A = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+    const double B = 2.0 * __builtin_fma(oz, dz, __builtin_fma(oy, dy, ox * dx));
+    const double rad = (double) r.radius;
+    const double C = __builtin_fma(oz, oz, __builtin_fma(oy, oy, ox * ox)) - rad * rad;
+    double near_t, far_t;
+    const bool found = solve_quadratic_d(A, B, C, near_t, far_t);
+    const bool out_bounds = !(near_t <= maxt && far_t >= mint);     // NaN-aware
+    const bool in_bounds = near_t < mint && far_t > maxt;
+    t_out = near_t < mint ? (float) far_t : (float) near_t;
+    u_out = v_out = 0.f;
+    return found && !out_bounds && !in_bounds;
+}
+
 // the leaf test: Mesh::ray_intersect_triangle (+ the rule above) or the analytic shape's own routine
 // (kdtree.h:2362-2391 intersect_prim). Analytic = false: the caller knows the scene holds triangles only.
 template <bool Analytic = true>
 MIW_HD bool prim_intersect(const Tri &tr, PrimCtx ctx, V3 o, V3 d, float mint, float maxt,
                            float &t, float &u, float &v) {
-    if (Analytic && tr.pad) return ray_intersect_rectangle(ctx.rects[tr.pad - 1u], o, d, mint, maxt, t, u, v);
+    if (Analytic && tr.pad) {
+        const RectRec &a = ctx.rects[tr.pad - 1u];
+        return a.kind == ANALYTIC_SPHERE ? ray_intersect_sphere(a, o, d, mint, maxt, t, u, v)
+                                         : ray_intersect_rectangle(a, o, d, mint, maxt, t, u, v);
+    }
     const V3 p0 = ld3(tr.p0), p1 = ld3(tr.p1), p2 = ld3(tr.p2);
     return ray_intersect_triangle(p0, p1, p2, o, d, mint, maxt, t, u, v) &&
            hit_in_bounds(tri_bounds(p0, p1, p2, ctx.accept_pad), o, d, t);
@@ -162,6 +208,30 @@ MIW_HD void compute_surface_interaction_rect(const RectRec &r, float t, float u,
     si.sh.s = normalize(fnmadd3(si.sh.n, dot(si.sh.n, dp_du), dp_du));   // initialize_sh_frame, interaction.h:153-156
     si.sh.t = cross(si.sh.n, si.sh.s);
     si.wi = to_local(si.sh, -ray_d);                   // interaction.h:591
+}
+
+// enoki's unit_angle_z (not vendored in the reference checkout; frozen here): the angle between v and +z,
+// 2 asin(|v - sign(z) e_z| / 2), mirrored for z < 0
+MIW_HD float unit_angle_z(V3 v) {
+    float temp = 2.f * asin_(.5f * __builtin_sqrtf(sqr(v.x) + sqr(v.y) + sqr(v.z - mulsign(1.f, v.z))));
+    return v.z >= 0.f ? temp : MIW_PI - temp;
+}
+// Sphere::compute_surface_interaction, sphere.cpp:338-402 + interaction.h:571-596
+MIW_HD void compute_surface_interaction_sphere(const RectRec &r, float t, V3 ray_o, V3 ray_d, SurfaceInteraction &si) {
+    const V3 center = ld3(r.n);
+    si.t = t;
+    V3 n = normalize(v3(fmadd(ray_d.x, t, ray_o.x), fmadd(ray_d.y, t, ray_o.y), fmadd(ray_d.z, t, ray_o.z)) - center);   // :359
+    si.p = v3(fmadd(n.x, r.radius, center.x), fmadd(n.y, r.radius, center.y), fmadd(n.z, r.radius, center.z));            // :362
+    V3 local = xf_point_affine(r.to_object, si.p);         // :365
+    float phi = atan2_(local.y, local.x);
+    if (phi < 0.f) phi += 2.f * MIW_PI;
+    si.uv = v2(phi * (.5f * MIW_INV_PI), unit_angle_z(local) * MIW_INV_PI);                                               // :371-373
+    V3 dp_du = xf_vector(r.to_world, v3(-local.y, local.x, 0.f)) * (2.f * MIW_PI);                                        // :375, :391
+    if (r.flip) n = -n;                                    // :396-397
+    si.sh.n = n; si.n = n;
+    si.sh.s = normalize(fnmadd3(si.sh.n, dot(si.sh.n, dp_du), dp_du));   // initialize_sh_frame, interaction.h:153-156
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = to_local(si.sh, -ray_d);
 }
 
 // interaction.h:58-61 — (1 + hmax(abs(p))) * RayEpsilon

@@ -1288,9 +1288,10 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         int32_t emitter_id = sh.emitter;
         if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
         ShapeRec r; r.bsdf = sh.bsdf; r.emitter = emitter_id; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
-        if (sh.flags & MI_SHAPE_RECTANGLE) {
-            if (sh.face_count != 1) return fail(c, MI_ERR_INVALID, "shape %u: an analytic rectangle is one primitive (face_count == 1)", i);
-            if (sh.flags & MI_SHAPE_HAS_NORMALS) return fail(c, MI_ERR_INVALID, "shape %u: a rectangle has no vertex normals", i);
+        if (sh.flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) {
+            if (sh.face_count != 1) return fail(c, MI_ERR_INVALID, "shape %u: an analytic shape is one primitive (face_count == 1)", i);
+            if (sh.flags & MI_SHAPE_HAS_NORMALS) return fail(c, MI_ERR_INVALID, "shape %u: an analytic shape has no vertex normals", i);
+            if ((sh.flags & MI_SHAPE_RECTANGLE) && (sh.flags & MI_SHAPE_SPHERE)) return fail(c, MI_ERR_INVALID, "shape %u: rectangle and sphere", i);
         }
         c->shapes[i] = r;
         any_normals = any_normals || (r.flags & 1u);
@@ -1308,8 +1309,18 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         if (!(c->rects.back().inv_area > 0.f) || !isfinite_(c->rects.back().inv_area))
             return fail(c, MI_ERR_INVALID, "rectangle %u: degenerate to_world", k);
     }
+    if (s->sphere_count && !s->spheres) return fail(c, MI_ERR_INVALID, "scene: sphere_count without spheres");
+    for (uint32_t k = 0; k < s->sphere_count; ++k) {          // spheres follow the rectangles in the analytic table
+        const mi_sphere &q = s->spheres[k];
+        if (q.shape >= s->shape_count || !(s->shapes[q.shape].flags & MI_SHAPE_SPHERE) || shape_rect[q.shape] >= 0)
+            return fail(c, MI_ERR_INVALID, "sphere %u: shape %u is not a (single) MI_SHAPE_SPHERE shape", k, q.shape);
+        if (!(q.radius > 0.f) || !isfinite_(q.radius)) return fail(c, MI_ERR_INVALID, "sphere %u: radius must be positive", k);
+        shape_rect[q.shape] = (int32_t) c->rects.size();
+        c->rects.push_back(sphere_record(q.center, q.radius, q.flip_normals != 0, q.to_world, q.to_object, q.shape, s->shapes[q.shape].first_face));
+    }
     for (uint32_t i = 0; i < s->shape_count; ++i)
-        if ((s->shapes[i].flags & MI_SHAPE_RECTANGLE) && shape_rect[i] < 0) return fail(c, MI_ERR_INVALID, "shape %u: no mi_rectangle record", i);
+        if ((s->shapes[i].flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) && shape_rect[i] < 0)
+            return fail(c, MI_ERR_INVALID, "shape %u: no mi_rectangle record", i);
     c->tris_in.resize((size_t) s->face_count + c->rects.size());
     c->tri_vn_in.clear();
     if (any_normals) c->tri_vn_in.assign(c->tris_in.size() * 9, 0.f);
@@ -1318,7 +1329,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         Tri &t = c->tris_in[f];
         if (shape_rect[face_shape[f]] >= 0) {                  // the rectangle's primitive slot: its two bounding triangles
             Tri two[2];
-            rect_bounding_tris(c->rects[shape_rect[face_shape[f]]], (uint32_t) shape_rect[face_shape[f]], two);
+            analytic_bounding_tris(c->rects[shape_rect[face_shape[f]]], (uint32_t) shape_rect[face_shape[f]], two);
             t = two[0]; c->tris_in[(size_t) s->face_count + shape_rect[face_shape[f]]] = two[1];
             continue;
         }

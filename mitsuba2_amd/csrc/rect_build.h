@@ -24,6 +24,7 @@ inline RectRec rect_record(const float *to_world, const float *to_object, uint32
     r.dp_dv[0] = dp_dv.x; r.dp_dv[1] = dp_dv.y; r.dp_dv[2] = dp_dv.z;
     r.inv_area = rcp(norm(cross(dp_du, dp_dv)));                                 // :94, surface_area() :103-105
     r.shape = shape; r.prim = prim;
+    r.kind = ANALYTIC_RECTANGLE; r.radius = 0.f; r.flip = 0; r.pad_ = 0;
     return r;
 }
 
@@ -35,6 +36,34 @@ inline void rect_bounding_tris(const RectRec &r, uint32_t rect_index, Tri out[2]
     for (int k = 0; k < 2; ++k) { out[k].shape = r.shape; out[k].prim = r.prim; out[k].pad = rect_index + 1u; }
     put(out[0].p0, a); put(out[0].p1, b); put(out[0].p2, c);
     put(out[1].p0, a); put(out[1].p1, c); put(out[1].p2, d);
+}
+
+// Sphere::update(), src/shapes/sphere.cpp:108-131: center, radius, flip, the rebuilt to_world (uniform scale,
+// rotation, translation) and its inverse come from the host (transform_decompose / transform_compose).
+inline RectRec sphere_record(const float *center, float radius, bool flip, const float *to_world, const float *to_object,
+                             uint32_t shape, uint32_t prim) {
+    RectRec r;
+    std::memset(&r, 0, sizeof r);
+    std::memcpy(r.to_world, to_world, 64); std::memcpy(r.to_object, to_object, 64);
+    r.n[0] = center[0]; r.n[1] = center[1]; r.n[2] = center[2];
+    r.inv_area = rcp(4.f * MIW_PI * radius * radius);                           // :131, surface_area() :141-143
+    r.shape = shape; r.prim = prim; r.kind = ANALYTIC_SPHERE; r.radius = radius; r.flip = flip ? 1u : 0u;
+    return r;
+}
+// two triangles that both span bbox() = center -+ radius (:133-139) corner to corner: every leaf box holding one of
+// them contains the whole sphere
+inline void sphere_bounding_tris(const RectRec &r, uint32_t index, Tri out[2]) {
+    const float lo[3] = { r.n[0] - r.radius, r.n[1] - r.radius, r.n[2] - r.radius },
+                hi[3] = { r.n[0] + r.radius, r.n[1] + r.radius, r.n[2] + r.radius };
+    for (int k = 0; k < 2; ++k) {
+        out[k].shape = r.shape; out[k].prim = r.prim; out[k].pad = index + 1u;
+        std::memcpy(out[k].p0, lo, 12); std::memcpy(out[k].p1, hi, 12);
+    }
+    out[0].p2[0] = lo[0]; out[0].p2[1] = hi[1]; out[0].p2[2] = lo[2];
+    out[1].p2[0] = hi[0]; out[1].p2[1] = lo[1]; out[1].p2[2] = hi[2];
+}
+inline void analytic_bounding_tris(const RectRec &r, uint32_t index, Tri out[2]) {
+    if (r.kind == ANALYTIC_SPHERE) sphere_bounding_tris(r, index, out); else rect_bounding_tris(r, index, out);
 }
 
 } // namespace miw

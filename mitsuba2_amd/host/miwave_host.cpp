@@ -1103,10 +1103,50 @@ std::shared_ptr<Mesh> make_rectangle(const Properties &props) {
     mesh->m_rectangle = true; mesh->m_rect_to_world = tw;
     return mesh;
 }
+std::shared_ptr<Mesh> make_sphere(const Properties &props) {
+    Transform4f tw = props.transform("to_world", Transform4f());
+    Color3f c = props.has_property("center") ? props.texture("center") : Color3f{ 0.f, 0.f, 0.f };   // a 3-vector property
+    tw = tw * Transform4f::translate({ c[0], c[1], c[2] });                                          // sphere.cpp:101-102
+    float rs = props.float_("radius", 1.f);
+    tw = tw * Transform4f::scale({ rs, rs, rs });
+    // update(), :108-131. transform_decompose belongs to enoki (not vendored); for the transforms the plugin accepts
+    // (no shear, uniform scale) S = radius * I, Q = M / radius, T = the translation column.
+    const float *m = tw.m;
+    auto col = [&](int k) { return miw::v3(m[4 * k], m[4 * k + 1], m[4 * k + 2]); };
+    const float radius = miw::norm(col(0));
+    for (int k = 1; k < 3; ++k)
+        if (std::fabs(miw::norm(col(k)) - radius) > 1e-4f * radius) Throw("'to_world' transform shouldn't contain non-uniform scaling!");
+    if (std::fabs(miw::dot(col(0), col(1))) > 1e-4f * radius * radius || std::fabs(miw::dot(col(0), col(2))) > 1e-4f * radius * radius ||
+        std::fabs(miw::dot(col(1), col(2))) > 1e-4f * radius * radius) Throw("'to_world' transform shouldn't contain any shearing!");
+    if (!(radius > 0.f)) Throw("sphere: the radius must be positive");
+    mi_sphere rec{};
+    rec.center[0] = m[12]; rec.center[1] = m[13]; rec.center[2] = m[14];
+    rec.radius = radius; rec.flip_normals = props.bool_("flip_normals", false) ? 1u : 0u;
+    // transform_compose(radius, Q, T) and its inverse ((1 / radius) Q^T, -(1 / radius) Q^T T)
+    const float inv_r = 1.f / radius;
+    float q[3][3];
+    for (int k = 0; k < 3; ++k) { miw::V3 v = col(k); q[0][k] = v.x * inv_r; q[1][k] = v.y * inv_r; q[2][k] = v.z * inv_r; }
+    std::memset(rec.to_world, 0, 64); std::memset(rec.to_object, 0, 64);
+    for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 3; ++r) {
+        rec.to_world[cc * 4 + r] = q[r][cc] * radius;
+        rec.to_object[cc * 4 + r] = q[cc][r] * inv_r;
+    }
+    for (int r = 0; r < 3; ++r) {
+        rec.to_world[12 + r] = rec.center[r];
+        rec.to_object[12 + r] = -(rec.to_object[0 + r] * rec.center[0] + rec.to_object[4 + r] * rec.center[1] + rec.to_object[8 + r] * rec.center[2]);
+    }
+    rec.to_world[15] = rec.to_object[15] = 1.f;
+    std::vector<float> P;                                          // bbox() corners, :133-139
+    for (int i = 0; i < 8; ++i)
+        for (int a = 0; a < 3; ++a) P.push_back(rec.center[a] + (((i >> a) & 1) ? radius : -radius));
+    auto mesh = std::make_shared<Mesh>("sphere", std::move(P), std::vector<uint32_t>{ 0, 1, 2 });
+    mesh->m_sphere = true; mesh->m_sphere_rec = rec;
+    return mesh;
+}
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
                     std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
-                    std::vector<mi_emitter> &erecs, std::vector<mi_rectangle> &rrecs) {
-    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear();
+                    std::vector<mi_emitter> &erecs, std::vector<mi_rectangle> &rrecs, std::vector<mi_sphere> &sphrecs) {
+    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear(); sphrecs.clear();
     bool any_normals = false;
     for (auto &m : shapes) any_normals = any_normals || m->has_vertex_normals();
     std::map<const BSDF *, uint32_t> bsdf_index;
@@ -1158,12 +1198,18 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
             std::memcpy(r.to_world, m->rectangle_to_world().m, 64); std::memcpy(r.to_object, m->rectangle_to_world().inv, 64);
             rrecs.push_back(r);
         }
+        if (m->is_sphere()) {
+            s.flags |= MI_SHAPE_SPHERE;
+            mi_sphere r = m->sphere_record(); r.shape = (uint32_t) srecs.size();
+            sphrecs.push_back(r);
+        }
         srecs.push_back(s);
     }
 }
 void Scene::build(int device, int bvh_quality) {
     if (m_shapes.empty()) Throw("Scene: no shapes");
-    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs);
+    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
+    m_desc.spheres = m_sphere_recs.empty() ? nullptr : m_sphere_recs.data(); m_desc.sphere_count = (uint32_t) m_sphere_recs.size();
     m_desc.rectangles = m_rect_recs.empty() ? nullptr : m_rect_recs.data(); m_desc.rectangle_count = (uint32_t) m_rect_recs.size();
     m_desc.vertex_positions = m_positions.data();
     m_desc.vertex_normals = m_normals.empty() ? nullptr : m_normals.data();
@@ -1481,6 +1527,7 @@ std::vector<const XmlNode *> parse_properties(const XmlCtx &cx, const XmlNode &n
         else if (c.tag == "string") props.set_string(cx.get(c, "name"), cx.get(c, "value"));
         else if (c.tag == "rgb") { auto f = parse_floats(cx.get(c, "value"), "an <rgb> value"); if (f.size() == 1) f = { f[0], f[0], f[0] }; if (f.size() != 3) Throw("Error while loading XML: 'rgb' tag requires one or three values"); props.set_color(cx.get(c, "name"), { f[0], f[1], f[2] }); }
         else if (c.tag == "spectrum") { auto f = parse_floats(cx.get(c, "value"), "a <spectrum> value"); if (f.size() != 1) Throw("Error while loading XML: only constant <spectrum value=\"v\"/> is supported"); props.set_float(cx.get(c, "name"), f[0]); }
+        else if (c.tag == "point" || c.tag == "vector") { Vector3f v = parse_vec3(cx, c, 0.f); props.set_color(cx.get(c, "name"), Color3f{ v[0], v[1], v[2] }); }
         else if (c.tag == "transform") props.set_transform(cx.get(c, "name"), parse_transform(cx, c));
         else objects.push_back(&c);
     }
@@ -1578,6 +1625,8 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
                 mesh = p.plugin_name() == "obj" ? load_obj(p) : load_ply(p);
             } else if (p.plugin_name() == "rectangle") {
                 mesh = make_rectangle(p);
+            } else if (p.plugin_name() == "sphere") {
+                mesh = make_sphere(p);
             } else Throw("Plugin \"" + p.plugin_name() + "\" not found!");
             for (const XmlNode *c : objs) {
                 if (c->tag == "bsdf") mesh->set_bsdf(parse_bsdf(cx, *c));
@@ -1686,6 +1735,9 @@ void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uin
         std::vector<uint32_t> f(faces, faces + 3 * (size_t) nf);
         std::vector<float> n; if (normals) n.assign(normals, normals + 3 * (size_t) nv);
         return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n)) }; MIH_CATCH(nullptr)
+}
+void *mih_sphere_create(void *props) {                       // the `sphere` shape plugin (analytic)
+    MIH_TRY return new Box<Mesh>{ make_sphere(*(Properties *) props) }; MIH_CATCH(nullptr)
 }
 void *mih_rectangle_create(void *props) {                    // the `rectangle` shape plugin (analytic)
     MIH_TRY return new Box<Mesh>{ make_rectangle(*(Properties *) props) }; MIH_CATCH(nullptr)

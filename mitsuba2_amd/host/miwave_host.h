@@ -295,14 +295,22 @@ public:
     // device; its vertex buffer holds the four corners (scene bounds), its single face entry is a placeholder
     bool is_rectangle() const { return m_rectangle; }
     const Transform4f &rectangle_to_world() const { return m_rect_to_world; }
+    // the analytic `sphere` shape (make_sphere): one primitive; vertex buffer = the corners of its bounding box
+    bool is_sphere() const { return m_sphere; }
+    const mi_sphere &sphere_record() const { return m_sphere_rec; }
 private:
     friend std::shared_ptr<Mesh> make_rectangle(const Properties &props);
+// The `sphere` shape plugin (src/shapes/sphere.cpp:96-131): properties center (0), radius (1), to_world (identity:
+// rotation, translation, uniform scale only), flip_normals (false). An analytic primitive.
+std::shared_ptr<Mesh> make_sphere(const Properties &props);
+    friend std::shared_ptr<Mesh> make_sphere(const Properties &props);
     std::string m_name;
     std::vector<float> m_positions, m_normals;
     std::vector<uint32_t> m_faces;
     std::shared_ptr<BSDF> m_bsdf;
     std::shared_ptr<AreaLight> m_emitter;
     bool m_rectangle = false; Transform4f m_rect_to_world;
+    bool m_sphere = false; mi_sphere m_sphere_rec{};
 };
 // The `rectangle` shape plugin (src/shapes/rectangle.cpp:76-84): [-1, 1]^2 in z = 0, normal +z, properties
 // to_world (identity) and flip_normals (false). An analytic primitive — not two triangles.
@@ -344,7 +352,7 @@ private:
     std::vector<mi_shape> m_shape_recs;
     std::vector<mi_bsdf> m_bsdf_recs;
     std::vector<mi_emitter> m_emitters;
-    std::vector<mi_rectangle> m_rect_recs;
+    std::vector<mi_rectangle> m_rect_recs; std::vector<mi_sphere> m_sphere_recs;
     std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;

@@ -213,6 +213,32 @@ def rect_box(width, height, spp, seed=0, device=0, rfilter="gaussian", **film_kw
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 
+def sphere_box_meshes():
+    """Cornell box (mesh walls) lit by an analytic sphere light hanging under the ceiling, with an analytic glass sphere,
+    a rough-conductor sphere (rotated, to exercise to_world) and the short block."""
+    white = api.BSDF("diffuse", reflectance=WHITE)
+    red = api.BSDF("diffuse", reflectance=RED)
+    green = api.BSDF("diffuse", reflectance=GREEN)
+    shapes = []
+    for name, bsdf in (("floor", white), ("ceiling", white), ("back", white), ("right", green), ("left", red)):
+        v, f = _quad(_CBOX[name], inward_point=_ROOM_CENTER)
+        shapes.append(api.Mesh(name, v, f, bsdf=bsdf))
+    shapes.append(api.Mesh.sphere((278, 470, 280), 40.0, emitter=api.AreaLight((30.0, 24.0, 12.0)), name="bulb"))
+    v, f = _block(_SHORT); shapes.append(api.Mesh("short_block", v, f, bsdf=white))
+    shapes.append(api.Mesh.sphere((368, 110, 351), 110.0, bsdf=api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277), name="glass"))
+    a = np.deg2rad(30.0)
+    rot = np.array([[np.cos(a), 0, np.sin(a), 150.0], [0, 1, 0, 260.0], [-np.sin(a), 0, np.cos(a), 150.0], [0, 0, 0, 1]], np.float32)
+    metal = api.BSDF("roughconductor", distribution="ggx", alpha=0.15, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+    shapes.append(api.Mesh.sphere((0, 0, 0), 60.0, to_world=rot, bsdf=metal, name="metal"))
+    return shapes
+
+
+def sphere_box(width, height, spp, seed=0, device=0, rfilter="gaussian", **film_kw):
+    """-> (scene, sensor): analytic spheres (one of them the light) in the Cornell room (sphere_box_meshes)"""
+    scene = api.Scene(sphere_box_meshes()).build(device)
+    return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
+
+
 def sky_envmap(width=64, height=32, seed=1):
     """Synthetic lat-long HDR sky (the reference's data submodule is absent): vertical sky
     gradient, warm horizon band, dark ground, a sun blob and a little seeded noise. -> H x W x 3 float32."""

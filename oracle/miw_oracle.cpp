@@ -101,6 +101,12 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         o.rects.push_back(rect_record(q.to_world, q.to_object, q.shape, f));
         o.tris[f].pad = k + 1u; o.tris[f].prim = f;
     }
+    for (uint32_t k = 0; k < s->sphere_count; ++k) {           // Sphere(props) + update(), sphere.cpp:96-131
+        const mi_sphere &q = s->spheres[k];
+        const uint32_t f = s->shapes[q.shape].first_face;
+        o.rects.push_back(sphere_record(q.center, q.radius, q.flip_normals != 0, q.to_world, q.to_object, q.shape, f));
+        o.tris[f].pad = (uint32_t) o.rects.size(); o.tris[f].prim = f;
+    }
     for (uint32_t f = 0; f < s->face_count; ++f) {
         Tri &t = o.tris[f];
         if (t.pad) continue;                                  // a rectangle's primitive slot
@@ -143,7 +149,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
 #else
         r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
 #endif
-        if (sh.flags & MI_SHAPE_RECTANGLE) {                   // Rectangle::sample_position / pdf_position: no tables
+        if (sh.flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) {   // analytic shape: sampled by its own routines, no tables
             const uint32_t k = o.tris[sh.first_face].pad - 1u;
             r.shape = e.shape; r.tri_first = k; r.tri_count = 0; r.flags = 2u;
             r.normalization = o.rects[k].inv_area; r.sum = rcp(o.rects[k].inv_area);
@@ -183,7 +189,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     {   // shape.h: the bounds rule of every triangle hit; same extent as the product (mesh vertices + rectangle corners)
         std::vector<Tri> ext;
         for (const Tri &t : o.tris) if (!t.pad) ext.push_back(t);
-        for (size_t k = 0; k < o.rects.size(); ++k) { Tri two[2]; rect_bounding_tris(o.rects[k], (uint32_t) k, two); ext.push_back(two[0]); ext.push_back(two[1]); }
+        for (size_t k = 0; k < o.rects.size(); ++k) { Tri two[2]; analytic_bounding_tris(o.rects[k], (uint32_t) k, two); ext.push_back(two[0]); ext.push_back(two[1]); }
         v.accept_pad = scene_pad_unit(ext);
     }
     v.tri_bounds = nullptr;
@@ -228,8 +234,10 @@ bool ray_intersect(const OScene &sc, const Ray &ray, SurfaceInteraction &si) {
     OHit h = ray_intersect_preliminary(sc, ray);
     if (!h.valid) { si.t = std::numeric_limits<float>::infinity(); si.wi = -ray.d; return false; }
     const Tri &tr = sc.tris[h.prim];
-    if (tr.pad) {                                          // Rectangle::compute_surface_interaction, rectangle.cpp:175-208
-        compute_surface_interaction_rect(sc.rects[tr.pad - 1u], h.t, h.u, h.v, ray.o, ray.d, si);
+    if (tr.pad) {                                          // the analytic shape's own compute_surface_interaction
+        const RectRec &a = sc.rects[tr.pad - 1u];
+        if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.t, ray.o, ray.d, si);   // sphere.cpp:338-402
+        else compute_surface_interaction_rect(a, h.t, h.u, h.v, ray.o, ray.d, si);                     // rectangle.cpp:175-208
     } else {
         const float *vn = (sc.shapes[tr.shape].flags & 1u) ? &sc.tri_vn[(size_t) h.prim * 9] : nullptr;
         compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.t, h.u, h.v, ray.d, si);
@@ -344,7 +352,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
             }
             float emitter_pdf = 0.f;
             if (!(bs.sampled_type & BSDF_Delta))
-                emitter_pdf = pdf_emitter_direction(view, (uint32_t) emitter, d, dist, n);
+                emitter_pdf = pdf_emitter_direction(view, (uint32_t) emitter, d, dist, n, si.p);   // it = si
             emission_weight = mis_weight(bs.pdf, emitter_pdf);
         }
         si = si_bsdf; si_valid = si_bsdf_valid;          // :207

@@ -46,7 +46,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     }
     // analytic rectangles: record + two bounding triangles (the second one behind the faces), as mi_scene_upload
     o.rects.clear();
-    o.tris_in.resize((size_t) s->face_count + s->rectangle_count);
+    o.tris_in.resize((size_t) s->face_count + s->rectangle_count + s->sphere_count);
     for (uint32_t k = 0; k < s->rectangle_count; ++k) {
         const mi_rectangle &q = s->rectangles[k];
         const uint32_t f = s->shapes[q.shape].first_face;
@@ -54,6 +54,14 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         Tri two[2];
         rect_bounding_tris(o.rects.back(), k, two);
         o.tris_in[f] = two[0]; o.tris_in[(size_t) s->face_count + k] = two[1];
+    }
+    for (uint32_t k = 0; k < s->sphere_count; ++k) {
+        const mi_sphere &q = s->spheres[k];
+        const uint32_t f = s->shapes[q.shape].first_face, idx = (uint32_t) o.rects.size();
+        o.rects.push_back(sphere_record(q.center, q.radius, q.flip_normals != 0, q.to_world, q.to_object, q.shape, f));
+        Tri two[2];
+        sphere_bounding_tris(o.rects.back(), idx, two);
+        o.tris_in[f] = two[0]; o.tris_in[(size_t) s->face_count + idx] = two[1];
     }
     if (any_normals) o.vn_in.assign(o.tris_in.size() * 9, 0.f);
     for (uint32_t f = 0; f < s->face_count; ++f) {
@@ -97,7 +105,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
 #else
         r.radiance.type = TEX_RGB; std::memcpy(r.radiance.v, e.radiance, 12);
 #endif
-        if (sh.flags & MI_SHAPE_RECTANGLE) {
+        if (sh.flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) {
             const uint32_t k = o.tris_in[sh.first_face].pad - 1u;
             r.shape = e.shape; r.tri_first = k; r.tri_count = 0; r.flags = 2u;
             r.normalization = o.rects[k].inv_area; r.sum = rcp(o.rects[k].inv_area);
