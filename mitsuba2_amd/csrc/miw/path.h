@@ -242,7 +242,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         const Tri &tr = sc.tris[tri_idx];
         const ShapeRec &shape = sc.shapes[tr.shape];
         if (Analytic && tr.pad) {                        // analytic shape: its own compute_surface_interaction
-            const RectRec &a = sc.rects[tr.pad - 1u];
+            const AnalyticRec &a = sc.rects[tr.pad - 1u];
             if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.x, prev_o(), ray_d, si);
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, prev_o(), ray_d, si);
         } else {

@@ -56,7 +56,7 @@ struct SceneView {
     const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
     const float *emit_pmf, *emit_cdf;
     const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
-    const RectRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
+    const AnalyticRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
     float accept_pad;                               // shape.h: the bounds rule of every triangle hit
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
@@ -87,7 +87,7 @@ MIW_HD V3 square_to_uniform_sphere(V2 sample) {
 }
 // Sphere::sample_direction (:169-246): uniform over the cone the sphere subtends from outside, over the surface from
 // inside. Fills ds.p, ds.n, ds.d, ds.dist, ds.pdf.
-MIW_HD void sphere_sample_direction(const RectRec &r, V3 ref_p, V2 sample, DirectionSample &ds) {
+MIW_HD void sphere_sample_direction(const AnalyticRec &r, V3 ref_p, V2 sample, DirectionSample &ds) {
     const V3 center = ld3(r.n);
     const float radius = r.radius;
     V3 dc_v = center - ref_p;
@@ -130,7 +130,7 @@ MIW_HD void sphere_sample_direction(const RectRec &r, V3 ref_p, V2 sample, Direc
     if (r.flip) ds.n = -ds.n;                              // :243-244
 }
 // Sphere::pdf_direction, :248-262
-MIW_HD float sphere_pdf_direction(const RectRec &r, V3 ref_p, V3 ds_d, float ds_dist, V3 ds_n) {
+MIW_HD float sphere_pdf_direction(const AnalyticRec &r, V3 ref_p, V3 ds_d, float ds_dist, V3 ds_n) {
     float sin_alpha = r.radius * rcp(norm(ld3(r.n) - ref_p)),
           cos_alpha = safe_sqrt(1.f - sin_alpha * sin_alpha);
     return sin_alpha < (1.f - MIW_EPSILON) ? (.5f * MIW_INV_PI) / (1.f - cos_alpha)       // math::OneMinusEpsilon

@@ -23,14 +23,14 @@ struct Tri {
     uint32_t shape;      // index into the shape table
     uint32_t prim;       // global primitive id (scene order) — closest-hit tie break
     uint32_t pad;        // 0: a mesh triangle. k > 0: one of the two bounding triangles of analytic rectangle k - 1
-                         // (RectRec table): the BVH builders see ordinary triangles, the leaf test runs the
+                         // (AnalyticRec table): the BVH builders see ordinary triangles, the leaf test runs the
                          // rectangle's own intersection routine (both halves give the same answer)
 };
 
 // Analytic shapes. kind 0 = rectangle (src/shapes/rectangle.cpp): [-1, 1]^2 in z = 0 of object space;
 // kind 1 = sphere (src/shapes/sphere.cpp). 4x4 matrices column-major.
 enum : uint32_t { ANALYTIC_RECTANGLE = 0, ANALYTIC_SPHERE = 1 };
-struct RectRec {
+struct AnalyticRec {
     float to_world[16], to_object[16];
     float n[3], inv_area;         // rectangle: m_frame.n; sphere: m_center. m_inv_surface_area
     float dp_du[3]; uint32_t shape;
@@ -79,7 +79,7 @@ MIW_HD bool ray_intersect_triangle(V3 p0, V3 p1, V3 p2, V3 o, V3 d, float mint, 
 }
 
 // Rectangle::ray_intersect_preliminary / ray_test, rectangle.cpp:139-173 (u, v = prim_uv = local x, y)
-MIW_HD bool ray_intersect_rectangle(const RectRec &r, V3 o, V3 d, float mint, float maxt,
+MIW_HD bool ray_intersect_rectangle(const AnalyticRec &r, V3 o, V3 d, float mint, float maxt,
                                     float &t_out, float &u_out, float &v_out) {
     V3 ol = xf_point_affine(r.to_object, o), dl = xf_vector(r.to_object, d);   // m_to_object.transform_affine(ray_)
     float t = -ol.z * rcp(dl.z);                                                 // -ray.o.z() * ray.d_rcp.z()
@@ -98,7 +98,7 @@ MIW_HD bool ray_intersect_rectangle(const RectRec &r, V3 o, V3 d, float mint, fl
 // `accept_pad` (1e-5 x the largest |coordinate| of the scene; the BVH boxes are grown by twice that, so a hit
 // that counts is never culled). Brute force, packet sweep, leaf filter and both tree walks then agree by
 // construction; for well-conditioned hits the rule never fires.
-struct PrimCtx { const RectRec *rects; float accept_pad; };
+struct PrimCtx { const AnalyticRec *rects; float accept_pad; };
 struct TriBounds { float lo[3], hi[3]; };                  // bounding box of a triangle's vertices, grown by accept_pad
 MIW_HD TriBounds tri_bounds(V3 p0, V3 p1, V3 p2, float pad) {
     TriBounds b;
@@ -128,7 +128,7 @@ MIW_HD bool solve_quadratic_d(double a, double b, double c, double &x0, double &
     return valid_linear || valid_quadratic;
 }
 // Sphere::ray_intersect_preliminary / ray_test, sphere.cpp:281-336 (u = v = 0: the sphere reports no prim_uv)
-MIW_HD bool ray_intersect_sphere(const RectRec &r, V3 o_, V3 d_, float mint_, float maxt_,
+MIW_HD bool ray_intersect_sphere(const AnalyticRec &r, V3 o_, V3 d_, float mint_, float maxt_,
                                  float &t_out, float &u_out, float &v_out) {
     const double mint = (double) mint_, maxt = (double) maxt_;
     const double ox = (double) o_.x - (double) r.n[0], oy = (double) o_.y - (double) r.n[1], oz = (double) o_.z - (double) r.n[2];
@@ -153,7 +153,7 @@ template <bool Analytic = true>
 MIW_HD bool prim_intersect(const Tri &tr, PrimCtx ctx, V3 o, V3 d, float mint, float maxt,
                            float &t, float &u, float &v) {
     if (Analytic && tr.pad) {
-        const RectRec &a = ctx.rects[tr.pad - 1u];
+        const AnalyticRec &a = ctx.rects[tr.pad - 1u];
         return a.kind == ANALYTIC_SPHERE ? ray_intersect_sphere(a, o, d, mint, maxt, t, u, v)
                                          : ray_intersect_rectangle(a, o, d, mint, maxt, t, u, v);
     }
@@ -198,7 +198,7 @@ MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
 }
 
 // Rectangle::compute_surface_interaction, rectangle.cpp:175-208 + interaction.h:571-596
-MIW_HD void compute_surface_interaction_rect(const RectRec &r, float t, float u, float v, V3 ray_o, V3 ray_d,
+MIW_HD void compute_surface_interaction_rect(const AnalyticRec &r, float t, float u, float v, V3 ray_o, V3 ray_d,
                                              SurfaceInteraction &si) {
     si.t = t;
     si.p = v3(fmadd(ray_d.x, t, ray_o.x), fmadd(ray_d.y, t, ray_o.y), fmadd(ray_d.z, t, ray_o.z));   // ray(pi.t), :196
@@ -217,7 +217,7 @@ MIW_HD float unit_angle_z(V3 v) {
     return v.z >= 0.f ? temp : MIW_PI - temp;
 }
 // Sphere::compute_surface_interaction, sphere.cpp:338-402 + interaction.h:571-596
-MIW_HD void compute_surface_interaction_sphere(const RectRec &r, float t, V3 ray_o, V3 ray_d, SurfaceInteraction &si) {
+MIW_HD void compute_surface_interaction_sphere(const AnalyticRec &r, float t, V3 ray_o, V3 ray_d, SurfaceInteraction &si) {
     const V3 center = ld3(r.n);
     si.t = t;
     V3 n = normalize(v3(fmadd(ray_d.x, t, ray_o.x), fmadd(ray_d.y, t, ray_o.y), fmadd(ray_d.z, t, ray_o.z)) - center);   // :359
@@ -264,7 +264,7 @@ MIW_HD uint32_t distr_sample(const MeshSampler &m, float value) {
 struct PositionSample { V3 p, n; V2 uv; float pdf; };
 
 // Rectangle::sample_position, rectangle.cpp:111-125
-MIW_HD PositionSample rect_sample_position(const RectRec &r, V2 sample) {
+MIW_HD PositionSample rect_sample_position(const AnalyticRec &r, V2 sample) {
     PositionSample ps;
     ps.p = xf_point_affine(r.to_world, v3(sample.x * 2.f - 1.f, sample.y * 2.f - 1.f, 0.f));
     ps.n = ld3(r.n); ps.pdf = r.inv_area; ps.uv = sample;

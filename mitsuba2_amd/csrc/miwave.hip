@@ -1163,7 +1163,7 @@ struct mi_ctx {
     std::vector<Tri> tris_in;
     std::vector<float> tri_vn_in;       // 9 per tri or empty
     std::vector<ShapeRec> shapes;
-    std::vector<RectRec> rects;                 // analytic rectangles
+    std::vector<AnalyticRec> rects;                 // analytic rectangles
     std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
@@ -1171,7 +1171,7 @@ struct mi_ctx {
 
     // device scene
     DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
-    DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<RectRec> d_rects;
+    DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<AnalyticRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds;
     DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
@@ -1398,7 +1398,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         r.radiance.type = TEX_RGB; memcpy(r.radiance.v, e.radiance, 12);
 #endif
         if (shape_rect[e.shape] >= 0) {                        // area light on an analytic rectangle: no face tables
-            const RectRec &q = c->rects[shape_rect[e.shape]];
+            const AnalyticRec &q = c->rects[shape_rect[e.shape]];
             r.shape = e.shape; r.tri_first = (uint32_t) shape_rect[e.shape]; r.tri_count = 0; r.flags = 2u;
             r.valid_lo = r.valid_hi = 0; r.normalization = q.inv_area; r.sum = rcp(q.inv_area);
             c->emitters.push_back(r);

@@ -8,8 +8,8 @@
 namespace miw {
 
 // to_world / to_object: 4x4 column-major (Transform4f::matrix and its inverse)
-inline RectRec rect_record(const float *to_world, const float *to_object, uint32_t shape, uint32_t prim) {
-    RectRec r;
+inline AnalyticRec rect_record(const float *to_world, const float *to_object, uint32_t shape, uint32_t prim) {
+    AnalyticRec r;
     std::memcpy(r.to_world, to_world, 64); std::memcpy(r.to_object, to_object, 64);
     const V3 dp_du = xf_vector(to_world, v3(2.f, 0.f, 0.f)), dp_dv = xf_vector(to_world, v3(0.f, 2.f, 0.f));   // :89-90
     // m_to_world * Normal3f(0, 0, 1): columns of the inverse transpose = rows of the inverse, transform.h:134-142
@@ -29,7 +29,7 @@ inline RectRec rect_record(const float *to_world, const float *to_object, uint32
 }
 
 // the two triangles (A, B, C), (A, C, D) over the corners (-1,-1), (1,-1), (1,1), (-1,1): same bounds as bbox()
-inline void rect_bounding_tris(const RectRec &r, uint32_t rect_index, Tri out[2]) {
+inline void rect_bounding_tris(const AnalyticRec &r, uint32_t rect_index, Tri out[2]) {
     const V3 a = xf_point_affine(r.to_world, v3(-1.f, -1.f, 0.f)), b = xf_point_affine(r.to_world, v3(1.f, -1.f, 0.f)),
              c = xf_point_affine(r.to_world, v3(1.f, 1.f, 0.f)), d = xf_point_affine(r.to_world, v3(-1.f, 1.f, 0.f));
     auto put = [](float *dst, V3 p) { dst[0] = p.x; dst[1] = p.y; dst[2] = p.z; };
@@ -40,9 +40,9 @@ inline void rect_bounding_tris(const RectRec &r, uint32_t rect_index, Tri out[2]
 
 // Sphere::update(), src/shapes/sphere.cpp:108-131: center, radius, flip, the rebuilt to_world (uniform scale,
 // rotation, translation) and its inverse come from the host (transform_decompose / transform_compose).
-inline RectRec sphere_record(const float *center, float radius, bool flip, const float *to_world, const float *to_object,
+inline AnalyticRec sphere_record(const float *center, float radius, bool flip, const float *to_world, const float *to_object,
                              uint32_t shape, uint32_t prim) {
-    RectRec r;
+    AnalyticRec r;
     std::memset(&r, 0, sizeof r);
     std::memcpy(r.to_world, to_world, 64); std::memcpy(r.to_object, to_object, 64);
     r.n[0] = center[0]; r.n[1] = center[1]; r.n[2] = center[2];
@@ -52,7 +52,7 @@ inline RectRec sphere_record(const float *center, float radius, bool flip, const
 }
 // two triangles that both span bbox() = center -+ radius (:133-139) corner to corner: every leaf box holding one of
 // them contains the whole sphere
-inline void sphere_bounding_tris(const RectRec &r, uint32_t index, Tri out[2]) {
+inline void sphere_bounding_tris(const AnalyticRec &r, uint32_t index, Tri out[2]) {
     const float lo[3] = { r.n[0] - r.radius, r.n[1] - r.radius, r.n[2] - r.radius },
                 hi[3] = { r.n[0] + r.radius, r.n[1] + r.radius, r.n[2] + r.radius };
     for (int k = 0; k < 2; ++k) {
@@ -62,7 +62,7 @@ inline void sphere_bounding_tris(const RectRec &r, uint32_t index, Tri out[2]) {
     out[0].p2[0] = lo[0]; out[0].p2[1] = hi[1]; out[0].p2[2] = lo[2];
     out[1].p2[0] = hi[0]; out[1].p2[1] = lo[1]; out[1].p2[2] = hi[2];
 }
-inline void analytic_bounding_tris(const RectRec &r, uint32_t index, Tri out[2]) {
+inline void analytic_bounding_tris(const AnalyticRec &r, uint32_t index, Tri out[2]) {
     if (r.kind == ANALYTIC_SPHERE) sphere_bounding_tris(r, index, out); else rect_bounding_tris(r, index, out);
 }
 

@@ -71,7 +71,7 @@ struct FtzScope {
 // ---- scene in scene order (no acceleration structure: brute force) ------------------------
 struct OScene {
     std::vector<Tri> tris;              // face order == global primitive id; pad = k + 1: the slot of analytic rectangle k
-    std::vector<RectRec> rects;         // analytic rectangles (src/shapes/rectangle.cpp)
+    std::vector<AnalyticRec> rects;         // analytic rectangles (src/shapes/rectangle.cpp)
     std::vector<float> tri_vn;          // 9 per face or empty
     std::vector<ShapeRec> shapes;
     std::vector<BsdfRec> bsdfs;
@@ -235,7 +235,7 @@ bool ray_intersect(const OScene &sc, const Ray &ray, SurfaceInteraction &si) {
     if (!h.valid) { si.t = std::numeric_limits<float>::infinity(); si.wi = -ray.d; return false; }
     const Tri &tr = sc.tris[h.prim];
     if (tr.pad) {                                          // the analytic shape's own compute_surface_interaction
-        const RectRec &a = sc.rects[tr.pad - 1u];
+        const AnalyticRec &a = sc.rects[tr.pad - 1u];
         if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.t, ray.o, ray.d, si);   // sphere.cpp:338-402
         else compute_surface_interaction_rect(a, h.t, h.u, h.v, ray.o, ray.d, si);                     // rectangle.cpp:175-208
     } else {

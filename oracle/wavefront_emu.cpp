@@ -25,7 +25,7 @@ using namespace miw;
 namespace {
 struct EmuScene {
     std::vector<Tri> tris_in; std::vector<float> vn_in;
-    std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters; std::vector<RectRec> rects;
+    std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters; std::vector<AnalyticRec> rects;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     BvhBuildResult bvh; std::vector<float> vn_leaf;
     EnvmapTables env;
