@@ -53,6 +53,8 @@ def main():
                     help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs oracle/_ref/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
     ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
+    ap.add_argument("--integrator", default="path", choices=["path", "direct"],
+                    help="path = the headline (BASELINE metric); direct = src/integrators/direct.cpp on the same device loop")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
     ap.add_argument("--samples-per-launch", type=int, default=-1,
                     help="resident plan: samples each pixel advances per launch (-1 = all spp in one launch, 0 = library default)")
@@ -87,7 +89,8 @@ def main():
     dev = api.Device(local_rank)
     dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
     bvh = dev.counters()
-    integ = api.PathIntegrator()
+    make_integrator = api.DirectIntegrator if args.integrator == "direct" else api.PathIntegrator
+    integ = make_integrator()
     integ.set_shard(rank, world)
     if args.shard_of > 1 and world == 1:
         integ.set_shard(0, args.shard_of)
@@ -182,7 +185,7 @@ def main():
             O = oracle_py.load(args.variant)
             cores = os.cpu_count() or 1
             nblocks = max(8, cores)                          # bounded sample: one centre-most spiral block per host thread, full spp
-            one = api.PathIntegrator().render_job(sensor)
+            one = make_integrator().render_job(sensor)
             _, _, st = O.render(scene.desc(), one, threads=cores, want_f64=False, only_blocks=np.arange(nblocks, dtype=np.uint32))
             cpu = {"value": st.samples / st.seconds / 1e6, "unit": "Msamples/sec", "cores": cores, "kind": "port",
                    "sample": "first %d spiral blocks (32x32 px) of the same %dx%d@%dspp job, %d samples, %.1f s" %
@@ -191,7 +194,7 @@ def main():
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "variant": args.variant,
+            "variant": args.variant, "integrator": args.integrator,
             "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                     "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
                                     "procedural interior (911 362 triangles: displaced wall grids + 200 icospheres, diffuse / GGX / "

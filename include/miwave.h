@@ -201,7 +201,16 @@ typedef struct {
      * of pass p carry ids p * block_count + counter, spiral.cpp:41); this pass's block tiles are added onto it,
      * after the ids already in it. 0: the film is overwritten. */
     int32_t accumulate;
+    /* which SamplingIntegrator::sample runs per camera sample:
+     * MI_INTEGRATOR_PATH   PathIntegrator (src/integrators/path.cpp:100-211): max_depth, rr_depth above,
+     * MI_INTEGRATOR_DIRECT DirectIntegrator (src/integrators/direct.cpp:78-198): emitter_samples + bsdf_samples
+     *                      (>= 1 in total; `shading_samples` sets both, :89-96) and hide_emitters
+     *                      (integrator.cpp:37); max_depth / rr_depth are ignored. Resident plan only. */
+    int32_t integrator;
+    uint32_t emitter_samples, bsdf_samples;
+    int32_t hide_emitters;
 } mi_render_cfg;
+enum { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_DIRECT = 1 };
 
 typedef struct {
     uint64_t samples;          /* camera samples finished                               */

@@ -77,7 +77,9 @@ class mi_render_cfg(C.Structure):
                 ("filter_lut", C.c_float * 32), ("filter_radius", C.c_float), ("filter_border", C.c_int32),
                 ("film_on_device", C.c_int32), ("film_f64", C.c_int32), ("film_mode", C.c_int32),
                 ("profile", C.c_int32),
-                ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32), ("accumulate", C.c_int32)]
+                ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32), ("accumulate", C.c_int32),
+                ("integrator", C.c_int32), ("emitter_samples", C.c_uint32), ("bsdf_samples", C.c_uint32),
+                ("hide_emitters", C.c_int32)]
 
 
 class mi_counters(C.Structure):
@@ -93,6 +95,7 @@ class mi_counters(C.Structure):
                 ("bvh_on_device", C.c_uint32), ("pad_", C.c_uint32), ("ms_film_pack", C.c_double)]
 
 
+MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
 MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
                FP_SEMANTICS=7, SPECIAL=8, ENVMAP=9, INVTRIG=10)

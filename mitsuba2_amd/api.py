@@ -446,7 +446,7 @@ def _load_xml(text_or_path, is_file, params):
     sensor = None
     if hs[1]:
         sensor = _wrap(Sensor, hs[1], film=_wrap(Film, hs[2]), sampler=_wrap(Sampler, hs[3]))
-    return scene, sensor, _wrap(PathIntegrator, hs[4])
+    return scene, sensor, _wrap(SamplingIntegrator, hs[4])
 
 
 def load_string(xml, **params):
@@ -468,9 +468,12 @@ class RenderJob:
         self.cfg, self.block_ids, self.tiles = cfg, block_ids, tiles
 
 
-class PathIntegrator:
+class SamplingIntegrator:
+    """include/mitsuba/render/integrator.h: what every sampling integrator shares; `plugin` names the sample() routine"""
+    plugin = None
+
     def __init__(self, **kw):
-        self._p = Properties("path", **kw)
+        self._p = Properties(self.plugin, **kw)
         self.h = host_lib().mih_integrator_create(self._p.h)
         if not self.h:
             raise RuntimeError(_err())
@@ -516,6 +519,16 @@ class PathIntegrator:
     def __del__(self):
         if getattr(self, "h", None):
             host_lib().mih_integrator_destroy(self.h); self.h = None
+
+
+class PathIntegrator(SamplingIntegrator):
+    """src/integrators/path.cpp: max_depth, rr_depth (+ block_size, samples_per_pass, timeout)"""
+    plugin = "path"
+
+
+class DirectIntegrator(SamplingIntegrator):
+    """src/integrators/direct.cpp: shading_samples | emitter_samples + bsdf_samples, hide_emitters"""
+    plugin = "direct"
 
 
 def spiral(w, h, block_size, offset=(0, 0)):

@@ -62,12 +62,21 @@ struct LaneQueues {
     F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
 };
 
+// Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)
+enum : uint32_t { INTEG_PATH = 0, INTEG_DIRECT = 1 };
+struct DirectRec {
+    uint32_t emitter_samples, bsdf_samples, hide_emitters;
+    float frac_bsdf, frac_lum, weight_bsdf, weight_lum;
+};
+
 struct RenderParams {
     SensorRec sensor;
     FilmRec film;
     uint32_t spp;
     int32_t max_depth, rr_depth;
     uint32_t n_lanes;
+    uint32_t integrator;             // INTEG_*
+    DirectRec direct;
 };
 
 // per-launch device counters (mi_get_counters)
@@ -459,8 +468,12 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
     }
 }
 
+template <bool Analytic, typename Work, typename Trace2>
+MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
+                                       Trace2 trace2, Counters *cnt_local);     // direct.h
+
 // One pixel, samples [st.w, sample_end): returns the updated st word.
-template <typename Trace2, typename Sink>
+template <uint32_t Integ = INTEG_PATH, typename Trace2, typename Sink>
 MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
                        Trace2 trace2, Sink sink, Counters *cnt_local) {
     struct OnePixel {
@@ -469,7 +482,8 @@ MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixe
         MIW_HD void store(U4 s) { st = s; }
         MIW_HD void put(uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { sink(px, sample_idx, pos, aovs); }
     } work{ pixel, st, false, sink };
-    pixel_stream_render(P, sc, sample_end, work, trace2, cnt_local);
+    if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<true>(P, sc, sample_end, work, trace2, cnt_local);
+    else pixel_stream_render(P, sc, sample_end, work, trace2, cnt_local);
     return work.st;
 }
 

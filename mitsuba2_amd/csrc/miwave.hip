@@ -49,6 +49,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "miw/film.h"
 #include "miw/bvh.h"
 #include "miw/path.h"
+#include "miw/direct.h"
 #include "rect_build.h"
 #include "miw/film_gather.h"
 #include "bvh_build.h"
@@ -603,7 +604,8 @@ struct QueueWork {
 };
 
 // Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
-template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0)>
+// Integ: which SamplingIntegrator::sample the pixel loop runs (path.h / direct.h).
+template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH>
 __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -632,7 +634,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
-        pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
+        if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
+        else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];
         if (!(st.z & LF_DONE)) {
@@ -640,11 +643,11 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
             if (T.side) {
                 TileAdd add; add.tile = tile; add.x0 = tile_x0; add.y0 = tile_y0; add.side = (int) T.side;
                 SplatXYSink<TileAdd> sink; sink.film = &P.film; sink.add = add;
-                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
+                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
             } else {
                 FilmAdd add; add.accum = accum;
                 SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
-                st = pixel_render(P, sc, pixel, st, sample_end, tr2, sink, &local);
+                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
             }
             Q.st[lane] = st;
         }
@@ -1637,8 +1640,8 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
         return fail(c, MI_ERR_INVALID, "render: film larger than 65535 pixels per side");
     if (cfg->block_size <= 0 || (cfg->block_size & (cfg->block_size - 1)))
         return fail(c, MI_ERR_INVALID, "render: block_size must be a power of two");
-    if (cfg->rr_depth <= 0) return fail(c, MI_ERR_INVALID, "\"rr_depth\" must be set to a value greater than zero!");
-    if (cfg->max_depth < 0 && cfg->max_depth != -1) return fail(c, MI_ERR_INVALID, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+    if (cfg->integrator == MI_INTEGRATOR_PATH && cfg->rr_depth <= 0) return fail(c, MI_ERR_INVALID, "\"rr_depth\" must be set to a value greater than zero!");
+    if (cfg->integrator == MI_INTEGRATOR_PATH && cfg->max_depth < 0 && cfg->max_depth != -1) return fail(c, MI_ERR_INVALID, "\"max_depth\" must be set to -1 (infinite) or a value >= 0");
     if (cfg->filter_radius <= 0.f || cfg->filter_radius > 4.f) return fail(c, MI_ERR_INVALID, "render: filter radius out of range (0, 4]");
     memset(&P, 0, sizeof P);
     memcpy(P.sensor.sample_to_camera, cfg->sample_to_camera, 64);
@@ -1651,6 +1654,15 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
     P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
+    if (cfg->integrator == MI_INTEGRATOR_DIRECT) {               // direct.cpp:82-103
+        const uint32_t ne = cfg->emitter_samples, nb = cfg->bsdf_samples;
+        if (ne + nb == 0) return fail(c, MI_ERR_INVALID, "Must have at least 1 BSDF or emitter sample!");
+        P.integrator = INTEG_DIRECT;
+        P.direct.emitter_samples = ne; P.direct.bsdf_samples = nb; P.direct.hide_emitters = cfg->hide_emitters ? 1u : 0u;
+        P.direct.weight_bsdf = 1.f / (float) nb; P.direct.weight_lum = 1.f / (float) ne;
+        P.direct.frac_bsdf = (float) nb / (float) (ne + nb); P.direct.frac_lum = (float) ne / (float) (ne + nb);
+    } else if (cfg->integrator != MI_INTEGRATOR_PATH)
+        return fail(c, MI_ERR_INVALID, "render: unknown integrator %d", cfg->integrator);
     return MI_OK;
 }
 
@@ -1691,6 +1703,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     if (cfg->plan == 1) return fail(c, MI_ERR_INVALID, "render: the scalar_spectral library runs the resident plan only (plan 0 or 2)");
     plan = 2;
 #endif
+    const bool direct = P.integrator == INTEG_DIRECT;
+    if (direct) {                                                // direct.h runs on the paired query of the resident plan
+        if (cfg->plan == 1) return fail(c, MI_ERR_INVALID, "render: the direct integrator runs the resident plan only (plan 0 or 2)");
+        plan = 2;
+    }
     c->counters.plan = (uint32_t) plan;
 
     size_t nl = std::max<uint32_t>(n_lanes, 1);
@@ -1818,6 +1835,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             if (c->lds_bytes + tile_bytes > 64 * 1024) {
                 HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
                 HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 1, MATS_ALL, false, INTEG_DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
+                HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 0, MATS_ALL, true, INTEG_DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
             }
         }
         const bool tiny = c->lds_cfg.brute != 0;
@@ -1839,13 +1858,21 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
-                if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
+                if (direct) {
+                    if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                    else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                }
+                else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_ALL);
                 else if (tiny) MIW_PATH_LAUNCH(1, MATS_ALL);
                 else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_ALL);
                 else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
-            } else if (tiny)
+            } else if (direct && tiny)
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1, MATS_ALL, false, INTEG_DIRECT>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+            else if (direct)
+                MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 0, MATS_ALL, true, INTEG_DIRECT>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+            else if (tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             else
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 0>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));

@@ -1274,19 +1274,43 @@ bool Scene::ray_test(const Ray3f &r) const {
 // ============================================================================================
 static uint32_t round_to_power_of_two(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return v == 0 ? 0 : r; }
 
-PathIntegrator::PathIntegrator(const Properties &props) {
+SamplingIntegrator::SamplingIntegrator(const Properties &props) {
     m_block_size = (uint32_t) props.int_("block_size", 0);
     uint32_t bs = round_to_power_of_two(m_block_size);
     if (m_block_size > 0 && bs != m_block_size) m_block_size = bs;   // integrator.cpp:27-32 (warns)
     m_samples_per_pass = (uint32_t) props.int_("samples_per_pass", (int64_t) (uint32_t) -1);
     m_timeout = props.float_("timeout", -1.f);
     m_hide_emitters = props.bool_("hide_emitters", false);
+}
+PathIntegrator::PathIntegrator(const Properties &props) : SamplingIntegrator(props) {
     m_rr_depth = (int) props.int_("rr_depth", 5);
     if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
     m_max_depth = (int) props.int_("max_depth", -1);
     if (m_max_depth < 0 && m_max_depth != -1) Throw("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
 }
-void PathIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
+void PathIntegrator::fill_integrator(mi_render_cfg &cfg) const {
+    cfg.integrator = MI_INTEGRATOR_PATH; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+}
+// direct.cpp:82-103
+DirectIntegrator::DirectIntegrator(const Properties &props) : SamplingIntegrator(props) {
+    if (props.has_property("shading_samples") && (props.has_property("emitter_samples") || props.has_property("bsdf_samples")))
+        Throw("Cannot specify both 'shading_samples' and ('emitter_samples' and/or 'bsdf_samples').");
+    size_t shading_samples = (size_t) props.int_("shading_samples", 1);
+    m_emitter_samples = (size_t) props.int_("emitter_samples", (int64_t) shading_samples);
+    m_bsdf_samples = (size_t) props.int_("bsdf_samples", (int64_t) shading_samples);
+    if (m_emitter_samples + m_bsdf_samples == 0) Throw("Must have at least 1 BSDF or emitter sample!");
+}
+void DirectIntegrator::fill_integrator(mi_render_cfg &cfg) const {
+    cfg.integrator = MI_INTEGRATOR_DIRECT; cfg.max_depth = -1; cfg.rr_depth = 5;
+    cfg.emitter_samples = (uint32_t) m_emitter_samples; cfg.bsdf_samples = (uint32_t) m_bsdf_samples;
+    cfg.hide_emitters = m_hide_emitters ? 1 : 0;
+}
+std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props) {
+    if (props.plugin_name() == "path") return std::make_shared<PathIntegrator>(props);
+    if (props.plugin_name() == "direct") return std::make_shared<DirectIntegrator>(props);
+    Throw("Plugin \"" + props.plugin_name() + "\" not found!");
+}
+void SamplingIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
 
 // integrator.cpp:75-86
 static size_t samples_per_pass_of(uint32_t samples_per_pass, size_t total_spp) {
@@ -1295,11 +1319,11 @@ static size_t samples_per_pass_of(uint32_t samples_per_pass, size_t total_spp) {
         Throw("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(spp_pass) + ").");
     return spp_pass;
 }
-uint32_t PathIntegrator::pass_count(const PerspectiveCamera *sensor) const {
+uint32_t SamplingIntegrator::pass_count(const PerspectiveCamera *sensor) const {
     size_t total_spp = sensor->sampler()->sample_count();
     return (uint32_t) (total_spp / samples_per_pass_of(m_samples_per_pass, total_spp));
 }
-void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
                                      std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
                                      uint32_t n_threads, uint32_t pass) const {
     std::memset(&cfg, 0, sizeof cfg);
@@ -1319,7 +1343,8 @@ void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_
         }
     }
     cfg.crop_x = co[0]; cfg.crop_y = co[1]; cfg.crop_w = cs[0]; cfg.crop_h = cs[1];
-    cfg.spp = (uint32_t) spp_pass; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+    cfg.spp = (uint32_t) spp_pass;
+    fill_integrator(cfg);
     cfg.accumulate = pass > 0 ? 1 : 0;
     cfg.base_seed = sensor->sampler()->base_seed();
     cfg.block_size = (int32_t) bs;
@@ -1351,7 +1376,7 @@ void PathIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_
     cfg.plan = m_plan;
 }
 
-bool PathIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+bool SamplingIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
     if (!scene || !sensor) Throw("render(): null scene or sensor");
     if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
     Film *film = sensor->film().get();
@@ -1581,9 +1606,9 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
         else if (n.tag == "bsdf") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <bsdf> needs an id"); parse_bsdf(cx, n); }
         else if (n.tag == "integrator") {
             Properties p(cx.get(n, "type"));
-            if (p.plugin_name() != "path") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
+            if (p.plugin_name() != "path" && p.plugin_name() != "direct") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
             parse_properties(cx, n, p);
-            out.integrator = std::make_shared<PathIntegrator>(p);
+            out.integrator = make_integrator(p);
         } else if (n.tag == "sensor") {
             Properties p(cx.get(n, "type"));
             if (p.plugin_name() != "perspective") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
@@ -1781,7 +1806,7 @@ int mih_load_xml(const char *xml_or_path, int is_file, const char *params, void 
         *sensor = ls.sensor ? new Box<PerspectiveCamera>{ ls.sensor } : nullptr;
         *film = ls.sensor ? new Box<Film>{ ls.sensor->film() } : nullptr;
         *sampler = ls.sensor ? new Box<IndependentSampler>{ ls.sensor->sampler() } : nullptr;
-        *integrator = new Box<PathIntegrator>{ ls.integrator };
+        *integrator = new Box<SamplingIntegrator>{ ls.integrator };
         return 0; MIH_CATCH(-1)
 }
 void *mih_scene_create() { return new Box<Scene>{ std::make_shared<Scene>() }; }
@@ -1860,24 +1885,23 @@ float mih_sensor_x_fov(void *s) { return ((Box<PerspectiveCamera> *) s)->p->x_fo
 void *mih_integrator_create(void *props) {
     MIH_TRY
         const Properties &p = *(Properties *) props;
-        if (p.plugin_name() != "path") throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
-        return new Box<PathIntegrator>{ std::make_shared<PathIntegrator>(p) }; MIH_CATCH(nullptr)
+        return new Box<SamplingIntegrator>{ make_integrator(p) }; MIH_CATCH(nullptr)
 }
-void mih_integrator_destroy(void *i) { delete (Box<PathIntegrator> *) i; }
-void mih_integrator_set_shard(void *i, uint32_t rank, uint32_t world) { ((Box<PathIntegrator> *) i)->p->set_shard(rank, world); }
-void mih_integrator_set_profile(void *i, int on) { ((Box<PathIntegrator> *) i)->p->set_profile(on != 0); }
-void mih_integrator_set_plan(void *i, int plan) { ((Box<PathIntegrator> *) i)->p->set_plan(plan); }
-void mih_integrator_cancel(void *i) { ((Box<PathIntegrator> *) i)->p->cancel(); }
+void mih_integrator_destroy(void *i) { delete (Box<SamplingIntegrator> *) i; }
+void mih_integrator_set_shard(void *i, uint32_t rank, uint32_t world) { ((Box<SamplingIntegrator> *) i)->p->set_shard(rank, world); }
+void mih_integrator_set_profile(void *i, int on) { ((Box<SamplingIntegrator> *) i)->p->set_profile(on != 0); }
+void mih_integrator_set_plan(void *i, int plan) { ((Box<SamplingIntegrator> *) i)->p->set_plan(plan); }
+void mih_integrator_cancel(void *i) { ((Box<SamplingIntegrator> *) i)->p->cancel(); }
 // 1 = finished, 0 = cancelled / timed out, -1 = error
 int mih_integrator_render(void *i, void *scene, void *sensor) {
-    MIH_TRY return ((Box<PathIntegrator> *) i)->p->render(((Box<Scene> *) scene)->p.get(), ((Box<PerspectiveCamera> *) sensor)->p.get()) ? 1 : 0; MIH_CATCH(-1)
+    MIH_TRY return ((Box<SamplingIntegrator> *) i)->p->render(((Box<Scene> *) scene)->p.get(), ((Box<PerspectiveCamera> *) sensor)->p.get()) ? 1 : 0; MIH_CATCH(-1)
 }
-int mih_integrator_counters(void *i, mi_counters *out) { *out = ((Box<PathIntegrator> *) i)->p->counters(); return 0; }
+int mih_integrator_counters(void *i, mi_counters *out) { *out = ((Box<SamplingIntegrator> *) i)->p->counters(); return 0; }
 // Host-side job description (no GPU needed). block_ids / tiles must hold `capacity` entries.
 int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads) {
     MIH_TRY
         std::vector<uint32_t> ids, tl;
-        ((Box<PathIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads);
+        ((Box<SamplingIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads);
         if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
         std::memcpy(block_ids, ids.data(), ids.size() * 4);
         std::memcpy(tiles, tl.data(), tl.size() * 4);
@@ -1887,7 +1911,7 @@ int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *blo
 int mih_make_render_cfg_pass(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads, uint32_t pass) {
     MIH_TRY
         std::vector<uint32_t> ids, tl;
-        ((Box<PathIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads, pass);
+        ((Box<SamplingIntegrator> *) i)->p->make_render_cfg(((Box<PerspectiveCamera> *) sensor)->p.get(), *cfg, ids, tl, n_threads, pass);
         if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
         std::memcpy(block_ids, ids.data(), ids.size() * 4);
         std::memcpy(tiles, tl.data(), tl.size() * 4);
@@ -1896,7 +1920,7 @@ int mih_make_render_cfg_pass(void *i, void *sensor, mi_render_cfg *cfg, uint32_t
 }
 int mih_integrator_pass_count(void *i, void *sensor) {
     MIH_TRY
-        return (int) ((Box<PathIntegrator> *) i)->p->pass_count(((Box<PerspectiveCamera> *) sensor)->p.get()); MIH_CATCH(-1)
+        return (int) ((Box<SamplingIntegrator> *) i)->p->pass_count(((Box<PerspectiveCamera> *) sensor)->p.get()); MIH_CATCH(-1)
 }
 // Spiral walk (test hook): writes offset.xy, size.xy, block_id per block; returns block count
 int mih_spiral(int w, int h, int off_x, int off_y, int block_size, int32_t *out5, int capacity) {

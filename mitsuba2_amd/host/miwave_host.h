@@ -360,14 +360,15 @@ private:
 };
 
 // ---- Integrator (include/mitsuba/render/integrator.h, src/librender/integrator.cpp) -------------
-class PathIntegrator {
+// SamplingIntegrator: the block / seed / film machinery every sampling integrator shares (integrator.cpp:23-179);
+// the plugin picks which `sample()` the device loop runs per camera sample (fill_integrator).
+class SamplingIntegrator {
 public:
-    explicit PathIntegrator(const Properties &props = Properties("path"));   // integrator.cpp:23-38,305-314
+    explicit SamplingIntegrator(const Properties &props);      // integrator.cpp:23-38
+    virtual ~SamplingIntegrator() = default;
     // SamplingIntegrator::render (integrator.cpp:51-179). Returns !m_stop.
     bool render(Scene *scene, PerspectiveCamera *sensor);
     void cancel();                                             // integrator.cpp:43-45
-    int max_depth() const { return m_max_depth; }
-    int rr_depth() const { return m_rr_depth; }
     uint32_t block_size() const { return m_block_size; }
     // pixel-tile shard for multi-GPU: this process renders blocks with
     // (spiral index % world_size) == rank; the film holds the partial sum.
@@ -385,9 +386,12 @@ public:
     void set_profile(bool p) { m_profile = p; }
     // execution plan of the device sample loop (mi_render_cfg::plan): 0 auto, 1 wavefront, 2 resident
     void set_plan(int plan) { m_plan = plan; }
-private:
+    bool hide_emitters() const { return m_hide_emitters; }
+protected:
+    // mi_render_cfg::integrator and the plugin's own parameters
+    virtual void fill_integrator(mi_render_cfg &cfg) const = 0;
     uint32_t m_block_size; uint32_t m_samples_per_pass; float m_timeout; bool m_hide_emitters;
-    int m_max_depth, m_rr_depth;
+private:
     uint32_t m_rank = 0, m_world = 1;
     bool m_profile = false;
     int m_plan = 0;
@@ -395,16 +399,43 @@ private:
     mi_counters m_counters{};
 };
 
+// src/integrators/path.cpp (MonteCarloIntegrator parameters, integrator.cpp:305-314)
+class PathIntegrator final : public SamplingIntegrator {
+public:
+    explicit PathIntegrator(const Properties &props = Properties("path"));
+    int max_depth() const { return m_max_depth; }
+    int rr_depth() const { return m_rr_depth; }
+protected:
+    void fill_integrator(mi_render_cfg &cfg) const override;
+private:
+    int m_max_depth, m_rr_depth;
+};
+
+// src/integrators/direct.cpp:78-104: shading_samples | emitter_samples + bsdf_samples, hide_emitters
+class DirectIntegrator final : public SamplingIntegrator {
+public:
+    explicit DirectIntegrator(const Properties &props = Properties("direct"));
+    size_t emitter_samples() const { return m_emitter_samples; }
+    size_t bsdf_samples() const { return m_bsdf_samples; }
+protected:
+    void fill_integrator(mi_render_cfg &cfg) const override;
+private:
+    size_t m_emitter_samples, m_bsdf_samples;
+};
+
+// PluginManager::create_object<Integrator>(props) for the integrators built here ("path", "direct")
+std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props);
+
 // ---- XML scene front-end, a subset (src/libcore/xml.cpp) --------------------------
 // <scene>, <default>, $parameters (also from `params`), <shape type="obj|ply|rectangle">, <bsdf> (inline, or
 // top-level with id + <ref id=.../>), <emitter type="area|envmap">, <sensor type="perspective"> with <film>,
-// <sampler>, <rfilter> children, <integrator type="path">; values <float> <integer> <boolean> <string> <rgb>
+// <sampler>, <rfilter> children, <integrator type="path|direct">; values <float> <integer> <boolean> <string> <rgb>
 // <spectrum value=...>; <transform name="to_world"> of <translate> <scale> <rotate> <lookat> <matrix>.
 // Anything else throws the reference's kind of error ("unexpected ..."/"Plugin ... not found").
 struct LoadedScene {
     std::shared_ptr<Scene> scene;
     std::shared_ptr<PerspectiveCamera> sensor;                 // nullptr if the file has none
-    std::shared_ptr<PathIntegrator> integrator;                // default-constructed `path` if the file has none
+    std::shared_ptr<SamplingIntegrator> integrator;            // default-constructed `path` if the file has none
     std::vector<std::shared_ptr<Mesh>> shapes;
 };
 LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, std::string> &params = {},

@@ -360,6 +360,89 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
     result_out = result; valid_ray_out = valid_ray;
 }
 
+// ---- DirectIntegrator::sample, src/integrators/direct.cpp:105-198 (scalar semantics) --------------------
+struct DirectConfig {
+    uint32_t emitter_samples, bsdf_samples; bool hide_emitters;
+    float frac_bsdf, frac_lum, weight_bsdf, weight_lum;
+    // direct.cpp:82-103
+    void set(uint32_t ne, uint32_t nb, bool hide) {
+        emitter_samples = ne; bsdf_samples = nb; hide_emitters = hide;
+        uint32_t sum = ne + nb;
+        weight_bsdf = 1.f / (float) nb; weight_lum = 1.f / (float) ne;
+        frac_bsdf = (float) nb / (float) sum; frac_lum = (float) ne / (float) sum;
+    }
+};
+
+void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths &wl, const DirectConfig &D,
+                   Spec &result_out, bool &valid_ray_out, PathStats &stats) {
+    const SceneView &view = sc.view;
+    const int32_t env_id = view.env ? (int32_t) view.env->emitter_index : -1;
+    SurfaceInteraction si;                               // :113
+    bool valid_ray = ray_intersect(sc, ray, si);         // :114
+    Spec result = spec(0.f);                             // :116
+
+    if (!D.hide_emitters) {                              // :119-123
+        int32_t emitter_vis = valid_ray ? sc.shapes[si.shape].emitter : env_id;
+        if (emitter_vis >= 0)
+            result = result + (valid_ray ? emitter_eval(sc.emitters[emitter_vis], si.wi, wl) : env_eval_spec(*view.env, ray.d));
+    }
+    if (!valid_ray) { result_out = result; valid_ray_out = false; return; }   // :125-127
+    stats.segments++;
+
+    const BsdfSide bsdf = bsdf_side(sc.bsdfs.data(), sc.shapes[si.shape].bsdf, si.wi);   // :132
+    const bool sample_emitter = (bsdf.flags & BSDF_Smooth) != 0;                        // :133
+
+    if (sample_emitter) {                                // :135-161
+        for (uint32_t i = 0; i < D.emitter_samples; ++i) {
+            DirectionSample ds;
+            Spec emitter_val = sample_emitter_direction(view, si.p, sampler.next_2d(), ds, wl);   // :141-142
+            if (ds.pdf != 0.f) {                         // test_visibility = true, scene.cpp:200-207
+                Ray shadow;
+                shadow.o = si.p; shadow.d = ds.d;
+                shadow.mint = MIW_RAY_EPSILON * (1.f + hmax(abs3(si.p)));
+                shadow.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON);
+                stats.shadow_rays++;
+                if (ray_test(sc, shadow)) emitter_val = spec(0.f);
+            }
+            if (ds.pdf == 0.f) continue;                 // :143-145
+            V3 wo = to_local(si.sh, ds.d);               // :148
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, wl);   // :150
+            float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo);       // :155
+            float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158
+            result = result + mis * bsdf_val * emitter_val;        // :159
+        }
+    }
+
+    for (uint32_t i = 0; i < D.bsdf_samples; ++i) {      // :165-196
+        float sample1 = sampler.next_1d();               // :166-167, Clang's argument order
+        V2 sample2 = sampler.next_2d();
+        BSDFSample bs;
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, wl);
+        if (all_zero(bsdf_val)) continue;                // :170: active_b
+        Ray next;                                        // :173-174, interaction.h:58-61
+        next.o = si.p; next.d = to_world(si.sh, bs.wo);
+        next.mint = (1.f + hmax(abs3(si.p))) * MIW_RAY_EPSILON;
+        next.maxt = std::numeric_limits<float>::infinity();
+        SurfaceInteraction si_bsdf;
+        bool hit = ray_intersect(sc, next, si_bsdf);
+        int32_t emitter = hit ? sc.shapes[si_bsdf.shape].emitter : env_id;   // :177
+        if (emitter < 0) continue;                       // :178
+        Spec emitter_val = hit ? emitter_eval(sc.emitters[emitter], si_bsdf.wi, wl) : env_eval_spec(*view.env, next.d);   // :181
+        // DirectionSample3f ds(si_bsdf, si), records.h:167-173
+        V3 d = next.d; float dist = 0.f; V3 n = v3(0.f);
+        if (hit) {
+            d = si_bsdf.p - si.p;
+            dist = norm(d);
+            d = d / dist;
+            n = si_bsdf.sh.n;
+        }
+        float emitter_pdf = (bs.sampled_type & BSDF_Delta) ? 0.f
+                          : pdf_emitter_direction(view, (uint32_t) emitter, d, dist, n, si.p);   // :189-190
+        result = result + bsdf_val * emitter_val * mis_weight(bs.pdf * D.frac_bsdf, emitter_pdf * D.frac_lum) * D.weight_bsdf;   // :192-195
+    }
+    result_out = result; valid_ray_out = true;
+}
+
 // ---- ImageBlock (src/librender/imageblock.cpp) ---------------------------------------------------
 struct ImageBlock {
     int off_x = 0, off_y = 0, w = 0, h = 0, border = 0;
@@ -543,6 +626,7 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
     std::atomic<uint64_t> total_samples{0}, total_segments{0}, total_shadow{0};
     if (n_threads < 1) n_threads = 1;
 
+    DirectConfig direct_cfg; direct_cfg.set(cfg->emitter_samples, cfg->bsdf_samples, cfg->hide_emitters != 0);
     auto worker = [&]() {
         FtzScope ftz;                                         // :117
         Sampler sampler; sampler.base_seed = cfg->base_seed;  // sampler->clone(), :113
@@ -575,7 +659,8 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
                     (void) wavelength_sample; ray_weight = spec(1.f);
 #endif
                     Spec L; bool valid;
-                    path_sample(sc, sampler, ray, wl, cfg->max_depth, cfg->rr_depth, L, valid, st);   // :264
+                    if (cfg->integrator == MI_INTEGRATOR_DIRECT) direct_sample(sc, sampler, ray, wl, direct_cfg, L, valid, st);
+                    else path_sample(sc, sampler, ray, wl, cfg->max_depth, cfg->rr_depth, L, valid, st);   // :264
 #if MIW_SPECTRAL
                     V3 xyz = spectrum_to_xyz(ray_weight * L, wl);                   // :266-271
 #else

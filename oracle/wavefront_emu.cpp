@@ -14,6 +14,7 @@
 
 #include "../include/miwave.h"
 #include "../mitsuba2_amd/csrc/miw/path.h"
+#include "../mitsuba2_amd/csrc/miw/direct.h"
 #include "../mitsuba2_amd/csrc/miw/film_gather.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
@@ -199,6 +200,15 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     std::memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
+    const bool direct = cfg->integrator == MI_INTEGRATOR_DIRECT;
+    if (direct) {                                              // fill_params (miwave.hip), direct.cpp:82-103
+        const uint32_t ne = cfg->emitter_samples, nb = cfg->bsdf_samples;
+        if (ne + nb == 0 || cfg->plan == 1) return -3;
+        P.integrator = INTEG_DIRECT;
+        P.direct.emitter_samples = ne; P.direct.bsdf_samples = nb; P.direct.hide_emitters = cfg->hide_emitters ? 1u : 0u;
+        P.direct.weight_bsdf = 1.f / (float) nb; P.direct.weight_lum = 1.f / (float) ne;
+        P.direct.frac_bsdf = (float) nb / (float) (ne + nb); P.direct.frac_lum = (float) ne / (float) (ne + nb);
+    }
 
     const uint32_t bs = (uint32_t) cfg->block_size, bs2 = bs * bs;
     const uint32_t blocks_x = (cfg->crop_w + bs - 1) / bs;
@@ -239,7 +249,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     auto add = [film64](int texel, int k, float v) { film64[(size_t) texel * 5 + k] += (double) v; };
     Counters cnt; std::memset(&cnt, 0, sizeof cnt);
     uint64_t iterations = 0;
-    if (cfg->plan == 2) {
+    if (cfg->plan == 2 || direct) {
         // the resident plan (k_init_pixels + k_path_resident): every pixel advanced
         // `samples_per_launch` samples per pass, state between passes = st word only
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {
@@ -267,7 +277,8 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                     splat(pixel, sample_idx, pos, aovs);
                     if (do_log) log(pixel, sample_idx, pos, aovs);
                 };
-                st[lane] = pixel_render(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt);
+                st[lane] = direct ? pixel_render<INTEG_DIRECT>(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt)
+                                  : pixel_render(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt);
             }
             done = end; ++iterations;
         }
