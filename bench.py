@@ -210,6 +210,8 @@ def main():
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if args.integrator == "direct":
+            out["config"]["workload"] = out["config"]["workload"].replace("path integrator max_depth=-1 rr_depth=5", "direct integrator shading_samples=1")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

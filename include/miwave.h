@@ -47,6 +47,7 @@ enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2,            /* roug
        MI_BSDF_FLAG_NONLINEAR = 1, MI_BSDF_FLAG_HAS_SPECULAR = 2,          /* plastic */
        MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE = 4, MI_BSDF_FLAG_HAS_SPEC_TRANSMITTANCE = 8,   /* roughdielectric (+ GGX, SAMPLE_VISIBLE) */
        MI_BSDF_FLAG_TWOSIDED = 0x100 };                                    /* any type: wrapped by <bsdf type="twosided"> */
+enum { MI_SHAPE_HAS_TEXCOORDS = 8 };   /* the shape's vertices carry texture coordinates (mi_scene_desc::vertex_texcoords) */
 enum { MI_SHAPE_HAS_NORMALS = 1,
        MI_SHAPE_RECTANGLE = 2,
        MI_SHAPE_SPHERE = 4 };      /* analytic sphere (src/shapes/sphere.cpp): like MI_SHAPE_RECTANGLE, geometry in `spheres` */   /* analytic rectangle (src/shapes/rectangle.cpp): face_count == 1 — the shape's single
@@ -57,9 +58,24 @@ enum { MI_SHAPE_HAS_NORMALS = 1,
  *   MI_TEX_UNIFORM   v[0] = value                              (src/spectra/uniform.cpp)
  *   MI_TEX_SRGB      v[0..2] = srgb_model_fetch coefficients   (src/spectra/srgb.cpp)
  *   MI_TEX_D65       v[0] = scale / 10568                      (src/spectra/d65.cpp)
- *   MI_TEX_SRGB_D65  v[0..2] = coefficients, v[3] = d65 scale / 10568 (src/spectra/srgb_d65.cpp) */
-enum { MI_TEX_RGB = 0, MI_TEX_UNIFORM = 1, MI_TEX_SRGB = 2, MI_TEX_D65 = 3, MI_TEX_SRGB_D65 = 4 };
+ *   MI_TEX_SRGB_D65  v[0..2] = coefficients, v[3] = d65 scale / 10568 (src/spectra/srgb_d65.cpp)
+ *   MI_TEX_BITMAP    v[0] = (float) index into mi_scene_desc::bitmaps   (src/textures/bitmap.cpp; either library) */
+enum { MI_TEX_RGB = 0, MI_TEX_UNIFORM = 1, MI_TEX_SRGB = 2, MI_TEX_D65 = 3, MI_TEX_SRGB_D65 = 4, MI_TEX_BITMAP = 5 };
 typedef struct { uint32_t type; float v[4]; } mi_texture;
+
+/* BitmapTexture (src/textures/bitmap.cpp:85-262) after its constructor ran on the host: the image converted to the
+ * working float representation, looked up at si.uv (mesh texture coordinates, or the analytic shapes' own uv).
+ *   channels 1: a scalar image (Y);  channels 3: linear RGB in the scalar_rgb library, the per-texel coefficients of
+ *   the sRGB upsampling model (srgb_model_fetch, bitmap.cpp:156-165) in the scalar_spectral library.
+ *   to_uv: the affine 2 x 3 part of the `to_uv` transform, column by column (m00 m10  m01 m11  m03 m13 of the 4 x 4). */
+enum { MI_BITMAP_NEAREST = 0, MI_BITMAP_BILINEAR = 1 };
+enum { MI_BITMAP_REPEAT = 0, MI_BITMAP_MIRROR = 1, MI_BITMAP_CLAMP = 2 };
+typedef struct {
+    const float *data;                 /* width * height * channels, row-major                   */
+    uint32_t width, height, channels;  /* >= 2 x 2 (bitmap.cpp:137-143 up-samples smaller images) */
+    uint32_t filter_type, wrap_mode;   /* MI_BITMAP_*                                             */
+    float to_uv[6];
+} mi_bitmap;
 
 typedef struct {
     uint32_t type;        /* MI_BSDF_*                                                   */
@@ -138,6 +154,12 @@ typedef struct {
     const mi_envmap  *envmap;          /* or NULL                                        */
     const mi_rectangle *rectangles; uint32_t rectangle_count;   /* one per MI_SHAPE_RECTANGLE shape, or NULL / 0 */
     const mi_sphere *spheres; uint32_t sphere_count;            /* one per MI_SHAPE_SPHERE shape, or NULL / 0    */
+    /* Mesh::vertex_texcoord (include/mitsuba/render/mesh.h:100-104): 2 * vertex_count, or NULL. Read for the shapes
+     * that carry MI_SHAPE_HAS_TEXCOORDS: si.uv is interpolated from them and dp_du / dp_dv — hence the shading
+     * frame's tangent — follow the uv parameterisation (src/librender/mesh.cpp:492-511). */
+    const float    *vertex_texcoords;
+    /* bitmap textures referenced by MI_TEX_BITMAP records of the bsdfs (emitter radiances stay constant) */
+    const mi_bitmap *bitmaps; uint32_t bitmap_count;
 } mi_scene_desc;
 
 /* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */

@@ -47,6 +47,11 @@ class mi_sphere(C.Structure):
                 ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
 
 
+class mi_bitmap(C.Structure):
+    _fields_ = [("data", c_float_p), ("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32),
+                ("filter_type", C.c_uint32), ("wrap_mode", C.c_uint32), ("to_uv", C.c_float * 6)]
+
+
 class mi_scene_desc(C.Structure):
     _fields_ = [("vertex_positions", c_float_p), ("vertex_normals", c_float_p), ("vertex_count", C.c_uint32),
                 ("faces", c_u32_p), ("face_count", C.c_uint32),
@@ -55,7 +60,8 @@ class mi_scene_desc(C.Structure):
                 ("emitters", C.POINTER(mi_emitter)), ("emitter_count", C.c_uint32),
                 ("envmap", C.POINTER(mi_envmap)),
                 ("rectangles", C.POINTER(mi_rectangle)), ("rectangle_count", C.c_uint32),
-                ("spheres", C.POINTER(mi_sphere)), ("sphere_count", C.c_uint32)]
+                ("spheres", C.POINTER(mi_sphere)), ("sphere_count", C.c_uint32),
+                ("vertex_texcoords", c_float_p), ("bitmaps", C.POINTER(mi_bitmap)), ("bitmap_count", C.c_uint32)]
 
 
 class mi_rays_soa(C.Structure):
@@ -161,7 +167,9 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_props_create": (vp, [cp]), "mih_props_destroy": (None, [vp]),
         "mih_props_set_float": (None, [vp, cp, f]), "mih_props_set_int": (None, [vp, cp, C.c_int64]),
         "mih_props_set_bool": (None, [vp, cp, i32]), "mih_props_set_string": (None, [vp, cp, cp]),
-        "mih_props_set_color": (None, [vp, cp, f, f, f]),
+        "mih_props_set_color": (None, [vp, cp, f, f, f]), "mih_props_set_texture": (None, [vp, cp, vp]),
+        "mih_bitmap_create": (vp, [vp, u32, u32, u32, c_float_p]), "mih_bitmap_destroy": (None, [vp]),
+        "mih_bitmap_info": (C.c_int, [vp, c_u32_p, c_float_p]),
         "mih_props_set_lookat": (None, [vp, cp, c_float_p, c_float_p, c_float_p]),
         "mih_props_set_matrix": (None, [vp, cp, c_float_p]), "mih_rectangle_create": (vp, [vp]), "mih_sphere_create": (vp, [vp]),
         "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]), "mih_bsdf_create_twosided": (vp, [vp, vp]),
@@ -170,7 +178,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_bsdf_sample": (i32, [vp, c_float_p, f, c_float_p, c_float_p]),
         "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),
         "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),
-        "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p]), "mih_mesh_destroy": (None, [vp]),
+        "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p, c_float_p]), "mih_mesh_copy_texcoords": (None, [vp, c_float_p]), "mih_mesh_destroy": (None, [vp]),
         "mih_mesh_load": (vp, [i32, vp]), "mih_mesh_recompute_normals": (i32, [vp]),
         "mih_mesh_counts": (None, [vp, c_u32_p, c_u32_p, c_i32_p]), "mih_mesh_copy": (None, [vp, c_float_p, c_u32_p, c_float_p]),
         "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),

@@ -76,6 +76,9 @@ class Properties:
             elif isinstance(v, np.ndarray) and v.shape == (4, 4):
                 m = np.ascontiguousarray(v, np.float32)
                 L.mih_props_set_matrix(self.h, n, _fp(m))
+            elif isinstance(v, BitmapTexture):
+                L.mih_props_set_texture(self.h, n, v.h)
+                self._keep = getattr(self, "_keep", []) + [v]
             elif isinstance(v, dict):
                 o = np.asarray(v["origin"], np.float32); t = np.asarray(v["target"], np.float32)
                 u = np.asarray(v.get("up", (0, 1, 0)), np.float32)
@@ -88,6 +91,38 @@ class Properties:
         if getattr(self, "h", None):
             host_lib().mih_props_destroy(self.h)
             self.h = None
+
+
+class BitmapTexture:
+    """<texture type="bitmap"> (src/textures/bitmap.cpp): BitmapTexture(pixels, filter_type="bilinear" | "nearest",
+    wrap_mode="repeat" | "mirror" | "clamp", raw=False, to_uv=4x4) with `pixels` a (h, w) or (h, w, 3) array of linear
+    floats, or BitmapTexture(filename="x.pfm", ...). Pass it where a BSDF takes a colour: BSDF("diffuse", reflectance=tex).
+    Needs texture coordinates on the mesh (Mesh(..., texcoords=)), or an analytic shape's own uv."""
+
+    def __init__(self, pixels=None, **kw):
+        self._p = Properties("bitmap", **kw)
+        w = h = c = 0; data = None
+        if pixels is not None:
+            a = np.ascontiguousarray(pixels, np.float32)
+            if a.ndim == 2:
+                a = a[..., None]
+            if a.ndim != 3 or a.shape[2] not in (1, 3):
+                raise ValueError("BitmapTexture: expected an (h, w) or (h, w, 3) array")
+            h, w, c = a.shape; data = _fp(a); self._pixels = a
+        self.h = host_lib().mih_bitmap_create(self._p.h, w, h, c, data)
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def info(self):
+        """-> (width, height, channels), per-channel mean"""
+        whc = np.zeros(3, np.uint32); mean = np.zeros(3, np.float32)
+        if host_lib().mih_bitmap_info(self.h, whc.ctypes.data_as(c_u32_p), _fp(mean)) != 0:
+            raise RuntimeError(_err())
+        return tuple(int(x) for x in whc), mean
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().mih_bitmap_destroy(self.h); self.h = None
 
 
 class BSDF:
@@ -160,14 +195,16 @@ class AreaLight:
 
 
 class Mesh:
-    def __init__(self, name, vertices, faces, normals=None, bsdf=None, emitter=None):
+    def __init__(self, name, vertices, faces, normals=None, bsdf=None, emitter=None, texcoords=None):
         self.name = name
         self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         self.faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
         self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
         self.h = host_lib().mih_mesh_create(name.encode(), _fp(self.vertices), len(self.vertices),
                                             self.faces.ctypes.data_as(c_u32_p), len(self.faces),
-                                            None if self.normals is None else _fp(self.normals))
+                                            None if self.normals is None else _fp(self.normals),
+                                            None if self.texcoords is None else _fp(self.texcoords))
         if not self.h:
             raise RuntimeError(_err())
         self.bsdf, self.emitter = bsdf, emitter
@@ -241,9 +278,12 @@ class Mesh:
         nv, nf, hn = C.c_uint32(), C.c_uint32(), C.c_int32()
         host_lib().mih_mesh_counts(self.h, C.byref(nv), C.byref(nf), C.byref(hn))
         self.vertices = np.zeros((nv.value, 3), np.float32); self.faces = np.zeros((nf.value, 3), np.uint32)
-        self.normals = np.zeros((nv.value, 3), np.float32) if hn.value else None
+        self.normals = np.zeros((nv.value, 3), np.float32) if hn.value & 1 else None
+        self.texcoords = np.zeros((nv.value, 2), np.float32) if hn.value & 2 else None
         host_lib().mih_mesh_copy(self.h, _fp(self.vertices), self.faces.ctypes.data_as(c_u32_p),
                                  None if self.normals is None else _fp(self.normals))
+        if self.texcoords is not None:
+            host_lib().mih_mesh_copy_texcoords(self.h, _fp(self.texcoords))
 
     def recompute_vertex_normals(self):
         """Mesh::recompute_vertex_normals (src/librender/mesh.cpp:200-246)"""

@@ -246,7 +246,7 @@ MIW_HD void mf_sample(const Microfacet &d, V3 wi, V2 sample, V3 &m_out, float &p
 }
 
 // ---- SmoothDiffuse (diffuse.cpp) ------------------------------------------------
-MIW_HD Spec diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     float cos_theta_i = wi.z;
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :88-91
@@ -254,12 +254,12 @@ MIW_HD Spec diffuse_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, 
     bs.pdf = square_to_cosine_hemisphere_pdf(bs.wo);
     bs.eta = 1.f;
     bs.sampled_type = BSDF_DiffuseReflection;
-    return (bs.pdf > 0.f) ? tex_eval(b.tex[0], wl) : spec(0.f);      // :101
+    return (bs.pdf > 0.f) ? tex_eval(b.tex[0], tc) : spec(0.f);      // :101
 }
-MIW_HD Spec diffuse_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec diffuse_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
     if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
-    return tex_eval(b.tex[0], wl) * MIW_INV_PI * cos_theta_o;        // :116-117
+    return tex_eval(b.tex[0], tc) * MIW_INV_PI * cos_theta_o;        // :116-117
 }
 MIW_HD float diffuse_pdf(V3 wi, V3 wo) {
     float pdf = square_to_cosine_hemisphere_pdf(wo);
@@ -267,7 +267,7 @@ MIW_HD float diffuse_pdf(V3 wi, V3 wo) {
 }
 
 // ---- SmoothDielectric (dielectric.cpp:201-310, unpolarized branch :289-307) -------
-MIW_HD Spec dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample &bs, const TexCtx &tc) {
     float cos_theta_i = wi.z;
     float r_i, cos_theta_t, eta_it, eta_ti;
     fresnel(cos_theta_i, b.p[0], r_i, cos_theta_t, eta_it, eta_ti);
@@ -278,9 +278,9 @@ MIW_HD Spec dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample
     bs.wo = selected_r ? reflect(wi) : refract(wi, cos_theta_t, eta_ti);
     bs.eta = selected_r ? 1.f : eta_it;
     Spec weight = spec(1.f);                                         // :290
-    if (selected_r) weight = weight * tex_eval(b.tex[0], wl);        // :296-297
+    if (selected_r) weight = weight * tex_eval(b.tex[0], tc);        // :296-297
     else {
-        weight = weight * tex_eval(b.tex[1], wl);                    // :299-300
+        weight = weight * tex_eval(b.tex[1], tc);                    // :299-300
         weight = weight * sqr(eta_ti);                               // :302-307 (Radiance mode)
     }
     return weight;
@@ -290,8 +290,8 @@ MIW_HD Spec dielectric_sample(const BsdfRec &b, V3 wi, float sample1, BSDFSample
 MIW_HD Microfacet rc_distr(const BsdfRec &b) {
     return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[1], (b.flags & 2u) != 0);
 }
-MIW_HD Spec rc_fresnel(const BsdfRec &b, float c, const Wavelengths &wl) {
-    Spec eta = tex_eval(b.tex[0], wl), k = tex_eval(b.tex[1], wl), r;
+MIW_HD Spec rc_fresnel(const BsdfRec &b, float c, const TexCtx &tc) {
+    Spec eta = tex_eval(b.tex[0], tc), k = tex_eval(b.tex[1], tc), r;
 #if MIW_SPECTRAL
     for (int i = 0; i < 4; ++i) r.c[i] = fresnel_conductor(c, eta.c[i], k.c[i]);
 #else
@@ -300,7 +300,7 @@ MIW_HD Spec rc_fresnel(const BsdfRec &b, float c, const Wavelengths &wl) {
     return r;
 }
 // :196-275
-MIW_HD Spec roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     float cos_theta_i = wi.z;
     if (!(cos_theta_i > 0.f)) return spec(0.f);
@@ -315,12 +315,12 @@ MIW_HD Spec roughconductor_sample(const BsdfRec &b, V3 wi, V2 sample2, BSDFSampl
     if (distr.sample_visible) weight = mf_smith_g1(distr, bs.wo, m);
     else weight = mf_G(distr, wi, bs.wo, m) * dot(wi, m) / (cos_theta_i * m.z);
     bs.pdf /= 4.f * dot(bs.wo, m);
-    Spec F = rc_fresnel(b, dot(wi, m), wl);
-    Spec w = spec(weight) * tex_eval(b.tex[2], wl);
+    Spec F = rc_fresnel(b, dot(wi, m), tc);
+    Spec w = spec(weight) * tex_eval(b.tex[2], tc);
     return active ? F * w : spec(0.f);
 }
 // :277-345
-MIW_HD Spec roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
     if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
     V3 H = normalize(wo + wi);
@@ -329,8 +329,8 @@ MIW_HD Spec roughconductor_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelength
     bool active = D != 0.f;
     float G = mf_G(distr, wi, wo, H);
     float res = D * G / (4.f * wi.z);
-    Spec F = rc_fresnel(b, dot(wi, H), wl);
-    Spec result = spec(res) * tex_eval(b.tex[2], wl);
+    Spec F = rc_fresnel(b, dot(wi, H), tc);
+    Spec result = spec(res) * tex_eval(b.tex[2], tc);
     return active ? F * result : spec(0.f);
 }
 // :347-382
@@ -349,7 +349,7 @@ MIW_HD float roughconductor_pdf(const BsdfRec &b, V3 wi, V3 wo) {
 }
 
 // ---- SmoothConductor (conductor.cpp:217-261, unpolarized branch :253-255) ---------------
-MIW_HD Spec conductor_sample(const BsdfRec &b, V3 wi, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec conductor_sample(const BsdfRec &b, V3 wi, BSDFSample &bs, const TexCtx &tc) {
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     float cos_theta_i = wi.z;
     if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :223-229
@@ -357,7 +357,7 @@ MIW_HD Spec conductor_sample(const BsdfRec &b, V3 wi, BSDFSample &bs, const Wave
     bs.wo = reflect(wi);
     bs.eta = 1.f;
     bs.pdf = 1.f;
-    return tex_eval(b.tex[2], wl) * rc_fresnel(b, cos_theta_i, wl);   // :254
+    return tex_eval(b.tex[2], tc) * rc_fresnel(b, cos_theta_i, tc);   // :254
 }
 
 // ---- SmoothPlastic (plastic.cpp) ---------------------------------------------------------
@@ -367,8 +367,8 @@ MIW_HD float plastic_fresnel(float cos_theta, float eta) {
     return r;
 }
 // diff = diffuse_reflectance / (1 - (nonlinear ? diff * fdr_int : fdr_int)), :237-238, :264-265
-MIW_HD Spec plastic_diffuse(const BsdfRec &b, const Wavelengths &wl) {
-    Spec value = tex_eval(b.tex[0], wl);
+MIW_HD Spec plastic_diffuse(const BsdfRec &b, const TexCtx &tc) {
+    Spec value = tex_eval(b.tex[0], tc);
     const float fdr_int = b.p[2];
     if (b.flags & 1u) {
 #if MIW_SPECTRAL
@@ -387,7 +387,7 @@ MIW_HD Spec plastic_diffuse(const BsdfRec &b, const Wavelengths &wl) {
     return value;
 }
 // :176-244 (all components enabled: the path integrator's BSDFContext)
-MIW_HD Spec plastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec plastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     float cos_theta_i = wi.z;
     if (!(cos_theta_i > 0.f)) return spec(0.f);                      // :187-193
@@ -403,23 +403,23 @@ MIW_HD Spec plastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, B
         bs.pdf = prob_specular;
         bs.sampled_type = BSDF_DeltaReflection;
         Spec value = spec(f_i / bs.pdf);
-        if (b.flags & 2u) value = value * tex_eval(b.tex[1], wl);
+        if (b.flags & 2u) value = value * tex_eval(b.tex[1], tc);
         return value;
     }
     bs.wo = square_to_cosine_hemisphere(sample2);                    // :226-241
     bs.pdf = prob_diffuse * square_to_cosine_hemisphere_pdf(bs.wo);
     bs.sampled_type = BSDF_DiffuseReflection;
     float f_o = plastic_fresnel(bs.wo.z, eta);
-    Spec value = plastic_diffuse(b, wl);
+    Spec value = plastic_diffuse(b, tc);
     return value * (inv_eta_2 * (1.f - f_i) * (1.f - f_o) / prob_diffuse);
 }
 // :246-270
-MIW_HD Spec plastic_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec plastic_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
     if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
     const float eta = b.p[0], inv_eta_2 = b.p[1];
     float f_i = plastic_fresnel(cos_theta_i, eta), f_o = plastic_fresnel(cos_theta_o, eta);
-    Spec diff = plastic_diffuse(b, wl);
+    Spec diff = plastic_diffuse(b, tc);
     return diff * (square_to_cosine_hemisphere_pdf(wo) * inv_eta_2 * (1.f - f_i) * (1.f - f_o));
 }
 // :272-298
@@ -443,7 +443,7 @@ MIW_HD Microfacet rd_distr(const BsdfRec &b) {
     return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[1], (b.flags & 2u) != 0);
 }
 // :204-316
-MIW_HD Spec roughdielectric_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec roughdielectric_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
     const float eta = b.p[2];
     float cos_theta_i = wi.z;
@@ -467,13 +467,13 @@ MIW_HD Spec roughdielectric_sample(const BsdfRec &b, V3 wi, float sample1, V2 sa
     float dwh_dwo = 0.f;
     if (selected_r) {                                                // :270-279
         bs.wo = reflect(wi, m);
-        if (b.flags & 4u) weight = weight * tex_eval(b.tex[0], wl);
+        if (b.flags & 4u) weight = weight * tex_eval(b.tex[0], tc);
         dwh_dwo = rcp(4.f * dot(bs.wo, m));
     }
     if (selected_t) {                                                // :282-300
         bs.wo = refract(wi, m, cos_theta_t, eta_ti);
         Spec factor = spec(sqr(eta_ti));
-        if (b.flags & 8u) factor = factor * tex_eval(b.tex[1], wl);
+        if (b.flags & 8u) factor = factor * tex_eval(b.tex[1], tc);
         weight = weight * factor;
         dwh_dwo = (sqr(bs.eta) * dot(bs.wo, m)) / sqr(dot(wi, m) + bs.eta * dot(bs.wo, m));
     }
@@ -483,7 +483,7 @@ MIW_HD Spec roughdielectric_sample(const BsdfRec &b, V3 wi, float sample1, V2 sa
     return active ? weight : spec(0.f);
 }
 // :318-386
-MIW_HD Spec roughdielectric_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec roughdielectric_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
     const float m_eta = b.p[2], m_inv_eta = b.p[3];
     float cos_theta_i = wi.z, cos_theta_o = wo.z;
     bool active = cos_theta_i != 0.f;
@@ -499,13 +499,13 @@ MIW_HD Spec roughdielectric_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengt
     if (!active) return spec(0.f);
     if (reflect_) {                                                  // :363-370
         Spec value = spec(F * D * G / (4.f * abs_(cos_theta_i)));
-        if (b.flags & 4u) value = value * tex_eval(b.tex[0], wl);
+        if (b.flags & 4u) value = value * tex_eval(b.tex[0], tc);
         return value;
     }
     float scale = sqr(inv_eta);                                      // :376
     Spec value = spec(abs_((scale * (1.f - F) * D * G * eta * eta * dot(wi, m) * dot(wo, m)) /
                            (cos_theta_i * sqr(dot(wi, m) + eta * dot(wo, m)))));             // :379-381
-    if (b.flags & 8u) value = value * tex_eval(b.tex[1], wl);
+    if (b.flags & 8u) value = value * tex_eval(b.tex[1], tc);
     return value;
 }
 // :388-441
@@ -534,24 +534,24 @@ MIW_HD float roughdielectric_pdf(const BsdfRec &b, V3 wi, V3 wo) {
 
 // ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
-MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     switch (b.type) {
-        case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, wl);
-        case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, wl);
-        case BSDF_TYPE_CONDUCTOR:  return conductor_sample(b, wi, bs, wl);
-        case BSDF_TYPE_PLASTIC:    return plastic_sample(b, wi, sample1, sample2, bs, wl);
-        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_sample(b, wi, sample1, sample2, bs, wl);
-        default:                   return roughconductor_sample(b, wi, sample2, bs, wl);
+        case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, tc);
+        case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, tc);
+        case BSDF_TYPE_CONDUCTOR:  return conductor_sample(b, wi, bs, tc);
+        case BSDF_TYPE_PLASTIC:    return plastic_sample(b, wi, sample1, sample2, bs, tc);
+        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_sample(b, wi, sample1, sample2, bs, tc);
+        default:                   return roughconductor_sample(b, wi, sample2, bs, tc);
     }
 }
-MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
     switch (b.type) {
-        case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, wl);
+        case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, tc);
         case BSDF_TYPE_DIELECTRIC: return spec(0.f);                 // dielectric.cpp:312-315
         case BSDF_TYPE_CONDUCTOR:  return spec(0.f);                 // conductor.cpp:263-266
-        case BSDF_TYPE_PLASTIC:    return plastic_eval(b, wi, wo, wl);
-        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_eval(b, wi, wo, wl);
-        default:                   return roughconductor_eval(b, wi, wo, wl);
+        case BSDF_TYPE_PLASTIC:    return plastic_eval(b, wi, wo, tc);
+        case BSDF_TYPE_ROUGHDIELECTRIC: return roughdielectric_eval(b, wi, wo, tc);
+        default:                   return roughconductor_eval(b, wi, wo, tc);
     }
 }
 MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {
@@ -581,15 +581,15 @@ MIW_HD BsdfSide bsdf_side(const BsdfRec *table, uint32_t index, V3 wi) {
     return s;
 }
 MIW_HD V3 bsdf_mirror(V3 w) { return v3(w.x, w.y, w.z * -1.f); }      // `wi.z() *= -1.f`
-MIW_HD Spec bsdf_side_sample(const BsdfSide &s, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const Wavelengths &wl) {
+MIW_HD Spec bsdf_side_sample(const BsdfSide &s, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     if (s.none) { bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0; return spec(0.f); }
-    Spec v = bsdf_sample(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, wl);
+    Spec v = bsdf_sample(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, tc);
     if (s.flip) bs.wo.z *= -1.f;                                     // :121
     return v;
 }
-MIW_HD Spec bsdf_side_eval(const BsdfSide &s, V3 wi, V3 wo, const Wavelengths &wl) {
+MIW_HD Spec bsdf_side_eval(const BsdfSide &s, V3 wi, V3 wo, const TexCtx &tc) {
     if (s.none) return spec(0.f);
-    return s.flip ? bsdf_eval(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), wl) : bsdf_eval(*s.b, wi, wo, wl);
+    return s.flip ? bsdf_eval(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_eval(*s.b, wi, wo, tc);
 }
 MIW_HD float bsdf_side_pdf(const BsdfSide &s, V3 wi, V3 wo) {
     if (s.none) return 0.f;

@@ -34,7 +34,8 @@ MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs 
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, ray_o, ray_d, si);
         } else {
             const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+            const float *tc = (shape.flags & SHAPE_HAS_TEXCOORDS) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
+            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, si);
         }
         si.shape = tr.shape; si.prim = tr.prim;
         emitter = shape.emitter; bsdf_index = shape.bsdf;
@@ -59,7 +60,7 @@ MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, La
     Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);   // :141-142
     if (ds.pdf == 0.f) return false;                              // :143-145
     V3 wo = to_local(si.sh, ds.d);                                // :148
-    Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, L.wl);        // :150
+    Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(L.wl, si.uv, sc.bitmaps));   // :150
     float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo);              // :155
     float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158 (no delta emitters)
     Spec c = mis * bsdf_val * emitter_val;                        // :159
@@ -70,11 +71,11 @@ MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, La
 }
 
 // One BSDF sample, direct.cpp:166-176. Returns true when its ray is queued in L.ray.
-MIW_HD bool direct_bsdf_sample(LaneRegs &L, const SurfaceInteraction &si, const BsdfSide &bsdf, DirectPending &pend) {
+MIW_HD bool direct_bsdf_sample(const SceneView &sc, LaneRegs &L, const SurfaceInteraction &si, const BsdfSide &bsdf, DirectPending &pend) {
     float s1 = next_1d(L.rng);                                    // :166-167 (Clang order: next_1d, then next_2d)
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    pend.bsdf_val = bsdf_side_sample(bsdf, si.wi, s1, s2, bs, L.wl);
+    pend.bsdf_val = bsdf_side_sample(bsdf, si.wi, s1, s2, bs, TexCtx(L.wl, si.uv, sc.bitmaps));
     if (all_zero(pend.bsdf_val)) return false;                    // :170
     pend.pdf = bs.pdf; pend.delta = (bs.sampled_type & BSDF_Delta) != 0;
     L.ray.d = to_world(si.sh, bs.wo);                             // :173-174, interaction.h:58-61
@@ -103,7 +104,8 @@ MIW_HD void direct_bsdf_hit(const RenderParams &P, const SceneView &sc, LaneRegs
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, ref_p, ray_d, sb);
         } else {
             const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, sb);
+            const float *tc = (shape.flags & SHAPE_HAS_TEXCOORDS) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
+            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, sb);
         }
     }
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;
@@ -175,7 +177,7 @@ MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &s
             bool queued = false;
             while (ie < n_emitter && !queued) { ++ie; queued = direct_emitter_sample(P, sc, L, si, bsdf, sh, cnt_local); }
             if (ie == n_emitter)                                   // the last shadow ray travels with the first BSDF-sampled ray
-                while (ib < n_bsdf && !(L.ray.maxt >= 0.f)) { ++ib; if (direct_bsdf_sample(L, si, bsdf, pend)) queued = true; }
+                while (ib < n_bsdf && !(L.ray.maxt >= 0.f)) { ++ib; if (direct_bsdf_sample(sc, L, si, bsdf, pend)) queued = true; }
             more = queued;
         }
         if (more) continue;

@@ -256,7 +256,9 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, prev_o(), ray_d, si);
         } else {
             const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.x, h.y, h.z, ray_d, si);
+            // a MATS_DIFFUSE kernel is only launched for scenes without texture coordinates (miwave.hip: diffuse_only)
+            const float *tc = (Mats != MATS_DIFFUSE && (shape.flags & SHAPE_HAS_TEXCOORDS)) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
+            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, si);
         }
         si.shape = tr.shape; si.prim = tr.prim;
         emitter = shape.emitter; bsdf_index = shape.bsdf;
@@ -307,13 +309,16 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
     L.ray.d = v3(0.f); L.ray.maxt = -1.f;
 
+    // what the plugin's texture lookups see of `si`; a MATS_DIFFUSE kernel is only launched for constant textures
+    const TexCtx tc(L.wl, si.uv, Mats == MATS_DIFFUSE ? nullptr : sc.bitmaps);
+
     // ---- emitter sampling, :155-172 ----
     if (bflags & BSDF_Smooth) {
         DirectionSample ds;
         Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
-            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, L.wl) : bsdf_side_eval(bsdf, si.wi, wo, L.wl);
+            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, tc) : bsdf_side_eval(bsdf, si.wi, wo, tc);
             float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf(bsdf, si.wi, wo);
             float mis = mis_weight(ds.pdf, bpdf);
             Spec c = mis * L.tp * bsdf_val * emitter_val;
@@ -329,7 +334,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, L.wl) : bsdf_side_sample(bsdf, si.wi, s1, s2, bs, L.wl);
+    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, tc) : bsdf_side_sample(bsdf, si.wi, s1, s2, bs, tc);
     L.tp = L.tp * bsdf_val;
     if (all_zero(L.tp))                              // :182-184
         return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;

@@ -28,7 +28,7 @@ struct BvhNode {
 struct ShapeRec {
     uint32_t bsdf;       // index into bsdfs
     int32_t  emitter;    // index into emitters or -1
-    uint32_t flags;      // bit0: has vertex normals
+    uint32_t flags;      // bit0: has vertex normals; bit3 (SHAPE_HAS_TEXCOORDS): has vertex texture coordinates
     uint32_t pad;
 };
 
@@ -44,11 +44,13 @@ struct EmitterRec {
     uint32_t type;       // 0: area light on `shape`; 1: the environment map (SceneView::env)
 };
 enum : uint32_t { EMITTER_AREA = 0, EMITTER_ENVMAP = 1 };
+enum : uint32_t { SHAPE_HAS_NORMALS = 1u, SHAPE_HAS_TEXCOORDS = 8u };     // ShapeRec::flags (= MI_SHAPE_* of include/miwave.h)
 
 struct SceneView {
     const BvhNode *nodes;   uint32_t node_count;
     const Tri     *tris;    uint32_t tri_count;     // BVH leaf order
     const float   *tri_vn;                          // 9 floats per tri (leaf order) or nullptr
+    const float   *tri_uv;                          // 6 floats per face (u0 v0 u1 v1 u2 v2), indexed by Tri::prim, or nullptr
     const ShapeRec *shapes; uint32_t shape_count;
     const BsdfRec  *bsdfs;  uint32_t bsdf_count;
     const EmitterRec *emitters; uint32_t emitter_count;
@@ -57,6 +59,7 @@ struct SceneView {
     const float *emit_pmf, *emit_cdf;
     const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
     const AnalyticRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
+    const BitmapRec *bitmaps;                       // bitmap textures (TexRec TEX_BITMAP indexes this table) or nullptr
     float accept_pad;                               // shape.h: the bounds rule of every triangle hit
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)

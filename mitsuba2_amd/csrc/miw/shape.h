@@ -172,9 +172,11 @@ struct SurfaceInteraction {
     uint32_t shape, prim;
 };
 
-// mesh.cpp:449-545 + interaction.h:571-596, for meshes without texcoords.
-// `vn` = per-vertex normals of this face or nullptr (mesh.cpp:514-519).
-MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
+// mesh.cpp:449-545 + interaction.h:571-596.
+// `vn` = per-vertex normals of this face or nullptr (mesh.cpp:514-519);
+// `tc` = per-vertex texture coordinates of this face (u0 v0 u1 v1 u2 v2) or nullptr (:492-511): they replace the
+// barycentric uv and, where the uv parameterisation is not degenerate, the tangents the shading frame is built on.
+MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn, const float *tc,
                                         float t, float b1, float b2, V3 ray_d,
                                         SurfaceInteraction &si) {
     float b0 = 1.f - b1 - b2;
@@ -185,6 +187,16 @@ MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
     si.uv = v2(b1, b2);                                // :490
     V3 dp_du, dp_dv;
     coordinate_system(si.n, dp_du, dp_dv);             // :491
+    if (tc) {                                          // :492-511
+        const V2 uv0 = v2(tc[0], tc[1]), uv1 = v2(tc[2], tc[3]), uv2 = v2(tc[4], tc[5]);
+        si.uv = v2(uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2);   // :497
+        const V2 duv0 = v2(uv1.x - uv0.x, uv1.y - uv0.y), duv1 = v2(uv2.x - uv0.x, uv2.y - uv0.y);
+        const float det = fmsub(duv0.x, duv1.y, duv0.y * duv1.x), inv_det = rcp(det);             // :503-504
+        if (det != 0.f) {                                                                          // :506-509
+            dp_du = fmsub3(dp0, duv1.y, dp1 * duv0.y) * inv_det;
+            dp_dv = fnmadd3(dp0, duv1.x, dp1 * duv0.x) * inv_det;
+        }
+    }
     if (vn) {                                          // :514-519
         V3 n0 = ld3(vn), n1 = ld3(vn + 3), n2 = ld3(vn + 6);
         si.sh.n = normalize(n0 * b0 + n1 * b1 + n2 * b2);
@@ -195,6 +207,10 @@ MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn,
     si.sh.s = normalize(fnmadd3(si.sh.n, dot(si.sh.n, dp_du), dp_du));
     si.sh.t = cross(si.sh.n, si.sh.s);
     si.wi = to_local(si.sh, -ray_d);                   // interaction.h:591
+}
+MIW_HD void compute_surface_interaction(V3 p0, V3 p1, V3 p2, const float *vn, float t, float b1, float b2, V3 ray_d,
+                                        SurfaceInteraction &si) {
+    compute_surface_interaction(p0, p1, p2, vn, nullptr, t, b1, b2, ray_d, si);
 }
 
 // Rectangle::compute_surface_interaction, rectangle.cpp:175-208 + interaction.h:571-596

@@ -20,8 +20,29 @@ namespace miw {
 //   TEX_SRGB      c0, c1, c2                   (src/spectra/srgb.cpp: srgb_model_fetch coefficients)
 //   TEX_D65       scale / 10568                (src/spectra/d65.cpp -> regular spectrum)
 //   TEX_SRGB_D65  c0, c1, c2, d65 scale / 10568 (src/spectra/srgb_d65.cpp)
-enum : uint32_t { TEX_RGB = 0, TEX_UNIFORM = 1, TEX_SRGB = 2, TEX_D65 = 3, TEX_SRGB_D65 = 4 };
+//   TEX_BITMAP    (float) index into the scene's bitmap table (src/textures/bitmap.cpp), looked up at si.uv
+enum : uint32_t { TEX_RGB = 0, TEX_UNIFORM = 1, TEX_SRGB = 2, TEX_D65 = 3, TEX_SRGB_D65 = 4, TEX_BITMAP = 5 };
 struct TexRec { uint32_t type; float v[4]; };
+
+// BitmapTextureImpl (bitmap.cpp:244-262): `data` = width * height * channels floats, row-major; channels 1 = a
+// scalar (raw or luminance-free greyscale image), 3 = linear RGB (scalar_rgb) or the sRGB-model coefficients the
+// host fetched per texel (scalar_spectral, bitmap.cpp:156-165); to_uv = the 2 x 3 affine part of the `to_uv`
+// transform (its three columns, transform.h:324-348).
+enum : uint32_t { BITMAP_NEAREST = 0, BITMAP_BILINEAR = 1 };
+enum : uint32_t { BITMAP_REPEAT = 0, BITMAP_MIRROR = 1, BITMAP_CLAMP = 2 };
+struct BitmapRec {
+    const float *data;
+    uint32_t width, height, channels, filter, wrap, pad;
+    float to_uv[6];
+};
+
+// What a texture lookup needs of the surface interaction: wavelengths, uv (and the scene's bitmap table).
+// A null table (or a constant record) evaluates exactly as before bitmaps existed.
+struct TexCtx {
+    Wavelengths wl; V2 uv; const BitmapRec *bitmaps;
+    MIW_HD TexCtx(const Wavelengths &w) : wl(w), uv(v2(0.f, 0.f)), bitmaps(nullptr) { }
+    MIW_HD TexCtx(const Wavelengths &w, V2 uv_, const BitmapRec *b) : wl(w), uv(uv_), bitmaps(b) { }
+};
 
 #if MIW_SPECTRAL
 
@@ -147,5 +168,69 @@ MIW_HD Spec tex_eval(const TexRec &t, const Wavelengths &wl) {
 MIW_HD Spec tex_eval(const TexRec &t, const Wavelengths &) { return v3(t.v[0], t.v[1], t.v[2]); }
 
 #endif
+
+// ---- bitmap texture, src/textures/bitmap.cpp:385-460 ---------------------------------------------------------
+MIW_HD int bitmap_floor2int(float x) {
+    if (!(x == x)) return 0;
+    int i = (int) x;
+    return ((float) i > x) ? i - 1 : i;
+}
+// :385-399 (enoki::divisor rounds toward zero like operator/)
+MIW_HD int bitmap_wrap(int value, int res, uint32_t mode) {
+    if (mode == BITMAP_CLAMP) return value < 0 ? 0 : (value > res - 1 ? res - 1 : value);
+    const int div = value / res;
+    int mod = value - div * res;
+    if (mod < 0) mod += res;
+    if (mode == BITMAP_MIRROR && !(((div & 1) == 0) != (value < 0))) mod = res - 1 - mod;
+    return mod;
+}
+// one texel as a Spec: a scalar broadcasts, an RGB triple is the colour (or, in spectral builds, the
+// coefficient triple of the sRGB model evaluated at the sample's wavelengths, :439-444)
+MIW_HD Spec bitmap_texel(const BitmapRec &b, int x, int y, const Wavelengths &wl) {
+    const float *p = b.data + ((size_t) y * b.width + (size_t) x) * b.channels;
+    if (b.channels == 1) return spec(p[0]);
+#if MIW_SPECTRAL
+    Spec r;
+    for (int i = 0; i < 4; ++i) r.c[i] = srgb_model_eval(p, wl.l[i]);
+    return r;
+#else
+    (void) wl;
+    return v3(p[0], p[1], p[2]);
+#endif
+}
+MIW_HD Spec spec_fmadd(float a, Spec x, Spec y) {            // fmadd(a, x, y) per channel
+#if MIW_SPECTRAL
+    Spec r; for (int i = 0; i < 4; ++i) r.c[i] = fmadd(a, x.c[i], y.c[i]); return r;
+#else
+    return v3(fmadd(a, x.x, y.x), fmadd(a, x.y, y.y), fmadd(a, x.z, y.z));
+#endif
+}
+// BitmapTextureImpl::interpolate, :401-460
+MIW_HD Spec bitmap_eval(const BitmapRec &b, V2 uv_in, const Wavelengths &wl) {
+    // m_transform.transform_affine(si.uv), transform.h:90-98
+    float u = b.to_uv[4], v = b.to_uv[5];
+    u = fmadd(b.to_uv[0], uv_in.x, u); v = fmadd(b.to_uv[1], uv_in.x, v);
+    u = fmadd(b.to_uv[2], uv_in.y, u); v = fmadd(b.to_uv[3], uv_in.y, v);
+    const int w = (int) b.width, h = (int) b.height;
+    if (b.filter == BITMAP_BILINEAR) {
+        u = fmadd(u, (float) w, -.5f); v = fmadd(v, (float) h, -.5f);          // :415
+        const int xi = bitmap_floor2int(u), yi = bitmap_floor2int(v);          // :418
+        const float w1x = u - (float) xi, w1y = v - (float) yi, w0x = 1.f - w1x, w0y = 1.f - w1y;   // :421-422
+        const int x0 = bitmap_wrap(xi, w, b.wrap), x1 = bitmap_wrap(xi + 1, w, b.wrap),
+                  y0 = bitmap_wrap(yi, h, b.wrap), y1 = bitmap_wrap(yi + 1, h, b.wrap);
+        const Spec v00 = bitmap_texel(b, x0, y0, wl), v10 = bitmap_texel(b, x1, y0, wl),
+                   v01 = bitmap_texel(b, x0, y1, wl), v11 = bitmap_texel(b, x1, y1, wl);
+        const Spec v0 = spec_fmadd(w0x, v00, w1x * v10), v1 = spec_fmadd(w0x, v01, w1x * v11);   // :447-448
+        return spec_fmadd(w0y, v0, w1y * v1);                                  // :450
+    }
+    u *= (float) w; v *= (float) h;                                            // :453
+    return bitmap_texel(b, bitmap_wrap(bitmap_floor2int(u), w, b.wrap), bitmap_wrap(bitmap_floor2int(v), h, b.wrap), wl);
+}
+
+// A plugin parameter at a surface point: a constant (tex_eval above) or a bitmap lookup.
+MIW_HD Spec tex_eval(const TexRec &t, const TexCtx &tc) {
+    if (tc.bitmaps && t.type == TEX_BITMAP) return bitmap_eval(tc.bitmaps[(uint32_t) t.v[0]], tc.uv, tc.wl);
+    return tex_eval(t, tc.wl);
+}
 
 } // namespace miw

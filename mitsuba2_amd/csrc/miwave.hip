@@ -52,6 +52,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "miw/direct.h"
 #include "rect_build.h"
 #include "miw/film_gather.h"
+#include "texture_build.h"
 #include "bvh_build.h"
 #include "envmap_build.h"
 #include "lbvh_device.h"
@@ -1165,6 +1166,7 @@ struct mi_ctx {
     // host copy of the scene (input order)
     std::vector<Tri> tris_in;
     std::vector<float> tri_vn_in;       // 9 per tri or empty
+    std::vector<float> tri_uv_in;       // 6 per face (texture coordinates, texture_build.h) or empty
     std::vector<ShapeRec> shapes;
     std::vector<AnalyticRec> rects;                 // analytic rectangles
     std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
@@ -1173,7 +1175,7 @@ struct mi_ctx {
     bool have_scene = false, have_bvh = false;
 
     // device scene
-    DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn;
+    DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn, d_tri_uv, d_bitmap_data; DevBuf<BitmapRec> d_bitmaps; uint32_t bitmap_count = 0;
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<AnalyticRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds;
@@ -1240,7 +1242,7 @@ void mi_destroy(mi_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
-    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_tri_uv.release(); c->d_bitmap_data.release(); c->d_bitmaps.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
@@ -1290,10 +1292,10 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         // emitter ids index the combined list: the environment map sits at envmap->emitter_index
         int32_t emitter_id = sh.emitter;
         if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
-        ShapeRec r; r.bsdf = sh.bsdf; r.emitter = emitter_id; r.flags = sh.flags & MI_SHAPE_HAS_NORMALS; r.pad = 0;
+        ShapeRec r; r.bsdf = sh.bsdf; r.emitter = emitter_id; r.flags = sh.flags & (MI_SHAPE_HAS_NORMALS | MI_SHAPE_HAS_TEXCOORDS); r.pad = 0;
         if (sh.flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) {
             if (sh.face_count != 1) return fail(c, MI_ERR_INVALID, "shape %u: an analytic shape is one primitive (face_count == 1)", i);
-            if (sh.flags & MI_SHAPE_HAS_NORMALS) return fail(c, MI_ERR_INVALID, "shape %u: an analytic shape has no vertex normals", i);
+            if (sh.flags & (MI_SHAPE_HAS_NORMALS | MI_SHAPE_HAS_TEXCOORDS)) return fail(c, MI_ERR_INVALID, "shape %u: an analytic shape has no vertex normals / texture coordinates", i);
             if ((sh.flags & MI_SHAPE_RECTANGLE) && (sh.flags & MI_SHAPE_SPHERE)) return fail(c, MI_ERR_INVALID, "shape %u: rectangle and sphere", i);
         }
         c->shapes[i] = r;
@@ -1324,6 +1326,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     for (uint32_t i = 0; i < s->shape_count; ++i)
         if ((s->shapes[i].flags & (MI_SHAPE_RECTANGLE | MI_SHAPE_SPHERE)) && shape_rect[i] < 0)
             return fail(c, MI_ERR_INVALID, "shape %u: no mi_rectangle record", i);
+    if (!build_face_texcoords(s, c->tri_uv_in)) return fail(c, MI_ERR_INVALID, "scene: MI_SHAPE_HAS_TEXCOORDS without vertex_texcoords (or a vertex index out of range)");
     c->tris_in.resize((size_t) s->face_count + c->rects.size());
     c->tri_vn_in.clear();
     if (any_normals) c->tri_vn_in.assign(c->tris_in.size() * 9, 0.f);
@@ -1350,8 +1353,10 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         const mi_bsdf &b = s->bsdfs[i];
         if (b.type >= BSDF_TYPE_COUNT) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
-        BsdfRec r; memset(&r, 0, sizeof r);
-        r.type = b.type; r.flags = b.flags; memcpy(r.p, b.params, sizeof r.p);
+        BsdfRec r; int slot = 0;
+        if (const char *why = bsdf_record_from_abi(b, s->bitmap_count, r, &slot))
+            return fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: %s", i, slot, why);
+        r.back = 0;
         if (b.flags & MI_BSDF_FLAG_TWOSIDED) {                 // twosided.cpp:62-92
             if (b.back >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "bsdf %u: back-side record %u out of range", i, b.back);
             const uint32_t tr = BSDF_Transmission;
@@ -1361,26 +1366,26 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
             if ((f0 | f1) & tr) return fail(c, MI_ERR_INVALID, "bsdf %u: only materials without a transmission component can be nested", i);
             r.back = b.back;
         }
-#if MIW_SPECTRAL
-        for (int k = 0; k < (int) bsdf_tex_slots(b.type); ++k) {
-            if (b.tex[k].type == MI_TEX_RGB || b.tex[k].type > MI_TEX_SRGB_D65)
-                return fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: the scalar_spectral library needs a spectral texture record", i, k);
-            memcpy(&r.tex[k], &b.tex[k], sizeof(TexRec));
-        }
-#else
-        {   // legacy RGB layout of params[] -> texture records
-            const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };
-            for (int k = 0; k < 3; ++k) {
-                r.tex[k].type = TEX_RGB;
-                if (off[b.type][k] >= 0) memcpy(r.tex[k].v, b.params + off[b.type][k], 12);
-                if (b.tex[k].type != MI_TEX_RGB) return fail(c, MI_ERR_INVALID, "bsdf %u: spectral texture record passed to the scalar_rgb library", i);
-            }
-        }
-#endif
         c->bsdfs[i] = r;
     }
     c->diffuse_only = true;
     for (const BsdfRec &r : c->bsdfs) if (r.type != BSDF_TYPE_DIFFUSE || (r.flags & BSDF_REC_TWOSIDED)) c->diffuse_only = false;
+    if (!c->tri_uv_in.empty()) c->diffuse_only = false;          // texture coordinates steer the shading frame (mesh.cpp:492-511)
+    for (const BsdfRec &r : c->bsdfs) if (bsdf_uses_bitmap(r)) c->diffuse_only = false;   // the plain-diffuse kernel reads constants only
+    {   // bitmap textures: one device buffer of texels, records pointing into it
+        std::vector<BitmapRec> recs; uint32_t bad = 0;
+        if (const char *why = build_bitmap_table(s, recs, &bad)) return fail(c, MI_ERR_INVALID, "bitmap %u: %s", bad, why);
+        std::vector<size_t> first(recs.size() + 1, 0);
+        for (size_t i = 0; i < recs.size(); ++i) first[i + 1] = first[i] + (size_t) recs[i].width * recs[i].height * recs[i].channels;
+        HIP_TRY(c, c->d_bitmap_data.resize(std::max<size_t>(first.back(), 1)));
+        for (size_t i = 0; i < recs.size(); ++i) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_bitmap_data.p + first[i], recs[i].data, (first[i + 1] - first[i]) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            recs[i].data = c->d_bitmap_data.p + first[i];
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));            // the caller's arrays may go away after this call
+        HIP_TRY(c, c->d_bitmaps.upload(recs, c->stream));
+        c->bitmap_count = (uint32_t) recs.size();
+    }
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
     c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
     bool any_emit_normals = false;
@@ -1450,6 +1455,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         c->have_env = true;
     }
     HIP_TRY(c, c->d_shapes.upload(c->shapes, c->stream));
+    HIP_TRY(c, c->d_tri_uv.upload(c->tri_uv_in, c->stream));
     HIP_TRY(c, c->d_rects.upload(c->rects, c->stream));
     HIP_TRY(c, c->d_bsdfs.upload(c->bsdfs, c->stream));
     HIP_TRY(c, c->d_emitters.upload(c->emitters, c->stream));
@@ -1548,6 +1554,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.nodes = c->d_nodes.p; v.node_count = node_count;
     v.tris = c->d_tris.p; v.tri_count = tri_count;
     v.tri_vn = c->tri_vn_in.empty() ? nullptr : c->d_tri_vn.p;
+    v.tri_uv = c->tri_uv_in.empty() ? nullptr : c->d_tri_uv.p;
+    v.bitmaps = c->bitmap_count ? c->d_bitmaps.p : nullptr;
     v.shapes = c->d_shapes.p; v.shape_count = (uint32_t) c->shapes.size();
     v.bsdfs = c->d_bsdfs.p; v.bsdf_count = (uint32_t) c->bsdfs.size();
     v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();

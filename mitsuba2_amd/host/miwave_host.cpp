@@ -157,8 +157,14 @@ float Properties::float_(const std::string &n) const {
     Throw("The property \"" + n + "\" has the wrong type (expected <float>).");
 }
 float Properties::float_(const std::string &n, float def) const { return has_property(n) ? float_(n) : def; }
+std::shared_ptr<BitmapTexture> Properties::bitmap(const std::string &n) const {
+    if (!has_property(n)) return nullptr;
+    if (const std::shared_ptr<BitmapTexture> *v = prop_get<std::shared_ptr<BitmapTexture>>(m_values, n)) return *v;
+    return nullptr;
+}
 Color3f Properties::texture(const std::string &n) const {
     if (!has_property(n)) Throw("Property \"" + n + "\" has not been specified!");
+    if (auto b = bitmap(n)) { Color3f m = b->mean(); for (float &v : m) v = std::min(std::max(v, 0.f), 1.f); return m; }
     if (const Color3f *v = prop_get<Color3f>(m_values, n)) return *v;
     if (const float *v = prop_get<float>(m_values, n)) return Color3f{ *v, *v, *v };
     Throw("The property \"" + n + "\" has the wrong type (expected <rgb> or <float>; only constant textures are supported).");
@@ -229,7 +235,8 @@ mi_texture Properties::texture_record(const std::string &n, float def, bool with
     mi_texture t{};
     bool is_color = false; Color3f color{ def, def, def }; float value = def;
     if (has_property(n)) {
-        if (const Color3f *v = prop_get<Color3f>(m_values, n)) { is_color = true; color = *v; }
+        if (bitmap(n)) { is_color = true; color = texture(n); }   // host-side stand-in: the (clamped) mean colour
+        else if (const Color3f *v = prop_get<Color3f>(m_values, n)) { is_color = true; color = *v; }
         else if (const float *v = prop_get<float>(m_values, n)) { value = *v; color = { *v, *v, *v }; }
         else Throw("The property \"" + n + "\" has the wrong type (expected <rgb> or <float>; only constant textures are supported).");
     }
@@ -661,6 +668,98 @@ float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
     return miw::bsdf_side_pdf(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]));
 }
 
+void BSDF::bind_texture(int slot, const Properties &props, const std::string &name, float def, bool unbounded) {
+    m_rec.tex[slot] = props.texture_record(name, def, false, unbounded);
+    m_bitmaps[slot] = props.bitmap(name);
+}
+
+// ---- bitmap texture (src/textures/bitmap.cpp:85-200) ---------------------------------------------------------
+BitmapTexture::BitmapTexture(const Properties &props) {
+    m_to_uv = props.transform("to_uv", Transform4f());
+    std::string filter_type = props.string("filter_type", "bilinear");
+    if (filter_type == "nearest") m_filter = MI_BITMAP_NEAREST;
+    else if (filter_type == "bilinear") m_filter = MI_BITMAP_BILINEAR;
+    else Throw("Invalid filter type \"" + filter_type + "\", must be one of: \"nearest\", or \"bilinear\"!");
+    std::string wrap_mode = props.string("wrap_mode", "repeat");
+    if (wrap_mode == "repeat") m_wrap = MI_BITMAP_REPEAT;
+    else if (wrap_mode == "mirror") m_wrap = MI_BITMAP_MIRROR;
+    else if (wrap_mode == "clamp") m_wrap = MI_BITMAP_CLAMP;
+    else Throw("Invalid wrap mode \"" + wrap_mode + "\", must be one of: \"repeat\", \"mirror\", or \"clamp\"!");
+    m_raw = props.bool_("raw", false);
+    if (props.has_property("filename")) {
+        m_name = props.string("filename");
+        read_pfm(m_name, m_width, m_height, m_channels, m_data);
+        finish();
+    }
+}
+void BitmapTexture::set_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float *data) {
+    if (channels != 1 && channels != 3) Throw("Unsupported channel count: " + std::to_string(channels) + " (expected 1 or 3)");
+    if (!data || width == 0 || height == 0) Throw("BitmapTexture: empty image");
+    m_width = width; m_height = height; m_channels = channels;
+    m_data.assign(data, data + (size_t) width * height * channels);
+    finish();
+}
+// bitmap.cpp:137-143 (images below 2 x 2 are up-sampled with a tent filter: here by replication, which is what that
+// resampling yields for a 1-texel axis) and :150-197 (conversion to the variant's representation)
+void BitmapTexture::finish() {
+    if (m_width < 2 || m_height < 2) {
+        const uint32_t w = std::max(m_width, 2u), h = std::max(m_height, 2u);
+        std::vector<float> up((size_t) w * h * m_channels);
+        for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) for (uint32_t c = 0; c < m_channels; ++c)
+            up[((size_t) y * w + x) * m_channels + c] = m_data[((size_t) std::min(y, m_height - 1) * m_width + std::min(x, m_width - 1)) * m_channels + c];
+        m_data.swap(up); m_width = w; m_height = h;
+    }
+    m_device_data.clear();
+#if MIW_SPECTRAL
+    if (m_channels == 3 && !m_raw) {                           // :156-165
+        m_device_data.resize(m_data.size());
+        for (size_t i = 0; i < m_data.size(); i += 3) {
+            auto cf = srgb_model_fetch(Color3f{ m_data[i], m_data[i + 1], m_data[i + 2] });
+            m_device_data[i] = cf[0]; m_device_data[i + 1] = cf[1]; m_device_data[i + 2] = cf[2];
+        }
+    }
+#endif
+}
+Color3f BitmapTexture::mean() const {
+    double sum[3] = { 0, 0, 0 };
+    const size_t n = (size_t) m_width * m_height;
+    for (size_t i = 0; i < n; ++i) for (uint32_t c = 0; c < 3; ++c) sum[c] += (double) m_data[i * m_channels + (m_channels == 3 ? c : 0)];
+    return Color3f{ (float) (sum[0] / (double) n), (float) (sum[1] / (double) n), (float) (sum[2] / (double) n) };
+}
+mi_bitmap BitmapTexture::record() const {
+    if (m_data.empty()) Throw("BitmapTexture: no image (give a \"filename\" or call set_bitmap)");
+#if MIW_SPECTRAL
+    if (m_channels == 3 && m_raw)                              // bitmap.cpp:269-273
+        Throw("The bitmap texture " + m_name + " was queried for a spectrum, but texture conversion into spectra was explicitly disabled! (raw=true)");
+#endif
+    mi_bitmap b{};
+    b.data = m_device_data.empty() ? m_data.data() : m_device_data.data();
+    b.width = m_width; b.height = m_height; b.channels = m_channels; b.filter_type = m_filter; b.wrap_mode = m_wrap;
+    // Transform4f::extract() to 3 x 3 (transform.h:324-348): upper-left 2 x 2 and the translation column
+    b.to_uv[0] = m_to_uv.m[0]; b.to_uv[1] = m_to_uv.m[1]; b.to_uv[2] = m_to_uv.m[4]; b.to_uv[3] = m_to_uv.m[5];
+    b.to_uv[4] = m_to_uv.m[12]; b.to_uv[5] = m_to_uv.m[13];
+    return b;
+}
+void read_pfm(const std::string &path, uint32_t &width, uint32_t &height, uint32_t &channels, std::vector<float> &data) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) Throw("Bitmap: \"" + path + "\": file not found");
+    char magic[3] = { 0, 0, 0 }; int w = 0, h = 0; float scale = 0.f;
+    if (std::fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || (std::strcmp(magic, "PF") && std::strcmp(magic, "Pf")) || w <= 0 || h <= 0 || scale == 0.f) {
+        std::fclose(f); Throw("Bitmap: \"" + path + "\" is not a Portable Float Map (only PFM images are read by this layer)");
+    }
+    std::fgetc(f);                                             // the single whitespace byte after the header
+    channels = magic[1] == 'F' ? 3u : 1u; width = (uint32_t) w; height = (uint32_t) h;
+    data.resize((size_t) w * h * channels);
+    const size_t row = (size_t) w * channels;
+    for (int y = h - 1; y >= 0; --y)                           // bottom-to-top scanlines
+        if (std::fread(data.data() + (size_t) y * row, sizeof(float), row, f) != row) { std::fclose(f); Throw("Bitmap: \"" + path + "\": truncated file"); }
+    std::fclose(f);
+    if (scale > 0.f)                                           // big endian
+        for (float &v : data) { uint32_t u; std::memcpy(&u, &v, 4); u = __builtin_bswap32(u); std::memcpy(&v, &u, 4); }
+    const float mul = std::fabs(scale);
+    if (mul != 1.f) for (float &v : data) v *= mul;
+}
+
 static void check_reflectance(const Color3f &c, const char *what) {  // src/spectra/srgb.cpp:30-31
     for (float v : c) if (v < 0.f || v > 1.f) Throw(std::string(what) + ": values must be in the range [0, 1]!");
 }
@@ -669,7 +768,7 @@ SmoothDiffuse::SmoothDiffuse(const Properties &props) {
     check_reflectance(r, "reflectance");
     m_rec.type = MI_BSDF_DIFFUSE; m_rec.flags = 0;
     m_rec.params[0] = r[0]; m_rec.params[1] = r[1]; m_rec.params[2] = r[2];
-    m_rec.tex[0] = props.texture_record("reflectance", .5f, false, false);
+    bind_texture(0, props, "reflectance", .5f, false);
 }
 SmoothDielectric::SmoothDielectric(const Properties &props) {
     float int_ior = lookup_ior(props, "int_ior", "bk7"), ext_ior = lookup_ior(props, "ext_ior", "air");
@@ -679,8 +778,8 @@ SmoothDielectric::SmoothDielectric(const Properties &props) {
     m_rec.type = MI_BSDF_DIELECTRIC; m_rec.flags = 0;
     m_rec.params[0] = int_ior / ext_ior;
     for (int i = 0; i < 3; ++i) { m_rec.params[1 + i] = sr[i]; m_rec.params[4 + i] = stt[i]; }
-    m_rec.tex[0] = props.texture_record("specular_reflectance", 1.f, false, false);
-    m_rec.tex[1] = props.texture_record("specular_transmittance", 1.f, false, false);
+    bind_texture(0, props, "specular_reflectance", 1.f, false);
+    bind_texture(1, props, "specular_transmittance", 1.f, false);
 }
 RoughConductor::RoughConductor(const Properties &props) {
     std::string material = props.string("material", "none");
@@ -713,9 +812,9 @@ RoughConductor::RoughConductor(const Properties &props) {
     m_rec.type = MI_BSDF_ROUGHCONDUCTOR; m_rec.flags = flags;
     m_rec.params[0] = au; m_rec.params[1] = av;
     for (int i = 0; i < 3; ++i) { m_rec.params[2 + i] = eta[i]; m_rec.params[5 + i] = k[i]; m_rec.params[8 + i] = sr[i]; }
-    m_rec.tex[0] = props.texture_record("eta", 0.f, false, true);    // xml.cpp is_unbounded_spectrum: eta, k
-    m_rec.tex[1] = props.texture_record("k", 1.f, false, true);
-    m_rec.tex[2] = props.texture_record("specular_reflectance", 1.f, false, false);
+    bind_texture(0, props, "eta", 0.f, true);    // xml.cpp is_unbounded_spectrum: eta, k
+    bind_texture(1, props, "k", 1.f, true);
+    bind_texture(2, props, "specular_reflectance", 1.f, false);
 }
 
 SmoothConductor::SmoothConductor(const Properties &props) {
@@ -731,9 +830,9 @@ SmoothConductor::SmoothConductor(const Properties &props) {
     check_reflectance(sr, "specular_reflectance");
     m_rec.type = MI_BSDF_CONDUCTOR; m_rec.flags = 0;
     for (int i = 0; i < 3; ++i) { m_rec.params[2 + i] = eta[i]; m_rec.params[5 + i] = k[i]; m_rec.params[8 + i] = sr[i]; }
-    m_rec.tex[0] = props.texture_record("eta", 0.f, false, true);
-    m_rec.tex[1] = props.texture_record("k", 1.f, false, true);
-    m_rec.tex[2] = props.texture_record("specular_reflectance", 1.f, false, false);
+    bind_texture(0, props, "eta", 0.f, true);
+    bind_texture(1, props, "k", 1.f, true);
+    bind_texture(2, props, "specular_reflectance", 1.f, false);
 }
 // fresnel.h:327-361
 float fresnel_diffuse_reflectance(float eta) {
@@ -762,8 +861,8 @@ SmoothPlastic::SmoothPlastic(const Properties &props) {
     m_rec.params[2] = fresnel_diffuse_reflectance(1.f / eta);
     m_rec.params[3] = s_mean / (d_mean + s_mean);
     for (int i = 0; i < 3; ++i) { m_rec.params[4 + i] = dr[i]; m_rec.params[7 + i] = sr[i]; }
-    m_rec.tex[0] = props.texture_record("diffuse_reflectance", .5f, false, false);
-    m_rec.tex[1] = props.texture_record("specular_reflectance", 1.f, false, false);
+    bind_texture(0, props, "diffuse_reflectance", .5f, false);
+    bind_texture(1, props, "specular_reflectance", 1.f, false);
 }
 RoughDielectric::RoughDielectric(const Properties &props) {
     float int_ior = lookup_ior(props, "int_ior", "bk7"), ext_ior = lookup_ior(props, "ext_ior", "air");
@@ -793,8 +892,8 @@ RoughDielectric::RoughDielectric(const Properties &props) {
     m_rec.type = MI_BSDF_ROUGHDIELECTRIC; m_rec.flags = flags;
     m_rec.params[0] = au; m_rec.params[1] = av; m_rec.params[2] = eta; m_rec.params[3] = 1.f / eta;   // parameters_changed(), :199-201
     for (int i = 0; i < 3; ++i) { m_rec.params[4 + i] = sr[i]; m_rec.params[7 + i] = stt[i]; }
-    m_rec.tex[0] = props.texture_record("specular_reflectance", 1.f, false, false);
-    m_rec.tex[1] = props.texture_record("specular_transmittance", 1.f, false, false);
+    bind_texture(0, props, "specular_reflectance", 1.f, false);
+    bind_texture(1, props, "specular_transmittance", 1.f, false);
 }
 TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back) {
     if (!front) Throw("A nested one-sided material is required!");
@@ -804,6 +903,7 @@ TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> ba
         Throw("Only materials without a transmission component can be nested!");
     m_rec = front->record();
     m_rec.flags |= MI_BSDF_FLAG_TWOSIDED;
+    for (int k = 0; k < 3; ++k) m_bitmaps[k] = front->bitmap(k);
     m_back = back;
 }
 
@@ -827,8 +927,9 @@ void EnvironmentMapEmitter::set_bitmap(uint32_t width, uint32_t height, const fl
 // ============================================================================================
 // Mesh / Scene
 // ============================================================================================
-Mesh::Mesh(std::string name, std::vector<float> p, std::vector<uint32_t> f, std::vector<float> n)
-    : m_name(std::move(name)), m_positions(std::move(p)), m_normals(std::move(n)), m_faces(std::move(f)) {
+Mesh::Mesh(std::string name, std::vector<float> p, std::vector<uint32_t> f, std::vector<float> n, std::vector<float> tc)
+    : m_name(std::move(name)), m_positions(std::move(p)), m_normals(std::move(n)), m_texcoords(std::move(tc)), m_faces(std::move(f)) {
+    if (!m_texcoords.empty() && m_texcoords.size() / 2 != m_positions.size() / 3) Throw("Mesh: vertex texture coordinate count mismatch");
     if (m_positions.size() % 3 || m_faces.size() % 3) Throw("Mesh: buffer sizes must be multiples of 3");
     if (!m_normals.empty() && m_normals.size() != m_positions.size()) Throw("Mesh: vertex normal count mismatch");
     for (uint32_t i : m_faces) if (i >= vertex_count()) Throw("Mesh: face references a vertex out of range");
@@ -948,7 +1049,8 @@ std::shared_ptr<Mesh> load_obj(const Properties &props) {
         if (parse_error) fail("could not parse line \"" + line + "\"");
     }
     const size_t nv = keys.size();
-    std::vector<float> P(nv * 3), N;
+    std::vector<float> P(nv * 3), N, T;
+    if (!texcoords.empty()) T.assign(nv * 2, 0.f);             // obj.cpp:285-286
     const bool keep_normals = !face_normals;
     if (keep_normals && !normals.empty()) N.assign(nv * 3, 0.f);
     for (size_t id = 0; id < nv; ++id) {
@@ -956,13 +1058,14 @@ std::shared_ptr<Mesh> load_obj(const Properties &props) {
         const miw::V3 &v = vertices[k.k[0] - 1];
         P[3 * id] = v.x; P[3 * id + 1] = v.y; P[3 * id + 2] = v.z;
         if (k.k[1] && (size_t) k.k[1] - 1 >= texcoords.size()) fail("reference to invalid texture coordinate " + std::to_string(k.k[1]) + "!");
+        if (k.k[1]) { T[2 * id] = texcoords[k.k[1] - 1][0]; T[2 * id + 1] = texcoords[k.k[1] - 1][1]; }   // obj.cpp:307-312
         if (keep_normals && k.k[2]) {
             if ((size_t) k.k[2] - 1 >= normals.size()) fail("reference to invalid normal " + std::to_string(k.k[2]) + "!");
             const miw::V3 &n = normals[k.k[2] - 1];
             N[3 * id] = n.x; N[3 * id + 1] = n.y; N[3 * id + 2] = n.z;
         }
     }
-    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(faces), std::move(N));
+    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(faces), std::move(N), std::move(T));
     if (keep_normals && normals.empty()) mesh->recompute_vertex_normals();      // obj.cpp:339-341
     return mesh;
 }
@@ -1026,19 +1129,22 @@ std::shared_ptr<Mesh> load_ply(const Properties &props) {
         if (t == "float" || t == "float32") { float v; std::memcpy(&v, b, 4); return v; }
         double v; std::memcpy(&v, b, 8); return v;
     };
-    std::vector<float> P, N; std::vector<uint32_t> F; bool has_normals = false;
+    std::vector<float> P, N, T; std::vector<uint32_t> F; bool has_normals = false;
     for (const Elem &el : elems) {
         if (el.name == "vertex") {
-            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
+            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
             for (size_t i = 0; i < el.props.size(); ++i) {
                 const std::string &n = el.props[i].name;
                 if (n == "x") ix = (int) i; else if (n == "y") iy = (int) i; else if (n == "z") iz = (int) i;
                 else if (n == "nx") inx = (int) i; else if (n == "ny") iny = (int) i; else if (n == "nz") inz = (int) i;
+                else if (n == "u" || n == "texture_u" || n == "s") iu = (int) i;      // ply.cpp:159-169
+                else if (n == "v" || n == "texture_v" || n == "t") iv = (int) i;
                 if (el.props[i].list) fail("vertex element with a list property");
             }
             if (ix < 0 || iy < 0 || iz < 0) fail("vertex coordinates missing");
             has_normals = inx >= 0 && iny >= 0 && inz >= 0 && !face_normals;
             P.resize(el.count * 3); if (has_normals) N.resize(el.count * 3);
+            if (iu >= 0 && iv >= 0) T.resize(el.count * 2);
             std::vector<double> row(el.props.size());
             for (size_t v = 0; v < el.count; ++v) {
                 for (size_t i = 0; i < el.props.size(); ++i) row[i] = read_num(el.props[i].type);
@@ -1048,6 +1154,7 @@ std::shared_ptr<Mesh> load_ply(const Properties &props) {
                     miw::V3 n = miw::normalize(xf_normal(to_world, miw::v3((float) row[inx], (float) row[iny], (float) row[inz])));
                     N[3 * v] = n.x; N[3 * v + 1] = n.y; N[3 * v + 2] = n.z;
                 }
+                if (!T.empty()) { T[2 * v] = (float) row[iu]; T[2 * v + 1] = (float) row[iv]; }   // ply.cpp:251-257
             }
         } else if (el.name == "face") {
             F.reserve(el.count * 3);
@@ -1070,7 +1177,7 @@ std::shared_ptr<Mesh> load_ply(const Properties &props) {
     }
     if (ascii) while (pos < data.size() && std::isspace((unsigned char) data[pos])) ++pos;
     if (pos != data.size()) fail("invalid file -- trailing content");
-    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(F), std::move(N));
+    auto mesh = std::make_shared<Mesh>(name, std::move(P), std::move(F), std::move(N), std::move(T));
     if (!face_normals && !has_normals) mesh->recompute_vertex_normals();        // ply.cpp:378-383
     return mesh;
 }
@@ -1144,18 +1251,40 @@ std::shared_ptr<Mesh> make_sphere(const Properties &props) {
     return mesh;
 }
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
+                    std::vector<float> &tex, std::vector<mi_bitmap> &bitmaps, std::vector<std::shared_ptr<BitmapTexture>> &bitmap_objs,
                     std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
                     std::vector<mi_emitter> &erecs, std::vector<mi_rectangle> &rrecs, std::vector<mi_sphere> &sphrecs) {
-    pos.clear(); nrm.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear(); sphrecs.clear();
-    bool any_normals = false;
-    for (auto &m : shapes) any_normals = any_normals || m->has_vertex_normals();
+    pos.clear(); nrm.clear(); tex.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear(); sphrecs.clear();
+    bool any_normals = false, any_texcoords = false;
+    for (auto &m : shapes) { any_normals = any_normals || m->has_vertex_normals(); any_texcoords = any_texcoords || m->has_vertex_texcoords(); }
     std::map<const BSDF *, uint32_t> bsdf_index;
+    bitmaps.clear(); bitmap_objs.clear();
+    std::map<const BitmapTexture *, uint32_t> bitmap_index;
+    // the plugin's C-ABI record, bitmap parameters resolved to entries of the scene's bitmap table
+    auto push_record = [&](const BSDF *b) {
+        mi_bsdf r = b->record();
+        for (int k = 0; k < 3; ++k) {
+            const std::shared_ptr<BitmapTexture> &t = b->bitmap(k);
+            if (!t) continue;
+            auto it = bitmap_index.find(t.get());
+            if (it == bitmap_index.end()) {
+                it = bitmap_index.emplace(t.get(), (uint32_t) bitmaps.size()).first;
+                bitmaps.push_back(t->record()); bitmap_objs.push_back(t);
+            }
+            r.tex[k] = mi_texture{}; r.tex[k].type = MI_TEX_BITMAP; r.tex[k].v[0] = (float) it->second;
+        }
+        brecs.push_back(r);
+    };
     for (auto &m : shapes) {
         uint32_t vbase = (uint32_t) (pos.size() / 3), fbase = (uint32_t) (faces.size() / 3);
         pos.insert(pos.end(), m->vertex_positions_buffer().begin(), m->vertex_positions_buffer().end());
         if (any_normals) {
             if (m->has_vertex_normals()) nrm.insert(nrm.end(), m->vertex_normals_buffer().begin(), m->vertex_normals_buffer().end());
             else nrm.insert(nrm.end(), m->vertex_positions_buffer().size(), 0.f);
+        }
+        if (any_texcoords) {
+            if (m->has_vertex_texcoords()) tex.insert(tex.end(), m->vertex_texcoords_buffer().begin(), m->vertex_texcoords_buffer().end());
+            else tex.insert(tex.end(), (size_t) m->vertex_count() * 2, 0.f);
         }
         for (uint32_t i : m->faces_buffer()) faces.push_back(i + vbase);
         mi_shape s{};
@@ -1169,14 +1298,16 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
         auto it = bsdf_index.find(b.get());
         if (it == bsdf_index.end()) {
             it = bsdf_index.emplace(b.get(), (uint32_t) brecs.size()).first;
-            brecs.push_back(b->record());
+            push_record(b.get());
             if (b->twosided()) {                                   // the back side's record follows (or is the front's own)
                 const uint32_t self = it->second;
                 const BSDF *back = b->back().get();
-                if (miw_same_record(back->record(), b->record())) brecs[self].back = self;
+                bool same_bitmaps = true;
+                for (int k = 0; k < 3; ++k) same_bitmaps = same_bitmaps && back->bitmap(k) == b->bitmap(k);
+                if (same_bitmaps && miw_same_record(back->record(), b->record())) brecs[self].back = self;
                 else {
                     auto jt = bsdf_index.find(back);
-                    if (jt == bsdf_index.end()) { jt = bsdf_index.emplace(back, (uint32_t) brecs.size()).first; brecs.push_back(back->record()); }
+                    if (jt == bsdf_index.end()) { jt = bsdf_index.emplace(back, (uint32_t) brecs.size()).first; push_record(back); }
                     brecs[self].back = jt->second;
                 }
             }
@@ -1190,7 +1321,7 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
             e.radiance_tex = m->emitter()->radiance_texture();
             erecs.push_back(e);
         }
-        s.flags = m->has_vertex_normals() ? MI_SHAPE_HAS_NORMALS : 0;
+        s.flags = (m->has_vertex_normals() ? MI_SHAPE_HAS_NORMALS : 0) | (m->has_vertex_texcoords() ? MI_SHAPE_HAS_TEXCOORDS : 0);
         s.first_face = fbase; s.face_count = m->face_count();
         if (m->is_rectangle()) {
             s.flags |= MI_SHAPE_RECTANGLE;
@@ -1208,11 +1339,13 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
 }
 void Scene::build(int device, int bvh_quality) {
     if (m_shapes.empty()) Throw("Scene: no shapes");
-    flatten(m_shapes, m_positions, m_normals, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
+    flatten(m_shapes, m_positions, m_normals, m_texcoords, m_bitmap_recs, m_bitmap_objs, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
     m_desc.spheres = m_sphere_recs.empty() ? nullptr : m_sphere_recs.data(); m_desc.sphere_count = (uint32_t) m_sphere_recs.size();
     m_desc.rectangles = m_rect_recs.empty() ? nullptr : m_rect_recs.data(); m_desc.rectangle_count = (uint32_t) m_rect_recs.size();
     m_desc.vertex_positions = m_positions.data();
     m_desc.vertex_normals = m_normals.empty() ? nullptr : m_normals.data();
+    m_desc.vertex_texcoords = m_texcoords.empty() ? nullptr : m_texcoords.data();
+    m_desc.bitmaps = m_bitmap_recs.empty() ? nullptr : m_bitmap_recs.data(); m_desc.bitmap_count = (uint32_t) m_bitmap_recs.size();
     m_desc.vertex_count = (uint32_t) (m_positions.size() / 3);
     m_desc.faces = m_faces.data(); m_desc.face_count = (uint32_t) (m_faces.size() / 3);
     m_desc.shapes = m_shape_recs.data(); m_desc.shape_count = (uint32_t) m_shape_recs.size();
@@ -1698,6 +1831,18 @@ void mih_props_set_float(void *p, const char *n, float v) { ((Properties *) p)->
 void mih_props_set_int(void *p, const char *n, int64_t v) { ((Properties *) p)->set_int(n, v); }
 void mih_props_set_bool(void *p, const char *n, int v) { ((Properties *) p)->set_bool(n, v != 0); }
 void mih_props_set_string(void *p, const char *n, const char *v) { ((Properties *) p)->set_string(n, v); }
+void mih_props_set_texture(void *p, const char *n, void *tex) { ((Properties *) p)->set_texture(n, ((Box<BitmapTexture> *) tex)->p); }
+void *mih_bitmap_create(void *props, uint32_t w, uint32_t h, uint32_t channels, const float *data) {
+    MIH_TRY
+        auto t = std::make_shared<BitmapTexture>(*(Properties *) props);
+        if (data) t->set_bitmap(w, h, channels, data);
+        return new Box<BitmapTexture>{ t }; MIH_CATCH(nullptr)
+}
+void mih_bitmap_destroy(void *t) { delete (Box<BitmapTexture> *) t; }
+int mih_bitmap_info(void *t, uint32_t *whc, float *mean3) {
+    MIH_TRY const BitmapTexture &b = *((Box<BitmapTexture> *) t)->p; whc[0] = b.width(); whc[1] = b.height(); whc[2] = b.channels();
+        Color3f m = b.mean(); mean3[0] = m[0]; mean3[1] = m[1]; mean3[2] = m[2]; return 0; MIH_CATCH(-1)
+}
 void mih_props_set_color(void *p, const char *n, float r, float g, float b) { ((Properties *) p)->set_color(n, Color3f{ r, g, b }); }
 // 4x4 row-major matrix (what <matrix value="..."/> holds, xml.cpp)
 void mih_props_set_matrix(void *p, const char *n, const float *row_major16) { ((Properties *) p)->set_transform(n, Transform4f::from_matrix(row_major16)); }
@@ -1754,12 +1899,14 @@ void *mih_emitter_create(void *props) {
 }
 void mih_emitter_destroy(void *e) { delete (Box<AreaLight> *) e; }
 
-void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals) {
+void *mih_mesh_create(const char *name, const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals,
+                      const float *texcoords) {
     MIH_TRY
         std::vector<float> p(pos, pos + 3 * (size_t) nv);
         std::vector<uint32_t> f(faces, faces + 3 * (size_t) nf);
         std::vector<float> n; if (normals) n.assign(normals, normals + 3 * (size_t) nv);
-        return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n)) }; MIH_CATCH(nullptr)
+        std::vector<float> tc; if (texcoords) tc.assign(texcoords, texcoords + 2 * (size_t) nv);
+        return new Box<Mesh>{ std::make_shared<Mesh>(name ? name : "", std::move(p), std::move(f), std::move(n), std::move(tc)) }; MIH_CATCH(nullptr)
 }
 void *mih_sphere_create(void *props) {                       // the `sphere` shape plugin (analytic)
     MIH_TRY return new Box<Mesh>{ make_sphere(*(Properties *) props) }; MIH_CATCH(nullptr)
@@ -1773,7 +1920,12 @@ void *mih_mesh_load(int kind, void *props) {
 }
 int mih_mesh_recompute_normals(void *m) { MIH_TRY ((Box<Mesh> *) m)->p->recompute_vertex_normals(); return 0; MIH_CATCH(-1) }
 void mih_mesh_counts(void *m, uint32_t *nv, uint32_t *nf, int *has_normals) {
-    const Mesh &me = *((Box<Mesh> *) m)->p; *nv = me.vertex_count(); *nf = me.face_count(); *has_normals = me.has_vertex_normals() ? 1 : 0;
+    const Mesh &me = *((Box<Mesh> *) m)->p; *nv = me.vertex_count(); *nf = me.face_count();
+    *has_normals = (me.has_vertex_normals() ? 1 : 0) | (me.has_vertex_texcoords() ? 2 : 0);     // bit 1: texture coordinates
+}
+void mih_mesh_copy_texcoords(void *m, float *texcoords) {
+    const Mesh &me = *((Box<Mesh> *) m)->p;
+    if (texcoords && me.has_vertex_texcoords()) std::memcpy(texcoords, me.vertex_texcoords_buffer().data(), me.vertex_texcoords_buffer().size() * 4);
 }
 void mih_mesh_copy(void *m, float *pos, uint32_t *faces, float *normals) {
     const Mesh &me = *((Box<Mesh> *) m)->p;

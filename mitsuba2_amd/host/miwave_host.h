@@ -48,10 +48,12 @@ struct Transform4f {
     bool has_scale() const;
 };
 
+class BitmapTexture;
+
 // ---- Properties (include/mitsuba/core/properties.h) ------------------------------------
 class Properties {
 public:
-    using Value = std::variant<bool, int64_t, float, std::string, Color3f, Transform4f>;
+    using Value = std::variant<bool, int64_t, float, std::string, Color3f, Transform4f, std::shared_ptr<BitmapTexture>>;
     Properties() = default;
     explicit Properties(std::string plugin_name) : m_plugin_name(std::move(plugin_name)) {}
     const std::string &plugin_name() const { return m_plugin_name; }
@@ -62,6 +64,9 @@ public:
     void set_string(const std::string &n, const std::string &v) { m_values[n] = v; }
     void set_color(const std::string &n, const Color3f &v) { m_values[n] = v; }
     void set_transform(const std::string &n, const Transform4f &v) { m_values[n] = v; }
+    // a nested <texture type="bitmap" name=...> object (Properties::set_object / texture<>(), properties.h:307-315)
+    void set_texture(const std::string &n, std::shared_ptr<BitmapTexture> t) { m_values[n] = std::move(t); }
+    std::shared_ptr<BitmapTexture> bitmap(const std::string &n) const;     // nullptr: a constant (or absent)
     bool bool_(const std::string &n) const;
     bool bool_(const std::string &n, bool def) const;
     int64_t int_(const std::string &n) const;
@@ -85,6 +90,30 @@ private:
     std::string m_plugin_name;
     std::map<std::string, Value> m_values;
 };
+
+// ---- Bitmap texture (src/textures/bitmap.cpp) -------------------------------------------------------
+// Properties: filter_type ("bilinear" | "nearest"), wrap_mode ("repeat" | "mirror" | "clamp"), raw (false),
+// to_uv (identity), filename (a PFM file; other image formats are out of scope — hand the pixels over with
+// set_bitmap instead). Values are linear floats: 1 channel (Y) or 3 (RGB). What the constructor of the reference
+// does with them happens in record(): in the scalar_spectral build an RGB image that is not `raw` is replaced by
+// its per-texel sRGB-model coefficients (bitmap.cpp:156-165).
+class BitmapTexture {
+public:
+    explicit BitmapTexture(const Properties &props);
+    void set_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float *data);
+    uint32_t width() const { return m_width; }
+    uint32_t height() const { return m_height; }
+    uint32_t channels() const { return m_channels; }
+    Color3f mean() const;                                      // per-channel mean (Texture::mean() is its luminance)
+    mi_bitmap record() const;                                  // pointers stay valid while this object lives
+private:
+    void finish();
+    uint32_t m_width = 0, m_height = 0, m_channels = 0, m_filter = MI_BITMAP_BILINEAR, m_wrap = MI_BITMAP_REPEAT;
+    bool m_raw = false; Transform4f m_to_uv; std::string m_name;
+    std::vector<float> m_data, m_device_data;
+};
+// Bitmap(path) for Portable Float Maps ("PF" = RGB, "Pf" = Y; bottom-to-top scanlines; src/libcore/bitmap.cpp read_pfm)
+void read_pfm(const std::string &path, uint32_t &width, uint32_t &height, uint32_t &channels, std::vector<float> &data);
 
 // ---- sRGB -> spectrum upsampling model (src/librender/srgb.cpp:14-42, ext/rgb2spec/rgb2spec.c) ----
 // scalar_spectral only. The coefficient table `data/srgb.coeff` is an artefact of the reference's
@@ -224,13 +253,18 @@ public:
     std::pair<BSDFSample3f, Color3f> sample(const Vector3f &wi, float sample1, const std::array<float, 2> &sample2) const;
     Color3f eval(const Vector3f &wi, const Vector3f &wo) const;
     float pdf(const Vector3f &wi, const Vector3f &wo) const;
-    const mi_bsdf &record() const { return m_rec; }
+    const mi_bsdf &record() const { return m_rec; }             // bitmap parameters appear as their mean here;
+    // the bitmap bound to texture slot k (nullptr: constant). Scene::build turns it into a MI_TEX_BITMAP record.
+    const std::shared_ptr<BitmapTexture> &bitmap(int k) const { return m_bitmaps[k]; }
     // twosided adapter: the nested back-side BSDF (nullptr: not twosided; == this: same BSDF on both sides)
     const std::shared_ptr<BSDF> &back() const { return m_back; }
     bool twosided() const { return (m_rec.flags & MI_BSDF_FLAG_TWOSIDED) != 0; }
 protected:
+    // m_rec.tex[slot] = props.texture_record(...) and remember the bitmap, if the property holds one
+    void bind_texture(int slot, const Properties &props, const std::string &name, float def, bool unbounded);
     mi_bsdf m_rec{};
     std::shared_ptr<BSDF> m_back;
+    std::shared_ptr<BitmapTexture> m_bitmaps[3];
 };
 class SmoothDiffuse final : public BSDF { public: explicit SmoothDiffuse(const Properties &props); };        // diffuse.cpp:72-76
 class SmoothDielectric final : public BSDF { public: explicit SmoothDielectric(const Properties &props); };  // dielectric.cpp:174-199
@@ -274,13 +308,17 @@ private:
 class Mesh {                                                  // include/mitsuba/render/mesh.h
 public:
     Mesh(std::string name, std::vector<float> vertex_positions, std::vector<uint32_t> faces,
-         std::vector<float> vertex_normals = {});
+         std::vector<float> vertex_normals = {}, std::vector<float> vertex_texcoords = {});
     uint32_t vertex_count() const { return (uint32_t) (m_positions.size() / 3); }
     uint32_t face_count() const { return (uint32_t) (m_faces.size() / 3); }
     uint32_t primitive_count() const { return face_count(); }
     bool has_vertex_normals() const { return !m_normals.empty(); }
     const std::vector<float> &vertex_positions_buffer() const { return m_positions; }
     const std::vector<float> &vertex_normals_buffer() const { return m_normals; }
+    // Mesh::has_vertex_texcoords / vertex_texcoord (mesh.h:100-104): 2 floats per vertex; they parameterise si.uv
+    // and the tangents of the shading frame (mesh.cpp:492-511)
+    bool has_vertex_texcoords() const { return !m_texcoords.empty(); }
+    const std::vector<float> &vertex_texcoords_buffer() const { return m_texcoords; }
     const std::vector<uint32_t> &faces_buffer() const { return m_faces; }
     // Mesh::recompute_vertex_normals (src/librender/mesh.cpp:200-246): angle-weighted face normals
     // (Thuermer & Wuethrich 1998); creates the normal buffer if the mesh has none
@@ -300,12 +338,9 @@ public:
     const mi_sphere &sphere_record() const { return m_sphere_rec; }
 private:
     friend std::shared_ptr<Mesh> make_rectangle(const Properties &props);
-// The `sphere` shape plugin (src/shapes/sphere.cpp:96-131): properties center (0), radius (1), to_world (identity:
-// rotation, translation, uniform scale only), flip_normals (false). An analytic primitive.
-std::shared_ptr<Mesh> make_sphere(const Properties &props);
     friend std::shared_ptr<Mesh> make_sphere(const Properties &props);
     std::string m_name;
-    std::vector<float> m_positions, m_normals;
+    std::vector<float> m_positions, m_normals, m_texcoords;
     std::vector<uint32_t> m_faces;
     std::shared_ptr<BSDF> m_bsdf;
     std::shared_ptr<AreaLight> m_emitter;
@@ -315,6 +350,9 @@ std::shared_ptr<Mesh> make_sphere(const Properties &props);
 // The `rectangle` shape plugin (src/shapes/rectangle.cpp:76-84): [-1, 1]^2 in z = 0, normal +z, properties
 // to_world (identity) and flip_normals (false). An analytic primitive — not two triangles.
 std::shared_ptr<Mesh> make_rectangle(const Properties &props);
+// The `sphere` shape plugin (src/shapes/sphere.cpp:96-131): properties center (0), radius (1), to_world (identity:
+// rotation, translation, uniform scale only), flip_normals (false). An analytic primitive.
+std::shared_ptr<Mesh> make_sphere(const Properties &props);
 
 // Mesh file loaders: the `obj` and `ply` shape plugins.
 // Properties: filename, face_normals (false), to_world (identity); obj: flip_tex_coords (true).
@@ -347,12 +385,13 @@ public:
     const mi_scene_desc &desc() const { return m_desc; }
 private:
     std::vector<std::shared_ptr<Mesh>> m_shapes;
-    std::vector<float> m_positions, m_normals;
+    std::vector<float> m_positions, m_normals, m_texcoords;
     std::vector<uint32_t> m_faces;
     std::vector<mi_shape> m_shape_recs;
     std::vector<mi_bsdf> m_bsdf_recs;
     std::vector<mi_emitter> m_emitters;
     std::vector<mi_rectangle> m_rect_recs; std::vector<mi_sphere> m_sphere_recs;
+    std::vector<mi_bitmap> m_bitmap_recs; std::vector<std::shared_ptr<BitmapTexture>> m_bitmap_objs;
     std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;

@@ -49,6 +49,7 @@
 #include "../mitsuba2_amd/csrc/miw/film.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
 #include "../mitsuba2_amd/csrc/rect_build.h"
+#include "../mitsuba2_amd/csrc/texture_build.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"     // scene_pad_unit only: the oracle has no acceleration structure
 
 using namespace miw;
@@ -73,6 +74,8 @@ struct OScene {
     std::vector<Tri> tris;              // face order == global primitive id; pad = k + 1: the slot of analytic rectangle k
     std::vector<AnalyticRec> rects;         // analytic rectangles (src/shapes/rectangle.cpp)
     std::vector<float> tri_vn;          // 9 per face or empty
+    std::vector<float> tri_uv;          // 6 per face (Mesh::vertex_texcoord of its three vertices) or empty
+    std::vector<BitmapRec> bitmaps;     // bitmap textures (data = the caller's arrays)
     std::vector<ShapeRec> shapes;
     std::vector<BsdfRec> bsdfs;
     std::vector<EmitterRec> emitters;
@@ -89,11 +92,12 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         const mi_shape &sh = s->shapes[i];
         int32_t emitter_id = sh.emitter;            // Scene::m_emitters order: the envmap sits at envmap->emitter_index
         if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
-        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & 1u, 0 };
+        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & (SHAPE_HAS_NORMALS | SHAPE_HAS_TEXCOORDS), 0 };
         any_normals = any_normals || (sh.flags & 1u);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris[f].shape = i;
     }
     if (any_normals) o.tri_vn.assign((size_t) s->face_count * 9, 0.f);
+    if (!build_face_texcoords(s, o.tri_uv)) return false;
     o.rects.clear();
     for (uint32_t k = 0; k < s->rectangle_count; ++k) {        // Rectangle(props) + update(), rectangle.cpp:76-96
         const mi_rectangle &q = s->rectangles[k];
@@ -121,21 +125,10 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
-        std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
-        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags; o.bsdfs[i].back = s->bsdfs[i].back;
-        std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
-#if MIW_SPECTRAL
-        std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
-#else
-        {   // legacy RGB layout of params[] (include/miwave.h) -> texture records
-            const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };
-            for (int k = 0; k < 3; ++k) {
-                o.bsdfs[i].tex[k].type = TEX_RGB;
-                if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
-            }
-        }
-#endif
+        int slot = 0;
+        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, o.bsdfs[i], &slot)) return false;
     }
+    { uint32_t bad = 0; if (build_bitmap_table(s, o.bitmaps, &bad)) return false; }
     // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:55-87)
     bool emit_normals = false;
     auto push_env = [&]() { EmitterRec r; std::memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; o.emitters.push_back(r); };
@@ -197,6 +190,8 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     v.nodes = nullptr; v.node_count = 0;
     v.tris = o.tris.data(); v.tri_count = (uint32_t) o.tris.size();
     v.tri_vn = o.tri_vn.empty() ? nullptr : o.tri_vn.data();
+    v.tri_uv = o.tri_uv.empty() ? nullptr : o.tri_uv.data();
+    v.bitmaps = o.bitmaps.empty() ? nullptr : o.bitmaps.data();
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
@@ -240,7 +235,8 @@ bool ray_intersect(const OScene &sc, const Ray &ray, SurfaceInteraction &si) {
         else compute_surface_interaction_rect(a, h.t, h.u, h.v, ray.o, ray.d, si);                     // rectangle.cpp:175-208
     } else {
         const float *vn = (sc.shapes[tr.shape].flags & 1u) ? &sc.tri_vn[(size_t) h.prim * 9] : nullptr;
-        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, h.t, h.u, h.v, ray.d, si);
+        const float *tc = (sc.shapes[tr.shape].flags & SHAPE_HAS_TEXCOORDS) ? &sc.tri_uv[(size_t) h.prim * 6] : nullptr;   // mesh.cpp:492-511
+        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.t, h.u, h.v, ray.d, si);
     }
     si.shape = tr.shape; si.prim = h.prim;
     return true;
@@ -311,7 +307,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
             }
             active_e = active_e && ds.pdf != 0.f;        // :160
             V3 wo = to_local(si.sh, ds.d);               // :163
-            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, wl);   // :164
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps));   // :164
             float bpdf = bsdf_side_pdf(bsdf, si.wi, wo);      // :168
             float mis = mis_weight(ds.pdf, bpdf);        // :170 (ds.delta is false for area lights)
             if (active_e)
@@ -322,7 +318,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
         float sample1 = sampler.next_1d();
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, wl);
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps));
 
         throughput = throughput * bsdf_val;              // :181
         active = active && !all_zero(throughput);        // :182
@@ -406,7 +402,7 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
             }
             if (ds.pdf == 0.f) continue;                 // :143-145
             V3 wo = to_local(si.sh, ds.d);               // :148
-            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, wl);   // :150
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps));   // :150
             float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo);       // :155
             float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158
             result = result + mis * bsdf_val * emitter_val;        // :159
@@ -417,7 +413,7 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
         float sample1 = sampler.next_1d();               // :166-167, Clang's argument order
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, wl);
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps));
         if (all_zero(bsdf_val)) continue;                // :170: active_b
         Ray next;                                        // :173-174, interaction.h:58-61
         next.o = si.p; next.d = to_world(si.sh, bs.wo);

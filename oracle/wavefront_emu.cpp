@@ -20,6 +20,7 @@
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
 #include "../mitsuba2_amd/csrc/rect_build.h"
+#include "../mitsuba2_amd/csrc/texture_build.h"
 
 using namespace miw;
 
@@ -28,7 +29,7 @@ struct EmuScene {
     std::vector<Tri> tris_in; std::vector<float> vn_in;
     std::vector<ShapeRec> shapes; std::vector<BsdfRec> bsdfs; std::vector<EmitterRec> emitters; std::vector<AnalyticRec> rects;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
-    BvhBuildResult bvh; std::vector<float> vn_leaf;
+    BvhBuildResult bvh; std::vector<float> vn_leaf, tri_uv; std::vector<BitmapRec> bitmaps;
     EnvmapTables env;
     SceneView view{};
 };
@@ -41,7 +42,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         const mi_shape &sh = s->shapes[i];
         int32_t emitter_id = sh.emitter;
         if (emitter_id >= 0 && s->envmap && (uint32_t) emitter_id >= s->envmap->emitter_index) emitter_id += 1;
-        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & 1u, 0 };
+        o.shapes[i] = ShapeRec{ sh.bsdf, emitter_id, sh.flags & (SHAPE_HAS_NORMALS | SHAPE_HAS_TEXCOORDS), 0 };
         any_normals = any_normals || (sh.flags & 1u);
         for (uint32_t f = sh.first_face; f < sh.first_face + sh.face_count; ++f) o.tris_in[f].shape = i;
     }
@@ -79,21 +80,10 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     }
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
-        std::memset(&o.bsdfs[i], 0, sizeof o.bsdfs[i]);
-        o.bsdfs[i].type = s->bsdfs[i].type; o.bsdfs[i].flags = s->bsdfs[i].flags; o.bsdfs[i].back = s->bsdfs[i].back;
-        std::memcpy(o.bsdfs[i].p, s->bsdfs[i].params, sizeof o.bsdfs[i].p);
-#if MIW_SPECTRAL
-        std::memcpy(o.bsdfs[i].tex, s->bsdfs[i].tex, sizeof o.bsdfs[i].tex);
-#else
-        {
-            const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };
-            for (int k = 0; k < 3; ++k) {
-                o.bsdfs[i].tex[k].type = TEX_RGB;
-                if (off[s->bsdfs[i].type][k] >= 0) std::memcpy(o.bsdfs[i].tex[k].v, s->bsdfs[i].params + off[s->bsdfs[i].type][k], 12);
-            }
-        }
-#endif
+        int slot = 0;
+        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, o.bsdfs[i], &slot)) return false;
     }
+    { uint32_t bad = 0; if (build_bitmap_table(s, o.bitmaps, &bad)) return false; }
     bool emit_normals = false;
     auto push_env = [&]() { EmitterRec r; std::memset(&r, 0, sizeof r); r.type = EMITTER_ENVMAP; r.shape = 0xffffffffu; o.emitters.push_back(r); };
     for (uint32_t i = 0; i < s->emitter_count; ++i) {
@@ -145,6 +135,9 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.nodes = o.bvh.nodes.data(); v.node_count = (uint32_t) o.bvh.nodes.size();
     v.tris = o.bvh.tris.data(); v.tri_count = (uint32_t) o.bvh.tris.size();
     v.tri_vn = o.vn_leaf.empty() ? nullptr : o.vn_leaf.data();
+    if (!build_face_texcoords(s, o.tri_uv)) return false;
+    v.tri_uv = o.tri_uv.empty() ? nullptr : o.tri_uv.data();
+    v.bitmaps = o.bitmaps.empty() ? nullptr : o.bitmaps.data();
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
