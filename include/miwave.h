@@ -314,8 +314,10 @@ enum {
     MI_EVAL_ENVMAP = 9,           /* in: d.xyz (world), ref.xyz, u1, u2 (8)
                                      out: eval.rgb, pdf_direction, sample{d.xyz, dist, pdf, spec.rgb} (12)          */
     MI_EVAL_INVTRIG = 10,         /* in: y, x                            out: atan2(y,x), acos(x), asin(x) (3)       */
-    MI_EVAL_SPECTRUM = 11         /* spectral library only. in: wavelength sample, c0,c1,c2, d65 scale (5)
+    MI_EVAL_SPECTRUM = 11,        /* spectral library only. in: wavelength sample, c0,c1,c2, d65 scale (5)
                                      out: wavelengths[4], weights[4], srgb[4], srgb_d65[4], xyz of weight*srgb_d65 (19) */
+    MI_EVAL_TEXTURE = 12          /* BitmapTexture::eval at si.uv. in: u, v, (float) bitmap index, wavelength sample (4)
+                                     out: the texture's Spectrum (3 / 4)                                             */
 };
 mi_status mi_eval(mi_ctx *ctx, int32_t op, const mi_render_cfg *cfg,
                   const float *in, int32_t in_stride, float *out, int32_t out_stride, uint64_t n);

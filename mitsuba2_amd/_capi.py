@@ -104,7 +104,7 @@ class mi_counters(C.Structure):
 MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
 MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
-               FP_SEMANTICS=7, SPECIAL=8, ENVMAP=9, INVTRIG=10)
+               FP_SEMANTICS=7, SPECIAL=8, ENVMAP=9, INVTRIG=10, SPECTRUM=11, TEXTURE=12)
 MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (2, 8), 6: (5, 14), 7: (3, 8), 8: (1, 4), 9: (8, 12), 10: (2, 3)}
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
@@ -124,6 +124,8 @@ def eval_strides(op, channels=3):
         return 5 + extra, 11 + channels
     if op == 11:
         return 5, 19
+    if op == 12:
+        return 4, channels
     return MI_EVAL_STRIDES[op]
 
 

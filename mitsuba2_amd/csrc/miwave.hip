@@ -1131,6 +1131,17 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
         } break;
 #endif
         case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
+        case MI_EVAL_TEXTURE: {
+            if (!sc.bitmaps) break;
+            Wavelengths wl;
+#if MIW_SPECTRAL
+            Spec wt; sample_wavelengths(a[3], wl, wt);
+#endif
+            TexRec t; t.type = TEX_BITMAP; t.v[0] = a[2]; t.v[1] = t.v[2] = t.v[3] = 0.f;
+            Spec r = tex_eval(t, TexCtx(wl, v2(a[0], a[1]), sc.bitmaps));
+            const float *rf = reinterpret_cast<const float *>(&r);
+            for (int k = 0; k < MIW_SPEC_N; ++k) o[k] = rf[k];
+        } break;
     }
 }
 
@@ -2063,7 +2074,7 @@ mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *
         mi_status st = fill_params(c, cfg, P);
         if (st != MI_OK) return st;
     }
-    if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE || op == MI_EVAL_ENVMAP) && !c->have_bvh)
+    if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE || op == MI_EVAL_ENVMAP || op == MI_EVAL_TEXTURE) && !c->have_bvh)
         return fail(c, MI_ERR_STATE, "mi_eval: scene required");
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> din, dout;

@@ -925,6 +925,17 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
             } break;
 #endif
             case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
+            case MI_EVAL_TEXTURE: {
+                if (!have_scene || !sc.view.bitmaps) return -1;
+                Wavelengths wl;
+    #if MIW_SPECTRAL
+                Spec wt; sample_wavelengths(a[3], wl, wt);
+    #endif
+                TexRec t; t.type = TEX_BITMAP; t.v[0] = a[2]; t.v[1] = t.v[2] = t.v[3] = 0.f;
+                Spec r = tex_eval(t, TexCtx(wl, v2(a[0], a[1]), sc.view.bitmaps));
+                const float *rf = reinterpret_cast<const float *>(&r);
+                for (int k = 0; k < MIW_SPEC_N; ++k) o[k] = rf[k];
+            } break;
             default: return -1;
         }
     }
