@@ -915,8 +915,16 @@ AreaLight::AreaLight(const Properties &props) {
 EnvironmentMapEmitter::EnvironmentMapEmitter(const Properties &props) {
     m_scale = props.float_("scale", 1.f);                      // envmap.cpp:124
     m_to_world = props.transform("to_world", Transform4f());
-    if (props.has_property("filename"))
-        Throw("envmap: image file I/O is outside this layer; pass the linear RGBA float pixels with set_bitmap()");
+    if (props.has_property("filename")) {                      // envmap.cpp:66-75: Bitmap(file).convert(RGBA, Float32); PFM files only here
+        uint32_t w, h, c; std::vector<float> px;
+        read_pfm(props.string("filename"), w, h, c, px);
+        std::vector<float> rgba((size_t) w * h * 4);
+        for (size_t i = 0; i < (size_t) w * h; ++i) {
+            for (uint32_t k = 0; k < 3; ++k) rgba[4 * i + k] = px[i * c + (c == 3 ? k : 0)];
+            rgba[4 * i + 3] = 1.f;
+        }
+        set_bitmap(w, h, rgba.data());
+    }
 }
 void EnvironmentMapEmitter::set_bitmap(uint32_t width, uint32_t height, const float *rgba) {
     if (width < 2 || height < 2 || !rgba) Throw("envmap: the bitmap must be at least 2x2");
@@ -1622,6 +1630,7 @@ struct XmlParser {
 struct XmlCtx {
     std::map<std::string, std::string> params;
     std::map<std::string, std::shared_ptr<BSDF>> bsdfs;
+    std::map<std::string, std::shared_ptr<BitmapTexture>> textures;
     std::string base_dir;
     std::string subst(const std::string &v) const {           // $name parameter substitution (xml.cpp:150-180)
         std::string out; size_t i = 0;
@@ -1701,6 +1710,17 @@ std::shared_ptr<BSDF> make_bsdf(const Properties &p) {
     if (t == "roughdielectric") return std::make_shared<RoughDielectric>(p);
     Throw("Plugin \"" + t + "\" not found!");
 }
+std::string resolve(const XmlCtx &cx, const std::string &f) { return (!f.empty() && f[0] == '/') ? f : cx.base_dir + "/" + f; }
+std::shared_ptr<BitmapTexture> parse_texture(XmlCtx &cx, const XmlNode &n) {
+    Properties p(cx.get(n, "type"));
+    if (p.plugin_name() != "bitmap") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
+    auto objs = parse_properties(cx, n, p);
+    if (!objs.empty()) Throw("Error while loading XML: unexpected <" + objs[0]->tag + "> inside <texture>");
+    p.set_string("filename", resolve(cx, p.string("filename")));
+    auto t = std::make_shared<BitmapTexture>(p);
+    if (n.attr.count("id")) cx.textures[cx.get(n, "id")] = t;
+    return t;
+}
 std::shared_ptr<BSDF> parse_bsdf(XmlCtx &cx, const XmlNode &n) {
     Properties p(cx.get(n, "type"));
     auto objs = parse_properties(cx, n, p);
@@ -1718,13 +1738,19 @@ std::shared_ptr<BSDF> parse_bsdf(XmlCtx &cx, const XmlNode &n) {
         if (nested.size() > 2) Throw("At most two nested BSDFs can be specified!");
         b = std::make_shared<TwoSidedBRDF>(nested.empty() ? nullptr : nested[0], nested.size() == 2 ? nested[1] : nullptr);
     } else {
-        if (!objs.empty()) Throw("Error while loading XML: unexpected <" + objs[0]->tag + "> inside <bsdf>");
+        for (const XmlNode *c : objs) {                        // <texture type="bitmap" name=...> / <ref id=... name=...>
+            if (c->tag == "texture") p.set_texture(cx.get(*c, "name"), parse_texture(cx, *c));
+            else if (c->tag == "ref" && c->attr.count("name")) {
+                auto it = cx.textures.find(cx.get(*c, "id"));
+                if (it == cx.textures.end()) Throw("Error while loading XML: reference to unknown object \"" + cx.get(*c, "id") + "\"!");
+                p.set_texture(cx.get(*c, "name"), it->second);
+            } else Throw("Error while loading XML: unexpected <" + c->tag + "> inside <bsdf>");
+        }
         b = make_bsdf(p);
     }
     if (n.attr.count("id")) cx.bsdfs[cx.get(n, "id")] = b;
     return b;
 }
-std::string resolve(const XmlCtx &cx, const std::string &f) { return (!f.empty() && f[0] == '/') ? f : cx.base_dir + "/" + f; }
 }
 
 LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, std::string> &params, const std::string &base_dir) {
@@ -1737,6 +1763,7 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
     for (const XmlNode &n : root.children) {
         if (n.tag == "default") { std::string k = cx.get(n, "name"); if (!cx.params.count(k)) cx.params[k] = cx.get(n, "value"); }
         else if (n.tag == "bsdf") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <bsdf> needs an id"); parse_bsdf(cx, n); }
+        else if (n.tag == "texture") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <texture> needs an id"); parse_texture(cx, n); }
         else if (n.tag == "integrator") {
             Properties p(cx.get(n, "type"));
             if (p.plugin_name() != "path" && p.plugin_name() != "direct") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
@@ -1773,7 +1800,8 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
             Properties p(cx.get(n, "type"));
             if (p.plugin_name() != "envmap") Throw("Error while loading XML: only <emitter type=\"envmap\"> may appear at the top level (area lights belong to a shape)");
             parse_properties(cx, n, p);
-            Throw("envmap: image file I/O is outside this layer; build the scene through the host classes and EnvironmentMapEmitter::set_bitmap()");
+            p.set_string("filename", resolve(cx, p.string("filename")));
+            out.scene->add_emitter(std::make_shared<EnvironmentMapEmitter>(p));   // its place among the shapes fixes the emitter order
         } else if (n.tag == "shape") {
             Properties p(cx.get(n, "type"));
             auto objs = parse_properties(cx, n, p);

@@ -295,11 +295,12 @@ def test_device_rejects_bad_texture_tables(native, dev):
     with pytest.raises(RuntimeError, match="bitmap index out of range"):
         dev.upload(p)
     d.bsdfs[0].tex[0].v[0] = 0.0
-    keep = d.vertex_texcoords
+    import ctypes
+    keep = ctypes.cast(d.vertex_texcoords, ctypes.c_void_p).value          # (a pointer field read from a struct aliases it)
     d.vertex_texcoords = None
     with pytest.raises(RuntimeError, match="HAS_TEXCOORDS without vertex_texcoords"):
         dev.upload(p)
-    d.vertex_texcoords = keep
+    d.vertex_texcoords = ctypes.cast(ctypes.c_void_p(keep), ctypes.POINTER(ctypes.c_float))
     d.bitmaps[0].channels = 2
     with pytest.raises(RuntimeError, match="Unsupported channel count"):
         dev.upload(p)

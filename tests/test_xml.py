@@ -109,3 +109,43 @@ def test_xml_errors(native, tmp_path):
         native.load_string('<scene version="2.0.0"><shape type="rectangle"><boolean name="flip_normals" value="yes"/></shape></scene>')
     scene, sensor, integ = native.load_string('<scene version="2.0.0"><shape type="rectangle"/></scene>')
     assert sensor is None and integ.render_job is not None
+
+
+def test_xml_bitmap_texture_and_envmap_files(native, oracle, tmp_path):
+    """<texture type="bitmap"> nested under a BSDF parameter (or shared through <ref id name>) and a top-level
+    <emitter type="envmap">, both reading Portable Float Maps relative to the scene file."""
+    rng = np.random.default_rng(0)
+    tex = (rng.random((4, 6, 3)) * .8 + .1).astype(np.float32)
+    sky = (rng.random((8, 16, 3)) * 2).astype(np.float32)
+    for name, arr in (("tex.pfm", tex), ("sky.pfm", sky)):
+        with open(tmp_path / name, "wb") as f:
+            f.write(("PF\n%d %d\n-1.0\n" % (arr.shape[1], arr.shape[0])).encode()); f.write(arr[::-1].astype("<f4").tobytes())
+    (tmp_path / "quad.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 3/3 2/2\nf 1/1 4/4 3/3\n")
+    (tmp_path / "scene.xml").write_text("""<scene version="2.0.0">
+      <texture type="bitmap" id="shared"><string name="filename" value="tex.pfm"/><string name="wrap_mode" value="mirror"/></texture>
+      <sensor type="perspective"><float name="fov" value="50"/>
+        <transform name="to_world"><lookat origin="0, 2, 2.5" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <film type="hdrfilm"><integer name="width" value="24"/><integer name="height" value="16"/></film>
+        <sampler type="independent"><integer name="sample_count" value="2"/></sampler></sensor>
+      <emitter type="envmap"><string name="filename" value="sky.pfm"/><float name="scale" value="0.5"/></emitter>
+      <shape type="obj"><string name="filename" value="quad.obj"/>
+        <bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="tex.pfm"/>
+          <string name="filter_type" value="nearest"/><transform name="to_uv"><scale value="3"/></transform></texture></bsdf></shape>
+      <shape type="sphere"><point name="center" x="0" y="0.4" z="0"/><float name="radius" value="0.4"/>
+        <bsdf type="roughconductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/>
+          <ref id="shared" name="specular_reflectance"/></bsdf></shape>
+    </scene>""")
+    scene, sensor, integ = native.load_file(str(tmp_path / "scene.xml"))
+    scene.build(-1)
+    d = scene.desc().contents
+    assert d.bitmap_count == 2 and d.envmap and d.envmap.contents.width == 16 and d.envmap.contents.scale == 0.5
+    assert (d.bitmaps[0].filter_type, d.bitmaps[0].to_uv[0], d.bitmaps[1].wrap_mode) == (0, 3.0, 1)
+    assert np.allclose(np.ctypeslib.as_array(d.bitmaps[0].data, (4, 6, 3)), tex)
+    assert np.allclose(np.ctypeslib.as_array(d.envmap.contents.rgba, (8, 16, 4))[..., :3], sky)
+    job = integ.render_job(sensor)
+    o32, _, st = oracle.render(scene.desc(), job, threads=2)
+    e64, e32, est = oracle.emu_render(scene.desc(), job)
+    assert np.array_equal(e32, o32) and o32[..., 1].min() > 0
+    with pytest.raises(RuntimeError, match="file not found"):
+        native.load_string('<scene version="2.0.0"><shape type="rectangle"><bsdf type="diffuse"><texture type="bitmap" name="reflectance">'
+                           '<string name="filename" value="nope.pfm"/></texture></bsdf></shape></scene>')
