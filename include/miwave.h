@@ -231,7 +231,15 @@ typedef struct {
     int32_t integrator;
     uint32_t emitter_samples, bsdf_samples;
     int32_t hide_emitters;
+    /* MomentIntegrator (src/integrators/moment.cpp) around the integrator above, scalar_rgb library: its film carries
+     * X Y Z A W, nested.X nested.Y nested.Z and their squares m2_nested.* (:44-53, :83-88). Every channel is the
+     * same filtered sum over the same samples, so the host renders the job twice with the same seeds:
+     *   MI_MOMENT_VALUES   this call delivers X Y Z A W (nested.XYZ are the same numbers),
+     *   MI_MOMENT_SQUARES  this call delivers X^2 Y^2 Z^2 A W (the m2_ channels);
+     * in both a sample is dropped when any of the eleven values fails ImageBlock::put's test (imageblock.cpp:85-109). */
+    int32_t moment_pass;
 } mi_render_cfg;
+enum { MI_MOMENT_OFF = 0, MI_MOMENT_VALUES = 1, MI_MOMENT_SQUARES = 2 };
 enum { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_DIRECT = 1 };
 
 typedef struct {

@@ -85,7 +85,7 @@ class mi_render_cfg(C.Structure):
                 ("profile", C.c_int32),
                 ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32), ("accumulate", C.c_int32),
                 ("integrator", C.c_int32), ("emitter_samples", C.c_uint32), ("bsdf_samples", C.c_uint32),
-                ("hide_emitters", C.c_int32)]
+                ("hide_emitters", C.c_int32), ("moment_pass", C.c_int32)]
 
 
 class mi_counters(C.Structure):
@@ -202,6 +202,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_sensor_create": (vp, [vp, vp, vp]), "mih_sensor_destroy": (None, [vp]),
         "mih_sensor_sample_ray": (i32, [vp, f, f, c_float_p]), "mih_sensor_x_fov": (f, [vp]),
         "mih_integrator_create": (vp, [vp]), "mih_integrator_destroy": (None, [vp]),
+        "mih_integrator_create_moment": (vp, [vp, vp, cp]), "mih_integrator_aov_names": (C.c_int, [vp, C.c_char_p, u32]),
         "mih_integrator_set_shard": (None, [vp, u32, u32]), "mih_integrator_set_profile": (None, [vp, i32]),
         "mih_integrator_set_plan": (None, [vp, i32]),
         "mih_integrator_cancel": (None, [vp]), "mih_integrator_render": (i32, [vp, vp, vp]),

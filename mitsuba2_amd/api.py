@@ -540,6 +540,13 @@ class SamplingIntegrator:
         host_lib().mih_integrator_counters(self.h, C.byref(c))
         return c
 
+    def aov_names(self):
+        buf = C.create_string_buffer(1024)
+        n = host_lib().mih_integrator_aov_names(self.h, buf, 1024)
+        if n < 0:
+            raise RuntimeError(_err())
+        return [x for x in buf.value.decode().split(",") if x]
+
     def pass_count(self, sensor):
         """sample_count / samples_per_pass (integrator.cpp:75-86)"""
         n = host_lib().mih_integrator_pass_count(self.h, sensor.h)
@@ -569,6 +576,25 @@ class PathIntegrator(SamplingIntegrator):
 class DirectIntegrator(SamplingIntegrator):
     """src/integrators/direct.cpp: shading_samples | emitter_samples + bsdf_samples, hide_emitters"""
     plugin = "direct"
+
+
+class MomentIntegrator(SamplingIntegrator):
+    """src/integrators/moment.cpp around one nested integrator (scalar_rgb): render() fills a film with the channels
+    X Y Z A W <name>.X <name>.Y <name>.Z m2_<name>.X m2_<name>.Y m2_<name>.Z (Film.data(11)). Through the raw C ABI
+    the two halves are two mi_render calls: render_job() is the nested integrator's job, with cfg.moment_pass = 1 / 2."""
+    plugin = "moment"
+
+    def __init__(self, nested, name="integrator", **kw):
+        self._p = Properties("moment", **kw)
+        self.nested = nested
+        self.h = host_lib().mih_integrator_create_moment(self._p.h, nested.h, name.encode())
+        if not self.h:
+            raise RuntimeError(_err())
+
+    def render_job(self, sensor, n_threads=1, capacity=1 << 16, pass_index=0, moment_pass=1):
+        job = self.nested.render_job(sensor, n_threads, capacity, pass_index)
+        job.cfg.moment_pass = moment_pass
+        return job
 
 
 def spiral(w, h, block_size, offset=(0, 0)):

@@ -77,6 +77,7 @@ struct RenderParams {
     uint32_t n_lanes;
     uint32_t integrator;             // INTEG_*
     DirectRec direct;
+    uint32_t moment_pass;            // moment.cpp around the integrator: 0 off, 1 values, 2 squares (include/miwave.h)
 };
 
 // per-launch device counters (mi_get_counters)
@@ -127,13 +128,19 @@ MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L
 // `sink(pixel, sample_idx, position_sample, aovs)` stands for block->put(position_sample, aovs), :285
 template <typename Sink>
 MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L, Sink sink) {
-    (void) P;
 #if MIW_SPECTRAL
     V3 xyz = spectrum_to_xyz(L.ray_weight * L.res, L.wl);   // :266-271
 #else
     V3 xyz = srgb_to_xyz(L.res);                         // :272-273 (ray_weight == 1 in RGB)
 #endif
     float aovs[5] = { xyz.x, xyz.y, xyz.z, (L.flags & LF_VALID_RAY) ? 1.f : 0.f, 1.f };
+    if (P.moment_pass) {                                 // moment.cpp:83-88: nested.XYZ and their squares ride along
+        const float sq[3] = { sqr(xyz.x), sqr(xyz.y), sqr(xyz.z) };
+        bool ok = true;                                  // ImageBlock::put tests all channels of the sample together
+        for (int k = 0; k < 3; ++k) ok = ok && aovs[k] >= -1e-5f && isfinite_(aovs[k]) && isfinite_(sq[k]);
+        if (P.moment_pass == 2u) { aovs[0] = sq[0]; aovs[1] = sq[1]; aovs[2] = sq[2]; }
+        if (!ok) aovs[0] = __builtin_nanf("");
+    }
     sink(pixel, L.sample_idx, L.pos, aovs);
     L.sample_idx++;                                      // :287
 }

@@ -1682,6 +1682,11 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
         P.direct.frac_bsdf = (float) nb / (float) (ne + nb); P.direct.frac_lum = (float) ne / (float) (ne + nb);
     } else if (cfg->integrator != MI_INTEGRATOR_PATH)
         return fail(c, MI_ERR_INVALID, "render: unknown integrator %d", cfg->integrator);
+    if (cfg->moment_pass < MI_MOMENT_OFF || cfg->moment_pass > MI_MOMENT_SQUARES) return fail(c, MI_ERR_INVALID, "render: moment_pass must be 0, 1 or 2");
+#if MIW_SPECTRAL
+    if (cfg->moment_pass) return fail(c, MI_ERR_INVALID, "render: the moment integrator is provided by the scalar_rgb library only");
+#endif
+    P.moment_pass = (uint32_t) cfg->moment_pass;
     return MI_OK;
 }
 

@@ -359,8 +359,9 @@ void Film::prepare(const std::vector<std::string> &channels) {
 std::vector<float> Film::bitmap_rgb() const {
     size_t n = (size_t) m_crop_size[0] * m_crop_size[1];
     std::vector<float> rgb(n * 3);
+    const size_t stride = std::max<size_t>(m_channels.size(), 5);      // X Y Z A W first; AOV channels (moment) behind them
     for (size_t i = 0; i < n; ++i) {
-        const float *p = &m_storage[i * 5];
+        const float *p = &m_storage[i * stride];
         float inv_w = p[4] != 0.f ? 1.f / p[4] : 0.f;         // struct.cpp:1734-1745 weight normalisation
         miw::V3 c = miw::xyz_to_srgb(miw::v3(p[0] * inv_w, p[1] * inv_w, p[2] * inv_w));
         rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
@@ -440,7 +441,7 @@ std::string Film::develop() const {
             for (int x = 0; x < W; ++x) {
                 const size_t i = (size_t) y * W + x;
                 float v;
-                if (ch == 'A') { const float *p = &m_storage[i * 5]; v = p[4] != 0.f ? p[3] / p[4] : 0.f; }
+                if (ch == 'A') { const float *p = &m_storage[i * std::max<size_t>(m_channels.size(), 5)]; v = p[4] != 0.f ? p[3] / p[4] : 0.f; }
                 else v = rgb[i * 3 + (ch == 'R' ? 0 : ch == 'G' ? 1 : 2)];
                 unsigned char *dst = &line[((size_t) c * W + x) * bpc];
                 if (half) { uint16_t h = float_to_half(v); std::memcpy(dst, &h, 2); } else std::memcpy(dst, &v, 4);
@@ -1447,6 +1448,7 @@ void DirectIntegrator::fill_integrator(mi_render_cfg &cfg) const {
     cfg.hide_emitters = m_hide_emitters ? 1 : 0;
 }
 std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props) {
+    if (props.plugin_name() == "moment") Throw("moment: needs a nested integrator (MomentIntegrator(props, nested))");
     if (props.plugin_name() == "path") return std::make_shared<PathIntegrator>(props);
     if (props.plugin_name() == "direct") return std::make_shared<DirectIntegrator>(props);
     Throw("Plugin \"" + props.plugin_name() + "\" not found!");
@@ -1517,18 +1519,15 @@ void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_ren
     cfg.plan = m_plan;
 }
 
-bool SamplingIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
-    if (!scene || !sensor) Throw("render(): null scene or sensor");
-    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
-    Film *film = sensor->film().get();
-    film->prepare({ "X", "Y", "Z", "A", "W" });                // integrator.cpp:67-73
+bool SamplingIntegrator::render_passes(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass) {
     const uint32_t passes = pass_count(sensor);
     mi_counters total{};
     for (uint32_t pass = 0; pass < passes; ++pass) {
         mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
         make_render_cfg(sensor, cfg, block_ids, tiles, 1, pass);
+        cfg.moment_pass = moment_pass;
         m_active_ctx.store(scene->ctx());
-        mi_status st = mi_render(scene->ctx(), &cfg, film->storage().data());
+        mi_status st = mi_render(scene->ctx(), &cfg, film5);
         m_active_ctx.store(nullptr);
         mi_get_counters(scene->ctx(), &m_counters);
         if (pass > 0) {                                        // work counters add up over the passes
@@ -1541,7 +1540,51 @@ bool SamplingIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
     }
     return true;
 }
+bool SamplingIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+    if (!scene || !sensor) Throw("render(): null scene or sensor");
+    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
+    Film *film = sensor->film().get();
+    film->prepare({ "X", "Y", "Z", "A", "W" });                // integrator.cpp:67-73
+    return render_passes(scene, sensor, film->storage().data(), MI_MOMENT_OFF);
+}
 
+// moment.cpp:33-53
+MomentIntegrator::MomentIntegrator(const Properties &props, std::shared_ptr<SamplingIntegrator> nested, std::string nested_name)
+    : SamplingIntegrator(props), m_nested(std::move(nested)), m_name(std::move(nested_name)) {
+    if (!m_nested) Throw("Child objects must be of type 'SamplingIntegrator'!");
+    if (dynamic_cast<MomentIntegrator *>(m_nested.get())) Throw("moment: nested moment integrators are not supported");
+#if MIW_SPECTRAL
+    Throw("moment: provided by the scalar_rgb build of this layer only");
+#endif
+}
+std::vector<std::string> MomentIntegrator::aov_names() const {
+    std::vector<std::string> names = { m_name + ".X", m_name + ".Y", m_name + ".Z" };
+    for (int i = 0; i < 3; ++i) names.push_back("m2_" + names[i]);
+    return names;
+}
+bool MomentIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+    if (!scene || !sensor) Throw("render(): null scene or sensor");
+    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
+    Film *film = sensor->film().get();
+    std::vector<std::string> channels = { "X", "Y", "Z", "A", "W" };
+    for (const std::string &n : aov_names()) channels.push_back(n);
+    film->prepare(channels);
+    auto cs = film->crop_size();
+    const size_t n = (size_t) cs[0] * cs[1];
+    std::vector<float> values(n * 5), squares(n * 5);
+    m_nested->set_shard(m_rank, m_world); m_nested->set_plan(m_plan); m_nested->set_profile(m_profile);
+    bool ok = m_nested->render_passes(scene, sensor, values.data(), MI_MOMENT_VALUES) &&
+              m_nested->render_passes(scene, sensor, squares.data(), MI_MOMENT_SQUARES);
+    m_counters = m_nested->counters();
+    float *out = film->storage().data();
+    for (size_t i = 0; i < n; ++i) {
+        const float *v = &values[i * 5], *q = &squares[i * 5];
+        float *o = out + i * 11;
+        for (int k = 0; k < 5; ++k) o[k] = v[k];
+        for (int k = 0; k < 3; ++k) { o[5 + k] = v[k]; o[8 + k] = q[k]; }
+    }
+    return ok;
+}
 
 // ============================================================================================
 // XML front-end (subset)
@@ -1766,9 +1809,17 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
         else if (n.tag == "texture") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <texture> needs an id"); parse_texture(cx, n); }
         else if (n.tag == "integrator") {
             Properties p(cx.get(n, "type"));
-            if (p.plugin_name() != "path" && p.plugin_name() != "direct") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
-            parse_properties(cx, n, p);
-            out.integrator = make_integrator(p);
+            if (p.plugin_name() != "path" && p.plugin_name() != "direct" && p.plugin_name() != "moment") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
+            auto objs = parse_properties(cx, n, p);
+            if (p.plugin_name() == "moment") {                 // <integrator type="moment"><integrator type="path" name=.../></integrator>
+                if (objs.size() != 1 || objs[0]->tag != "integrator") Throw("Error while loading XML: <integrator type=\"moment\"> takes one nested <integrator> in this layer");
+                Properties np(cx.get(*objs[0], "type"));
+                if (!parse_properties(cx, *objs[0], np).empty()) Throw("Error while loading XML: unexpected object inside the nested <integrator>");
+                out.integrator = std::make_shared<MomentIntegrator>(p, make_integrator(np), cx.get(*objs[0], "name", "integrator"));
+            } else {
+                if (!objs.empty()) Throw("Error while loading XML: unexpected <" + objs[0]->tag + "> inside <integrator>");
+                out.integrator = make_integrator(p);
+            }
         } else if (n.tag == "sensor") {
             Properties p(cx.get(n, "type"));
             if (p.plugin_name() != "perspective") Throw("Plugin \"" + p.plugin_name() + "\" not found!");
@@ -2066,6 +2117,13 @@ void *mih_integrator_create(void *props) {
     MIH_TRY
         const Properties &p = *(Properties *) props;
         return new Box<SamplingIntegrator>{ make_integrator(p) }; MIH_CATCH(nullptr)
+}
+void *mih_integrator_create_moment(void *props, void *nested, const char *name) {
+    MIH_TRY return new Box<SamplingIntegrator>{ std::make_shared<MomentIntegrator>(*(Properties *) props, ((Box<SamplingIntegrator> *) nested)->p, name ? name : "integrator") }; MIH_CATCH(nullptr)
+}
+int mih_integrator_aov_names(void *i, char *buf, uint32_t cap) {       // comma-separated
+    MIH_TRY std::string s; for (const std::string &n : ((Box<SamplingIntegrator> *) i)->p->aov_names()) s += (s.empty() ? "" : ",") + n;
+        if (s.size() + 1 > cap) return -1; std::memcpy(buf, s.c_str(), s.size() + 1); return (int) s.size(); MIH_CATCH(-1)
 }
 void mih_integrator_destroy(void *i) { delete (Box<SamplingIntegrator> *) i; }
 void mih_integrator_set_shard(void *i, uint32_t rank, uint32_t world) { ((Box<SamplingIntegrator> *) i)->p->set_shard(rank, world); }

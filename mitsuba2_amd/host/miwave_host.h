@@ -406,8 +406,10 @@ public:
     explicit SamplingIntegrator(const Properties &props);      // integrator.cpp:23-38
     virtual ~SamplingIntegrator() = default;
     // SamplingIntegrator::render (integrator.cpp:51-179). Returns !m_stop.
-    bool render(Scene *scene, PerspectiveCamera *sensor);
-    void cancel();                                             // integrator.cpp:43-45
+    virtual bool render(Scene *scene, PerspectiveCamera *sensor);
+    // Film channels render() produces (integrator.cpp:67-73: X Y Z A W + aov_names())
+    virtual std::vector<std::string> aov_names() const { return {}; }
+    virtual void cancel();                                     // integrator.cpp:43-45
     uint32_t block_size() const { return m_block_size; }
     // pixel-tile shard for multi-GPU: this process renders blocks with
     // (spiral index % world_size) == rank; the film holds the partial sum.
@@ -426,11 +428,12 @@ public:
     // execution plan of the device sample loop (mi_render_cfg::plan): 0 auto, 1 wavefront, 2 resident
     void set_plan(int plan) { m_plan = plan; }
     bool hide_emitters() const { return m_hide_emitters; }
-protected:
     // mi_render_cfg::integrator and the plugin's own parameters
     virtual void fill_integrator(mi_render_cfg &cfg) const = 0;
+    // all passes of one job into `film5` (crop_w * crop_h * 5 floats); moment_pass = mi_render_cfg::moment_pass
+    bool render_passes(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass);
+protected:
     uint32_t m_block_size; uint32_t m_samples_per_pass; float m_timeout; bool m_hide_emitters;
-private:
     uint32_t m_rank = 0, m_world = 1;
     bool m_profile = false;
     int m_plan = 0;
@@ -460,6 +463,23 @@ protected:
     void fill_integrator(mi_render_cfg &cfg) const override;
 private:
     size_t m_emitter_samples, m_bsdf_samples;
+};
+
+// src/integrators/moment.cpp around ONE nested sampling integrator (scalar_rgb build): the film gets the channels
+// X Y Z A W <name>.X <name>.Y <name>.Z m2_<name>.X m2_<name>.Y m2_<name>.Z — what the reference's z-test harness
+// (src/python/python/test/test_renders.py) estimates per-pixel variances from. The device renders the job twice with
+// the same seeds (values, then squares: mi_render_cfg::moment_pass); block_size / samples_per_pass / timeout are the
+// nested integrator's.
+class MomentIntegrator final : public SamplingIntegrator {
+public:
+    MomentIntegrator(const Properties &props, std::shared_ptr<SamplingIntegrator> nested, std::string nested_name = "integrator");
+    bool render(Scene *scene, PerspectiveCamera *sensor) override;
+    void cancel() override { m_nested->cancel(); }
+    std::vector<std::string> aov_names() const override;
+    const std::shared_ptr<SamplingIntegrator> &nested() const { return m_nested; }
+    void fill_integrator(mi_render_cfg &cfg) const override { m_nested->fill_integrator(cfg); }
+private:
+    std::shared_ptr<SamplingIntegrator> m_nested; std::string m_name;
 };
 
 // PluginManager::create_object<Integrator>(props) for the integrators built here ("path", "direct")

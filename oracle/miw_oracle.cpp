@@ -663,6 +663,17 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
                     V3 xyz = srgb_to_xyz(L);                                        // :272-273
 #endif
                     float aovs[5] = { xyz.x, xyz.y, xyz.z, valid ? 1.f : 0.f, 1.f };   // :279-283
+                    if (cfg->moment_pass) {
+                        // MomentIntegrator::sample, moment.cpp:66-91 with one nested integrator: the block holds
+                        // X Y Z A W | nested.X nested.Y nested.Z | m2_nested.X m2_nested.Y m2_nested.Z, all splatted by the
+                        // one put() below (:285) — same weights, one validity verdict for the eleven values
+                        float full[11] = { xyz.x, xyz.y, xyz.z, aovs[3], 1.f, xyz.x, xyz.y, xyz.z, 0.f, 0.f, 0.f };
+                        for (int k = 0; k < 3; ++k) full[8 + k] = full[5 + k] * full[5 + k];      // :87 sqr()
+                        bool all_valid = true;
+                        for (int k = 0; k < 11; ++k) all_valid = all_valid && std::isfinite(full[k]) && full[k] >= -1e-5f;   // imageblock.cpp:85-96
+                        if (cfg->moment_pass == MI_MOMENT_SQUARES) for (int k = 0; k < 3; ++k) aovs[k] = full[8 + k];
+                        if (!all_valid) { ++samples; continue; }                    // put() warns and drops it; :287 still advances
+                    }
                     block_put(block, film, position_sample, aovs);                  // :285
                     ++samples;                                                      // sampler->advance(), :287
                 }

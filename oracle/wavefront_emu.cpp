@@ -193,6 +193,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     std::memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
+    P.moment_pass = (uint32_t) cfg->moment_pass;
     const bool direct = cfg->integrator == MI_INTEGRATOR_DIRECT;
     if (direct) {                                              // fill_params (miwave.hip), direct.cpp:82-103
         const uint32_t ne = cfg->emitter_samples, nb = cfg->bsdf_samples;
