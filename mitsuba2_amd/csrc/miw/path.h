@@ -239,8 +239,9 @@ enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
 // Shared by every execution plan: the HBM-queue wavefront kernels (lane_shade below),
 // the register-resident kernel (k_path_resident) and the CPU checker.
 // `Mats` names the BSDF plugins the scene uses, so that a kernel compiled for MATS_DIFFUSE (every shape one-sided
-// smooth diffuse: BASELINE config 2) carries no dispatch and none of the other plugins' code; MATS_ALL is the table.
-enum { MATS_ALL = 0, MATS_DIFFUSE = 1 };
+// smooth diffuse: BASELINE config 2) carries no dispatch and none of the other plugins' code; MATS_ALL is the table;
+// MATS_PLAIN is the table for scenes without texture coordinates and bitmap textures (the lookups compiled out).
+enum { MATS_ALL = 0, MATS_DIFFUSE = 1, MATS_PLAIN = 2 };
 // `Analytic` = false compiles the analytic-shape branch out (scenes the caller knows to be triangles only).
 template <int Mats = MATS_ALL, bool Analytic = true, typename PrevO>
 MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
@@ -263,8 +264,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, prev_o(), ray_d, si);
         } else {
             const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            // a MATS_DIFFUSE kernel is only launched for scenes without texture coordinates (miwave.hip: diffuse_only)
-            const float *tc = (Mats != MATS_DIFFUSE && (shape.flags & SHAPE_HAS_TEXCOORDS)) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
+            // only MATS_ALL kernels are launched for scenes with texture coordinates (miwave.hip: diffuse_only / textured)
+            const float *tc = (Mats == MATS_ALL && (shape.flags & SHAPE_HAS_TEXCOORDS)) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
             compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, si);
         }
         si.shape = tr.shape; si.prim = tr.prim;
@@ -316,8 +317,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     L.ray.o = si.p; L.ray.mint = spawn_mint(si.p);   // shared by shadow + extension ray
     L.ray.d = v3(0.f); L.ray.maxt = -1.f;
 
-    // what the plugin's texture lookups see of `si`; a MATS_DIFFUSE kernel is only launched for constant textures
-    const TexCtx tc(L.wl, si.uv, Mats == MATS_DIFFUSE ? nullptr : sc.bitmaps);
+    // what the plugin's texture lookups see of `si`; only MATS_ALL kernels are launched for scenes with bitmap textures
+    const TexCtx tc(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr);
 
     // ---- emitter sampling, :155-172 ----
     if (bflags & BSDF_Smooth) {

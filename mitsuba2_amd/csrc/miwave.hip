@@ -1181,6 +1181,7 @@ struct mi_ctx {
     std::vector<ShapeRec> shapes;
     std::vector<AnalyticRec> rects;                 // analytic rectangles
     std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
+    bool textured = false;                                   // some shape has texture coordinates or some BSDF reads a bitmap
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     bool have_scene = false, have_bvh = false;
@@ -1397,6 +1398,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         HIP_TRY(c, c->d_bitmaps.upload(recs, c->stream));
         c->bitmap_count = (uint32_t) recs.size();
     }
+    c->textured = !c->tri_uv_in.empty();
+    for (const BsdfRec &r : c->bsdfs) if (bsdf_uses_bitmap(r)) c->textured = true;
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
     c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
     bool any_emit_normals = false;
@@ -1887,10 +1890,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
                 }
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
-                else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_ALL);
-                else if (tiny) MIW_PATH_LAUNCH(1, MATS_ALL);
-                else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_ALL);
-                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in
+                else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_PLAIN);
+                else if (tiny) MIW_PATH_LAUNCH(1, MATS_PLAIN);
+                else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_PLAIN);
+                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_PLAIN, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
             } else if (direct && tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1, MATS_ALL, false, INTEG_DIRECT>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
