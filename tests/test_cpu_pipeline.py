@@ -207,6 +207,25 @@ def test_golden_film_fixture(native, oracle):
     assert np.array_equal(o32, g["film_materials"]) and st.segments == int(g["segments_materials"])
 
 
+def _round1_plugin_jobs(native):
+    """the three jobs of tests/golden/round1_plugins.npz -> [(key, scene, job)]"""
+    from mitsuba2_amd import scenes
+    from test_textures import textured_quad, quad_sensor, checker
+    scene, sensor = scenes.cornell_box(32, 24, 4, diffuse_only=False, device=-1, ball_level=1)
+    tscene = native.Scene(textured_quad(native, native.BitmapTexture(checker(), wrap_mode="mirror"))).build(-1)
+    return [("direct", scene, native.DirectIntegrator(emitter_samples=2, bsdf_samples=1).render_job(sensor)),
+            ("squares", scene, native.MomentIntegrator(native.PathIntegrator(max_depth=3)).render_job(sensor, moment_pass=2)),
+            ("textured", tscene, native.PathIntegrator(max_depth=4).render_job(quad_sensor(native, 32, 24, 4)))]
+
+
+def test_golden_fixture_of_the_round1_plugins(native, oracle):
+    """direct integrator, moment squares pass, texture coordinates + bitmap texture: committed films"""
+    g = np.load(os.path.join(GOLDEN, "round1_plugins.npz"))
+    for key, scene, job in _round1_plugin_jobs(native):
+        o32, _, st = oracle.render(scene.desc(), job, threads=2, want_f64=False)
+        assert np.array_equal(o32, g["film_" + key]) and st.segments == int(g["segments_" + key]), key
+
+
 # ---- host logic --------------------------------------------------------------------------------------------
 def test_render_cfg_block_size_and_seeds(native):
     from mitsuba2_amd import scenes

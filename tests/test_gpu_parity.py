@@ -571,3 +571,22 @@ def test_full_size_c3_structures_agree(native, oracle):
     assert cb.bvh_on_device == 1 and cb.segments == ca.segments and np.array_equal(b, a)
     assert np.isfinite(a).all() and 3.0 < ca.segments / ca.samples < 5.0
     dev.close()
+
+
+@pytest.mark.gpu
+@needs_gpu
+def test_device_against_committed_golden_films(native, dev):
+    """The device against tests/golden/*.npz directly — no oracle in the loop on the GPU box."""
+    import os
+    from mitsuba2_amd import scenes
+    from test_cpu_pipeline import _round1_plugin_jobs, GOLDEN
+    g = np.load(os.path.join(GOLDEN, "cornell_48x32_4spp.npz"))
+    scene, sensor = scenes.cornell_box(48, 32, 4, device=-1)
+    dev.upload(scene.desc())
+    film, st = dev.render(native.PathIntegrator().render_job(sensor))
+    assert st == 0 and np.array_equal(film, g["film"]) and dev.counters().segments == int(g["segments"])
+    g = np.load(os.path.join(GOLDEN, "round1_plugins.npz"))
+    for key, scene, job in _round1_plugin_jobs(native):
+        dev.upload(scene.desc())
+        film, st = dev.render(job)
+        assert st == 0 and np.array_equal(film, g["film_" + key]) and dev.counters().segments == int(g["segments_" + key]), key
