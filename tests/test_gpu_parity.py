@@ -573,8 +573,6 @@ def test_full_size_c3_structures_agree(native, oracle):
     dev.close()
 
 
-@pytest.mark.gpu
-@needs_gpu
 def test_device_against_committed_golden_films(native, dev):
     """The device against tests/golden/*.npz directly — no oracle in the loop on the GPU box."""
     import os
