@@ -76,6 +76,8 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.barrier()          # creates the RCCL communicator now, outside the timed region (also with --warmup 0)
 
     W, H, SPP = args.width, args.height, args.spp
     if args.variant != "scalar_rgb":
