@@ -42,10 +42,11 @@ enum {
  * like ShapeKDTree::m_primitive_map (kdtree.h:2335-2353). */
 
 enum { MI_BSDF_DIFFUSE = 0, MI_BSDF_DIELECTRIC = 1, MI_BSDF_ROUGHCONDUCTOR = 2, MI_BSDF_CONDUCTOR = 3, MI_BSDF_PLASTIC = 4,
-       MI_BSDF_ROUGHDIELECTRIC = 5 };
+       MI_BSDF_ROUGHDIELECTRIC = 5, MI_BSDF_ROUGHPLASTIC = 6 };
 enum { MI_BSDF_FLAG_GGX = 1, MI_BSDF_FLAG_SAMPLE_VISIBLE = 2,            /* roughconductor */
        MI_BSDF_FLAG_NONLINEAR = 1, MI_BSDF_FLAG_HAS_SPECULAR = 2,          /* plastic */
        MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE = 4, MI_BSDF_FLAG_HAS_SPEC_TRANSMITTANCE = 8,   /* roughdielectric (+ GGX, SAMPLE_VISIBLE) */
+       MI_BSDF_FLAG_RP_NONLINEAR = 0x10,                                   /* roughplastic (+ GGX, SAMPLE_VISIBLE, HAS_SPEC_REFLECTANCE) */
        MI_BSDF_FLAG_TWOSIDED = 0x100 };                                    /* any type: wrapped by <bsdf type="twosided"> */
 enum { MI_SHAPE_HAS_TEXCOORDS = 8 };   /* the shape's vertices carry texture coordinates (mi_scene_desc::vertex_texcoords) */
 enum { MI_SHAPE_HAS_NORMALS = 1,
@@ -90,7 +91,11 @@ typedef struct {
      *                                              [3] specular_sampling_weight, [4..6] diffuse_reflectance,
      *                                              [7..9] specular_reflectance (MI_BSDF_FLAG_HAS_SPECULAR)
      * roughdielectric (src/bsdfs/roughdielectric.cpp:146-201): [0] alpha_u, [1] alpha_v, [2] eta, [3] 1/eta,
-     *                                              [4..6] specular_reflectance, [7..9] specular_transmittance */
+     *                                              [4..6] specular_reflectance, [7..9] specular_transmittance
+     * roughplastic (src/bsdfs/roughplastic.cpp:146-181,336-371): [0] alpha, [1] eta = int_ior/ext_ior, [2] 1/eta^2,
+     *                                              [3] internal reflectance, [4] specular_sampling_weight, [5] (float) offset
+     *                                              of its MI_ROUGH_TRANSMITTANCE_RES-entry external-transmittance table in
+     *                                              mi_scene_desc::bsdf_tables, [6..8] diffuse_reflectance, [9..11] specular_reflectance */
     float params[14];
     /* scalar_spectral (and optionally scalar_rgb: used when tex[0].type != MI_TEX_RGB or params carry no colour):
      * diffuse: tex[0] reflectance; dielectric: tex[0] specular_reflectance, tex[1] specular_transmittance;
@@ -160,7 +165,11 @@ typedef struct {
     const float    *vertex_texcoords;
     /* bitmap textures referenced by MI_TEX_BITMAP records of the bsdfs (emitter radiances stay constant) */
     const mi_bitmap *bitmaps; uint32_t bitmap_count;
+    /* float tables plugins precompute in their constructors (roughplastic's eval_transmittance over
+     * mu = i / 63, microfacet.h:504-552): one buffer, addressed by offsets stored in mi_bsdf::params */
+    const float *bsdf_tables; uint32_t bsdf_table_floats;
 } mi_scene_desc;
+enum { MI_ROUGH_TRANSMITTANCE_RES = 64 };
 
 /* ---- rays / hits for the Scene::ray_intersect surface ------------------------------- */
 typedef struct {          /* SoA, n entries each (Ray3f: o, d, mint, maxt)               */

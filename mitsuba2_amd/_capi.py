@@ -61,7 +61,8 @@ class mi_scene_desc(C.Structure):
                 ("envmap", C.POINTER(mi_envmap)),
                 ("rectangles", C.POINTER(mi_rectangle)), ("rectangle_count", C.c_uint32),
                 ("spheres", C.POINTER(mi_sphere)), ("sphere_count", C.c_uint32),
-                ("vertex_texcoords", c_float_p), ("bitmaps", C.POINTER(mi_bitmap)), ("bitmap_count", C.c_uint32)]
+                ("vertex_texcoords", c_float_p), ("bitmaps", C.POINTER(mi_bitmap)), ("bitmap_count", C.c_uint32),
+                ("bsdf_tables", c_float_p), ("bsdf_table_floats", C.c_uint32)]
 
 
 class mi_rays_soa(C.Structure):
@@ -177,6 +178,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_bsdf_create": (vp, [vp]), "mih_bsdf_destroy": (None, [vp]), "mih_bsdf_create_twosided": (vp, [vp, vp]),
         "mih_fresnel_diffuse_reflectance": (C.c_float, [C.c_float]),
         "mih_bsdf_record": (i32, [vp, C.POINTER(mi_bsdf)]), "mih_bsdf_flags": (u32, [vp]),
+        "mih_bsdf_table": (i32, [vp, c_float_p, u32]), "mih_gauss_legendre": (None, [i32, c_float_p, c_float_p]),
         "mih_bsdf_sample": (i32, [vp, c_float_p, f, c_float_p, c_float_p]),
         "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),
         "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),

@@ -140,6 +140,14 @@ class BSDF:
     def flags(self):
         return host_lib().mih_bsdf_flags(self.h)
 
+    def table(self):
+        """the float table the plugin precomputes (roughplastic: external transmittance over mu = i / 63), or empty"""
+        n = host_lib().mih_bsdf_table(self.h, None, 0)
+        out = np.zeros(n, np.float32)
+        if n:
+            host_lib().mih_bsdf_table(self.h, _fp(out), n)
+        return out
+
     def sample(self, wi, sample1, sample2):
         """-> dict(wo, pdf, eta, sampled_type, weight)  (BSDF::sample, local frame)"""
         wi = np.asarray(wi, np.float32); s2 = np.asarray(sample2, np.float32); out = np.zeros(9, np.float32)
@@ -595,6 +603,13 @@ class MomentIntegrator(SamplingIntegrator):
         job = self.nested.render_job(sensor, n_threads, capacity, pass_index)
         job.cfg.moment_pass = moment_pass
         return job
+
+
+def gauss_legendre(n):
+    """quad::gauss_legendre (src/libcore/quad.cpp:7-64) -> nodes, weights"""
+    x = np.zeros(n, np.float32); w = np.zeros(n, np.float32)
+    host_lib().mih_gauss_legendre(n, _fp(x), _fp(w))
+    return x, w
 
 
 def spiral(w, h, block_size, offset=(0, 0)):

@@ -26,7 +26,9 @@ enum : uint32_t {
 };
 
 enum : uint32_t { BSDF_TYPE_DIFFUSE = 0, BSDF_TYPE_DIELECTRIC = 1, BSDF_TYPE_ROUGHCONDUCTOR = 2,
-                  BSDF_TYPE_CONDUCTOR = 3, BSDF_TYPE_PLASTIC = 4, BSDF_TYPE_ROUGHDIELECTRIC = 5, BSDF_TYPE_COUNT = 6 };
+                  BSDF_TYPE_CONDUCTOR = 3, BSDF_TYPE_PLASTIC = 4, BSDF_TYPE_ROUGHDIELECTRIC = 5, BSDF_TYPE_ROUGHPLASTIC = 6,
+                  BSDF_TYPE_COUNT = 7 };
+#define MIW_ROUGH_TRANSMITTANCE_RES 64      /* roughplastic.cpp:12 */
 // record flag bits: 0-1 belong to the type (roughconductor: GGX, sample_visible; plastic: nonlinear, has
 // specular_reflectance); bit 8 marks a record wrapped by the twosided adapter, whose back side is record `back`
 enum : uint32_t { BSDF_REC_TWOSIDED = 0x100u };
@@ -45,6 +47,10 @@ enum : uint32_t { MF_BECKMANN = 0, MF_GGX = 1 };
 //   roughdielectric: p[0] alpha_u, p[1] alpha_v, p[2] eta, p[3] 1/eta (roughdielectric.cpp:160,200), tex[0]
 //                   specular_reflectance, tex[1] specular_transmittance; flags bit0 = GGX, bit1 = sample_visible,
 //                   bit2 / bit3 = specular_reflectance / specular_transmittance given
+//   roughplastic:   p[0] alpha, p[1] eta, p[2] 1/eta^2, p[3] internal reflectance, p[4] specular_sampling_weight
+//                   (roughplastic.cpp:339-371), p[5] = (float) offset of its 64-entry external-transmittance table in
+//                   the scene's table buffer (TexCtx::tables); tex[0] diffuse_reflectance, tex[1] specular_reflectance;
+//                   flags bit0 = GGX, bit1 = sample_visible, bit2 = specular_reflectance given, bit4 = nonlinear
 //   twosided:       the FRONT record with BSDF_REC_TWOSIDED set; `back` = table index of the back side's record
 // (scalar_rgb callers may fill only p[] in the legacy layout — diffuse p[0..2]; dielectric p[1..3],
 //  p[4..6]; roughconductor p[2..4], p[5..7], p[8..10] — the uploader derives the TEX_RGB records.)
@@ -55,7 +61,8 @@ struct BSDFSample { V3 wo; float pdf, eta; uint32_t sampled_type; };
 // texture slots a record of this type reads
 MIW_HD uint32_t bsdf_tex_slots(uint32_t type) {
     return type == BSDF_TYPE_DIFFUSE ? 1u
-         : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_PLASTIC || type == BSDF_TYPE_ROUGHDIELECTRIC) ? 2u : 3u;
+         : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_PLASTIC || type == BSDF_TYPE_ROUGHDIELECTRIC ||
+            type == BSDF_TYPE_ROUGHPLASTIC) ? 2u : 3u;
 }
 
 MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
@@ -65,6 +72,7 @@ MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
         case BSDF_TYPE_CONDUCTOR:  return BSDF_DeltaReflection;                          // conductor.cpp:202
         case BSDF_TYPE_PLASTIC:    return BSDF_DeltaReflection | BSDF_DiffuseReflection; // plastic.cpp:156-158
         case BSDF_TYPE_ROUGHDIELECTRIC: return BSDF_GlossyReflection | BSDF_GlossyTransmission;   // roughdielectric.cpp:189-194
+        case BSDF_TYPE_ROUGHPLASTIC: return BSDF_GlossyReflection | BSDF_DiffuseReflection;         // roughplastic.cpp:176-178
         default:                   return BSDF_GlossyReflection;
     }
 }
@@ -533,8 +541,88 @@ MIW_HD float roughdielectric_pdf(const BsdfRec &b, V3 wi, V3 wo) {
 }
 
 // ---- dispatch (the BSDF plugin vtable, flattened) -------------------------------------
+// ---- RoughPlastic (roughplastic.cpp:182-334; both components enabled) ------------------------------------------
+MIW_HD Microfacet rp_distr(const BsdfRec &b) { return microfacet_make((b.flags & 1u) ? MF_GGX : MF_BECKMANN, b.p[0], b.p[0], (b.flags & 2u) != 0); }
+// lerp_gather over the plugin's external-transmittance table, :296-307
+MIW_HD float rp_transmittance(const BsdfRec &b, const TexCtx &tc, float x) {
+    const float *data = tc.tables + (uint32_t) b.p[5];
+    x *= (float) (MIW_ROUGH_TRANSMITTANCE_RES - 1);
+    uint32_t index = (uint32_t) x;
+    if (index > (uint32_t) (MIW_ROUGH_TRANSMITTANCE_RES - 2)) index = MIW_ROUGH_TRANSMITTANCE_RES - 2;
+    const float v0 = data[index], v1 = data[index + 1], t = x - (float) index;
+    return fmadd(v1, t, fnmadd(v0, t, v0));                          // enoki lerp(a, b, t) = fmadd(b, t, fnmadd(a, t, a))
+}
+MIW_HD void rp_probabilities(const BsdfRec &b, float t_i, float &prob_specular, float &prob_diffuse) {   // :206-215
+    prob_specular = (1.f - t_i) * b.p[4];
+    prob_diffuse = t_i * (1.f - b.p[4]);
+    prob_specular = prob_specular / (prob_specular + prob_diffuse);
+    prob_diffuse = 1.f - prob_specular;
+}
+// :309-334
+MIW_HD float roughplastic_pdf(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return 0.f;
+    float prob_specular, prob_diffuse;
+    rp_probabilities(b, rp_transmittance(b, tc, cos_theta_i), prob_specular, prob_diffuse);
+    const V3 H = normalize(wo + wi);
+    const Microfacet distr = rp_distr(b);
+    float result;
+    if (distr.sample_visible) result = mf_eval(distr, H) * mf_smith_g1(distr, wi, H) / (4.f * cos_theta_i);
+    else result = mf_pdf(distr, wi, H) / (4.f * dot(wo, H));
+    result *= prob_specular;
+    result += prob_diffuse * square_to_cosine_hemisphere_pdf(wo);
+    return result;
+}
+// :243-294
+MIW_HD Spec roughplastic_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    const float cos_theta_i = wi.z, cos_theta_o = wo.z;
+    if (!(cos_theta_i > 0.f && cos_theta_o > 0.f)) return spec(0.f);
+    const Microfacet distr = rp_distr(b);
+    const V3 H = normalize(wo + wi);
+    const float D = mf_eval(distr, H);
+    float F, ct, a, c;
+    fresnel(dot(wi, H), b.p[1], F, ct, a, c);
+    const float G = mf_G(distr, wi, wo, H);
+    Spec value = spec(F * D * G / (4.f * cos_theta_i));
+    if (b.flags & 4u) value = value * tex_eval(b.tex[1], tc);
+    const float t_i = rp_transmittance(b, tc, cos_theta_i), t_o = rp_transmittance(b, tc, cos_theta_o);
+    Spec diff = tex_eval(b.tex[0], tc);
+    const float fdr = b.p[3];
+#if MIW_SPECTRAL
+    for (int i = 0; i < 4; ++i) diff.c[i] = diff.c[i] / (1.f - ((b.flags & 16u) ? diff.c[i] * fdr : fdr));
+#else
+    diff = v3(diff.x / (1.f - ((b.flags & 16u) ? diff.x * fdr : fdr)), diff.y / (1.f - ((b.flags & 16u) ? diff.y * fdr : fdr)),
+              diff.z / (1.f - ((b.flags & 16u) ? diff.z * fdr : fdr)));
+#endif
+    return value + diff * (MIW_INV_PI * b.p[2] * cos_theta_o * t_i * t_o);
+}
+// :182-241
+MIW_HD Spec roughplastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
+    bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0;
+    const float cos_theta_i = wi.z;
+    if (!(cos_theta_i > 0.f)) return spec(0.f);
+    float prob_specular, prob_diffuse;
+    rp_probabilities(b, rp_transmittance(b, tc, cos_theta_i), prob_specular, prob_diffuse);
+    bs.eta = 1.f;
+    if (sample1 < prob_specular) {
+        V3 m; float pdf_m;
+        mf_sample(rp_distr(b), wi, sample2, m, pdf_m);
+        bs.wo = reflect(wi, m);
+        bs.sampled_type = BSDF_GlossyReflection;
+    } else {
+        bs.wo = square_to_cosine_hemisphere(sample2);
+        bs.sampled_type = BSDF_DiffuseReflection;
+    }
+    bs.pdf = roughplastic_pdf(b, wi, bs.wo, tc);
+    if (!(bs.pdf > 0.f)) return spec(0.f);
+    return roughplastic_eval(b, wi, bs.wo, tc) / bs.pdf;
+}
+
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
+// `Ext` = false compiles the plugins out that only scenes marked "extended" by the uploader contain (roughplastic).
+template <bool Ext = true>
 MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
+    if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_sample(b, wi, sample1, sample2, bs, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, tc);
         case BSDF_TYPE_DIELECTRIC: return dielectric_sample(b, wi, sample1, bs, tc);
@@ -544,7 +632,9 @@ MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDF
         default:                   return roughconductor_sample(b, wi, sample2, bs, tc);
     }
 }
+template <bool Ext = true>
 MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_eval(b, wi, wo, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, tc);
         case BSDF_TYPE_DIELECTRIC: return spec(0.f);                 // dielectric.cpp:312-315
@@ -554,7 +644,9 @@ MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
         default:                   return roughconductor_eval(b, wi, wo, tc);
     }
 }
-MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo) {
+template <bool Ext = true>
+MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_pdf(b, wi, wo, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_pdf(wi, wo);
         case BSDF_TYPE_DIELECTRIC: return 0.f;                       // dielectric.cpp:317-320
@@ -581,19 +673,22 @@ MIW_HD BsdfSide bsdf_side(const BsdfRec *table, uint32_t index, V3 wi) {
     return s;
 }
 MIW_HD V3 bsdf_mirror(V3 w) { return v3(w.x, w.y, w.z * -1.f); }      // `wi.z() *= -1.f`
+template <bool Ext = true>
 MIW_HD Spec bsdf_side_sample(const BsdfSide &s, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     if (s.none) { bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0; return spec(0.f); }
-    Spec v = bsdf_sample(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, tc);
+    Spec v = bsdf_sample<Ext>(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, tc);
     if (s.flip) bs.wo.z *= -1.f;                                     // :121
     return v;
 }
+template <bool Ext = true>
 MIW_HD Spec bsdf_side_eval(const BsdfSide &s, V3 wi, V3 wo, const TexCtx &tc) {
     if (s.none) return spec(0.f);
-    return s.flip ? bsdf_eval(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_eval(*s.b, wi, wo, tc);
+    return s.flip ? bsdf_eval<Ext>(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_eval<Ext>(*s.b, wi, wo, tc);
 }
-MIW_HD float bsdf_side_pdf(const BsdfSide &s, V3 wi, V3 wo) {
+template <bool Ext = true>
+MIW_HD float bsdf_side_pdf(const BsdfSide &s, V3 wi, V3 wo, const TexCtx &tc) {
     if (s.none) return 0.f;
-    return s.flip ? bsdf_pdf(*s.b, bsdf_mirror(wi), bsdf_mirror(wo)) : bsdf_pdf(*s.b, wi, wo);
+    return s.flip ? bsdf_pdf<Ext>(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_pdf<Ext>(*s.b, wi, wo, tc);
 }
 
 } // namespace miw

@@ -60,8 +60,9 @@ MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, La
     Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);   // :141-142
     if (ds.pdf == 0.f) return false;                              // :143-145
     V3 wo = to_local(si.sh, ds.d);                                // :148
-    Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(L.wl, si.uv, sc.bitmaps));   // :150
-    float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo);              // :155
+    const TexCtx tc(L.wl, si.uv, sc.bitmaps, sc.bsdf_tables);
+    Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, tc);          // :150
+    float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo, tc);          // :155
     float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158 (no delta emitters)
     Spec c = mis * bsdf_val * emitter_val;                        // :159
     if (all_zero(c)) return false;
@@ -75,7 +76,7 @@ MIW_HD bool direct_bsdf_sample(const SceneView &sc, LaneRegs &L, const SurfaceIn
     float s1 = next_1d(L.rng);                                    // :166-167 (Clang order: next_1d, then next_2d)
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    pend.bsdf_val = bsdf_side_sample(bsdf, si.wi, s1, s2, bs, TexCtx(L.wl, si.uv, sc.bitmaps));
+    pend.bsdf_val = bsdf_side_sample(bsdf, si.wi, s1, s2, bs, TexCtx(L.wl, si.uv, sc.bitmaps, sc.bsdf_tables));
     if (all_zero(pend.bsdf_val)) return false;                    // :170
     pend.pdf = bs.pdf; pend.delta = (bs.sampled_type & BSDF_Delta) != 0;
     L.ray.d = to_world(si.sh, bs.wo);                             // :173-174, interaction.h:58-61

@@ -318,7 +318,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     L.ray.d = v3(0.f); L.ray.maxt = -1.f;
 
     // what the plugin's texture lookups see of `si`; only MATS_ALL kernels are launched for scenes with bitmap textures
-    const TexCtx tc(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr);
+    const TexCtx tc(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr, Mats == MATS_ALL ? sc.bsdf_tables : nullptr);
+    constexpr bool Ext = Mats == MATS_ALL;           // plugins only "extended" scenes contain (roughplastic)
 
     // ---- emitter sampling, :155-172 ----
     if (bflags & BSDF_Smooth) {
@@ -326,8 +327,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
-            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, tc) : bsdf_side_eval(bsdf, si.wi, wo, tc);
-            float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf(bsdf, si.wi, wo);
+            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, tc) : bsdf_side_eval<Ext>(bsdf, si.wi, wo, tc);
+            float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf<Ext>(bsdf, si.wi, wo, tc);
             float mis = mis_weight(ds.pdf, bpdf);
             Spec c = mis * L.tp * bsdf_val * emitter_val;
             if (!all_zero(c)) {
@@ -342,7 +343,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, tc) : bsdf_side_sample(bsdf, si.wi, s1, s2, bs, tc);
+    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, tc) : bsdf_side_sample<Ext>(bsdf, si.wi, s1, s2, bs, tc);
     L.tp = L.tp * bsdf_val;
     if (all_zero(L.tp))                              // :182-184
         return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;

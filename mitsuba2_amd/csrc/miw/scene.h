@@ -60,6 +60,7 @@ struct SceneView {
     const EnvmapRec *env;                           // environment emitter or nullptr (scene.h:150-151)
     const AnalyticRec *rects;   uint32_t rect_count;    // analytic rectangles (Tri::pad - 1 indexes this table)
     const BitmapRec *bitmaps;                       // bitmap textures (TexRec TEX_BITMAP indexes this table) or nullptr
+    const float *bsdf_tables;                       // per-plugin float tables (roughplastic: BsdfRec::p[5] = offset) or nullptr
     float accept_pad;                               // shape.h: the bounds rule of every triangle hit
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)

@@ -38,10 +38,11 @@ struct BitmapRec {
 
 // What a texture lookup needs of the surface interaction: wavelengths, uv (and the scene's bitmap table).
 // A null table (or a constant record) evaluates exactly as before bitmaps existed.
+// `tables`: the scene's buffer of per-plugin float tables (roughplastic's transmittance table), or nullptr.
 struct TexCtx {
-    Wavelengths wl; V2 uv; const BitmapRec *bitmaps;
-    MIW_HD TexCtx(const Wavelengths &w) : wl(w), uv(v2(0.f, 0.f)), bitmaps(nullptr) { }
-    MIW_HD TexCtx(const Wavelengths &w, V2 uv_, const BitmapRec *b) : wl(w), uv(uv_), bitmaps(b) { }
+    Wavelengths wl; V2 uv; const BitmapRec *bitmaps; const float *tables;
+    MIW_HD TexCtx(const Wavelengths &w) : wl(w), uv(v2(0.f, 0.f)), bitmaps(nullptr), tables(nullptr) { }
+    MIW_HD TexCtx(const Wavelengths &w, V2 uv_, const BitmapRec *b, const float *t = nullptr) : wl(w), uv(uv_), bitmaps(b), tables(t) { }
 };
 
 #if MIW_SPECTRAL

@@ -1077,12 +1077,13 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
 #endif
             const BsdfSide b = bsdf_side(sc.bsdfs, b_index, wi);
-            BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
+            const TexCtx tc(wl, v2(0.f, 0.f), nullptr, sc.bsdf_tables);
+            BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, tc);
             o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-            Spec e = bsdf_side_eval(b, wi, wo, wl);
+            Spec e = bsdf_side_eval(b, wi, wo, tc);
             const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
             for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
-            o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo);
+            o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo, tc);
         } break;
         case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
         case MI_EVAL_CAMERA_RAY: {
@@ -1181,7 +1182,8 @@ struct mi_ctx {
     std::vector<ShapeRec> shapes;
     std::vector<AnalyticRec> rects;                 // analytic rectangles
     std::vector<BsdfRec> bsdfs; bool diffuse_only = false;   // every record one-sided smooth diffuse
-    bool textured = false;                                   // some shape has texture coordinates or some BSDF reads a bitmap
+    bool textured = false;                                   // texture coordinates, bitmaps or an "extended" plugin: MATS_ALL kernels
+    std::vector<float> bsdf_tables; DevBuf<float> d_bsdf_tables;
     std::vector<EmitterRec> emitters;
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     bool have_scene = false, have_bvh = false;
@@ -1254,7 +1256,7 @@ void mi_destroy(mi_ctx *c) {
     if (!c) return;
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
-    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_tri_uv.release(); c->d_bitmap_data.release(); c->d_bitmaps.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
+    c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_tri_uv.release(); c->d_bitmap_data.release(); c->d_bitmaps.release(); c->d_bsdf_tables.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
@@ -1364,10 +1366,10 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     c->bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         const mi_bsdf &b = s->bsdfs[i];
-        if (b.type >= BSDF_TYPE_COUNT) return fail(c, MI_ERR_INVALID, "bsdf %u: unknown type %u", i, b.type);
         BsdfRec r; int slot = 0;
-        if (const char *why = bsdf_record_from_abi(b, s->bitmap_count, r, &slot))
-            return fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: %s", i, slot, why);
+        if (s->bsdf_table_floats && !s->bsdf_tables) return fail(c, MI_ERR_INVALID, "scene: bsdf_table_floats without bsdf_tables");
+        if (const char *why = bsdf_record_from_abi(b, s->bitmap_count, s->bsdf_table_floats, r, &slot))
+            return slot < 0 ? fail(c, MI_ERR_INVALID, "bsdf %u: %s", i, why) : fail(c, MI_ERR_INVALID, "bsdf %u: texture %d: %s", i, slot, why);
         r.back = 0;
         if (b.flags & MI_BSDF_FLAG_TWOSIDED) {                 // twosided.cpp:62-92
             if (b.back >= s->bsdf_count) return fail(c, MI_ERR_INVALID, "bsdf %u: back-side record %u out of range", i, b.back);
@@ -1399,7 +1401,10 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         c->bitmap_count = (uint32_t) recs.size();
     }
     c->textured = !c->tri_uv_in.empty();
-    for (const BsdfRec &r : c->bsdfs) if (bsdf_uses_bitmap(r)) c->textured = true;
+    for (const BsdfRec &r : c->bsdfs) if (bsdf_uses_bitmap(r) || bsdf_is_extended(r)) c->textured = true;   // -> the MATS_ALL kernels
+    c->bsdf_tables.assign(s->bsdf_tables, s->bsdf_tables + s->bsdf_table_floats);
+    HIP_TRY(c, c->d_bsdf_tables.upload(c->bsdf_tables, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     // emitters: Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution (distr_1d.h:55-87)
     c->emitters.clear(); c->emit_tri.clear(); c->emit_vnorm.clear(); c->emit_pmf.clear(); c->emit_cdf.clear();
     bool any_emit_normals = false;
@@ -1570,6 +1575,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.tri_vn = c->tri_vn_in.empty() ? nullptr : c->d_tri_vn.p;
     v.tri_uv = c->tri_uv_in.empty() ? nullptr : c->d_tri_uv.p;
     v.bitmaps = c->bitmap_count ? c->d_bitmaps.p : nullptr;
+    v.bsdf_tables = c->bsdf_tables.empty() ? nullptr : c->d_bsdf_tables.p;
     v.shapes = c->d_shapes.p; v.shape_count = (uint32_t) c->shapes.size();
     v.bsdfs = c->d_bsdfs.p; v.bsdf_count = (uint32_t) c->bsdfs.size();
     v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();

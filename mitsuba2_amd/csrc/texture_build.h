@@ -53,11 +53,18 @@ inline const char *build_bitmap_table(const mi_scene_desc *s, std::vector<Bitmap
 
 // mi_bsdf -> BsdfRec: texture slots from the record's tex[] (scalar_spectral) or from the RGB layout of params[]
 // (scalar_rgb), a MI_TEX_BITMAP slot taken as it is in either library. nullptr, or what is wrong with slot *bad.
-inline const char *bsdf_record_from_abi(const mi_bsdf &b, uint32_t bitmap_count, BsdfRec &r, int *bad) {
+inline const char *bsdf_record_from_abi(const mi_bsdf &b, uint32_t bitmap_count, uint32_t table_floats, BsdfRec &r, int *bad) {
     std::memset(&r, 0, sizeof r);
     r.type = b.type; r.flags = b.flags; r.back = b.back;
     std::memcpy(r.p, b.params, sizeof r.p);
-    const int off[6][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 } };   // RGB layout of params[]
+    *bad = -1;
+    if (b.type >= BSDF_TYPE_COUNT) return "unknown type";
+    if (b.type == BSDF_TYPE_ROUGHPLASTIC) {
+        const float o = b.params[5];
+        if (!(o >= 0.f) || o != (float) (uint32_t) o || (uint64_t) o + MI_ROUGH_TRANSMITTANCE_RES > table_floats)
+            return "roughplastic: transmittance table outside mi_scene_desc::bsdf_tables";
+    }
+    const int off[7][3] = { { 0, -1, -1 }, { 1, 4, -1 }, { 2, 5, 8 }, { 2, 5, 8 }, { 4, 7, -1 }, { 4, 7, -1 }, { 6, 9, -1 } };   // RGB layout of params[]
     for (int k = 0; k < 3; ++k) {
         *bad = k;
         const bool used = k < (int) bsdf_tex_slots(b.type);
@@ -82,6 +89,8 @@ inline const char *bsdf_record_from_abi(const mi_bsdf &b, uint32_t bitmap_count,
 }
 
 // true when a record of the table reads a bitmap
+// true when the record needs an "extended" kernel (plugins the plain kernels compile out)
+inline bool bsdf_is_extended(const BsdfRec &r) { return r.type == BSDF_TYPE_ROUGHPLASTIC; }
 inline bool bsdf_uses_bitmap(const BsdfRec &r) {
     for (uint32_t k = 0; k < bsdf_tex_slots(r.type); ++k) if (r.tex[k].type == TEX_BITMAP) return true;
     return false;

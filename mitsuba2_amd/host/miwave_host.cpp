@@ -636,12 +636,20 @@ uint32_t BSDF::flags() const {
     return f;
 }
 // the plugin as the integrator sees it: a two-record table {front, back} for the twosided adapter
-namespace { struct SideTable { miw::BsdfRec t[2]; };
-SideTable side_table(const mi_bsdf &rec, const std::shared_ptr<BSDF> &back) {
+namespace { struct SideTable { miw::BsdfRec t[2]; std::vector<float> tables; };
+SideTable side_table(const mi_bsdf &rec, const std::shared_ptr<BSDF> &back, const std::vector<float> &table) {
     SideTable s; s.t[0] = as_rec(rec); s.t[1] = back ? as_rec(back->record()) : as_rec(rec);
     s.t[0].back = 1; s.t[1].flags &= ~(uint32_t) MI_BSDF_FLAG_TWOSIDED;
+    s.tables = table;                                          // front's table at offset 0, the back side's behind it
+    if (s.t[0].type == miw::BSDF_TYPE_ROUGHPLASTIC) s.t[0].p[5] = 0.f;
+    if (s.t[1].type == miw::BSDF_TYPE_ROUGHPLASTIC) {
+        const std::vector<float> &bt = back ? back->table() : table;
+        s.t[1].p[5] = (float) s.tables.size();
+        s.tables.insert(s.tables.end(), bt.begin(), bt.end());
+    }
     return s;
-} }
+}
+miw::TexCtx host_ctx(const SideTable &s) { return miw::TexCtx(miw::Wavelengths(), miw::v2(0.f, 0.f), nullptr, s.tables.empty() ? nullptr : s.tables.data()); } }
 #if MIW_SPECTRAL
 std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &, float, const std::array<float, 2> &) const {
     Throw("BSDF::sample on the host is a scalar_rgb test helper");
@@ -650,23 +658,23 @@ Color3f BSDF::eval(const Vector3f &, const Vector3f &) const { Throw("BSDF::eval
 #else
 std::pair<BSDFSample3f, Color3f> BSDF::sample(const Vector3f &wi, float s1, const std::array<float, 2> &s2) const {
     miw::BSDFSample bs;
-    const SideTable tab = side_table(m_rec, m_back);
+    const SideTable tab = side_table(m_rec, m_back, m_table);
     const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
-    miw::V3 w = miw::bsdf_side_sample(miw::bsdf_side(tab.t, 0, wi_), wi_, s1, miw::v2(s2[0], s2[1]), bs, miw::Wavelengths());
+    miw::V3 w = miw::bsdf_side_sample(miw::bsdf_side(tab.t, 0, wi_), wi_, s1, miw::v2(s2[0], s2[1]), bs, host_ctx(tab));
     BSDFSample3f o; o.wo = { bs.wo.x, bs.wo.y, bs.wo.z }; o.pdf = bs.pdf; o.eta = bs.eta; o.sampled_type = bs.sampled_type;
     return { o, Color3f{ w.x, w.y, w.z } };
 }
 Color3f BSDF::eval(const Vector3f &wi, const Vector3f &wo) const {
-    const SideTable tab = side_table(m_rec, m_back);
+    const SideTable tab = side_table(m_rec, m_back, m_table);
     const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
-    miw::V3 v = miw::bsdf_side_eval(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]), miw::Wavelengths());
+    miw::V3 v = miw::bsdf_side_eval(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]), host_ctx(tab));
     return { v.x, v.y, v.z };
 }
 #endif
 float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
-    const SideTable tab = side_table(m_rec, m_back);
+    const SideTable tab = side_table(m_rec, m_back, m_table);
     const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);
-    return miw::bsdf_side_pdf(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]));
+    return miw::bsdf_side_pdf(miw::bsdf_side(tab.t, 0, wi_), wi_, miw::v3(wo[0], wo[1], wo[2]), host_ctx(tab));
 }
 
 void BSDF::bind_texture(int slot, const Properties &props, const std::string &name, float def, bool unbounded) {
@@ -896,6 +904,98 @@ RoughDielectric::RoughDielectric(const Properties &props) {
     bind_texture(0, props, "specular_reflectance", 1.f, false);
     bind_texture(1, props, "specular_transmittance", 1.f, false);
 }
+// n-point Gauss-Legendre rule: Newton's method on P_n from Chebyshev starting points, in double (quad.cpp:7-64)
+void gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights) {
+    if (n < 1) Throw("gauss_legendre(): n must be >= 1");
+    nodes.assign((size_t) n, 0.f); weights.assign((size_t) n, 0.f);
+    auto legendre = [n](double x, double &p, double &dp) {     // P_n(x), P_n'(x) by the three-term recurrence
+        double p0 = 1.0, p1 = x;
+        if (n == 0) { p = 1.0; dp = 0.0; return; }
+        for (int k = 2; k <= n; ++k) { double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k; p0 = p1; p1 = pk; }
+        p = p1; dp = n * (x * p1 - p0) / (x * x - 1.0);
+    };
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double x = -std::cos((2 * i + 1) / (double) (2 * n) * 3.14159265358979323846), p, dp;
+        if (n % 2 == 1 && i == n / 2) x = 0.0;
+        for (int it = 0; it < 30 && x != 0.0; ++it) {
+            legendre(x, p, dp);
+            const double step = p / dp; x -= step;
+            if (std::fabs(step) <= 4 * std::fabs(x) * std::numeric_limits<double>::epsilon()) break;
+        }
+        if (x == 0.0) { double p0 = 1.0, p1 = 0.0; for (int k = 2; k <= n; ++k) { double pk = -((k - 1) * p0) / k; p0 = p1; p1 = pk; } dp = n * p0; }   // P_n'(0) = n P_{n-1}(0)
+        else legendre(x, p, dp);
+        const double w = 2.0 / ((1.0 - x * x) * dp * dp);
+        nodes[i] = (float) x; nodes[n - 1 - i] = (float) -x; weights[i] = weights[n - 1 - i] = (float) w;
+    }
+}
+// eval_transmittance / eval_reflectance (microfacet.h:454-552) for one incident direction: the visible-normal
+// sampling routine of the distribution pushed through an n x n tensor Gauss-Legendre rule over the unit square
+static float rough_interface_integral(const miw::Microfacet &distr, miw::V3 wi, float eta, bool transmit) {
+    std::vector<float> nodes, weights;
+    gauss_legendre(eta > 1.f ? 32 : 128, nodes, weights);      // :468-472 (the packet padding adds nothing at these sizes)
+    double accum = 0.0;
+    for (size_t a = 0; a < nodes.size(); ++a)
+        for (size_t b = 0; b < nodes.size(); ++b) {
+            const miw::V2 node = miw::v2(miw::fmadd(nodes[b], .5f, .5f), miw::fmadd(nodes[a], .5f, .5f));
+            miw::V3 m; float pdf;
+            miw::mf_sample(distr, wi, node, m, pdf);
+            float f, cos_theta_t, eta_it, eta_ti;
+            miw::fresnel(miw::dot(wi, m), eta, f, cos_theta_t, eta_it, eta_ti);
+            float smith;
+            if (transmit) {
+                const miw::V3 wo = miw::refract(wi, m, cos_theta_t, eta_ti);
+                smith = miw::mf_smith_g1(distr, wo, m) * (1.f - f);
+                if (wo.z * wi.z >= 0.f) smith = 0.f;
+            } else {
+                const miw::V3 wo = miw::reflect(wi, m);
+                smith = miw::mf_smith_g1(distr, wo, m) * f;
+                if (wo.z <= 0.f || wi.z <= 0.f) smith = 0.f;
+            }
+            accum += (double) (smith * (weights[a] * weights[b]));
+        }
+    return (float) accum * .25f;
+}
+RoughPlastic::RoughPlastic(const Properties &props) {
+    float int_ior = lookup_ior(props, "int_ior", "polypropylene"), ext_ior = lookup_ior(props, "ext_ior", "air");
+    if (int_ior < 0.f || ext_ior < 0.f || int_ior == ext_ior)
+        Throw("The interior and exterior indices of refraction must be positive and differ!");   // :155-157
+    const float eta = int_ior / ext_ior;
+    uint32_t flags = 0;
+    if (props.has_property("distribution")) {
+        std::string distr = to_lower(props.string("distribution"));
+        if (distr == "ggx") flags |= MI_BSDF_FLAG_GGX;
+        else if (distr != "beckmann") Throw("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"!");
+    }
+    if (props.bool_("sample_visible", true)) flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
+    if (props.has_property("alpha_u") || props.has_property("alpha_v"))
+        Throw("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");   // :170-172
+    const float alpha = props.float_("alpha", 0.1f);
+    const bool has_spec = props.has_property("specular_reflectance");
+    Color3f dr = props.texture("diffuse_reflectance", .5f), sr = props.texture("specular_reflectance", 1.f);
+    check_reflectance(dr, "diffuse_reflectance");
+    if (has_spec) { check_reflectance(sr, "specular_reflectance"); flags |= MI_BSDF_FLAG_HAS_SPEC_REFLECTANCE; }
+    if (props.bool_("nonlinear", false)) flags |= MI_BSDF_FLAG_RP_NONLINEAR;
+    // parameters_changed(), :336-371
+    const float d_mean = props.texture_mean("diffuse_reflectance", .5f),
+                s_mean = has_spec ? props.texture_mean("specular_reflectance", 1.f) : 1.f;
+    const miw::Microfacet distr = miw::microfacet_make((flags & MI_BSDF_FLAG_GGX) ? miw::MF_GGX : miw::MF_BECKMANN, alpha, alpha, true);
+    m_table.resize(MI_ROUGH_TRANSMITTANCE_RES);
+    double refl = 0.0;
+    for (int i = 0; i < MI_ROUGH_TRANSMITTANCE_RES; ++i) {
+        const float mu = std::max(1e-6f, (float) i / (float) (MI_ROUGH_TRANSMITTANCE_RES - 1));
+        const miw::V3 wi = miw::v3(std::sqrt(1.f - mu * mu), 0.f, mu);
+        m_table[(size_t) i] = rough_interface_integral(distr, wi, eta, true);
+        refl += (double) (rough_interface_integral(distr, wi, 1.f / eta, false) * wi.z);
+    }
+    m_rec.type = MI_BSDF_ROUGHPLASTIC; m_rec.flags = flags;
+    m_rec.params[0] = alpha; m_rec.params[1] = eta; m_rec.params[2] = 1.f / (eta * eta);
+    m_rec.params[3] = (float) (refl / MI_ROUGH_TRANSMITTANCE_RES) * 2.f;        // hmean(...) * 2, :368-369
+    m_rec.params[4] = s_mean / (d_mean + s_mean);
+    m_rec.params[5] = 0.f;                                     // table offset: assigned by Scene::build
+    for (int i = 0; i < 3; ++i) { m_rec.params[6 + i] = dr[i]; m_rec.params[9 + i] = sr[i]; }
+    bind_texture(0, props, "diffuse_reflectance", .5f, false);
+    bind_texture(1, props, "specular_reflectance", 1.f, false);
+}
 TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back) {
     if (!front) Throw("A nested one-sided material is required!");
     if (front->twosided() || (back && back->twosided())) Throw("twosided: nested twosided materials are not supported");
@@ -905,6 +1005,7 @@ TwoSidedBRDF::TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> ba
     m_rec = front->record();
     m_rec.flags |= MI_BSDF_FLAG_TWOSIDED;
     for (int k = 0; k < 3; ++k) m_bitmaps[k] = front->bitmap(k);
+    m_table = front->table();
     m_back = back;
 }
 
@@ -1261,17 +1362,21 @@ std::shared_ptr<Mesh> make_sphere(const Properties &props) {
 }
 static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vector<float> &pos, std::vector<float> &nrm,
                     std::vector<float> &tex, std::vector<mi_bitmap> &bitmaps, std::vector<std::shared_ptr<BitmapTexture>> &bitmap_objs,
-                    std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
+                    std::vector<float> &tables, std::vector<uint32_t> &faces, std::vector<mi_shape> &srecs, std::vector<mi_bsdf> &brecs,
                     std::vector<mi_emitter> &erecs, std::vector<mi_rectangle> &rrecs, std::vector<mi_sphere> &sphrecs) {
     pos.clear(); nrm.clear(); tex.clear(); faces.clear(); srecs.clear(); brecs.clear(); erecs.clear(); rrecs.clear(); sphrecs.clear();
     bool any_normals = false, any_texcoords = false;
     for (auto &m : shapes) { any_normals = any_normals || m->has_vertex_normals(); any_texcoords = any_texcoords || m->has_vertex_texcoords(); }
     std::map<const BSDF *, uint32_t> bsdf_index;
-    bitmaps.clear(); bitmap_objs.clear();
+    bitmaps.clear(); bitmap_objs.clear(); tables.clear();
     std::map<const BitmapTexture *, uint32_t> bitmap_index;
     // the plugin's C-ABI record, bitmap parameters resolved to entries of the scene's bitmap table
     auto push_record = [&](const BSDF *b) {
         mi_bsdf r = b->record();
+        if (!b->table().empty()) {                             // roughplastic: its transmittance table joins the scene's buffer
+            r.params[5] = (float) tables.size();
+            tables.insert(tables.end(), b->table().begin(), b->table().end());
+        }
         for (int k = 0; k < 3; ++k) {
             const std::shared_ptr<BitmapTexture> &t = b->bitmap(k);
             if (!t) continue;
@@ -1348,13 +1453,14 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
 }
 void Scene::build(int device, int bvh_quality) {
     if (m_shapes.empty()) Throw("Scene: no shapes");
-    flatten(m_shapes, m_positions, m_normals, m_texcoords, m_bitmap_recs, m_bitmap_objs, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
+    flatten(m_shapes, m_positions, m_normals, m_texcoords, m_bitmap_recs, m_bitmap_objs, m_bsdf_tables, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
     m_desc.spheres = m_sphere_recs.empty() ? nullptr : m_sphere_recs.data(); m_desc.sphere_count = (uint32_t) m_sphere_recs.size();
     m_desc.rectangles = m_rect_recs.empty() ? nullptr : m_rect_recs.data(); m_desc.rectangle_count = (uint32_t) m_rect_recs.size();
     m_desc.vertex_positions = m_positions.data();
     m_desc.vertex_normals = m_normals.empty() ? nullptr : m_normals.data();
     m_desc.vertex_texcoords = m_texcoords.empty() ? nullptr : m_texcoords.data();
     m_desc.bitmaps = m_bitmap_recs.empty() ? nullptr : m_bitmap_recs.data(); m_desc.bitmap_count = (uint32_t) m_bitmap_recs.size();
+    m_desc.bsdf_tables = m_bsdf_tables.empty() ? nullptr : m_bsdf_tables.data(); m_desc.bsdf_table_floats = (uint32_t) m_bsdf_tables.size();
     m_desc.vertex_count = (uint32_t) (m_positions.size() / 3);
     m_desc.faces = m_faces.data(); m_desc.face_count = (uint32_t) (m_faces.size() / 3);
     m_desc.shapes = m_shape_recs.data(); m_desc.shape_count = (uint32_t) m_shape_recs.size();
@@ -1751,6 +1857,7 @@ std::shared_ptr<BSDF> make_bsdf(const Properties &p) {
     if (t == "conductor") return std::make_shared<SmoothConductor>(p);
     if (t == "plastic") return std::make_shared<SmoothPlastic>(p);
     if (t == "roughdielectric") return std::make_shared<RoughDielectric>(p);
+    if (t == "roughplastic") return std::make_shared<RoughPlastic>(p);
     Throw("Plugin \"" + t + "\" not found!");
 }
 std::string resolve(const XmlCtx &cx, const std::string &f) { return (!f.empty() && f[0] == '/') ? f : cx.base_dir + "/" + f; }
@@ -1940,6 +2047,7 @@ void *mih_bsdf_create(void *props) {
         else if (p.plugin_name() == "conductor") b = std::make_shared<SmoothConductor>(p);
         else if (p.plugin_name() == "plastic") b = std::make_shared<SmoothPlastic>(p);
         else if (p.plugin_name() == "roughdielectric") b = std::make_shared<RoughDielectric>(p);
+        else if (p.plugin_name() == "roughplastic") b = std::make_shared<RoughPlastic>(p);
         else throw std::runtime_error("Plugin \"" + p.plugin_name() + "\" not found!");
         return new Box<BSDF>{ b }; MIH_CATCH(nullptr)
 }
@@ -1951,6 +2059,15 @@ void *mih_bsdf_create_twosided(void *front, void *back) {
 }
 float mih_fresnel_diffuse_reflectance(float eta) { return fresnel_diffuse_reflectance(eta); }
 void mih_bsdf_destroy(void *b) { delete (Box<BSDF> *) b; }
+int mih_bsdf_table(void *b, float *out, uint32_t cap) {          // -> entries of the plugin's float table (0: none)
+    const std::vector<float> &t = ((Box<BSDF> *) b)->p->table();
+    if (out && cap >= t.size()) std::memcpy(out, t.data(), t.size() * sizeof(float));
+    return (int) t.size();
+}
+void mih_gauss_legendre(int n, float *nodes, float *weights) {
+    std::vector<float> x, w; gauss_legendre(n, x, w);
+    std::memcpy(nodes, x.data(), x.size() * 4); std::memcpy(weights, w.data(), w.size() * 4);
+}
 int mih_bsdf_record(void *b, mi_bsdf *out) { *out = ((Box<BSDF> *) b)->p->record(); return 0; }
 uint32_t mih_bsdf_flags(void *b) { return ((Box<BSDF> *) b)->p->flags(); }
 // out: wo.xyz, pdf, eta, sampled_type(bits), weight.rgb

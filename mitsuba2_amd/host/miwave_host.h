@@ -256,6 +256,9 @@ public:
     const mi_bsdf &record() const { return m_rec; }             // bitmap parameters appear as their mean here;
     // the bitmap bound to texture slot k (nullptr: constant). Scene::build turns it into a MI_TEX_BITMAP record.
     const std::shared_ptr<BitmapTexture> &bitmap(int k) const { return m_bitmaps[k]; }
+    // the float table the plugin's record addresses with params[5] (roughplastic: 64 entries; empty otherwise).
+    // Scene::build appends it to mi_scene_desc::bsdf_tables and stores the offset in the record.
+    const std::vector<float> &table() const { return m_table; }
     // twosided adapter: the nested back-side BSDF (nullptr: not twosided; == this: same BSDF on both sides)
     const std::shared_ptr<BSDF> &back() const { return m_back; }
     bool twosided() const { return (m_rec.flags & MI_BSDF_FLAG_TWOSIDED) != 0; }
@@ -265,6 +268,7 @@ protected:
     mi_bsdf m_rec{};
     std::shared_ptr<BSDF> m_back;
     std::shared_ptr<BitmapTexture> m_bitmaps[3];
+    std::vector<float> m_table;
 };
 class SmoothDiffuse final : public BSDF { public: explicit SmoothDiffuse(const Properties &props); };        // diffuse.cpp:72-76
 class SmoothDielectric final : public BSDF { public: explicit SmoothDielectric(const Properties &props); };  // dielectric.cpp:174-199
@@ -272,6 +276,12 @@ class RoughConductor final : public BSDF { public: explicit RoughConductor(const
 class SmoothConductor final : public BSDF { public: explicit SmoothConductor(const Properties &props); };    // conductor.cpp:201-215
 class SmoothPlastic final : public BSDF { public: explicit SmoothPlastic(const Properties &props); };        // plastic.cpp:135-174
 class RoughDielectric final : public BSDF { public: explicit RoughDielectric(const Properties &props); };    // roughdielectric.cpp:146-201
+// roughplastic.cpp:146-181 + parameters_changed :336-371: isotropic Beckmann / GGX coating over a diffuse base; its
+// constructor integrates the rough transmittance table (eval_transmittance, microfacet.h:504-552) and the internal
+// reflectance (eval_reflectance, :454-502) with Gauss-Legendre quadrature (src/libcore/quad.cpp:7-64)
+class RoughPlastic final : public BSDF { public: explicit RoughPlastic(const Properties &props); };
+// nodes and weights of the n-point Gauss-Legendre rule on [-1, 1] (quad::gauss_legendre)
+void gauss_legendre(int n, std::vector<float> &nodes, std::vector<float> &weights);
 // twosided.cpp:62-92: wraps one nested BRDF (both sides) or two (front, back); nested BSDFs must not transmit
 class TwoSidedBRDF final : public BSDF { public: explicit TwoSidedBRDF(std::shared_ptr<BSDF> front, std::shared_ptr<BSDF> back = nullptr); };
 float fresnel_diffuse_reflectance(float eta);                                                                 // fresnel.h:327-361
@@ -392,6 +402,7 @@ private:
     std::vector<mi_emitter> m_emitters;
     std::vector<mi_rectangle> m_rect_recs; std::vector<mi_sphere> m_sphere_recs;
     std::vector<mi_bitmap> m_bitmap_recs; std::vector<std::shared_ptr<BitmapTexture>> m_bitmap_objs;
+    std::vector<float> m_bsdf_tables;
     std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;

@@ -126,7 +126,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         int slot = 0;
-        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, o.bsdfs[i], &slot)) return false;
+        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, s->bsdf_table_floats, o.bsdfs[i], &slot)) return false;
     }
     { uint32_t bad = 0; if (build_bitmap_table(s, o.bitmaps, &bad)) return false; }
     // Mesh::build_pmf (mesh.cpp:285-312) + DiscreteDistribution::update (distr_1d.h:55-87)
@@ -192,6 +192,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     v.tri_vn = o.tri_vn.empty() ? nullptr : o.tri_vn.data();
     v.tri_uv = o.tri_uv.empty() ? nullptr : o.tri_uv.data();
     v.bitmaps = o.bitmaps.empty() ? nullptr : o.bitmaps.data();
+    v.bsdf_tables = s->bsdf_table_floats ? s->bsdf_tables : nullptr;   // the caller's array
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
@@ -307,8 +308,8 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
             }
             active_e = active_e && ds.pdf != 0.f;        // :160
             V3 wo = to_local(si.sh, ds.d);               // :163
-            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps));   // :164
-            float bpdf = bsdf_side_pdf(bsdf, si.wi, wo);      // :168
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));   // :164
+            float bpdf = bsdf_side_pdf(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));      // :168
             float mis = mis_weight(ds.pdf, bpdf);        // :170 (ds.delta is false for area lights)
             if (active_e)
                 result = result + mis * throughput * bsdf_val * emitter_val;   // :171
@@ -318,7 +319,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
         float sample1 = sampler.next_1d();
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps));
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));
 
         throughput = throughput * bsdf_val;              // :181
         active = active && !all_zero(throughput);        // :182
@@ -402,8 +403,8 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
             }
             if (ds.pdf == 0.f) continue;                 // :143-145
             V3 wo = to_local(si.sh, ds.d);               // :148
-            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps));   // :150
-            float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo);       // :155
+            Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));   // :150
+            float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));       // :155
             float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158
             result = result + mis * bsdf_val * emitter_val;        // :159
         }
@@ -413,7 +414,7 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
         float sample1 = sampler.next_1d();               // :166-167, Clang's argument order
         V2 sample2 = sampler.next_2d();
         BSDFSample bs;
-        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps));
+        Spec bsdf_val = bsdf_side_sample(bsdf, si.wi, sample1, sample2, bs, TexCtx(wl, si.uv, view.bitmaps, view.bsdf_tables));
         if (all_zero(bsdf_val)) continue;                // :170: active_b
         Ray next;                                        // :173-174, interaction.h:58-61
         next.o = si.p; next.d = to_world(si.sh, bs.wo);
@@ -881,12 +882,13 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
 #endif
                 const BsdfSide b = bsdf_side(sc.bsdfs.data(), b_index, wi);
-                BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, wl);
+                const TexCtx tc(wl, v2(0.f, 0.f), nullptr, sc.view.bsdf_tables);
+                BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, tc);
                 o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-                Spec e = bsdf_side_eval(b, wi, wo, wl);
+                Spec e = bsdf_side_eval(b, wi, wo, tc);
                 const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
                 for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
-                o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo);
+                o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo, tc);
             } break;
             case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
             case MI_EVAL_CAMERA_RAY: {

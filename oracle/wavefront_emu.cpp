@@ -81,7 +81,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     o.bsdfs.resize(s->bsdf_count);
     for (uint32_t i = 0; i < s->bsdf_count; ++i) {
         int slot = 0;
-        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, o.bsdfs[i], &slot)) return false;
+        if (bsdf_record_from_abi(s->bsdfs[i], s->bitmap_count, s->bsdf_table_floats, o.bsdfs[i], &slot)) return false;
     }
     { uint32_t bad = 0; if (build_bitmap_table(s, o.bitmaps, &bad)) return false; }
     bool emit_normals = false;
@@ -138,6 +138,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     if (!build_face_texcoords(s, o.tri_uv)) return false;
     v.tri_uv = o.tri_uv.empty() ? nullptr : o.tri_uv.data();
     v.bitmaps = o.bitmaps.empty() ? nullptr : o.bitmaps.data();
+    v.bsdf_tables = s->bsdf_table_floats ? s->bsdf_tables : nullptr;   // the caller's array
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();

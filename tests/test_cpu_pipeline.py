@@ -264,7 +264,7 @@ def test_property_errors(native):
     with pytest.raises(RuntimeError, match="max_depth"):
         native.PathIntegrator(max_depth=-2)
     with pytest.raises(RuntimeError, match="not found"):
-        native.BSDF("roughplastic")
+        native.BSDF("blendbsdf")
     with pytest.raises(RuntimeError, match="invalid distribution"):
         native.BSDF("roughconductor", distribution="phong")
     with pytest.raises(RuntimeError, match="alpha_u"):
