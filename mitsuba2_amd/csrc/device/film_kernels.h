@@ -1,0 +1,361 @@
+// Film assembly: k_film_resolve (float64 sums), k_film_blocks (texel patches), k_film_pack + k_film_groups
+// (packed records, 4 x 2 texel groups), k_film_merge.
+// Part of the single translation unit csrc/miwave.hip (included there, in this order; not a stand-alone header).
+__global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n, int accumulate) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (out64) out64[i] = accumulate ? out64[i] + accum[i] : accum[i];
+    else out32[i] = accumulate ? (float) ((double) out32[i] + accum[i]) : (float) accum[i];
+}
+
+// Ordered film assembly, step 1 (miw/film_gather.h): the bordered ImageBlock of every spiral block
+// is rebuilt by TEXEL PATCHES — one wavefront owns an 8x8 patch of block texels, one texel per lane,
+// the five channel sums live in registers. The wave walks the block's pixels in Morton order
+// (render_block's order, integrator.cpp:196-203), skips those whose filter footprint cannot reach
+// the patch, and replays each remaining pixel's sample run front to back: 64 samples are fetched with
+// one coalesced load (lane i = sample i; the log is [lane][sample]), the owning lane derives what
+// ImageBlock::put derives once per sample (lo, clipped extent, the discretised x/y weights,
+// imageblock.cpp:114-146) and parks the weights in LDS, then the samples are broadcast one by one
+// (v_readlane) and each lane adds value*wy*wx to its texel iff the footprint covers it (:148-161).
+// Every texel therefore sees exactly the reference's sequence of float32 additions; there are no
+// atomics and no cross-lane accumulation, and the dependent chain per texel is register-only.
+#define MIW_FP_SIDE 8                  /* patch = 8 x 8 texels = one wavefront */
+#define MIW_FP_MAXN 8                  /* filter footprint is at most 8 x 8 (radius <= 4) */
+struct PatchArgs { uint32_t patches_x, patches_y; int32_t reach; };
+
+template <bool wide>
+__global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles) {
+    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
+    __shared__ float s_w[64 * 2 * MIW_FP_MAXN];              // per staged sample: wx[8], wy[8]
+    const uint32_t l = threadIdx.x;
+    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
+    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
+    const int tx = ptx0 + (int) (l & 7u), ty = pty0 + (int) (l >> 3);
+    if (l < 32) s_lut[l] = F.lut[l];
+    __syncthreads();
+
+    // pixels (block-local) whose samples can reach this patch
+    int x0 = ptx0 - F.border - PA.reach, x1 = ptx0 + MIW_FP_SIDE - 1 - F.border + PA.reach,
+        y0 = pty0 - F.border - PA.reach, y1 = pty0 + MIW_FP_SIDE - 1 - F.border + PA.reach;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > g.bw - 1) x1 = g.bw - 1;
+    if (y1 > g.bh - 1) y1 = g.bh - 1;
+
+    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
+    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
+    if (n > MIW_FP_MAXN) n = MIW_FP_MAXN;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+    const uint32_t bs2 = 1u << A.bs2_log2;
+
+    for (uint32_t q = 0; q < bs2; ++q) {                     // wave-uniform scan in Morton order
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        if ((int) x < x0 || (int) x > x1 || (int) y < y0 || (int) y > y1) continue;
+        const uint32_t lane = (tile << A.bs2_log2) + q;
+        const uint32_t count = (uint32_t) __builtin_amdgcn_readfirstlane((int) A.st[lane].w);
+        const F2 *lp = A.log_pos + (size_t) lane * A.spp; const F4 *lv = A.log_val + (size_t) lane * A.spp;
+        for (uint32_t j0 = 0; j0 < count; j0 += 64) {
+            const uint32_t m = count - j0 < 64u ? count - j0 : 64u;
+            // ---- stage: lane i owns sample j0 + i ----
+            F2 p; p.x = __builtin_nanf(""); p.y = 0.f;
+            F4 v; v.x = v.y = v.z = v.w = 0.f;
+            if (l < m) { p = lp[j0 + l]; v = lv[j0 + l]; }
+            int lo_x = 0, lo_y = 0, nx = 0, ny = 0;
+            float wx[MIW_FP_MAXN], wy[MIW_FP_MAXN];
+            for (int i = 0; i < MIW_FP_MAXN; ++i) wx[i] = wy[i] = 0.f;
+            if (p.x == p.x) {                                // not a rejected sample (imageblock.cpp:98-108)
+                const float posx = p.x - kx, posy = p.y - ky;                        // :114
+                if (wide) {
+                    lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
+                    if (lo_x < 0) lo_x = 0;
+                    if (lo_y < 0) lo_y = 0;
+                    int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
+                    if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
+                    if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
+                    const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
+                    for (int i = 0; i < MIW_FP_MAXN; ++i) {
+                        if (i < n) {
+                            int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
+                                iy = (int) abs_((base_y + (float) i) * F.scale_factor);
+                            if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
+                            if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
+                            wx[i] = s_lut[ix]; wy[i] = s_lut[iy];
+                        }
+                    }
+                    nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;   // texels enabled by `y <= hi_y`, `x <= hi_x`
+                    if (nx > n) nx = n;
+                    if (ny > n) ny = n;
+                    if (nx < 0) nx = 0;
+                    if (ny < 0) ny = 0;
+                } else {                                     // box filter, :163-170: one texel, weight 1
+                    lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
+                    const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
+                    nx = ny = in ? 1 : 0; wx[0] = wy[0] = 1.f;
+                    if (!in) lo_x = lo_y = 0;
+                }
+            }
+            __syncthreads();                                 // previous chunk's weights fully consumed
+            for (int i = 0; i < MIW_FP_MAXN; ++i) { s_w[l * 16 + i] = wx[i]; s_w[l * 16 + 8 + i] = wy[i]; }
+            __syncthreads();
+            const int pk_lo = lo_x | (lo_y << 16), pk_n = nx | (ny << 8);
+            // ---- replay: this pixel's samples back to back, four per trip ----
+            // Lanes the footprint does not cover add value * 0 (= +-0: leaves a finite sum unchanged), which
+            // keeps the trip branch-free; staged slots >= m carry nx = ny = 0 and value 0.
+            const uint32_t m4 = (m + 3u) & ~3u;
+            for (uint32_t s0 = 0; s0 < m4; s0 += 4) {
+                float w[4], vx[4], vy[4], vz[4], va[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sl = (int) (s0 + k);
+                    const int slo = __builtin_amdgcn_readlane(pk_lo, sl), sn = __builtin_amdgcn_readlane(pk_n, sl);
+                    const int xr = tx - (slo & 0xffff), yr = ty - (slo >> 16);
+                    const bool hit = (uint32_t) xr < (uint32_t) (sn & 0xff) && (uint32_t) yr < (uint32_t) (sn >> 8);
+                    const float wk = s_w[sl * 16 + 8 + (yr & 7)] * s_w[sl * 16 + (xr & 7)];            // wy * wx, :155
+                    w[k] = hit ? wk : 0.f;
+                    vx[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.x), sl));
+                    vy[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.y), sl));
+                    vz[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.z), sl));
+                    va[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.w), sl));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (wide) { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += 1.f * w[k]; }
+                    else      { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += w[k]; }
+                }
+            }
+        }
+    }
+    if (tx < g.size_x && ty < g.size_y) {
+        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
+    }
+}
+
+// ---- fast form of step 1 for filters whose footprint is at most 4 x 4 texels (radius <= 2: box, tent,
+// gaussian, mitchell, catmullrom) and blocks of at most 127 bordered texels a side ----
+//
+// k_film_blocks spends one wave-iteration of all 64 texel lanes on every sample of every pixel in reach of
+// the 8x8 patch (144 pixels for 64 texels), although a sample touches 16 texels: 6 % of the lane-iterations add
+// anything. The fast form splits the work in two:
+//   k_film_pack   once per SAMPLE: everything ImageBlock::put derives from the position alone (lo, the clipped
+//                 extent, the discretised weight indices, imageblock.cpp:114-146) is packed into the 8 bytes the
+//                 position occupied in the log: per axis lo (7 bits) | extent (3) | 4 x LUT index (5 each).
+//                 The same pass records, per pixel, the union of its samples' footprints (block texels).
+//   k_film_groups once per (texel GROUP, sample): a wavefront still owns an 8x8 patch, one texel per lane,
+//                 accumulators in registers, but its lanes form independent groups of GW x GH texels. Each
+//                 group walks ITS OWN Morton-ordered list of the pixels whose footprint union overlaps the
+//                 group (25 pixels for a 2x2 group instead of 144), so one wave-iteration serves 64 / (GW*GH)
+//                 (group, sample) pairs; a lane decodes the packed record with a handful of integer ops.
+//                 Sample runs are staged through LDS with coalesced loads, 16 samples per group at a time.
+// Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order,
+// each pixel's samples front to back), so the tiles are bit-identical to k_film_blocks'.
+#define MIW_PK_LO_BITS 7
+#define MIW_PK_MAX_SIDE 127
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+
+// one wavefront per pixel (lane i = samples i, i + 64, ...); boxes[lane] = min lo_x | max hi_x << 8 | min lo_y << 16 | max hi_y << 24
+template <bool wide>
+__global__ __launch_bounds__(256) void k_film_pack(FilmRec F, BlockReplayArgs A, uint32_t n_lanes, uint32_t *boxes) {
+    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+    if (lane >= n_lanes) return;
+    const uint32_t tile = lane >> A.bs2_log2, q = lane & ((1u << A.bs2_log2) - 1u);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    uint32_t x, y;
+    morton_decode2(q, x, y);
+    uint32_t count = A.st[lane].w;
+    if ((int) x >= g.bw || (int) y >= g.bh) count = 0;
+    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
+    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
+    if (n > 4) n = 4;
+    uint2 *recs = reinterpret_cast<uint2 *>(const_cast<F2 *>(A.log_pos)) + (size_t) lane * A.spp;
+    uint32_t min_x = 127u, max_x = 0u, min_y = 127u, max_y = 0u;
+    for (uint32_t j = l; j < count; j += 64u) {
+        const F2 p = A.log_pos[(size_t) lane * A.spp + j];
+        uint32_t w0 = 0u, w1 = 0u;
+        if (p.x == p.x) {                                    // not a rejected sample (imageblock.cpp:98-108)
+            const float posx = p.x - kx, posy = p.y - ky;                            // :114
+            int lo_x, lo_y, nx, ny;
+            if (wide) {
+                lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
+                if (lo_x < 0) lo_x = 0;
+                if (lo_y < 0) lo_y = 0;
+                int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
+                if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
+                if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
+                nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;
+                if (nx > n) nx = n;
+                if (ny > n) ny = n;
+                if (nx < 0) nx = 0;
+                if (ny < 0) ny = 0;
+                const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n) {
+                        int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
+                            iy = (int) abs_((base_y + (float) i) * F.scale_factor);
+                        if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
+                        if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
+                        w0 |= (uint32_t) ix << (10 + 5 * i); w1 |= (uint32_t) iy << (10 + 5 * i);
+                    }
+                }
+            } else {                                         // box filter, :163-170: one texel, weight 1
+                lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
+                const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
+                nx = ny = in ? 1 : 0;
+                if (!in) lo_x = lo_y = 0;
+            }
+            if (nx == 0 || ny == 0) { nx = ny = 0; lo_x = lo_y = 0; w0 = w1 = 0u; }
+            else {
+                min_x = min(min_x, (uint32_t) lo_x); max_x = max(max_x, (uint32_t) (lo_x + nx - 1));
+                min_y = min(min_y, (uint32_t) lo_y); max_y = max(max_y, (uint32_t) (lo_y + ny - 1));
+            }
+            w0 |= (uint32_t) lo_x | ((uint32_t) nx << MIW_PK_LO_BITS);
+            w1 |= (uint32_t) lo_y | ((uint32_t) ny << MIW_PK_LO_BITS);
+        }
+        recs[j] = make_uint2(w0, w1);
+    }
+    min_x = wave_min_u32(min_x); max_x = wave_max_u32(max_x); min_y = wave_min_u32(min_y); max_y = wave_max_u32(max_y);
+    if (l == 0) boxes[lane] = min_x | (max_x << 8) | (min_y << 16) | (max_y << 24);
+}
+
+#define MIW_FG_CHUNK 16                /* samples per group staged per trip */
+template <int GW, int GH, bool wide>
+__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, const uint32_t *boxes, float *tiles) {
+    constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group, groups, groups per patch row
+    constexpr int LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
+    static_assert(PASSES >= 1, "group too large");
+    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
+    __shared__ unsigned short s_list[NG][LCAP];
+    __shared__ uint32_t s_m[NG];
+    __shared__ uint2 s_rec[NG][MIW_FG_CHUNK + 1];
+    __shared__ float4 s_val[NG][MIW_FG_CHUNK + 1];
+    const uint32_t l = threadIdx.x;
+    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
+    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
+    const uint32_t h = l / GL, li = l % GL;
+    const int tx = ptx0 + (int) (h % GPX) * GW + (int) (li % GW), ty = pty0 + (int) (h / GPX) * GH + (int) (li / GW);
+    if (l < MIW_FILTER_RESOLUTION + 1) s_lut[l] = F.lut[l];
+
+    // ---- per group: the pixels whose footprint union overlaps the group, in Morton order ----
+    const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
+    uint32_t fill[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) fill[i] = 0;
+    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
+        const uint32_t q = q0 + l;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        uint32_t box = 127u | (127u << 16);                  // empty
+        if (q < bs2 && (int) x < g.bw && (int) y < g.bh) box = boxes[lane0 + q];
+        const int bx0 = (int) (box & 255u), bx1 = (int) ((box >> 8) & 255u), by0 = (int) ((box >> 16) & 255u), by1 = (int) (box >> 24);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int gx0 = ptx0 + (i % GPX) * GW, gy0 = pty0 + (i / GPX) * GH;
+            // window of k_film_blocks (bounds the list) and the exact footprint test
+            const bool in = (int) x >= gx0 - F.border - PA.reach && (int) x <= gx0 + GW - 1 - F.border + PA.reach &&
+                            (int) y >= gy0 - F.border - PA.reach && (int) y <= gy0 + GH - 1 - F.border + PA.reach &&
+                            bx0 <= gx0 + GW - 1 && bx1 >= gx0 && by0 <= gy0 + GH - 1 && by1 >= gy0;
+            const unsigned long long m = __ballot(in);
+            if (in) {
+                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
+                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
+            }
+            fill[i] += (uint32_t) __popcll(m);
+        }
+    }
+    uint32_t max_m = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
+        if (l == 0) s_m[i] = m;
+        max_m = m > max_m ? m : max_m;
+    }
+    __syncthreads();
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+    const uint2 *recs = reinterpret_cast<const uint2 *>(A.log_pos);
+    const uint32_t my_m = s_m[h];
+    for (uint32_t k = 0; k < max_m; ++k) {
+        // staging rows of this step: pass i loads group i * 4 + l / 16, sample l % 16
+        size_t row[PASSES]; uint32_t cnt[PASSES];
+        uint32_t step_max = 0;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
+            cnt[i] = 0; row[i] = 0;
+            if (k < s_m[hs]) {
+                const uint32_t lane = lane0 + s_list[hs][k];
+                cnt[i] = A.st[lane].w; row[i] = (size_t) lane * A.spp;
+            }
+            step_max = cnt[i] > step_max ? cnt[i] : step_max;
+        }
+        step_max = wave_max_u32(step_max);
+        (void) my_m;
+        // the next chunk's loads are in flight while the current one is replayed
+        const uint32_t jj = l & 15u;
+        uint2 nr[PASSES]; float4 nv[PASSES];
+        auto fetch = [&](uint32_t j0) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                nr[i] = make_uint2(0u, 0u); nv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + jj < cnt[i]) {
+                    nr[i] = recs[row[i] + j0 + jj];
+                    const F4 t = A.log_val[row[i] + j0 + jj];
+                    nv[i] = make_float4(t.x, t.y, t.z, t.w);
+                }
+            }
+        };
+        fetch(0);
+        for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
+                s_rec[hs][jj] = nr[i]; s_val[hs][jj] = nv[i];
+            }
+            if (j0 + MIW_FG_CHUNK < step_max) fetch(j0 + MIW_FG_CHUNK);
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < MIW_FG_CHUNK; ++s) {
+                const uint2 r = s_rec[h][s];
+                const float4 v = s_val[h][s];
+                const int xr = tx - (int) (r.x & 127u), yr = ty - (int) (r.y & 127u);
+                const bool hit = (uint32_t) xr < ((r.x >> MIW_PK_LO_BITS) & 7u) && (uint32_t) yr < ((r.y >> MIW_PK_LO_BITS) & 7u);
+                float w = 1.f;
+                if (wide) w = s_lut[(r.y >> (10 + 5 * (yr & 3))) & 31u] * s_lut[(r.x >> (10 + 5 * (xr & 3))) & 31u];   // wy * wx, :155
+                if (hit) { acc0 += v.x * w; acc1 += v.y * w; acc2 += v.z * w; acc3 += v.w * w; acc4 += w; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tx < g.size_x && ty < g.size_y) {
+        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
+    }
+}
+
+// step 2: every film texel sums the block tiles covering it, ascending block id
+__global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64, int accumulate) {
+    int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;
+    if (fx >= F.crop_w || fy >= F.crop_h) return;
+    float v[MIW_FILM_CHANNELS];
+    size_t o = ((size_t) fy * F.crop_w + fx) * MIW_FILM_CHANNELS;
+    if (accumulate) for (int k = 0; k < MIW_FILM_CHANNELS; ++k) v[k] = out64 ? (float) out64[o + k] : out32[o + k];
+    film_merge_texel(F, A, tiles, fx, fy, v, accumulate != 0);
+    for (int k = 0; k < MIW_FILM_CHANNELS; ++k) {
+        if (out64) out64[o + k] = (double) v[k]; else out32[o + k] = v[k];
+    }
+}

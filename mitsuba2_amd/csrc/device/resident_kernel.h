@@ -1,0 +1,136 @@
+// Plan 2 (resident): k_init_pixels, the shared pixel queue and k_path_resident (path / direct integrators).
+// Part of the single translation unit csrc/miwave.hip (included there, in this order; not a stand-alone header).
+// ---- the resident plan -----------------------------------------------------------------
+// k_init_pixels: pixel <-> lane map and PCG32 seeding only (a pixel carries nothing else
+// between two camera samples).
+__global__ __launch_bounds__(MIW_BLOCK) void k_init_pixels(RenderParams P, U4 *st_out, uint32_t *pixel_out, InitArgs A) {
+    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= P.n_lanes) return;
+    uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
+    uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
+    uint32_t x, y;
+    morton_decode2(i, x, y);                                   // integrator.cpp:200
+    int32_t bw = P.film.crop_w - (int32_t) (bx * A.bs), bh = P.film.crop_h - (int32_t) (by * A.bs);
+    if (bw > (int32_t) A.bs) bw = (int32_t) A.bs;
+    if (bh > (int32_t) A.bs) bh = (int32_t) A.bs;
+    if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
+        U4 st; st.x = st.y = 0; st.z = LF_DONE; st.w = 0;
+        st_out[lane] = st; pixel_out[lane] = 0;
+        return;
+    }
+    uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
+    pixel_out[lane] = px | (py << 16);
+    st_out[lane] = lane_seed_state(A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i);   // :198
+}
+
+// k_path_resident: one thread = one pixel, advanced from its current sample to `sample_end`.
+// Path state, ray, hit record and the pending emitter contribution never leave registers;
+// the geometry is swept / walked in LDS (trace_one); HBM sees 20 B of pixel state per launch
+// and the 24 B/sample log (or the film atomics).
+struct TileArgs {               // film_mode 2 in the resident plan; side == 0: splat straight into `accum`
+    const uint32_t *tile_list; uint32_t blocks_x, bs, bs2_log2;
+    uint32_t side;              // 16 + 2 * margin, margin = max(filter border, floor(radius + .5))
+    uint32_t geom16;            // uint4 slots of dynamic LDS in front of the tile
+};
+
+// Log mode feeds the lanes from ONE shared pixel queue (`next_pixel`): a lane that finishes its pixel takes
+// the next unclaimed one inside the iteration loop (wavefront-aggregated: ballot + one atomic per wave per
+// refill), so no lane waits for the slowest pixel of its wavefront and the launch drains evenly. The grid is
+// sized to the machine; workgroups that start late find the queue empty and retire.
+struct QueueWork {
+    const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane;
+    __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
+        for (;;) {
+            // claim: ballot over the lanes asking, one atomic for all of them
+            const unsigned long long b = __ballot(1);
+            const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+            uint32_t base = 0;
+            if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
+            base = (uint32_t) __shfl((int) base, (int) leader, 64);
+            lane = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
+            if (lane >= n_lanes) return false;
+            st = Q->st[lane];
+            if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
+            pixel = Q->pixel[lane];
+            return true;
+        }
+    }
+    __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
+    __device__ __forceinline__ void put(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) {
+        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp;
+        sink(0u, sample_idx, pos, aovs);
+    }
+};
+
+// Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
+// Integ: which SamplingIntegrator::sample the pixel loop runs (path.h / direct.h).
+template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH>
+__global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+                                                               TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
+#endif
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    // workgroup film tile
+    double *tile = reinterpret_cast<double *>(smem + T.geom16);
+    int tile_x0 = 0, tile_y0 = 0;
+    if (!UseLog && T.side) {
+        const uint32_t lane0 = blockIdx.x * blockDim.x, t = lane0 >> T.bs2_log2, q0 = lane0 & ((1u << T.bs2_log2) - 1u);
+        const uint32_t b = T.tile_list ? T.tile_list[t] : t;
+        uint32_t qx, qy;
+        morton_decode2(q0, qx, qy);
+        const int margin = (int) (T.side - 16u) / 2;
+        tile_x0 = (int) ((b % T.blocks_x) * T.bs + qx) - margin;
+        tile_y0 = (int) ((b / T.blocks_x) * T.bs + qy) - margin;
+        for (uint32_t i = threadIdx.x; i < T.side * T.side * MIW_FILM_CHANNELS; i += blockDim.x) tile[i] = 0.0;
+        __syncthreads();
+    }
+    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
+        trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
+    };
+    if (UseLog) {
+        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
+        if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
+        else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
+    } else if (lane < P.n_lanes) {
+        U4 st = Q.st[lane];
+        if (!(st.z & LF_DONE)) {
+            const uint32_t pixel = Q.pixel[lane];
+            if (T.side) {
+                TileAdd add; add.tile = tile; add.x0 = tile_x0; add.y0 = tile_y0; add.side = (int) T.side;
+                SplatXYSink<TileAdd> sink; sink.film = &P.film; sink.add = add;
+                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
+            } else {
+                FilmAdd add; add.accum = accum;
+                SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
+                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
+            }
+            Q.st[lane] = st;
+        }
+    }
+    if (!UseLog && T.side) {                                     // flush the tile: one f64 atomic per touched slot
+        __syncthreads();
+        const int n = (int) (T.side * T.side);
+        for (int i = (int) threadIdx.x; i < n * MIW_FILM_CHANNELS; i += (int) blockDim.x) {
+            const double v = tile[i];
+            if (v == 0.0) continue;
+            const int texel = i / MIW_FILM_CHANNELS, k = i - texel * MIW_FILM_CHANNELS;
+            const int fx = tile_x0 + texel % (int) T.side, fy = tile_y0 + texel / (int) T.side;
+            unsafeAtomicAdd(accum + ((size_t) fy * P.film.crop_w + fx) * MIW_FILM_CHANNELS + k, v);
+        }
+    }
+    unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
+    if ((threadIdx.x & 63) == 0) {
+        Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
+        if (a) atomicAdd(&shard->segments, a);
+        if (b) atomicAdd(&shard->samples, b);
+        if (c) atomicAdd(&shard->shadow_rays, c);
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) if (b_[i]) atomicAdd(&g_sections[i], b_[i]); }
+#endif
+    }
+}

@@ -1,0 +1,284 @@
+// Scene queries of the device kernels: what a workgroup stages in LDS (BVH top, triangle packets, leaf boxes), the
+// fast slab test, the LDS-stack BVH walk and the paired extension + shadow query of the resident plan (trace2).
+// Part of the single translation unit csrc/miwave.hip (included there, in this order; not a stand-alone header).
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+
+struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
+    uint32_t nodes_staged;  // first `nodes_staged` BVH nodes (breadth-first = top of tree)
+    uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
+    uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets (+ leaf boxes), no BVH walk
+    uint32_t leaves;        // brute: number of LeafBox records staged behind the packets
+    uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
+    uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
+};
+
+// Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
+struct alignas(16) LeafBox { float lo[3]; uint32_t mask_lo; float hi[3]; uint32_t mask_hi; };   // mask: one bit per triangle of the leaf (leaf order)
+static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
+
+// Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
+struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
+static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
+
+__device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
+    if (cfg.brute) {
+        TriPacket *dst = reinterpret_cast<TriPacket *>(smem);
+        for (uint32_t i = threadIdx.x; i < sc.tri_count; i += blockDim.x) {
+            const Tri &t = sc.tris[i];
+            V3 p0 = ld3(t.p0), e1 = ld3(t.p1) - p0, e2 = ld3(t.p2) - p0;
+            TriPacket k;
+            k.p0[0] = p0.x; k.p0[1] = p0.y; k.p0[2] = p0.z; k.e1[0] = e1.x; k.e1[1] = e1.y; k.e1[2] = e1.z;
+            k.e2[0] = e2.x; k.e2[1] = e2.y; k.e2[2] = e2.z; k.prim = t.prim; k.pad[0] = k.pad[1] = 0;
+            dst[i] = k;
+        }
+        // leaf boxes of the SAH tree behind the packets (k_path_resident's candidate filter)
+        uint4 *dst_b = smem + sc.tri_count * (sizeof(TriPacket) / 16);
+        const uint4 *src_b = reinterpret_cast<const uint4 *>(sc.leaf_boxes);
+        for (uint32_t i = threadIdx.x; i < cfg.leaves * (sizeof(LeafBox) / 16); i += blockDim.x) dst_b[i] = src_b[i];
+        // per-packet vertex bounds grown by accept_pad (shape.h: the accept rule), 24 B each, behind the boxes
+        float *dst_t = reinterpret_cast<float *>(dst_b + cfg.leaves * (sizeof(LeafBox) / 16));
+        const float *src_t = reinterpret_cast<const float *>(sc.tri_bounds);
+        for (uint32_t i = threadIdx.x; i < sc.tri_count * 6u; i += blockDim.x) dst_t[i] = src_t[i];
+        __syncthreads();
+        return;
+    }
+    const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
+    uint32_t n16 = cfg.nodes_staged * (sizeof(BvhNode) / 16);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) smem[i] = src_n[i];
+    const uint4 *src_t = reinterpret_cast<const uint4 *>(sc.tris);
+    uint32_t t16 = cfg.tris_staged * (sizeof(Tri) / 16);
+    uint4 *dst_t = smem + n16;
+    for (uint32_t i = threadIdx.x; i < t16; i += blockDim.x) dst_t[i] = src_t[i];
+    __syncthreads();
+}
+
+// Candidate-box test shared by the tiny-scene filter (trace2) and the stack traversal below: the slab
+// test of bvh.h re-expressed for speed — v_rcp_f32 for 1/d, t = fma(plane, inv_d, -o*inv_d), hardware
+// min/max (v_min3/v_max3). It only has to stay CONSERVATIVE, not bit-reproducible: boxes are padded by
+// 1e-5 x the scene extent (bvh_build.h), orders of magnitude above the rounding differences between the
+// two forms, and every hit is decided by the exact Moeller-Trumbore test.
+struct FastRay { V3 inv_d, neg_o_inv_d; float mint; };
+__device__ __forceinline__ FastRay fast_ray(V3 o, V3 d, float mint) {
+    FastRay r;
+    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
+          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
+          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
+    r.inv_d = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
+    r.mint = mint;
+    return r;
+}
+__device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, const FastRay &r, float tmax_wide, float &tn_out) {
+    float t0x = __builtin_fmaf(lo[0], r.inv_d.x, r.neg_o_inv_d.x), t1x = __builtin_fmaf(hi[0], r.inv_d.x, r.neg_o_inv_d.x),
+          t0y = __builtin_fmaf(lo[1], r.inv_d.y, r.neg_o_inv_d.y), t1y = __builtin_fmaf(hi[1], r.inv_d.y, r.neg_o_inv_d.y),
+          t0z = __builtin_fmaf(lo[2], r.inv_d.z, r.neg_o_inv_d.z), t1z = __builtin_fmaf(hi[2], r.inv_d.z, r.neg_o_inv_d.z);
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    // widened like bvh.h's box_test, plus slack for the fma-form rounding
+    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
+    tn_out = tn;
+    return tn <= tf && tn <= tmax_wide;
+}
+__device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t), 2e-6f, t); }
+
+// Stack traversal of the BVH2 for scenes that do not fit LDS: the per-lane stack lives in LDS
+// (entry-major, one dword per lane per entry: conflict-free), the top of the tree is read from LDS
+// and the rest through L1/L2. Same observable result as bvh_intersect (== brute force, ties to the
+// smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
+// trail walk of bvh.h runs.
+#define MIW_STACK_ENTRIES 32
+#ifndef MIW_TREE_WAVES
+#define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
+#endif
+template <bool AnyHit, bool Analytic, typename NodeAt, typename TriAt>
+__device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
+                                                    V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx) {
+    best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+    const FastRay r = fast_ray(o, d, mint);
+    float tmax = maxt;
+    int32_t cur = 0, sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode &n = node_at(cur);
+            float tn0, tn1;
+            const float wide = widen(tmax);
+            const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
+            const int32_t c0 = n.child0, c1 = n.child1;
+            if (h0 && h1) {
+                const bool second_first = tn1 < tn0;
+                stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
+                cur = second_first ? c1 : c0;
+                continue;
+            }
+            if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
+        } else {
+            const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const Tri &tr = tri_at(first + i);
+                float t, u, v;
+                if (prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v)) {
+                    if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
+                    if (t < best.t || (t == best.t && tr.prim < best.prim)) {
+                        best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
+                        tmax = t;
+                    }
+                }
+            }
+        }
+        if (sp == 0) return best.tri != MIW_MISS;
+        --sp; cur = stack[sp * MIW_BLOCK];
+    }
+}
+
+// per-packet vertex bounds of a tiny scene, staged behind the leaf boxes (stage_to_lds)
+__device__ __forceinline__ const TriBounds *packet_bounds(const SceneView &sc, TraceLds cfg, const uint4 *smem) {
+    return reinterpret_cast<const TriBounds *>(smem + sc.tri_count * (sizeof(TriPacket) / 16) + cfg.leaves * (sizeof(LeafBox) / 16));
+}
+// Tiny scenes without a candidate filter: every lane sweeps every packet — wave-uniform LDS addresses
+// (broadcast reads, no bank conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
+template <bool AnyHit>
+__device__ __forceinline__ bool trace_brute(const SceneView &sc, TraceLds cfg, const uint4 *smem, V3 o, V3 d, float mint, float maxt, Hit &h) {
+    const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+    const TriBounds *tb = packet_bounds(sc, cfg, smem);
+    h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
+    bool any = false;
+    for (uint32_t i = 0; i < sc.tri_count; ++i) {
+        const TriPacket &k = pk[i];
+        float t, u, v;
+        bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v) &&
+                   hit_in_bounds(tb[i], o, d, t);
+        if (AnyHit) {
+            any = any || hit;
+        } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
+            h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim;
+        }
+    }
+    if (AnyHit) { if (any) { h.t = 0.f; h.tri = 0; } return any; }
+    return h.tri != MIW_MISS;
+}
+
+template <bool AnyHit, bool Analytic = true>
+__device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
+                                          V3 o, V3 d, float mint, float maxt, Hit &h) {
+    if (cfg.brute) return trace_brute<AnyHit>(sc, cfg, smem, o, d, mint, maxt, h);
+    RayPrep r = ray_prepare(o, d, mint, maxt);
+    const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
+    const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
+    const BvhNode *gnodes = sc.nodes;
+    const Tri *gtris = sc.tris;
+    if (cfg.nodes_staged >= sc.node_count && cfg.tris_staged >= sc.tri_count) {
+        // whole scene is LDS resident: pure ds_read traversal
+        auto node_at = [lnodes](int32_t i) -> const BvhNode & { return lnodes[i]; };
+        auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
+    } else {
+        uint32_t ns = cfg.nodes_staged;
+        auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
+            return (uint32_t) i < ns ? lnodes[i] : gnodes[i];
+        };
+        auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
+        if (cfg.stack) {
+            int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
+            return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, prim_ctx(sc));
+        }
+        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
+    }
+}
+
+// The resident plan's paired query: extension ray E and shadow ray S leave the same vertex
+// (same origin, same mint). Tiny scenes (packets in LDS) are resolved in two phases:
+//   1. a wave-uniform pass over the SAH leaves' padded boxes (broadcast LDS reads, the
+//      conservative slab test of bvh.h — a triangle Moeller-Trumbore accepts is never culled)
+//      leaves every lane two 64-bit candidate masks, one bit per triangle;
+//   2. every lane pops its own candidates (E's first, then S's) and runs the exact
+//      Moeller-Trumbore test on that packet (per-lane LDS address). The wave iterates
+//      max-over-lanes(candidates) times instead of 2 x tri_count.
+// Results are those of the full sweep: closest hit with ties to the smaller primitive id,
+// "any triangle passes" for S.
+// `Tiny` selects the code that is compiled in: the two-phase LDS query (tiny scenes) or the tree walks —
+// one kernel per scene class keeps each one's register budget (occupancy) to what it needs.
+template <int Tiny, bool Analytic = true>
+__device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
+                                       V3 o, float mint, V3 dE, float maxtE, bool hasE,
+                                       V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
+    Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
+    bool occ = false;
+    if (Tiny && cfg.leaves) {
+        // candidate masks: 32 bits when the scene has <= 32 triangles (Tiny == 2), else 64
+        using Mask = typename std::conditional<Tiny == 2, uint32_t, unsigned long long>::type;
+        auto lowest = [](Mask m) -> uint32_t {
+            return Tiny == 2 ? (uint32_t) __ffs((int) (uint32_t) m) - 1u : (uint32_t) __ffsll((long long) m) - 1u;
+        };
+        const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
+        const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
+        const TriBounds *tb = packet_bounds(sc, cfg, smem);
+        const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
+        const float wideE = widen(maxtE), wideS = widen(maxtS);
+        Mask mE = 0, mS = 0;
+        for (uint32_t i = 0; i < cfg.leaves; ++i) {
+            const LeafBox &b = lb[i];                              // wave-uniform address
+            const Mask bits = Tiny == 2 ? (Mask) b.mask_lo : (Mask) (b.mask_lo | ((unsigned long long) b.mask_hi << 32));
+            float tn;
+            if (box_test_fast(b.lo, b.hi, rE, wideE, tn)) mE |= bits;
+            if (box_test_fast(b.lo, b.hi, rS, wideS, tn)) mS |= bits;
+        }
+        if (!hasE) mE = 0;
+        if (!hasS) mS = 0;
+        MIW_SECTION(1);
+        while (mE != 0) {                                      // closest hit of E over its candidates
+            const uint32_t i = lowest(mE);
+            mE &= mE - 1;
+            const TriPacket &k = pk[i];
+            float t, u, v;
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
+                (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
+        }
+        MIW_SECTION(2);
+        uint32_t s_tri = 0; float s_t = 0.f;
+        while (mS != 0) {                                      // any hit of S
+            const uint32_t i = lowest(mS);
+            mS &= mS - 1;
+            const TriPacket &k = pk[i];
+            float t, u, v;
+            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) {
+                occ = true; mS = 0; s_tri = i; s_t = t;
+            }
+        }
+        // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
+        // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
+        // through the full sweep with the rule inside, which is what the rule means.
+        if (h.tri != MIW_MISS && !hit_in_bounds(tb[h.tri], o, dE, h.t)) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (occ && !hit_in_bounds(tb[s_tri], o, dS, s_t)) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+        MIW_SECTION(3);
+#if defined(MIW_VERIFY_FILTER)
+        {   // debug builds: every filtered query against the full sweep; mismatching rays go to g_verify
+            Hit hb; bool occ_b = false;
+            if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, hb); else { hb.tri = MIW_MISS; hb.t = MIW_INFINITY; }
+            if (hasS) { Hit hs; occ_b = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+            const bool badE = hasE && (hb.tri != h.tri || f2u(hb.t) != f2u(h.t)), badS = hasS && occ_b != occ;
+            if (badE || badS) {
+                const uint32_t k = atomicAdd(&g_verify_n, 1u);
+                if (k < 16u) {
+                    float *r = g_verify + k * 16;
+                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint;
+                    const V3 d = badE ? dE : dS;
+                    r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = badE ? maxtE : maxtS;
+                    r[8] = badE ? 1.f : 2.f; r[9] = u2f(badE ? hb.tri : (uint32_t) occ_b); r[10] = u2f(badE ? h.tri : (uint32_t) occ);
+                    r[11] = hb.t; r[12] = h.t;
+                }
+            }
+        }
+#endif
+    } else if (Tiny) {                                         // tiny scene, filter switched off (MI_BVH_NO_LEAF_FILTER)
+        if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+    } else {
+        if (hasE) trace_one<false, Analytic>(sc, cfg, smem, o, dE, mint, maxtE, h);
+        if (hasS) { Hit hs; occ = trace_one<true, Analytic>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
+    }
+    hit_out.x = h.t; hit_out.y = h.u; hit_out.z = h.v; hit_out.w = u2f(h.tri);
+    occ_out = occ;
+}

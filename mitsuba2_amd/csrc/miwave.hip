@@ -1,18 +1,12 @@
-// libmiwave.so — gfx950 kernels and the C ABI declared in include/miwave.h.
-//
-// Kernel set (one launch each per wavefront iteration, all over lane-indexed
-// SoA-of-16-byte-field queues in HBM, see miw/path.h):
-//   k_init_lanes     render_block prologue: pixel <-> lane map, PCG32 seeding,
-//                    first camera ray          (integrator.cpp:181-261)
-//   k_trace<closest> Scene::ray_intersect_preliminary over the ray queue
-//   k_trace<any>     Scene::ray_test over the shadow queue
-//   k_shade          one depth-loop iteration of PathIntegrator::sample, plus
-//                    ImageBlock::put + regeneration when a sample ends
-//   k_film_resolve   float64 accumulators -> float32 XYZAW film
-//   k_trace_soa      the public mi_trace entry (caller's SoA rays)
-//   k_eval           leaf-function known-answer evaluation (mi_eval)
-// The BVH (+ all triangles when they fit) is staged in LDS by every trace
-// workgroup; traversal is stackless (miw/bvh.h).
+// libmiwave.so — gfx950 kernels and the C ABI declared in include/miwave.h. One translation unit:
+//   miw/*.h                      leaf arithmetic shared with the CPU checker (float32, fixed operation order)
+//   device/trace.h               LDS staging, packet sweep + leaf filter, LDS-stack BVH walk, trace2
+//   device/wavefront_kernels.h   plan 1: k_init_lanes, k_trace<closest|any>, k_shade over SoA queues in HBM
+//   device/resident_kernel.h     plan 2: k_init_pixels, the pixel queue, k_path_resident (path / direct)
+//   device/film_kernels.h        k_film_resolve, k_film_blocks, k_film_pack, k_film_groups, k_film_merge
+//   device/eval_kernels.h        k_trace_soa (mi_trace), k_eval (mi_eval)
+//   lbvh_device.h                device LBVH builder
+// followed here by the host side: context, scene upload, BVH build, mi_trace, mi_render, mi_eval, mi_selftest.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,1082 +63,11 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #define MIW_BRUTE_MAX_LEAF 2        /* triangles per leaf box of the resident plan's candidate filter */
 #define MIW_BRUTE_MAX_TRIS 64       /* <= this many triangles: LDS brute-force sweep instead of the BVH */
 
-// ---------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------
-
-struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
-    uint32_t nodes_staged;  // first `nodes_staged` BVH nodes (breadth-first = top of tree)
-    uint32_t tris_staged;   // first `tris_staged` triangles (all of them or none)
-    uint32_t brute;         // 1: tiny scene — LDS holds edge-form triangle packets (+ leaf boxes), no BVH walk
-    uint32_t leaves;        // brute: number of LeafBox records staged behind the packets
-    uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
-    uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
-};
-
-// Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
-struct alignas(16) LeafBox { float lo[3]; uint32_t mask_lo; float hi[3]; uint32_t mask_hi; };   // mask: one bit per triangle of the leaf (leaf order)
-static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
-
-// Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
-struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
-static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
-
-__device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
-    if (cfg.brute) {
-        TriPacket *dst = reinterpret_cast<TriPacket *>(smem);
-        for (uint32_t i = threadIdx.x; i < sc.tri_count; i += blockDim.x) {
-            const Tri &t = sc.tris[i];
-            V3 p0 = ld3(t.p0), e1 = ld3(t.p1) - p0, e2 = ld3(t.p2) - p0;
-            TriPacket k;
-            k.p0[0] = p0.x; k.p0[1] = p0.y; k.p0[2] = p0.z; k.e1[0] = e1.x; k.e1[1] = e1.y; k.e1[2] = e1.z;
-            k.e2[0] = e2.x; k.e2[1] = e2.y; k.e2[2] = e2.z; k.prim = t.prim; k.pad[0] = k.pad[1] = 0;
-            dst[i] = k;
-        }
-        // leaf boxes of the SAH tree behind the packets (k_path_resident's candidate filter)
-        uint4 *dst_b = smem + sc.tri_count * (sizeof(TriPacket) / 16);
-        const uint4 *src_b = reinterpret_cast<const uint4 *>(sc.leaf_boxes);
-        for (uint32_t i = threadIdx.x; i < cfg.leaves * (sizeof(LeafBox) / 16); i += blockDim.x) dst_b[i] = src_b[i];
-        // per-packet vertex bounds grown by accept_pad (shape.h: the accept rule), 24 B each, behind the boxes
-        float *dst_t = reinterpret_cast<float *>(dst_b + cfg.leaves * (sizeof(LeafBox) / 16));
-        const float *src_t = reinterpret_cast<const float *>(sc.tri_bounds);
-        for (uint32_t i = threadIdx.x; i < sc.tri_count * 6u; i += blockDim.x) dst_t[i] = src_t[i];
-        __syncthreads();
-        return;
-    }
-    const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
-    uint32_t n16 = cfg.nodes_staged * (sizeof(BvhNode) / 16);
-    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) smem[i] = src_n[i];
-    const uint4 *src_t = reinterpret_cast<const uint4 *>(sc.tris);
-    uint32_t t16 = cfg.tris_staged * (sizeof(Tri) / 16);
-    uint4 *dst_t = smem + n16;
-    for (uint32_t i = threadIdx.x; i < t16; i += blockDim.x) dst_t[i] = src_t[i];
-    __syncthreads();
-}
-
-// Candidate-box test shared by the tiny-scene filter (trace2) and the stack traversal below: the slab
-// test of bvh.h re-expressed for speed — v_rcp_f32 for 1/d, t = fma(plane, inv_d, -o*inv_d), hardware
-// min/max (v_min3/v_max3). It only has to stay CONSERVATIVE, not bit-reproducible: boxes are padded by
-// 1e-5 x the scene extent (bvh_build.h), orders of magnitude above the rounding differences between the
-// two forms, and every hit is decided by the exact Moeller-Trumbore test.
-struct FastRay { V3 inv_d, neg_o_inv_d; float mint; };
-__device__ __forceinline__ FastRay fast_ray(V3 o, V3 d, float mint) {
-    FastRay r;
-    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
-          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
-          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
-    r.inv_d = v3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
-    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
-    r.mint = mint;
-    return r;
-}
-__device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, const FastRay &r, float tmax_wide, float &tn_out) {
-    float t0x = __builtin_fmaf(lo[0], r.inv_d.x, r.neg_o_inv_d.x), t1x = __builtin_fmaf(hi[0], r.inv_d.x, r.neg_o_inv_d.x),
-          t0y = __builtin_fmaf(lo[1], r.inv_d.y, r.neg_o_inv_d.y), t1y = __builtin_fmaf(hi[1], r.inv_d.y, r.neg_o_inv_d.y),
-          t0z = __builtin_fmaf(lo[2], r.inv_d.z, r.neg_o_inv_d.z), t1z = __builtin_fmaf(hi[2], r.inv_d.z, r.neg_o_inv_d.z);
-    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
-    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-    // widened like bvh.h's box_test, plus slack for the fma-form rounding
-    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
-    tn_out = tn;
-    return tn <= tf && tn <= tmax_wide;
-}
-__device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t), 2e-6f, t); }
-
-// Stack traversal of the BVH2 for scenes that do not fit LDS: the per-lane stack lives in LDS
-// (entry-major, one dword per lane per entry: conflict-free), the top of the tree is read from LDS
-// and the rest through L1/L2. Same observable result as bvh_intersect (== brute force, ties to the
-// smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
-// trail walk of bvh.h runs.
-#define MIW_STACK_ENTRIES 32
-#ifndef MIW_TREE_WAVES
-#define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
-#endif
-template <bool AnyHit, bool Analytic, typename NodeAt, typename TriAt>
-__device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
-                                                    V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx) {
-    best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
-    const FastRay r = fast_ray(o, d, mint);
-    float tmax = maxt;
-    int32_t cur = 0, sp = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const BvhNode &n = node_at(cur);
-            float tn0, tn1;
-            const float wide = widen(tmax);
-            const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
-            const int32_t c0 = n.child0, c1 = n.child1;
-            if (h0 && h1) {
-                const bool second_first = tn1 < tn0;
-                stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
-                cur = second_first ? c1 : c0;
-                continue;
-            }
-            if (h0 || h1) { cur = h0 ? c0 : c1; continue; }
-        } else {
-            const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const Tri &tr = tri_at(first + i);
-                float t, u, v;
-                if (prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v)) {
-                    if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
-                    if (t < best.t || (t == best.t && tr.prim < best.prim)) {
-                        best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
-                        tmax = t;
-                    }
-                }
-            }
-        }
-        if (sp == 0) return best.tri != MIW_MISS;
-        --sp; cur = stack[sp * MIW_BLOCK];
-    }
-}
-
-// per-packet vertex bounds of a tiny scene, staged behind the leaf boxes (stage_to_lds)
-__device__ __forceinline__ const TriBounds *packet_bounds(const SceneView &sc, TraceLds cfg, const uint4 *smem) {
-    return reinterpret_cast<const TriBounds *>(smem + sc.tri_count * (sizeof(TriPacket) / 16) + cfg.leaves * (sizeof(LeafBox) / 16));
-}
-// Tiny scenes without a candidate filter: every lane sweeps every packet — wave-uniform LDS addresses
-// (broadcast reads, no bank conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
-template <bool AnyHit>
-__device__ __forceinline__ bool trace_brute(const SceneView &sc, TraceLds cfg, const uint4 *smem, V3 o, V3 d, float mint, float maxt, Hit &h) {
-    const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
-    const TriBounds *tb = packet_bounds(sc, cfg, smem);
-    h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
-    bool any = false;
-    for (uint32_t i = 0; i < sc.tri_count; ++i) {
-        const TriPacket &k = pk[i];
-        float t, u, v;
-        bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, maxt, t, u, v) &&
-                   hit_in_bounds(tb[i], o, d, t);
-        if (AnyHit) {
-            any = any || hit;
-        } else if (hit && (t < h.t || (t == h.t && k.prim < h.prim))) {
-            h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim;
-        }
-    }
-    if (AnyHit) { if (any) { h.t = 0.f; h.tri = 0; } return any; }
-    return h.tri != MIW_MISS;
-}
-
-template <bool AnyHit, bool Analytic = true>
-__device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, const uint4 *smem,
-                                          V3 o, V3 d, float mint, float maxt, Hit &h) {
-    if (cfg.brute) return trace_brute<AnyHit>(sc, cfg, smem, o, d, mint, maxt, h);
-    RayPrep r = ray_prepare(o, d, mint, maxt);
-    const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
-    const Tri *ltris = reinterpret_cast<const Tri *>(smem + cfg.nodes_staged * (sizeof(BvhNode) / 16));
-    const BvhNode *gnodes = sc.nodes;
-    const Tri *gtris = sc.tris;
-    if (cfg.nodes_staged >= sc.node_count && cfg.tris_staged >= sc.tri_count) {
-        // whole scene is LDS resident: pure ds_read traversal
-        auto node_at = [lnodes](int32_t i) -> const BvhNode & { return lnodes[i]; };
-        auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
-    } else {
-        uint32_t ns = cfg.nodes_staged;
-        auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
-            return (uint32_t) i < ns ? lnodes[i] : gnodes[i];
-        };
-        auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
-        if (cfg.stack) {
-            int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
-            return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, prim_ctx(sc));
-        }
-        return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
-    }
-}
-
-// The resident plan's paired query: extension ray E and shadow ray S leave the same vertex
-// (same origin, same mint). Tiny scenes (packets in LDS) are resolved in two phases:
-//   1. a wave-uniform pass over the SAH leaves' padded boxes (broadcast LDS reads, the
-//      conservative slab test of bvh.h — a triangle Moeller-Trumbore accepts is never culled)
-//      leaves every lane two 64-bit candidate masks, one bit per triangle;
-//   2. every lane pops its own candidates (E's first, then S's) and runs the exact
-//      Moeller-Trumbore test on that packet (per-lane LDS address). The wave iterates
-//      max-over-lanes(candidates) times instead of 2 x tri_count.
-// Results are those of the full sweep: closest hit with ties to the smaller primitive id,
-// "any triangle passes" for S.
-// `Tiny` selects the code that is compiled in: the two-phase LDS query (tiny scenes) or the tree walks —
-// one kernel per scene class keeps each one's register budget (occupancy) to what it needs.
-template <int Tiny, bool Analytic = true>
-__device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const uint4 *smem,
-                                       V3 o, float mint, V3 dE, float maxtE, bool hasE,
-                                       V3 dS, float maxtS, bool hasS, F4 &hit_out, bool &occ_out) {
-    Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
-    bool occ = false;
-    if (Tiny && cfg.leaves) {
-        // candidate masks: 32 bits when the scene has <= 32 triangles (Tiny == 2), else 64
-        using Mask = typename std::conditional<Tiny == 2, uint32_t, unsigned long long>::type;
-        auto lowest = [](Mask m) -> uint32_t {
-            return Tiny == 2 ? (uint32_t) __ffs((int) (uint32_t) m) - 1u : (uint32_t) __ffsll((long long) m) - 1u;
-        };
-        const TriPacket *pk = reinterpret_cast<const TriPacket *>(smem);
-        const LeafBox *lb = reinterpret_cast<const LeafBox *>(smem + sc.tri_count * (sizeof(TriPacket) / 16));
-        const TriBounds *tb = packet_bounds(sc, cfg, smem);
-        const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
-        const float wideE = widen(maxtE), wideS = widen(maxtS);
-        Mask mE = 0, mS = 0;
-        for (uint32_t i = 0; i < cfg.leaves; ++i) {
-            const LeafBox &b = lb[i];                              // wave-uniform address
-            const Mask bits = Tiny == 2 ? (Mask) b.mask_lo : (Mask) (b.mask_lo | ((unsigned long long) b.mask_hi << 32));
-            float tn;
-            if (box_test_fast(b.lo, b.hi, rE, wideE, tn)) mE |= bits;
-            if (box_test_fast(b.lo, b.hi, rS, wideS, tn)) mS |= bits;
-        }
-        if (!hasE) mE = 0;
-        if (!hasS) mS = 0;
-        MIW_SECTION(1);
-        while (mE != 0) {                                      // closest hit of E over its candidates
-            const uint32_t i = lowest(mE);
-            mE &= mE - 1;
-            const TriPacket &k = pk[i];
-            float t, u, v;
-            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
-                (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
-        }
-        MIW_SECTION(2);
-        uint32_t s_tri = 0; float s_t = 0.f;
-        while (mS != 0) {                                      // any hit of S
-            const uint32_t i = lowest(mS);
-            mS &= mS - 1;
-            const TriPacket &k = pk[i];
-            float t, u, v;
-            if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) {
-                occ = true; mS = 0; s_tri = i; s_t = t;
-            }
-        }
-        // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
-        // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
-        // through the full sweep with the rule inside, which is what the rule means.
-        if (h.tri != MIW_MISS && !hit_in_bounds(tb[h.tri], o, dE, h.t)) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
-        if (occ && !hit_in_bounds(tb[s_tri], o, dS, s_t)) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
-        MIW_SECTION(3);
-#if defined(MIW_VERIFY_FILTER)
-        {   // debug builds: every filtered query against the full sweep; mismatching rays go to g_verify
-            Hit hb; bool occ_b = false;
-            if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, hb); else { hb.tri = MIW_MISS; hb.t = MIW_INFINITY; }
-            if (hasS) { Hit hs; occ_b = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
-            const bool badE = hasE && (hb.tri != h.tri || f2u(hb.t) != f2u(h.t)), badS = hasS && occ_b != occ;
-            if (badE || badS) {
-                const uint32_t k = atomicAdd(&g_verify_n, 1u);
-                if (k < 16u) {
-                    float *r = g_verify + k * 16;
-                    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint;
-                    const V3 d = badE ? dE : dS;
-                    r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = badE ? maxtE : maxtS;
-                    r[8] = badE ? 1.f : 2.f; r[9] = u2f(badE ? hb.tri : (uint32_t) occ_b); r[10] = u2f(badE ? h.tri : (uint32_t) occ);
-                    r[11] = hb.t; r[12] = h.t;
-                }
-            }
-        }
-#endif
-    } else if (Tiny) {                                         // tiny scene, filter switched off (MI_BVH_NO_LEAF_FILTER)
-        if (hasE) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
-        if (hasS) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
-    } else {
-        if (hasE) trace_one<false, Analytic>(sc, cfg, smem, o, dE, mint, maxtE, h);
-        if (hasS) { Hit hs; occ = trace_one<true, Analytic>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
-    }
-    hit_out.x = h.t; hit_out.y = h.u; hit_out.z = h.v; hit_out.w = u2f(h.tri);
-    occ_out = occ;
-}
-
-// ---------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------
-
-// ---- wavefront plan: stream compaction and material sorting -----------------------------
-// The stage kernels do not sweep all lanes: every workgroup consumes a dense list of the lane ids
-// (of its own 256-lane slice) that need the stage, and appends the lanes that need the next stage
-// to that stage's list. Appending is a wavefront-level ballot + popcount prefix sum with one LDS
-// atomic per wave per list — no global atomics (same-address device atomics serialise at ~12 ns),
-// no memsets: a workgroup owns segment [g*256, g*256+256) of every list and publishes its counts when
-// it finishes. Lists are double-buffered by iteration parity. k_trace<closest> files every traced
-// lane under the BSDF type of the surface it hit, so k_shade walks the lists type by type: a
-// wavefront shades one material (at most three wavefronts per workgroup straddle a boundary), idle
-// wavefronts retire at once. Lane state stays lane-indexed (SoA of 16-byte fields), so list order
-// never changes a result.
-enum { WL_E = 0, WL_S = 1, WL_SHADE0 = 2, WL_KEYS = 4, WL_LISTS = 6 };   // shade keys: bsdf type 0..2, 3 = no surface
-struct WorkLists {
-    uint32_t *list[WL_LISTS];     // n_lanes entries each, segmented per workgroup
-    uint32_t *count;              // [workgroup][WL_LISTS]
-};
-
-__device__ __forceinline__ void wave_append(bool pred, uint32_t *segment, uint32_t *lds_counter, uint32_t value) {
-    const unsigned long long b = __ballot(pred);
-    if (b == 0ull) return;                                     // wave-uniform
-    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(lds_counter, (uint32_t) __popcll(b));
-    base = (uint32_t) __shfl((int) base, (int) leader, 64);
-    if (pred) segment[base + (uint32_t) __popcll(b & ((1ull << lane) - 1ull))] = value;
-}
-
-struct InitArgs {
-    const uint32_t *block_ids;    // per block (row-major grid)
-    const uint32_t *tile_list;    // or nullptr
-    uint32_t blocks_x, blocks_y;
-    uint32_t bs, bs2_log2;
-    uint64_t base_seed;
-};
-
-#if !MIW_SPECTRAL   // HBM-queue plan: RGB builds only (path.h)
-// -> true when the lane starts with a camera ray queued
-__device__ __forceinline__ bool init_one_lane(const RenderParams &P, const LaneQueues &Q, uint32_t *pixel_out, const InitArgs &A, uint32_t lane) {
-    uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
-    uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
-    uint32_t x, y;
-    morton_decode2(i, x, y);                                   // integrator.cpp:200
-    int32_t bw = P.film.crop_w - (int32_t) (bx * A.bs), bh = P.film.crop_h - (int32_t) (by * A.bs);
-    if (bw > (int32_t) A.bs) bw = (int32_t) A.bs;
-    if (bh > (int32_t) A.bs) bh = (int32_t) A.bs;
-    if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
-        pixel_out[lane] = 0;
-        lane_init_unused(Q, lane);
-        return false;
-    }
-    uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
-    uint32_t pixel = px | (py << 16);
-    pixel_out[lane] = pixel;
-    uint64_t seed = A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i;   // :198
-    lane_init(P, Q, lane, pixel, seed);
-    return P.spp > 0;
-}
-
-__global__ __launch_bounds__(MIW_BLOCK) void k_init_lanes(RenderParams P, LaneQueues Q, uint32_t *pixel_out, InitArgs A, WorkLists W) {
-    __shared__ uint32_t s_cnt[WL_LISTS];
-    if (threadIdx.x < WL_LISTS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    bool has_ray = false;
-    if (lane < P.n_lanes) has_ray = init_one_lane(P, Q, pixel_out, A, lane);
-    wave_append(has_ray, W.list[WL_E] + blockIdx.x * MIW_BLOCK, &s_cnt[WL_E], lane);
-    __syncthreads();
-    if (threadIdx.x < WL_LISTS) W.count[blockIdx.x * WL_LISTS + threadIdx.x] = s_cnt[threadIdx.x];
-}
-#endif
-
-template <bool AnyHit>
-__global__ __launch_bounds__(MIW_BLOCK) void k_trace(SceneView sc, LaneQueues Q, TraceLds cfg, WorkLists io) {
-    extern __shared__ uint4 smem[];
-    __shared__ uint32_t s_cnt[WL_KEYS];
-    const uint32_t seg = blockIdx.x * MIW_BLOCK, *cnt = io.count + blockIdx.x * WL_LISTS;
-    const uint32_t n = cnt[AnyHit ? WL_S : WL_E];
-    if (AnyHit && n == 0) return;                              // nothing to test in this slice (uniform)
-    // the "no surface" list already holds the lanes k_shade parked there (samples waiting for a shadow ray)
-    if (!AnyHit && threadIdx.x < WL_KEYS) s_cnt[threadIdx.x] = threadIdx.x == WL_KEYS - 1 ? cnt[WL_SHADE0 + WL_KEYS - 1] : 0u;
-    stage_to_lds(sc, cfg, smem);                               // ends with __syncthreads()
-    const bool mine = threadIdx.x < n;
-    uint32_t lane = 0, key = WL_KEYS - 1;
-    if (mine) {
-        lane = io.list[AnyHit ? WL_S : WL_E][seg + threadIdx.x];
-        F4 d = AnyHit ? Q.sh_d[lane] : Q.ray_d[lane];
-        F4 o = Q.ray_o[lane];
-        Hit h;
-        bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, h);
-        if (AnyHit) {
-            Q.sh_vis[lane] = hit ? 0u : 1u;
-        } else {
-            F4 r; r.x = h.t; r.y = h.u; r.z = h.v; r.w = u2f(h.tri);
-            Q.hit[lane] = r;
-            if (hit) { key = sc.bsdfs[sc.shapes[sc.tris[h.tri].shape].bsdf].type; if (key > 2u) key = 2u; }   // material sort key (conductor / plastic share the rough conductor's list)
-        }
-    }
-    if (!AnyHit) {
-#pragma unroll
-        for (uint32_t k = 0; k < WL_KEYS; ++k)
-            wave_append(mine && key == k, io.list[WL_SHADE0 + k] + seg, &s_cnt[k], lane);
-        __syncthreads();
-        if (threadIdx.x < WL_KEYS) io.count[blockIdx.x * WL_LISTS + WL_SHADE0 + threadIdx.x] = s_cnt[threadIdx.x];
-    }
-}
-
-struct FilmAdd {
-    double *accum;
-    __device__ __forceinline__ void operator()(int texel, int k, float v) const {
-        unsafeAtomicAdd(accum + (size_t) texel * MIW_FILM_CHANNELS + k, (double) v);
-    }
-};
-
-// Workgroup-local film tile (resident plan, film_mode 2): the 256 lanes of a workgroup are one
-// Morton-contiguous 16 x 16 pixel quad of a spiral block, so everything they splat lands in the
-// (16 + 2*border)^2 texels around it. The tile is accumulated in LDS with float64 adds (ds_add_f64:
-// the sum is order-free to float32 precision) and flushed to the film accumulators once per launch.
-struct TileAdd {
-    double *tile; int x0, y0, side;     // tile origin in crop-relative film coordinates
-    __device__ __forceinline__ void operator()(int fx, int fy, int k, float v) const {
-        const int tx = fx - x0, ty = fy - y0;
-        if ((unsigned) tx < (unsigned) side && (unsigned) ty < (unsigned) side)
-            unsafeAtomicAdd(tile + (ty * side + tx) * MIW_FILM_CHANNELS + k, (double) v);
-    }
-};
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-#if !MIW_SPECTRAL
-template <bool UseLog>
-__global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
-                                                       uint32_t count_active, WorkLists in, WorkLists out) {
-    __shared__ uint32_t s_cnt[WL_LISTS];
-    if (threadIdx.x < WL_LISTS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t seg = blockIdx.x * MIW_BLOCK, *cnt_in = in.count + blockIdx.x * WL_LISTS;
-    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
-    // this workgroup's four material lists, back to back
-    uint32_t lane = 0; bool mine = false;
-    {
-        uint32_t base = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < WL_KEYS; ++k) {
-            const uint32_t n = cnt_in[WL_SHADE0 + k];
-            if (!mine && threadIdx.x - base < n) { lane = in.list[WL_SHADE0 + k][seg + threadIdx.x - base]; mine = true; }
-            base += n;
-        }
-    }
-    uint32_t flags = LF_DONE;
-    if (mine) {
-        if (UseLog) {
-            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
-            flags = lane_shade(P, sc, Q, lane, &local, sink);
-        } else {
-            FilmAdd add; add.accum = accum;
-            SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
-            flags = lane_shade(P, sc, Q, lane, &local, sink);
-        }
-        local.active_lanes = (!(flags & LF_DONE) && count_active) ? 1 : 0;
-    }
-    // next iteration's work: rays to trace, shadow rays to test, samples that only wait for a shadow ray
-    const bool alive = mine && !(flags & LF_DONE);
-    wave_append(alive && (flags & LF_RAY_ACTIVE), out.list[WL_E] + seg, &s_cnt[WL_E], lane);
-    wave_append(alive && (flags & LF_HAS_SHADOW), out.list[WL_S] + seg, &s_cnt[WL_S], lane);
-    wave_append(alive && (flags & LF_DEAD_PENDING), out.list[WL_SHADE0 + WL_KEYS - 1] + seg, &s_cnt[WL_SHADE0 + WL_KEYS - 1], lane);
-    __syncthreads();
-    if (threadIdx.x < WL_LISTS) out.count[blockIdx.x * WL_LISTS + threadIdx.x] = s_cnt[threadIdx.x];
-    // Statistics: wave-level reduce, then one atomic per wave into one of
-    // MIW_CNT_SHARDS counter records (same-address device atomics serialise at
-    // ~12 ns each — 131k waves on one word would cost more than the shading).
-    unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples),
-                       c = wave_sum(local.shadow_rays), d = wave_sum(local.active_lanes);
-    if ((threadIdx.x & 63) == 0) {
-        Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
-        if (a) atomicAdd(&shard->segments, a);
-        if (b) atomicAdd(&shard->samples, b);
-        if (c) atomicAdd(&shard->shadow_rays, c);
-        if (d) atomicAdd(&shard->active_lanes, d);
-    }
-}
-#endif   // !MIW_SPECTRAL
-
-// ---- the resident plan -----------------------------------------------------------------
-// k_init_pixels: pixel <-> lane map and PCG32 seeding only (a pixel carries nothing else
-// between two camera samples).
-__global__ __launch_bounds__(MIW_BLOCK) void k_init_pixels(RenderParams P, U4 *st_out, uint32_t *pixel_out, InitArgs A) {
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= P.n_lanes) return;
-    uint32_t tile = lane >> A.bs2_log2, i = lane & ((1u << A.bs2_log2) - 1u);
-    uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    uint32_t bx = b % A.blocks_x, by = b / A.blocks_x;
-    uint32_t x, y;
-    morton_decode2(i, x, y);                                   // integrator.cpp:200
-    int32_t bw = P.film.crop_w - (int32_t) (bx * A.bs), bh = P.film.crop_h - (int32_t) (by * A.bs);
-    if (bw > (int32_t) A.bs) bw = (int32_t) A.bs;
-    if (bh > (int32_t) A.bs) bh = (int32_t) A.bs;
-    if ((int32_t) x >= bw || (int32_t) y >= bh) {                // :201-202 — pixel outside the block
-        U4 st; st.x = st.y = 0; st.z = LF_DONE; st.w = 0;
-        st_out[lane] = st; pixel_out[lane] = 0;
-        return;
-    }
-    uint32_t px = (uint32_t) P.film.crop_x + bx * A.bs + x, py = (uint32_t) P.film.crop_y + by * A.bs + y;
-    pixel_out[lane] = px | (py << 16);
-    st_out[lane] = lane_seed_state(A.base_seed + (uint64_t) A.block_ids[b] * (uint64_t) (A.bs * A.bs) + i);   // :198
-}
-
-// k_path_resident: one thread = one pixel, advanced from its current sample to `sample_end`.
-// Path state, ray, hit record and the pending emitter contribution never leave registers;
-// the geometry is swept / walked in LDS (trace_one); HBM sees 20 B of pixel state per launch
-// and the 24 B/sample log (or the film atomics).
-struct TileArgs {               // film_mode 2 in the resident plan; side == 0: splat straight into `accum`
-    const uint32_t *tile_list; uint32_t blocks_x, bs, bs2_log2;
-    uint32_t side;              // 16 + 2 * margin, margin = max(filter border, floor(radius + .5))
-    uint32_t geom16;            // uint4 slots of dynamic LDS in front of the tile
-};
-
-// Log mode feeds the lanes from ONE shared pixel queue (`next_pixel`): a lane that finishes its pixel takes
-// the next unclaimed one inside the iteration loop (wavefront-aggregated: ballot + one atomic per wave per
-// refill), so no lane waits for the slowest pixel of its wavefront and the launch drains evenly. The grid is
-// sized to the machine; workgroups that start late find the queue empty and retire.
-struct QueueWork {
-    const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane;
-    __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
-        for (;;) {
-            // claim: ballot over the lanes asking, one atomic for all of them
-            const unsigned long long b = __ballot(1);
-            const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
-            uint32_t base = 0;
-            if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
-            base = (uint32_t) __shfl((int) base, (int) leader, 64);
-            lane = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
-            if (lane >= n_lanes) return false;
-            st = Q->st[lane];
-            if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
-            pixel = Q->pixel[lane];
-            return true;
-        }
-    }
-    __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
-    __device__ __forceinline__ void put(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) {
-        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp;
-        sink(0u, sample_idx, pos, aovs);
-    }
-};
-
-// Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
-// Integ: which SamplingIntegrator::sample the pixel loop runs (path.h / direct.h).
-template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH>
-__global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
-                                                               TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
-    extern __shared__ uint4 smem[];
-    stage_to_lds(sc, cfg, smem);
-#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
-#endif
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    // workgroup film tile
-    double *tile = reinterpret_cast<double *>(smem + T.geom16);
-    int tile_x0 = 0, tile_y0 = 0;
-    if (!UseLog && T.side) {
-        const uint32_t lane0 = blockIdx.x * blockDim.x, t = lane0 >> T.bs2_log2, q0 = lane0 & ((1u << T.bs2_log2) - 1u);
-        const uint32_t b = T.tile_list ? T.tile_list[t] : t;
-        uint32_t qx, qy;
-        morton_decode2(q0, qx, qy);
-        const int margin = (int) (T.side - 16u) / 2;
-        tile_x0 = (int) ((b % T.blocks_x) * T.bs + qx) - margin;
-        tile_y0 = (int) ((b / T.blocks_x) * T.bs + qy) - margin;
-        for (uint32_t i = threadIdx.x; i < T.side * T.side * MIW_FILM_CHANNELS; i += blockDim.x) tile[i] = 0.0;
-        __syncthreads();
-    }
-    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
-    auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
-        trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
-    };
-    if (UseLog) {
-        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
-        if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
-        else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
-    } else if (lane < P.n_lanes) {
-        U4 st = Q.st[lane];
-        if (!(st.z & LF_DONE)) {
-            const uint32_t pixel = Q.pixel[lane];
-            if (T.side) {
-                TileAdd add; add.tile = tile; add.x0 = tile_x0; add.y0 = tile_y0; add.side = (int) T.side;
-                SplatXYSink<TileAdd> sink; sink.film = &P.film; sink.add = add;
-                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
-            } else {
-                FilmAdd add; add.accum = accum;
-                SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
-                st = pixel_render<Integ>(P, sc, pixel, st, sample_end, tr2, sink, &local);
-            }
-            Q.st[lane] = st;
-        }
-    }
-    if (!UseLog && T.side) {                                     // flush the tile: one f64 atomic per touched slot
-        __syncthreads();
-        const int n = (int) (T.side * T.side);
-        for (int i = (int) threadIdx.x; i < n * MIW_FILM_CHANNELS; i += (int) blockDim.x) {
-            const double v = tile[i];
-            if (v == 0.0) continue;
-            const int texel = i / MIW_FILM_CHANNELS, k = i - texel * MIW_FILM_CHANNELS;
-            const int fx = tile_x0 + texel % (int) T.side, fy = tile_y0 + texel / (int) T.side;
-            unsafeAtomicAdd(accum + ((size_t) fy * P.film.crop_w + fx) * MIW_FILM_CHANNELS + k, v);
-        }
-    }
-    unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
-    if ((threadIdx.x & 63) == 0) {
-        Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
-        if (a) atomicAdd(&shard->segments, a);
-        if (b) atomicAdd(&shard->samples, b);
-        if (c) atomicAdd(&shard->shadow_rays, c);
-#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) if (b_[i]) atomicAdd(&g_sections[i], b_[i]); }
-#endif
-    }
-}
-
-__global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n, int accumulate) {
-    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (out64) out64[i] = accumulate ? out64[i] + accum[i] : accum[i];
-    else out32[i] = accumulate ? (float) ((double) out32[i] + accum[i]) : (float) accum[i];
-}
-
-// Ordered film assembly, step 1 (miw/film_gather.h): the bordered ImageBlock of every spiral block
-// is rebuilt by TEXEL PATCHES — one wavefront owns an 8x8 patch of block texels, one texel per lane,
-// the five channel sums live in registers. The wave walks the block's pixels in Morton order
-// (render_block's order, integrator.cpp:196-203), skips those whose filter footprint cannot reach
-// the patch, and replays each remaining pixel's sample run front to back: 64 samples are fetched with
-// one coalesced load (lane i = sample i; the log is [lane][sample]), the owning lane derives what
-// ImageBlock::put derives once per sample (lo, clipped extent, the discretised x/y weights,
-// imageblock.cpp:114-146) and parks the weights in LDS, then the samples are broadcast one by one
-// (v_readlane) and each lane adds value*wy*wx to its texel iff the footprint covers it (:148-161).
-// Every texel therefore sees exactly the reference's sequence of float32 additions; there are no
-// atomics and no cross-lane accumulation, and the dependent chain per texel is register-only.
-#define MIW_FP_SIDE 8                  /* patch = 8 x 8 texels = one wavefront */
-#define MIW_FP_MAXN 8                  /* filter footprint is at most 8 x 8 (radius <= 4) */
-struct PatchArgs { uint32_t patches_x, patches_y; int32_t reach; };
-
-template <bool wide>
-__global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles) {
-    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
-    __shared__ float s_w[64 * 2 * MIW_FP_MAXN];              // per staged sample: wx[8], wy[8]
-    const uint32_t l = threadIdx.x;
-    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
-    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    const BlockGeom g = block_geom(F, A.blocks_x, b);
-    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
-    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
-    const int tx = ptx0 + (int) (l & 7u), ty = pty0 + (int) (l >> 3);
-    if (l < 32) s_lut[l] = F.lut[l];
-    __syncthreads();
-
-    // pixels (block-local) whose samples can reach this patch
-    int x0 = ptx0 - F.border - PA.reach, x1 = ptx0 + MIW_FP_SIDE - 1 - F.border + PA.reach,
-        y0 = pty0 - F.border - PA.reach, y1 = pty0 + MIW_FP_SIDE - 1 - F.border + PA.reach;
-    if (x0 < 0) x0 = 0;
-    if (y0 < 0) y0 = 0;
-    if (x1 > g.bw - 1) x1 = g.bw - 1;
-    if (y1 > g.bh - 1) y1 = g.bh - 1;
-
-    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
-    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
-    if (n > MIW_FP_MAXN) n = MIW_FP_MAXN;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
-    const uint32_t bs2 = 1u << A.bs2_log2;
-
-    for (uint32_t q = 0; q < bs2; ++q) {                     // wave-uniform scan in Morton order
-        uint32_t x, y;
-        morton_decode2(q, x, y);
-        if ((int) x < x0 || (int) x > x1 || (int) y < y0 || (int) y > y1) continue;
-        const uint32_t lane = (tile << A.bs2_log2) + q;
-        const uint32_t count = (uint32_t) __builtin_amdgcn_readfirstlane((int) A.st[lane].w);
-        const F2 *lp = A.log_pos + (size_t) lane * A.spp; const F4 *lv = A.log_val + (size_t) lane * A.spp;
-        for (uint32_t j0 = 0; j0 < count; j0 += 64) {
-            const uint32_t m = count - j0 < 64u ? count - j0 : 64u;
-            // ---- stage: lane i owns sample j0 + i ----
-            F2 p; p.x = __builtin_nanf(""); p.y = 0.f;
-            F4 v; v.x = v.y = v.z = v.w = 0.f;
-            if (l < m) { p = lp[j0 + l]; v = lv[j0 + l]; }
-            int lo_x = 0, lo_y = 0, nx = 0, ny = 0;
-            float wx[MIW_FP_MAXN], wy[MIW_FP_MAXN];
-            for (int i = 0; i < MIW_FP_MAXN; ++i) wx[i] = wy[i] = 0.f;
-            if (p.x == p.x) {                                // not a rejected sample (imageblock.cpp:98-108)
-                const float posx = p.x - kx, posy = p.y - ky;                        // :114
-                if (wide) {
-                    lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
-                    if (lo_x < 0) lo_x = 0;
-                    if (lo_y < 0) lo_y = 0;
-                    int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
-                    if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
-                    if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
-                    const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
-                    for (int i = 0; i < MIW_FP_MAXN; ++i) {
-                        if (i < n) {
-                            int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
-                                iy = (int) abs_((base_y + (float) i) * F.scale_factor);
-                            if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
-                            if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
-                            wx[i] = s_lut[ix]; wy[i] = s_lut[iy];
-                        }
-                    }
-                    nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;   // texels enabled by `y <= hi_y`, `x <= hi_x`
-                    if (nx > n) nx = n;
-                    if (ny > n) ny = n;
-                    if (nx < 0) nx = 0;
-                    if (ny < 0) ny = 0;
-                } else {                                     // box filter, :163-170: one texel, weight 1
-                    lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
-                    const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
-                    nx = ny = in ? 1 : 0; wx[0] = wy[0] = 1.f;
-                    if (!in) lo_x = lo_y = 0;
-                }
-            }
-            __syncthreads();                                 // previous chunk's weights fully consumed
-            for (int i = 0; i < MIW_FP_MAXN; ++i) { s_w[l * 16 + i] = wx[i]; s_w[l * 16 + 8 + i] = wy[i]; }
-            __syncthreads();
-            const int pk_lo = lo_x | (lo_y << 16), pk_n = nx | (ny << 8);
-            // ---- replay: this pixel's samples back to back, four per trip ----
-            // Lanes the footprint does not cover add value * 0 (= +-0: leaves a finite sum unchanged), which
-            // keeps the trip branch-free; staged slots >= m carry nx = ny = 0 and value 0.
-            const uint32_t m4 = (m + 3u) & ~3u;
-            for (uint32_t s0 = 0; s0 < m4; s0 += 4) {
-                float w[4], vx[4], vy[4], vz[4], va[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int sl = (int) (s0 + k);
-                    const int slo = __builtin_amdgcn_readlane(pk_lo, sl), sn = __builtin_amdgcn_readlane(pk_n, sl);
-                    const int xr = tx - (slo & 0xffff), yr = ty - (slo >> 16);
-                    const bool hit = (uint32_t) xr < (uint32_t) (sn & 0xff) && (uint32_t) yr < (uint32_t) (sn >> 8);
-                    const float wk = s_w[sl * 16 + 8 + (yr & 7)] * s_w[sl * 16 + (xr & 7)];            // wy * wx, :155
-                    w[k] = hit ? wk : 0.f;
-                    vx[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.x), sl));
-                    vy[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.y), sl));
-                    vz[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.z), sl));
-                    va[k] = u2f((uint32_t) __builtin_amdgcn_readlane((int) f2u(v.w), sl));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (wide) { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += 1.f * w[k]; }
-                    else      { acc0 += vx[k] * w[k]; acc1 += vy[k] * w[k]; acc2 += vz[k] * w[k]; acc3 += va[k] * w[k]; acc4 += w[k]; }
-                }
-            }
-        }
-    }
-    if (tx < g.size_x && ty < g.size_y) {
-        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
-        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
-    }
-}
-
-// ---- fast form of step 1 for filters whose footprint is at most 4 x 4 texels (radius <= 2: box, tent,
-// gaussian, mitchell, catmullrom) and blocks of at most 127 bordered texels a side ----
-//
-// k_film_blocks spends one wave-iteration of all 64 texel lanes on every sample of every pixel in reach of
-// the 8x8 patch (144 pixels for 64 texels), although a sample touches 16 texels: 6 % of the lane-iterations add
-// anything. The fast form splits the work in two:
-//   k_film_pack   once per SAMPLE: everything ImageBlock::put derives from the position alone (lo, the clipped
-//                 extent, the discretised weight indices, imageblock.cpp:114-146) is packed into the 8 bytes the
-//                 position occupied in the log: per axis lo (7 bits) | extent (3) | 4 x LUT index (5 each).
-//                 The same pass records, per pixel, the union of its samples' footprints (block texels).
-//   k_film_groups once per (texel GROUP, sample): a wavefront still owns an 8x8 patch, one texel per lane,
-//                 accumulators in registers, but its lanes form independent groups of GW x GH texels. Each
-//                 group walks ITS OWN Morton-ordered list of the pixels whose footprint union overlaps the
-//                 group (25 pixels for a 2x2 group instead of 144), so one wave-iteration serves 64 / (GW*GH)
-//                 (group, sample) pairs; a lane decodes the packed record with a handful of integer ops.
-//                 Sample runs are staged through LDS with coalesced loads, 16 samples per group at a time.
-// Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order,
-// each pixel's samples front to back), so the tiles are bit-identical to k_film_blocks'.
-#define MIW_PK_LO_BITS 7
-#define MIW_PK_MAX_SIDE 127
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t < v ? t : v; }
-    return v;
-}
-
-// one wavefront per pixel (lane i = samples i, i + 64, ...); boxes[lane] = min lo_x | max hi_x << 8 | min lo_y << 16 | max hi_y << 24
-template <bool wide>
-__global__ __launch_bounds__(256) void k_film_pack(FilmRec F, BlockReplayArgs A, uint32_t n_lanes, uint32_t *boxes) {
-    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
-    if (lane >= n_lanes) return;
-    const uint32_t tile = lane >> A.bs2_log2, q = lane & ((1u << A.bs2_log2) - 1u);
-    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    const BlockGeom g = block_geom(F, A.blocks_x, b);
-    uint32_t x, y;
-    morton_decode2(q, x, y);
-    uint32_t count = A.st[lane].w;
-    if ((int) x >= g.bw || (int) y >= g.bh) count = 0;
-    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
-    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
-    if (n > 4) n = 4;
-    uint2 *recs = reinterpret_cast<uint2 *>(const_cast<F2 *>(A.log_pos)) + (size_t) lane * A.spp;
-    uint32_t min_x = 127u, max_x = 0u, min_y = 127u, max_y = 0u;
-    for (uint32_t j = l; j < count; j += 64u) {
-        const F2 p = A.log_pos[(size_t) lane * A.spp + j];
-        uint32_t w0 = 0u, w1 = 0u;
-        if (p.x == p.x) {                                    // not a rejected sample (imageblock.cpp:98-108)
-            const float posx = p.x - kx, posy = p.y - ky;                            // :114
-            int lo_x, lo_y, nx, ny;
-            if (wide) {
-                lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
-                if (lo_x < 0) lo_x = 0;
-                if (lo_y < 0) lo_y = 0;
-                int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
-                if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
-                if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
-                nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;
-                if (nx > n) nx = n;
-                if (ny > n) ny = n;
-                if (nx < 0) nx = 0;
-                if (ny < 0) ny = 0;
-                const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
-                for (int i = 0; i < 4; ++i) {
-                    if (i < n) {
-                        int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
-                            iy = (int) abs_((base_y + (float) i) * F.scale_factor);
-                        if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
-                        if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
-                        w0 |= (uint32_t) ix << (10 + 5 * i); w1 |= (uint32_t) iy << (10 + 5 * i);
-                    }
-                }
-            } else {                                         // box filter, :163-170: one texel, weight 1
-                lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
-                const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
-                nx = ny = in ? 1 : 0;
-                if (!in) lo_x = lo_y = 0;
-            }
-            if (nx == 0 || ny == 0) { nx = ny = 0; lo_x = lo_y = 0; w0 = w1 = 0u; }
-            else {
-                min_x = min(min_x, (uint32_t) lo_x); max_x = max(max_x, (uint32_t) (lo_x + nx - 1));
-                min_y = min(min_y, (uint32_t) lo_y); max_y = max(max_y, (uint32_t) (lo_y + ny - 1));
-            }
-            w0 |= (uint32_t) lo_x | ((uint32_t) nx << MIW_PK_LO_BITS);
-            w1 |= (uint32_t) lo_y | ((uint32_t) ny << MIW_PK_LO_BITS);
-        }
-        recs[j] = make_uint2(w0, w1);
-    }
-    min_x = wave_min_u32(min_x); max_x = wave_max_u32(max_x); min_y = wave_min_u32(min_y); max_y = wave_max_u32(max_y);
-    if (l == 0) boxes[lane] = min_x | (max_x << 8) | (min_y << 16) | (max_y << 24);
-}
-
-#define MIW_FG_CHUNK 16                /* samples per group staged per trip */
-template <int GW, int GH, bool wide>
-__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, const uint32_t *boxes, float *tiles) {
-    constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group, groups, groups per patch row
-    constexpr int LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
-    static_assert(PASSES >= 1, "group too large");
-    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
-    __shared__ unsigned short s_list[NG][LCAP];
-    __shared__ uint32_t s_m[NG];
-    __shared__ uint2 s_rec[NG][MIW_FG_CHUNK + 1];
-    __shared__ float4 s_val[NG][MIW_FG_CHUNK + 1];
-    const uint32_t l = threadIdx.x;
-    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
-    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    const BlockGeom g = block_geom(F, A.blocks_x, b);
-    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
-    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
-    const uint32_t h = l / GL, li = l % GL;
-    const int tx = ptx0 + (int) (h % GPX) * GW + (int) (li % GW), ty = pty0 + (int) (h / GPX) * GH + (int) (li / GW);
-    if (l < MIW_FILTER_RESOLUTION + 1) s_lut[l] = F.lut[l];
-
-    // ---- per group: the pixels whose footprint union overlaps the group, in Morton order ----
-    const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
-    uint32_t fill[NG];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) fill[i] = 0;
-    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
-        const uint32_t q = q0 + l;
-        uint32_t x, y;
-        morton_decode2(q, x, y);
-        uint32_t box = 127u | (127u << 16);                  // empty
-        if (q < bs2 && (int) x < g.bw && (int) y < g.bh) box = boxes[lane0 + q];
-        const int bx0 = (int) (box & 255u), bx1 = (int) ((box >> 8) & 255u), by0 = (int) ((box >> 16) & 255u), by1 = (int) (box >> 24);
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int gx0 = ptx0 + (i % GPX) * GW, gy0 = pty0 + (i / GPX) * GH;
-            // window of k_film_blocks (bounds the list) and the exact footprint test
-            const bool in = (int) x >= gx0 - F.border - PA.reach && (int) x <= gx0 + GW - 1 - F.border + PA.reach &&
-                            (int) y >= gy0 - F.border - PA.reach && (int) y <= gy0 + GH - 1 - F.border + PA.reach &&
-                            bx0 <= gx0 + GW - 1 && bx1 >= gx0 && by0 <= gy0 + GH - 1 && by1 >= gy0;
-            const unsigned long long m = __ballot(in);
-            if (in) {
-                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
-                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
-            }
-            fill[i] += (uint32_t) __popcll(m);
-        }
-    }
-    uint32_t max_m = 0;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
-        if (l == 0) s_m[i] = m;
-        max_m = m > max_m ? m : max_m;
-    }
-    __syncthreads();
-
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
-    const uint2 *recs = reinterpret_cast<const uint2 *>(A.log_pos);
-    const uint32_t my_m = s_m[h];
-    for (uint32_t k = 0; k < max_m; ++k) {
-        // staging rows of this step: pass i loads group i * 4 + l / 16, sample l % 16
-        size_t row[PASSES]; uint32_t cnt[PASSES];
-        uint32_t step_max = 0;
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
-            cnt[i] = 0; row[i] = 0;
-            if (k < s_m[hs]) {
-                const uint32_t lane = lane0 + s_list[hs][k];
-                cnt[i] = A.st[lane].w; row[i] = (size_t) lane * A.spp;
-            }
-            step_max = cnt[i] > step_max ? cnt[i] : step_max;
-        }
-        step_max = wave_max_u32(step_max);
-        (void) my_m;
-        // the next chunk's loads are in flight while the current one is replayed
-        const uint32_t jj = l & 15u;
-        uint2 nr[PASSES]; float4 nv[PASSES];
-        auto fetch = [&](uint32_t j0) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                nr[i] = make_uint2(0u, 0u); nv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j0 + jj < cnt[i]) {
-                    nr[i] = recs[row[i] + j0 + jj];
-                    const F4 t = A.log_val[row[i] + j0 + jj];
-                    nv[i] = make_float4(t.x, t.y, t.z, t.w);
-                }
-            }
-        };
-        fetch(0);
-        for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
-                s_rec[hs][jj] = nr[i]; s_val[hs][jj] = nv[i];
-            }
-            if (j0 + MIW_FG_CHUNK < step_max) fetch(j0 + MIW_FG_CHUNK);
-            __syncthreads();
-#pragma unroll 4
-            for (int s = 0; s < MIW_FG_CHUNK; ++s) {
-                const uint2 r = s_rec[h][s];
-                const float4 v = s_val[h][s];
-                const int xr = tx - (int) (r.x & 127u), yr = ty - (int) (r.y & 127u);
-                const bool hit = (uint32_t) xr < ((r.x >> MIW_PK_LO_BITS) & 7u) && (uint32_t) yr < ((r.y >> MIW_PK_LO_BITS) & 7u);
-                float w = 1.f;
-                if (wide) w = s_lut[(r.y >> (10 + 5 * (yr & 3))) & 31u] * s_lut[(r.x >> (10 + 5 * (xr & 3))) & 31u];   // wy * wx, :155
-                if (hit) { acc0 += v.x * w; acc1 += v.y * w; acc2 += v.z * w; acc3 += v.w * w; acc4 += w; }
-            }
-            __syncthreads();
-        }
-    }
-    if (tx < g.size_x && ty < g.size_y) {
-        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
-        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
-    }
-}
-
-// step 2: every film texel sums the block tiles covering it, ascending block id
-__global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64, int accumulate) {
-    int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;
-    if (fx >= F.crop_w || fy >= F.crop_h) return;
-    float v[MIW_FILM_CHANNELS];
-    size_t o = ((size_t) fy * F.crop_w + fx) * MIW_FILM_CHANNELS;
-    if (accumulate) for (int k = 0; k < MIW_FILM_CHANNELS; ++k) v[k] = out64 ? (float) out64[o + k] : out32[o + k];
-    film_merge_texel(F, A, tiles, fx, fy, v, accumulate != 0);
-    for (int k = 0; k < MIW_FILM_CHANNELS; ++k) {
-        if (out64) out64[o + k] = (double) v[k]; else out32[o + k] = v[k];
-    }
-}
-
-struct SoaRays { const float *ox, *oy, *oz, *dx, *dy, *dz, *mint, *maxt; };
-struct SoaHits { float *t, *u, *v; uint32_t *prim, *shape; };
-
-template <bool AnyHit>
-__global__ __launch_bounds__(MIW_BLOCK) void k_trace_soa(SceneView sc, SoaRays R, SoaHits H, uint64_t n, TraceLds cfg) {
-    extern __shared__ uint4 smem[];
-    stage_to_lds(sc, cfg, smem);
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Hit h;
-    bool hit = trace_one<AnyHit>(sc, cfg, smem, v3(R.ox[i], R.oy[i], R.oz[i]), v3(R.dx[i], R.dy[i], R.dz[i]),
-                                 R.mint[i], R.maxt[i], h);
-    H.t[i] = hit ? h.t : MIW_INFINITY;
-    if (H.u) H.u[i] = h.u;
-    if (H.v) H.v[i] = h.v;
-    if (H.prim) H.prim[i] = hit ? h.prim : 0xffffffffu;
-    if (H.shape) H.shape[i] = hit ? sc.tris[h.tri].shape : 0xffffffffu;
-}
-
-__global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, int is, float *out, int os, uint64_t n) {
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *a = in + i * (uint64_t) is;
-    float *o = out + i * (uint64_t) os;
-    switch (op) {
-        case MI_EVAL_PCG32: {
-            PCG32 r; pcg32_seed(r, (uint64_t) f2u(a[0]) | ((uint64_t) f2u(a[1]) << 32), MIW_PCG32_DEFAULT_STREAM);
-            for (int k = 0; k < 8; ++k) o[k] = pcg32_next_f32(r);
-        } break;
-        case MI_EVAL_SINCOS: sincos_(a[0], o[0], o[1]); break;
-        case MI_EVAL_COSINE_HEMISPHERE: {
-            V3 w = square_to_cosine_hemisphere(v2(a[0], a[1]));
-            o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = square_to_cosine_hemisphere_pdf(w);
-        } break;
-        case MI_EVAL_BSDF: {      // spectral builds: in[10..13] = wavelengths; colour outputs have MIW_SPEC_N channels
-            const uint32_t b_index = f2u(a[0]);
-            V3 wi = v3(a[1], a[2], a[3]), wo = v3(a[7], a[8], a[9]);
-            Wavelengths wl;
-#if MIW_SPECTRAL
-            for (int k = 0; k < 4; ++k) wl.l[k] = a[10 + k];
-#endif
-            const BsdfSide b = bsdf_side(sc.bsdfs, b_index, wi);
-            const TexCtx tc(wl, v2(0.f, 0.f), nullptr, sc.bsdf_tables);
-            BSDFSample bs; Spec w = bsdf_side_sample(b, wi, a[4], v2(a[5], a[6]), bs, tc);
-            o[0] = bs.wo.x; o[1] = bs.wo.y; o[2] = bs.wo.z; o[3] = bs.pdf; o[4] = bs.eta; o[5] = u2f(bs.sampled_type);
-            Spec e = bsdf_side_eval(b, wi, wo, tc);
-            const float *wf = reinterpret_cast<const float *>(&w), *ef = reinterpret_cast<const float *>(&e);
-            for (int k = 0; k < MIW_SPEC_N; ++k) { o[6 + k] = wf[k]; o[6 + MIW_SPEC_N + k] = ef[k]; }
-            o[6 + 2 * MIW_SPEC_N] = bsdf_side_pdf(b, wi, wo, tc);
-        } break;
-        case MI_EVAL_FRESNEL: fresnel(a[0], a[1], o[0], o[1], o[2], o[3]); break;
-        case MI_EVAL_CAMERA_RAY: {
-            V2 adj = v2((a[0] - (float) P.film.crop_x) / (float) P.film.crop_w,
-                        (a[1] - (float) P.film.crop_y) / (float) P.film.crop_h);
-            Ray r = sensor_sample_ray(P.sensor, adj);
-            o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z; o[6] = r.mint; o[7] = r.maxt;
-        } break;
-        case MI_EVAL_EMITTER_SAMPLE: {   // spectral builds: in[5..8] = wavelengths
-            Wavelengths wl;
-#if MIW_SPECTRAL
-            for (int k = 0; k < 4; ++k) wl.l[k] = a[5 + k];
-#endif
-            DirectionSample ds; Spec s = sample_emitter_direction(sc, v3(a[0], a[1], a[2]), v2(a[3], a[4]), ds, wl);
-            o[0] = ds.d.x; o[1] = ds.d.y; o[2] = ds.d.z; o[3] = ds.dist; o[4] = ds.pdf;
-            o[5] = ds.p.x; o[6] = ds.p.y; o[7] = ds.p.z; o[8] = ds.n.x; o[9] = ds.n.y; o[10] = ds.n.z;
-            const float *sf = reinterpret_cast<const float *>(&s);
-            for (int k = 0; k < MIW_SPEC_N; ++k) o[11 + k] = sf[k];
-        } break;
-        case MI_EVAL_FP_SEMANTICS: {
-            float x = a[0], y = a[1], z = a[2];
-            o[0] = x + y; o[1] = x * y; o[2] = x / y; o[3] = __builtin_sqrtf(abs_(x));
-            o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
-        } break;
-        case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
-#if !MIW_SPECTRAL
-        case MI_EVAL_ENVMAP: {
-            if (!sc.env) break;
-            V3 d = v3(a[0], a[1], a[2]);
-            V3 e = env_eval(*sc.env, d); o[0] = e.x; o[1] = e.y; o[2] = e.z;
-            o[3] = env_pdf_direction(*sc.env, d);
-            V3 sd, sp, sn; float dist, pdf;
-            V3 spec = env_sample_direction(*sc.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
-            o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
-        } break;
-#else
-        case MI_EVAL_SPECTRUM: {         // in: wavelength sample, c0, c1, c2 (srgb coefficients), d65 scale
-            Wavelengths wl; Spec wt;
-            sample_wavelengths(a[0], wl, wt);
-            TexRec t; t.type = TEX_SRGB_D65; t.v[0] = a[1]; t.v[1] = a[2]; t.v[2] = a[3]; t.v[3] = a[4];
-            Spec sd = tex_eval(t, wl);
-            t.type = TEX_SRGB; Spec sr = tex_eval(t, wl);
-            for (int k = 0; k < 4; ++k) { o[k] = wl.l[k]; o[4 + k] = wt.c[k]; o[8 + k] = sr.c[k]; o[12 + k] = sd.c[k]; }
-            V3 xyz = spectrum_to_xyz(wt * sd, wl);
-            o[16] = xyz.x; o[17] = xyz.y; o[18] = xyz.z;
-        } break;
-#endif
-        case MI_EVAL_INVTRIG: o[0] = atan2_(a[0], a[1]); o[1] = acos_(a[1]); o[2] = asin_(a[1]); break;
-        case MI_EVAL_TEXTURE: {
-            if (!sc.bitmaps) break;
-            Wavelengths wl;
-#if MIW_SPECTRAL
-            Spec wt; sample_wavelengths(a[3], wl, wt);
-#endif
-            TexRec t; t.type = TEX_BITMAP; t.v[0] = a[2]; t.v[1] = t.v[2] = t.v[3] = 0.f;
-            Spec r = tex_eval(t, TexCtx(wl, v2(a[0], a[1]), sc.bitmaps));
-            const float *rf = reinterpret_cast<const float *>(&r);
-            for (int k = 0; k < MIW_SPEC_N; ++k) o[k] = rf[k];
-        } break;
-    }
-}
+#include "device/trace.h"
+#include "device/wavefront_kernels.h"
+#include "device/resident_kernel.h"
+#include "device/film_kernels.h"
+#include "device/eval_kernels.h"
 
 // ---------------------------------------------------------------------------------------
 // host side
