@@ -391,7 +391,7 @@ def test_errors_are_loud(native, dev):
     with pytest.raises(RuntimeError):
         native.PathIntegrator(rr_depth=0)
     with pytest.raises(RuntimeError):
-        native.BSDF("roughplastic")
+        native.BSDF("blendbsdf")
     # malformed descriptions of the newer record types are refused by mi_scene_upload with a message
     from mitsuba2_amd import scenes
     d3 = native.Device(0)
