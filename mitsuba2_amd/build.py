@@ -46,7 +46,7 @@ def _newer(target, sources):
 def _headers(d):
     out = []
     for base, _, files in os.walk(d):
-        out += [os.path.join(base, f) for f in files if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
+        out += [os.path.join(base, f) for f in files if f.endswith((".h", ".hpp", ".hip", ".cpp", ".inl"))]
     return out
 
 

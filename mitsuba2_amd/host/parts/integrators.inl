@@ -1,0 +1,176 @@
+// libmiwave_host: SamplingIntegrator machinery, path / direct / moment integrators.
+// Part of the single translation unit host/miwave_host.cpp (included there, in this order).
+// ============================================================================================
+// PathIntegrator
+// ============================================================================================
+static uint32_t round_to_power_of_two(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return v == 0 ? 0 : r; }
+
+SamplingIntegrator::SamplingIntegrator(const Properties &props) {
+    m_block_size = (uint32_t) props.int_("block_size", 0);
+    uint32_t bs = round_to_power_of_two(m_block_size);
+    if (m_block_size > 0 && bs != m_block_size) m_block_size = bs;   // integrator.cpp:27-32 (warns)
+    m_samples_per_pass = (uint32_t) props.int_("samples_per_pass", (int64_t) (uint32_t) -1);
+    m_timeout = props.float_("timeout", -1.f);
+    m_hide_emitters = props.bool_("hide_emitters", false);
+}
+PathIntegrator::PathIntegrator(const Properties &props) : SamplingIntegrator(props) {
+    m_rr_depth = (int) props.int_("rr_depth", 5);
+    if (m_rr_depth <= 0) Throw("\"rr_depth\" must be set to a value greater than zero!");
+    m_max_depth = (int) props.int_("max_depth", -1);
+    if (m_max_depth < 0 && m_max_depth != -1) Throw("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
+}
+void PathIntegrator::fill_integrator(mi_render_cfg &cfg) const {
+    cfg.integrator = MI_INTEGRATOR_PATH; cfg.max_depth = m_max_depth; cfg.rr_depth = m_rr_depth;
+}
+// direct.cpp:82-103
+DirectIntegrator::DirectIntegrator(const Properties &props) : SamplingIntegrator(props) {
+    if (props.has_property("shading_samples") && (props.has_property("emitter_samples") || props.has_property("bsdf_samples")))
+        Throw("Cannot specify both 'shading_samples' and ('emitter_samples' and/or 'bsdf_samples').");
+    size_t shading_samples = (size_t) props.int_("shading_samples", 1);
+    m_emitter_samples = (size_t) props.int_("emitter_samples", (int64_t) shading_samples);
+    m_bsdf_samples = (size_t) props.int_("bsdf_samples", (int64_t) shading_samples);
+    if (m_emitter_samples + m_bsdf_samples == 0) Throw("Must have at least 1 BSDF or emitter sample!");
+}
+void DirectIntegrator::fill_integrator(mi_render_cfg &cfg) const {
+    cfg.integrator = MI_INTEGRATOR_DIRECT; cfg.max_depth = -1; cfg.rr_depth = 5;
+    cfg.emitter_samples = (uint32_t) m_emitter_samples; cfg.bsdf_samples = (uint32_t) m_bsdf_samples;
+    cfg.hide_emitters = m_hide_emitters ? 1 : 0;
+}
+std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props) {
+    if (props.plugin_name() == "moment") Throw("moment: needs a nested integrator (MomentIntegrator(props, nested))");
+    if (props.plugin_name() == "path") return std::make_shared<PathIntegrator>(props);
+    if (props.plugin_name() == "direct") return std::make_shared<DirectIntegrator>(props);
+    Throw("Plugin \"" + props.plugin_name() + "\" not found!");
+}
+void SamplingIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
+
+// integrator.cpp:75-86
+static size_t samples_per_pass_of(uint32_t samples_per_pass, size_t total_spp) {
+    size_t spp_pass = (samples_per_pass == (uint32_t) -1) ? total_spp : std::min((size_t) samples_per_pass, total_spp);
+    if (spp_pass == 0 || (total_spp % spp_pass) != 0)
+        Throw("sample_count (" + std::to_string(total_spp) + ") must be a multiple of samples_per_pass (" + std::to_string(spp_pass) + ").");
+    return spp_pass;
+}
+uint32_t SamplingIntegrator::pass_count(const PerspectiveCamera *sensor) const {
+    size_t total_spp = sensor->sampler()->sample_count();
+    return (uint32_t) (total_spp / samples_per_pass_of(m_samples_per_pass, total_spp));
+}
+void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+                                     std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
+                                     uint32_t n_threads, uint32_t pass) const {
+    std::memset(&cfg, 0, sizeof cfg);
+    const Film *film = sensor->film().get();
+    auto cs = film->crop_size(); auto co = film->crop_offset();
+    size_t total_spp = sensor->sampler()->sample_count();
+    size_t spp_pass = samples_per_pass_of(m_samples_per_pass, total_spp);
+    if (pass >= total_spp / spp_pass) Throw("make_render_cfg: pass index out of range");
+    // block size, integrator.cpp:88-97 (MTS_BLOCK_SIZE = 32, spiral.h:9-10)
+    uint32_t bs = m_block_size;
+    if (bs == 0) {
+        bs = 32;
+        while (true) {
+            size_t blocks = (size_t) ((cs[0] + bs - 1) / bs) * ((cs[1] + bs - 1) / bs);
+            if (bs == 1 || blocks >= n_threads) break;
+            bs /= 2;
+        }
+    }
+    cfg.crop_x = co[0]; cfg.crop_y = co[1]; cfg.crop_w = cs[0]; cfg.crop_h = cs[1];
+    cfg.spp = (uint32_t) spp_pass;
+    fill_integrator(cfg);
+    cfg.accumulate = pass > 0 ? 1 : 0;
+    cfg.base_seed = sensor->sampler()->base_seed();
+    cfg.block_size = (int32_t) bs;
+    // spiral visitation order -> block id per row-major block (spiral.cpp)
+    Spiral spiral(cs, co, bs, 1);
+    uint32_t nbx = (cs[0] + bs - 1) / bs;
+    block_ids.assign(spiral.block_count(), 0);
+    std::vector<uint32_t> by_id(spiral.block_count());
+    for (size_t i = 0; i < spiral.block_count(); ++i) {
+        Spiral::Block b = spiral.next_block();
+        uint32_t bx = (uint32_t) (b.offset[0] - co[0]) / bs, by = (uint32_t) (b.offset[1] - co[1]) / bs;
+        block_ids[by * nbx + bx] = (uint32_t) (b.block_id + (size_t) pass * spiral.block_count());   // spiral.cpp:41
+        by_id[b.block_id] = by * nbx + bx;
+    }
+    tiles.clear();
+    if (m_world > 1)                                           // interleaved shard over the spiral order
+        for (size_t id = m_rank; id < by_id.size(); id += m_world) tiles.push_back(by_id[id]);
+    cfg.block_ids = block_ids.data(); cfg.block_count = (uint32_t) block_ids.size();
+    cfg.tile_list = m_world > 1 ? tiles.data() : nullptr; cfg.tile_count = (uint32_t) tiles.size();
+    std::memcpy(cfg.sample_to_camera, sensor->sample_to_camera().m, 64);
+    std::memcpy(cfg.to_world, sensor->world_transform().m, 64);
+    cfg.near_clip = sensor->near_clip(); cfg.far_clip = sensor->far_clip();
+    auto pp = sensor->principal_point_offset();
+    cfg.principal_point_offset[0] = pp[0]; cfg.principal_point_offset[1] = pp[1];
+    const ReconstructionFilter *rf = film->reconstruction_filter();
+    for (int i = 0; i < 32; ++i) cfg.filter_lut[i] = rf->values()[i];
+    cfg.filter_radius = rf->radius(); cfg.filter_border = (int32_t) rf->border_size();
+    cfg.timeout_s = m_timeout; cfg.profile = m_profile ? 1 : 0;
+    cfg.plan = m_plan;
+}
+
+bool SamplingIntegrator::render_passes(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass) {
+    const uint32_t passes = pass_count(sensor);
+    mi_counters total{};
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
+        make_render_cfg(sensor, cfg, block_ids, tiles, 1, pass);
+        cfg.moment_pass = moment_pass;
+        m_active_ctx.store(scene->ctx());
+        mi_status st = mi_render(scene->ctx(), &cfg, film5);
+        m_active_ctx.store(nullptr);
+        mi_get_counters(scene->ctx(), &m_counters);
+        if (pass > 0) {                                        // work counters add up over the passes
+            m_counters.samples += total.samples; m_counters.segments += total.segments; m_counters.shadow_rays += total.shadow_rays;
+            m_counters.iterations += total.iterations; m_counters.ms_render += total.ms_render;
+        }
+        total = m_counters;
+        if (st == MI_ERR_CANCELLED) return false;
+        if (st != MI_OK) Throw(std::string("mi_render: ") + mi_last_error(scene->ctx()));
+    }
+    return true;
+}
+bool SamplingIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+    if (!scene || !sensor) Throw("render(): null scene or sensor");
+    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
+    Film *film = sensor->film().get();
+    film->prepare({ "X", "Y", "Z", "A", "W" });                // integrator.cpp:67-73
+    return render_passes(scene, sensor, film->storage().data(), MI_MOMENT_OFF);
+}
+
+// moment.cpp:33-53
+MomentIntegrator::MomentIntegrator(const Properties &props, std::shared_ptr<SamplingIntegrator> nested, std::string nested_name)
+    : SamplingIntegrator(props), m_nested(std::move(nested)), m_name(std::move(nested_name)) {
+    if (!m_nested) Throw("Child objects must be of type 'SamplingIntegrator'!");
+    if (dynamic_cast<MomentIntegrator *>(m_nested.get())) Throw("moment: nested moment integrators are not supported");
+#if MIW_SPECTRAL
+    Throw("moment: provided by the scalar_rgb build of this layer only");
+#endif
+}
+std::vector<std::string> MomentIntegrator::aov_names() const {
+    std::vector<std::string> names = { m_name + ".X", m_name + ".Y", m_name + ".Z" };
+    for (int i = 0; i < 3; ++i) names.push_back("m2_" + names[i]);
+    return names;
+}
+bool MomentIntegrator::render(Scene *scene, PerspectiveCamera *sensor) {
+    if (!scene || !sensor) Throw("render(): null scene or sensor");
+    if (!scene->ctx()) Throw("render(): the scene has no device context (Scene::build(device >= 0) first)");
+    Film *film = sensor->film().get();
+    std::vector<std::string> channels = { "X", "Y", "Z", "A", "W" };
+    for (const std::string &n : aov_names()) channels.push_back(n);
+    film->prepare(channels);
+    auto cs = film->crop_size();
+    const size_t n = (size_t) cs[0] * cs[1];
+    std::vector<float> values(n * 5), squares(n * 5);
+    m_nested->set_shard(m_rank, m_world); m_nested->set_plan(m_plan); m_nested->set_profile(m_profile);
+    bool ok = m_nested->render_passes(scene, sensor, values.data(), MI_MOMENT_VALUES) &&
+              m_nested->render_passes(scene, sensor, squares.data(), MI_MOMENT_SQUARES);
+    m_counters = m_nested->counters();
+    float *out = film->storage().data();
+    for (size_t i = 0; i < n; ++i) {
+        const float *v = &values[i * 5], *q = &squares[i * 5];
+        float *o = out + i * 11;
+        for (int k = 0; k < 5; ++k) o[k] = v[k];
+        for (int k = 0; k < 3; ++k) { o[5 + k] = v[k]; o[8 + k] = q[k]; }
+    }
+    return ok;
+}
