@@ -149,6 +149,18 @@ def test_twosided_roughplastic_and_xml(native, oracle):
     assert np.array_equal(e32, o32) and o32[..., 1].max() > 0
 
 
+def test_spectral_roughplastic(spectral, oracle_spectral):
+    """scalar_spectral: the diffuse base is an sRGB-upsampled spectrum, the coating is achromatic"""
+    from mitsuba2_amd import scenes
+    scene = _scene(spectral, alpha=0.2, diffuse_reflectance=(0.2, 0.5, 0.7), nonlinear=True)
+    sensor = scenes.cornell_sensor(24, 16, 3)
+    job = spectral.PathIntegrator(max_depth=4).render_job(sensor)
+    o32, _, st = oracle_spectral.render(scene.desc(), job, threads=4)
+    job.cfg.plan = 2
+    e64, e32, est = oracle_spectral.emu_render(scene.desc(), job)
+    assert est[1] == st.segments and np.array_equal(e32, o32) and o32[..., 1].max() > 0
+
+
 # ---- device ------------------------------------------------------------------------------------------------
 needs_gpu = pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
 
