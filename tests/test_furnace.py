@@ -78,3 +78,41 @@ def test_rough_coatings_never_gain_energy_in_the_furnace(native, oracle):
         img, _, _ = oracle.render(scene.desc(), native.PathIntegrator().render_job(_sensor(native, 128)), threads=16)
         L = _radiance(img)
         assert L.mean() < 1.0 + 5e-3 and L.max() < 1.12 and L.min() > 0.3
+
+
+def test_convex_object_under_a_uniform_environment(native, oracle):
+    """A convex diffuse object lit by a uniform environment sees Le over its whole hemisphere: L = rho Le on the
+    object (no inter-reflection), Le on the background — environment-map sampling (hierarchical warp), its MIS against
+    BSDF sampling and the analytic sphere in one closed form."""
+    le, rho = 0.8, 0.6
+    env = native.EnvMap(np.full((16, 32, 3), le, np.float32))
+    ball = native.Mesh.sphere(center=(0, 0, 0), radius=1.0, bsdf=native.BSDF("diffuse", reflectance=(rho, rho, rho)))
+    scene = native.Scene([ball], envmap=env).build(-1)
+    film = native.Film(rfilter="box", width=32, height=32)
+    sensor = native.Sensor(film, native.Sampler(sample_count=128, seed=2), fov=40.0,
+                           to_world=dict(origin=(0, 0, -4), target=(0, 0, 0), up=(0, 1, 0)))
+    img, _, st = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=16)
+    L = _radiance(img); alpha = img[..., 3] / img[..., 4]
+    on, off = alpha == 1, alpha == 0
+    assert on.sum() > 150 and off.sum() > 400
+    assert np.allclose(L[off], le, rtol=1e-5)                        # misses see the map itself
+    assert abs(L[on].mean() / (rho * le) - 1) < 3e-3 and np.abs(L[on] / (rho * le) - 1).max() < 0.1
+
+
+def test_spectral_furnace_scales_like_the_closed_form(spectral, oracle_spectral):
+    """scalar_spectral: uniform reflectance rho under a D65 emitter: L(lambda) = Le(lambda) / (1 - rho) wavelength by
+    wavelength, so the XYZ film of the rho = 0.5 enclosure is twice that of the black one"""
+    sensor = _sensor(spectral, 128)
+    films = []
+    for rho in (0.0, 0.5):
+        v = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32) * 2
+        f = np.array([[0, 1, 2], [0, 2, 3], [4, 6, 5], [4, 7, 6], [0, 4, 5], [0, 5, 1], [3, 2, 6], [3, 6, 7],
+                      [0, 3, 7], [0, 7, 4], [1, 5, 6], [1, 6, 2]], np.uint32)
+        walls = spectral.Mesh("walls", v, f, bsdf=spectral.BSDF("diffuse", reflectance=float(rho)),
+                              emitter=spectral.AreaLight(radiance=(1.0, 1.0, 1.0)))
+        scene = spectral.Scene([walls]).build(-1)
+        img, _, _ = oracle_spectral.render(scene.desc(), spectral.PathIntegrator().render_job(sensor), threads=16)
+        films.append(img)
+    for k in range(3):
+        ratio = films[1][..., k].sum() / films[0][..., k].sum()
+        assert abs(ratio / 2.0 - 1) < 6e-3, (k, ratio)
