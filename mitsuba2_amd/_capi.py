@@ -182,7 +182,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_bsdf_sample": (i32, [vp, c_float_p, f, c_float_p, c_float_p]),
         "mih_bsdf_eval_pdf": (i32, [vp, c_float_p, c_float_p, c_float_p]),
         "mih_emitter_create": (vp, [vp]), "mih_emitter_destroy": (None, [vp]),
-        "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p, c_float_p]), "mih_mesh_copy_texcoords": (None, [vp, c_float_p]), "mih_mesh_destroy": (None, [vp]),
+        "mih_mesh_create": (vp, [cp, c_float_p, u32, c_u32_p, u32, c_float_p, c_float_p]), "mih_mesh_copy_texcoords": (None, [vp, c_float_p]),
+        "mih_mesh_bbox_area": (None, [vp, c_float_p]), "mih_scene_bbox": (None, [vp, c_float_p]), "mih_mesh_destroy": (None, [vp]),
         "mih_mesh_load": (vp, [i32, vp]), "mih_mesh_recompute_normals": (i32, [vp]),
         "mih_mesh_counts": (None, [vp, c_u32_p, c_u32_p, c_i32_p]), "mih_mesh_copy": (None, [vp, c_float_p, c_u32_p, c_float_p]),
         "mih_mesh_set_bsdf": (None, [vp, vp]), "mih_mesh_set_emitter": (None, [vp, vp]),

@@ -293,6 +293,16 @@ class Mesh:
         if self.texcoords is not None:
             host_lib().mih_mesh_copy_texcoords(self.h, _fp(self.texcoords))
 
+    def bbox(self):
+        """Shape::bbox() -> (min xyz, max xyz)"""
+        out = np.zeros(7, np.float32); host_lib().mih_mesh_bbox_area(self.h, _fp(out))
+        return out[0:3].copy(), out[3:6].copy()
+
+    def surface_area(self):
+        """Shape::surface_area()"""
+        out = np.zeros(7, np.float32); host_lib().mih_mesh_bbox_area(self.h, _fp(out))
+        return float(out[6])
+
     def recompute_vertex_normals(self):
         """Mesh::recompute_vertex_normals (src/librender/mesh.cpp:200-246)"""
         if host_lib().mih_mesh_recompute_normals(self.h) != 0:
@@ -343,6 +353,11 @@ class EnvMap:
 
 
 class Scene:
+    def bbox(self):
+        """Scene::bbox() -> (min xyz, max xyz)"""
+        out = np.zeros(6, np.float32); host_lib().mih_scene_bbox(self.h, _fp(out))
+        return out[0:3].copy(), out[3:6].copy()
+
     def __init__(self, shapes, envmap=None, envmap_after=None):
         """`envmap`: an EnvMap child; `envmap_after` = number of shapes listed before it in the scene
         (default: after all shapes) — fixes its position in the emitter order (scene.cpp:38-60)."""

@@ -322,6 +322,10 @@ public:
     uint32_t vertex_count() const { return (uint32_t) (m_positions.size() / 3); }
     uint32_t face_count() const { return (uint32_t) (m_faces.size() / 3); }
     uint32_t primitive_count() const { return face_count(); }
+    // Shape::bbox (mesh.cpp:98-112) as {min xyz, max xyz}; Mesh::surface_area (mesh.cpp:285-312, 417-420: the face
+    // areas summed in double, as build_pmf feeds them to the DiscreteDistribution)
+    std::array<float, 6> bbox() const;
+    float surface_area() const;
     bool has_vertex_normals() const { return !m_normals.empty(); }
     const std::vector<float> &vertex_positions_buffer() const { return m_positions; }
     const std::vector<float> &vertex_normals_buffer() const { return m_normals; }
@@ -386,6 +390,7 @@ public:
     void build(int device = 0, int bvh_quality = 1);
     const std::vector<std::shared_ptr<Mesh>> &shapes() const { return m_shapes; }
     size_t emitter_count() const { return m_emitters.size(); }
+    std::array<float, 6> bbox() const;                         // Scene::bbox(): union of the shapes' boxes
     // Scene::ray_intersect_preliminary / ray_test for one ray or a batch
     PreliminaryIntersection3f ray_intersect_preliminary(const Ray3f &ray) const;
     bool ray_test(const Ray3f &ray) const;

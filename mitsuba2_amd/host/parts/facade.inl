@@ -133,6 +133,10 @@ void mih_mesh_copy(void *m, float *pos, uint32_t *faces, float *normals) {
     if (faces) std::memcpy(faces, me.faces_buffer().data(), me.faces_buffer().size() * 4);
     if (normals && me.has_vertex_normals()) std::memcpy(normals, me.vertex_normals_buffer().data(), me.vertex_normals_buffer().size() * 4);
 }
+void mih_mesh_bbox_area(void *m, float *out7) {               // min xyz, max xyz, surface area
+    const Mesh &me = *((Box<Mesh> *) m)->p; auto b = me.bbox(); for (int k = 0; k < 6; ++k) out7[k] = b[k]; out7[6] = me.surface_area();
+}
+void mih_scene_bbox(void *s, float *out6) { auto b = ((Box<Scene> *) s)->p->bbox(); for (int k = 0; k < 6; ++k) out6[k] = b[k]; }
 void mih_mesh_destroy(void *m) { delete (Box<Mesh> *) m; }
 void mih_mesh_set_bsdf(void *m, void *b) { ((Box<Mesh> *) m)->p->set_bsdf(((Box<BSDF> *) b)->p); }
 void mih_mesh_set_emitter(void *m, void *e) { ((Box<Mesh> *) m)->p->set_emitter(((Box<AreaLight> *) e)->p); }

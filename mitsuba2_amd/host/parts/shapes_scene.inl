@@ -18,6 +18,32 @@ static float unit_angle(miw::V3 a, miw::V3 b) {
     float temp = 2.f * miw::asin_(.5f * miw::norm(t));
     return dot_uv >= 0.f ? temp : MIW_PI - temp;
 }
+std::array<float, 6> Mesh::bbox() const {
+    const float inf = std::numeric_limits<float>::infinity();
+    std::array<float, 6> b{ inf, inf, inf, -inf, -inf, -inf };
+    if (m_sphere) {                                            // sphere.cpp:133-138
+        for (int k = 0; k < 3; ++k) { b[k] = m_sphere_rec.center[k] - m_sphere_rec.radius; b[3 + k] = m_sphere_rec.center[k] + m_sphere_rec.radius; }
+        return b;
+    }
+    for (size_t i = 0; i < m_positions.size(); i += 3)
+        for (int k = 0; k < 3; ++k) { b[k] = std::min(b[k], m_positions[i + k]); b[3 + k] = std::max(b[3 + k], m_positions[i + k]); }
+    return b;
+}
+float Mesh::surface_area() const {
+    if (m_sphere) return 4.f * MIW_PI * m_sphere_rec.radius * m_sphere_rec.radius;              // sphere.cpp:140-142
+    if (m_rectangle) {                                         // rectangle.cpp:88-96: |dp_du x dp_dv|
+        const float *m = m_rect_to_world.m;
+        miw::V3 du = miw::v3(2.f * m[0], 2.f * m[1], 2.f * m[2]), dv = miw::v3(2.f * m[4], 2.f * m[5], 2.f * m[6]);
+        return miw::norm(miw::cross(du, dv));
+    }
+    double sum = 0.0;
+    for (size_t f = 0; f < m_faces.size(); f += 3) {
+        auto P = [&](uint32_t i) { return miw::v3(m_positions[3 * i], m_positions[3 * i + 1], m_positions[3 * i + 2]); };
+        const miw::V3 p0 = P(m_faces[f]), p1 = P(m_faces[f + 1]), p2 = P(m_faces[f + 2]);
+        sum += (double) (.5f * miw::norm(miw::cross(p1 - p0, p2 - p0)));                           // face_area, mesh.h:127-134
+    }
+    return (float) sum;
+}
 void Mesh::recompute_vertex_normals() {
     const uint32_t nv = vertex_count(), nf = face_count();
     std::vector<miw::V3> acc(nv, miw::v3(0.f));
@@ -262,6 +288,12 @@ bool PreliminaryIntersection3f::is_valid() const { return t != std::numeric_limi
 
 Scene::Scene() {}
 Scene::~Scene() { if (m_ctx) mi_destroy(m_ctx); }
+std::array<float, 6> Scene::bbox() const {
+    const float inf = std::numeric_limits<float>::infinity();
+    std::array<float, 6> b{ inf, inf, inf, -inf, -inf, -inf };
+    for (const auto &m : m_shapes) { auto s = m->bbox(); for (int k = 0; k < 3; ++k) { b[k] = std::min(b[k], s[k]); b[3 + k] = std::max(b[3 + k], s[3 + k]); } }
+    return b;
+}
 void Scene::add_shape(std::shared_ptr<Mesh> mesh) {
     if (m_built) Throw("Scene: cannot add shapes after build()");
     m_shapes.push_back(std::move(mesh));

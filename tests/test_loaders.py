@@ -111,3 +111,18 @@ def test_loaded_mesh_renders_like_the_in_memory_mesh(native, oracle, tmp_path):
         films.append(oracle.render(scene.desc(), job, threads=4, want_f64=False)[0])
     assert np.allclose(films[0], films[1], rtol=2e-3, atol=1e-5) and films[0][..., 1].max() > 0
     assert (films[0] == films[1]).mean() > 0.5
+
+
+def test_mesh_bbox_and_surface_area(native):
+    """src/librender/tests/test_mesh.py:10-32 (test01_create_mesh): bbox [0,0,0]-[1,1,0], surface_area 0.96"""
+    m = native.Mesh("MyMesh", [[0.0, 0.0, 0.0], [1.0, 0.2, 0.0], [0.2, 1.0, 0.0]], [[0, 1, 2], [1, 2, 0]])
+    lo, hi = m.bbox()
+    assert np.array_equal(lo, [0, 0, 0]) and np.array_equal(hi, [1, 1, 0])
+    assert m.surface_area() == pytest.approx(0.96, abs=1e-6)
+    s = native.Mesh.sphere(center=(1, 2, 3), radius=0.5)
+    lo, hi = s.bbox()
+    assert np.allclose(lo, [.5, 1.5, 2.5]) and np.allclose(hi, [1.5, 2.5, 3.5]) and s.surface_area() == pytest.approx(np.pi, rel=1e-6)
+    r = native.Mesh.rectangle(to_world=np.diag([2.0, 3.0, 1.0, 1.0]).astype(np.float32))
+    assert r.surface_area() == pytest.approx(24.0, rel=1e-6)
+    lo, hi = native.Scene([m, s]).bbox()
+    assert np.allclose(lo, [0, 0, 0]) and np.allclose(hi, [1.5, 2.5, 3.5])
