@@ -196,7 +196,7 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_scene_ray_intersect": (i32, [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), u64]),
         "mih_scene_ray_test": (i32, [vp, C.POINTER(mi_rays_soa), c_float_p, u64]),
         "mih_film_create": (vp, [vp]), "mih_film_destroy": (None, [vp]),
-        "mih_film_set_filter": (i32, [vp, cp, vp]),
+        "mih_film_set_filter": (i32, [vp, cp, vp]), "mih_film_filter_eval": (i32, [vp, f, c_float_p]),
         "mih_film_develop": (cp, [vp, cp]), "mih_film_set_data": (i32, [vp, c_float_p, u64]),
         "mih_film_crop_size": (None, [vp, c_i32_p, c_i32_p]),
         "mih_film_data": (c_float_p, [vp, C.POINTER(u64)]), "mih_film_develop_rgb": (i32, [vp, c_float_p]),

@@ -422,6 +422,13 @@ class Film:
         host_lib().mih_film_crop_size(self.h, C.byref(w), C.byref(h))
         return w.value, h.value
 
+    def rfilter(self, x):
+        """the film's reconstruction filter at x -> dict(eval, eval_discretized, radius, border_size)"""
+        out = np.zeros(4, np.float32)
+        if host_lib().mih_film_filter_eval(self.h, float(x), _fp(out)) != 0:
+            raise RuntimeError(_err())
+        return dict(eval=float(out[0]), eval_discretized=float(out[1]), radius=float(out[2]), border_size=int(out[3]))
+
     def set_data(self, xyzaw):
         """fill the film's X, Y, Z, A, W storage (what mi_render writes)"""
         a = np.ascontiguousarray(xyzaw, np.float32)

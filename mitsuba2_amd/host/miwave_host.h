@@ -152,6 +152,32 @@ public:
     float eval(float x) const override;
 };
 
+// src/rfilters/{tent,mitchell,catmullrom,lanczos}.cpp. The device takes any filter as its 32-entry table + radius
+// (mi_render_cfg::filter_lut): footprints up to 4 x 4 texels replay through k_film_groups, wider ones (lanczos)
+// through k_film_blocks. On-device parity has been verified for box and gaussian; the others share their code paths.
+class TentFilter final : public ReconstructionFilter {
+public:
+    explicit TentFilter(const Properties &props = Properties("tent"));          // tent.cpp:25-31: radius 1
+    float eval(float x) const override;
+private:
+    float m_inv_radius;
+};
+class MitchellNetravaliFilter final : public ReconstructionFilter {
+public:
+    explicit MitchellNetravaliFilter(const Properties &props = Properties("mitchell"));   // mitchell.cpp:28-36: radius 2, B = C = 1/3
+    MitchellNetravaliFilter(float b, float c);                                  // catmullrom.cpp: B = 0, C = 1/2
+    float eval(float x) const override;
+private:
+    float m_b, m_c;
+};
+class LanczosSincFilter final : public ReconstructionFilter {
+public:
+    explicit LanczosSincFilter(const Properties &props = Properties("lanczos")); // lanczos.cpp:33-38: radius = lobes (3)
+    float eval(float x) const override;
+};
+// PluginManager::create_object<ReconstructionFilter>(props): box, tent, gaussian, mitchell, catmullrom, lanczos
+std::shared_ptr<ReconstructionFilter> make_rfilter(const Properties &props);
+
 // ---- Film / HDRFilm (src/librender/film.cpp:7-50, src/films/hdrfilm.cpp) ---------------
 class Film {
 public:

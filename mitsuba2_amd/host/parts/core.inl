@@ -304,3 +304,33 @@ BoxFilter::BoxFilter(const Properties &props) {
     init_discretization();
 }
 float BoxFilter::eval(float x) const { return std::abs(x) <= m_radius ? 1.f : 0.f; }
+TentFilter::TentFilter(const Properties &) { m_radius = 1.f; m_inv_radius = 1.f / m_radius; init_discretization(); }
+float TentFilter::eval(float x) const { return std::max(0.f, 1.f - std::abs(x * m_inv_radius)); }
+MitchellNetravaliFilter::MitchellNetravaliFilter(const Properties &props) {
+    m_radius = 2.f; m_b = props.float_("B", 1.f / 3.f); m_c = props.float_("C", 1.f / 3.f);
+    init_discretization();
+}
+MitchellNetravaliFilter::MitchellNetravaliFilter(float b, float c) { m_radius = 2.f; m_b = b; m_c = c; init_discretization(); }
+float MitchellNetravaliFilter::eval(float x_) const {           // mitchell.cpp:38-51, catmullrom.cpp:29-44
+    const float x = std::abs(x_), x2 = x * x, x3 = x2 * x, B = m_b, C = m_c;
+    const float inner = (12.f - 9.f * B - 6.f * C) * x3 + (-18.f + 12.f * B + 6.f * C) * x2 + (6.f - 2.f * B),
+                outer = (-B - 6.f * C) * x3 + (6.f * B + 30.f * C) * x2 + (-12.f * B - 48.f * C) * x + (8.f * B + 24.f * C);
+    const float result = (1.f / 6.f) * (x < 1.f ? inner : outer);
+    return x < 2.f ? result : 0.f;
+}
+LanczosSincFilter::LanczosSincFilter(const Properties &props) { m_radius = (float) props.int_("lobes", 3); init_discretization(); }
+float LanczosSincFilter::eval(float x_) const {                 // lanczos.cpp:40-50
+    const float x = std::abs(x_), x1 = MIW_PI * x, x2 = x1 / m_radius;
+    if (x < MIW_EPSILON) return 1.f;
+    return x > m_radius ? 0.f : (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+}
+std::shared_ptr<ReconstructionFilter> make_rfilter(const Properties &props) {
+    const std::string &n = props.plugin_name();
+    if (n == "gaussian") return std::make_shared<GaussianFilter>(props);
+    if (n == "box") return std::make_shared<BoxFilter>(props);
+    if (n == "tent") return std::make_shared<TentFilter>(props);
+    if (n == "mitchell") return std::make_shared<MitchellNetravaliFilter>(props);
+    if (n == "catmullrom") return std::make_shared<MitchellNetravaliFilter>(0.f, .5f);
+    if (n == "lanczos") return std::make_shared<LanczosSincFilter>(props);
+    Throw("Plugin \"" + n + "\" not found!");
+}

@@ -186,11 +186,15 @@ int mih_film_set_filter(void *f, const char *name, void *props) {
         std::shared_ptr<ReconstructionFilter> rf;
         Properties def(name);
         const Properties &p = props ? *(Properties *) props : def;
-        if (std::string(name) == "gaussian") rf = std::make_shared<GaussianFilter>(p);
-        else if (std::string(name) == "box") rf = std::make_shared<BoxFilter>(p);
-        else throw std::runtime_error(std::string("Plugin \"") + name + "\" not found!");
+        Properties named(name);
+        rf = make_rfilter(props ? p : named);
         ((Box<Film> *) f)->p->set_reconstruction_filter(rf);
         return 0; MIH_CATCH(-1)
+}
+// ReconstructionFilter::eval / eval_discretized / radius / border_size of the film's filter
+int mih_film_filter_eval(void *f, float x, float *out4) {
+    MIH_TRY const ReconstructionFilter *rf = ((Box<Film> *) f)->p->reconstruction_filter();
+        out4[0] = rf->eval(x); out4[1] = rf->eval_discretized(x); out4[2] = rf->radius(); out4[3] = (float) rf->border_size(); return 0; MIH_CATCH(-1)
 }
 const float *mih_film_data(void *f, uint64_t *count) {
     auto &s = ((Box<Film> *) f)->p->storage();

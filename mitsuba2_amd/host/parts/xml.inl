@@ -248,9 +248,7 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
                     for (const XmlNode *r : fobjs) {
                         if (r->tag != "rfilter") Throw("Error while loading XML: unexpected <" + r->tag + "> inside <film>");
                         Properties rp(cx.get(*r, "type")); parse_properties(cx, *r, rp);
-                        if (rp.plugin_name() == "gaussian") film->set_reconstruction_filter(std::make_shared<GaussianFilter>(rp));
-                        else if (rp.plugin_name() == "box") film->set_reconstruction_filter(std::make_shared<BoxFilter>(rp));
-                        else Throw("Plugin \"" + rp.plugin_name() + "\" not found!");
+                        film->set_reconstruction_filter(make_rfilter(rp));
                     }
                 } else if (c->tag == "sampler") {
                     Properties sp(cx.get(*c, "type"));
