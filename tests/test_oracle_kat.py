@@ -636,3 +636,26 @@ def test_inverse_trig_accuracy(oracle):
     assert np.max(np.abs(got[:, 2] - np.arcsin(x.astype(np.float64)))) < 3e-7
     sp = oracle.eval(10, np.array([[0.0, -1.0], [-0.0, -1.0], [0.0, 1.0], [1.0, 0.0], [-1.0, 0.0]], np.float32))[:, 0]
     assert np.allclose(sp, [np.pi, -np.pi, 0.0, np.pi / 2, -np.pi / 2], atol=1e-7)
+
+
+@pytest.mark.parametrize("direction", [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+@pytest.mark.parametrize("fov", [34.0, 80.0])
+def test_perspective_fov_axis(native, direction, fov):
+    """src/sensors/tests/test_perspective.py:133-163 (test04_fov_axis): film aspect 1.5; the film's edge along the chosen
+    axis (its corners for `diagonal`) is fov / 2 away from the optical axis"""
+    from mitsuba2_amd import api
+    origin = [1.0, 0.0, 1.5]
+    film = api.Film(width=768, height=512); sampler = api.Sampler()
+    t = [origin[i] + direction[i] for i in range(3)]
+
+    def check(axis, samples):
+        cam = api.Sensor(film, sampler, fov=fov, fov_axis=axis, near_clip=1.0, far_clip=35.0, to_world=dict(origin=origin, target=t, up=(0, 1, 0)))
+        for sx, sy in samples:
+            r = cam.sample_ray(sx, sy)
+            ang = math.degrees(math.acos(np.clip(np.dot(r[3:6], direction), -1, 1)))
+            assert abs(ang - fov / 2) < 2e-3, (axis, sx, sy, ang)
+    for axis in ("x", "larger"):
+        check(axis, [(0.0, 0.5), (1.0, 0.5)])
+    for axis in ("y", "smaller"):
+        check(axis, [(0.5, 0.0), (0.5, 1.0)])
+    check("diagonal", [(0.0, 0.0), (0.0, 1.0), (1.0, 0.0), (1.0, 1.0)])
