@@ -152,3 +152,21 @@ def test_device_film_with_every_filter(native, oracle, name):
         assert st == 0 and np.array_equal(g64.astype(np.float32), o64.astype(np.float32))
     finally:
         dev.close()
+
+
+def test_hdrfilm_construct_and_crops(native):
+    """src/films/tests/test_hdrfilm.py:7-71 (test01_construct, test02_crops)"""
+    assert native.Film().rfilter(0)["radius"] == 2.0                 # default reconstruction filter: gaussian
+    film = native.Film()
+    props = native.Properties("gaussian", stddev=18.5)
+    assert native.host_lib().mih_film_set_filter(film.h, b"gaussian", props.h) == 0 and film.rfilter(0)["radius"] == 4 * 18.5
+    for bad in (dict(component_format="uint8"), dict(pixel_format="brga")):
+        with pytest.raises(RuntimeError):
+            native.Film(**bad)
+    film = native.Film(width=32, height=21, crop_width=11, crop_height=5, crop_offset_x=2, crop_offset_y=3,
+                       high_quality_edges=True, pixel_format="rgba")
+    assert film.crop_size() == (11, 5)
+    incomplete = dict(width=32, height=21, crop_offset_x=30, crop_offset_y=20)
+    with pytest.raises(RuntimeError, match="Invalid crop window"):
+        native.Film(**incomplete)                                   # the crop size does not adjust itself
+    assert native.Film(crop_width=2, crop_height=1, **incomplete).crop_size() == (2, 1)
