@@ -116,3 +116,35 @@ def test_spectral_furnace_scales_like_the_closed_form(spectral, oracle_spectral)
     for k in range(3):
         ratio = films[1][..., k].sum() / films[0][..., k].sum()
         assert abs(ratio / 2.0 - 1) < 6e-3, (k, ratio)
+
+
+@pytest.mark.parametrize("light", ["rectangle", "mesh"])
+@pytest.mark.parametrize("integ", ["direct", "path"])
+def test_irradiance_under_a_square_light_matches_the_form_factor(native, oracle, light, integ):
+    """A diffuse floor point straight below the centre of a parallel square emitter (half side a, height h) receives
+    E = Le pi F with the classic differential-element-to-rectangle form factor F = 4 F_corner(a / h, a / h),
+    F_corner(X, Y) = [X / sqrt(1 + X^2) atan(Y / sqrt(1 + X^2)) + Y / sqrt(1 + Y^2) atan(X / sqrt(1 + Y^2))] / (2 pi);
+    the camera sees rho Le F there. Analytic rectangle light and two-triangle mesh light, one-bounce integrators."""
+    a, h, le, rho = 0.5, 1.0, 3.0, 0.8
+    X = a / h
+    f_corner = (X / np.sqrt(1 + X * X) * np.arctan(X / np.sqrt(1 + X * X))) * 2 / (2 * np.pi)
+    want = rho * le * 4 * f_corner
+    floor = native.Mesh("floor", [[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], [[0, 2, 1], [0, 3, 2]],
+                        bsdf=native.BSDF("diffuse", reflectance=(rho, rho, rho)))
+    black = native.BSDF("diffuse", reflectance=(0, 0, 0))
+    if light == "mesh":
+        lamp = native.Mesh("lamp", [[-a, h, -a], [a, h, -a], [a, h, a], [-a, h, a]], [[0, 1, 2], [0, 2, 3]], bsdf=black,
+                           emitter=native.AreaLight(radiance=(le, le, le)))
+    else:
+        m = np.array([[a, 0, 0, 0], [0, 0, -a, h], [0, a, 0, 0], [0, 0, 0, 1]], np.float32)     # [-1,1]^2 -> the same square, normal -y
+        lamp = native.Mesh.rectangle(to_world=m, bsdf=black, emitter=native.AreaLight(radiance=(le, le, le)))
+    scene = native.Scene([floor, lamp]).build(-1)
+    film = native.Film(rfilter="box", width=8, height=8)
+    # looking at the origin from the side, under the lamp's plane, with a narrow field of view
+    sensor = native.Sensor(film, native.Sampler(sample_count=2048, seed=5), fov=0.5,
+                           to_world=dict(origin=(3.0, 0.6, 0.0), target=(0, 0, 0), up=(0, 1, 0)))
+    integrator = native.DirectIntegrator() if integ == "direct" else native.PathIntegrator(max_depth=2)
+    img, _, st = oracle.render(scene.desc(), integrator.render_job(sensor), threads=16)
+    L = _radiance(img)
+    assert (img[..., 3] == img[..., 4]).all()
+    assert abs(L.mean() / want - 1) < 4e-3, (L.mean(), want)
