@@ -148,3 +148,22 @@ def test_irradiance_under_a_square_light_matches_the_form_factor(native, oracle,
     L = _radiance(img)
     assert (img[..., 3] == img[..., 4]).all()
     assert abs(L.mean() / want - 1) < 4e-3, (L.mean(), want)
+
+
+def test_irradiance_from_a_sphere_light(native, oracle):
+    """A surface element facing a spherical emitter (radius r, centre at distance d along its normal) receives
+    E = pi Le (r / d)^2: the analytic sphere's solid-angle (cone) sampling and its pdf under MIS"""
+    r, d, le, rho = 0.4, 1.5, 5.0, 0.7
+    want = rho * le * (r / d) ** 2
+    floor = native.Mesh("floor", [[-20, 0, -20], [20, 0, -20], [20, 0, 20], [-20, 0, 20]], [[0, 2, 1], [0, 3, 2]],
+                        bsdf=native.BSDF("diffuse", reflectance=(rho, rho, rho)))
+    lamp = native.Mesh.sphere(center=(0, d, 0), radius=r, bsdf=native.BSDF("diffuse", reflectance=(0, 0, 0)),
+                              emitter=native.AreaLight(radiance=(le, le, le)))
+    scene = native.Scene([floor, lamp]).build(-1)
+    film = native.Film(rfilter="box", width=8, height=8)
+    sensor = native.Sensor(film, native.Sampler(sample_count=2048, seed=6), fov=0.5,
+                           to_world=dict(origin=(3.0, 0.6, 0.0), target=(0, 0, 0), up=(0, 1, 0)))
+    for integrator in (native.DirectIntegrator(), native.DirectIntegrator(emitter_samples=0, bsdf_samples=4)):
+        img, _, _ = oracle.render(scene.desc(), integrator.render_job(sensor), threads=16)
+        tol = 4e-3 if integrator.render_job(sensor).cfg.emitter_samples else 2e-2       # BSDF sampling alone is noisier
+        assert abs(_radiance(img).mean() / want - 1) < tol, (_radiance(img).mean(), want)
