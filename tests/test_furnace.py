@@ -167,3 +167,24 @@ def test_irradiance_from_a_sphere_light(native, oracle):
         img, _, _ = oracle.render(scene.desc(), integrator.render_job(sensor), threads=16)
         tol = 4e-3 if integrator.render_job(sensor).cfg.emitter_samples else 2e-2       # BSDF sampling alone is noisier
         assert abs(_radiance(img).mean() / want - 1) < tol, (_radiance(img).mean(), want)
+
+
+def test_floor_under_a_zenith_weighted_sky(native, oracle):
+    """Lat-long environment map whose radiance depends on the polar angle only, L(theta) = C max(0, cos theta)^2 with
+    theta measured from +Y (row 0 = +Y pole, envmap.cpp:140-143): a horizontal diffuse floor receives
+    E = C int cos^3 theta d omega = pi C / 2 and shows rho C / 2 — the map's orientation, its importance sampling
+    through the hierarchical warp and the MIS with BSDF sampling, against a closed form"""
+    C, rho, H, W = 2.0, 0.6, 256, 512
+    theta = np.pi * np.arange(H) / (H - 1)
+    row = C * np.maximum(0.0, np.cos(theta)) ** 2
+    sky = np.repeat(np.repeat(row[:, None, None], W, axis=1), 3, axis=2).astype(np.float32)
+    floor = native.Mesh("floor", [[-50, 0, -50], [50, 0, -50], [50, 0, 50], [-50, 0, 50]], [[0, 2, 1], [0, 3, 2]],
+                        bsdf=native.BSDF("diffuse", reflectance=(rho, rho, rho)))
+    scene = native.Scene([floor], envmap=native.EnvMap(sky)).build(-1)
+    film = native.Film(rfilter="box", width=8, height=8)
+    sensor = native.Sensor(film, native.Sampler(sample_count=1024, seed=7), fov=1.0,
+                           to_world=dict(origin=(2.0, 3.0, 1.0), target=(0, 0, 0), up=(0, 1, 0)))
+    want = rho * C / 2
+    for integrator in (native.PathIntegrator(), native.DirectIntegrator(shading_samples=2)):
+        img, _, _ = oracle.render(scene.desc(), integrator.render_job(sensor), threads=16)
+        assert abs(_radiance(img).mean() / want - 1) < 4e-3, (_radiance(img).mean(), want)
