@@ -3,6 +3,7 @@
 #include "miwave_host.h"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <mutex>

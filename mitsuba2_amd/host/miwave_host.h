@@ -528,7 +528,7 @@ private:
 std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props);
 
 // ---- XML scene front-end, a subset (src/libcore/xml.cpp) --------------------------
-// <scene>, <default>, $parameters (also from `params`), <shape type="obj|ply|rectangle|sphere">, <bsdf> (inline, or
+// <scene>, <default>, <include>, <alias>, $parameters (also from `params`), <shape type="obj|ply|rectangle|sphere">, <bsdf> (inline, or
 // top-level with id + <ref id=.../>), <texture type="bitmap"> (PFM files; nested in a <bsdf> under the parameter's
 // name, or top-level with id + <ref id=... name=.../>), <emitter type="area">, <emitter type="envmap"> (PFM file), <sensor type="perspective"> with <film>,
 // <sampler>, <rfilter> children, <integrator type="path|direct">; values <float> <integer> <boolean> <string> <rgb>

@@ -218,8 +218,28 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
     XmlCtx cx; cx.params = params; cx.base_dir = base_dir;
     LoadedScene out; out.scene = std::make_shared<Scene>();
     std::shared_ptr<EnvironmentMapEmitter> pending_env;
-    for (const XmlNode &n : root.children) {
-        if (n.tag == "default") { std::string k = cx.get(n, "name"); if (!cx.params.count(k)) cx.params[k] = cx.get(n, "value"); }
+    // one child of <scene>; <include> re-enters with the children of the included file's <scene> (xml.cpp:653-700)
+    std::function<void(const XmlNode &, int)> handle = [&](const XmlNode &n, int depth) {
+        if (n.tag == "include") {
+            if (depth >= 15) Throw("Exceeded <include> recursion limit of 15");               // MTS_XML_INCLUDE_MAX_RECURSION
+            const std::string file = resolve(cx, cx.get(n, "filename"));
+            FILE *probe = std::fopen(file.c_str(), "rb");
+            if (!probe) Throw("Error while loading XML: included file \"" + file + "\" not found");
+            std::fclose(probe);
+            const std::string text = read_file(file, "XML");
+            XmlParser nested(text);
+            XmlNode inc = nested.element();
+            if (inc.tag != "scene") Throw("Error while loading XML: the included file \"" + file + "\" must have a <scene> root in this layer");
+            for (const XmlNode &c : inc.children) handle(c, depth + 1);
+        }
+        else if (n.tag == "alias") {                           // xml.cpp:594-612
+            const std::string src = cx.get(n, "id"), dst = cx.get(n, "as");
+            if (cx.bsdfs.count(dst) || cx.textures.count(dst)) Throw("Error while loading XML: \"alias\" has duplicate id \"" + dst + "\"");
+            if (cx.bsdfs.count(src)) cx.bsdfs[dst] = cx.bsdfs[src];
+            else if (cx.textures.count(src)) cx.textures[dst] = cx.textures[src];
+            else Throw("Error while loading XML: referenced id \"" + src + "\" not found");
+        }
+        else if (n.tag == "default") { std::string k = cx.get(n, "name"); if (!cx.params.count(k)) cx.params[k] = cx.get(n, "value"); }
         else if (n.tag == "bsdf") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <bsdf> needs an id"); parse_bsdf(cx, n); }
         else if (n.tag == "texture") { if (!n.attr.count("id")) Throw("Error while loading XML: a top-level <texture> needs an id"); parse_texture(cx, n); }
         else if (n.tag == "integrator") {
@@ -290,7 +310,8 @@ LoadedScene load_xml_string(const std::string &xml, const std::map<std::string, 
             }
             out.scene->add_shape(mesh); out.shapes.push_back(mesh);
         } else Throw("Error while loading XML: unexpected <" + n.tag + "> inside <scene>");
-    }
+    };
+    for (const XmlNode &n : root.children) handle(n, 0);
     if (!out.integrator) out.integrator = std::make_shared<PathIntegrator>(Properties("path"));
     return out;
 }

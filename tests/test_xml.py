@@ -149,3 +149,29 @@ def test_xml_bitmap_texture_and_envmap_files(native, oracle, tmp_path):
     with pytest.raises(RuntimeError, match="file not found"):
         native.load_string('<scene version="2.0.0"><shape type="rectangle"><bsdf type="diffuse"><texture type="bitmap" name="reflectance">'
                            '<string name="filename" value="nope.pfm"/></texture></bsdf></shape></scene>')
+
+
+def test_xml_include_and_alias(native, oracle, tmp_path):
+    """<include filename=.../> splices the children of another file's <scene> in place (xml.cpp:653-700); <alias id as>
+    gives an object a second id (:594-612)"""
+    (tmp_path / "materials.xml").write_text("""<scene version="2.0.0">
+        <bsdf type="diffuse" id="red"><rgb name="reflectance" value="0.6, 0.1, 0.1"/></bsdf>
+        <alias id="red" as="wall"/>
+    </scene>""")
+    (tmp_path / "main.xml").write_text("""<scene version="2.0.0">
+        <include filename="materials.xml"/>
+        <shape type="rectangle"><ref id="wall"/></shape>
+        <shape type="rectangle"><transform name="to_world"><translate z="1"/></transform><ref id="red"/></shape>
+    </scene>""")
+    scene, sensor, integ = native.load_file(str(tmp_path / "main.xml"))
+    scene.build(-1)
+    d = scene.desc().contents
+    assert d.shape_count == 2 and d.bsdf_count == 1 and d.shapes[0].bsdf == d.shapes[1].bsdf == 0      # one object, two names
+    assert np.allclose(list(d.bsdfs[0].params)[:3], [0.6, 0.1, 0.1])
+    with pytest.raises(RuntimeError, match="not found"):
+        native.load_string('<scene version="2.0.0"><include filename="nope.xml"/></scene>')
+    with pytest.raises(RuntimeError, match="referenced id"):
+        native.load_string('<scene version="2.0.0"><alias id="a" as="b"/></scene>')
+    (tmp_path / "loop.xml").write_text('<scene version="2.0.0"><include filename="loop.xml"/></scene>')
+    with pytest.raises(RuntimeError, match="recursion limit"):
+        native.load_file(str(tmp_path / "loop.xml"))
