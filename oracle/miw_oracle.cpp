@@ -22,6 +22,9 @@
 // hold for this path; the whole-image result is NOT pinned by the reference (its
 // stored references are statistical and its data submodule is absent; the real
 // binary cannot be built here: ext/enoki, ext/tbb ... are empty) — see DESIGN.md.
+// The estimators as a whole (path, direct: also restated here, direct.cpp:105-198; the moment wrapper) are checked
+// against closed forms that share no code with them (tests/test_furnace.py) and by the statistical tier of the
+// reference's own tests (tests/test_chi2.py, tests/test_moment.py).
 //
 // Denormals: preserved (plain IEEE) on both sides — see FtzScope below.
 #include <algorithm>
