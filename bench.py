@@ -53,6 +53,11 @@ def main():
                     help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs oracle/_ref/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
     ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"],
+                    help="how N ranks split the frame. tiles (default, the north star's partition): spiral blocks dealt round-robin, "
+                         "every rank renders all spp of its pixels. passes: the reference's own samples_per_pass = spp / N run "
+                         "(integrator.cpp:75-86, spiral.cpp:41) with pass r rendered by rank r — every rank keeps all pixels (full "
+                         "occupancy), the image is the one scalar_rgb produces for that samples_per_pass, not for a single pass")
     ap.add_argument("--integrator", default="path", choices=["path", "direct"],
                     help="path = the headline (BASELINE metric); direct = src/integrators/direct.cpp on the same device loop")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
@@ -92,14 +97,22 @@ def main():
     dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
     bvh = dev.counters()
     make_integrator = api.DirectIntegrator if args.integrator == "direct" else api.PathIntegrator
-    integ = make_integrator()
-    integ.set_shard(rank, world)
-    if args.shard_of > 1 and world == 1:
-        integ.set_shard(0, args.shard_of)
-    job = integ.render_job(sensor)
+    parts = world if world > 1 else max(args.shard_of, 1)          # ranks, or the rank count --shard-of stands for
+    if args.shard == "passes" and parts > 1:
+        if SPP % parts:
+            raise SystemExit("--shard passes: spp must be a multiple of the number of ranks")
+        integ = make_integrator(samples_per_pass=SPP // parts)
+        job = integ.render_job(sensor, pass_index=rank)            # pass r carries block ids r * block_count + counter
+        job.cfg.accumulate = 0                                     # a rank's film holds its own pass; the reduce adds them
+    else:
+        integ = make_integrator()
+        integ.set_shard(rank, world)
+        if args.shard_of > 1 and world == 1:
+            integ.set_shard(0, args.shard_of)
+        job = integ.render_job(sensor)
     cfg = job.cfg
     cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
-    cfg.plan = args.plan; cfg.samples_per_launch = SPP if args.samples_per_launch < 0 else args.samples_per_launch
+    cfg.plan = args.plan; cfg.samples_per_launch = int(cfg.spp) if args.samples_per_launch < 0 else args.samples_per_launch
     film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     dev.check(dev.L.mi_set_stream(dev.ctx, C.c_void_p(stream.cuda_stream)))
@@ -207,7 +220,7 @@ def main():
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
                        "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 3),
                                "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
-                       "parallelism": "tile-shard x%d + RCCL film reduce" % world if world > 1 else "single GPU",
+                       "parallelism": ("%s-shard x%d + RCCL film reduce" % ("tile" if args.shard == "tiles" else "pass", world)) if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu,

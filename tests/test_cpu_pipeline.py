@@ -147,6 +147,28 @@ def test_samples_per_pass(native, oracle):
         native.PathIntegrator(samples_per_pass=4).render_job(sensor)
 
 
+def test_pass_shards_sum_to_the_multi_pass_film(native, oracle):
+    """bench.py --shard passes: rank r renders pass r of the samples_per_pass = spp / N run into its own film
+    (accumulate = 0), one reduce adds them. Sum of the pass films == the film the passes build one onto the other
+    (the reference's order), up to the rounding of a different float32 summation order; exactly in float64."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(40, 36, 8, device=-1)
+    integ = native.PathIntegrator(samples_per_pass=2)
+    seq32 = seq64 = None
+    parts32, parts64 = [], []
+    for p in range(4):
+        job = integ.render_job(sensor, pass_index=p)
+        seq32, seq64, _ = oracle.render(scene.desc(), job, threads=4, onto=(seq32, seq64))
+        job.cfg.accumulate = 0
+        a32, a64, st = oracle.render(scene.desc(), job, threads=4)
+        assert st.samples == 40 * 36 * 2
+        parts32.append(a32); parts64.append(a64)
+    total = np.sum(np.asarray(parts32, np.float64), axis=0)
+    assert rel_l2(total, seq32) < 1e-6 and np.allclose(total, seq32, rtol=2e-6, atol=1e-7)
+    assert np.allclose(np.sum(parts64, axis=0), seq64, rtol=1e-12)
+    assert not np.array_equal(parts32[0], parts32[1])               # different seeds per pass (spiral.cpp:41)
+
+
 @pytest.mark.parametrize("kw", [dict(max_depth=1), dict(max_depth=2), dict(max_depth=3, rr_depth=1), dict(rr_depth=2)])
 def test_depth_and_rr_variants(native, oracle, kw):
     from mitsuba2_amd import scenes
