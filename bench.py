@@ -53,11 +53,13 @@ def main():
                     help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs oracle/_ref/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
     ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
-    ap.add_argument("--shard", default="tiles", choices=["tiles", "passes"],
-                    help="how N ranks split the frame. tiles (default, the north star's partition): spiral blocks dealt round-robin, "
-                         "every rank renders all spp of its pixels. passes: the reference's own samples_per_pass = spp / N run "
-                         "(integrator.cpp:75-86, spiral.cpp:41) with pass r rendered by rank r — every rank keeps all pixels (full "
-                         "occupancy), the image is the one scalar_rgb produces for that samples_per_pass, not for a single pass")
+    ap.add_argument("--shard", default="auto", choices=["auto", "tiles", "passes"],
+                    help="how N ranks split the frame. tiles (the north star's partition): spiral blocks dealt round-robin, every "
+                         "rank renders all spp of its pixels; the N-GPU film equals the 1-GPU film. passes: the reference's own "
+                         "samples_per_pass = spp / N run (integrator.cpp:75-86, spiral.cpp:41) with pass r rendered by rank r — every "
+                         "rank keeps all pixels; the film is the one scalar_rgb produces for that samples_per_pass. auto (default): "
+                         "tiles while a rank's tiles still hold >= 4 pixels per resident lane (262 144 lanes: 4 workgroups of 256 on 256 CUs), passes below "
+                         "that, where a pixel's serial sample stream leaves the machine short of work (DESIGN.md section 7)")
     ap.add_argument("--integrator", default="path", choices=["path", "direct"],
                     help="path = the headline (BASELINE metric); direct = src/integrators/direct.cpp on the same device loop")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
@@ -98,9 +100,13 @@ def main():
     bvh = dev.counters()
     make_integrator = api.DirectIntegrator if args.integrator == "direct" else api.PathIntegrator
     parts = world if world > 1 else max(args.shard_of, 1)          # ranks, or the rank count --shard-of stands for
-    if args.shard == "passes" and parts > 1:
-        if SPP % parts:
-            raise SystemExit("--shard passes: spp must be a multiple of the number of ranks")
+    shard = args.shard
+    if shard == "auto":
+        resident_lanes = 4 * 256 * 256                             # 4 workgroups of 256 lanes on each of 256 CUs
+        shard = "passes" if parts > 1 and SPP % parts == 0 and W * H / parts < 4 * resident_lanes else "tiles"
+    if shard == "passes" and (parts == 1 or SPP % parts):
+        shard = "tiles"                                            # nothing to split / spp not divisible: the tile partition always works
+    if shard == "passes":
         integ = make_integrator(samples_per_pass=SPP // parts)
         job = integ.render_job(sensor, pass_index=rank)            # pass r carries block ids r * block_count + counter
         job.cfg.accumulate = 0                                     # a rank's film holds its own pass; the reduce adds them
@@ -220,7 +226,7 @@ def main():
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
                        "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 3),
                                "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
-                       "parallelism": ("%s-shard x%d + RCCL film reduce" % ("tile" if args.shard == "tiles" else "pass", world)) if world > 1 else "single GPU",
+                       "parallelism": ("%s-shard x%d + RCCL film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world)) if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu,
