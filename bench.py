@@ -100,16 +100,10 @@ def main():
     bvh = dev.counters()
     make_integrator = api.DirectIntegrator if args.integrator == "direct" else api.PathIntegrator
     parts = world if world > 1 else max(args.shard_of, 1)          # ranks, or the rank count --shard-of stands for
-    shard = args.shard
-    if shard == "auto":
-        resident_lanes = 4 * 256 * 256                             # 4 workgroups of 256 lanes on each of 256 CUs
-        shard = "passes" if parts > 1 and SPP % parts == 0 and W * H / parts < 4 * resident_lanes else "tiles"
-    if shard == "passes" and (parts == 1 or SPP % parts):
-        shard = "tiles"                                            # nothing to split / spp not divisible: the tile partition always works
+    from mitsuba2_amd import dist as mdist
+    shard = mdist.choose_shard(args.shard, parts, W, H, SPP)
     if shard == "passes":
-        integ = make_integrator(samples_per_pass=SPP // parts)
-        job = integ.render_job(sensor, pass_index=rank)            # pass r carries block ids r * block_count + counter
-        job.cfg.accumulate = 0                                     # a rank's film holds its own pass; the reduce adds them
+        integ, job = mdist.pass_job(make_integrator, sensor, rank, parts, SPP)   # pass r carries block ids r * block_count + counter
     else:
         integ = make_integrator()
         integ.set_shard(rank, world)

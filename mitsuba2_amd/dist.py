@@ -1,4 +1,4 @@
-"""Multi-GPU plumbing: one process per GPU, pixel-tile sharding, one film reduce.
+"""Multi-GPU plumbing: one process per GPU, pixel-tile (or sample-pass) sharding, one film reduce.
 
 The path shards by pixels only (a pixel's spp samples share one PCG32 stream,
 src/librender/integrator.cpp:196-209): rank r renders the spiral blocks with
@@ -28,6 +28,35 @@ def init(backend=None):
 def shard_blocks(n_blocks, rank, world):
     """Spiral block ids rendered by `rank` (must match PathIntegrator::set_shard in the host layer)."""
     return list(range(rank, n_blocks, world))
+
+
+RESIDENT_LANES = 4 * 256 * 256      # k_path_resident: 4 workgroups of 256 lanes on each of MI355X's 256 CUs
+
+
+def choose_shard(mode, parts, width, height, spp):
+    """How `parts` ranks split a width x height x spp frame -> "tiles" | "passes".
+    tiles: spiral blocks dealt round-robin (shard_blocks), every rank renders all spp of its pixels; the N-GPU film
+    equals the 1-GPU film. passes: the reference's samples_per_pass = spp / parts run (integrator.cpp:75-86,
+    spiral.cpp:41), pass r on rank r: every rank keeps all pixels. mode "auto" takes tiles while a rank's tiles hold at
+    least 4 pixels per resident lane and passes below that (a pixel's samples are one serial PCG32 stream: with fewer
+    pixels than that the kernels run out of parallel work, DESIGN.md section 7). Passes need spp divisible by parts;
+    otherwise (and for a single rank) the answer is tiles."""
+    if mode not in ("auto", "tiles", "passes"):
+        raise ValueError("shard mode must be auto, tiles or passes")
+    if parts <= 1 or spp % parts:
+        return "tiles"
+    if mode == "auto":
+        return "passes" if width * height / parts < 4 * RESIDENT_LANES else "tiles"
+    return mode
+
+
+def pass_job(make_integrator, sensor, rank, parts, spp):
+    """The render job of rank `rank` under pass sharding: pass `rank` of the samples_per_pass = spp / parts run, rendered
+    into the rank's own film (accumulate = 0: the film reduce adds the passes). -> (integrator, job)"""
+    integ = make_integrator(samples_per_pass=spp // parts)
+    job = integ.render_job(sensor, pass_index=rank)
+    job.cfg.accumulate = 0
+    return integ, job
 
 
 def reduce_film(film, dst=0):

@@ -383,3 +383,23 @@ def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path):
     full = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=4)[1]
     got = np.load(out)
     assert np.array_equal(got.astype(np.float32), full.astype(np.float32))
+
+
+def test_shard_mode_selection_and_pass_jobs(native):
+    """mitsuba2_amd/dist.py: what bench.py --shard auto picks, and the per-rank jobs of the pass partition"""
+    from mitsuba2_amd import dist as mdist, scenes
+    pick = mdist.choose_shard
+    assert [pick("auto", n, 1920, 1080, 512) for n in (1, 2, 3, 4, 8)] == ["tiles", "passes", "tiles", "passes", "passes"]
+    assert [pick("auto", n, 3840, 2160, 512) for n in (2, 4, 8)] == ["tiles", "tiles", "passes"]      # a 4K frame fills 4 GPUs
+    assert pick("tiles", 8, 1920, 1080, 512) == "tiles" and pick("passes", 2, 7680, 4320, 512) == "passes"
+    assert pick("passes", 8, 1920, 1080, 100) == "tiles"                                             # spp not divisible
+    with pytest.raises(ValueError):
+        pick("rows", 2, 64, 64, 4)
+    scene, sensor = scenes.cornell_box(64, 48, 8, device=-1)
+    one = native.PathIntegrator().render_job(sensor)
+    for make in (native.PathIntegrator, native.DirectIntegrator):
+        for rank in range(4):
+            integ, job = mdist.pass_job(make, sensor, rank, 4, 8)
+            c = job.cfg
+            assert (c.spp, c.accumulate, c.tile_count, c.block_count) == (2, 0, 0, one.cfg.block_count)
+            assert np.array_equal(job.block_ids[:c.block_count], one.block_ids[:c.block_count] + rank * c.block_count)
