@@ -103,7 +103,7 @@ def main():
     from mitsuba2_amd import dist as mdist
     shard = mdist.choose_shard(args.shard, parts, W, H, SPP)
     if shard == "passes":
-        integ, job = mdist.pass_job(make_integrator, sensor, rank, parts, SPP)   # pass r carries block ids r * block_count + counter
+        integ, job = mdist.pass_job(make_integrator, sensor, rank, parts, SPP)   # pass r carries block ids (N - 1 - r) * block_count + counter
     else:
         integ = make_integrator()
         integ.set_shard(rank, world)

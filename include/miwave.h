@@ -229,7 +229,7 @@ typedef struct {
     int32_t plan;
     int32_t samples_per_launch;               /* plan 2: <= 0 = default (128)            */
     /* 1: `film` already holds earlier passes (samples_per_pass < sample_count, integrator.cpp:75-86: the blocks
-     * of pass p carry ids p * block_count + counter, spiral.cpp:41); this pass's block tiles are added onto it,
+     * of the p-th pass rendered carry ids (n_passes - 1 - p) * block_count + counter, spiral.cpp:41); this pass's block tiles are added onto it,
      * after the ids already in it. 0: the film is overwritten. */
     int32_t accumulate;
     /* which SamplingIntegrator::sample runs per camera sample:
@@ -303,6 +303,47 @@ mi_status mi_bvh_build(mi_ctx *ctx, int32_t quality);
  * include/mitsuba/render/scene.h:38-128, for n rays. */
 mi_status mi_trace(mi_ctx *ctx, const mi_rays_soa *rays, const mi_hits_soa *hits,
                    uint64_t n, int32_t any_hit);
+
+/* ---- the rest of the Scene query surface (include/mitsuba/render/scene.h:38-128) -------------------
+ * The reference's integrators, BSDF tests and Python scripts call these on the Scene; the path kernels run the same
+ * device functions in place. Records are arrays of structs, one per query. */
+typedef struct {            /* SurfaceInteraction3f (include/mitsuba/render/interaction.h:104-199), the fields the hot path fills */
+    float t;                /* +inf: the ray hit nothing (is_valid() false); then only wi = -ray.d (world) is meaningful  */
+    float p[3];             /* position, interpolated from the vertices (mesh.cpp:484)                                    */
+    float n[3];             /* geometric normal                                                                          */
+    float sh_s[3], sh_t[3], sh_n[3];   /* shading frame (initialize_sh_frame, interaction.h:153-156)                      */
+    float uv[2];            /* mesh texture coordinates if present, else the barycentrics (mesh.cpp:490-497)              */
+    float wi[3];            /* incident direction in the shading frame (interaction.h:591)                               */
+    uint32_t prim_index;    /* global primitive id, 0xffffffff on a miss                                                  */
+    uint32_t shape_index;   /* 0xffffffff on a miss                                                                      */
+    int32_t emitter_index;  /* si.emitter(scene), scene.h:243-253: the shape's area light, the environment map on a miss,
+                               -1 for none; indexes the scene's emitter list (mi_scene_desc order, envmap slot included) */
+} mi_surface_interaction;   /* 24 words */
+
+typedef struct {            /* DirectionSample3f (include/mitsuba/render/records.h:120-214) without uv / time (no consumer on this path) */
+    float p[3], n[3];       /* sampled position on the emitter, its normal                                               */
+    float d[3], dist;       /* unit direction ref -> p, distance                                                          */
+    float pdf;              /* solid-angle density; 0: no sample                                                          */
+    int32_t emitter_index;  /* `object`: the emitter that was sampled                                                     */
+} mi_direction_sample;      /* 12 words */
+
+/* Scene::ray_intersect(ray) (scene.cpp:113-121 -> scene_native.inl:23-41): closest hit + full surface interaction */
+mi_status mi_ray_intersect(mi_ctx *ctx, const mi_rays_soa *rays, mi_surface_interaction *si, uint64_t n);
+
+/* Scene::sample_emitter_direction(ref, sample, test_visibility) (scene.cpp:164-214) for n reference points.
+ *   emitter < 0: the scene's own choice among all emitters (scene.cpp:180-197, pdf and value rescaled);
+ *   emitter >= 0: Endpoint::sample_direction of that emitter alone (endpoint.h:119-139; area.cpp:121-166, envmap.cpp:157-190).
+ *   ref_p: 3 n floats; sample: 2 n floats; wavelengths: 4 n floats (scalar_spectral library), else NULL.
+ *   test_visibility != 0: the shadow ray of scene.cpp:203-207 is traced; occluded samples come back with a zero spectrum.
+ *   spec: N n floats (N = mi_spectrum_channels()): emitted radiance / pdf. */
+mi_status mi_sample_emitter_direction(mi_ctx *ctx, int32_t emitter, const float *ref_p, const float *sample, const float *wavelengths,
+                                      int32_t test_visibility, mi_direction_sample *ds, float *spec, uint64_t n);
+/* Scene::pdf_emitter_direction(ref, ds) (scene.cpp:216-231; emitter < 0: ds[i].emitter_index, times 1 / emitter count) or
+ * Endpoint::pdf_direction of one emitter (emitter >= 0; area.cpp:168-187, envmap.cpp:192-208). Reads ds[i].d / dist / n. */
+mi_status mi_pdf_emitter_direction(mi_ctx *ctx, int32_t emitter, const float *ref_p, const mi_direction_sample *ds, float *pdf, uint64_t n);
+/* Endpoint::eval(si) of the emitter each surface interaction sees, si.emitter(scene)->eval(si) (area.cpp:63-71,
+ * envmap.cpp:134-147); zero where si[i].emitter_index < 0. spec: N n floats. */
+mi_status mi_emitter_eval(mi_ctx *ctx, const mi_surface_interaction *si, const float *wavelengths, float *spec, uint64_t n);
 
 /* SamplingIntegrator::render (integrator.cpp:51-179) with PathIntegrator::sample
  * (src/integrators/path.cpp:100-211): renders the ctx's tile shard into `film`.

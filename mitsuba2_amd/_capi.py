@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# MIWAVE_LIB_DIR: another directory holding the same libraries (tools/build_variants.py writes experiment builds of the
+# kernels — other -D switches — next to a copy of the host library); the default is the in-tree product build.
+LIB_DIR = os.environ.get("MIWAVE_LIB_DIR") or os.path.join(_HERE, "lib")
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -73,6 +75,25 @@ class mi_hits_soa(C.Structure):
     _fields_ = [("t", c_float_p), ("u", c_float_p), ("v", c_float_p), ("prim", c_u32_p), ("shape", c_u32_p)]
 
 
+class mi_surface_interaction(C.Structure):
+    _fields_ = [("t", C.c_float), ("p", C.c_float * 3), ("n", C.c_float * 3), ("sh_s", C.c_float * 3), ("sh_t", C.c_float * 3),
+                ("sh_n", C.c_float * 3), ("uv", C.c_float * 2), ("wi", C.c_float * 3), ("prim_index", C.c_uint32),
+                ("shape_index", C.c_uint32), ("emitter_index", C.c_int32)]
+
+
+class mi_direction_sample(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("n", C.c_float * 3), ("d", C.c_float * 3), ("dist", C.c_float), ("pdf", C.c_float),
+                ("emitter_index", C.c_int32)]
+
+
+# numpy views of the two records (same layout: 24 and 12 four-byte words)
+import numpy as _np
+SI_DTYPE = _np.dtype([("t", "f4"), ("p", "f4", 3), ("n", "f4", 3), ("sh_s", "f4", 3), ("sh_t", "f4", 3), ("sh_n", "f4", 3),
+                      ("uv", "f4", 2), ("wi", "f4", 3), ("prim_index", "u4"), ("shape_index", "u4"), ("emitter_index", "i4")])
+DS_DTYPE = _np.dtype([("p", "f4", 3), ("n", "f4", 3), ("d", "f4", 3), ("dist", "f4"), ("pdf", "f4"), ("emitter_index", "i4")])
+assert SI_DTYPE.itemsize == C.sizeof(mi_surface_interaction) == 96 and DS_DTYPE.itemsize == C.sizeof(mi_direction_sample) == 48
+
+
 class mi_render_cfg(C.Structure):
     _fields_ = [("crop_x", C.c_int32), ("crop_y", C.c_int32), ("crop_w", C.c_int32), ("crop_h", C.c_int32),
                 ("spp", C.c_uint32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
@@ -110,7 +131,8 @@ MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (
 
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
 MI_SYMBOLS = ["mi_spectrum_channels", "mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
-              "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval", "mi_selftest"]
+              "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval", "mi_selftest",
+              "mi_ray_intersect", "mi_sample_emitter_direction", "mi_pdf_emitter_direction", "mi_emitter_eval"]
 
 
 VARIANT_SUFFIX = {"scalar_rgb": "", "scalar_spectral": "_spectral"}
@@ -159,6 +181,12 @@ def load_device_lib(variant="scalar_rgb"):
                             C.c_uint64]
     lib.mi_eval.restype = C.c_int32
     lib.mi_selftest.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64)]; lib.mi_selftest.restype = C.c_int32
+    sip, dsp = C.POINTER(mi_surface_interaction), C.POINTER(mi_direction_sample)
+    lib.mi_ray_intersect.argtypes = [vp, C.POINTER(mi_rays_soa), sip, C.c_uint64]; lib.mi_ray_intersect.restype = C.c_int32
+    lib.mi_sample_emitter_direction.argtypes = [vp, C.c_int32, c_float_p, c_float_p, c_float_p, C.c_int32, dsp, c_float_p, C.c_uint64]
+    lib.mi_sample_emitter_direction.restype = C.c_int32
+    lib.mi_pdf_emitter_direction.argtypes = [vp, C.c_int32, c_float_p, dsp, c_float_p, C.c_uint64]; lib.mi_pdf_emitter_direction.restype = C.c_int32
+    lib.mi_emitter_eval.argtypes = [vp, sip, c_float_p, c_float_p, C.c_uint64]; lib.mi_emitter_eval.restype = C.c_int32
     return lib
 
 
@@ -195,6 +223,13 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_scene_desc": (C.POINTER(mi_scene_desc), [vp]), "mih_scene_ctx": (vp, [vp]),
         "mih_scene_ray_intersect": (i32, [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), u64]),
         "mih_scene_ray_test": (i32, [vp, C.POINTER(mi_rays_soa), c_float_p, u64]),
+        "mih_scene_ray_intersect_si": (i32, [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_surface_interaction), u64]),
+        "mih_scene_ray_intersect_one": (i32, [vp, c_float_p, C.POINTER(mi_surface_interaction), c_i32_p, c_i32_p]),
+        "mih_scene_sample_emitter_direction": (i32, [vp, i32, c_float_p, c_float_p, c_float_p, i32, C.POINTER(mi_direction_sample), c_float_p]),
+        "mih_scene_pdf_emitter_direction": (i32, [vp, i32, c_float_p, C.POINTER(mi_direction_sample), c_float_p]),
+        "mih_scene_emitter_eval": (i32, [vp, i32, C.POINTER(mi_surface_interaction), c_float_p, c_float_p]),
+        "mih_scene_emitter_count": (i32, [vp]),
+        "mih_bsdf_sample_ctx": (i32, [vp, u32, u32, u32, c_float_p, f, c_float_p, c_float_p]),
         "mih_film_create": (vp, [vp]), "mih_film_destroy": (None, [vp]),
         "mih_film_set_filter": (i32, [vp, cp, vp]), "mih_film_filter_eval": (i32, [vp, f, c_float_p]),
         "mih_film_develop": (cp, [vp, cp]), "mih_film_set_data": (i32, [vp, c_float_p, u64]),

@@ -387,13 +387,64 @@ class Scene:
     def ctx(self):
         return host_lib().mih_scene_ctx(self.h)
 
-    def ray_intersect(self, o, d, mint=0.0, maxt=np.inf):
+    def ray_intersect_preliminary(self, o, d, mint=0.0, maxt=np.inf):
         """Scene::ray_intersect_preliminary for a batch -> dict(t,u,v,prim,shape)"""
         r, keep, n = _rays_struct(o, d, mint, maxt)
         h, out = _hits_struct(n)
         if host_lib().mih_scene_ray_intersect(self.h, C.byref(r), C.byref(h), n) != 0:
             raise RuntimeError(_err())
         return out
+
+    def ray_intersect(self, o, d, mint=0.0, maxt=np.inf):
+        """Scene::ray_intersect for a batch -> structured array of SurfaceInteraction3f records (_capi.SI_DTYPE:
+        t, p, n, sh_s, sh_t, sh_n, uv, wi, prim_index, shape_index, emitter_index)"""
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        si = np.zeros(n, _capi.SI_DTYPE)
+        if host_lib().mih_scene_ray_intersect_si(self.h, C.byref(r), si.ctypes.data_as(C.POINTER(_capi.mi_surface_interaction)), n) != 0:
+            raise RuntimeError(_err())
+        return si
+
+    def ray_intersect_one(self, ray8):
+        """The one-ray C++ overload Scene::ray_intersect(Ray3f) -> (valid, record, has_bsdf, emitter index of si.emitter(scene))"""
+        r = np.ascontiguousarray(ray8, np.float32)
+        si = np.zeros(1, _capi.SI_DTYPE); hb = C.c_int32(0); ei = C.c_int32(0)
+        rc = host_lib().mih_scene_ray_intersect_one(self.h, _fp(r), si.ctypes.data_as(C.POINTER(_capi.mi_surface_interaction)), C.byref(hb), C.byref(ei))
+        if rc < 0:
+            raise RuntimeError(_err())
+        return bool(rc), si[0], bool(hb.value), int(ei.value)
+
+    def emitter_count(self):
+        return host_lib().mih_scene_emitter_count(self.h)
+
+    def sample_emitter_direction(self, ref_p, sample, test_visibility=True, emitter=-1, wavelengths=None):
+        """Scene::sample_emitter_direction(ref, sample, test_visibility) (emitter = -1) or
+        Scene::emitters()[emitter].sample_direction(ref, sample) for ONE reference point -> (record, spectrum)"""
+        ds = np.zeros(1, _capi.DS_DTYPE); spec = np.zeros(4, np.float32)
+        wl = None if wavelengths is None else np.ascontiguousarray(wavelengths, np.float32)
+        rc = host_lib().mih_scene_sample_emitter_direction(self.h, int(emitter), _fp(np.ascontiguousarray(ref_p, np.float32)),
+                                                           None if wl is None else _fp(wl), _fp(np.ascontiguousarray(sample, np.float32)),
+                                                           int(bool(test_visibility)), ds.ctypes.data_as(C.POINTER(_capi.mi_direction_sample)), _fp(spec))
+        if rc != 0:
+            raise RuntimeError(_err())
+        return ds[0], spec[:host_lib().mih_spectrum_channels()].copy()
+
+    def pdf_emitter_direction(self, ref_p, ds, emitter=-1):
+        d = np.array([ds], _capi.DS_DTYPE); pdf = C.c_float(0)
+        if host_lib().mih_scene_pdf_emitter_direction(self.h, int(emitter), _fp(np.ascontiguousarray(ref_p, np.float32)),
+                                                      d.ctypes.data_as(C.POINTER(_capi.mi_direction_sample)), C.byref(pdf)) != 0:
+            raise RuntimeError(_err())
+        return float(pdf.value)
+
+    def emitter_eval(self, si, emitter=-1, wavelengths=None):
+        """si.emitter(scene).eval(si) (emitter = -1; zero spectrum and found = False when the interaction sees none) or
+        Scene::emitters()[emitter].eval(si) -> (found, spectrum)"""
+        x = np.array([si], _capi.SI_DTYPE); spec = np.zeros(4, np.float32)
+        wl = None if wavelengths is None else np.ascontiguousarray(wavelengths, np.float32)
+        rc = host_lib().mih_scene_emitter_eval(self.h, int(emitter), x.ctypes.data_as(C.POINTER(_capi.mi_surface_interaction)),
+                                               None if wl is None else _fp(wl), _fp(spec))
+        if rc < 0:
+            raise RuntimeError(_err())
+        return bool(rc), spec[:host_lib().mih_spectrum_channels()].copy()
 
     def ray_test(self, o, d, mint=0.0, maxt=np.inf):
         r, keep, n = _rays_struct(o, d, mint, maxt)
@@ -585,7 +636,7 @@ class SamplingIntegrator:
         return n
 
     def render_job(self, sensor, n_threads=1, capacity=1 << 16, pass_index=0):
-        """The job of pass `pass_index` (ascending block-id offset; passes after the first accumulate onto the film)"""
+        """The job of pass `pass_index` (execution order; the first pass carries the highest block-id offset, spiral.cpp:41; passes after the first accumulate onto the film)"""
         cfg = mi_render_cfg()
         block_ids = np.zeros(capacity, np.uint32); tiles = np.zeros(capacity, np.uint32)
         if host_lib().mih_make_render_cfg_pass(self.h, sensor.h, C.byref(cfg), block_ids.ctypes.data_as(c_u32_p),
@@ -665,6 +716,37 @@ class Device:
         h, out = _hits_struct(n)
         self.check(self.L.mi_trace(self.ctx, C.byref(r), C.byref(h), n, int(any_hit)))
         return out
+
+    # ---- the Scene query surface through the raw C ABI (batches) ----
+    def ray_intersect(self, o, d, mint=0.0, maxt=np.inf):
+        """mi_ray_intersect -> structured array of _capi.SI_DTYPE records"""
+        r, keep, n = _rays_struct(o, d, mint, maxt)
+        si = np.zeros(n, _capi.SI_DTYPE)
+        self.check(self.L.mi_ray_intersect(self.ctx, C.byref(r), si.ctypes.data_as(C.POINTER(_capi.mi_surface_interaction)), n))
+        return si
+
+    def sample_emitter_direction(self, ref_p, sample, test_visibility=True, emitter=-1, wavelengths=None):
+        """mi_sample_emitter_direction -> (records (_capi.DS_DTYPE), spectra [n, N])"""
+        ref = np.ascontiguousarray(ref_p, np.float32).reshape(-1, 3); smp = np.ascontiguousarray(sample, np.float32).reshape(-1, 2)
+        n = len(ref); nch = self.L.mi_spectrum_channels()
+        wl = None if wavelengths is None else np.ascontiguousarray(wavelengths, np.float32).reshape(n, 4)
+        ds = np.zeros(n, _capi.DS_DTYPE); spec = np.zeros((n, nch), np.float32)
+        self.check(self.L.mi_sample_emitter_direction(self.ctx, int(emitter), _fp(ref), _fp(smp), None if wl is None else _fp(wl),
+                                                      int(bool(test_visibility)), ds.ctypes.data_as(C.POINTER(_capi.mi_direction_sample)), _fp(spec), n))
+        return ds, spec
+
+    def pdf_emitter_direction(self, ref_p, ds, emitter=-1):
+        ref = np.ascontiguousarray(ref_p, np.float32).reshape(-1, 3); d = np.ascontiguousarray(ds, _capi.DS_DTYPE)
+        pdf = np.zeros(len(ref), np.float32)
+        self.check(self.L.mi_pdf_emitter_direction(self.ctx, int(emitter), _fp(ref), d.ctypes.data_as(C.POINTER(_capi.mi_direction_sample)), _fp(pdf), len(ref)))
+        return pdf
+
+    def emitter_eval(self, si, wavelengths=None):
+        x = np.ascontiguousarray(si, _capi.SI_DTYPE); n = len(x); nch = self.L.mi_spectrum_channels()
+        wl = None if wavelengths is None else np.ascontiguousarray(wavelengths, np.float32).reshape(n, 4)
+        spec = np.zeros((n, nch), np.float32)
+        self.check(self.L.mi_emitter_eval(self.ctx, x.ctypes.data_as(C.POINTER(_capi.mi_surface_interaction)), None if wl is None else _fp(wl), _fp(spec), n))
+        return spec
 
     def render(self, job, f64=False, profile=False, film_mode=0, plan=None, samples_per_launch=None, onto=None):
         """film_mode 0 auto / 1 sample log + ordered gather (float32, reference order) / 2 float64 atomics;

@@ -19,6 +19,93 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_trace_soa(SceneView sc, SoaRays R
     if (H.shape) H.shape[i] = hit ? sc.tris[h.tri].shape : 0xffffffffu;
 }
 
+// ---- the Scene query surface (include/miwave.h: mi_ray_intersect, mi_sample_emitter_direction, ...) ----
+__device__ __forceinline__ void st3(float *dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+__global__ __launch_bounds__(MIW_BLOCK) void k_ray_intersect(SceneView sc, SoaRays R, mi_surface_interaction *out, uint64_t n, TraceLds cfg) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = v3(R.ox[i], R.oy[i], R.oz[i]), d = v3(R.dx[i], R.dy[i], R.dz[i]);
+    Hit h;
+    const bool hit = trace_one<false>(sc, cfg, smem, o, d, R.mint[i], R.maxt[i], h);
+    mi_surface_interaction r;
+    memset(&r, 0, sizeof r);
+    if (hit) {
+        SurfaceInteraction si; uint32_t bsdf_index; int32_t emitter;
+        hit_surface_interaction<true, true>(sc, h.tri, h.t, h.u, h.v, [o]() { return o; }, d, si, bsdf_index, emitter);
+        r.t = si.t; st3(r.p, si.p); st3(r.n, si.n); st3(r.sh_s, si.sh.s); st3(r.sh_t, si.sh.t); st3(r.sh_n, si.sh.n);
+        r.uv[0] = si.uv.x; r.uv[1] = si.uv.y; st3(r.wi, si.wi);
+        r.prim_index = si.prim; r.shape_index = si.shape; r.emitter_index = emitter;
+    } else {                                                   // interaction.h:571-596 on an invalid pi: t = inf, wi = -ray.d
+        r.t = MIW_INFINITY; st3(r.wi, -d);
+        r.prim_index = r.shape_index = 0xffffffffu;
+        r.emitter_index = sc.env ? (int32_t) sc.env->emitter_index : -1;   // scene.h:248-249
+    }
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(MIW_BLOCK) void k_sample_emitter_direction(SceneView sc, int32_t emitter, const float *ref_p, const float *sample,
+                                                                       const float *wavelengths, int test_visibility, mi_direction_sample *out,
+                                                                       float *spec_out, uint64_t n, TraceLds cfg) {
+    extern __shared__ uint4 smem[];
+    stage_to_lds(sc, cfg, smem);
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Wavelengths wl;
+#if MIW_SPECTRAL
+    for (int k = 0; k < 4; ++k) wl.l[k] = wavelengths[4 * i + k];
+#else
+    (void) wavelengths;
+#endif
+    const V3 ref = v3(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]);
+    const V2 u = v2(sample[2 * i], sample[2 * i + 1]);
+    DirectionSample ds;
+    Spec value = emitter < 0 ? sample_emitter_direction(sc, ref, u, ds, wl) : emitter_sample_direction(sc, (uint32_t) emitter, ref, u, ds, wl);
+    if (test_visibility && ds.pdf != 0.f) {                    // scene.cpp:203-207
+        Hit h;
+        if (trace_one<true>(sc, cfg, smem, ref, ds.d, spawn_mint(ref), ds.dist * (1.f - MIW_SHADOW_EPSILON), h)) value = spec(0.f);
+    }
+    mi_direction_sample r;
+    st3(r.p, ds.p); st3(r.n, ds.n); st3(r.d, ds.d); r.dist = ds.dist; r.pdf = ds.pdf; r.emitter_index = (int32_t) ds.emitter;
+    out[i] = r;
+    const float *vf = reinterpret_cast<const float *>(&value);
+    for (int k = 0; k < MIW_SPEC_N; ++k) spec_out[MIW_SPEC_N * i + k] = vf[k];
+}
+
+__global__ void k_pdf_emitter_direction(SceneView sc, int32_t emitter, const float *ref_p, const mi_direction_sample *ds, float *pdf, uint64_t n) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mi_direction_sample r = ds[i];
+    const V3 ref = v3(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]);
+    const uint32_t e = emitter < 0 ? (uint32_t) r.emitter_index : (uint32_t) emitter;
+    float v = 0.f;
+    if (e < sc.emitter_count)
+        v = emitter < 0 ? pdf_emitter_direction(sc, e, ld3(r.d), r.dist, ld3(r.n), ref) : emitter_pdf_direction(sc, e, ld3(r.d), r.dist, ld3(r.n), ref);
+    pdf[i] = v;
+}
+
+__global__ void k_emitter_eval(SceneView sc, const mi_surface_interaction *si, const float *wavelengths, float *spec_out, uint64_t n) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Wavelengths wl;
+#if MIW_SPECTRAL
+    for (int k = 0; k < 4; ++k) wl.l[k] = wavelengths[4 * i + k];
+#else
+    (void) wavelengths;
+#endif
+    const mi_surface_interaction r = si[i];
+    Spec value = spec(0.f);
+    if (r.emitter_index >= 0 && (uint32_t) r.emitter_index < sc.emitter_count) {
+        const EmitterRec &e = sc.emitters[r.emitter_index];
+        if (e.type == EMITTER_ENVMAP) { if (sc.env) value = env_eval_spec(*sc.env, -ld3(r.wi)); }   // envmap.cpp:137: v = to_local(-si.wi)
+        else value = emitter_eval(e, ld3(r.wi), wl);
+    }
+    const float *vf = reinterpret_cast<const float *>(&value);
+    for (int k = 0; k < MIW_SPEC_N; ++k) spec_out[MIW_SPEC_N * i + k] = vf[k];
+}
+
 __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, int is, float *out, int os, uint64_t n) {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

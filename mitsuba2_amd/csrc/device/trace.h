@@ -90,6 +90,12 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 // smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
 // trail walk of bvh.h runs.
 #define MIW_STACK_ENTRIES 32
+#ifndef MIW_WALK
+#define MIW_WALK 1                /* 0: one loop, node or leaf per iteration; 1: while-while; 2: while-while + one postponed leaf per lane */
+#endif
+#ifndef MIW_LDS_TOP
+#define MIW_LDS_TOP 1             /* 1: the first 255 nodes of a tree that does not fit LDS are staged there (flat-address select per node visit) */
+#endif
 #ifndef MIW_TREE_WAVES
 #define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
 #endif
@@ -131,6 +137,91 @@ __device__ __forceinline__ bool bvh_intersect_stack(NodeAt node_at, TriAt tri_at
         if (sp == 0) return best.tri != MIW_MISS;
         --sp; cur = stack[sp * MIW_BLOCK];
     }
+}
+
+// The same traversal as a WHILE-WHILE loop (MIW_WALK >= 1, the default): a wavefront's lanes sit at different places of
+// their walks, and in the loop above every wave-iteration in which ANY lane holds a leaf pays the whole leaf body
+// (up to 4 Moeller-Trumbore tests) next to the node body, although only ~1 lane in 8 is at a leaf. Here each lane
+// first descends through inner nodes until it holds a leaf (the wave leaves the node loop when every lane does),
+// then all lanes test their leaf's triangles together. MIW_WALK == 2 postpones ONE leaf per lane: a lane that
+// reaches its first leaf parks it and keeps descending until it reaches a second one, so that it does not idle
+// while its neighbours still descend (speculative traversal; tmax is then one leaf late for the nodes in between,
+// which only costs box tests — the result is the same: every triangle Moeller-Trumbore accepts is tested).
+// Debug builds (-DMIW_WALK_STATS=1): lane-steps and wave-steps of the node and the triangle loop, per ray kind,
+// summed into g_walk_stats (printed by mi_render under MIW_DEBUG): lane-steps / (64 x wave-steps) = SIMT efficiency.
+#if defined(MIW_WALK_STATS)
+#define MIW_WALK_STATS_DECL unsigned long long ws_lane_[2] = { 0, 0 }; float ws_wave_[2] = { 0.f, 0.f }
+#define MIW_WALK_STATS_STEP(k) do { ws_lane_[k]++; ws_wave_[k] += 1.f / (float) __popcll(__ballot(1)); } while (0)
+#define MIW_WALK_STATS_FLUSH(base) do { atomicAdd(&g_walk_stats[(base)], ws_lane_[0]); atomicAdd(&g_walk_stats[(base) + 1], ws_lane_[1]); \
+        atomicAdd(&g_walk_statsf[(base)], ws_wave_[0]); atomicAdd(&g_walk_statsf[(base) + 1], ws_wave_[1]); \
+        atomicAdd(&g_walk_stats[(base) + 2], 1ull); } while (0)
+#else
+#define MIW_WALK_STATS_DECL do { } while (0)
+#define MIW_WALK_STATS_STEP(k) do { } while (0)
+#define MIW_WALK_STATS_FLUSH(base) do { } while (0)
+#endif
+#define MIW_WALK_DONE ((int32_t) 0x80000000)      /* not a leaf code: ~DONE >> 4 is past every triangle index */
+template <bool AnyHit, bool Analytic, int Postpone, typename NodeAt, typename TriAt>
+__device__ __forceinline__ bool bvh_intersect_ww(NodeAt node_at, TriAt tri_at, int32_t *stack /* + threadIdx.x */,
+                                                 V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx) {
+    best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+    const FastRay r = fast_ray(o, d, mint);
+    float tmax = maxt;
+    int32_t cur = 0, sp = 0, parked = MIW_WALK_DONE;
+    MIW_WALK_STATS_DECL;
+    for (;;) {
+        if (Postpone && cur < 0 && cur != MIW_WALK_DONE && parked == MIW_WALK_DONE) {
+            parked = cur;
+            if (sp == 0) cur = MIW_WALK_DONE; else { --sp; cur = stack[sp * MIW_BLOCK]; }
+        }
+        while (cur >= 0) {                                       // ---- node phase: descend to the next leaf
+            MIW_WALK_STATS_STEP(0);
+            const BvhNode &n = node_at(cur);
+            float tn0, tn1;
+            const float wide = widen(tmax);
+            const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
+            const int32_t c0 = n.child0, c1 = n.child1;
+            const bool second_first = tn1 < tn0;
+            int32_t next = h0 ? c0 : c1;
+            if (h0 && h1) {
+                stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
+                next = second_first ? c1 : c0;
+            } else if (!(h0 || h1)) {
+                if (sp == 0) next = MIW_WALK_DONE; else { --sp; next = stack[sp * MIW_BLOCK]; }
+            }
+            if (Postpone && next < 0 && next != MIW_WALK_DONE && parked == MIW_WALK_DONE) {
+                parked = next;                                   // first leaf: park it, keep descending
+                if (sp == 0) next = MIW_WALK_DONE; else { --sp; next = stack[sp * MIW_BLOCK]; }
+            }
+            cur = next;
+        }
+        int32_t leaf;                                            // ---- leaf phase
+        if (Postpone) {
+            if (parked == MIW_WALK_DONE) break;                  // nothing parked: cur is DONE as well
+            leaf = parked; parked = MIW_WALK_DONE;
+        } else {
+            if (cur == MIW_WALK_DONE) break;
+            leaf = cur;
+            if (sp == 0) cur = MIW_WALK_DONE; else { --sp; cur = stack[sp * MIW_BLOCK]; }
+        }
+        const uint32_t code = (uint32_t) ~leaf, first = code >> 4, count = (code & 15u) + 1u;
+        bool found = false;
+        for (uint32_t i = 0; i < count; ++i) {
+            MIW_WALK_STATS_STEP(1);
+            const Tri &tr = tri_at(first + i);
+            float t, u, v;
+            if (prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v)) {
+                if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; found = true; break; }
+                if (t < best.t || (t == best.t && tr.prim < best.prim)) {
+                    best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
+                    tmax = t;
+                }
+            }
+        }
+        if (AnyHit && found) break;
+    }
+    MIW_WALK_STATS_FLUSH(AnyHit ? 4 : 0);
+    return best.tri != MIW_MISS;
 }
 
 // per-packet vertex bounds of a tiny scene, staged behind the leaf boxes (stage_to_lds)
@@ -175,14 +266,22 @@ __device__ __forceinline__ bool trace_one(const SceneView &sc, TraceLds cfg, con
         auto tri_at  = [ltris](uint32_t i) -> const Tri & { return ltris[i]; };
         return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
     } else {
+#if MIW_LDS_TOP
         uint32_t ns = cfg.nodes_staged;
         auto node_at = [lnodes, gnodes, ns](int32_t i) -> const BvhNode & {
             return (uint32_t) i < ns ? lnodes[i] : gnodes[i];
         };
+#else
+        auto node_at = [gnodes](int32_t i) -> const BvhNode & { return gnodes[i]; };   // global loads only (top of the tree lives in L1 / L2)
+#endif
         auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
         if (cfg.stack) {
             int32_t *stack = reinterpret_cast<int32_t *>(const_cast<uint4 *>(smem) + cfg.stack16) + threadIdx.x;
+#if MIW_WALK == 0
             return bvh_intersect_stack<AnyHit, Analytic>(node_at, tri_at, stack, o, d, mint, maxt, h, prim_ctx(sc));
+#else
+            return bvh_intersect_ww<AnyHit, Analytic, MIW_WALK == 2>(node_at, tri_at, stack, o, d, mint, maxt, h, prim_ctx(sc));
+#endif
         }
         return bvh_intersect<AnyHit>(node_at, tri_at, r, h, prim_ctx(sc));
     }

@@ -80,32 +80,32 @@ MIW_HD void film_merge_texel(const FilmRec &f, const BlockReplayArgs &a, const f
                              bool accumulate = false) {
     const int bs = f.block_size;
     if (!accumulate) for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = 0.f;
-    // blocks whose bordered area contains the texel: at most 2 x 2
+    // blocks whose bordered area contains the texel: 2 x 2 at most for block_size >= 2 * border, more for the tiny blocks
+    // a many-threaded render of a small frame uses (integrator.cpp:88-97 halves the block size down to 1)
     int bx_lo = (fx - f.border) / bs, bx_hi = (fx + f.border) / bs,
         by_lo = (fy - f.border) / bs, by_hi = (fy + f.border) / bs;
     if (fx - f.border < 0) bx_lo = 0;
     if (fy - f.border < 0) by_lo = 0;
     if (bx_hi > (int) a.blocks_x - 1) bx_hi = (int) a.blocks_x - 1;
     if (by_hi > (int) a.blocks_y - 1) by_hi = (int) a.blocks_y - 1;
-    uint32_t cand[4]; uint32_t cand_id[4]; int nc = 0;
-    for (int by = by_lo; by <= by_hi && nc < 4; ++by)
-        for (int bx = bx_lo; bx <= bx_hi && nc < 4; ++bx) {
-            uint32_t b = (uint32_t) by * a.blocks_x + (uint32_t) bx;
-            if (a.block_tile[b] < 0) continue;           // rendered by another rank
-            cand[nc] = b; cand_id[nc] = a.block_ids[b]; ++nc;
-        }
-    // ascending spiral id = the restatement's film->put order
-    for (int i = 1; i < nc; ++i)
-        for (int j = i; j > 0 && cand_id[j - 1] > cand_id[j]; --j) {
-            uint32_t t = cand_id[j]; cand_id[j] = cand_id[j - 1]; cand_id[j - 1] = t;
-            t = cand[j]; cand[j] = cand[j - 1]; cand[j - 1] = t;
-        }
-    for (int i = 0; i < nc; ++i) {
-        const uint32_t b = cand[i];
-        const BlockGeom g = block_geom(f, a.blocks_x, b);
+    // ascending spiral id = the restatement's film->put order: repeatedly take the covering block with the smallest
+    // id above the last one added (ids are unique; no candidate array, any number of covering blocks)
+    uint64_t floor_id = 0;                                 // next id must be >= floor_id
+    for (;;) {
+        uint64_t best_id = ~0ull; uint32_t best_b = 0;
+        for (int by = by_lo; by <= by_hi; ++by)
+            for (int bx = bx_lo; bx <= bx_hi; ++bx) {
+                const uint32_t b = (uint32_t) by * a.blocks_x + (uint32_t) bx;
+                if (a.block_tile[b] < 0) continue;       // rendered by another rank
+                const uint64_t id = a.block_ids[b];
+                if (id >= floor_id && id < best_id) { best_id = id; best_b = b; }
+            }
+        if (best_id == ~0ull) break;
+        floor_id = best_id + 1;
+        const BlockGeom g = block_geom(f, a.blocks_x, best_b);
         const int tx = fx - g.px0 + f.border, ty = fy - g.py0 + f.border;
         if (tx < 0 || ty < 0 || tx >= g.size_x || ty >= g.size_y) continue;
-        const float *src = tiles + (size_t) a.block_tile[b] * a.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+        const float *src = tiles + (size_t) a.block_tile[best_b] * a.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
         for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] += src[k];   // imageblock.cpp:49-77
     }
 }

@@ -255,22 +255,8 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     SurfaceInteraction si;
     uint32_t bsdf_index = 0;
     int32_t emitter = -1;                            // scene.h:243-253 (no environment emitter)
-    if (valid) {
-        const Tri &tr = sc.tris[tri_idx];
-        const ShapeRec &shape = sc.shapes[tr.shape];
-        if (Analytic && tr.pad) {                        // analytic shape: its own compute_surface_interaction
-            const AnalyticRec &a = sc.rects[tr.pad - 1u];
-            if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.x, prev_o(), ray_d, si);
-            else compute_surface_interaction_rect(a, h.x, h.y, h.z, prev_o(), ray_d, si);
-        } else {
-            const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            // only MATS_ALL kernels are launched for scenes with texture coordinates (miwave.hip: diffuse_only / textured)
-            const float *tc = (Mats == MATS_ALL && (shape.flags & SHAPE_HAS_TEXCOORDS)) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, si);
-        }
-        si.shape = tr.shape; si.prim = tr.prim;
-        emitter = shape.emitter; bsdf_index = shape.bsdf;
-    }
+    // only MATS_ALL kernels are launched for scenes with texture coordinates (miwave.hip: diffuse_only / textured)
+    if (valid) hit_surface_interaction<Analytic, Mats == MATS_ALL>(sc, tri_idx, h.x, h.y, h.z, prev_o, ray_d, si, bsdf_index, emitter);
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;   // a miss sees the environment, scene.h:248-249
     if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
 

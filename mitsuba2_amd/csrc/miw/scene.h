@@ -68,6 +68,29 @@ struct SceneView {
 
 MIW_HD PrimCtx prim_ctx(const SceneView &sc) { PrimCtx c; c.rects = sc.rects; c.accept_pad = sc.accept_pad; return c; }
 
+// Scene::ray_intersect's second half (scene_native.inl:32-40 -> PreliminaryIntersection::compute_surface_interaction,
+// interaction.h:571-596): the SurfaceInteraction of hit record (t, u, v, triangle `tri_idx` in leaf order) of the ray
+// (ray_o(), ray_d), plus the two lookups the integrators make on it: si.bsdf() (bsdf.h:485-500) and si.emitter()
+// (scene.h:243-253). Analytic = false / Texcoords = false compile the analytic-shape branch / the texture-coordinate
+// path out (scenes the caller knows to have none). One definition for the path kernels and for mi_ray_intersect.
+template <bool Analytic, bool Texcoords, typename RayO>
+MIW_HD void hit_surface_interaction(const SceneView &sc, uint32_t tri_idx, float t, float u, float v, RayO ray_o, V3 ray_d,
+                                    SurfaceInteraction &si, uint32_t &bsdf_index, int32_t &emitter) {
+    const Tri &tr = sc.tris[tri_idx];
+    const ShapeRec &shape = sc.shapes[tr.shape];
+    if (Analytic && tr.pad) {                            // analytic shape: its own compute_surface_interaction
+        const AnalyticRec &a = sc.rects[tr.pad - 1u];
+        if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, t, ray_o(), ray_d, si);
+        else compute_surface_interaction_rect(a, t, u, v, ray_o(), ray_d, si);
+    } else {
+        const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
+        const float *tc = (Texcoords && (shape.flags & SHAPE_HAS_TEXCOORDS)) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
+        compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, t, u, v, ray_d, si);
+    }
+    si.shape = tr.shape; si.prim = tr.prim;
+    emitter = shape.emitter; bsdf_index = shape.bsdf;
+}
+
 struct DirectionSample { V3 p, n, d; float dist, pdf; uint32_t emitter; };
 
 MIW_HD MeshSampler emitter_mesh(const SceneView &sc, const EmitterRec &e) {
@@ -155,23 +178,9 @@ MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V
 MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d) { return env_eval(e, d); }
 #endif
 
-// scene.cpp:164-200 + area.cpp:121-166 + shape.cpp:292-309, *without* the
-// visibility test (the shadow ray is a separate wavefront stage). Returns the
-// unoccluded emitter value; `ds.pdf == 0` means "no sample" (path.cpp:160).
-MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
-    if (sc.emitter_count == 0) {                       // scene.cpp:208-211
-        ds.p = ds.n = ds.d = v3(0.f); ds.dist = 0.f; ds.pdf = 0.f; ds.emitter = 0;
-        return spec(0.f);
-    }
-    uint32_t index = 0;
-    float emitter_pdf = 1.f;
-    if (sc.emitter_count > 1) {                        // scene.cpp:180-188
-        float n = (float) sc.emitter_count;
-        emitter_pdf = 1.f / n;
-        uint32_t i = (uint32_t) (sample.x * n);
-        index = i < sc.emitter_count - 1 ? i : sc.emitter_count - 1;
-        sample.x = (sample.x - (float) index * emitter_pdf) * n;
-    }
+// Endpoint::sample_direction of emitter `index` (endpoint.h:119-139): AreaLight (area.cpp:121-166 +
+// shape.cpp:292-309) or the environment map (envmap.cpp:157-190). Returns radiance / pdf; `ds.pdf == 0`: no sample.
+MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
     const EmitterRec &e = sc.emitters[index];
     Spec value;
     ds.emitter = index;
@@ -197,6 +206,27 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
         value = tex_eval(e.radiance, wl) / ds.pdf;
         if (!active) value = spec(0.f);
     }
+    return value;
+}
+
+// scene.cpp:164-200, *without* the visibility test (the shadow ray is a separate stage of the kernels;
+// mi_sample_emitter_direction traces it on request). Returns the unoccluded emitter value; `ds.pdf == 0`
+// means "no sample" (path.cpp:160).
+MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
+    if (sc.emitter_count == 0) {                       // scene.cpp:208-211
+        ds.p = ds.n = ds.d = v3(0.f); ds.dist = 0.f; ds.pdf = 0.f; ds.emitter = 0;
+        return spec(0.f);
+    }
+    uint32_t index = 0;
+    float emitter_pdf = 1.f;
+    if (sc.emitter_count > 1) {                        // scene.cpp:180-188
+        float n = (float) sc.emitter_count;
+        emitter_pdf = 1.f / n;
+        uint32_t i = (uint32_t) (sample.x * n);
+        index = i < sc.emitter_count - 1 ? i : sc.emitter_count - 1;
+        sample.x = (sample.x - (float) index * emitter_pdf) * n;
+    }
+    Spec value = emitter_sample_direction(sc, index, ref_p, sample, ds, wl);
     if (sc.emitter_count > 1) {                        // scene.cpp:195-197
         ds.pdf *= emitter_pdf;
         value = value * rcp(emitter_pdf);
@@ -204,27 +234,27 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
     return value;
 }
 
-// scene.cpp:216-231 + area.cpp:168-187 + shape.cpp:311-323.
+// Endpoint::pdf_direction of emitter `emitter` (area.cpp:168-187 + shape.cpp:311-323, envmap.cpp:192-208).
 // `ds_d`, `ds_dist`, `ds_n` come from DirectionSample(si_bsdf, si) (records.h:167-173).
 // `ref_p` = it.p, the point the direction leaves from (only the sphere's pdf_direction needs it).
-MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
+MIW_HD float emitter_pdf_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
     const EmitterRec &e = sc.emitters[emitter];
-    float value;
-    if (e.type == EMITTER_ENVMAP) {
-        value = env_pdf_direction(*sc.env, ds_d);
+    if (e.type == EMITTER_ENVMAP) return env_pdf_direction(*sc.env, ds_d);
+    float dp = dot(ds_d, ds_n);
+    bool active = dp < 0.f;
+    float pdf;
+    if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
+        pdf = sphere_pdf_direction(sc.rects[e.tri_first], ref_p, ds_d, ds_dist, ds_n);
     } else {
-        float dp = dot(ds_d, ds_n);
-        bool active = dp < 0.f;
-        float pdf;
-        if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
-            pdf = sphere_pdf_direction(sc.rects[e.tri_first], ref_p, ds_d, ds_dist, ds_n);
-        } else {
-            pdf = e.normalization;
-            float adp = abs_dot(ds_d, ds_n);
-            pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
-        }
-        value = active ? pdf : 0.f;
+        pdf = e.normalization;
+        float adp = abs_dot(ds_d, ds_n);
+        pdf *= (adp != 0.f) ? (ds_dist * ds_dist) / adp : 0.f;
     }
+    return active ? pdf : 0.f;
+}
+// scene.cpp:216-231
+MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
+    float value = emitter_pdf_direction(sc, emitter, ds_d, ds_dist, ds_n, ref_p);
     if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);
     return value;
 }

@@ -3,6 +3,7 @@
 //   device/trace.h               LDS staging, packet sweep + leaf filter, LDS-stack BVH walk, trace2
 //   device/wavefront_kernels.h   plan 1: k_init_lanes, k_trace<closest|any>, k_shade over SoA queues in HBM
 //   device/resident_kernel.h     plan 2: k_init_pixels, the pixel queue, k_path_resident (path / direct)
+//   device/phased_kernel.h       plan 2 over a tree: k_path_phased (wave-level phase machine: node steps / triangle tests / shade)
 //   device/film_kernels.h        k_film_resolve, k_film_blocks, k_film_pack, k_film_groups, k_film_merge
 //   device/eval_kernels.h        k_trace_soa (mi_trace), k_eval (mi_eval)
 //   lbvh_device.h                device LBVH builder
@@ -23,6 +24,10 @@
 // into g_sections and printed by mi_render when MIW_DEBUG is set. Not compiled into the product library.
 #if defined(MIW_SECTION_PROFILE)
 __device__ unsigned long long g_sections[16];
+#endif
+#if defined(MIW_WALK_STATS)
+__device__ unsigned long long g_walk_stats[8];     // per ray kind (closest 0.., any 4..): node lane-steps, triangle lane-steps, rays
+__device__ float g_walk_statsf[8];                 //                                      node wave-steps, triangle wave-steps
 #endif
 #if defined(MIW_VERIFY_FILTER)
 __device__ unsigned int g_verify_n;
@@ -66,6 +71,7 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #include "device/trace.h"
 #include "device/wavefront_kernels.h"
 #include "device/resident_kernel.h"
+#include "device/phased_kernel.h"
 #include "device/film_kernels.h"
 #include "device/eval_kernels.h"
 
@@ -91,6 +97,9 @@ template <typename T> struct DevBuf {
     }
     void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
 };
+
+// a DevBuf local to one call: freed on every return path (HIP_TRY returns early)
+template <typename T> struct TmpBuf : DevBuf<T> { TmpBuf() = default; TmpBuf(const TmpBuf &) = delete; ~TmpBuf() { this->release(); } };
 
 struct mi_ctx {
     int device = 0;
@@ -428,8 +437,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // ---- device LBVH (lbvh_device.h) ----
         hipStream_t s = c->stream;
         const int n = (int) tri_count;
-        DevBuf<Tri> d_in; DevBuf<float> d_vn_in; DevBuf<uint64_t> d_keys, d_keys_sorted; DevBuf<uint32_t> d_bounds, d_arrivals, d_height;
-        DevBuf<LbvhBox> d_boxes; DevBuf<LbvhLinks> d_inner; DevBuf<int32_t> d_leaf_parent; DevBuf<unsigned char> d_tmp;
+        TmpBuf<Tri> d_in; TmpBuf<float> d_vn_in; TmpBuf<uint64_t> d_keys, d_keys_sorted; TmpBuf<uint32_t> d_bounds, d_arrivals, d_height;
+        TmpBuf<LbvhBox> d_boxes; TmpBuf<LbvhLinks> d_inner; TmpBuf<int32_t> d_leaf_parent; TmpBuf<unsigned char> d_tmp;
         auto free_tmp = [&]() { d_in.release(); d_vn_in.release(); d_keys.release(); d_keys_sorted.release(); d_bounds.release();
                                 d_arrivals.release(); d_height.release(); d_boxes.release(); d_inner.release(); d_leaf_parent.release(); d_tmp.release(); };
         HIP_TRY(c, d_in.upload(c->tris_in, s));
@@ -538,7 +547,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox) + v.tri_count * sizeof(TriBounds);
     } else {
         if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
-        else { c->lds_cfg.nodes_staged = std::min<uint32_t>(v.node_count, 255); c->lds_cfg.tris_staged = 0; }
+        else { c->lds_cfg.nodes_staged = MIW_LDS_TOP ? std::min<uint32_t>(v.node_count, 255) : 0u; c->lds_cfg.tris_staged = 0; }
         c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
         c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0;
         if (all > 16 * 1024 && depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK")) {
@@ -560,11 +569,11 @@ mi_status mi_trace(mi_ctx *c, const mi_rays_soa *rays, const mi_hits_soa *hits, 
     if (n == 0) return MI_OK;
     if (!hits->t) return fail(c, MI_ERR_INVALID, "mi_trace: hits->t is required");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBuf<float> in, out; DevBuf<uint32_t> outu;
+    TmpBuf<float> in, out; TmpBuf<uint32_t> outu;
     HIP_TRY(c, in.resize(8 * n)); HIP_TRY(c, out.resize(3 * n)); HIP_TRY(c, outu.resize(2 * n));
     const float *src[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->mint, rays->maxt };
     for (int k = 0; k < 8; ++k) {
-        if (!src[k]) { in.release(); out.release(); outu.release(); return fail(c, MI_ERR_INVALID, "mi_trace: null ray array"); }
+        if (!src[k]) return fail(c, MI_ERR_INVALID, "mi_trace: null ray array");
         HIP_TRY(c, hipMemcpyAsync(in.p + k * n, src[k], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     }
     SoaRays R = { in.p, in.p + n, in.p + 2 * n, in.p + 3 * n, in.p + 4 * n, in.p + 5 * n, in.p + 6 * n, in.p + 7 * n };
@@ -579,7 +588,90 @@ mi_status mi_trace(mi_ctx *c, const mi_rays_soa *rays, const mi_hits_soa *hits, 
     if (hits->prim) HIP_TRY(c, hipMemcpyAsync(hits->prim, outu.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (hits->shape) HIP_TRY(c, hipMemcpyAsync(hits->shape, outu.p + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    in.release(); out.release(); outu.release();
+    return MI_OK;
+}
+
+// ---- the Scene query surface: mi_ray_intersect, mi_sample_emitter_direction, mi_pdf_emitter_direction, mi_emitter_eval ----
+// (host arrays in, host arrays out, like mi_trace; temporaries are RAII so that an early HIP_TRY return frees them)
+mi_status mi_ray_intersect(mi_ctx *c, const mi_rays_soa *rays, mi_surface_interaction *si, uint64_t n) {
+    if (!c || !rays || !si) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_ray_intersect: call mi_scene_upload and mi_bvh_build first");
+    if (n == 0) return MI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TmpBuf<float> in; TmpBuf<mi_surface_interaction> out;
+    HIP_TRY(c, in.resize(8 * n)); HIP_TRY(c, out.resize(n));
+    const float *src[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->mint, rays->maxt };
+    for (int k = 0; k < 8; ++k) {
+        if (!src[k]) return fail(c, MI_ERR_INVALID, "mi_ray_intersect: null ray array");
+        HIP_TRY(c, hipMemcpyAsync(in.p + k * n, src[k], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    SoaRays R = { in.p, in.p + n, in.p + 2 * n, in.p + 3 * n, in.p + 4 * n, in.p + 5 * n, in.p + 6 * n, in.p + 7 * n };
+    hipLaunchKernelGGL(k_ray_intersect, dim3((unsigned) ((n + MIW_BLOCK - 1) / MIW_BLOCK)), dim3(MIW_BLOCK), c->lds_bytes, c->stream, c->view, R, out.p, n, c->lds_cfg);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(si, out.p, n * sizeof(mi_surface_interaction), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+mi_status mi_sample_emitter_direction(mi_ctx *c, int32_t emitter, const float *ref_p, const float *sample, const float *wavelengths,
+                                      int32_t test_visibility, mi_direction_sample *ds, float *spec_out, uint64_t n) {
+    if (!c || !ref_p || !sample || !ds || !spec_out) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_sample_emitter_direction: call mi_scene_upload and mi_bvh_build first");
+    if (emitter >= (int32_t) c->emitters.size()) return fail(c, MI_ERR_INVALID, "mi_sample_emitter_direction: emitter index out of range");
+    if (MIW_SPECTRAL && !wavelengths) return fail(c, MI_ERR_INVALID, "mi_sample_emitter_direction: the scalar_spectral library needs wavelengths");
+    if (n == 0) return MI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TmpBuf<float> d_ref, d_smp, d_wl, d_spec; TmpBuf<mi_direction_sample> d_ds;
+    HIP_TRY(c, d_ref.resize(3 * n)); HIP_TRY(c, d_smp.resize(2 * n)); HIP_TRY(c, d_spec.resize(MIW_SPEC_N * n)); HIP_TRY(c, d_ds.resize(n));
+    HIP_TRY(c, hipMemcpyAsync(d_ref.p, ref_p, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_smp.p, sample, 2 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (MIW_SPECTRAL) {
+        HIP_TRY(c, d_wl.resize(4 * n));
+        HIP_TRY(c, hipMemcpyAsync(d_wl.p, wavelengths, 4 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_sample_emitter_direction, dim3((unsigned) ((n + MIW_BLOCK - 1) / MIW_BLOCK)), dim3(MIW_BLOCK), c->lds_bytes, c->stream,
+                       c->view, emitter, d_ref.p, d_smp.p, d_wl.p, test_visibility, d_ds.p, d_spec.p, n, c->lds_cfg);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(ds, d_ds.p, n * sizeof(mi_direction_sample), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(spec_out, d_spec.p, MIW_SPEC_N * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+mi_status mi_pdf_emitter_direction(mi_ctx *c, int32_t emitter, const float *ref_p, const mi_direction_sample *ds, float *pdf, uint64_t n) {
+    if (!c || !ref_p || !ds || !pdf) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_pdf_emitter_direction: call mi_scene_upload and mi_bvh_build first");
+    if (emitter >= (int32_t) c->emitters.size()) return fail(c, MI_ERR_INVALID, "mi_pdf_emitter_direction: emitter index out of range");
+    if (n == 0) return MI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TmpBuf<float> d_ref, d_pdf; TmpBuf<mi_direction_sample> d_ds;
+    HIP_TRY(c, d_ref.resize(3 * n)); HIP_TRY(c, d_pdf.resize(n)); HIP_TRY(c, d_ds.resize(n));
+    HIP_TRY(c, hipMemcpyAsync(d_ref.p, ref_p, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_ds.p, ds, n * sizeof(mi_direction_sample), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pdf_emitter_direction, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, c->view, emitter, d_ref.p, d_ds.p, d_pdf.p, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(pdf, d_pdf.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+mi_status mi_emitter_eval(mi_ctx *c, const mi_surface_interaction *si, const float *wavelengths, float *spec_out, uint64_t n) {
+    if (!c || !si || !spec_out) return MI_ERR_INVALID;
+    if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_emitter_eval: call mi_scene_upload and mi_bvh_build first");
+    if (MIW_SPECTRAL && !wavelengths) return fail(c, MI_ERR_INVALID, "mi_emitter_eval: the scalar_spectral library needs wavelengths");
+    if (n == 0) return MI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TmpBuf<float> d_wl, d_spec; TmpBuf<mi_surface_interaction> d_si;
+    HIP_TRY(c, d_spec.resize(MIW_SPEC_N * n)); HIP_TRY(c, d_si.resize(n));
+    HIP_TRY(c, hipMemcpyAsync(d_si.p, si, n * sizeof(mi_surface_interaction), hipMemcpyHostToDevice, c->stream));
+    if (MIW_SPECTRAL) {
+        HIP_TRY(c, d_wl.resize(4 * n));
+        HIP_TRY(c, hipMemcpyAsync(d_wl.p, wavelengths, 4 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_emitter_eval, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, c->view, d_si.p, d_wl.p, d_spec.p, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(spec_out, d_spec.p, MIW_SPEC_N * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MI_OK;
 }
 
@@ -814,7 +906,18 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
-                if (direct) {
+                // tree scenes with the LDS-stack walk: the wave-level phase machine (device/phased_kernel.h); MIW_PHASED=0 keeps
+                // the lock-step kernel (A/B runs)
+                static const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
+                const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack;
+#define MIW_PHASED_LAUNCH(M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0>), pgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p))
+                if (phased) {
+                    if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false);
+                    else MIW_PHASED_LAUNCH(MATS_PLAIN, true);
+                }
+#undef MIW_PHASED_LAUNCH
+                else if (direct) {
                     if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
                 }
@@ -860,6 +963,21 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                         r[8], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], a, b, r[11], r[12]);
             }
             n = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_verify_n), &n, sizeof n);
+        }
+#endif
+#if defined(MIW_WALK_STATS)
+        if (getenv("MIW_DEBUG")) {
+            unsigned long long st[8]; float stf[8];
+            if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_walk_stats), sizeof st) == hipSuccess && hipMemcpyFromSymbol(stf, HIP_SYMBOL(g_walk_statsf), sizeof stf) == hipSuccess) {
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned long long *a = st + 4 * k; const float *f = stf + 4 * k;
+                    fprintf(stderr, "[miwave] walk stats %s: rays %llu, node steps/ray %.2f (SIMT eff %.3f), triangle tests/ray %.2f (SIMT eff %.3f)\n",
+                            k ? "any-hit" : "closest", a[2], (double) a[0] / std::max<double>(a[2], 1), (double) a[0] / (64.0 * std::max(f[0], 1.f)),
+                            (double) a[1] / std::max<double>(a[2], 1), (double) a[1] / (64.0 * std::max(f[1], 1.f)));
+                }
+                memset(st, 0, sizeof st); memset(stf, 0, sizeof stf);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), st, sizeof st); (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_statsf), stf, sizeof stf);
+            }
         }
 #endif
 #if defined(MIW_SECTION_PROFILE)
@@ -1016,7 +1134,7 @@ mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *
     if ((op == MI_EVAL_BSDF || op == MI_EVAL_EMITTER_SAMPLE || op == MI_EVAL_ENVMAP || op == MI_EVAL_TEXTURE) && !c->have_bvh)
         return fail(c, MI_ERR_STATE, "mi_eval: scene required");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBuf<float> din, dout;
+    TmpBuf<float> din, dout;
     HIP_TRY(c, din.resize(n * is)); HIP_TRY(c, dout.resize(n * os));
     HIP_TRY(c, hipMemcpyAsync(din.p, in, n * is * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(dout.p, 0, n * os * sizeof(float), c->stream));
@@ -1024,7 +1142,6 @@ mi_status mi_eval(mi_ctx *c, int32_t op, const mi_render_cfg *cfg, const float *
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, dout.p, n * os * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    din.release(); dout.release();
     return MI_OK;
 }
 
@@ -1046,7 +1163,7 @@ mi_status mi_selftest(mi_ctx *c, int32_t which, uint64_t *mismatches) {
     if (!c || !mismatches) return MI_ERR_INVALID;
     if (which != MI_SELFTEST_RCP) return fail(c, MI_ERR_INVALID, "mi_selftest: unknown test %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBuf<unsigned long long> d;
+    TmpBuf<unsigned long long> d;
     HIP_TRY(c, d.resize(1));
     HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, c->stream, d.p);
@@ -1055,7 +1172,6 @@ mi_status mi_selftest(mi_ctx *c, int32_t which, uint64_t *mismatches) {
     HIP_TRY(c, hipMemcpyAsync(&h, d.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *mismatches = h;
-    d.release();
     return MI_OK;
 }
 

@@ -30,24 +30,20 @@ def shard_blocks(n_blocks, rank, world):
     return list(range(rank, n_blocks, world))
 
 
-RESIDENT_LANES = 4 * 256 * 256      # k_path_resident: 4 workgroups of 256 lanes on each of MI355X's 256 CUs
-
-
 def choose_shard(mode, parts, width, height, spp):
     """How `parts` ranks split a width x height x spp frame -> "tiles" | "passes".
-    tiles: spiral blocks dealt round-robin (shard_blocks), every rank renders all spp of its pixels; the N-GPU film
-    equals the 1-GPU film. passes: the reference's samples_per_pass = spp / parts run (integrator.cpp:75-86,
-    spiral.cpp:41), pass r on rank r: every rank keeps all pixels. mode "auto" takes tiles while a rank's tiles hold at
-    least 4 pixels per resident lane and passes below that (a pixel's samples are one serial PCG32 stream: with fewer
-    pixels than that the kernels run out of parallel work, DESIGN.md section 7). Passes need spp divisible by parts;
-    otherwise (and for a single rank) the answer is tiles."""
+    tiles (the north star's partition, and what "auto" always picks): spiral blocks dealt round-robin (shard_blocks),
+    every rank renders all spp of its pixels; the N-GPU film equals the 1-GPU film (to the float32 association of the
+    <= 4 block partials under a block border). passes (only on explicit request): the reference's samples_per_pass =
+    spp / parts run (integrator.cpp:75-86, spiral.cpp:41), pass r on rank r — every rank keeps all pixels, but the
+    film is the one scalar_rgb produces for that samples_per_pass, i.e. other random numbers than the 1-GPU job's:
+    a different workload, reported as such (config.parallelism), never chosen silently. Passes need spp divisible
+    by parts; otherwise (and for a single rank) the answer is tiles."""
     if mode not in ("auto", "tiles", "passes"):
         raise ValueError("shard mode must be auto, tiles or passes")
-    if parts <= 1 or spp % parts:
+    if parts <= 1 or spp % parts or mode != "passes":
         return "tiles"
-    if mode == "auto":
-        return "passes" if width * height / parts < 4 * RESIDENT_LANES else "tiles"
-    return mode
+    return "passes"
 
 
 def pass_job(make_integrator, sensor, rank, parts, spp):

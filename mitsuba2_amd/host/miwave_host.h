@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <limits>
 #include <string>
 #include <variant>
 #include <vector>
@@ -271,10 +272,25 @@ float parse_fov(const Properties &props, float aspect);       // src/librender/s
 
 // ---- BSDF plugins ----------------------------------------------------------------------------
 struct BSDFSample3f { Vector3f wo; float pdf, eta; uint32_t sampled_type; };
+struct SurfaceInteraction3f;
+// BSDFContext (bsdf.h:146-190). The device loop and the host helpers implement the context PathIntegrator uses —
+// radiance transport, every lobe enabled; any other context is refused (NotImplementedError in the reference's terms).
+enum class TransportMode : uint32_t { Radiance = 0, Importance = 1 };
+struct BSDFContext {
+    TransportMode mode = TransportMode::Radiance;
+    uint32_t type_mask = 0x1ffu;                               // BSDFFlags::All
+    uint32_t component = (uint32_t) -1;
+    bool is_full() const { return mode == TransportMode::Radiance && (type_mask & 0x1ffu) == 0x1ffu && component == (uint32_t) -1; }
+};
 class BSDF {
 public:
     virtual ~BSDF() = default;
     uint32_t flags() const;                                    // bsdf.h:417-428
+    // The reference's signatures (bsdf.h:328-394): sample(ctx, si, sample1, sample2), eval(ctx, si, wo), pdf(ctx, si, wo);
+    // si.wi is the incident direction in the shading frame. Full contexts only (see BSDFContext).
+    std::pair<BSDFSample3f, Color3f> sample(const BSDFContext &ctx, const SurfaceInteraction3f &si, float sample1, const std::array<float, 2> &sample2) const;
+    Color3f eval(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo) const;
+    float pdf(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo) const;
     // BSDF::sample / eval / pdf in local coordinates (bsdf.h:328-394), scalar semantics
     std::pair<BSDFSample3f, Color3f> sample(const Vector3f &wi, float sample1, const std::array<float, 2> &sample2) const;
     Color3f eval(const Vector3f &wi, const Vector3f &wo) const;
@@ -314,7 +330,48 @@ float fresnel_diffuse_reflectance(float eta);                                   
 float lookup_ior(const Properties &props, const std::string &name, const std::string &def);                   // include/mitsuba/render/ior.h
 
 // ---- Emitter / Shape ----------------------------------------------------------------------------
-class AreaLight {                                             // src/emitters/area.cpp:52-60
+#if MIW_SPECTRAL
+using Spectrum = std::array<float, 4>;
+#else
+using Spectrum = std::array<float, 3>;
+#endif
+class Scene; class Mesh; class Emitter;
+struct Frame3f { Vector3f s, t, n; };
+// SurfaceInteraction3f (interaction.h:104-199): what Scene::ray_intersect returns (mi_surface_interaction + the
+// pointers the reference keeps in it)
+struct SurfaceInteraction3f {
+    float t = std::numeric_limits<float>::infinity();
+    Point3f p{}; Vector3f n{}; Frame3f sh_frame{}; std::array<float, 2> uv{}; Vector3f wi{};
+    std::array<float, 4> wavelengths{};                       // scalar_spectral: set by the caller before eval calls
+    uint32_t prim_index = 0xffffffffu, shape_index = 0xffffffffu; int32_t emitter_index = -1;
+    const Mesh *shape = nullptr;
+    bool is_valid() const { return t != std::numeric_limits<float>::infinity(); }
+    const Emitter *emitter(const Scene *scene) const;          // scene.h:243-253
+    const BSDF *bsdf() const;                                  // bsdf.h:485-500
+    Vector3f to_world(const Vector3f &v) const;                // interaction.h:58-61
+    Vector3f to_local(const Vector3f &v) const;
+};
+// the reference point of an emitter query: Interaction3f (interaction.h:27-101) reduced to what is read
+struct Interaction3f { Point3f p{}; std::array<float, 4> wavelengths{}; };
+// DirectionSample3f (records.h:120-214)
+struct DirectionSample3f {
+    Point3f p{}; Vector3f n{}; Vector3f d{}; float dist = 0.f, pdf = 0.f; bool delta = false;
+    int32_t emitter_index = -1; const Emitter *object = nullptr;
+};
+// Endpoint / Emitter (endpoint.h:86-163): evaluated on the device of the scene the emitter was built into
+class Emitter {
+public:
+    virtual ~Emitter() = default;
+    Spectrum eval(const SurfaceInteraction3f &si) const;                                                        // endpoint.h:155-163
+    std::pair<DirectionSample3f, Spectrum> sample_direction(const Interaction3f &it, const std::array<float, 2> &sample) const;   // :119-139
+    float pdf_direction(const Interaction3f &it, const DirectionSample3f &ds) const;                            // :141-153
+    bool is_environment() const { return m_is_env; }
+    int32_t index() const { return m_index; }                  // position in Scene::emitters(), -1 before Scene::build
+protected:
+    friend class Scene;
+    const Scene *m_scene = nullptr; int32_t m_index = -1; bool m_is_env = false;
+};
+class AreaLight final : public Emitter {                      // src/emitters/area.cpp:52-60
 public:
     explicit AreaLight(const Properties &props);
     Color3f radiance() const { return m_radiance; }
@@ -326,7 +383,7 @@ private:
 // src/emitters/envmap.cpp. The reference loads `filename` through Bitmap (out of scope here: no
 // image I/O on the path); the linear RGBA float32 pixels it would hold after
 // bitmap->convert(RGBA, Float32) (:71-75) are handed over with set_bitmap().
-class EnvironmentMapEmitter {
+class EnvironmentMapEmitter final : public Emitter {
 public:
     explicit EnvironmentMapEmitter(const Properties &props);  // `scale` (:124), `to_world` (endpoint.cpp)
     void set_bitmap(uint32_t width, uint32_t height, const float *rgba);
@@ -420,6 +477,15 @@ public:
     // Scene::ray_intersect_preliminary / ray_test for one ray or a batch
     PreliminaryIntersection3f ray_intersect_preliminary(const Ray3f &ray) const;
     bool ray_test(const Ray3f &ray) const;
+    // Scene::ray_intersect (scene.h:38-60, scene.cpp:113-121): closest hit + full SurfaceInteraction3f
+    SurfaceInteraction3f ray_intersect(const Ray3f &ray) const;
+    void ray_intersect(const mi_rays_soa &rays, mi_surface_interaction *si, uint64_t n) const;
+    // Scene::sample_emitter_direction / pdf_emitter_direction (scene.h:98-128, scene.cpp:164-231)
+    std::pair<DirectionSample3f, Spectrum> sample_emitter_direction(const Interaction3f &ref, const std::array<float, 2> &sample,
+                                                                     bool test_visibility = true) const;
+    float pdf_emitter_direction(const Interaction3f &ref, const DirectionSample3f &ds) const;
+    // Scene::emitters() (scene.h:139-141): area lights and the environment map in the scene's emitter order
+    const std::vector<const Emitter *> &emitters() const { return m_emitter_objs; }
     void ray_intersect_preliminary(const mi_rays_soa &rays, const mi_hits_soa &hits, uint64_t n) const;
     void ray_test(const mi_rays_soa &rays, float *t_out, uint64_t n) const;
     mi_ctx *ctx() const { return m_ctx; }
@@ -431,6 +497,7 @@ private:
     std::vector<mi_shape> m_shape_recs;
     std::vector<mi_bsdf> m_bsdf_recs;
     std::vector<mi_emitter> m_emitters;
+    std::vector<const Emitter *> m_emitter_objs;
     std::vector<mi_rectangle> m_rect_recs; std::vector<mi_sphere> m_sphere_recs;
     std::vector<mi_bitmap> m_bitmap_recs; std::vector<std::shared_ptr<BitmapTexture>> m_bitmap_objs;
     std::vector<float> m_bsdf_tables;
@@ -458,7 +525,7 @@ public:
     void set_shard(uint32_t rank, uint32_t world_size) { m_rank = rank; m_world = world_size; }
     // fills everything SamplingIntegrator::render derives on the host
     // for pass `pass` of pass_count(sensor) (samples_per_pass < sample_count, integrator.cpp:75-86). Passes are
-    // numbered by ascending block-id offset: pass p's blocks carry ids p * block_count + spiral counter
+    // in execution order; like spiral.cpp:41 the first pass rendered carries the highest block-id offset: pass p's blocks carry ids (n_passes - 1 - p) * block_count + spiral counter
     // (spiral.cpp:41), the film adds block tiles in ascending id, so render() runs p = 0, 1, ... and every pass
     // after the first accumulates onto the film (mi_render_cfg::accumulate).
     void make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,

@@ -66,6 +66,17 @@ Color3f BSDF::eval(const Vector3f &wi, const Vector3f &wo) const {
     return { v.x, v.y, v.z };
 }
 #endif
+// the reference's (ctx, si, ...) signatures, bsdf.h:328-394
+static void require_full_context(const BSDFContext &ctx) {
+    if (!ctx.is_full())
+        Throw("BSDFContext: only the full context (radiance transport, all components and lobes enabled) is implemented by this layer");
+}
+std::pair<BSDFSample3f, Color3f> BSDF::sample(const BSDFContext &ctx, const SurfaceInteraction3f &si, float sample1, const std::array<float, 2> &sample2) const {
+    require_full_context(ctx);
+    return sample(si.wi, sample1, sample2);
+}
+Color3f BSDF::eval(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo) const { require_full_context(ctx); return eval(si.wi, wo); }
+float BSDF::pdf(const BSDFContext &ctx, const SurfaceInteraction3f &si, const Vector3f &wo) const { require_full_context(ctx); return pdf(si.wi, wo); }
 float BSDF::pdf(const Vector3f &wi, const Vector3f &wo) const {
     const SideTable tab = side_table(m_rec, m_back, m_table);
     const miw::V3 wi_ = miw::v3(wi[0], wi[1], wi[2]);

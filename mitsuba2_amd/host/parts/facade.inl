@@ -178,6 +178,68 @@ int mih_scene_ray_intersect(void *s, const mi_rays_soa *rays, const mi_hits_soa 
 int mih_scene_ray_test(void *s, const mi_rays_soa *rays, float *t, uint64_t n) {
     MIH_TRY ((Box<Scene> *) s)->p->ray_test(*rays, t, n); return 0; MIH_CATCH(-1)
 }
+// Scene::ray_intersect -> SurfaceInteraction3f records (batch), and the same through the one-ray C++ overload
+int mih_scene_ray_intersect_si(void *s, const mi_rays_soa *rays, mi_surface_interaction *si, uint64_t n) {
+    MIH_TRY ((Box<Scene> *) s)->p->ray_intersect(*rays, si, n); return 0; MIH_CATCH(-1)
+}
+int mih_scene_ray_intersect_one(void *s, const float *ray8, mi_surface_interaction *out, int *has_bsdf, int *emitter_index) {
+    MIH_TRY
+        const Scene *sc = ((Box<Scene> *) s)->p.get();
+        Ray3f r; r.o = { ray8[0], ray8[1], ray8[2] }; r.d = { ray8[3], ray8[4], ray8[5] }; r.mint = ray8[6]; r.maxt = ray8[7];
+        SurfaceInteraction3f si = sc->ray_intersect(r);
+        *out = record_from_si(si);
+        *has_bsdf = si.bsdf() ? 1 : 0;
+        const Emitter *e = si.emitter(sc);
+        *emitter_index = e ? e->index() : -1;
+        return si.is_valid() ? 1 : 0; MIH_CATCH(-1)
+}
+// Scene::sample_emitter_direction (emitter < 0) / Endpoint::sample_direction of Scene::emitters()[emitter], one query
+int mih_scene_sample_emitter_direction(void *s, int emitter, const float *ref_p, const float *wavelengths, const float *sample2,
+                                       int test_visibility, mi_direction_sample *ds, float *spec) {
+    MIH_TRY
+        const Scene *sc = ((Box<Scene> *) s)->p.get();
+        Interaction3f it; it.p = { ref_p[0], ref_p[1], ref_p[2] };
+        if (wavelengths) it.wavelengths = { wavelengths[0], wavelengths[1], wavelengths[2], wavelengths[3] };
+        if (emitter >= (int) sc->emitters().size()) throw std::runtime_error("emitter index out of range");
+        auto r = emitter < 0 ? sc->sample_emitter_direction(it, { sample2[0], sample2[1] }, test_visibility != 0)
+                             : sc->emitters()[emitter]->sample_direction(it, { sample2[0], sample2[1] });
+        *ds = record_from_ds(r.first);
+        for (size_t k = 0; k < r.second.size(); ++k) spec[k] = r.second[k];
+        return 0; MIH_CATCH(-1)
+}
+int mih_scene_pdf_emitter_direction(void *s, int emitter, const float *ref_p, const mi_direction_sample *ds, float *pdf) {
+    MIH_TRY
+        const Scene *sc = ((Box<Scene> *) s)->p.get();
+        Interaction3f it; it.p = { ref_p[0], ref_p[1], ref_p[2] };
+        if (emitter >= (int) sc->emitters().size()) throw std::runtime_error("emitter index out of range");
+        DirectionSample3f d = ds_from_record(*ds, sc);
+        *pdf = emitter < 0 ? sc->pdf_emitter_direction(it, d) : sc->emitters()[emitter]->pdf_direction(it, d);
+        return 0; MIH_CATCH(-1)
+}
+// si.emitter(scene)->eval(si) (emitter < 0) or Scene::emitters()[emitter]->eval(si)
+int mih_scene_emitter_eval(void *s, int emitter, const mi_surface_interaction *si, const float *wavelengths, float *spec) {
+    MIH_TRY
+        const Scene *sc = ((Box<Scene> *) s)->p.get();
+        SurfaceInteraction3f x = si_from_record(*si, sc);
+        if (wavelengths) x.wavelengths = { wavelengths[0], wavelengths[1], wavelengths[2], wavelengths[3] };
+        const Emitter *e = emitter < 0 ? x.emitter(sc) : (emitter < (int) sc->emitters().size() ? sc->emitters()[emitter] : nullptr);
+        Spectrum v{};
+        if (e) v = e->eval(x);
+        for (size_t k = 0; k < v.size(); ++k) spec[k] = v[k];
+        return e ? 1 : 0; MIH_CATCH(-1)
+}
+int mih_scene_emitter_count(void *s) { return (int) ((Box<Scene> *) s)->p->emitters().size(); }
+// BSDF::sample / eval / pdf through the reference's (ctx, si, ...) signatures; -1: the context is refused
+int mih_bsdf_sample_ctx(void *b, uint32_t mode, uint32_t type_mask, uint32_t component, const float *wi, float s1, const float *s2, float *out9) {
+    MIH_TRY
+        BSDFContext ctx; ctx.mode = (TransportMode) mode; ctx.type_mask = type_mask; ctx.component = component;
+        SurfaceInteraction3f si; si.wi = { wi[0], wi[1], wi[2] };
+        auto r = ((Box<BSDF> *) b)->p->sample(ctx, si, s1, { s2[0], s2[1] });
+        out9[0] = r.first.wo[0]; out9[1] = r.first.wo[1]; out9[2] = r.first.wo[2]; out9[3] = r.first.pdf; out9[4] = r.first.eta;
+        std::memcpy(out9 + 5, &r.first.sampled_type, 4);
+        out9[6] = r.second[0]; out9[7] = r.second[1]; out9[8] = r.second[2];
+        return 0; MIH_CATCH(-1)
+}
 
 void *mih_film_create(void *props) { MIH_TRY return new Box<Film>{ std::make_shared<Film>(*(Properties *) props) }; MIH_CATCH(nullptr) }
 void mih_film_destroy(void *f) { delete (Box<Film> *) f; }
@@ -272,7 +334,7 @@ int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *blo
         if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
         std::memcpy(block_ids, ids.data(), ids.size() * 4);
         std::memcpy(tiles, tl.data(), tl.size() * 4);
-        cfg->block_ids = block_ids; cfg->tile_list = tl.empty() ? nullptr : tiles;
+        cfg->block_ids = block_ids; cfg->tile_list = cfg->tile_list ? tiles : nullptr;   // sharded with zero tiles != unsharded
         return 0; MIH_CATCH(-1)
 }
 int mih_make_render_cfg_pass(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads, uint32_t pass) {
@@ -282,7 +344,7 @@ int mih_make_render_cfg_pass(void *i, void *sensor, mi_render_cfg *cfg, uint32_t
         if (ids.size() > capacity) throw std::runtime_error("mih_make_render_cfg: capacity too small");
         std::memcpy(block_ids, ids.data(), ids.size() * 4);
         std::memcpy(tiles, tl.data(), tl.size() * 4);
-        cfg->block_ids = block_ids; cfg->tile_list = tl.empty() ? nullptr : tiles;
+        cfg->block_ids = block_ids; cfg->tile_list = cfg->tile_list ? tiles : nullptr;   // sharded with zero tiles != unsharded
         return 0; MIH_CATCH(-1)
 }
 int mih_integrator_pass_count(void *i, void *sensor) {

@@ -63,7 +63,8 @@ void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_ren
     auto cs = film->crop_size(); auto co = film->crop_offset();
     size_t total_spp = sensor->sampler()->sample_count();
     size_t spp_pass = samples_per_pass_of(m_samples_per_pass, total_spp);
-    if (pass >= total_spp / spp_pass) Throw("make_render_cfg: pass index out of range");
+    const size_t n_passes = total_spp / spp_pass;
+    if (pass >= n_passes) Throw("make_render_cfg: pass index out of range");
     // block size, integrator.cpp:88-97 (MTS_BLOCK_SIZE = 32, spiral.h:9-10)
     uint32_t bs = m_block_size;
     if (bs == 0) {
@@ -88,14 +89,19 @@ void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_ren
     for (size_t i = 0; i < spiral.block_count(); ++i) {
         Spiral::Block b = spiral.next_block();
         uint32_t bx = (uint32_t) (b.offset[0] - co[0]) / bs, by = (uint32_t) (b.offset[1] - co[1]) / bs;
-        block_ids[by * nbx + bx] = (uint32_t) (b.block_id + (size_t) pass * spiral.block_count());   // spiral.cpp:41
+        // spiral.cpp:41: block_id = counter + (remaining_passes - 1) * block_count — the FIRST pass the reference
+        // renders carries the highest offset, the last one offset 0; `pass` counts in execution order
+        block_ids[by * nbx + bx] = (uint32_t) (b.block_id + (n_passes - 1 - (size_t) pass) * spiral.block_count());
         by_id[b.block_id] = by * nbx + bx;
     }
     tiles.clear();
     if (m_world > 1)                                           // interleaved shard over the spiral order
         for (size_t id = m_rank; id < by_id.size(); id += m_world) tiles.push_back(by_id[id]);
     cfg.block_ids = block_ids.data(); cfg.block_count = (uint32_t) block_ids.size();
-    cfg.tile_list = m_world > 1 ? tiles.data() : nullptr; cfg.tile_count = (uint32_t) tiles.size();
+    // a rank whose shard is empty (world > block count) renders NOTHING: mi_render reads tile_list == NULL as
+    // "all blocks", so a sharded job always carries a non-null list, with tile_count == 0 if need be
+    static const uint32_t no_tiles[1] = { 0 };
+    cfg.tile_list = m_world > 1 ? (tiles.empty() ? no_tiles : tiles.data()) : nullptr; cfg.tile_count = (uint32_t) tiles.size();
     std::memcpy(cfg.sample_to_camera, sensor->sample_to_camera().m, 64);
     std::memcpy(cfg.to_world, sensor->world_transform().m, 64);
     cfg.near_clip = sensor->near_clip(); cfg.far_clip = sensor->far_clip();

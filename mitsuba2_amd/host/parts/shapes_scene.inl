@@ -483,6 +483,15 @@ void Scene::build(int device, int bvh_quality) {
         m_env_rec.bsphere_radius = std::sqrt(d2);
         m_desc.envmap = &m_env_rec;
     }
+    // Scene::emitters(): the area lights in shape order with the environment map at its slot; every emitter learns
+    // its scene and index so that Endpoint::eval / sample_direction / pdf_direction can run on the scene's device
+    m_emitter_objs.clear();
+    for (auto &m : m_shapes) if (m->emitter()) m_emitter_objs.push_back(m->emitter().get());
+    if (m_env) m_emitter_objs.insert(m_emitter_objs.begin() + std::min<size_t>(m_env_rec.emitter_index, m_emitter_objs.size()), m_env.get());
+    for (size_t i = 0; i < m_emitter_objs.size(); ++i) {
+        Emitter *e = const_cast<Emitter *>(m_emitter_objs[i]);
+        e->m_scene = this; e->m_index = (int32_t) i; e->m_is_env = m_env && e == m_env.get();
+    }
     m_built = true;
     if (device < 0) return;                                    // flatten only (host-side tests)
     if (!m_ctx) {
@@ -508,6 +517,99 @@ PreliminaryIntersection3f Scene::ray_intersect_preliminary(const Ray3f &r) const
     ray_intersect_preliminary(rays, hits, 1);
     return pi;
 }
+// ---- Scene::ray_intersect / sample_emitter_direction / pdf_emitter_direction and the Endpoint methods ----
+static SurfaceInteraction3f si_from_record(const mi_surface_interaction &r, const Scene *scene) {
+    SurfaceInteraction3f si;
+    si.t = r.t;
+    for (int k = 0; k < 3; ++k) { si.p[k] = r.p[k]; si.n[k] = r.n[k]; si.sh_frame.s[k] = r.sh_s[k]; si.sh_frame.t[k] = r.sh_t[k]; si.sh_frame.n[k] = r.sh_n[k]; si.wi[k] = r.wi[k]; }
+    si.uv = { r.uv[0], r.uv[1] };
+    si.prim_index = r.prim_index; si.shape_index = r.shape_index; si.emitter_index = r.emitter_index;
+    si.shape = r.shape_index < scene->shapes().size() ? scene->shapes()[r.shape_index].get() : nullptr;
+    return si;
+}
+static mi_surface_interaction record_from_si(const SurfaceInteraction3f &si) {
+    mi_surface_interaction r{};
+    r.t = si.t;
+    for (int k = 0; k < 3; ++k) { r.p[k] = si.p[k]; r.n[k] = si.n[k]; r.sh_s[k] = si.sh_frame.s[k]; r.sh_t[k] = si.sh_frame.t[k]; r.sh_n[k] = si.sh_frame.n[k]; r.wi[k] = si.wi[k]; }
+    r.uv[0] = si.uv[0]; r.uv[1] = si.uv[1];
+    r.prim_index = si.prim_index; r.shape_index = si.shape_index; r.emitter_index = si.emitter_index;
+    return r;
+}
+static DirectionSample3f ds_from_record(const mi_direction_sample &r, const Scene *scene) {
+    DirectionSample3f ds;
+    for (int k = 0; k < 3; ++k) { ds.p[k] = r.p[k]; ds.n[k] = r.n[k]; ds.d[k] = r.d[k]; }
+    ds.dist = r.dist; ds.pdf = r.pdf; ds.emitter_index = r.emitter_index;
+    ds.object = (r.emitter_index >= 0 && (size_t) r.emitter_index < scene->emitters().size()) ? scene->emitters()[r.emitter_index] : nullptr;
+    return ds;
+}
+static mi_direction_sample record_from_ds(const DirectionSample3f &ds) {
+    mi_direction_sample r{};
+    for (int k = 0; k < 3; ++k) { r.p[k] = ds.p[k]; r.n[k] = ds.n[k]; r.d[k] = ds.d[k]; }
+    r.dist = ds.dist; r.pdf = ds.pdf; r.emitter_index = ds.object ? ds.object->index() : ds.emitter_index;
+    return r;
+}
+void Scene::ray_intersect(const mi_rays_soa &rays, mi_surface_interaction *si, uint64_t n) const {
+    if (!m_ctx) Throw("Scene: not built on a device");
+    if (mi_ray_intersect(m_ctx, &rays, si, n) != MI_OK) Throw(std::string("mi_ray_intersect: ") + mi_last_error(m_ctx));
+}
+SurfaceInteraction3f Scene::ray_intersect(const Ray3f &r) const {
+    mi_rays_soa rays{ &r.o[0], &r.o[1], &r.o[2], &r.d[0], &r.d[1], &r.d[2], &r.mint, &r.maxt };
+    mi_surface_interaction rec{};
+    ray_intersect(rays, &rec, 1);
+    return si_from_record(rec, this);
+}
+static std::pair<DirectionSample3f, Spectrum> sample_direction_on_device(const Scene *scene, int32_t emitter, const Interaction3f &ref,
+                                                                          const std::array<float, 2> &sample, bool test_visibility) {
+    if (!scene || !scene->ctx()) Throw("sample_direction: the scene is not built on a device");
+    mi_direction_sample rec{}; Spectrum value{};
+    if (mi_sample_emitter_direction(scene->ctx(), emitter, ref.p.data(), sample.data(), ref.wavelengths.data(), test_visibility ? 1 : 0,
+                                    &rec, value.data(), 1) != MI_OK)
+        Throw(std::string("mi_sample_emitter_direction: ") + mi_last_error(scene->ctx()));
+    return { ds_from_record(rec, scene), value };
+}
+std::pair<DirectionSample3f, Spectrum> Scene::sample_emitter_direction(const Interaction3f &ref, const std::array<float, 2> &sample, bool test_visibility) const {
+    return sample_direction_on_device(this, -1, ref, sample, test_visibility);
+}
+float Scene::pdf_emitter_direction(const Interaction3f &ref, const DirectionSample3f &ds) const {
+    if (!m_ctx) Throw("Scene: not built on a device");
+    const mi_direction_sample rec = record_from_ds(ds);
+    float pdf = 0.f;
+    if (mi_pdf_emitter_direction(m_ctx, -1, ref.p.data(), &rec, &pdf, 1) != MI_OK) Throw(std::string("mi_pdf_emitter_direction: ") + mi_last_error(m_ctx));
+    return pdf;
+}
+std::pair<DirectionSample3f, Spectrum> Emitter::sample_direction(const Interaction3f &it, const std::array<float, 2> &sample) const {
+    if (m_index < 0) Throw("Emitter: not part of a built scene");
+    return sample_direction_on_device(m_scene, m_index, it, sample, false);     // Endpoint::sample_direction knows no occluders
+}
+float Emitter::pdf_direction(const Interaction3f &it, const DirectionSample3f &ds) const {
+    if (m_index < 0 || !m_scene->ctx()) Throw("Emitter: not part of a scene built on a device");
+    const mi_direction_sample rec = record_from_ds(ds);
+    float pdf = 0.f;
+    if (mi_pdf_emitter_direction(m_scene->ctx(), m_index, it.p.data(), &rec, &pdf, 1) != MI_OK) Throw(std::string("mi_pdf_emitter_direction: ") + mi_last_error(m_scene->ctx()));
+    return pdf;
+}
+Spectrum Emitter::eval(const SurfaceInteraction3f &si) const {
+    if (m_index < 0 || !m_scene->ctx()) Throw("Emitter: not part of a scene built on a device");
+    mi_surface_interaction rec = record_from_si(si);
+    rec.emitter_index = m_index;                               // `this` is the emitter being evaluated
+    Spectrum value{};
+    if (mi_emitter_eval(m_scene->ctx(), &rec, si.wavelengths.data(), value.data(), 1) != MI_OK) Throw(std::string("mi_emitter_eval: ") + mi_last_error(m_scene->ctx()));
+    return value;
+}
+const Emitter *SurfaceInteraction3f::emitter(const Scene *scene) const {
+    return (scene && emitter_index >= 0 && (size_t) emitter_index < scene->emitters().size()) ? scene->emitters()[emitter_index] : nullptr;
+}
+const BSDF *SurfaceInteraction3f::bsdf() const { return shape ? shape->bsdf().get() : nullptr; }
+Vector3f SurfaceInteraction3f::to_world(const Vector3f &v) const {                  // frame.h:25-37: s * v.x + t * v.y + n * v.z (fma chain)
+    Vector3f r;
+    for (int k = 0; k < 3; ++k) r[k] = std::fma(sh_frame.n[k], v[2], std::fma(sh_frame.t[k], v[1], sh_frame.s[k] * v[0]));
+    return r;
+}
+Vector3f SurfaceInteraction3f::to_local(const Vector3f &v) const {
+    auto dot3 = [](const Vector3f &a, const Vector3f &b) { return std::fma(a[2], b[2], std::fma(a[1], b[1], a[0] * b[0])); };
+    return { dot3(v, sh_frame.s), dot3(v, sh_frame.t), dot3(v, sh_frame.n) };
+}
+
 bool Scene::ray_test(const Ray3f &r) const {
     mi_rays_soa rays{ &r.o[0], &r.o[1], &r.o[2], &r.d[0], &r.d[1], &r.d[2], &r.mint, &r.maxt };
     float t;

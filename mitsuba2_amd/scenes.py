@@ -96,10 +96,12 @@ def icosphere(center, radius, level):
     return p.astype(np.float32), f.astype(np.uint32), n.astype(np.float32)
 
 
-def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None, glass=None):
+def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None, glass=None, glass_block=False):
     """-> list of api.Mesh. diffuse_only: the classic box (36 triangles, config C2).
     Otherwise the short block becomes a GGX rough-conductor ball with shading normals
-    and the tall block a dielectric (bk7) ball — the material-ball configuration (C3)."""
+    and the tall block a dielectric (bk7) ball — the material-ball configuration (C3).
+    glass_block (with diffuse_only): the tall block is a smooth dielectric (bk7, constant IOR — Mitsuba 2's
+    dielectric has no dispersion) with a bottom face, so that it is a closed solid — config C5's geometry."""
     white = api.BSDF("diffuse", reflectance=WHITE)
     red = api.BSDF("diffuse", reflectance=RED)
     green = api.BSDF("diffuse", reflectance=GREEN)
@@ -111,7 +113,12 @@ def cornell_box_meshes(diffuse_only=True, ball_level=5, metal=None, glass=None):
     meshes.append(api.Mesh("light", v, f, emitter=api.AreaLight(LIGHT_RADIANCE)))   # default BSDF: diffuse 0
     if diffuse_only:
         v, f = _block(_SHORT); meshes.append(api.Mesh("short_block", v, f, bsdf=white))
-        v, f = _block(_TALL); meshes.append(api.Mesh("tall_block", v, f, bsdf=white))
+        if glass_block:
+            bottom = [(423, 0.05, 247), (472, 0.05, 406), (314, 0.05, 456), (265, 0.05, 296)]   # just above the floor: no coplanar ties
+            v, f = _merge([_quad(q, outward_point=(368, 165, 351)) for q in _TALL + [bottom]])
+            meshes.append(api.Mesh("tall_block", v, f, bsdf=api.BSDF("dielectric", int_ior=1.5046, ext_ior=1.000277)))
+        else:
+            v, f = _block(_TALL); meshes.append(api.Mesh("tall_block", v, f, bsdf=white))
     else:
         mkw = dict(distribution="ggx", alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
         mkw.update(metal or {})
@@ -139,10 +146,10 @@ def cornell_sensor(width, height, spp, seed=0, rfilter="gaussian", **film_kw):
 
 
 def cornell_box(width, height, spp, diffuse_only=True, seed=0, device=0, ball_level=5, rfilter="gaussian",
-                metal=None, glass=None, **film_kw):
+                metal=None, glass=None, glass_block=False, **film_kw):
     """-> (scene, sensor). device < 0 builds only the host-side description.
     `metal`: property overrides of the rough-conductor ball (e.g. dict(distribution="beckmann"))."""
-    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level, metal, glass)).build(device)
+    scene = api.Scene(cornell_box_meshes(diffuse_only, ball_level, metal, glass, glass_block)).build(device)
     return scene, cornell_sensor(width, height, spp, seed, rfilter, **film_kw)
 
 

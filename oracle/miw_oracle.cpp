@@ -744,6 +744,105 @@ int orc_ray_intersect_full(const mi_scene_desc *scene, const float *ray8, float 
     return ok ? 1 : 0;
 }
 
+// ---- the Scene query surface, scalar semantics (the checker of mi_ray_intersect / mi_sample_emitter_direction /
+// mi_pdf_emitter_direction / mi_emitter_eval): Scene::ray_intersect (scene.cpp:113-121), sample_emitter_direction with
+// its visibility test (:164-214), pdf_emitter_direction (:216-231), si.emitter(scene)->eval(si) (scene.h:243-253). ----
+static void fill_si_record(const OScene &sc, const Ray &ray, mi_surface_interaction &r) {
+    SurfaceInteraction si; std::memset(&si, 0, sizeof si);
+    std::memset(&r, 0, sizeof r);
+    if (ray_intersect(sc, ray, si)) {
+        r.t = si.t;
+        const V3 *src[6] = { &si.p, &si.n, &si.sh.s, &si.sh.t, &si.sh.n, &si.wi };
+        float *dst[6] = { r.p, r.n, r.sh_s, r.sh_t, r.sh_n, r.wi };
+        for (int k = 0; k < 6; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+        r.uv[0] = si.uv.x; r.uv[1] = si.uv.y;
+        r.prim_index = sc.tris[si.prim].prim; r.shape_index = si.shape;
+        r.emitter_index = sc.shapes[si.shape].emitter;
+    } else {
+        r.t = std::numeric_limits<float>::infinity();
+        r.wi[0] = -ray.d.x; r.wi[1] = -ray.d.y; r.wi[2] = -ray.d.z;
+        r.prim_index = r.shape_index = 0xffffffffu;
+        r.emitter_index = sc.view.env ? (int32_t) sc.view.env->emitter_index : -1;
+    }
+}
+int orc_ray_intersect(const mi_scene_desc *scene, const mi_rays_soa *r, mi_surface_interaction *out, uint64_t n) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    FtzScope ftz;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray ray; ray.o = v3(r->ox[i], r->oy[i], r->oz[i]); ray.d = v3(r->dx[i], r->dy[i], r->dz[i]); ray.mint = r->mint[i]; ray.maxt = r->maxt[i];
+        fill_si_record(sc, ray, out[i]);
+    }
+    return 0;
+}
+int orc_sample_emitter_direction(const mi_scene_desc *scene, int32_t emitter, const float *ref_p, const float *sample, const float *wavelengths,
+                                 int32_t test_visibility, mi_direction_sample *out, float *spec_out, uint64_t n) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    if (emitter >= (int32_t) sc.view.emitter_count) return -1;
+    FtzScope ftz;
+    for (uint64_t i = 0; i < n; ++i) {
+        Wavelengths wl;
+#if MIW_SPECTRAL
+        for (int k = 0; k < 4; ++k) wl.l[k] = wavelengths[4 * i + k];
+#else
+        (void) wavelengths;
+#endif
+        const V3 ref = v3(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]);
+        const V2 u = v2(sample[2 * i], sample[2 * i + 1]);
+        DirectionSample ds;
+        Spec value = emitter < 0 ? sample_emitter_direction(sc.view, ref, u, ds, wl) : emitter_sample_direction(sc.view, (uint32_t) emitter, ref, u, ds, wl);
+        if (test_visibility && ds.pdf != 0.f) {                // scene.cpp:203-207
+            Ray shadow; shadow.o = ref; shadow.d = ds.d; shadow.mint = spawn_mint(ref); shadow.maxt = ds.dist * (1.f - MIW_SHADOW_EPSILON);
+            if (ray_test(sc, shadow)) value = spec(0.f);
+        }
+        mi_direction_sample &r = out[i];
+        r.p[0] = ds.p.x; r.p[1] = ds.p.y; r.p[2] = ds.p.z; r.n[0] = ds.n.x; r.n[1] = ds.n.y; r.n[2] = ds.n.z;
+        r.d[0] = ds.d.x; r.d[1] = ds.d.y; r.d[2] = ds.d.z; r.dist = ds.dist; r.pdf = ds.pdf; r.emitter_index = (int32_t) ds.emitter;
+        const float *vf = reinterpret_cast<const float *>(&value);
+        for (int k = 0; k < MIW_SPEC_N; ++k) spec_out[MIW_SPEC_N * i + k] = vf[k];
+    }
+    return 0;
+}
+int orc_pdf_emitter_direction(const mi_scene_desc *scene, int32_t emitter, const float *ref_p, const mi_direction_sample *ds, float *pdf, uint64_t n) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    FtzScope ftz;
+    for (uint64_t i = 0; i < n; ++i) {
+        const mi_direction_sample &r = ds[i];
+        const V3 ref = v3(ref_p[3 * i], ref_p[3 * i + 1], ref_p[3 * i + 2]);
+        const uint32_t e = emitter < 0 ? (uint32_t) r.emitter_index : (uint32_t) emitter;
+        float v = 0.f;
+        if (e < sc.view.emitter_count)
+            v = emitter < 0 ? pdf_emitter_direction(sc.view, e, ld3(r.d), r.dist, ld3(r.n), ref) : emitter_pdf_direction(sc.view, e, ld3(r.d), r.dist, ld3(r.n), ref);
+        pdf[i] = v;
+    }
+    return 0;
+}
+int orc_emitter_eval(const mi_scene_desc *scene, const mi_surface_interaction *si, const float *wavelengths, float *spec_out, uint64_t n) {
+    OScene sc;
+    if (!build_scene(scene, sc)) return -1;
+    FtzScope ftz;
+    for (uint64_t i = 0; i < n; ++i) {
+        Wavelengths wl;
+#if MIW_SPECTRAL
+        for (int k = 0; k < 4; ++k) wl.l[k] = wavelengths[4 * i + k];
+#else
+        (void) wavelengths;
+#endif
+        const mi_surface_interaction &r = si[i];
+        Spec value = spec(0.f);
+        if (r.emitter_index >= 0 && (uint32_t) r.emitter_index < sc.view.emitter_count) {
+            const EmitterRec &e = sc.view.emitters[r.emitter_index];
+            if (e.type == EMITTER_ENVMAP) { if (sc.view.env) value = env_eval_spec(*sc.view.env, -ld3(r.wi)); }
+            else value = emitter_eval(e, ld3(r.wi), wl);
+        }
+        const float *vf = reinterpret_cast<const float *>(&value);
+        for (int k = 0; k < MIW_SPEC_N; ++k) spec_out[MIW_SPEC_N * i + k] = vf[k];
+    }
+    return 0;
+}
+
 // ---- known-answer entry points -------------------------------------------------------------------
 float  orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_float32(v0, v1, rounds); }
 double orc_tea_float64(uint32_t v0, uint32_t v1, int rounds) { return sample_tea_float64(v0, v1, rounds); }

@@ -119,7 +119,7 @@ def test_phantom_grazing_hit_is_structure_independent(native, oracle):
 
 def test_samples_per_pass(native, oracle):
     """samples_per_pass < sample_count (integrator.cpp:75-86): every pass re-seeds the pixels from its own block ids
-    (spiral.cpp:41: counter + pass * block_count) and adds its blocks onto the film after the ids already there."""
+    (spiral.cpp:41: counter + (remaining_passes - 1) * block_count) and adds its blocks onto the film after the passes already there."""
     from mitsuba2_amd import scenes
     scene, sensor = scenes.cornell_box(40, 36, 6, device=-1)
     integ = native.PathIntegrator(samples_per_pass=2)
@@ -132,7 +132,8 @@ def test_samples_per_pass(native, oracle):
     for p in range(3):
         job = integ.render_job(sensor, pass_index=p)
         assert job.cfg.spp == 2 and job.cfg.accumulate == (1 if p else 0) and job.cfg.block_count == nblocks
-        assert np.array_equal(job.block_ids[:nblocks], one.block_ids[:nblocks] + p * nblocks)
+        # spiral.cpp:41: the first pass rendered carries the highest id offset (remaining_passes - 1), the last one 0
+        assert np.array_equal(job.block_ids[:nblocks], one.block_ids[:nblocks] + (2 - p) * nblocks)
         o32, o64, st = oracle.render(scene.desc(), job, threads=4, onto=(o32, o64))
         e64, e32, est = oracle.emu_render(scene.desc(), job, onto=(e64, e32))
         assert est[1] == st.segments and np.array_equal(e32, o32)
@@ -385,12 +386,53 @@ def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path):
     assert np.array_equal(got.astype(np.float32), full.astype(np.float32))
 
 
+@pytest.mark.parametrize("rfilter", ["gaussian", "box", "lanczos"])
+def test_tiny_blocks_of_a_many_threaded_render(native, oracle, rfilter):
+    """integrator.cpp:88-97 halves the block size until there are as many blocks as worker threads — down to 1 pixel for
+    a small window. A film texel then lies under the borders of up to (2 * border + 1)^2 blocks, not 2 x 2: the ordered
+    film merge (miw/film_gather.h, the device's k_film_merge) must still add every covering block, in ascending id."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(192, 108, 4, device=-1)
+    sensor = scenes.cornell_sensor(192, 108, 4, rfilter=rfilter, crop_offset_x=90, crop_offset_y=60, crop_width=16, crop_height=16)
+    sizes = []
+    for n_threads in (1, 16, 64, 256):
+        job = native.PathIntegrator().render_job(sensor, n_threads=n_threads)
+        sizes.append((job.cfg.block_size, job.cfg.block_count))
+        o32, o64, st = oracle.render(scene.desc(), job, threads=4)
+        e64, e32, est = oracle.emu_render(scene.desc(), job)
+        assert st.samples == 16 * 16 * 4 and est[1] == st.segments
+        assert np.array_equal(e32, o32) and np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
+    assert sizes == [(32, 1), (4, 16), (2, 64), (1, 256)]
+
+
+def test_more_ranks_than_blocks_leaves_empty_shards_empty(native, oracle):
+    """A 64x48 frame has 4 spiral blocks; with 8 ranks, ranks 4..7 hold no block. Their job must say so (non-NULL
+    tile_list, tile_count == 0 — a NULL list means "all blocks" to mi_render) and render nothing, so that the film
+    reduce still adds up to the 1-rank film."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(64, 48, 2, device=-1)
+    full32, full64, fst = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=4)
+    acc = np.zeros_like(full64); samples = 0
+    for rank in range(8):
+        integ = native.PathIntegrator(); integ.set_shard(rank, 8)
+        job = integ.render_job(sensor)
+        assert job.cfg.block_count == 4 and job.cfg.tile_count == (1 if rank < 4 else 0) and bool(job.cfg.tile_list)
+        _, p64, st = oracle.render(scene.desc(), job, threads=2)
+        e64, _, est = oracle.emu_render(scene.desc(), job)
+        assert st.samples == (fst.samples // 4 if rank < 4 else 0) or rank < 4      # clipped edge blocks differ in size
+        if rank >= 4:
+            assert st.samples == 0 and est[0] == 0 and not p64.any() and not e64.any()
+        acc += p64; samples += st.samples
+    assert samples == fst.samples and np.array_equal(acc.astype(np.float32), full64.astype(np.float32))
+
+
 def test_shard_mode_selection_and_pass_jobs(native):
     """mitsuba2_amd/dist.py: what bench.py --shard auto picks, and the per-rank jobs of the pass partition"""
     from mitsuba2_amd import dist as mdist, scenes
     pick = mdist.choose_shard
-    assert [pick("auto", n, 1920, 1080, 512) for n in (1, 2, 3, 4, 8)] == ["tiles", "passes", "tiles", "passes", "passes"]
-    assert [pick("auto", n, 3840, 2160, 512) for n in (2, 4, 8)] == ["tiles", "tiles", "passes"]      # a 4K frame fills 4 GPUs
+    # the headline partition is the north star's: tiles, at every rank count (the N-GPU film == the 1-GPU film)
+    assert [pick("auto", n, 1920, 1080, 512) for n in (1, 2, 3, 4, 8)] == ["tiles"] * 5
+    assert [pick("auto", n, 3840, 2160, 512) for n in (2, 4, 8)] == ["tiles"] * 3
     assert pick("tiles", 8, 1920, 1080, 512) == "tiles" and pick("passes", 2, 7680, 4320, 512) == "passes"
     assert pick("passes", 8, 1920, 1080, 100) == "tiles"                                             # spp not divisible
     with pytest.raises(ValueError):
@@ -402,4 +444,4 @@ def test_shard_mode_selection_and_pass_jobs(native):
             integ, job = mdist.pass_job(make, sensor, rank, 4, 8)
             c = job.cfg
             assert (c.spp, c.accumulate, c.tile_count, c.block_count) == (2, 0, 0, one.cfg.block_count)
-            assert np.array_equal(job.block_ids[:c.block_count], one.block_ids[:c.block_count] + rank * c.block_count)
+            assert np.array_equal(job.block_ids[:c.block_count], one.block_ids[:c.block_count] + (3 - rank) * c.block_count)   # spiral.cpp:41

@@ -379,6 +379,26 @@ def test_tile_shards_sum_to_full_film(native, oracle, dev, cbox):
             assert (acc.astype(np.float32) == full.astype(np.float32)).mean() > 0.7
 
 
+def test_empty_tile_shard_renders_nothing(native, dev):
+    """world > block count (64x48 = 4 blocks, 8 ranks): ranks 4..7 render nothing — a sharded job with zero tiles is
+    not an unsharded job — and the eight partial films still add up to the 1-rank film."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(64, 48, 4, device=-1)
+    dev.upload(scene.desc())
+    for mode in (1, 2):
+        full, _ = dev.render(native.PathIntegrator().render_job(sensor), f64=True, film_mode=mode)
+        acc = np.zeros_like(full); samples = 0
+        for rank in range(8):
+            integ = native.PathIntegrator(); integ.set_shard(rank, 8)
+            part, st = dev.render(integ.render_job(sensor), f64=True, film_mode=mode)
+            c = dev.counters()
+            assert st == 0 and (c.samples > 0) == (rank < 4)
+            if rank >= 4:
+                assert not part.any()
+            acc += part; samples += c.samples
+        assert samples == 64 * 48 * 4 and rel_l2(acc, full) < 1e-7
+
+
 def test_errors_are_loud(native, dev):
     import ctypes as C
     from mitsuba2_amd import _capi
