@@ -6,8 +6,11 @@
 A "step" is one complete render of the workload (scene + BVH already resident in
 HBM; the timed region is mi_render + the film reduce). For N > 1 launch with
 torch.distributed.run, one rank per GPU: pixel tiles (spiral blocks) are sharded
-round-robin over ranks, each rank splats into a private full-size
-float64 film and one RCCL reduce(sum) to rank 0 closes the step.
+round-robin over ranks (the N-GPU film equals the 1-GPU film), each rank
+splats into a private full-size float32 film and one RCCL reduce(sum) to rank 0 closes
+the step. `--shard passes` (never chosen automatically) renders the reference's
+samples_per_pass = spp / N job instead, one pass per rank; the JSON line names the
+partition in `shard` and `config.parallelism`.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
 (dominant kernel, HIP-event timed inside the library on its own stream) and
 `cpu_baseline` (the scalar_rgb oracle on the host cores, bounded sample).
@@ -30,6 +33,19 @@ B_TRACE_ANY = 40.0           # shadow ray R 32, visibility W+R 8
 B_SPLAT = 320.0              # per finished sample: 4x4 texels x 5 channels x 4 B
 
 
+def kernel_src_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources (mitsuba2_amd/csrc/**, sorted by path): what a committed PMC
+    profile must have been taken on for its numbers to be quoted in the JSON line"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "mitsuba2_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".h", ".hip")):
+                h.update(os.path.relpath(os.path.join(d, f), base).encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,20 +62,23 @@ def main():
                     "of an N-GPU run executes; `value` then counts only that shard's samples")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "matball", "interior"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "matball", "interior", "glassblock"],
                     help="cornell = BASELINE configs[1] (diffuse Cornell box); matball = configs[2] (GGX rough conductor + "
-                         "dielectric balls, 41k triangles; quoted at 1024 spp)")
+                         "dielectric balls, 41k triangles; quoted at 1024 spp); interior = configs[3] class (0.9 M triangles, area "
+                         "light + environment map); glassblock = configs[4]'s geometry (Cornell box with a dielectric block; with "
+                         "--variant scalar_spectral)")
+    ap.add_argument("--tess", type=int, default=5, help="matball: icosphere subdivision level of the two balls (5 = 40 972 triangles, "
+                    "the config; 1..4 = 172 / 652 / 2 572 / 10 252: the triangle-count series of DESIGN.md)")
     ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
-                    help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs oracle/_ref/srgb.coeff or "
+                    help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs mitsuba2_amd/data/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
     ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = device LBVH")
     ap.add_argument("--shard", default="auto", choices=["auto", "tiles", "passes"],
-                    help="how N ranks split the frame. tiles (the north star's partition): spiral blocks dealt round-robin, every "
-                         "rank renders all spp of its pixels; the N-GPU film equals the 1-GPU film. passes: the reference's own "
-                         "samples_per_pass = spp / N run (integrator.cpp:75-86, spiral.cpp:41) with pass r rendered by rank r — every "
-                         "rank keeps all pixels; the film is the one scalar_rgb produces for that samples_per_pass. auto (default): "
-                         "tiles while a rank's tiles still hold >= 4 pixels per resident lane (262 144 lanes: 4 workgroups of 256 on 256 CUs), passes below "
-                         "that, where a pixel's serial sample stream leaves the machine short of work (DESIGN.md section 7)")
+                    help="how N ranks split the frame. tiles (the north star's partition; what auto picks, always): spiral blocks dealt "
+                         "round-robin, every rank renders all spp of its pixels; the N-GPU film equals the 1-GPU film. passes (explicit "
+                         "request only): the reference's own samples_per_pass = spp / N run (integrator.cpp:75-86, spiral.cpp:41) with "
+                         "pass r rendered by rank r — every rank keeps all pixels, but the film is the one scalar_rgb produces for that "
+                         "samples_per_pass: another set of random numbers than the 1-GPU job (DESIGN.md section 7)")
     ap.add_argument("--integrator", default="path", choices=["path", "direct"],
                     help="path = the headline (BASELINE metric); direct = src/integrators/direct.cpp on the same device loop")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 wavefront (HBM queues), 2 resident (registers + LDS)")
@@ -90,11 +109,13 @@ def main():
     if args.variant != "scalar_rgb":
         api.set_variant(args.variant)
         if not os.environ.get("MIWAVE_SRGB_COEFF"):
-            api.set_srgb_model(os.path.join(ROOT, "oracle", "_ref", "srgb.coeff"))   # a data file the reference's build makes
+            api.set_srgb_model(api.default_srgb_coeff())   # mitsuba2_amd/data/srgb.coeff: the table the reference's build generates
     if args.scene == "interior":     # BASELINE configs[3] class: ~0.9 M triangles, area light + environment map
         scene, sensor = scenes.interior_scene(W, H, SPP, device=-1)
+    elif args.scene == "glassblock":
+        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=True, glass_block=True, device=-1)
     else:
-        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), device=-1)
+        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), ball_level=args.tess, device=-1)
     dev = api.Device(local_rank)
     dev.upload(scene.desc(), bvh_quality=args.bvh_quality)   # scene + BVH resident before timing
     bvh = dev.counters()
@@ -156,13 +177,17 @@ def main():
             total_samples = float(agg["samples"])
         value = total_samples / elapsed / 1e6
         s_bar = agg["segments"] / max(agg["samples"], 1)
+        pk = dev.counters().path_kernel
+        path_kernel = "k_path_phased" if pk == 1 else "k_path_resident"
+        tc_name, ta_name = ("k_trace_stream", "k_sort_hits") if pk == 2 else ("k_trace<closest>", "k_trace<any>")
         # dominant kernel by summed HIP-event time (rank 0's shard)
         kernels = {
             "k_shade": (agg["ms_shade"], agg["n_shade"], B_SHADE * agg["segments"] + B_SPLAT * agg["samples"]),
-            "k_trace<closest>": (agg["ms_tc"], agg["n_tc"], B_TRACE_CLOSEST * agg["segments"]),
-            "k_trace<any>": (agg["ms_ta"], agg["n_ta"], B_TRACE_ANY * agg["shadow"]),
+            # plan 1 over a tree: one persistent stream kernel walks the E and the S rays (+ k_sort_hits: 4 B of key per segment)
+            tc_name: (agg["ms_tc"], agg["n_tc"], B_TRACE_CLOSEST * agg["segments"] + (B_TRACE_ANY * agg["shadow"] if pk == 2 else 0.0)),
+            ta_name: (agg["ms_ta"], agg["n_ta"], 8.0 * agg["segments"] if pk == 2 else B_TRACE_ANY * agg["shadow"]),
             # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
-            "k_path_resident": (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
+            path_kernel: (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
             # ordered film replay: reads the 24 B/sample log, writes the block tiles (k_film_groups after k_film_pack
             # for footprints <= 4x4, else k_film_blocks)
             ("k_film_groups" if agg["ms_fp"] > 0 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], 24.0 * agg["samples"]),
@@ -173,19 +198,27 @@ def main():
             ms, n, alg_bytes = kernels[name]
             achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             b_alg = 280.0 * s_bar + 320.0
-            # measured HBM bytes per launch of that kernel (rocprofv3 PMC passes, committed under profiles/)
-            traffic = None
+            # What the counters say about that kernel (rocprofv3 PMC passes cannot run inside this process): the committed
+            # profiles/traffic.json entry of this exact workload — used only while the kernel sources still hash to what the
+            # profile was taken on (kernel_src_sha16), otherwise the fields stay null rather than go stale.
+            traffic = None; measured = None
             try:
                 key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, dev.counters().plan,
                                                                  dev.counters().film_mode, cfg.samples_per_launch)
-                entry = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get(name)
-                if entry and world == 1:
+                table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                entry = table.get(key, {}).get(name)
+                if entry and world == 1 and table.get(key, {}).get("kernel_src_sha16") == kernel_src_sha16():
                     traffic = entry["hbm_bytes_per_launch"]
+                    measured = {"source": table[key].get("source"), "hbm_bytes_per_launch": traffic,
+                                # the real bound next to the decreed one: HBM bytes the kernel really moves / its time / 8 TB/s,
+                                # and the share of SIMD issue cycles that carried a VALU instruction
+                                "hbm_measured_frac": traffic / (ms / max(n, 1) * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                                "valu_issue_frac": entry.get("valu_issue_frac")}
             except Exception:
-                traffic = None
+                traffic = None; measured = None
             roofline = {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured": measured,
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
                 "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
                                   k_film_merge=round(agg["ms_fm"], 3), k_film_pack=round(agg["ms_fp"], 3), k_init=round(agg["ms_init"], 3)),
@@ -202,26 +235,35 @@ def main():
             nblocks = max(8, cores)                          # bounded sample: one centre-most spiral block per host thread, full spp
             one = make_integrator().render_job(sensor)
             _, _, st = O.render(scene.desc(), one, threads=cores, want_f64=False, only_blocks=np.arange(nblocks, dtype=np.uint32))
+            # the single-thread figure: the centre-most block at 1/8 of the spp (throughput is spp-independent)
+            few = make_integrator().render_job(scenes.cornell_sensor(W, H, max(SPP // 8, 1)))
+            _, _, st1 = O.render(scene.desc(), few, threads=1, want_f64=False, only_blocks=np.arange(1, dtype=np.uint32))
             cpu = {"value": st.samples / st.seconds / 1e6, "unit": "Msamples/sec", "cores": cores, "kind": "port",
                    "sample": "first %d spiral blocks (32x32 px) of the same %dx%d@%dspp job, %d samples, %.1f s" %
-                             (nblocks, W, H, SPP, st.samples, st.seconds)}
+                             (nblocks, W, H, SPP, st.samples, st.seconds),
+                   "single_thread": {"value": st1.samples / st1.seconds / 1e6, "unit": "Msamples/sec", "cores": 1,
+                                     "sample": "centre-most spiral block at %d spp, %d samples, %.1f s" % (max(SPP // 8, 1), st1.samples, st1.seconds)}}
         out = {
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "variant": args.variant, "integrator": args.integrator,
+            "variant": args.variant, "integrator": args.integrator, "shard": shard if world > 1 or args.shard_of > 1 else None,
             "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                     "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
+                                    "Cornell box with a bk7 dielectric block (34 triangles), %dx%d @ %d spp, path integrator max_depth=-1 "
+                                    "rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "glassblock" else
                                     "procedural interior (911 362 triangles: displaced wall grids + 200 icospheres, diffuse / GGX / "
                                     "Beckmann conductors / dielectric), area light + 1024x512 environment map, %dx%d @ %d spp, path "
                                     "integrator max_depth=-1 rr_depth=5" if args.scene == "interior" else
-                                    "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, 40972 "
-                                    "triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
+                                    "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, " + str(bvh.bvh_tris) +
+                                    " triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
                        "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 3),
                                "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
                        "parallelism": ("%s-shard x%d + RCCL film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world)) if world > 1 else "single GPU",
-                       "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage", 2: "resident: path state in registers, geometry in LDS"}[dev.counters().plan],
+                       "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage" + (" (persistent stream walk kernel with dynamic ray fetch)" if pk == 2 else ""), 2: "resident: path state in registers, geometry in LDS"
+                                if path_kernel == "k_path_resident" else "resident, wave-level phase machine: path + walk state in registers, "
+                                "per-lane LDS stack, nodes / triangles through L1 / L2"}[dev.counters().plan],
                        "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu,
         }

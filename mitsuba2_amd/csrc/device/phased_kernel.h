@@ -2,13 +2,17 @@
 // WAVE-LEVEL PHASE MACHINE. Part of the single translation unit csrc/miwave.hip (not a stand-alone header).
 //
 // Why: in k_path_resident a wavefront executes  trace(E) ; trace(S) ; path_step  once per depth-loop iteration, and
-// each of the three lasts as long as its slowest lane: max_lanes(E) + max_lanes(S) + shade, iteration after iteration
-// (walk statistics of the material-ball scene: node loop 40 - 45 % SIMT efficiency). Nothing ties the lanes of a
-// wavefront together — one lane = one pixel = one PCG32 stream — so here every lane carries its own little state
+// each of the three lasts as long as its slowest lane: max_lanes(E) + max_lanes(S) + shade, iteration after iteration.
+// Walk lengths are heavy-tailed (a ray that meets a tessellated ball takes ten times the node steps of one that meets
+// a wall), so the lanes of a wave mostly wait: measured SIMT efficiency of the node loop 12 % (material balls) and
+// 16 % (0.9 M-triangle interior), of the triangle loop 19 % / 23 % (-DMIW_WALK_STATS=1 builds, profiles/).
+// Nothing ties the lanes of a wavefront together — one lane = one pixel = one PCG32 stream — so here every lane
+// carries its own little state
 //   SHADE -> TRAV_E -> [TRAV_S] -> SHADE ...        (a traversal being a run of node steps and triangle tests)
-// and the WAVE repeatedly votes (three ballots) which body to run next for the lanes that are ready for it:
+// and the WAVE repeatedly votes (ballots + s_bcnt1) which body to run next for the lanes that are ready for it:
 //   node step      one BVH2 node: two slab tests, push / pop on the per-lane LDS stack
 //   triangle test  one Moeller-Trumbore test (+ the accept rule) of the leaf range a lane holds
+//   walk end       hand the hit record over / start the shadow walk (a handful of moves)
 //   shade          everything between two scene queries: add the resolved emitter-sampling term, path_step,
 //                  sample finish (log write), next camera ray, next pixel from the shared queue
 // A lane that finishes its E walk starts its S walk at once, a lane that finishes both waits for the next shade
@@ -17,16 +21,23 @@
 // Per-lane arithmetic is untouched — the same path_step / prim_intersect calls in the same per-lane order — so the
 // film is the same bit for bit (the sample log is indexed by lane and sample, not by time).
 //
-// MIW_PHASE_SPEC (template Spec): a lane holding an untested leaf range may keep descending (it is eligible for node
-// steps and triangle tests); it stalls only when it reaches a second leaf.
+// Code shape matters as much as the schedule: every body is one exec-masked region that writes the few state
+// registers it owns (node step: cur, sp, leaf range; triangle test: best hit, tmax, leaf range, cur, sp), and the
+// rare transitions (walk end, shade) live in their own bodies, so the hot bodies carry no phi copies of the ray or
+// path state. MIW_PHASE_SPEC (template Spec): a lane holding an untested leaf range may keep descending; it stalls
+// only when it reaches a second leaf.
 
 enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 #ifndef MIW_PHASE_SPEC
 #define MIW_PHASE_SPEC 0
 #endif
-#ifndef MIW_PHASE_NODE_BURST
-#define MIW_PHASE_NODE_BURST 4      /* node steps per vote while the node lanes stay a majority */
+#ifndef MIW_PHASE_END_WEIGHT
+#define MIW_PHASE_END_WEIGHT 4      /* the walk-end body is cheap: it runs once a quarter as many lanes wait for it as for the leading body */
+#endif
+#ifndef MIW_PHASE_SHADE_NUM
+#define MIW_PHASE_SHADE_NUM 1       /* shade runs once n_shade * NUM >= DEN * (lanes of the leading walk body) */
+#define MIW_PHASE_SHADE_DEN 1
 #endif
 
 template <int Mats, bool Analytic, bool Spec>
@@ -44,7 +55,7 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
     const PrimCtx ctx = prim_ctx(sc);
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
 
-    QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
+    QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
     uint32_t pixel = 0;
@@ -53,7 +64,7 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
     F4 hitE; hitE.x = MIW_INFINITY; hitE.y = hitE.z = 0.f; hitE.w = u2f(MIW_MISS);
     uint32_t mode = PH_SHADE;
 
-    // the walk a lane is in: current node (or pending leaf code, or DONE), stack depth, untested leaf range, best hit
+    // the walk a lane is in: current node (>= 0), pending leaf code (< 0) or DONE; stack depth; untested leaf range; best hit
     int32_t cur = MIW_WALK_DONE, sp = 0;
     uint32_t tri_i = 0, tri_end = 0;
     float tmax = 0.f, maxt_cur = 0.f;
@@ -67,84 +78,41 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
         cur = 0; sp = 0; tri_i = tri_end = 0;
         best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     };
-    auto pop = [&]() -> int32_t {
-        if (sp == 0) return MIW_WALK_DONE;
-        --sp; return stack[sp * MIW_BLOCK];
-    };
-    // a walk is over: E hands its hit record to the shade phase and starts S if a shadow ray is queued
-    auto end_walk = [&](bool found_any) {
-        if (mode == PH_TRAV_E) {
-            hitE.x = best.t; hitE.y = best.u; hitE.z = best.v; hitE.w = u2f(best.tri);
-            if (sh.has) { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }
-            else mode = PH_SHADE;
-        } else {
-            occluded = found_any;
-            mode = PH_SHADE;
-        }
-    };
-    // after a step: an empty leaf range is refilled from a pending leaf code, or the walk ends
-    auto settle = [&]() {
-        if (tri_i < tri_end) return;
-        if (cur >= 0) return;
-        if (cur != MIW_WALK_DONE) {
-            const uint32_t code = (uint32_t) ~cur;
-            tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
-            cur = pop();
-        } else end_walk(false);
-    };
+
+    // -DMIW_PHASE_STATS=1 (debug builds): per body, how often a wave ran it, with how many lanes, and the wall cycles it took
+#if defined(MIW_PHASE_STATS)
+    unsigned long long ps_runs[4] = { 0, 0, 0, 0 }, ps_lanes[4] = { 0, 0, 0, 0 }, ps_cycles[4] = { 0, 0, 0, 0 }, ps_t0 = __builtin_amdgcn_s_memtime();
+#define MIW_PS(k, lanes_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ps_runs[k]++; ps_lanes[k] += (unsigned) (lanes_); ps_cycles[k] += now_ - ps_t0; ps_t0 = now_; } while (0)
+#else
+#define MIW_PS(k, lanes_) do { } while (0)
+#endif
+    // lane predicates -> lane counts: ballot + s_bcnt1 (the builtin keeps the predicate in an SGPR pair)
+    auto count = [](bool p) -> int { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); };
 
     for (;;) {
+        // ---- the vote: which lanes are ready for which body ----
         const bool trav = (mode - 1u) < 2u;
-        const bool e_leaf = trav && tri_i < tri_end;
-        bool e_node = trav && cur >= 0 && (Spec || !e_leaf);
+        bool has_range = tri_i < tri_end;
+        bool e_leaf = trav && has_range;
+        bool e_node = trav && cur >= 0 && (Spec || !has_range);
+        const bool e_end = trav && !has_range && cur == MIW_WALK_DONE;
         const bool e_shade = mode == PH_SHADE;
-        const int n_node = __popcll(__ballot(e_node)), n_leaf = __popcll(__ballot(e_leaf)), n_shade = __popcll(__ballot(e_shade));
-        if ((n_node | n_leaf | n_shade) == 0) break;
+        int n_node = count(e_node), n_leaf = count(e_leaf);
+        const int n_end = count(e_end), n_shade = count(e_shade);
+        if ((n_node | n_leaf | n_end | n_shade) == 0) break;
+        const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
 
-        if (n_node >= n_leaf && n_node >= n_shade) {
-            // ---------------- node steps ----------------
-            const int floor_ = n_leaf > n_shade ? n_leaf : n_shade;
-            for (int burst = 0; burst < MIW_PHASE_NODE_BURST; ++burst) {
-                if (e_node) {
-#if MIW_LDS_TOP
-                    const BvhNode &n = (uint32_t) cur < ns ? lnodes[cur] : gnodes[cur];
-#else
-                    const BvhNode &n = gnodes[cur];
-#endif
-                    float tn0, tn1;
-                    const float wide = widen(tmax);
-                    const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
-                    const int32_t c0 = n.child0, c1 = n.child1;
-                    const bool second_first = tn1 < tn0;
-                    int32_t next = h0 ? c0 : c1;
-                    if (h0 && h1) {
-                        stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
-                        next = second_first ? c1 : c0;
-                    } else if (!(h0 || h1)) next = pop();
-                    cur = next;
-                    settle();
-                    e_node = ((mode - 1u) < 2u) && cur >= 0 && (Spec || tri_i >= tri_end);
-                }
-                if (burst + 1 < MIW_PHASE_NODE_BURST && __popcll(__ballot(e_node)) * 2 < n_node + floor_) break;
+        if (n_end * MIW_PHASE_END_WEIGHT >= lead && n_end > 0 && n_end * MIW_PHASE_END_WEIGHT >= n_shade) {
+            // ---------------- walk end: E hands its hit record to the shade phase and starts S if a shadow ray is queued ----------------
+            if (e_end) {
+                if (mode == PH_TRAV_E) {
+                    hitE.x = best.t; hitE.y = best.u; hitE.z = best.v; hitE.w = u2f(best.tri);
+                    if (sh.has) { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }
+                    else mode = PH_SHADE;
+                } else mode = PH_SHADE;                                  // S: `occluded` was set by the triangle test that hit
             }
-        } else if (n_leaf >= n_shade) {
-            // ---------------- one triangle test per lane ----------------
-            if (e_leaf) {
-                const Tri &tr = gtris[tri_i];
-                float t, u, v;
-                bool found = false;
-                if (prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v)) {
-                    if (mode == PH_TRAV_S) found = true;
-                    else if (t < best.t || (t == best.t && tr.prim < best.prim)) {
-                        best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
-                        tmax = t;
-                    }
-                }
-                ++tri_i;
-                if (found) { tri_i = tri_end = 0; cur = MIW_WALK_DONE; end_walk(true); }
-                else settle();
-            }
-        } else {
+            MIW_PS(2, n_end);
+        } else if (n_shade * MIW_PHASE_SHADE_NUM >= lead * MIW_PHASE_SHADE_DEN && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             if (e_shade) {
                 if (!(L.flags & LF_DONE)) {
@@ -180,9 +148,86 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
                 else if (!dead_pending) { mode = PH_TRAV_E; begin_walk(L.ray.d, L.ray.maxt); }
                 else { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }       // dead_pending implies a queued shadow ray
             }
+            MIW_PS(3, n_shade);
+        } else if (n_node >= n_leaf) {
+            // ---------------- node steps: an inner loop that owns cur, sp and the leaf range only; it runs while the node
+            // lanes remain the largest group (lanes that reach a leaf or the end of their walk drop out of it) ----------------
+            const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;
+            int n_gone = 0;
+            do {
+                MIW_PS(0, count(e_node));
+                if (e_node) {
+#if MIW_LDS_TOP
+                    const BvhNode &n = (uint32_t) cur < ns ? lnodes[cur] : gnodes[cur];
+#else
+                    const BvhNode &n = gnodes[cur];
+#endif
+                    float tn0, tn1;
+                    const float wide = widen(tmax);
+                    const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
+                    const int32_t c0 = n.child0, c1 = n.child1;
+                    const bool second_first = tn1 < tn0;
+                    int32_t next = h0 ? c0 : c1;
+                    if (h0 && h1) {
+                        stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
+                        next = second_first ? c1 : c0;
+                    } else if (!(h0 || h1)) {
+                        next = MIW_WALK_DONE;
+                        if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                    }
+                    // a leaf: it becomes the lane's triangle range (if it holds none), and the next stack entry its current node
+                    if (next < 0 && next != MIW_WALK_DONE && (!Spec || tri_i >= tri_end)) {
+                        const uint32_t code = (uint32_t) ~next;
+                        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
+                        next = MIW_WALK_DONE;
+                        if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                    }
+                    cur = next;
+                }
+                has_range = tri_i < tri_end;
+                e_node = trav && cur >= 0 && (Spec || !has_range);
+                const int now = count(e_node);
+                n_leaf = count(trav && has_range);
+                n_gone = n_node - now;                                   // lanes of this burst now at a leaf / at their walk's end
+                if (now < n_leaf || now < others + n_gone / 2 || now == 0) break;
+            } while (true);
+        } else {
+            // ---------------- triangle tests: same shape; owns the best hit, tmax, the leaf range, cur and sp ----------------
+            const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;
+            do {
+                MIW_PS(1, count(e_leaf));
+                if (e_leaf) {
+                    const Tri &tr = gtris[tri_i];
+                    float t, u, v;
+                    if (prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v)) {
+                        if (mode == PH_TRAV_S) {                         // any hit ends the shadow walk
+                            occluded = true; tri_end = 0; cur = MIW_WALK_DONE; sp = 0;
+                        } else if (t < best.t || (t == best.t && tr.prim < best.prim)) {
+                            best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
+                            tmax = t;
+                        }
+                    }
+                    ++tri_i;
+                    if (tri_i >= tri_end && cur < 0 && cur != MIW_WALK_DONE) {   // range drained and the stack handed over another leaf
+                        const uint32_t code = (uint32_t) ~cur;
+                        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
+                        cur = MIW_WALK_DONE;
+                        if (sp != 0) { --sp; cur = stack[sp * MIW_BLOCK]; }
+                    }
+                }
+                has_range = tri_i < tri_end;
+                e_leaf = trav && has_range;
+                const int now = count(e_leaf);
+                n_node = count(trav && cur >= 0 && (Spec || !has_range));
+                if (now <= n_node || now < others || now == 0) break;
+            } while (true);
         }
     }
 
+#if defined(MIW_PHASE_STATS)
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 4; ++k) { atomicAdd(&g_phase_stats[k], ps_runs[k]); atomicAdd(&g_phase_stats[4 + k], ps_lanes[k]); atomicAdd(&g_phase_stats[8 + k], ps_cycles[k]); }
+#endif
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
     if ((threadIdx.x & 63) == 0) {
         Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));

@@ -39,7 +39,7 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // refill), so no lane waits for the slowest pixel of its wavefront and the launch drains evenly. The grid is
 // sized to the machine; workgroups that start late find the queue empty and retire.
 struct QueueWork {
-    const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane;
+    const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
             // claim: ballot over the lanes asking, one atomic for all of them
@@ -58,7 +58,7 @@ struct QueueWork {
     }
     __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
     __device__ __forceinline__ void put(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) {
-        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp;
+        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp; sink.warn_negative = warn_negative;
         sink(0u, sample_idx, pos, aovs);
     }
 };
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
         trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
     };
     if (UseLog) {
-        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0;
+        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
         if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
         else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 #define MIW_WALK 1                /* 0: one loop, node or leaf per iteration; 1: while-while; 2: while-while + one postponed leaf per lane */
 #endif
 #ifndef MIW_LDS_TOP
-#define MIW_LDS_TOP 1             /* 1: the first 255 nodes of a tree that does not fit LDS are staged there (flat-address select per node visit) */
+#define MIW_LDS_TOP 0             /* 1: the first 255 nodes of a tree that does not fit LDS are staged there — a flat-address select per node visit; measured 4 - 12 % slower than plain global loads (the top of the tree lives in L1 / L2 anyway) */
 #endif
 #ifndef MIW_TREE_WAVES
 #define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     uint32_t flags = LF_DONE;
     if (mine) {
         if (UseLog) {
-            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp;
+            LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp; sink.warn_negative = P.film.warn_negative;
             flags = lane_shade(P, sc, Q, lane, &local, sink);
         } else {
             FilmAdd add; add.accum = accum;

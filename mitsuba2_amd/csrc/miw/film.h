@@ -27,6 +27,7 @@ struct FilmRec {
     float radius;                       // rfilter radius
     float scale_factor;                 // MTS_FILTER_RESOLUTION / radius (rfilter.cpp:18)
     float lut[MIW_FILTER_RESOLUTION + 1];
+    uint32_t warn_negative;             // ImageBlock::m_warn_negative = !has_aovs (integrator.cpp:110-113): 0 under the moment integrator
 };
 
 // rfilter.h:62-65
@@ -41,10 +42,12 @@ MIW_HD int floor2int(float x) { return (int) __builtin_floorf(x); }
 
 // The sample-validity test of imageblock.cpp:85-109 (invalid samples are
 // dropped, not fatal).
-MIW_HD bool sample_is_valid(const float *value) {
+// `warn_negative` = ImageBlock::m_warn_negative: SamplingIntegrator::render builds its blocks with
+// warn_negative = !has_aovs (integrator.cpp:110-113), so under the moment integrator only the isfinite test applies.
+MIW_HD bool sample_is_valid(const float *value, bool warn_negative = true) {
     bool ok = true;
     for (int k = 0; k < MIW_FILM_CHANNELS; ++k)
-        ok = ok && (value[k] >= -1e-5f) && isfinite_(value[k]);
+        ok = ok && (!warn_negative || value[k] >= -1e-5f) && isfinite_(value[k]);
     return ok;
 }
 
@@ -111,7 +114,7 @@ MIW_HD void block_of_pixel(const FilmRec &f, int px, int py, int &bx, int &by, i
 // `px,py` = the pixel the sample belongs to.
 template <typename AddXY>
 MIW_HD void film_splat_xy(const FilmRec &f, int px, int py, V2 pos_, const float *value, AddXY add_xy) {
-    if (!sample_is_valid(value)) return;
+    if (!sample_is_valid(value, f.warn_negative != 0)) return;
     int bx, by, bw, bh;
     block_of_pixel(f, px, py, bx, by, bw, bh);
     const int size_x = bw + 2 * f.border;

@@ -136,8 +136,8 @@ MIW_HD void lane_finish_sample(const RenderParams &P, uint32_t pixel, LaneRegs &
     float aovs[5] = { xyz.x, xyz.y, xyz.z, (L.flags & LF_VALID_RAY) ? 1.f : 0.f, 1.f };
     if (P.moment_pass) {                                 // moment.cpp:83-88: nested.XYZ and their squares ride along
         const float sq[3] = { sqr(xyz.x), sqr(xyz.y), sqr(xyz.z) };
-        bool ok = true;                                  // ImageBlock::put tests all channels of the sample together
-        for (int k = 0; k < 3; ++k) ok = ok && aovs[k] >= -1e-5f && isfinite_(aovs[k]) && isfinite_(sq[k]);
+        bool ok = true;                                  // ImageBlock::put tests all channels of the sample together; the block of an
+        for (int k = 0; k < 3; ++k) ok = ok && isfinite_(aovs[k]) && isfinite_(sq[k]);   // integrator with AOVs has warn_negative = false (integrator.cpp:113)
         if (P.moment_pass == 2u) { aovs[0] = sq[0]; aovs[1] = sq[1]; aovs[2] = sq[2]; }
         if (!ok) aovs[0] = __builtin_nanf("");
     }
@@ -163,9 +163,10 @@ template <typename AddXY> struct SplatXYSink {
 // ordered gather (miw/film_gather.h), in the reference's float32 accumulation order.
 struct LogSink {
     F2 *log_pos; F4 *log_val; uint32_t lane, spp;        // [lane][sample]: one contiguous run per pixel
+    uint32_t warn_negative;                              // FilmRec::warn_negative
     MIW_HD void operator()(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) const {
         size_t i = (size_t) lane * spp + sample_idx;
-        F2 p; p.x = sample_is_valid(aovs) ? pos.x : __builtin_nanf(""); p.y = pos.y;
+        F2 p; p.x = sample_is_valid(aovs, warn_negative != 0) ? pos.x : __builtin_nanf(""); p.y = pos.y;
         F4 v; v.x = aovs[0]; v.y = aovs[1]; v.z = aovs[2]; v.w = aovs[3];
         log_pos[i] = p; log_val[i] = v;
     }

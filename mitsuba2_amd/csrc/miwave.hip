@@ -4,6 +4,7 @@
 //   device/wavefront_kernels.h   plan 1: k_init_lanes, k_trace<closest|any>, k_shade over SoA queues in HBM
 //   device/resident_kernel.h     plan 2: k_init_pixels, the pixel queue, k_path_resident (path / direct)
 //   device/phased_kernel.h       plan 2 over a tree: k_path_phased (wave-level phase machine: node steps / triangle tests / shade)
+//   device/stream_trace.h        plan 1 over a tree: k_trace_stream (persistent walk kernel, dynamic ray fetch), k_sort_hits
 //   device/film_kernels.h        k_film_resolve, k_film_blocks, k_film_pack, k_film_groups, k_film_merge
 //   device/eval_kernels.h        k_trace_soa (mi_trace), k_eval (mi_eval)
 //   lbvh_device.h                device LBVH builder
@@ -24,6 +25,9 @@
 // into g_sections and printed by mi_render when MIW_DEBUG is set. Not compiled into the product library.
 #if defined(MIW_SECTION_PROFILE)
 __device__ unsigned long long g_sections[16];
+#endif
+#if defined(MIW_PHASE_STATS)
+__device__ unsigned long long g_phase_stats[12];   // k_path_phased: per body (node, triangle, walk end, shade) runs, lanes, wall cycles
 #endif
 #if defined(MIW_WALK_STATS)
 __device__ unsigned long long g_walk_stats[8];     // per ray kind (closest 0.., any 4..): node lane-steps, triangle lane-steps, rays
@@ -72,6 +76,7 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #include "device/wavefront_kernels.h"
 #include "device/resident_kernel.h"
 #include "device/phased_kernel.h"
+#include "device/stream_trace.h"
 #include "device/film_kernels.h"
 #include "device/eval_kernels.h"
 
@@ -696,6 +701,7 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
     P.film.radius = cfg->filter_radius;
     P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
+    P.film.warn_negative = cfg->moment_pass ? 0u : 1u;           // integrator.cpp:113: !has_aovs
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
     if (cfg->integrator == MI_INTEGRATOR_DIRECT) {               // direct.cpp:82-103
         const uint32_t ne = cfg->emitter_samples, nb = cfg->bsdf_samples;
@@ -806,7 +812,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0;
 
     // event pool for per-launch timing
     struct Stamp { int cls; size_t e0, e1; };
@@ -910,6 +916,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // the lock-step kernel (A/B runs)
                 static const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
                 const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack;
+                K.path_kernel = phased ? 1u : 0u;
 #define MIW_PHASED_LAUNCH(M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0>), pgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p))
                 if (phased) {
                     if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true);
@@ -965,6 +972,22 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             n = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_verify_n), &n, sizeof n);
         }
 #endif
+#if defined(MIW_PHASE_STATS)
+        if (getenv("MIW_DEBUG")) {
+            unsigned long long ps[12];
+            if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
+                static const char *names[4] = { "node step", "triangle test", "walk end", "shade" };
+                unsigned long long tot = 0;
+                for (int k = 0; k < 4; ++k) tot += ps[8 + k];
+                for (int k = 0; k < 4; ++k)
+                    fprintf(stderr, "[miwave] phase %-13s runs/segment %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
+                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[4 + k] / std::max<double>((double) ps[k], 1),
+                            (double) ps[8 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[8 + k] / std::max<double>((double) tot, 1));
+                memset(ps, 0, sizeof ps);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), ps, sizeof ps);
+            }
+        }
+#endif
 #if defined(MIW_WALK_STATS)
         if (getenv("MIW_DEBUG")) {
             unsigned long long st[8]; float stf[8];
@@ -1013,6 +1036,16 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         MIW_TIMED(3, hipLaunchKernelGGL(k_init_lanes, grid, block, 0, s, P, Q, c->q_pixel.p, A, WL[0]));
         HIP_TRY(c, hipGetLastError());
 
+        // trees walked with the LDS stack: one persistent stream kernel serves the E and the S rays of an iteration
+        // (device/stream_trace.h); MIW_STREAM=0 keeps the slice-per-workgroup kernels (A/B runs)
+        static const bool stream_on = !(getenv("MIW_STREAM") && atoi(getenv("MIW_STREAM")) == 0);
+        const bool stream = stream_on && c->lds_cfg.stack && !c->lds_cfg.brute && c->lds_cfg.nodes_staged == 0;
+        K.path_kernel = stream ? 2u : 0u;
+        if (stream) {
+            HIP_TRY(c, c->d_next_pixel.resize(1));
+            HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
+        }
+        const dim3 sgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * MIW_STREAM_WAVES));
         const int check_every = 16;
         bool first = true;
         unsigned long long active_prev = 0;
@@ -1020,12 +1053,18 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         for (;;) {
             for (int it = 0; it < check_every; ++it, parity ^= 1u) {
                 const WorkLists &cur = WL[parity], &nxt = WL[parity ^ 1u];
-                if (!first) {
-                    MIW_TIMED(1, hipLaunchKernelGGL(k_trace<true>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
-                    K.n_trace_any++;
+                if (stream) {
+                    MIW_TIMED(0, hipLaunchKernelGGL(k_trace_stream, sgrid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur, (uint32_t) n_wg, c->d_next_pixel.p));
+                    MIW_TIMED(1, hipLaunchKernelGGL(k_sort_hits, grid, block, 0, s, c->view, Q, cur, c->d_next_pixel.p));
+                    K.n_trace_closest++; K.n_trace_any++;
+                } else {
+                    if (!first) {
+                        MIW_TIMED(1, hipLaunchKernelGGL(k_trace<true>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
+                        K.n_trace_any++;
+                    }
+                    MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
+                    K.n_trace_closest++;
                 }
-                MIW_TIMED(0, hipLaunchKernelGGL(k_trace<false>, grid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur));
-                K.n_trace_closest++;
                 const uint32_t count_active = it == check_every - 1 ? 1u : 0u;
                 if (film_mode == 1)
                     MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, count_active, cur, nxt));

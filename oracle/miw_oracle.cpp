@@ -460,7 +460,8 @@ struct ImageBlock {
 void block_put(ImageBlock &b, const FilmRec &f, V2 pos_, const float *value) {
     const int C = 5;
     bool is_valid = true;
-    for (int k = 0; k < C; ++k) is_valid = is_valid && value[k] >= -1e-5f;
+    if (f.warn_negative)                                       // imageblock.cpp:88-91 (m_warn_negative)
+        for (int k = 0; k < C; ++k) is_valid = is_valid && value[k] >= -1e-5f;
     for (int k = 0; k < C; ++k) is_valid = is_valid && std::isfinite(value[k]);
     if (!is_valid) return;
     float filter_radius = f.radius;
@@ -565,6 +566,7 @@ void fill_records(const mi_render_cfg *cfg, SensorRec &sensor, FilmRec &film) {
     film.block_size = cfg->block_size; film.border = cfg->filter_border; film.radius = cfg->filter_radius;
     film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     std::memcpy(film.lut, cfg->filter_lut, sizeof film.lut);
+    film.warn_negative = cfg->moment_pass ? 0u : 1u;          // integrator.cpp:113: ImageBlock(..., warn_negative = !has_aovs)
 }
 
 } // namespace
@@ -674,7 +676,7 @@ int orc_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, float *film
                         float full[11] = { xyz.x, xyz.y, xyz.z, aovs[3], 1.f, xyz.x, xyz.y, xyz.z, 0.f, 0.f, 0.f };
                         for (int k = 0; k < 3; ++k) full[8 + k] = full[5 + k] * full[5 + k];      // :87 sqr()
                         bool all_valid = true;
-                        for (int k = 0; k < 11; ++k) all_valid = all_valid && std::isfinite(full[k]) && full[k] >= -1e-5f;   // imageblock.cpp:85-96
+                        for (int k = 0; k < 11; ++k) all_valid = all_valid && std::isfinite(full[k]);   // imageblock.cpp:93-96; warn_negative is off: the block has AOVs (integrator.cpp:113)
                         if (cfg->moment_pass == MI_MOMENT_SQUARES) for (int k = 0; k < 3; ++k) aovs[k] = full[8 + k];
                         if (!all_valid) { ++samples; continue; }                    // put() warns and drops it; :287 still advances
                     }

@@ -193,6 +193,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     P.film.block_size = cfg->block_size; P.film.border = cfg->filter_border; P.film.radius = cfg->filter_radius;
     P.film.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
     std::memcpy(P.film.lut, cfg->filter_lut, sizeof P.film.lut);
+    P.film.warn_negative = cfg->moment_pass ? 0u : 1u;
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
     P.moment_pass = (uint32_t) cfg->moment_pass;
     const bool direct = cfg->integrator == MI_INTEGRATOR_DIRECT;
@@ -266,7 +267,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             for (uint32_t lane = 0; lane < n_lanes; ++lane) {
                 if (st[lane].z & LF_DONE) continue;
                 SplatSink<decltype(add)> splat{ &P.film, add };
-                LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp };
+                LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
                 bool do_log = film32 != nullptr;
                 auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                     splat(pixel, sample_idx, pos, aovs);
@@ -298,7 +299,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         uint64_t active = 0;
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
-            LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp };
+            LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);

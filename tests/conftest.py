@@ -40,14 +40,14 @@ def has_gpu():
         return False
 
 
-SRGB_COEFF = os.path.join(ROOT, "oracle", "_ref", "srgb.coeff")
+SRGB_COEFF = os.path.join(ROOT, "mitsuba2_amd", "data", "srgb.coeff")
 
 
 @pytest.fixture()
 def spectral(native):
     """Switches the host layer to the scalar_spectral variant for one test (mitsuba.set_variant)."""
     if not os.path.exists(SRGB_COEFF):
-        pytest.skip("oracle/_ref/srgb.coeff missing (built from the reference's ext/rgb2spec by mitsuba2_amd.build)")
+        pytest.skip("mitsuba2_amd/data/srgb.coeff missing (generated with the reference's ext/rgb2spec by mitsuba2_amd.build)")
     native.set_variant("scalar_spectral")
     native.set_srgb_model(SRGB_COEFF)
     yield native

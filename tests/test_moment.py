@@ -74,6 +74,28 @@ def test_overflowing_square_drops_the_whole_sample(native, oracle):
     assert np.array_equal(e32, squares)
 
 
+def test_negative_values_are_kept_under_the_moment_integrator(native, oracle):
+    """SamplingIntegrator::render builds its ImageBlocks with warn_negative = !has_aovs (integrator.cpp:110-113): the plain
+    path / direct integrators drop a sample with a channel below -1e-5 (imageblock.cpp:88-91), the moment integrator —
+    whose block carries AOVs — only drops non-finite ones. A light of negative radiance makes the difference visible."""
+    from test_textures import textured_quad, quad_sensor
+    meshes = textured_quad(native, (0.5, 0.5, 0.5))
+    meshes[1] = native.Mesh("light", meshes[1].vertices, meshes[1].faces, bsdf=native.BSDF("diffuse", reflectance=(0, 0, 0)),
+                            emitter=native.AreaLight(radiance=(-2.0, -2.0, -2.0)))
+    scene = native.Scene(meshes).build(-1)
+    sensor = quad_sensor(native, 32, 24, 2)
+    integ = native.DirectIntegrator(emitter_samples=1, bsdf_samples=0, hide_emitters=False)
+    plain, _, pst = oracle.render(scene.desc(), integ.render_job(sensor), threads=2)
+    values, squares = _passes(native, oracle, scene, sensor, integ)
+    assert values[..., 4].sum() > plain[..., 4].sum() > 0              # the plain block rejected the negative samples
+    assert values[..., 1].min() < -0.1 and squares[..., 1].max() > 0.005 and np.array_equal(values[..., 4], squares[..., 4])
+    for mp, want in ((1, values), (2, squares)):                       # the device stages agree (log sink and splat sink)
+        job = native.MomentIntegrator(integ).render_job(sensor, moment_pass=mp)
+        job.cfg.plan = 2
+        e64, e32, _ = oracle.emu_render(scene.desc(), job)
+        assert np.array_equal(e32, want)
+
+
 def _z_test(a_val, a_sq, b_val, b_sq, spp):
     """test_renders.py:63-132 for two renders: per-pixel means and variances from the moment channels, Welch-style
     z statistic on luminance, Sidak-corrected significance 0.01"""

@@ -69,7 +69,7 @@ def test_srgb_d65_is_d65_times_srgb(oracle_spectral):
 # ---- host layer: srgb_model_fetch vs the reference's ext/rgb2spec --------------------------------------------------
 def test_srgb_model_fetch_matches_reference_rgb2spec(spectral):
     """The host layer's table fetch (srgb.cpp:14-42 + rgb2spec_fetch) against the reference's own rgb2spec.c, compiled
-    from where it lies into oracle/_ref/librgb2spec_ref.so; both read oracle/_ref/srgb.coeff = `rgb2spec_opt 64`."""
+    from where it lies into oracle/_ref/librgb2spec_ref.so; both read mitsuba2_amd/data/srgb.coeff = `rgb2spec_opt 64`."""
     from conftest import SRGB_COEFF
     ref_path = os.path.join(ROOT, "oracle", "_ref", "librgb2spec_ref.so")
     if not os.path.exists(ref_path):

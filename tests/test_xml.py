@@ -175,3 +175,92 @@ def test_xml_include_and_alias(native, oracle, tmp_path):
     (tmp_path / "loop.xml").write_text('<scene version="2.0.0"><include filename="loop.xml"/></scene>')
     with pytest.raises(RuntimeError, match="recursion limit"):
         native.load_file(str(tmp_path / "loop.xml"))
+
+
+SHOWROOM_XML = """<scene version="2.0.0">
+    <default name="spp" value="8"/>
+    <integrator type="path"><integer name="rr_depth" value="3"/></integrator>
+    <sensor type="perspective">
+        <float name="fov" value="42"/>
+        <transform name="to_world"><lookat origin="0, 1.6, 4.2" target="0, 0.6, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sample_count" value="$spp"/><integer name="seed" value="3"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="96"/><integer name="height" value="64"/></film>
+    </sensor>
+    <bsdf type="diffuse" id="grey"><rgb name="reflectance" value="0.6, 0.6, 0.55"/></bsdf>
+    <shape type="rectangle">                                             <!-- floor: analytic primitive -->
+        <transform name="to_world"><scale value="6"/><rotate x="1" angle="-90"/></transform>
+        <ref id="grey"/>
+    </shape>
+    <shape type="obj">                                                   <!-- no vn records: normals generated (obj.cpp:339-341) -->
+        <string name="filename" value="blob.obj"/>
+        <transform name="to_world"><translate x="-0.9" y="0.7" z="0"/></transform>
+        <bsdf type="roughconductor"><string name="distribution" value="ggx"/><float name="alpha" value="0.15"/>
+            <rgb name="eta" value="0.2, 0.92, 1.1"/><rgb name="k" value="3.9, 2.45, 2.14"/></bsdf>
+    </shape>
+    <shape type="ply">                                                   <!-- binary PLY with its own vertex normals -->
+        <string name="filename" value="ball.ply"/>
+        <bsdf type="dielectric"><float name="int_ior" value="1.5046"/><float name="ext_ior" value="1.000277"/></bsdf>
+    </shape>
+    <shape type="obj">
+        <string name="filename" value="faceted.obj"/>
+        <boolean name="face_normals" value="true"/>                       <!-- vn records dropped again -->
+        <ref id="grey"/>
+    </shape>
+    <shape type="obj">
+        <string name="filename" value="lamp.obj"/>
+        <emitter type="area"><rgb name="radiance" value="30, 28, 24"/></emitter>
+    </shape>
+</scene>
+"""
+
+
+@pytest.mark.gpu
+def test_xml_scene_with_obj_and_ply_files_renders_on_the_device(native, oracle, tmp_path):
+    """(f)1 + (f)2 end to end on the GPU: load_file() of an XML scene whose shapes come from an OBJ without normals (the
+    loader generates them, obj.cpp:339-341), a binary PLY with normals, an OBJ loaded with face_normals and an OBJ area
+    light, next to an analytic rectangle; built on the device, rendered, and the film is the oracle's bit for bit —
+    through Scene::build / PathIntegrator::render of the host classes and through the raw C ABI."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    from test_loaders import _write_ply
+    from mitsuba2_amd import scenes
+    v, f, n = scenes.icosphere((0.0, 0.0, 0.0), 0.7, 2)
+    with open(tmp_path / "blob.obj", "w") as fh:                         # positions only, 1-based faces
+        for a in v:
+            fh.write("v %r %r %r\n" % tuple(float(x) for x in a))
+        for t in f:
+            fh.write("f %d %d %d\n" % tuple(int(x) + 1 for x in t))
+    v2, f2, n2 = scenes.icosphere((0.9, 0.55, 0.4), 0.55, 2)
+    _write_ply(tmp_path / "ball.ply", v2, f2, "binary_little_endian", normals=n2)
+    v3, f3, n3 = scenes.icosphere((0.0, 0.35, -1.3), 0.35, 1)
+    with open(tmp_path / "faceted.obj", "w") as fh:
+        for a in v3:
+            fh.write("v %r %r %r\n" % tuple(float(x) for x in a))
+        for a in n3:
+            fh.write("vn %r %r %r\n" % tuple(float(x) for x in a))
+        for t in f3:
+            fh.write("f %d//%d %d//%d %d//%d\n" % tuple(int(x) + 1 for x in np.repeat(t, 2)))
+    (tmp_path / "lamp.obj").write_text("v -1 3 -1\nv 1 3 -1\nv 1 3 1\nv -1 3 1\nf 1 2 3 4\n")     # a quad facing down
+    (tmp_path / "showroom.xml").write_text(SHOWROOM_XML)
+
+    scene, sensor, integ = native.load_file(tmp_path / "showroom.xml")
+    scene.build(0)                                                       # upload + SAH BVH on the device
+    d = scene.desc().contents
+    assert d.shape_count == 5 and d.rectangle_count == 1 and d.emitter_count == 1 and d.face_count == 1 + 320 + 320 + 80 + 2
+    flags = [d.shapes[i].flags for i in range(5)]
+    assert flags[1] & 1 and flags[2] & 1 and not flags[3] & 1            # generated normals, file normals, face normals
+    job = integ.render_job(sensor)
+    o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
+    assert integ.render(scene, sensor) is True                           # SamplingIntegrator::render of the host layer
+    film = sensor.film.data((64, 96, 5))
+    c = integ.counters()
+    assert c.samples == ost.samples == 96 * 64 * 8 and c.segments == ost.segments and c.bvh_tris == 724
+    assert np.array_equal(film, o32)
+    dev = native.Device(0)
+    for quality in (1, 0):                                               # and through the raw C ABI, SAH and device LBVH
+        dev.upload(scene.desc(), bvh_quality=quality)
+        g, st = dev.render(job)
+        assert st == 0 and np.array_equal(g, o32)
+    dev.close()
+    # the image shows what the file says: lit floor, a lamp overhead, non-trivial paths through the glass ball
+    assert o32[..., 1].max() > 0 and ost.segments / ost.samples > 1.2
