@@ -30,7 +30,7 @@
 enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 #ifndef MIW_PHASE_SPEC
-#define MIW_PHASE_SPEC 0
+#define MIW_PHASE_SPEC 1
 #endif
 #ifndef MIW_PHASE_END_WEIGHT
 #define MIW_PHASE_END_WEIGHT 4      /* the walk-end body is cheap: it runs once a quarter as many lanes wait for it as for the leading body */
@@ -40,8 +40,10 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 #define MIW_PHASE_SHADE_DEN 1
 #endif
 
-template <int Mats, bool Analytic, bool Spec>
-__global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
+// Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs, no spills) or 4 (128 VGPRs, a few spills in the shade body):
+// big trees, whose node fetches miss L2, gain more from the fourth wave's latency hiding than they lose to the spills.
+template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES>
+__global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
@@ -61,7 +63,6 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
     uint32_t pixel = 0;
     bool have = false, dead_pending = false, occluded = false;
     ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
-    F4 hitE; hitE.x = MIW_INFINITY; hitE.y = hitE.z = 0.f; hitE.w = u2f(MIW_MISS);
     uint32_t mode = PH_SHADE;
 
     // the walk a lane is in: current node (>= 0), pending leaf code (< 0) or DONE; stack depth; untested leaf range; best hit
@@ -95,24 +96,19 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
         bool has_range = tri_i < tri_end;
         bool e_leaf = trav && has_range;
         bool e_node = trav && cur >= 0 && (Spec || !has_range);
-        const bool e_end = trav && !has_range && cur == MIW_WALK_DONE;
-        const bool e_shade = mode == PH_SHADE;
-        int n_node = count(e_node), n_leaf = count(e_leaf);
-        const int n_end = count(e_end), n_shade = count(e_shade);
-        if ((n_node | n_leaf | n_end | n_shade) == 0) break;
+        // a walk that is over: an E walk with a shadow ray queued turns into the S walk at the next entry to the node body
+        // (`e_turn`; the hit record stays in `best`, which an S walk never writes), every other one is ready to shade
+        const bool walk_over = trav && !has_range && cur == MIW_WALK_DONE;
+        const bool e_turn = walk_over && mode == PH_TRAV_E && sh.has;
+        const bool e_shade = mode == PH_SHADE || (walk_over && !e_turn);
+        const int n_turn = count(e_turn);
+        int n_node = count(e_node) + n_turn, n_leaf = count(e_leaf);
+        const int n_shade = count(e_shade);
+        const int n_end = 0;
+        if ((n_node | n_leaf | n_shade) == 0) break;
         const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
 
-        if (n_end * MIW_PHASE_END_WEIGHT >= lead && n_end > 0 && n_end * MIW_PHASE_END_WEIGHT >= n_shade) {
-            // ---------------- walk end: E hands its hit record to the shade phase and starts S if a shadow ray is queued ----------------
-            if (e_end) {
-                if (mode == PH_TRAV_E) {
-                    hitE.x = best.t; hitE.y = best.u; hitE.z = best.v; hitE.w = u2f(best.tri);
-                    if (sh.has) { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }
-                    else mode = PH_SHADE;
-                } else mode = PH_SHADE;                                  // S: `occluded` was set by the triangle test that hit
-            }
-            MIW_PS(2, n_end);
-        } else if (n_shade * MIW_PHASE_SHADE_NUM >= lead * MIW_PHASE_SHADE_DEN && n_shade > 0) {
+        if (n_shade * MIW_PHASE_SHADE_NUM >= lead * MIW_PHASE_SHADE_DEN && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             if (e_shade) {
                 if (!(L.flags & LF_DONE)) {
@@ -120,6 +116,7 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
                     if (sh.has && !occluded) L.res = L.res + sh.c;          // path.cpp:171 of the previous vertex
                     sh.has = false; occluded = false;
                     int rstep = STEP_FINISHED;
+                    F4 hitE; hitE.x = best.t; hitE.y = best.u; hitE.z = best.v; hitE.w = u2f(best.tri);   // of the E walk (unused when dead_pending)
                     if (!dead_pending) rstep = path_step<Mats, Analytic>(P, sc, L, hitE, [o]() { return o; }, sh, &local);
                     if (!dead_pending && rstep == STEP_DEAD_PENDING) dead_pending = true;   // one more pass for its shadow ray
                     else if (dead_pending || rstep == STEP_FINISHED) {
@@ -154,6 +151,16 @@ __global__ __launch_bounds__(MIW_BLOCK, MIW_TREE_WAVES) void k_path_phased(Rende
             // lanes remain the largest group (lanes that reach a leaf or the end of their walk drop out of it) ----------------
             const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;
             int n_gone = 0;
+            if (n_turn > 0) {                                            // E walks that ended with a shadow ray queued: start the S walk
+                if (e_turn) {
+                    mode = PH_TRAV_S;
+                    r = fast_ray(L.ray.o, sh.d, L.ray.mint);
+                    d_cur = sh.d; maxt_cur = sh.maxt; tmax = sh.maxt;
+                    cur = 0; sp = 0; tri_i = tri_end = 0;
+                    e_node = true;
+                }
+                MIW_PS(2, n_turn);
+            }
             do {
                 MIW_PS(0, count(e_node));
                 if (e_node) {

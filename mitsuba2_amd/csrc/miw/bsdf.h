@@ -620,8 +620,15 @@ MIW_HD Spec roughplastic_sample(const BsdfRec &b, V3 wi, float sample1, V2 sampl
 
 // Argument order matches BSDF::sample(ctx, si, sample1, sample2) (bsdf.h:328-340).
 // `Ext` = false compiles the plugins out that only scenes marked "extended" by the uploader contain (roughplastic).
-template <bool Ext = true>
+// `Trio` = true: the caller knows every record to be diffuse, dielectric or roughconductor (BASELINE configs 3 and 4):
+// the other plugins are compiled out — a kernel's code size is what its waves stream through the instruction cache.
+template <bool Ext = true, bool Trio = false>
 MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
+    if (Trio) {
+        if (b.type == BSDF_TYPE_DIFFUSE) return diffuse_sample(b, wi, sample2, bs, tc);
+        if (b.type == BSDF_TYPE_DIELECTRIC) return dielectric_sample(b, wi, sample1, bs, tc);
+        return roughconductor_sample(b, wi, sample2, bs, tc);
+    }
     if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_sample(b, wi, sample1, sample2, bs, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_sample(b, wi, sample2, bs, tc);
@@ -632,8 +639,13 @@ MIW_HD Spec bsdf_sample(const BsdfRec &b, V3 wi, float sample1, V2 sample2, BSDF
         default:                   return roughconductor_sample(b, wi, sample2, bs, tc);
     }
 }
-template <bool Ext = true>
+template <bool Ext = true, bool Trio = false>
 MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    if (Trio) {
+        if (b.type == BSDF_TYPE_DIFFUSE) return diffuse_eval(b, wi, wo, tc);
+        if (b.type == BSDF_TYPE_DIELECTRIC) return spec(0.f);
+        return roughconductor_eval(b, wi, wo, tc);
+    }
     if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_eval(b, wi, wo, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_eval(b, wi, wo, tc);
@@ -644,8 +656,13 @@ MIW_HD Spec bsdf_eval(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
         default:                   return roughconductor_eval(b, wi, wo, tc);
     }
 }
-template <bool Ext = true>
+template <bool Ext = true, bool Trio = false>
 MIW_HD float bsdf_pdf(const BsdfRec &b, V3 wi, V3 wo, const TexCtx &tc) {
+    if (Trio) {
+        if (b.type == BSDF_TYPE_DIFFUSE) return diffuse_pdf(wi, wo);
+        if (b.type == BSDF_TYPE_DIELECTRIC) return 0.f;
+        return roughconductor_pdf(b, wi, wo);
+    }
     if (Ext && b.type == BSDF_TYPE_ROUGHPLASTIC) return roughplastic_pdf(b, wi, wo, tc);
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return diffuse_pdf(wi, wo);
@@ -673,22 +690,23 @@ MIW_HD BsdfSide bsdf_side(const BsdfRec *table, uint32_t index, V3 wi) {
     return s;
 }
 MIW_HD V3 bsdf_mirror(V3 w) { return v3(w.x, w.y, w.z * -1.f); }      // `wi.z() *= -1.f`
-template <bool Ext = true>
+template <bool Ext = true, bool Trio = false>
 MIW_HD Spec bsdf_side_sample(const BsdfSide &s, V3 wi, float sample1, V2 sample2, BSDFSample &bs, const TexCtx &tc) {
     if (s.none) { bs.wo = v3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.sampled_type = 0; return spec(0.f); }
-    Spec v = bsdf_sample<Ext>(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, tc);
+    Spec v = bsdf_sample<Ext, Trio>(*s.b, s.flip ? bsdf_mirror(wi) : wi, sample1, sample2, bs, tc);
     if (s.flip) bs.wo.z *= -1.f;                                     // :121
     return v;
 }
-template <bool Ext = true>
+// (one inlined copy of the plugin code each: the mirrored directions are selected first, not the results)
+template <bool Ext = true, bool Trio = false>
 MIW_HD Spec bsdf_side_eval(const BsdfSide &s, V3 wi, V3 wo, const TexCtx &tc) {
     if (s.none) return spec(0.f);
-    return s.flip ? bsdf_eval<Ext>(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_eval<Ext>(*s.b, wi, wo, tc);
+    return bsdf_eval<Ext, Trio>(*s.b, s.flip ? bsdf_mirror(wi) : wi, s.flip ? bsdf_mirror(wo) : wo, tc);
 }
-template <bool Ext = true>
+template <bool Ext = true, bool Trio = false>
 MIW_HD float bsdf_side_pdf(const BsdfSide &s, V3 wi, V3 wo, const TexCtx &tc) {
     if (s.none) return 0.f;
-    return s.flip ? bsdf_pdf<Ext>(*s.b, bsdf_mirror(wi), bsdf_mirror(wo), tc) : bsdf_pdf<Ext>(*s.b, wi, wo, tc);
+    return bsdf_pdf<Ext, Trio>(*s.b, s.flip ? bsdf_mirror(wi) : wi, s.flip ? bsdf_mirror(wo) : wo, tc);
 }
 
 } // namespace miw

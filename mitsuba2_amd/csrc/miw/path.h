@@ -242,7 +242,8 @@ enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
 // `Mats` names the BSDF plugins the scene uses, so that a kernel compiled for MATS_DIFFUSE (every shape one-sided
 // smooth diffuse: BASELINE config 2) carries no dispatch and none of the other plugins' code; MATS_ALL is the table;
 // MATS_PLAIN is the table for scenes without texture coordinates and bitmap textures (the lookups compiled out).
-enum { MATS_ALL = 0, MATS_DIFFUSE = 1, MATS_PLAIN = 2 };
+// MATS_TRIO is MATS_PLAIN for scenes whose records are all diffuse / dielectric / roughconductor (BASELINE configs 3, 4).
+enum { MATS_ALL = 0, MATS_DIFFUSE = 1, MATS_PLAIN = 2, MATS_TRIO = 3 };
 // `Analytic` = false compiles the analytic-shape branch out (scenes the caller knows to be triangles only).
 template <int Mats = MATS_ALL, bool Analytic = true, typename PrevO>
 MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
@@ -276,7 +277,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
                     d = d / dist;
                     n = si.sh.n;
                 }
-                emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, n, ref_p);
+                emitter_pdf = pdf_emitter_direction<Analytic>(sc, (uint32_t) emitter, d, dist, n, ref_p);
             }
             emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
         }
@@ -307,15 +308,16 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     // what the plugin's texture lookups see of `si`; only MATS_ALL kernels are launched for scenes with bitmap textures
     const TexCtx tc(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr, Mats == MATS_ALL ? sc.bsdf_tables : nullptr);
     constexpr bool Ext = Mats == MATS_ALL;           // plugins only "extended" scenes contain (roughplastic)
+    constexpr bool Trio = Mats == MATS_TRIO;
 
     // ---- emitter sampling, :155-172 ----
     if (bflags & BSDF_Smooth) {
         DirectionSample ds;
-        Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);
+        Spec emitter_val = sample_emitter_direction<Analytic>(sc, si.p, next_2d(L.rng), ds, L.wl);
         if (ds.pdf != 0.f) {
             V3 wo = to_local(si.sh, ds.d);
-            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, tc) : bsdf_side_eval<Ext>(bsdf, si.wi, wo, tc);
-            float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf<Ext>(bsdf, si.wi, wo, tc);
+            Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_eval(*bsdf.b, si.wi, wo, tc) : bsdf_side_eval<Ext, Trio>(bsdf, si.wi, wo, tc);
+            float bpdf = Mats == MATS_DIFFUSE ? diffuse_pdf(si.wi, wo) : bsdf_side_pdf<Ext, Trio>(bsdf, si.wi, wo, tc);
             float mis = mis_weight(ds.pdf, bpdf);
             Spec c = mis * L.tp * bsdf_val * emitter_val;
             if (!all_zero(c)) {
@@ -330,7 +332,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, tc) : bsdf_side_sample<Ext>(bsdf, si.wi, s1, s2, bs, tc);
+    Spec bsdf_val = Mats == MATS_DIFFUSE ? diffuse_sample(*bsdf.b, si.wi, s2, bs, tc) : bsdf_side_sample<Ext, Trio>(bsdf, si.wi, s1, s2, bs, tc);
     L.tp = L.tp * bsdf_val;
     if (all_zero(L.tp))                              // :182-184
         return sh.has ? STEP_DEAD_PENDING : STEP_FINISHED;

@@ -180,6 +180,8 @@ MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d) { return env_eval(e, d); }
 
 // Endpoint::sample_direction of emitter `index` (endpoint.h:119-139): AreaLight (area.cpp:121-166 +
 // shape.cpp:292-309) or the environment map (envmap.cpp:157-190). Returns radiance / pdf; `ds.pdf == 0`: no sample.
+// Analytic = false: the caller knows the scene to hold no analytic shapes, hence no sphere / rectangle lights (their code is compiled out).
+template <bool Analytic = true>
 MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
     const EmitterRec &e = sc.emitters[index];
     Spec value;
@@ -187,12 +189,12 @@ MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref
     if (e.type == EMITTER_ENVMAP) {
         value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
     } else {
-        if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
+        if (Analytic && (e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
             sphere_sample_direction(sc.rects[e.tri_first], ref_p, sample, ds);      // the sphere's own sample_direction
         } else {
             // Shape::sample_direction, shape.cpp:292-309
-            PositionSample ps = (e.flags & 2u) ? rect_sample_position(sc.rects[e.tri_first], sample)
-                                               : mesh_sample_position(emitter_mesh(sc, e), sample);
+            PositionSample ps = (Analytic && (e.flags & 2u)) ? rect_sample_position(sc.rects[e.tri_first], sample)
+                                                             : mesh_sample_position(emitter_mesh(sc, e), sample);
             ds.p = ps.p; ds.n = ps.n; ds.pdf = ps.pdf;
             ds.d = ds.p - ref_p;
             float dist_squared = squared_norm(ds.d);
@@ -212,6 +214,7 @@ MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref
 // scene.cpp:164-200, *without* the visibility test (the shadow ray is a separate stage of the kernels;
 // mi_sample_emitter_direction traces it on request). Returns the unoccluded emitter value; `ds.pdf == 0`
 // means "no sample" (path.cpp:160).
+template <bool Analytic = true>
 MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, DirectionSample &ds, const Wavelengths &wl) {
     if (sc.emitter_count == 0) {                       // scene.cpp:208-211
         ds.p = ds.n = ds.d = v3(0.f); ds.dist = 0.f; ds.pdf = 0.f; ds.emitter = 0;
@@ -226,7 +229,7 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
         index = i < sc.emitter_count - 1 ? i : sc.emitter_count - 1;
         sample.x = (sample.x - (float) index * emitter_pdf) * n;
     }
-    Spec value = emitter_sample_direction(sc, index, ref_p, sample, ds, wl);
+    Spec value = emitter_sample_direction<Analytic>(sc, index, ref_p, sample, ds, wl);
     if (sc.emitter_count > 1) {                        // scene.cpp:195-197
         ds.pdf *= emitter_pdf;
         value = value * rcp(emitter_pdf);
@@ -237,13 +240,14 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
 // Endpoint::pdf_direction of emitter `emitter` (area.cpp:168-187 + shape.cpp:311-323, envmap.cpp:192-208).
 // `ds_d`, `ds_dist`, `ds_n` come from DirectionSample(si_bsdf, si) (records.h:167-173).
 // `ref_p` = it.p, the point the direction leaves from (only the sphere's pdf_direction needs it).
+template <bool Analytic = true>
 MIW_HD float emitter_pdf_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
     const EmitterRec &e = sc.emitters[emitter];
     if (e.type == EMITTER_ENVMAP) return env_pdf_direction(*sc.env, ds_d);
     float dp = dot(ds_d, ds_n);
     bool active = dp < 0.f;
     float pdf;
-    if ((e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
+    if (Analytic && (e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
         pdf = sphere_pdf_direction(sc.rects[e.tri_first], ref_p, ds_d, ds_dist, ds_n);
     } else {
         pdf = e.normalization;
@@ -253,8 +257,9 @@ MIW_HD float emitter_pdf_direction(const SceneView &sc, uint32_t emitter, V3 ds_
     return active ? pdf : 0.f;
 }
 // scene.cpp:216-231
+template <bool Analytic = true>
 MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
-    float value = emitter_pdf_direction(sc, emitter, ds_d, ds_dist, ds_n, ref_p);
+    float value = emitter_pdf_direction<Analytic>(sc, emitter, ds_d, ds_dist, ds_n, ref_p);
     if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);
     return value;
 }
