@@ -56,6 +56,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 #endif
     const PrimCtx ctx = prim_ctx(sc);
     Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
+#endif
 
     QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     LaneRegs L;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 
         if (n_shade * MIW_PHASE_SHADE_NUM >= lead * MIW_PHASE_SHADE_DEN && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
+            MIW_SECTION(6);                                              // everything since the last shade body: walks + votes
             if (e_shade) {
                 if (!(L.flags & LF_DONE)) {
                     const V3 o = L.ray.o;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         lane_begin_sample(P, pixel, L, sample_end);
                     }
                 }
+                MIW_SECTION(11);
                 while (L.flags & LF_DONE) {                                 // pixel finished (or no pixel yet): take the next one
                     if (have) {
                         U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 else if (!dead_pending) { mode = PH_TRAV_E; begin_walk(L.ray.d, L.ray.maxt); }
                 else { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }       // dead_pending implies a queued shadow ray
             }
+            MIW_SECTION(12);
             MIW_PS(3, n_shade);
         } else if (n_node >= n_leaf) {
             // ---------------- node steps: an inner loop that owns cur, sp and the leaf range only; it runs while the node
@@ -236,6 +242,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         for (int k = 0; k < 4; ++k) { atomicAdd(&g_phase_stats[k], ps_runs[k]); atomicAdd(&g_phase_stats[4 + k], ps_lanes[k]); atomicAdd(&g_phase_stats[8 + k], ps_cycles[k]); }
 #endif
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
+#if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 63) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) if (b_[i]) atomicAdd(&g_sections[i], b_[i]); }
+#endif
     if ((threadIdx.x & 63) == 0) {
         Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
         if (a) atomicAdd(&shard->segments, a);

@@ -225,6 +225,10 @@ MIW_HD void lane_init_unused(const LaneQueues &Q, uint32_t lane) {
 }
 #endif   // !MIW_SPECTRAL
 
+#ifndef MIW_SECTION
+#define MIW_SECTION(i) do { } while (0)      /* section clock of debug builds (miwave.hip) */
+#endif
+
 // What one depth-loop iteration hands to the shadow stage (scene.cpp:203-207):
 // origin and mint are the extension ray's (L.ray.o, L.ray.mint).
 struct ShadowOut { bool has; V3 d; float maxt; Spec c; };
@@ -261,6 +265,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     if (valid) hit_surface_interaction<Analytic, Mats == MATS_ALL>(sc, tri_idx, h.x, h.y, h.z, prev_o, ray_d, si, bsdf_index, emitter);
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;   // a miss sees the environment, scene.h:248-249
     if (depth == 1 && valid) L.flags |= LF_VALID_RAY;   // path.cpp:121
+    MIW_SECTION(7);                                   // (sections 6.. : the shade body of the phase machine, debug builds)
 
     // ---- intersection with emitters, path.cpp:126-129 ----
     if (emitter >= 0) {
@@ -285,6 +290,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         L.res = L.res + emission_weight * L.tp * radiance;
     }
 
+    MIW_SECTION(8);
     bool active = valid;                             // :131
 
     // ---- Russian roulette, :137-141 (the draw happens even for dead paths) ----
@@ -328,6 +334,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
         }
     }
 
+    MIW_SECTION(9);
     // ---- BSDF sampling, :177-186 (Clang order: next_1d, then next_2d) ----
     float s1 = next_1d(L.rng);
     V2 s2 = next_2d(L.rng);
@@ -342,6 +349,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
     L.prev_pdf = bs.pdf;
     L.flags = (L.flags & ~(LF_DEPTH_MASK | LF_PREV_DELTA)) | ((depth + 1) & LF_DEPTH_MASK)
             | ((bs.sampled_type & BSDF_Delta) ? LF_PREV_DELTA : 0u) | LF_RAY_ACTIVE;
+    MIW_SECTION(10);
     return STEP_CONTINUE;
 }
 
@@ -421,9 +429,6 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 // store(st) publishes a pixel's state when its run is over, put(...) is block->put(). A lane that
 // finishes a pixel fetches the next one INSIDE the iteration loop, so the other lanes of its wavefront
 // never wait for it (the device feeds lanes from one shared queue; the CPU checker hands out one pixel).
-#ifndef MIW_SECTION
-#define MIW_SECTION(i) do { } while (0)      /* section clock of debug builds (miwave.hip) */
-#endif
 template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2>
 MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                 Trace2 trace2, Counters *cnt_local) {

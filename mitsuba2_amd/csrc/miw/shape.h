@@ -107,7 +107,16 @@ MIW_HD TriBounds tri_bounds(V3 p0, V3 p1, V3 p2, float pad) {
     b.lo[2] = min_(p0.z, min_(p1.z, p2.z)) - pad; b.hi[2] = max_(p0.z, max_(p1.z, p2.z)) + pad;
     return b;
 }
+// Build switch: -DMIW_ACCEPT_RULE=0 (all libraries and the checker alike) drops the rule — the reference's bare test,
+// mesh.h:194-226; results then depend on which triangles a structure happens to test for ill-conditioned grazing rays.
+#ifndef MIW_ACCEPT_RULE
+#define MIW_ACCEPT_RULE 1
+#endif
 MIW_HD bool hit_in_bounds(const TriBounds &b, V3 o, V3 d, float t) {
+#if !MIW_ACCEPT_RULE
+    (void) b; (void) o; (void) d; (void) t;
+    return true;
+#endif
     const float px = fmadd(d.x, t, o.x), py = fmadd(d.y, t, o.y), pz = fmadd(d.z, t, o.z);
     return px >= b.lo[0] && px <= b.hi[0] && py >= b.lo[1] && py <= b.hi[1] && pz >= b.lo[2] && pz <= b.hi[2];
 }

@@ -1017,10 +1017,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         if (getenv("MIW_DEBUG")) {
             unsigned long long sec[16];
             if (hipMemcpyFromSymbol(sec, HIP_SYMBOL(g_sections), sizeof sec) == hipSuccess) {
-                static const char *names[6] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin" };
+                static const char *names[13] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin",
+                                                 "walks + votes", "shade: surface interaction", "shade: emitter hit + MIS", "shade: RR + emitter sampling + bsdf eval",
+                                                 "shade: bsdf sample", "shade: finish + next sample", "shade: pixel fetch + walk start" };
                 unsigned long long tot = 0;
-                for (int i = 0; i < 6; ++i) tot += sec[i];
-                for (int i = 0; i < 6; ++i) fprintf(stderr, "[miwave] section %-13s %6.2f %%\n", names[i], 100.0 * (double) sec[i] / (double) std::max<unsigned long long>(tot, 1));
+                for (int i = 0; i < 13; ++i) tot += sec[i];
+                for (int i = 0; i < 13; ++i) if (sec[i]) fprintf(stderr, "[miwave] section %-40s %6.2f %%\n", names[i], 100.0 * (double) sec[i] / (double) std::max<unsigned long long>(tot, 1));
                 memset(sec, 0, sizeof sec);
                 (void) hipMemcpyToSymbol(HIP_SYMBOL(g_sections), sec, sizeof sec);
             }

@@ -386,6 +386,36 @@ def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path):
     assert np.array_equal(got.astype(np.float32), full.astype(np.float32))
 
 
+def test_accept_rule_is_a_build_switch_and_silent_on_the_bench_scenes(native, oracle, tmp_path):
+    """The bounding-box accept rule of triangle hits (miw/shape.h; a documented departure from mesh.h:194-226) can be
+    compiled out with -DMIW_ACCEPT_RULE=0. With well-conditioned rays it never fires: the checker built without it gives
+    the same hits on 60 000 camera + bounce rays and the same films on the benchmark scene classes."""
+    import ctypes as C
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from mitsuba2_amd import scenes, build
+    so = str(tmp_path / "libmiw_oracle_norule.so")
+    subprocess.check_call([build.CXX] + build.CXX_FLAGS + ["-DMIW_ACCEPT_RULE=0", os.path.join(ROOT, "oracle", "miw_oracle.cpp"),
+                                                           os.path.join(ROOT, "oracle", "wavefront_emu.cpp"), "-o", so, "-lpthread"])
+    bare = oracle_py.Oracle(C.CDLL(so), 3)
+    for scene, sensor in (scenes.cornell_box(64, 48, 8, device=-1), scenes.cornell_box(64, 48, 4, diffuse_only=False, device=-1, ball_level=2)):
+        job = native.PathIntegrator().render_job(sensor)
+        a, _, sa = oracle.render(scene.desc(), job, threads=4, want_f64=False)
+        b, _, sb = bare.render(scene.desc(), job, threads=4, want_f64=False)
+        assert sa.segments == sb.segments and np.array_equal(a, b)
+        rng = np.random.default_rng(12)
+        rays = np.array([sensor.sample_ray(x, y) for x, y in rng.uniform(0, 1, (20000, 2)).astype(np.float32)])
+        h = oracle.trace(scene.desc(), rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7])
+        hit = np.isfinite(h["t"])
+        p = rays[hit, 0:3] + rays[hit, 3:6] * h["t"][hit, None]
+        d2 = rng.normal(size=p.shape).astype(np.float32); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        o = np.concatenate([rays[:, 0:3], p]); d = np.concatenate([rays[:, 3:6], d2])
+        mint = np.concatenate([rays[:, 6], np.full(len(p), 1e-2, np.float32)]); maxt = np.concatenate([rays[:, 7], np.full(len(p), np.inf, np.float32)])
+        x, y = oracle.trace(scene.desc(), o, d, mint, maxt), bare.trace(scene.desc(), o, d, mint, maxt)
+        assert np.array_equal(x["prim"], y["prim"]) and np.array_equal(x["t"].view(np.uint32), y["t"].view(np.uint32))
+
+
 @pytest.mark.parametrize("rfilter", ["gaussian", "box", "lanczos"])
 def test_tiny_blocks_of_a_many_threaded_render(native, oracle, rfilter):
     """integrator.cpp:88-97 halves the block size until there are as many blocks as worker threads — down to 1 pixel for
