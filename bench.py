@@ -34,14 +34,15 @@ B_SPLAT = 320.0              # per finished sample: 4x4 texels x 5 channels x 4 
 
 
 def kernel_src_sha16():
-    """sha256 (first 16 hex digits) over the kernel sources (mitsuba2_amd/csrc/**, sorted by path): what a committed PMC
-    profile must have been taken on for its numbers to be quoted in the JSON line"""
+    """sha256 (first 16 hex digits) over the kernel sources (the headers under mitsuba2_amd/csrc — leaf arithmetic, device
+    kernels, LBVH builder — sorted by path; miwave.hip, the host side of the C ABI, is not part of it): what a committed
+    PMC profile must have been taken on for its numbers to be quoted in the JSON line"""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "mitsuba2_amd", "csrc")
     for d, _, files in sorted(os.walk(base)):
         for f in sorted(files):
-            if f.endswith((".h", ".hip")):
+            if f.endswith(".h"):
                 h.update(os.path.relpath(os.path.join(d, f), base).encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -68,7 +69,7 @@ def main():
                          "light + environment map); glassblock = configs[4]'s geometry (Cornell box with a dielectric block; with "
                          "--variant scalar_spectral)")
     ap.add_argument("--tess", type=int, default=5, help="matball: icosphere subdivision level of the two balls (5 = 40 972 triangles, "
-                    "the config; 1..4 = 172 / 652 / 2 572 / 10 252: the triangle-count series of DESIGN.md)")
+                    "the config; 0..4 = 52 / 172 / 652 / 2 572 / 10 252: the triangle-count series of DESIGN.md)")
     ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
                     help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs mitsuba2_amd/data/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")

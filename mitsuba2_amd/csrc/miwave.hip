@@ -554,11 +554,16 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         v.tri_bounds = c->d_tri_bounds.p;
         c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox) + v.tri_count * sizeof(TriBounds);
     } else {
-        if (all <= 16 * 1024) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
+        // A whole tree that fits 16 KiB could be walked out of LDS with the stackless trail walk; measured (r02 triangle-count
+        // series: 172 triangles, 375 Msamples/s that way against 850 with the LDS-stack walk of the phase machine, whose
+        // node fetches hit L1) that only pays for the forced-tree test path of <= 64 triangles, which keeps it covered.
+        const bool stack_ok = depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK");
+        const bool resident_tree = all <= 16 * 1024 && (!stack_ok || v.tri_count <= MIW_BRUTE_MAX_TRIS);
+        if (resident_tree) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
         else { c->lds_cfg.nodes_staged = MIW_LDS_TOP ? std::min<uint32_t>(v.node_count, 255) : 0u; c->lds_cfg.tris_staged = 0; }
         c->lds_bytes = c->lds_cfg.nodes_staged * sizeof(BvhNode) + c->lds_cfg.tris_staged * sizeof(Tri);
         c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0;
-        if (all > 16 * 1024 && depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK")) {
+        if (!resident_tree && stack_ok) {
             c->lds_cfg.stack = 1; c->lds_cfg.stack16 = (uint32_t) (c->lds_bytes / 16);
             c->lds_bytes += (size_t) MIW_STACK_ENTRIES * MIW_BLOCK * sizeof(int32_t);
         }
