@@ -179,7 +179,7 @@ def main():
         value = total_samples / elapsed / 1e6
         s_bar = agg["segments"] / max(agg["samples"], 1)
         pk = dev.counters().path_kernel
-        path_kernel = "k_path_phased" if pk == 1 else "k_path_resident"
+        path_kernel = "k_path_phased" if pk in (1, 3) else "k_path_resident"
         tc_name, ta_name = ("k_trace_stream", "k_sort_hits") if pk == 2 else ("k_trace<closest>", "k_trace<any>")
         # dominant kernel by summed HIP-event time (rank 0's shard)
         kernels = {

@@ -10,7 +10,8 @@
 // carries its own little state
 //   SHADE -> TRAV_E -> [TRAV_S] -> SHADE ...        (a traversal being a run of node steps and triangle tests)
 // and the WAVE repeatedly votes (ballots + s_bcnt1) which body to run next for the lanes that are ready for it:
-//   node step      one BVH2 node: two slab tests, push / pop on the per-lane LDS stack
+//   node step      one BVH2 node: two slab tests, push / pop on the per-lane LDS stack (template Wide: one 64-byte BVH4 node,
+//                  four quantised child boxes, miw/bvh4.h)
 //   triangle test  one Moeller-Trumbore test (+ the accept rule) of the leaf range a lane holds
 //   walk end       hand the hit record over / start the shadow walk (a handful of moves)
 //   shade          everything between two scene queries: add the resolved emitter-sampling term, path_step,
@@ -42,14 +43,18 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 // Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs, no spills) or 4 (128 VGPRs, a few spills in the shade body):
 // big trees, whose node fetches miss L2, gain more from the fourth wave's latency hiding than they lose to the spills.
-template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES>
+// Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h instead of the BVH2 (MIW_BVH4=1, measured
+// neutral — see DESIGN.md §4 — and therefore not the default; instantiated for the MATS_TRIO kernels only).
+template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = false>
 __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
     int32_t *stack = reinterpret_cast<int32_t *>(smem + cfg.stack16) + threadIdx.x;
     const BvhNode *gnodes = sc.nodes;
+    const Bvh4Node *nodes4 = sc.nodes4;
     const Tri *gtris = sc.tris;
+    (void) gnodes; (void) nodes4;
 #if MIW_LDS_TOP
     const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
     const uint32_t ns = cfg.nodes_staged;
@@ -170,23 +175,38 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             do {
                 MIW_PS(0, count(e_node));
                 if (e_node) {
+                    int32_t next = MIW_WALK_DONE;
+                    if (Wide) {
+                        // one 64-byte node = four quantised child boxes (miw/bvh4.h): slab tests, a 5-exchange sort of the
+                        // entry distances, far ... near hits onto the stack, the nearest becomes the next node
+                        const Bvh4Node &n = nodes4[cur];
+                        uint32_t k[4];
+                        bvh4_test(n, r, widen(tmax), k);
+                        bvh4_sort(k);
+                        if (bvh4_key_hit(k[3])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[3]); ++sp; }
+                        if (bvh4_key_hit(k[2])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[2]); ++sp; }
+                        if (bvh4_key_hit(k[1])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[1]); ++sp; }
+                        if (bvh4_key_hit(k[0])) next = bvh4_child_of(n, k[0]);
+                        else if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                    } else {
 #if MIW_LDS_TOP
-                    const BvhNode &n = (uint32_t) cur < ns ? lnodes[cur] : gnodes[cur];
+                        const BvhNode &n = (uint32_t) cur < ns ? lnodes[cur] : gnodes[cur];
 #else
-                    const BvhNode &n = gnodes[cur];
+                        const BvhNode &n = gnodes[cur];
 #endif
-                    float tn0, tn1;
-                    const float wide = widen(tmax);
-                    const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
-                    const int32_t c0 = n.child0, c1 = n.child1;
-                    const bool second_first = tn1 < tn0;
-                    int32_t next = h0 ? c0 : c1;
-                    if (h0 && h1) {
-                        stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
-                        next = second_first ? c1 : c0;
-                    } else if (!(h0 || h1)) {
-                        next = MIW_WALK_DONE;
-                        if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                        float tn0, tn1;
+                        const float wide = widen(tmax);
+                        const bool h0 = box_test_fast(n.lo0, n.hi0, r, wide, tn0), h1 = box_test_fast(n.lo1, n.hi1, r, wide, tn1);
+                        const int32_t c0 = n.child0, c1 = n.child1;
+                        const bool second_first = tn1 < tn0;
+                        next = h0 ? c0 : c1;
+                        if (h0 && h1) {
+                            stack[sp * MIW_BLOCK] = second_first ? c0 : c1; ++sp;
+                            next = second_first ? c1 : c0;
+                        } else if (!(h0 || h1)) {
+                            next = MIW_WALK_DONE;
+                            if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                        }
                     }
                     // a leaf: it becomes the lane's triangle range (if it holds none), and the next stack entry its current node
                     if (next < 0 && next != MIW_WALK_DONE && (!Spec || tri_i >= tri_end)) {

@@ -89,7 +89,9 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 // and the rest through L1/L2. Same observable result as bvh_intersect (== brute force, ties to the
 // smaller primitive id); used when the tree depth fits MIW_STACK_ENTRIES, otherwise the stackless
 // trail walk of bvh.h runs.
+#ifndef MIW_STACK_ENTRIES
 #define MIW_STACK_ENTRIES 32
+#endif
 #ifndef MIW_WALK
 #define MIW_WALK 1                /* 0: one loop, node or leaf per iteration; 1: while-while; 2: while-while + one postponed leaf per lane */
 #endif

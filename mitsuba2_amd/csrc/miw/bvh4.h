@@ -1,0 +1,124 @@
+// 4-wide BVH with quantised child boxes — the tree the wave-level phase machine walks (device/phased_kernel.h).
+//
+// Why: the tree kernels are bound by dependent fetches (a node step is one L2 round trip per lane, ~170 cycles of issue in
+// ~1 100 - 1 700 wall cycles per wave; the 0.9 M-triangle interior moves 4 TB/s through the fabric, profiles/r02_*). A
+// 64-byte node that holds FOUR child boxes (8-bit planes relative to the node's own origin and per-axis power-of-two
+// scale, after Ylitie, Karras & Laine 2017) halves the round trips and the bytes per ray against the BVH2's two full
+// boxes per 64 bytes; the extra slab tests are VALU work, of which the kernels use 35 - 40 % of the issue slots.
+//
+// Like every box test here the quantised test only has to be CONSERVATIVE (planes are rounded outwards; the BVH2 boxes
+// it is built from are already padded by 2e-5 x the scene extent, orders of magnitude above the float rounding of
+// origin + q * scale): every hit is decided by the exact Moeller-Trumbore test, so the observable result is the
+// BVH2's and brute force's — closest t, ties to the smaller primitive id; any-hit = some triangle passes.
+#pragma once
+#include "base.h"
+#include "scene.h"
+#include "bvh.h"
+
+namespace miw {
+
+#define MIW_BVH4_ABSENT ((int32_t) 0x80000000)      /* = MIW_WALK_DONE: never a leaf code */
+
+struct alignas(64) Bvh4Node {
+    float origin[3];          // lo corner of the node's box
+    uint32_t exps;            // bytes 0..2: biased exponent e of the per-axis plane spacing 2^(e - 127); byte 3: child count
+    uint32_t qlo[3];          // per axis: byte c = quantised lo plane of child c (rounded down)
+    uint32_t qhi[3];          // per axis: byte c = quantised hi plane of child c (rounded up)
+    int32_t child[4];         // >= 0: Bvh4Node index; < 0: leaf, ~child = (first_tri << 4) | (count - 1); absent: MIW_BVH4_ABSENT
+    uint32_t pad[2];
+};
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be one 64-byte line");
+
+// The ray as the slab test wants it: t(plane) = fma(plane, inv_d, neg_o_inv_d). (FastRay of device/trace.h has the same
+// fields; the host fills them with IEEE divisions — the test is conservative, not bit-reproducible, on both sides.)
+struct SlabRay { V3 inv_d, neg_o_inv_d; float mint; };
+MIW_HD SlabRay slab_ray_host(V3 o, V3 d, float mint) {
+    SlabRay r;
+    float dx = abs_(d.x) < 1e-30f ? mulsign(1e-30f, d.x) : d.x,
+          dy = abs_(d.y) < 1e-30f ? mulsign(1e-30f, d.y) : d.y,
+          dz = abs_(d.z) < 1e-30f ? mulsign(1e-30f, d.z) : d.z;
+    r.inv_d = v3(1.f / dx, 1.f / dy, 1.f / dz);
+    r.neg_o_inv_d = v3(-(o.x * r.inv_d.x), -(o.y * r.inv_d.y), -(o.z * r.inv_d.z));
+    r.mint = mint;
+    return r;
+}
+
+MIW_HD float bvh4_byte(uint32_t w, int c) { return (float) ((w >> (8 * c)) & 0xffu); }   // v_cvt_f32_ubyte{c} on gfx950
+
+// Slab-tests the four child boxes of `n`. keys[c] = entry distance of child c (bits, >= 0: ordered like unsigned integers)
+// with the child's slot in the two low mantissa bits, 0x7f800000 | slot (> every hit key) for a miss or an absent child.
+// `tmax_wide` = the caller's current tmax, widened (2e-6 relative) like every fast slab test.
+template <typename Ray>
+MIW_HD void bvh4_test(const Bvh4Node &n, const Ray &r, float tmax_wide, uint32_t keys[4]) {
+    // t(q) = (origin + q * s - o) / d = q * (s * inv_d) + (origin * inv_d - o * inv_d)
+    const float sx = u2f((n.exps & 0xffu) << 23), sy = u2f(((n.exps >> 8) & 0xffu) << 23), sz = u2f(((n.exps >> 16) & 0xffu) << 23);
+    const float ax = sx * r.inv_d.x, ay = sy * r.inv_d.y, az = sz * r.inv_d.z;
+    const float bx = __builtin_fmaf(n.origin[0], r.inv_d.x, r.neg_o_inv_d.x),
+                by = __builtin_fmaf(n.origin[1], r.inv_d.y, r.neg_o_inv_d.y),
+                bz = __builtin_fmaf(n.origin[2], r.inv_d.z, r.neg_o_inv_d.z);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 4; ++c) {
+        const float t0x = __builtin_fmaf(bvh4_byte(n.qlo[0], c), ax, bx), t1x = __builtin_fmaf(bvh4_byte(n.qhi[0], c), ax, bx),
+                    t0y = __builtin_fmaf(bvh4_byte(n.qlo[1], c), ay, by), t1y = __builtin_fmaf(bvh4_byte(n.qhi[1], c), ay, by),
+                    t0z = __builtin_fmaf(bvh4_byte(n.qlo[2], c), az, bz), t1z = __builtin_fmaf(bvh4_byte(n.qhi[2], c), az, bz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                         __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
+        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+        tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
+        const bool hit = n.child[c] != MIW_BVH4_ABSENT && tn <= tf && tn <= tmax_wide;
+        keys[c] = hit ? ((f2u(tn) & ~3u) | (uint32_t) c) : (0x7f800000u | (uint32_t) c);
+    }
+}
+// ascending keys: nearest child first (5 compare-exchanges)
+MIW_HD void bvh4_sort(uint32_t k[4]) {
+#define MIW_CE(a, b) do { const uint32_t lo_ = k[a] < k[b] ? k[a] : k[b], hi_ = k[a] < k[b] ? k[b] : k[a]; k[a] = lo_; k[b] = hi_; } while (0)
+    MIW_CE(0, 1); MIW_CE(2, 3); MIW_CE(0, 2); MIW_CE(1, 3); MIW_CE(1, 2);
+#undef MIW_CE
+}
+MIW_HD bool bvh4_key_hit(uint32_t key) { return key < 0x7f800000u; }
+MIW_HD int32_t bvh4_child_of(const Bvh4Node &n, uint32_t key) {
+    const uint32_t s = key & 3u;
+    return s == 0u ? n.child[0] : (s == 1u ? n.child[1] : (s == 2u ? n.child[2] : n.child[3]));
+}
+
+// Reference walk (host array stack): the definition the device bodies of phased_kernel.h restate, run by the CPU checker
+// against brute force. Same observable result as bvh_intersect / brute_intersect.
+template <bool AnyHit, typename TriAt>
+MIW_HD bool bvh4_intersect(const Bvh4Node *nodes, TriAt tri_at, V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx,
+                           uint32_t *max_stack_seen = nullptr) {
+    best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+    const SlabRay r = slab_ray_host(o, d, mint);
+    float tmax = maxt;
+    int32_t stack[128]; int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const Bvh4Node &n = nodes[cur];
+            uint32_t k[4];
+            bvh4_test(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), k);
+            bvh4_sort(k);
+            for (int i = 3; i >= 1; --i) if (bvh4_key_hit(k[i])) stack[sp++] = bvh4_child_of(n, k[i]);   // far ... near
+            if (max_stack_seen && (uint32_t) sp > *max_stack_seen) *max_stack_seen = (uint32_t) sp;
+            if (bvh4_key_hit(k[0])) { cur = bvh4_child_of(n, k[0]); continue; }
+        } else {
+            const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const Tri &tr = tri_at(first + i);
+                float t, u, v;
+                if (prim_intersect(tr, ctx, o, d, mint, maxt, t, u, v)) {
+                    if (AnyHit) { best.t = 0.f; best.tri = first + i; best.prim = tr.prim; return true; }
+                    if (t < best.t || (t == best.t && tr.prim < best.prim)) {
+                        best.t = t; best.u = u; best.v = v; best.tri = first + i; best.prim = tr.prim;
+                        tmax = t;
+                    }
+                }
+            }
+        }
+        if (sp == 0) return best.tri != MIW_MISS;
+        cur = stack[--sp];
+    }
+}
+
+} // namespace miw

@@ -64,6 +64,7 @@ struct SceneView {
     float accept_pad;                               // shape.h: the bounds rule of every triangle hit
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
+    const struct Bvh4Node *nodes4;                  // device only: the 4-wide quantised tree the phase machine walks (bvh4.h) or nullptr
 };
 
 MIW_HD PrimCtx prim_ctx(const SceneView &sc) { PrimCtx c; c.rects = sc.rects; c.accept_pad = sc.accept_pad; return c; }

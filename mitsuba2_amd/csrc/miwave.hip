@@ -57,6 +57,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "miw/film_gather.h"
 #include "texture_build.h"
 #include "bvh_build.h"
+#include "bvh4_build.h"
 #include "envmap_build.h"
 #include "lbvh_device.h"
 
@@ -130,7 +131,7 @@ struct mi_ctx {
     DevBuf<BvhNode> d_nodes; DevBuf<Tri> d_tris; DevBuf<float> d_tri_vn, d_tri_uv, d_bitmap_data; DevBuf<BitmapRec> d_bitmaps; uint32_t bitmap_count = 0;
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<AnalyticRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
-    DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds;
+    DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds; DevBuf<Bvh4Node> d_nodes4; uint32_t nodes4_count = 0, nodes4_stack = 0;
     DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
     bool have_env = false;
     SceneView view{};
@@ -195,7 +196,7 @@ void mi_destroy(mi_ctx *c) {
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
     c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_tri_uv.release(); c->d_bitmap_data.release(); c->d_bitmaps.release(); c->d_bsdf_tables.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
-    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_nodes4.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
@@ -527,7 +528,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
     // otherwise the top of the tree only.
     size_t all = (size_t) node_count * sizeof(BvhNode) + (size_t) tri_count * sizeof(Tri);
-    c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr;
+    c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr; v.nodes4 = nullptr; c->nodes4_count = c->nodes4_stack = 0;
     if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS && c->rects.empty()) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
@@ -566,6 +567,25 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         if (!resident_tree && stack_ok) {
             c->lds_cfg.stack = 1; c->lds_cfg.stack16 = (uint32_t) (c->lds_bytes / 16);
             c->lds_bytes += (size_t) MIW_STACK_ENTRIES * MIW_BLOCK * sizeof(int32_t);
+        }
+        // MIW_BVH4=1 (off by default: measured neutral): the phase machine walks the 4-wide quantised collapse
+        // of this tree (bvh4_build.h; MIW_BVH4_FAN = 2..4 caps the fan-out) instead of the BVH2, which stays for mi_trace, the
+        // scene queries and plan 1. A device-built LBVH is read back for the collapse.
+        const bool wide_on = getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) != 0;
+        if (c->lds_cfg.stack && wide_on) {
+            if (built_on_device) {
+                r.nodes.resize(node_count);
+                HIP_TRY(c, hipMemcpy(r.nodes.data(), c->d_nodes.p, (size_t) node_count * sizeof(BvhNode), hipMemcpyDeviceToHost));
+            }
+            int fan = 4;
+            if (const char *e = getenv("MIW_BVH4_FAN")) fan = atoi(e);
+            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES, fan);
+            if (b4.ok) {
+                HIP_TRY(c, c->d_nodes4.upload(b4.nodes, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                v.nodes4 = c->d_nodes4.p; c->nodes4_count = (uint32_t) b4.nodes.size(); c->nodes4_stack = b4.stack_bound;
+            }
+            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4: %zu nodes (bvh2 %u), depth %u, stack bound %u, ok %d\n", b4.nodes.size(), node_count, b4.depth, b4.stack_bound, (int) b4.ok);
         }
     }
 
@@ -929,16 +949,19 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 int ph_waves = c->view.tri_count >= 200000u ? 4 : 3;
                 if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
                 const dim3 phgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (unsigned) ph_waves));
-#define MIW_PHASED_LAUNCH(M, A) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); \
-                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); } while (0)
+#define MIW_PHASED_LAUNCH_W(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); \
+                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); } while (0)
+#define MIW_PHASED_LAUNCH(M, A) MIW_PHASED_LAUNCH_W(M, A, false)
                 static const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
                 if (phased) {
                     if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true);
+                    else if (c->trio && trio_on && c->rects.empty() && c->view.nodes4) { MIW_PHASED_LAUNCH_W(MATS_TRIO, false, true); K.path_kernel = 3u; }   // MIW_BVH4=1
                     else if (c->trio && trio_on && c->rects.empty()) MIW_PHASED_LAUNCH(MATS_TRIO, false);   // configs 3 / 4: 52 KB of code instead of 84
                     else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false);
                     else MIW_PHASED_LAUNCH(MATS_PLAIN, true);
                 }
 #undef MIW_PHASED_LAUNCH
+#undef MIW_PHASED_LAUNCH_W
                 else if (direct) {
                     if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));

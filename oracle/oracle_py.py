@@ -42,6 +42,9 @@ class Oracle:
         L.emu_trace.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
                                 C.c_int, C.c_int, c_u32_p]
         L.emu_trace.restype = C.c_int
+        L.emu_trace4.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, c_u32_p]
+        L.emu_trace4.restype = C.c_int
         L.emu_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_double_p, c_float_p, C.POINTER(C.c_uint64)]
         L.emu_render.restype = C.c_int
         L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.orc_tea_float32.restype = C.c_float
@@ -127,6 +130,13 @@ class Oracle:
         stats = (C.c_uint32 * 3)()
         out = self._trace(self.L.emu_trace, desc, o, d, mint, maxt, any_hit, max_leaf, stats)
         out["bvh"] = list(stats)
+        return out
+
+    def emu_trace4(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, stack_budget=32, max_fan=4):
+        """The 4-wide quantised tree (csrc/miw/bvh4.h, collapsed by csrc/bvh4_build.h) walked on the CPU."""
+        stats = (C.c_uint32 * 6)()
+        out = self._trace(self.L.emu_trace4, desc, o, d, mint, maxt, any_hit, max_leaf, stack_budget, max_fan, stats)
+        out["bvh4"] = dict(zip(("nodes2", "nodes4", "depth", "stack_bound", "stack_seen", "ok"), list(stats)))
         return out
 
     def ray_intersect_full(self, desc, ray8):

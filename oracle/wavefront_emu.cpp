@@ -18,6 +18,7 @@
 #include "../mitsuba2_amd/csrc/miw/film_gather.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
+#include "../mitsuba2_amd/csrc/bvh4_build.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
 #include "../mitsuba2_amd/csrc/rect_build.h"
 #include "../mitsuba2_amd/csrc/texture_build.h"
@@ -144,7 +145,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
-    v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr;
+    v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr; v.nodes4 = nullptr;
     v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
     v.accept_pad = scene_pad_unit(o.tris_in); v.tri_bounds = nullptr;
     return true;
@@ -174,6 +175,33 @@ int emu_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_so
         if (h->prim) h->prim[i] = ok ? hit.prim : 0xffffffffu;
         if (h->shape) h->shape[i] = ok ? tris[hit.tri].shape : 0xffffffffu;
     }
+    return 0;
+}
+
+// the 4-wide quantised tree of miw/bvh4.h (collapsed from the same SAH build) over caller rays.
+// stats6: BVH2 nodes, BVH4 nodes, BVH4 depth, exact stack bound, deepest stack any of the rays reached, ok flag
+int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_soa *h, uint64_t n, int any_hit, int max_leaf,
+               int stack_budget, int max_fan, uint32_t *stats6) {
+    EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
+    Ftz ftz;
+    const Bvh4BuildResult b4 = bvh4_collapse(sc.bvh.nodes, (uint32_t) stack_budget, max_fan);
+    uint32_t seen = 0;
+    if (stats6) { stats6[0] = sc.view.node_count; stats6[1] = (uint32_t) b4.nodes.size(); stats6[2] = b4.depth; stats6[3] = b4.stack_bound; stats6[4] = 0; stats6[5] = b4.ok ? 1u : 0u; }
+    if (!b4.ok) return 1;
+    const Tri *tris = sc.view.tris; const PrimCtx rects = prim_ctx(sc.view);
+    auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
+    for (uint64_t i = 0; i < n; ++i) {
+        const V3 o = v3(r->ox[i], r->oy[i], r->oz[i]), d = v3(r->dx[i], r->dy[i], r->dz[i]);
+        Hit hit; bool ok;
+        if (any_hit) ok = bvh4_intersect<true>(b4.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen);
+        else ok = bvh4_intersect<false>(b4.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen);
+        h->t[i] = ok ? hit.t : MIW_INFINITY;
+        if (h->u) h->u[i] = hit.u;
+        if (h->v) h->v[i] = hit.v;
+        if (h->prim) h->prim[i] = ok ? hit.prim : 0xffffffffu;
+        if (h->shape) h->shape[i] = ok ? tris[hit.tri].shape : 0xffffffffu;
+    }
+    if (stats6) stats6[4] = seen;
     return 0;
 }
 

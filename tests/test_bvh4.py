@@ -1,0 +1,114 @@
+"""The 4-wide quantised tree of the phase machine (csrc/miw/bvh4.h, collapsed from the BVH2 by csrc/bvh4_build.h).
+
+Its contract is the BVH2's (csrc/miw/bvh.h): over all triangles that pass the exact triangle test inside [mint, maxt], the
+closest hit, ties to the smaller primitive id; any-hit = some triangle passes — i.e. brute force (the scalar oracle's
+orc_trace). The CPU tier walks the very node test / sort / push order the gfx950 node body runs (bvh4_test, bvh4_sort,
+bvh4_intersect) over the host collapse; the GPU tier renders through it (k_path_phased) and compares films with the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+
+def _rays(desc, n, seed):
+    d_ = desc.contents
+    v = np.ctypeslib.as_array(d_.vertex_positions, (d_.vertex_count * 3,)).reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    g = np.random.default_rng(seed)
+    o = (lo - 0.1 * (hi - lo) + 1.2 * (hi - lo) * g.random((n, 3))).astype(np.float32)
+    d = g.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n // 10                                                   # axis-parallel rays: zero components in the slab test
+    d[:k] = np.eye(3)[g.integers(0, 3, k)] * np.sign(g.normal(size=(k, 1)))
+    return o, d.astype(np.float32)
+
+
+def _same(a, b, any_hit):
+    ok = np.array_equal(np.asarray(a["t"]).view(np.uint32), np.asarray(b["t"]).view(np.uint32))
+    return ok and (any_hit or np.array_equal(a["prim"], b["prim"]))
+
+
+@pytest.mark.parametrize("fan,budget", [(4, 32), (3, 32), (2, 32), (4, 20)])
+def test_bvh4_walk_equals_brute_force(native, oracle, fan, budget):
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(32, 32, 1, diffuse_only=False, ball_level=3, device=-1)    # 2 x 1280-triangle balls + the box
+    desc = scene.desc()
+    o, d = _rays(desc, 6000, 3)
+    for any_hit in (False, True):
+        for mint, maxt in ((1e-4, np.inf), (0.0, 150.0)):
+            brute = oracle.trace(desc, o, d, mint, maxt, any_hit=any_hit)
+            for max_leaf in (1, 4):
+                w = oracle.emu_trace4(desc, o, d, mint, maxt, any_hit=any_hit, max_leaf=max_leaf, stack_budget=budget, max_fan=fan)
+                b = w["bvh4"]
+                assert b["ok"] == 1 and b["stack_seen"] <= b["stack_bound"] <= budget
+                assert fan > 2 or b["nodes4"] == b["nodes2"]                      # fan-out 2 keeps the BVH2's topology
+                assert _same(brute, w, any_hit)
+            assert np.isfinite(brute["t"]).sum() > 1000
+
+
+def test_bvh4_collapse_respects_the_stack_budget(native, oracle):
+    """A budget below the BVH2's height cannot be met by any fan-out: the collapse refuses (the device then keeps the BVH2
+    kernels); a budget that just fits degrades the fan-out instead of overflowing the per-lane LDS stack."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(32, 32, 1, diffuse_only=False, ball_level=3, device=-1)
+    desc = scene.desc()
+    o, d = _rays(desc, 2000, 5)
+    full = oracle.emu_trace4(desc, o, d, 1e-4, np.inf)["bvh4"]
+    two = oracle.emu_trace4(desc, o, d, 1e-4, np.inf, max_fan=2)["bvh4"]
+    height = two["stack_bound"]                                               # fan-out 2: the BVH2's own worst case
+    assert full["nodes4"] < 0.6 * full["nodes2"] and full["stack_bound"] > height
+    tight = oracle.emu_trace4(desc, o, d, 1e-4, np.inf, stack_budget=height)
+    assert tight["bvh4"]["ok"] == 1 and tight["bvh4"]["stack_bound"] <= height
+    assert _same(oracle.trace(desc, o, d, 1e-4, np.inf), tight, False)
+    with pytest.raises(RuntimeError):
+        oracle.emu_trace4(desc, o, d, 1e-4, np.inf, stack_budget=height - 1)
+
+
+def test_bvh4_ties_and_degenerate_boxes(native, oracle):
+    """Coplanar duplicates (equal t: the smaller primitive id wins) and axis-aligned geometry whose boxes have zero extent on
+    one axis (plane spacing of a degenerate axis, rays inside the plane)."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.plugin_box(16, 16, 1, device=-1)
+    desc = scene.desc()
+    o, d = _rays(desc, 4000, 9)
+    d_ = desc.contents
+    v = np.ctypeslib.as_array(d_.vertex_positions, (d_.vertex_count * 3,)).reshape(-1, 3)
+    o[:200, 1] = v[:, 1].min(); d[:200, 1] = 0.0                              # rays inside the floor plane
+    d[:200] /= np.maximum(np.linalg.norm(d[:200], axis=1, keepdims=True), 1e-9)
+    for any_hit in (False, True):
+        brute = oracle.trace(desc, o, d, 0.0, np.inf, any_hit=any_hit)
+        for max_leaf in (1, 2, 4):
+            assert _same(brute, oracle.emu_trace4(desc, o, d, 0.0, np.inf, any_hit=any_hit, max_leaf=max_leaf), any_hit)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("fan", ["4", "3", "2"])
+def test_phase_machine_over_bvh4_equals_oracle(native, oracle, fan):
+    """The film of the material-ball scene rendered by k_path_phased over the collapsed tree (MIW_BVH4=1: an experiment
+    switch read per mi_bvh_build, off by default), for every fan-out the collapse can fall back to (MIW_BVH4_FAN), is the
+    oracle's bit for bit."""
+    from mitsuba2_amd import scenes
+    old = os.environ.get("MIW_BVH4_FAN"), os.environ.get("MIW_BVH4")
+    os.environ["MIW_BVH4_FAN"] = fan
+    os.environ["MIW_BVH4"] = "1"
+    try:
+        scene, sensor = scenes.cornell_box(48, 40, 8, diffuse_only=False, ball_level=3, device=-1)
+        job = native.PathIntegrator().render_job(sensor, n_threads=8)
+        o32, _, ost = oracle.render(scene.desc(), job, threads=os.cpu_count() or 8, want_f64=False)
+        dev = native.Device(0)
+        dev.upload(scene.desc(), bvh_quality=1)
+        g, st = dev.render(job)
+        c = dev.counters()
+        dev.close()
+        assert st == 0 and c.path_kernel == 3
+        assert c.samples == ost.samples and c.segments == ost.segments
+        assert np.array_equal(g, o32)
+    finally:
+        for k, v in zip(("MIW_BVH4_FAN", "MIW_BVH4"), old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

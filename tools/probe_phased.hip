@@ -14,6 +14,7 @@
 #include "../mitsuba2_amd/csrc/miw/scene.h"
 #include "../mitsuba2_amd/csrc/miw/film.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
+#include "../mitsuba2_amd/csrc/miw/bvh4.h"
 #include "../mitsuba2_amd/csrc/miw/path.h"
 #include "../mitsuba2_amd/csrc/miw/direct.h"
 using namespace miw;
