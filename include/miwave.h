@@ -270,8 +270,8 @@ typedef struct {
     double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
     uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran the device LBVH builder    */
     uint32_t path_kernel;      /* last render. plan 2: 0 = k_path_resident (lock-step lanes: packet scenes, direct integrator,
-                                  float64 film), 1 = k_path_phased (wave-level phase machine over the LDS-stack tree walk),
-                                  3 = k_path_phased over the 4-wide quantised tree (MIW_BVH4=1, experiment switch).
+                                  float64 film, trees the 4-wide collapse refuses), 1 = k_path_phased (wave-level phase machine over the 4-wide
+                                  quantised tree, per-lane LDS stack), 3 = k_path_phased over the BVH2 (MIW_BVH4=0, A/B switch).
                                   plan 1: 0 = k_trace<closest|any> per list slice, 2 = k_trace_stream (persistent walk kernel
                                   with dynamic ray fetch; ms_trace_closest = its time, ms_trace_any = k_sort_hits) */
     double ms_film_pack;       /* film_mode 1: k_film_pack (sample records + footprint boxes), part of ms_resolve */

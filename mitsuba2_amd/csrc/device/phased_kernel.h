@@ -10,8 +10,8 @@
 // carries its own little state
 //   SHADE -> TRAV_E -> [TRAV_S] -> SHADE ...        (a traversal being a run of node steps and triangle tests)
 // and the WAVE repeatedly votes (ballots + s_bcnt1) which body to run next for the lanes that are ready for it:
-//   node step      one BVH2 node: two slab tests, push / pop on the per-lane LDS stack (template Wide: one 64-byte BVH4 node,
-//                  four quantised child boxes, miw/bvh4.h)
+//   node step      one 64-byte BVH4 node: four quantised child boxes (miw/bvh4.h), slab tests, sort, push / pop on the per-lane
+//                  LDS stack (template Wide = false: one BVH2 node, two boxes)
 //   triangle test  one Moeller-Trumbore test (+ the accept rule) of the leaf range a lane holds
 //   walk end       hand the hit record over / start the shadow walk (a handful of moves)
 //   shade          everything between two scene queries: add the resolved emitter-sampling term, path_step,
@@ -43,9 +43,9 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 // Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs, no spills) or 4 (128 VGPRs, a few spills in the shade body):
 // big trees, whose node fetches miss L2, gain more from the fourth wave's latency hiding than they lose to the spills.
-// Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h instead of the BVH2 (MIW_BVH4=1, measured
-// neutral — see DESIGN.md §4 — and therefore not the default; instantiated for the MATS_TRIO kernels only).
-template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = false>
+// Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h (the default) instead of the BVH2 (MIW_BVH4=0:
+// instantiated for the MATS_TRIO kernels only, A/B runs).
+template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = true>
 __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -178,15 +178,18 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     int32_t next = MIW_WALK_DONE;
                     if (Wide) {
                         // one 64-byte node = four quantised child boxes (miw/bvh4.h): slab tests, a 5-exchange sort of the
-                        // entry distances, far ... near hits onto the stack, the nearest becomes the next node
+                        // entry distances, far ... near hits onto the stack, the nearest becomes the next node. The stores
+                        // are unconditional and only `sp` is predicated (a store past the last hit is overwritten by the next
+                        // push; the collapse budgets MIW_STACK_ENTRIES - 1 entries so that it stays inside the lane's column)
                         const Bvh4Node &n = nodes4[cur];
                         uint32_t k[4];
+                        int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
                         bvh4_test(n, r, widen(tmax), k);
-                        bvh4_sort(k);
-                        if (bvh4_key_hit(k[3])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[3]); ++sp; }
-                        if (bvh4_key_hit(k[2])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[2]); ++sp; }
-                        if (bvh4_key_hit(k[1])) { stack[sp * MIW_BLOCK] = bvh4_child_of(n, k[1]); ++sp; }
-                        if (bvh4_key_hit(k[0])) next = bvh4_child_of(n, k[0]);
+                        bvh4_sort(k, ch);
+                        stack[sp * MIW_BLOCK] = ch[3]; sp += bvh4_key_hit(k[3]) ? 1 : 0;
+                        stack[sp * MIW_BLOCK] = ch[2]; sp += bvh4_key_hit(k[2]) ? 1 : 0;
+                        stack[sp * MIW_BLOCK] = ch[1]; sp += bvh4_key_hit(k[1]) ? 1 : 0;
+                        if (bvh4_key_hit(k[0])) next = ch[0];
                         else if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
                     } else {
 #if MIW_LDS_TOP

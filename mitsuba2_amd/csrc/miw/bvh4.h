@@ -45,9 +45,12 @@ MIW_HD SlabRay slab_ray_host(V3 o, V3 d, float mint) {
 
 MIW_HD float bvh4_byte(uint32_t w, int c) { return (float) ((w >> (8 * c)) & 0xffu); }   // v_cvt_f32_ubyte{c} on gfx950
 
-// Slab-tests the four child boxes of `n`. keys[c] = entry distance of child c (bits, >= 0: ordered like unsigned integers)
-// with the child's slot in the two low mantissa bits, 0x7f800000 | slot (> every hit key) for a miss or an absent child.
-// `tmax_wide` = the caller's current tmax, widened (2e-6 relative) like every fast slab test.
+// Slab-tests the four child boxes of `n`. keys[c] = entry distance of child c (bits of a float >= +0: ordered like unsigned
+// integers) with the child's slot in the two low mantissa bits, 0x7f800000 | slot (> every hit key) for a miss or an absent
+// child. `tmax_wide` = the caller's current tmax, widened (2e-6 relative) like every fast slab test.
+// The ray's octant says through which plane of an axis it enters a box (lo if it travels in +axis, hi otherwise; t(q) =
+// fma(q, a, b) is monotone in q), so the entry / exit bytes are selected once per node — three word swaps — instead of a
+// min / max pair per child and axis; the distances are the same floats either way.
 template <typename Ray>
 MIW_HD void bvh4_test(const Bvh4Node &n, const Ray &r, float tmax_wide, uint32_t keys[4]) {
     // t(q) = (origin + q * s - o) / d = q * (s * inv_d) + (origin * inv_d - o * inv_d)
@@ -56,32 +59,32 @@ MIW_HD void bvh4_test(const Bvh4Node &n, const Ray &r, float tmax_wide, uint32_t
     const float bx = __builtin_fmaf(n.origin[0], r.inv_d.x, r.neg_o_inv_d.x),
                 by = __builtin_fmaf(n.origin[1], r.inv_d.y, r.neg_o_inv_d.y),
                 bz = __builtin_fmaf(n.origin[2], r.inv_d.z, r.neg_o_inv_d.z);
+    const bool px = r.inv_d.x >= 0.f, py = r.inv_d.y >= 0.f, pz = r.inv_d.z >= 0.f;
+    const uint32_t nx = px ? n.qlo[0] : n.qhi[0], fx = px ? n.qhi[0] : n.qlo[0],
+                   ny = py ? n.qlo[1] : n.qhi[1], fy = py ? n.qhi[1] : n.qlo[1],
+                   nz = pz ? n.qlo[2] : n.qhi[2], fz = pz ? n.qhi[2] : n.qlo[2];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int c = 0; c < 4; ++c) {
-        const float t0x = __builtin_fmaf(bvh4_byte(n.qlo[0], c), ax, bx), t1x = __builtin_fmaf(bvh4_byte(n.qhi[0], c), ax, bx),
-                    t0y = __builtin_fmaf(bvh4_byte(n.qlo[1], c), ay, by), t1y = __builtin_fmaf(bvh4_byte(n.qhi[1], c), ay, by),
-                    t0z = __builtin_fmaf(bvh4_byte(n.qlo[2], c), az, bz), t1z = __builtin_fmaf(bvh4_byte(n.qhi[2], c), az, bz);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                         __builtin_fmaxf(__builtin_fminf(t0z, t1z), r.mint));
-        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-        tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
-        const bool hit = n.child[c] != MIW_BVH4_ABSENT && tn <= tf && tn <= tmax_wide;
-        keys[c] = hit ? ((f2u(tn) & ~3u) | (uint32_t) c) : (0x7f800000u | (uint32_t) c);
+        const float tnx = __builtin_fmaf(bvh4_byte(nx, c), ax, bx), tfx = __builtin_fmaf(bvh4_byte(fx, c), ax, bx),
+                    tny = __builtin_fmaf(bvh4_byte(ny, c), ay, by), tfy = __builtin_fmaf(bvh4_byte(fy, c), ay, by),
+                    tnz = __builtin_fmaf(bvh4_byte(nz, c), az, bz), tfz = __builtin_fmaf(bvh4_byte(fz, c), az, bz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, r.mint));
+        float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+        tf = __builtin_fminf(__builtin_fmaf(abs_(tf), 2e-6f, tf), tmax_wide);
+        const bool hit = n.child[c] != MIW_BVH4_ABSENT && tn <= tf;
+        keys[c] = hit ? ((f2u(tn) & 0x7ffffffcu) | (uint32_t) c) : (0x7f800000u | (uint32_t) c);     // (the mask also clears the sign of a -0)
     }
 }
-// ascending keys: nearest child first (5 compare-exchanges)
-MIW_HD void bvh4_sort(uint32_t k[4]) {
-#define MIW_CE(a, b) do { const uint32_t lo_ = k[a] < k[b] ? k[a] : k[b], hi_ = k[a] < k[b] ? k[b] : k[a]; k[a] = lo_; k[b] = hi_; } while (0)
+// ascending keys, the child references riding along: nearest child first (5 compare-exchanges)
+MIW_HD void bvh4_sort(uint32_t k[4], int32_t ch[4]) {
+#define MIW_CE(a, b) do { const bool sw_ = k[b] < k[a]; const uint32_t ka_ = sw_ ? k[b] : k[a], kb_ = sw_ ? k[a] : k[b]; \
+                          const int32_t ca_ = sw_ ? ch[b] : ch[a], cb_ = sw_ ? ch[a] : ch[b]; k[a] = ka_; k[b] = kb_; ch[a] = ca_; ch[b] = cb_; } while (0)
     MIW_CE(0, 1); MIW_CE(2, 3); MIW_CE(0, 2); MIW_CE(1, 3); MIW_CE(1, 2);
 #undef MIW_CE
 }
 MIW_HD bool bvh4_key_hit(uint32_t key) { return key < 0x7f800000u; }
-MIW_HD int32_t bvh4_child_of(const Bvh4Node &n, uint32_t key) {
-    const uint32_t s = key & 3u;
-    return s == 0u ? n.child[0] : (s == 1u ? n.child[1] : (s == 2u ? n.child[2] : n.child[3]));
-}
 
 // Reference walk (host array stack): the definition the device bodies of phased_kernel.h restate, run by the CPU checker
 // against brute force. Same observable result as bvh_intersect / brute_intersect.
@@ -97,11 +100,12 @@ MIW_HD bool bvh4_intersect(const Bvh4Node *nodes, TriAt tri_at, V3 o, V3 d, floa
         if (cur >= 0) {
             const Bvh4Node &n = nodes[cur];
             uint32_t k[4];
+            int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
             bvh4_test(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), k);
-            bvh4_sort(k);
-            for (int i = 3; i >= 1; --i) if (bvh4_key_hit(k[i])) stack[sp++] = bvh4_child_of(n, k[i]);   // far ... near
+            bvh4_sort(k, ch);
+            for (int i = 3; i >= 1; --i) if (bvh4_key_hit(k[i])) stack[sp++] = ch[i];                    // far ... near
             if (max_stack_seen && (uint32_t) sp > *max_stack_seen) *max_stack_seen = (uint32_t) sp;
-            if (bvh4_key_hit(k[0])) { cur = bvh4_child_of(n, k[0]); continue; }
+            if (bvh4_key_hit(k[0])) { cur = ch[0]; continue; }
         } else {
             const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
             for (uint32_t i = 0; i < count; ++i) {

@@ -568,10 +568,12 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             c->lds_cfg.stack = 1; c->lds_cfg.stack16 = (uint32_t) (c->lds_bytes / 16);
             c->lds_bytes += (size_t) MIW_STACK_ENTRIES * MIW_BLOCK * sizeof(int32_t);
         }
-        // MIW_BVH4=1 (off by default: measured neutral): the phase machine walks the 4-wide quantised collapse
-        // of this tree (bvh4_build.h; MIW_BVH4_FAN = 2..4 caps the fan-out) instead of the BVH2, which stays for mi_trace, the
-        // scene queries and plan 1. A device-built LBVH is read back for the collapse.
-        const bool wide_on = getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) != 0;
+        // The phase machine (plan 2 over a stack-walked tree) walks the 4-wide quantised collapse of this tree (miw/bvh4.h,
+        // bvh4_build.h; +10 % on the material balls and the interior against the BVH2 walk). The BVH2 stays for
+        // mi_trace, the scene queries and plan 1; a device-built LBVH is read back for the collapse. MIW_BVH4=0 switches it
+        // off (A/B runs), MIW_BVH4_FAN = 2..4 caps the fan-out. A tree the collapse refuses (height above the stack budget,
+        // coordinates beyond the quantisation range) is rendered by the lock-step kernel.
+        const bool wide_on = !(getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) == 0);
         if (c->lds_cfg.stack && wide_on) {
             if (built_on_device) {
                 r.nodes.resize(node_count);
@@ -579,7 +581,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             }
             int fan = 4;
             if (const char *e = getenv("MIW_BVH4_FAN")) fan = atoi(e);
-            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES, fan);
+            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, fan);   // one entry of slack: the node body's unconditional stores
             if (b4.ok) {
                 HIP_TRY(c, c->d_nodes4.upload(b4.nodes, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -943,25 +945,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // tree scenes with the LDS-stack walk: the wave-level phase machine (device/phased_kernel.h); MIW_PHASED=0 keeps
                 // the lock-step kernel (A/B runs)
                 static const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
-                const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack;
-                K.path_kernel = phased ? 1u : 0u;
-                // 4 waves per SIMD for big trees (measured: 0.9 M triangles +11 %, 41 k triangles -1 %); MIW_PHASED_WAVES = 3 | 4 overrides
+                // the phase machine over the 4-wide tree; MIW_BVH4=0 keeps the BVH2 node body for the MATS_TRIO class (configs 3 / 4: A/B runs)
+                static const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
+                const bool trio_kernel = c->trio && trio_on && c->rects.empty() && !c->textured;   // 52 KB of code instead of 84
+                const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel);
+                K.path_kernel = phased ? (c->view.nodes4 ? 1u : 3u) : 0u;
+                // 4 waves per SIMD for big trees (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0); MIW_PHASED_WAVES = 3 | 4 overrides
                 int ph_waves = c->view.tri_count >= 200000u ? 4 : 3;
                 if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
                 const dim3 phgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (unsigned) ph_waves));
-#define MIW_PHASED_LAUNCH_W(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); \
+#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); \
                                      else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); } while (0)
-#define MIW_PHASED_LAUNCH(M, A) MIW_PHASED_LAUNCH_W(M, A, false)
-                static const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
                 if (phased) {
-                    if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true);
-                    else if (c->trio && trio_on && c->rects.empty() && c->view.nodes4) { MIW_PHASED_LAUNCH_W(MATS_TRIO, false, true); K.path_kernel = 3u; }   // MIW_BVH4=1
-                    else if (c->trio && trio_on && c->rects.empty()) MIW_PHASED_LAUNCH(MATS_TRIO, false);   // configs 3 / 4: 52 KB of code instead of 84
-                    else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false);
-                    else MIW_PHASED_LAUNCH(MATS_PLAIN, true);
+                    if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, false);
+                    else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, true);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH(MATS_TRIO, false, true);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false, true);
+                    else MIW_PHASED_LAUNCH(MATS_PLAIN, true, true);
                 }
 #undef MIW_PHASED_LAUNCH
-#undef MIW_PHASED_LAUNCH_W
                 else if (direct) {
                     if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));

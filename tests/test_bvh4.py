@@ -85,15 +85,17 @@ def test_bvh4_ties_and_degenerate_boxes(native, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
-@pytest.mark.parametrize("fan", ["4", "3", "2"])
+@pytest.mark.parametrize("fan", ["4", "3", "2", "off"])
 def test_phase_machine_over_bvh4_equals_oracle(native, oracle, fan):
-    """The film of the material-ball scene rendered by k_path_phased over the collapsed tree (MIW_BVH4=1: an experiment
-    switch read per mi_bvh_build, off by default), for every fan-out the collapse can fall back to (MIW_BVH4_FAN), is the
-    oracle's bit for bit."""
+    """The film of the material-ball scene rendered by k_path_phased over the collapsed tree, for every fan-out the
+    collapse can fall back to (MIW_BVH4_FAN, read per mi_bvh_build) and over the BVH2 (MIW_BVH4=0, the A/B switch), is
+    the oracle's bit for bit."""
     from mitsuba2_amd import scenes
     old = os.environ.get("MIW_BVH4_FAN"), os.environ.get("MIW_BVH4")
-    os.environ["MIW_BVH4_FAN"] = fan
-    os.environ["MIW_BVH4"] = "1"
+    if fan == "off":
+        os.environ["MIW_BVH4"] = "0"
+    else:
+        os.environ["MIW_BVH4_FAN"] = fan
     try:
         scene, sensor = scenes.cornell_box(48, 40, 8, diffuse_only=False, ball_level=3, device=-1)
         job = native.PathIntegrator().render_job(sensor, n_threads=8)
@@ -103,7 +105,7 @@ def test_phase_machine_over_bvh4_equals_oracle(native, oracle, fan):
         g, st = dev.render(job)
         c = dev.counters()
         dev.close()
-        assert st == 0 and c.path_kernel == 3
+        assert st == 0 and c.path_kernel == (3 if fan == "off" else 1)
         assert c.samples == ost.samples and c.segments == ost.segments
         assert np.array_equal(g, o32)
     finally:

@@ -26,4 +26,4 @@ using namespace miw;
 #include "../mitsuba2_amd/csrc/device/phased_kernel.h"
 template __global__ void k_path_phased<MATS_PLAIN, false, MIW_PHASE_SPEC != 0>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #include "../mitsuba2_amd/csrc/device/stream_trace.h"
-template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 3, false>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
