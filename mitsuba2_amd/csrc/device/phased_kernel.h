@@ -33,14 +33,12 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 #ifndef MIW_PHASE_SPEC
 #define MIW_PHASE_SPEC 1
 #endif
+#ifndef MIW_TRI_PAIR
+#define MIW_TRI_PAIR 1              /* 1: the triangle body tests two triangles of a leaf range per iteration (both fetched up front: +2 - 4 %); 0: one */
+#endif
 #ifndef MIW_PHASE_END_WEIGHT
 #define MIW_PHASE_END_WEIGHT 4      /* the walk-end body is cheap: it runs once a quarter as many lanes wait for it as for the leading body */
 #endif
-#ifndef MIW_PHASE_SHADE_NUM
-#define MIW_PHASE_SHADE_NUM 1       /* shade runs once n_shade * NUM >= DEN * (lanes of the leading walk body) */
-#define MIW_PHASE_SHADE_DEN 1
-#endif
-
 // Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs, no spills) or 4 (128 VGPRs, a few spills in the shade body):
 // big trees, whose node fetches miss L2, gain more from the fourth wave's latency hiding than they lose to the spills.
 // Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h (the default) instead of the BVH2 (MIW_BVH4=0:
@@ -97,6 +95,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 #endif
     // lane predicates -> lane counts: ballot + s_bcnt1 (the builtin keeps the predicate in an SGPR pair)
     auto count = [](bool p) -> int { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); };
+    // shade once the shade-ready lanes outnumber the busier walk body num : den (host: 3 : 2, 2 : 1 with an environment map —
+    // a shade run costs ~2 200 instruction slots whatever its lane count, a walk step ~100 - 200, so shade runs are worth filling)
+    const int shade_num = (int) cfg.shade_num, shade_den = (int) cfg.shade_den;
 
     for (;;) {
         // ---- the vote: which lanes are ready for which body ----
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         if ((n_node | n_leaf | n_shade) == 0) break;
         const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
 
-        if (n_shade * MIW_PHASE_SHADE_NUM >= lead * MIW_PHASE_SHADE_DEN && n_shade > 0) {
+        if (n_shade * shade_num >= lead * shade_den && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             MIW_SECTION(6);                                              // everything since the last shade body: walks + votes
             if (e_shade) {
@@ -233,6 +234,32 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             do {
                 MIW_PS(1, count(e_leaf));
                 if (e_leaf) {
+#if MIW_TRI_PAIR
+                    // two triangles of the range per iteration: both records are fetched before either test runs (the second
+                    // address is clamped into the range, its test predicated), so a multi-triangle leaf costs one round trip
+                    // per pair; the tests run in range order, which is all the closest-hit / any-hit rules ask for
+                    const bool two = tri_i + 1u < tri_end;
+                    const Tri &tr = gtris[tri_i];
+                    const Tri &tr2 = gtris[two ? tri_i + 1u : tri_i];
+                    float t, u, v, t2, u2, v2;
+                    const bool hit1 = prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v);
+                    const bool hit2 = prim_intersect<Analytic>(tr2, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t2, u2, v2) && two;
+                    if (hit1 || hit2) {
+                        if (mode == PH_TRAV_S) {                         // any hit ends the shadow walk
+                            occluded = true; tri_end = 0; cur = MIW_WALK_DONE; sp = 0;
+                        } else {
+                            if (hit1 && (t < best.t || (t == best.t && tr.prim < best.prim))) {
+                                best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
+                                tmax = t;
+                            }
+                            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < best.prim))) {
+                                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u; best.prim = tr2.prim;
+                                tmax = t2;
+                            }
+                        }
+                    }
+                    tri_i += two ? 2u : 1u;
+#else
                     const Tri &tr = gtris[tri_i];
                     float t, u, v;
                     if (prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v)) {
@@ -244,6 +271,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         }
                     }
                     ++tri_i;
+#endif
                     if (tri_i >= tri_end && cur < 0 && cur != MIW_WALK_DONE) {   // range drained and the stack handed over another leaf
                         const uint32_t code = (uint32_t) ~cur;
                         tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;

@@ -12,6 +12,7 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t leaves;        // brute: number of LeafBox records staged behind the packets
     uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
     uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
+    uint32_t shade_num, shade_den;   // k_path_phased's shade vote: shade once n_shade * shade_num >= shade_den * (lanes of the busier walk body)
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.

@@ -954,8 +954,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 int ph_waves = c->view.tri_count >= 200000u ? 4 : 3;
                 if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
                 const dim3 phgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (unsigned) ph_waves));
-#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); \
-                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, c->lds_cfg, end, c->d_next_pixel.p)); } while (0)
+                // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the
+                // 4-wide tree (gpurun r2f / r2g, Msamples/s at 1 : 1 -> 3 : 2 -> 2 : 1): balls 844 -> 873 -> 860; interior with its
+                // environment-map lookups 338 -> 348 -> 361. MIW_SHADE_VOTE=num:den overrides (A/B runs).
+                TraceLds ph_cfg = c->lds_cfg;
+                ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
+                if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
+#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); \
+                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); } while (0)
                 if (phased) {
                     if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, false);
                     else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, true);

@@ -145,8 +145,9 @@ def main():
         out = [head, cmd % (" --scene %s --spp %d" % (key, spp), tag), "# %s — kernel_stats.csv verbatim" % title, stats(name), "",
                pmc_head, pmc_text(g, name), "",
                "# bench lines of the same session: phase machine (default) / lock-step resident kernel (MIW_PHASED=0) / wavefront plan with "
-               "the stream walk kernel (--plan 1) / phase machine over the BVH2 instead of the 4-wide tree (MIW_BVH4=0) / device LBVH (--bvh-quality 0)"]
-        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_lbvh"):
+               "the stream walk kernel (--plan 1) / phase machine over the BVH2 instead of the 4-wide tree (MIW_BVH4=0) / shade vote 1 : 1 instead of "
+               "3 : 2 (2 : 1 with an environment map) (MIW_SHADE_VOTE=1:1) / device LBVH (--bvh-quality 0)"]
+        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh"):
             if os.path.exists("%s_bench_%s%s.log" % (g, name, suffix)):
                 out.append(bench_line(g, "bench_%s%s" % (name, suffix), name + suffix))
         if name == "c3":

@@ -30,6 +30,7 @@ timeout 300 python bench.py --scene matball --spp 1024 --steps 1 --warmup 1 --no
 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --plan 1 > $out/${tag}_bench_c3_plan1.log 2>&1
 MIW_PHASED=0 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_lockstep.log 2>&1
 MIW_BVH4=0 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_bvh2.log 2>&1
+MIW_SHADE_VOTE=1:1 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_vote11.log 2>&1
 timeout 300 python bench.py --variant scalar_spectral --scene glassblock --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c5.log 2>&1
 timeout 300 python bench.py --variant scalar_spectral --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c5_diffuse.log 2>&1
 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4.log 2>&1
@@ -37,6 +38,7 @@ timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-
 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --plan 1 > $out/${tag}_bench_c4_plan1.log 2>&1
 MIW_PHASED=0 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4_lockstep.log 2>&1
 MIW_BVH4=0 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4_bvh2.log 2>&1
+MIW_SHADE_VOTE=1:1 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4_vote11.log 2>&1
 # the triangle-count series between the packet kernels (<= 64 triangles) and config 3 (icosphere levels 0..4 of the two balls)
 for t in 0 1 2 3 4; do timeout 200 python bench.py --scene matball --tess $t --spp 128 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_tess_$t.log 2>&1; done
 for so in 1 2 4 8; do timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shard tiles --shard-of $so > $out/${tag}_shard_$so.log 2>&1; done
