@@ -83,6 +83,26 @@ def test_bvh4_ties_and_degenerate_boxes(native, oracle):
             assert _same(brute, oracle.emu_trace4(desc, o, d, 0.0, np.inf, any_hit=any_hit, max_leaf=max_leaf), any_hit)
 
 
+def test_bvh4_big_tree_with_a_binding_stack_budget(native, oracle):
+    """A 348 k-triangle tree (the interior scene at a coarser grid) whose full collapse would need more stack than the device
+    has: the budget the device uses (MIW_STACK_ENTRIES - 1 = 31) binds, the fan-out degrades locally, the walk never goes
+    deeper than the bound, and the answers are brute force's."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.interior_scene(32, 32, 1, grid=96, device=-1, env_size=(32, 16))
+    desc = scene.desc()
+    o, d = _rays(desc, 400, 17)
+    loose = oracle.emu_trace4(desc, o, d, 1e-4, np.inf, stack_budget=64)["bvh4"]
+    for any_hit in (False, True):
+        brute = oracle.trace(desc, o, d, 1e-4, np.inf, any_hit=any_hit)
+        w = oracle.emu_trace4(desc, o, d, 1e-4, np.inf, any_hit=any_hit, stack_budget=31)
+        b = w["bvh4"]
+        assert b["ok"] == 1 and b["stack_seen"] <= b["stack_bound"] <= 31 < loose["stack_bound"]
+        assert b["nodes4"] > loose["nodes4"]                          # the budget cost some fan-out ...
+        assert b["nodes4"] < 0.62 * b["nodes2"]                       # ... but the tree is still about half the BVH2
+        assert _same(brute, w, any_hit)
+    assert np.isfinite(brute["t"]).sum() > 100
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
 @pytest.mark.parametrize("fan", ["4", "3", "2", "off"])
