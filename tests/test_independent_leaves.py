@@ -393,3 +393,70 @@ def test_surface_interaction_against_float64_restatement(native, oracle):
         assert _close(si["p"][i], P[a] * (1 - bary.sum()) + P[b] * bary[0] + P[c] * bary[1], 0, 2e-6)
         checked += 1
     assert checked > 200
+
+
+def test_environment_map_against_float64_restatement(native, oracle):
+    """EnvironmentMapEmitter (envmap.cpp): eval (:134-147, lat-long coordinates + the bilinear lookup of eval_spectrum
+    :269-320), pdf_direction (:192-208) with the density Hierarchical2D normalises in its constructor (distr_2d.h:372-440:
+    patch averages of luminance * sin(theta), summed in double) and sample_direction (:157-190) — whose warp is checked here
+    through what it must satisfy: the direction it returns carries exactly the density pdf_direction assigns to it, the value
+    is eval / pdf, the point lies two bounding-sphere radii away (set_scene, :127-131). The warp's own mapping is pinned by
+    the reference's spot values and a chi-square test (tests/test_oracle_kat.py)."""
+    from mitsuba2_amd import scenes
+    Wd, Hd = 48, 24
+    img = scenes.sky_envmap(Wd, Hd).astype(np.float64)
+    scale = 1.7
+    org, tgt, up = np.array([0.0, 0, 0]), np.array([0.3, 0.1, 1.0]), np.array([0.0, 1, 0])
+    fwd = (tgt - org) / np.linalg.norm(tgt - org)                                  # Transform::look_at, transform.h:241-258
+    left = np.cross(up, fwd); left /= np.linalg.norm(left)
+    R = np.stack([left, np.cross(fwd, left), fwd], 1)                              # columns: to_world's rotation
+    env = native.EnvMap(img.astype(np.float32), scale=scale, to_world=dict(origin=tuple(org), target=tuple(tgt), up=tuple(up)))
+    v = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2], [0, 3, 0]], np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2], [0, 1, 4]], np.uint32)
+    scene = native.Scene([native.Mesh("m", v, f, bsdf=native.BSDF("diffuse", reflectance=(0.5, 0.5, 0.5)))], envmap=env).build(-1)
+    lo, hi = v.astype(np.float64).min(0), v.astype(np.float64).max(0)
+    eps = 2.0 ** -24 * 1500
+    radius = max(eps, np.linalg.norm(0.5 * (lo + hi) - hi) * (1 + eps))             # bbox.h:329-332, envmap.cpp:127-131
+
+    lum = img[..., 0] * 0.212671 + img[..., 1] * 0.715160 + img[..., 2] * 0.072169    # mitsuba::luminance, spectrum.h
+    lum = lum.astype(np.float32).astype(np.float64)
+    sin_t = np.sin(np.arange(Hd) / (Hd - 1) * PI)
+    dens = lum * sin_t[:, None]
+    avg = 0.25 * (dens[:-1, :-1] + dens[:-1, 1:] + dens[1:, :-1] + dens[1:, 1:])
+    dens = dens * ((Wd - 1) * (Hd - 1) / avg.sum())
+
+    def bilinear(table, uv):
+        x, y = uv[0] * (Wd - 1), uv[1] * (Hd - 1)
+        px, py = min(int(x), Wd - 2), min(int(y), Hd - 2)
+        w1x, w1y = x - px, y - py
+        return ((1 - w1y) * ((1 - w1x) * table[py, px] + w1x * table[py, px + 1]) +
+                w1y * ((1 - w1x) * table[py + 1, px] + w1x * table[py + 1, px + 1]))
+
+    def to_uv(d_world):
+        dl = R.T @ d_world
+        uv = np.array([math.atan2(dl[0], -dl[2]) / (2 * PI), math.acos(max(-1.0, min(1.0, dl[1]))) / PI])
+        return uv - np.floor(uv), dl
+
+    rng = np.random.default_rng(31)
+    n = 400
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x = np.concatenate([d, rng.uniform(-1, 1, (n, 3)), rng.random((n, 2))], 1).astype(np.float32)
+    out = oracle.eval(9, x, scene.desc())
+    checked = 0
+    for xi, o in zip(x.astype(np.float64), out.astype(np.float64)):
+        uv, dl = to_uv(xi[0:3])
+        if min(uv[0], 1 - uv[0]) < 1e-3 or abs(dl[1]) > 0.999:
+            continue                                              # the atan2 seam / the poles (inv_sin_theta ill-conditioned)
+        inv_sin = 1 / math.sqrt(max(dl[0] ** 2 + dl[2] ** 2, (2.0 ** -24) ** 2))
+        assert _close(o[0:3], bilinear(img, uv) * scale, 3e-4, 1e-5), (xi[:3], uv, o[:3])            # eval
+        assert _close(o[3], bilinear(dens, uv) * inv_sin / (2 * PI * PI), 3e-4, 1e-7)                # pdf_direction
+        sd, dist, pdf, spec = o[4:7], o[7], o[8], o[9:12]                                             # sample_direction
+        assert abs(np.linalg.norm(sd) - 1) < 1e-5 and _close(dist, 2 * radius, 1e-6)
+        suv, sdl = to_uv(sd / np.linalg.norm(sd))
+        if min(suv[0], 1 - suv[0]) < 1e-3 or abs(sdl[1]) > 0.999 or pdf <= 0:
+            continue
+        s_inv_sin = 1 / math.sqrt(max(sdl[0] ** 2 + sdl[2] ** 2, (2.0 ** -24) ** 2))
+        assert _close(pdf, bilinear(dens, suv) * s_inv_sin / (2 * PI * PI), 2e-3, 1e-7), (xi[6:8], suv, pdf)
+        assert _close(spec * pdf, bilinear(img, suv) * scale, 2e-3, 1e-5)
+        checked += 1
+    assert checked > 300
