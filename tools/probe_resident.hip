@@ -1,0 +1,26 @@
+// ISA probe: only the C2 kernel, k_path_resident<true, 1, MATS_DIFFUSE...> (see tools/probe_phased.hip):
+//   cd /tmp/x && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -c -save-temps [-DMIW_CAND_PAIR=1] <repo>/tools/probe_resident.hip
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../include/miwave.h"
+#include "../mitsuba2_amd/csrc/miw/base.h"
+#include "../mitsuba2_amd/csrc/miw/rng.h"
+#include "../mitsuba2_amd/csrc/miw/warp.h"
+#include "../mitsuba2_amd/csrc/miw/special.h"
+#include "../mitsuba2_amd/csrc/miw/shape.h"
+#include "../mitsuba2_amd/csrc/miw/bsdf.h"
+#include "../mitsuba2_amd/csrc/miw/scene.h"
+#include "../mitsuba2_amd/csrc/miw/film.h"
+#include "../mitsuba2_amd/csrc/miw/bvh.h"
+#include "../mitsuba2_amd/csrc/miw/bvh4.h"
+#include "../mitsuba2_amd/csrc/miw/path.h"
+#include "../mitsuba2_amd/csrc/miw/direct.h"
+using namespace miw;
+#define MIW_BLOCK 256
+#define MIW_CNT_SHARDS 1024
+#include "../mitsuba2_amd/csrc/device/trace.h"
+#include "../mitsuba2_amd/csrc/device/wavefront_kernels.h"
+#include "../mitsuba2_amd/csrc/device/resident_kernel.h"
+template __global__ void k_path_resident<true, 1, 1, false, 0u>(RenderParams, SceneView, LaneQueues, double *, Counters *, TraceLds, unsigned int, TileArgs, unsigned int *);
