@@ -133,8 +133,6 @@ from conftest import has_gpu  # noqa: E402
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
 @pytest.mark.parametrize("name", ["tent", "mitchell", "catmullrom", "lanczos"])
-@pytest.mark.xfail(strict=False, reason="added after this round's last GPU session: first hardware run pending (tent / mitchell / catmullrom "
-                   "replay through the k_film_pack + k_film_groups path verified with box and gaussian tables, lanczos through k_film_blocks<wide>)")
 def test_device_film_with_every_filter(native, oracle, name):
     """the replay kernels take the filter as a table: k_film_pack + k_film_groups for footprints up to 4 x 4 texels,
     k_film_blocks for wider ones — bit-identical to ImageBlock::put's order for every table"""
