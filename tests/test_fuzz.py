@@ -32,13 +32,14 @@ def test_random_scenes_device_equals_scalar_restatement(native, oracle, seed):
     from mitsuba2_amd import scenes
     scene, sensor, ikw, recipe, keep = fuzz_cpu.make_case(native, scenes, seed)
     ikw.pop("samples_per_pass", None)
-    job = native.PathIntegrator(**ikw).render_job(sensor)
+    integ = native.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else native.PathIntegrator
+    job = integ(**ikw).render_job(sensor)
     o32, _, ost = oracle.render(scene.desc(), job, threads=os.cpu_count() or 8, want_f64=False)
     dev = native.Device(0)
     try:
         for quality in (1, 0):
             dev.upload(scene.desc(), bvh_quality=quality)
-            for plan in (2, 1):
+            for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):            # the direct integrator runs on the resident plan
                 g, st = dev.render(job, plan=plan)
                 c = dev.counters()
                 assert st == 0 and c.samples == ost.samples and c.segments == ost.segments, (seed, quality, plan, recipe)

@@ -6,10 +6,11 @@ stage functions in plain loops) against the scalar restatement of the reference 
 Every seed draws a scene (closed or open room, random blocks / spheres / rectangles / triangle soups with or without shading
 normals and texture coordinates, a random BSDF of every plugin on each of them, one to three area lights among meshes, spheres
 and rectangles, an optional environment map at a random position in the emitter order), a sensor (resolution, crop window,
-reconstruction filter, spp, seed) and an integrator (max_depth, rr_depth, samples_per_pass), renders it both ways and requires
+reconstruction filter, spp, seed) and an integrator (path: max_depth, rr_depth; direct: any split of emitter / BSDF samples,
+hide_emitters; samples_per_pass), renders it both ways and requires
 the float32 films to be bit-identical and the segment counts equal. The two sides share the leaf headers but not their control
-flow (queues, stage cuts, regeneration, film replay vs. one scalar loop), which is what this exercises; the tree walks behind
-both are checked against brute force on the same rays. A failing seed is reported with its recipe. Test infrastructure only.
+flow (queues, stage cuts, regeneration, film replay vs. one scalar loop), which is what this exercises; the tree walks (the
+stackless BVH2 walk and the 4-wide quantised tree of the phase machine) are checked against brute force on random rays. A failing seed is reported with its recipe. Test infrastructure only.
 """
 import argparse
 import os
@@ -142,7 +143,14 @@ def make_case(api, scenes, seed):
     eye = g.uniform(1.0, room - 1.0, 3); tgt = g.uniform(3.0, room - 3.0, 3)
     sensor = api.Sensor(film, sampler, fov=float(g.uniform(25, 95)),
                         to_world=dict(origin=tuple(float(x) for x in eye), target=tuple(float(x) for x in tgt), up=(0, 1, 0)))
-    ikw = dict(max_depth=int(g.choice([-1, -1, 1, 2, 3, 6])), rr_depth=int(g.choice([5, 5, 1, 2, 8])))
+    if g.random() < 0.2:                                                          # src/integrators/direct.cpp on the same stages
+        ikw = dict(integrator="direct", hide_emitters=bool(g.random() < 0.3))
+        if g.random() < 0.5:
+            ikw["shading_samples"] = int(g.integers(1, 4))
+        else:
+            ikw["emitter_samples"] = int(g.integers(0, 4)); ikw["bsdf_samples"] = int(g.integers(0 if ikw["emitter_samples"] else 1, 4))
+    else:
+        ikw = dict(max_depth=int(g.choice([-1, -1, 1, 2, 3, 6])), rr_depth=int(g.choice([5, 5, 1, 2, 8])))
     if spp % 2 == 0 and g.random() < 0.2:
         ikw["samples_per_pass"] = spp // 2
     recipe.append("film %dx%d %s %s spp %d; %s" % (W, H, film_kw, rfilter, spp, ikw))
@@ -151,7 +159,8 @@ def make_case(api, scenes, seed):
 
 def run_case(api, scenes, orc, seed):
     scene, sensor, ikw, recipe, keep = make_case(api, scenes, seed)
-    integ = api.PathIntegrator(**ikw)
+    ikw = dict(ikw)
+    integ = (api.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else api.PathIntegrator)(**ikw)
     passes = integ.pass_count(sensor)
     o_acc, e_acc = (None, None), (None, None)                    # (f32, f64) of the oracle, (f64, f32) of the emulator
     segs = [0, 0]
@@ -173,6 +182,9 @@ def run_case(api, scenes, orc, seed):
         a = orc.trace(scene.desc(), o, d, 1e-4, np.inf, any_hit=any_hit)
         b = orc.emu_trace(scene.desc(), o, d, 1e-4, np.inf, any_hit=any_hit)
         ok = ok and np.array_equal(np.asarray(a["t"]).view(np.uint32), np.asarray(b["t"]).view(np.uint32))
+        w = orc.emu_trace4(scene.desc(), o, d, 1e-4, np.inf, any_hit=any_hit, stack_budget=31)      # the 4-wide quantised tree
+        ok = ok and np.array_equal(np.asarray(a["t"]).view(np.uint32), np.asarray(w["t"]).view(np.uint32))
+        ok = ok and (any_hit or np.array_equal(a["prim"], w["prim"])) and w["bvh4"]["stack_seen"] <= w["bvh4"]["stack_bound"] <= 31
     return ok, recipe, segs
 
 
