@@ -7,7 +7,8 @@ Every seed draws a scene (closed or open room, random blocks / spheres / rectang
 normals and texture coordinates, a random BSDF of every plugin on each of them, one to three area lights among meshes, spheres
 and rectangles, an optional environment map at a random position in the emitter order), a sensor (resolution, crop window,
 reconstruction filter, spp, seed) and an integrator (path: max_depth, rr_depth; direct: any split of emitter / BSDF samples,
-hide_emitters; samples_per_pass), renders it both ways and requires
+hide_emitters; samples_per_pass; wavefront stages or the resident sample loop in launches of a few samples), renders it both
+ways and requires
 the float32 films to be bit-identical and the segment counts equal. The two sides share the leaf headers but not their control
 flow (queues, stage cuts, regeneration, film replay vs. one scalar loop), which is what this exercises; the tree walks (the
 stackless BVH2 walk and the 4-wide quantised tree of the phase machine) are checked against brute force on random rays. A failing seed is reported with its recipe. Test infrastructure only.
@@ -162,10 +163,15 @@ def run_case(api, scenes, orc, seed):
     ikw = dict(ikw)
     integ = (api.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else api.PathIntegrator)(**ikw)
     passes = integ.pass_count(sensor)
+    gp = np.random.default_rng(seed + 99)
+    plan2, per_launch = bool(gp.random() < 0.5), int(gp.integers(1, 9))
+    recipe.append("plan %s" % ("2, %d samples per launch" % per_launch if plan2 else "1"))
     o_acc, e_acc = (None, None), (None, None)                    # (f32, f64) of the oracle, (f64, f32) of the emulator
     segs = [0, 0]
     for p in range(passes):
         job = integ.render_job(sensor, pass_index=p)
+        if plan2:                                                  # the resident plan's per-pixel sample loop, advanced in launches
+            job.cfg.plan = 2; job.cfg.samples_per_launch = per_launch
         o32, o64, st = orc.render(scene.desc(), job, threads=2, onto=o_acc)
         e64, e32, est = orc.emu_render(scene.desc(), job, onto=e_acc)
         o_acc, e_acc = (o32, o64), (e64, e32)
