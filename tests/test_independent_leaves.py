@@ -460,3 +460,154 @@ def test_environment_map_against_float64_restatement(native, oracle):
         assert _close(spec * pdf, bilinear(img, suv) * scale, 2e-3, 1e-5)
         checked += 1
     assert checked > 300
+
+
+def fresnel_diffuse_reflectance(eta):
+    """render/fresnel.h:327-362"""
+    if eta < 1:
+        return -1.4399 * eta * eta + 0.7099 * eta + 0.6681 + 0.0636 / eta
+    i = 1 / eta
+    return 0.919317 - 3.4793 * i + 6.75335 * i ** 2 - 7.80989 * i ** 3 + 4.98554 * i ** 4 - 1.36881 * i ** 5
+
+
+@pytest.mark.parametrize("nonlinear", [False, True])
+def test_plastic_and_conductor_against_float64_restatement(native, oracle, nonlinear):
+    """plastic.cpp:161-290 (lobe choice by the Fresnel-weighted sampling weights of parameters_changed, :161-176; the diffuse
+    lobe's 1 / (1 - fdr_int * rho) with and without `nonlinear`) and the smooth conductor (conductor.cpp:216-262)."""
+    rho = np.array([0.55, 0.3, 0.12])
+    int_ior, ext_ior = 1.49, 1.000277
+    eta = int_ior / ext_ior
+    scene = _one_bsdf_scene(native, native.BSDF("plastic", diffuse_reflectance=tuple(rho), int_ior=int_ior, ext_ior=ext_ior, nonlinear=nonlinear))
+    x = _bsdf_inputs(np.random.default_rng(13), 700, upper=False)
+    out = oracle.eval(3, x, scene.desc())
+    fdr_int = fresnel_diffuse_reflectance(1 / eta)
+    ssw = 1.0 / (rho.mean() + 1.0)                               # specular sampling weight, s_mean = 1
+    inv_eta_2 = 1 / (eta * eta)
+    n_spec = n_diff = 0
+    for xi, o in zip(x.astype(np.float64), out.astype(np.float64)):
+        wi, s1, u2, wo = xi[1:4], xi[4], xi[5:7], xi[7:10]
+        f_i = fresnel(wi[2], eta)[0]
+        ps, pd_ = f_i * ssw, (1 - f_i) * (1 - ssw)
+        ps = ps / (ps + pd_)
+        diff = rho / (1 - (rho * fdr_int if nonlinear else fdr_int))
+        if wi[2] > 0 and wo[2] > 0:
+            f_o = fresnel(wo[2], eta)[0]
+            assert _close(o[9:12], diff * wo[2] / PI * inv_eta_2 * (1 - f_i) * (1 - f_o), 3e-5, 1e-8)       # eval
+            assert _close(o[12], wo[2] / PI * (1 - ps), 3e-5, 1e-8)                                            # pdf
+        else:
+            assert not o[9:13].any()
+        if wi[2] <= 0:
+            assert not o[6:9].any()
+            continue
+        if abs(s1 - ps) < 1e-4:
+            continue
+        if s1 < ps:
+            assert _close(o[0:3], [-wi[0], -wi[1], wi[2]], 0, 1e-7) and _close(o[3], ps, 3e-5) and _close(o[6:9], [f_i / ps] * 3, 3e-5)
+            n_spec += 1
+        elif abs(abs(2 * u2[0] - 1) - abs(2 * u2[1] - 1)) > 1e-3:
+            s = cosine_hemisphere(u2)
+            f_o = fresnel(s[2], eta)[0]
+            assert _close(o[0:3], s, 0, 3e-6) and _close(o[3], (1 - ps) * s[2] / PI, 3e-5, 2e-6)
+            assert _close(o[6:9], diff * inv_eta_2 * (1 - f_i) * (1 - f_o) / (1 - ps), 1e-4, 1e-7)
+            n_diff += 1
+    assert n_spec > 10 and n_diff > 150
+    if nonlinear:
+        return
+    eta_c, k_c = np.array([0.2, 0.92, 1.1]), np.array([3.9, 2.45, 2.14])
+    scene = _one_bsdf_scene(native, native.BSDF("conductor", eta=tuple(eta_c), k=tuple(k_c)))
+    x = _bsdf_inputs(np.random.default_rng(14), 300, upper=False)
+    out = oracle.eval(3, x, scene.desc())
+    for xi, o in zip(x.astype(np.float64), out.astype(np.float64)):
+        wi = xi[1:4]
+        assert not o[9:13].any()                                 # a delta lobe: eval = pdf = 0
+        if wi[2] > 0:
+            assert _close(o[0:3], [-wi[0], -wi[1], wi[2]], 0, 1e-7) and o[3] == 1.0 and o[4] == 1.0
+            assert _close(o[6:9], fresnel_conductor(wi[2], eta_c, k_c), 3e-5)
+        else:
+            assert not o[6:9].any()
+
+
+def roughdielectric(kind, au, av, visible, eta, wi, s1, u2, wo_eval):
+    """roughdielectric.cpp:203-310 (sample), :312-390 (eval), :392-447 (pdf); TransportMode::Radiance, both lobes enabled"""
+    ms = lambda v, s: v if s >= 0 else -v                         # enoki::mulsign on vectors / scalars
+    d = Microfacet(kind, au, av, visible)
+    ci = wi[2]
+    out_s = None
+    if ci != 0:
+        sd = Microfacet(kind, au, av, visible)
+        if not visible:
+            k = 1.2 - 0.2 * math.sqrt(abs(ci))
+            sd.au, sd.av = sd.au * k, sd.av * k                  # scale_alpha, microfacet.h:173-176
+        m, pdf = sd.sample(ms(wi, ci), u2)
+        if pdf != 0:
+            F, cos_t, eta_it, eta_ti = fresnel(float(np.dot(wi, m)), eta)
+            if s1 <= F:
+                wo = 2 * np.dot(wi, m) * m - wi
+                pdf *= F; bs_eta = 1.0; w = 1.0
+                dwh = 1 / (4 * np.dot(wo, m))
+            else:
+                wo = m * (np.dot(wi, m) * eta_ti + cos_t) - wi * eta_ti
+                pdf *= 1 - F; bs_eta = eta_it; w = eta_ti * eta_ti
+                dwh = (bs_eta ** 2 * np.dot(wo, m)) / (np.dot(wi, m) + bs_eta * np.dot(wo, m)) ** 2
+            w *= d.g1(wo, m) if visible else d.G(wi, wo, m) * np.dot(wi, m) / (ci * m[2])
+            out_s = (wo, pdf * abs(dwh), bs_eta, w, F)
+    ev = pd = 0.0
+    co = wo_eval[2]
+    if ci != 0:
+        refl = ci * co > 0
+        e, inv_e = (eta, 1 / eta) if ci > 0 else (1 / eta, eta)
+        m = wi + wo_eval * (1.0 if refl else e)
+        m /= np.linalg.norm(m)
+        m = ms(m, m[2])
+        D = d.eval(m)
+        F = fresnel(float(np.dot(wi, m)), eta)[0]
+        G = d.G(wi, wo_eval, m)
+        if refl:
+            ev = F * D * G / (4 * abs(ci))
+        else:
+            ev = abs((inv_e ** 2 * (1 - F) * D * G * e * e * np.dot(wi, m) * np.dot(wo_eval, m)) /
+                     (ci * (np.dot(wi, m) + e * np.dot(wo_eval, m)) ** 2))
+        if np.dot(wi, m) * ci > 0 and np.dot(wo_eval, m) * co > 0:
+            dwh = 1 / (4 * np.dot(wo_eval, m)) if refl else (e * e * np.dot(wo_eval, m)) / (np.dot(wi, m) + e * np.dot(wo_eval, m)) ** 2
+            sd = Microfacet(kind, au, av, visible)
+            if not visible:
+                k = 1.2 - 0.2 * math.sqrt(abs(ci))
+                sd.au, sd.av = sd.au * k, sd.av * k
+            pd = sd.pdf(ms(wi, ci), m) * (F if refl else 1 - F) * abs(dwh)
+    return out_s, ev, pd
+
+
+@pytest.mark.parametrize("kw", [
+    dict(distribution="ggx", alpha=0.2),
+    dict(distribution="ggx", alpha_u=0.1, alpha_v=0.35, sample_visible=False),
+    dict(distribution="beckmann", alpha=0.3, sample_visible=False),
+])
+def test_roughdielectric_against_float64_restatement(native, oracle, kw):
+    """roughdielectric.cpp: reflection and transmission lobes from both sides, the half-vector Jacobians, Walter's roughness
+    scaling for plain sampling, the solid-angle compression factor (Beckmann's visible-normal inversion excepted, as above)."""
+    int_ior, ext_ior = 1.5046, 1.000277
+    eta = int_ior / ext_ior
+    scene = _one_bsdf_scene(native, native.BSDF("roughdielectric", int_ior=int_ior, ext_ior=ext_ior, **kw))
+    x = _bsdf_inputs(np.random.default_rng(23), 900, upper=False)
+    x[np.abs(x[:, 3]) < 0.05, 3] = 0.3                           # keep wi off the horizon (pdfs blow up there)
+    x[:, 1:4] /= np.linalg.norm(x[:, 1:4], axis=1, keepdims=True)
+    out = oracle.eval(3, x, scene.desc())
+    au, av = kw.get("alpha_u", kw.get("alpha")), kw.get("alpha_v", kw.get("alpha"))
+    vis = kw.get("sample_visible", True)
+    n_r = n_t = n_ev = 0
+    for xi, o in zip(x.astype(np.float64), out.astype(np.float64)):
+        wi, s1, u2, wo = xi[1:4], xi[4], xi[5:7], xi[7:10]
+        if min(u2[0], 1 - u2[0], abs(abs(2 * u2[0] - 1) - abs(2 * u2[1] - 1))) < 1e-3 or abs(abs(u2[1] - 0.5) - 0.25) < 1e-3:
+            continue
+        smp, ev, pd = roughdielectric(kw["distribution"], au, av, vis, eta, wi, s1, u2, wo)
+        if abs(wo[2]) > 0.02:
+            assert _close(o[9], ev, 5e-4, 1e-6) and _close(o[12], pd, 5e-4, 1e-6), (kw, wi, wo, o[9:13], ev, pd)
+            n_ev += ev > 0
+        if smp is None:
+            continue
+        s_wo, s_pdf, s_eta, s_w, F = smp
+        if abs(s1 - F) < 1e-3 or s_pdf < 1e-3 or abs(s_wo[2]) < 1e-2 or s_w == 0:
+            continue
+        assert _close(o[0:3], s_wo, 0, 3e-4) and _close(o[3], s_pdf, 2e-3) and _close(o[4], s_eta, 1e-6) and _close(o[6:9], [s_w] * 3, 1e-3, 1e-6), (kw, wi, s1, u2, o[:9], smp)
+        n_r += s_eta == 1.0; n_t += s_eta != 1.0
+    assert n_r > 30 and n_t > 200 and n_ev > 300
