@@ -1,0 +1,59 @@
+"""Device counterpart of tools/fuzz_cpu.py: the recipes of the CPU fuzzer rendered on the GPU (both tree builders, both plans)
+against the scalar restatement. Run by hand on a GPU box:
+
+    python tools/fuzz_gpu.py [--seeds 20] [--first 0]
+
+Written after round 2's GPU budget was spent and therefore NOT part of the `-m gpu` tier yet: promote a sample of it to
+tests/test_fuzz.py once it has been seen green on hardware. Test infrastructure only.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=20)
+    ap.add_argument("--first", type=int, default=0)
+    a = ap.parse_args()
+    from mitsuba2_amd import api, scenes, build
+    build.build_all(oracle=True)
+    api.host_lib()
+    import fuzz_cpu
+    import oracle_py
+    orc = oracle_py.load()
+    bad = 0
+    dev = api.Device(0)
+    for seed in range(a.first, a.first + a.seeds):
+        try:
+            scene, sensor, ikw, recipe, keep = fuzz_cpu.make_case(api, scenes, seed)
+        except Exception as e:
+            print("seed %d: recipe rejected: %s" % (seed, str(e)[:120])); continue
+        ikw = dict(ikw); ikw.pop("samples_per_pass", None)
+        integ = api.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else api.PathIntegrator
+        job = integ(**ikw).render_job(sensor)
+        o32, _, ost = orc.render(scene.desc(), job, threads=os.cpu_count() or 8, want_f64=False)
+        for quality in (1, 0):
+            dev.upload(scene.desc(), bvh_quality=quality)
+            for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):     # the direct integrator runs on the resident plan
+                g, st = dev.render(job, plan=plan)
+                c = dev.counters()
+                ok = st == 0 and c.samples == ost.samples and c.segments == ost.segments and np.array_equal(g, o32)
+                if not ok:
+                    bad += 1
+                    print("seed %d MISMATCH (bvh quality %d, plan %d, status %d, segments %d vs %d)\n    %s" %
+                          (seed, quality, plan, st, c.segments, ost.segments, "\n    ".join(recipe)))
+    dev.close()
+    print("%d seeds, %d mismatches" % (a.seeds, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
