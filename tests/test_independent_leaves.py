@@ -611,3 +611,65 @@ def test_roughdielectric_against_float64_restatement(native, oracle, kw):
         assert _close(o[0:3], s_wo, 0, 3e-4) and _close(o[3], s_pdf, 2e-3) and _close(o[4], s_eta, 1e-6) and _close(o[6:9], [s_w] * 3, 1e-3, 1e-6), (kw, wi, s1, u2, o[:9], smp)
         n_r += s_eta == 1.0; n_t += s_eta != 1.0
     assert n_r > 30 and n_t > 200 and n_ev > 300
+
+
+def _reference_tables():
+    """CIE 1931 (src/libcore/spectrum.cpp:110-186, 95 samples x 3, 360 - 830 nm) and D65 (src/spectra/d65.cpp:12-25), parsed from
+    the reference's sources where they lie — this test runs only where /root/reference exists (the CPU tier's box)."""
+    import os
+    import re
+    ref = "/root/reference"
+    if not os.path.exists(ref + "/src/libcore/spectrum.cpp"):
+        pytest.skip("the reference tree is not on this box")
+    num = r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?"
+    txt = open(ref + "/src/libcore/spectrum.cpp").read()
+    body = txt[txt.index("cie1931_tbl[MTS_CIE_SAMPLES * 3] = {"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    cie = np.array([float(x) for x in re.findall(num, re.sub(r"(?<=\d)f", "", body))]).reshape(3, 95)
+    txt = open(ref + "/src/spectra/d65.cpp").read()
+    body = txt[txt.index("const float data[95] = {"):]
+    body = body[body.index("{") + 1:body.index("};")]
+    d65 = np.array([float(x) for x in re.findall(num, re.sub(r"(?<=\d)f", "", body))])
+    assert cie.shape == (3, 95) and d65.shape == (95,)
+    return cie, d65
+
+
+def test_spectral_leaves_against_float64_restatement(native, oracle_spectral):
+    """scalar_spectral (config 5): sample_shifted (math.h:419-442) + sample_rgb_spectrum (spectrum.h:271-285), srgb_model_eval
+    (srgb.h:9-23), the srgb_d65 emitter spectrum = the upsampled colour times the D65 table (srgb_d65.cpp:56-62, d65.cpp:50-66,
+    `regular`'s linear interpolation distr_1d.h:378-392) and spectrum_to_xyz over the CIE 1931 table (spectrum.h:147-217) —
+    with both tables read from the reference's sources, not from the product's generated header."""
+    cie, d65 = _reference_tables()
+
+    def lerp_table(tab, lam):
+        t = (lam - 360.0) * (94 / 470.0)
+        i = int(min(max(int(t), 0), 93))
+        return (1 - (t - i)) * tab[i] + (t - i) * tab[i + 1] if 360.0 <= lam <= 830.0 else 0.0
+
+    rng = np.random.default_rng(41)
+    n = 300
+    x = np.zeros((n, 5), np.float32)
+    x[:, 0] = rng.random(n)
+    x[:, 1] = rng.normal(0, 2e-5, n); x[:, 2] = rng.normal(0, 2e-2, n); x[:, 3] = rng.normal(0, 3.0, n)   # sigmoid-polynomial coefficients
+    x[:, 4] = rng.uniform(0.2, 30.0, n) / 10568.0                                                          # D65Spectrum::m_scale (d65.cpp:54-55: scale / 10568; the host folds it into the record)
+    out = oracle_spectral.eval(11, x).astype(np.float64)
+    for xi, o in zip(x.astype(np.float64), out):
+        u, c0, c1, c2, scale = xi
+        for k in range(4):
+            s = u + k / 4.0
+            if s > 1:
+                s -= 1
+            if min(s, 1 - s) < 1e-3:
+                continue                                          # atanh's argument near its poles
+            lam = 538.0 - math.atanh(0.8569106254698279 - 1.8275019724092267 * s) * 138.88888888888889
+            wgt = 253.82 * math.cosh(0.0072 * (lam - 538.0)) ** 2
+            assert _close(o[k], lam, 3e-6) and _close(o[4 + k], wgt, 3e-5), (u, k, o[k], lam)
+            lam32 = o[k]                                          # evaluate the spectra at the wavelength the float32 code drew
+            v = (c0 * lam32 + c1) * lam32 + c2
+            srgb = max(0.0, 0.5 * v / math.sqrt(v * v + 1) + 0.5)
+            assert _close(o[8 + k], srgb, 2e-4, 2e-6), (c0, c1, c2, lam32, o[8 + k], srgb)
+            # (the sigmoid cancels badly for very negative v: the D65 factor is checked on the float32 colour the line above accepted)
+            assert _close(o[12 + k], o[8 + k] * lerp_table(d65, lam32) * scale, 2e-5, 1e-12)
+        lam4, w4, sd4 = o[0:4], o[4:8], o[12:16]
+        xyz = [np.mean([lerp_table(cie[c], lam4[k]) * w4[k] * sd4[k] for k in range(4)]) for c in range(3)]
+        assert _close(o[16:19], xyz, 2e-5, 1e-12)
