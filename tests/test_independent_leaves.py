@@ -673,3 +673,81 @@ def test_spectral_leaves_against_float64_restatement(native, oracle_spectral):
         lam4, w4, sd4 = o[0:4], o[4:8], o[12:16]
         xyz = [np.mean([lerp_table(cie[c], lam4[k]) * w4[k] * sd4[k] for k in range(4)]) for c in range(3)]
         assert _close(o[16:19], xyz, 2e-5, 1e-12)
+
+
+def hier2d_build(data):
+    """Hierarchical2D<Float, 0> constructor, distr_2d.h:372-462 -> levels[0] = normalised data, levels[1..] = MIP hierarchy"""
+    h, w = data.shape
+    ny, nx = h - 1, w - 1
+    avg = 0.25 * (data[:-1, :-1] + data[:-1, 1:] + data[1:, :-1] + data[1:, 1:])
+    scale = nx * ny / avg.sum()
+    levels = [data * scale]
+
+    def pad(a):
+        return np.pad(a, ((0, a.shape[0] & 1), (0, a.shape[1] & 1)))
+    cur = pad(avg * scale)
+    levels.append(cur)
+    max_level = int(math.ceil(math.log2(max(nx, ny)))) if max(nx, ny) > 1 else 0
+    for _ in range(2, max_level + 2):
+        nxt = cur[0::2, 0::2] + cur[0::2, 1::2] + cur[1::2, 0::2] + cur[1::2, 1::2]
+        cur = pad(nxt) if max(nxt.shape) > 1 else nxt
+        levels.append(cur)
+    return levels, (nx, ny)
+
+
+def hier2d_sample(levels, npatch, u):
+    """Hierarchical2D::sample, distr_2d.h:473-556 + warp::square_to_bilinear / interval_to_linear, warp.h:359-407"""
+    sx, sy = min(max(u[0], 0.0), 1.0), min(max(u[1], 0.0), 1.0)
+    ox = oy = 0
+    for l in range(len(levels) - 2, 0, -1):
+        lv = levels[l]
+        ox, oy = ox * 2, oy * 2
+        # the four entries the reference fetches are consecutive in ITS storage (2 x 2 blocks, Level::index); here by coordinates
+        v00, v10, v01, v11 = lv[oy, ox], lv[oy, ox + 1], lv[oy + 1, ox], lv[oy + 1, ox + 1]
+        sx, sy = min(max(sx, 0.0), 1.0), min(max(sy, 0.0), 1.0)
+        r0, r1 = v00 + v10, v01 + v11
+        sy *= r0 + r1
+        m = sy > r0
+        if m:
+            oy += 1; sy -= r0
+        sy /= r1 if m else r0
+        c0, c1 = (v01, v11) if m else (v00, v10)
+        sx *= c0 + c1
+        m = sx > c0
+        if m:
+            sx -= c0; ox += 1
+        sx /= c1 if m else c0
+    d = levels[0]
+    v00, v10, v01, v11 = d[oy, ox], d[oy, ox + 1], d[oy + 1, ox], d[oy + 1, ox + 1]
+
+    def i2l(v0, v1, s):
+        if abs(v0 - v1) > 1e-4 * (v0 + v1):
+            return (v0 - math.sqrt(max(0.0, v0 * v0 + (v1 * v1 - v0 * v0) * s))) / (v0 - v1)
+        return s
+    r0, r1 = v00 + v10, v01 + v11
+    sy = i2l(r0, r1, sy)
+    c0, c1 = v00 + (v01 - v00) * sy, v10 + (v11 - v10) * sy
+    sx = i2l(c0, c1, sx)
+    return (ox + sx) / npatch[0], (oy + sy) / npatch[1], c0 + (c1 - c0) * sx
+
+
+@pytest.mark.parametrize("shape", [(5, 7), (2, 2), (9, 4), (17, 33)])
+def test_hierarchical2d_sample_against_float64_restatement(oracle, shape):
+    """The warp the environment map is sampled with: the MIP hierarchy of patch averages (zero-padded to even sizes) and the
+    top-down row / column selection of Hierarchical2D::sample, then the bilinear patch — odd and even sizes, the 1-patch case."""
+    import ctypes as C
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    data = (rng.random(shape) * 10 + 0.05).astype(np.float32)
+    levels, npatch = hier2d_build(data.astype(np.float64))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    checked = 0
+    for u in rng.random((300, 2)):
+        xy = np.array(u, np.float32); out = np.zeros(3, np.float32)
+        assert oracle.L.orc_hier2d(fp(data), shape[1], shape[0], 0, fp(xy), fp(out)) == 0
+        x, y, pdf = hier2d_sample(levels, npatch, xy.astype(np.float64))
+        # a sample within float32 rounding of a row / column boundary may legitimately fall on the other side
+        if abs(x * npatch[0] - round(x * npatch[0])) < 2e-3 or abs(y * npatch[1] - round(y * npatch[1])) < 2e-3:
+            continue
+        assert _close(out[0:2], [x, y], 0, 3e-5) and _close(out[2], pdf, 3e-4), (shape, u, out, (x, y, pdf))
+        checked += 1
+    assert checked > 200
