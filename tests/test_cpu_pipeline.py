@@ -475,3 +475,29 @@ def test_shard_mode_selection_and_pass_jobs(native):
             c = job.cfg
             assert (c.spp, c.accumulate, c.tile_count, c.block_count) == (2, 0, 0, one.cfg.block_count)
             assert np.array_equal(job.block_ids[:c.block_count], one.block_ids[:c.block_count] + (3 - rank) * c.block_count)   # spiral.cpp:41
+
+
+def test_golden_digests_of_round2(native, oracle):
+    """tests/golden/round2.json: film digests + segment counts of the scene classes and plugins the .npz fixtures do not cover
+    and of twelve fuzz recipes (tests/golden/make_golden_r2.py). The oracle and the device share their leaf headers: an
+    accidental leaf edit moves both, and only a committed answer notices."""
+    import json
+    sys.path.insert(0, GOLDEN)
+    import make_golden_r2 as mk
+    from mitsuba2_amd import scenes
+    want = json.load(open(os.path.join(GOLDEN, "round2.json")))
+    got = mk.compute(native, scenes, oracle, mk.rgb_cases(native, scenes))
+    assert len(got) == 21
+    for key, rec in got.items():
+        assert rec["sha256"] == want[key]["sha256"] and rec["segments"] == want[key]["segments"], (key, rec, want[key])
+
+
+def test_golden_digest_of_the_spectral_glass_block(spectral, oracle_spectral):
+    import json
+    sys.path.insert(0, GOLDEN)
+    import make_golden_r2 as mk
+    from mitsuba2_amd import scenes
+    want = json.load(open(os.path.join(GOLDEN, "round2.json")))
+    got = mk.compute(spectral, scenes, oracle_spectral, mk.spectral_cases(spectral, scenes))
+    for key, rec in got.items():
+        assert rec["sha256"] == want[key]["sha256"] and rec["segments"] == want[key]["segments"], (key, rec, want[key])

@@ -72,6 +72,8 @@ def box_mesh(lo, hi):
 
 
 def make_case(api, scenes, seed):
+    """-> scene, sensor, integrator kwargs, recipe lines, objects to keep alive. Twelve seeds of this draw are pinned as film digests
+    in tests/golden/round2.json: after changing the draw, rerun tests/golden/make_golden_r2.py."""
     g = np.random.default_rng(seed)
     recipe = []
     shapes = []
