@@ -101,6 +101,45 @@ MIW_HD void block_splat(const FilmRec &f, int off_x, int off_y, int bw, int bh, 
     }
 }
 
+// ---- phase classes: what ImageBlock::put derives from a sample's position, in one byte per axis ----------------------
+// Everything put() computes from the position of a sample (imageblock.cpp:114-146: lo, the footprint, the discretised
+// weight indices) depends, per axis, only on the sample's PHASE phi = pos - (block-local texel coordinate of its pixel),
+// a multiple of 2^-23 in [-.5, .5] — under the guards of film_classes.h (radius a multiple of 1/2, border >= reach: nothing
+// is clipped, every subtraction on the way is exact). It is a step function of phi with ~70 steps (r = 2; each of the n
+// weight indices moves through ~16 LUT bins as the sample crosses its pixel), so the host enumerates it once per filter
+// (film_classes.h: all 2^23 + 1 phases through the reference's own float expressions) into
+//   thr[256]     ascending phase thresholds: class c = [thr[c], thr[c + 1]); +inf beyond the last class
+//   w[256][8]    w[c][a] = the weight put() gives texel (pixel's texel - reach + a), 0 outside the footprint;
+//                row 255 = 0 (rejected sample)
+// and the render kernels log 16 bytes per sample — X, Y, Z, class_x | class_y << 8 | alpha << 16 — instead of 8 bytes of
+// position + 16 of value; the film replay looks the two weights up in its LDS copy of w. Same float32 products and
+// sums as block_splat() above, texel for texel (tests/test_film_classes.py; every film parity test runs through it).
+#define MIW_FC_CLASSES 256
+#define MIW_FC_STRIDE 8
+#define MIW_FC_REJECTED 255u
+struct FilmClassView {
+    const float *thr;                   // [256]
+    const float *w;                     // [256][8]
+    uint32_t count;                     // classes in use (<= 255)
+    int32_t reach;                      // texels a footprint extends to the left of its pixel's texel (2 for r = 2, 1 for box)
+};
+// :114 for one axis, then the phase. pixel = film coordinate of the sample's pixel (crop offset included).
+MIW_HD float film_phase(const FilmRec &f, float pos, int pixel, int crop_off) {
+    const int local = pixel - crop_off, b0 = local & ~(f.block_size - 1);          // block_size is a power of two (mi_render checks)
+    const float p = pos - ((float) (b0 + crop_off - f.border) + .5f);              // block-local position, as block_splat
+    return p - (float) (local - b0 + f.border);                                    // exact: both multiples of ulp(p), |result| <= .5
+}
+template <typename Thr>
+MIW_HD uint32_t film_class_of(Thr thr, float phi) {
+    uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t step = 128u; step; step >>= 1) c += (phi >= thr[c + step]) ? step : 0u;
+    return c;
+}
+MIW_HD uint32_t film_pack_meta(uint32_t cx, uint32_t cy, bool alpha) { return cx | (cy << 8) | (alpha ? 1u << 16 : 0u); }
+
 // The spiral block a pixel belongs to (spiral.cpp:43-45): bordered-block origin and clipped size
 MIW_HD void block_of_pixel(const FilmRec &f, int px, int py, int &bx, int &by, int &bw, int &bh) {
     bx = ((px - f.crop_x) / f.block_size) * f.block_size;

@@ -72,7 +72,19 @@ struct FtzScope {
     ~FtzScope() { _mm_setcsr(csr); }
 };
 
-// ---- scene in scene order (no acceleration structure: brute force) ------------------------
+// ---- scene in scene order. Scene queries are brute force by definition; orc_set_accel(1) routes them through the
+// checker's OWN spatial index below (OAccel), which exists only so that the configured sizes of BASELINE configs 3 / 4 (a
+// 128x128 window at 1024 spp over 41 k triangles, 2048 spp over 0.9 M) finish in minutes on the host. It shares nothing with
+// the product's builders or walks (csrc/bvh_build.h, miw/bvh.h, miw/bvh4.h): median splits, float64 slab arithmetic, and the
+// SAME leaf test as the brute-force loop (prim_intersect, min t, ties to the smaller primitive id). It must return brute
+// force's answer bit for bit: tests/test_oracle_accel.py (random, axis-parallel, in-plane and edge-grazing rays; films).
+struct OAccelNode { double lo[3], hi[3]; uint32_t left, right, first, count; };   // count > 0: leaf over prims[first, first + count)
+struct OAccel {
+    std::vector<OAccelNode> nodes; std::vector<uint32_t> prims; std::vector<uint32_t> always;   // always: analytic primitives (tested on every query)
+    bool on = false;
+};
+std::atomic<int> g_accel{0};
+
 struct OScene {
     std::vector<Tri> tris;              // face order == global primitive id; pad = k + 1: the slot of analytic rectangle k
     std::vector<AnalyticRec> rects;         // analytic rectangles (src/shapes/rectangle.cpp)
@@ -85,7 +97,80 @@ struct OScene {
     std::vector<float> emit_tri, emit_vnorm, emit_pmf, emit_cdf;
     EnvmapTables env;                   // environment emitter (scene.cpp:47-51) or !ok
     SceneView view{};
+    OAccel accel;
 };
+
+// Why the index cannot lose a hit brute force counts: a triangle hit counts only if fl(o + t d) lies inside the triangle's
+// vertex bounds grown by accept_pad (shape.h, the accept rule); the exact point o + t d is within a few ulps of the scene
+// extent of that float point, i.e. well inside the bounds grown by 2 x accept_pad — the boxes used here. The slab interval
+// of such a box, computed in float64 from the float inputs (relative error 1e-16, slack 1e-9 below), therefore contains t,
+// and t also lies in [mint, min(maxt, best t so far)]: a node is skipped only when its interval misses that range.
+// (-DMIW_ACCEPT_RULE=0 builds have no such bound: there the index is refused, orc_render falls back to brute force.)
+void accel_build(OScene &o) {
+    OAccel &A = o.accel;
+    A.nodes.clear(); A.prims.clear(); A.always.clear(); A.on = false;
+#if !MIW_ACCEPT_RULE
+    return;
+#endif
+    const double pad = 2.0 * (double) o.view.accept_pad;
+    const size_t n = o.tris.size();
+    std::vector<double> blo(3 * n), bhi(3 * n), cen(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const Tri &t = o.tris[i];
+        if (t.pad) { A.always.push_back((uint32_t) i); continue; }
+        for (int a = 0; a < 3; ++a) {
+            const double x0 = t.p0[a], x1 = t.p1[a], x2 = t.p2[a];
+            blo[3 * i + a] = std::min(x0, std::min(x1, x2)) - pad; bhi[3 * i + a] = std::max(x0, std::max(x1, x2)) + pad;
+            cen[3 * i + a] = (x0 + x1 + x2) / 3.0;
+        }
+        A.prims.push_back((uint32_t) i);
+    }
+    if (A.prims.empty()) { A.on = true; return; }
+    struct Job { uint32_t node, first, count; };
+    std::vector<Job> todo;
+    A.nodes.push_back(OAccelNode{});
+    todo.push_back({ 0u, 0u, (uint32_t) A.prims.size() });
+    while (!todo.empty()) {
+        const Job j = todo.back(); todo.pop_back();
+        OAccelNode nd{};
+        double clo[3] = { 1e300, 1e300, 1e300 }, chi[3] = { -1e300, -1e300, -1e300 };
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = 1e300; nd.hi[a] = -1e300; }
+        for (uint32_t k = j.first; k < j.first + j.count; ++k) {
+            const uint32_t i = A.prims[k];
+            for (int a = 0; a < 3; ++a) {
+                nd.lo[a] = std::min(nd.lo[a], blo[3 * i + a]); nd.hi[a] = std::max(nd.hi[a], bhi[3 * i + a]);
+                clo[a] = std::min(clo[a], cen[3 * i + a]); chi[a] = std::max(chi[a], cen[3 * i + a]);
+            }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        if (j.count <= 4u || !(chi[axis] > clo[axis])) {         // few primitives, or all centroids coincide: a leaf
+            nd.first = j.first; nd.count = j.count;
+            A.nodes[j.node] = nd;
+            continue;
+        }
+        const uint32_t half = j.count / 2u;
+        std::nth_element(A.prims.begin() + j.first, A.prims.begin() + j.first + half, A.prims.begin() + j.first + j.count,
+                         [&](uint32_t x, uint32_t y) { const double cx = cen[3 * x + axis], cy = cen[3 * y + axis]; return cx < cy || (cx == cy && x < y); });
+        nd.count = 0; nd.left = (uint32_t) A.nodes.size(); nd.right = nd.left + 1u;
+        A.nodes.push_back(OAccelNode{}); A.nodes.push_back(OAccelNode{});
+        A.nodes[j.node] = nd;
+        todo.push_back({ nd.left, j.first, half });
+        todo.push_back({ nd.right, j.first + half, j.count - half });
+    }
+    A.on = true;
+}
+// slab interval of a box for the ray (float inputs, float64 arithmetic); false: the ray misses the box
+inline bool accel_slab(const OAccelNode &nd, const double o[3], const double d[3], double &tn, double &tf) {
+    tn = -1e300; tf = 1e300;
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] == 0.0) { if (o[a] < nd.lo[a] || o[a] > nd.hi[a]) return false; continue; }
+        double t0 = (nd.lo[a] - o[a]) / d[a], t1 = (nd.hi[a] - o[a]) / d[a];
+        if (t0 > t1) std::swap(t0, t1);
+        tn = std::max(tn, t0); tf = std::min(tf, t1);
+    }
+    return true;
+}
 
 bool build_scene(const mi_scene_desc *s, OScene &o) {
     o.tris.assign(s->face_count, Tri{});
@@ -201,6 +286,8 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
+    o.accel.on = false;
+    if (g_accel.load()) accel_build(o);
     return true;
 }
 
@@ -209,7 +296,50 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
 // rule (smaller global primitive id) is this code base's definition.
 struct OHit { bool valid; float t, u, v; uint32_t prim; };
 
+// the indexed form of the two loops below: same leaf test, same closest / tie rule; visits only what the ray can reach
+template <bool Any>
+OHit accel_query(const OScene &sc, const Ray &ray) {
+    OHit best{ false, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0xffffffffu };
+    const OAccel &A = sc.accel;
+    const PrimCtx ctx = prim_ctx(sc.view);
+    auto test = [&](uint32_t i) -> bool {
+        float t, u, v;
+        if (prim_intersect(sc.tris[i], ctx, ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) {
+            if (Any) { best.valid = true; return true; }
+            if (t < best.t || (t == best.t && i < best.prim)) { best.valid = true; best.t = t; best.u = u; best.v = v; best.prim = i; }
+        }
+        return false;
+    };
+    for (uint32_t i : A.always) if (test(i)) return best;
+    if (A.nodes.empty()) return best;
+    const double o[3] = { ray.o.x, ray.o.y, ray.o.z }, d[3] = { ray.d.x, ray.d.y, ray.d.z };
+    const double mint = ray.mint, maxt = ray.maxt;
+    uint32_t stack[128]; int sp = 0;
+    stack[sp++] = 0u;
+    while (sp > 0) {
+        const OAccelNode &nd = A.nodes[stack[--sp]];
+        double tn, tf;
+        if (!accel_slab(nd, o, d, tn, tf)) continue;
+        const double hi = std::min(maxt, (double) best.t);             // ties (t == best t) stay reachable: the test is inclusive
+        const double slack = 1e-9;
+        if (tn > tf + slack * std::fabs(tf) + 1e-300) continue;
+        if (tf < mint - slack * std::fabs(mint) || tn > hi + slack * std::fabs(hi)) continue;
+        if (nd.count) {
+            for (uint32_t k = nd.first; k < nd.first + nd.count; ++k) if (test(A.prims[k])) return best;
+            continue;
+        }
+        // nearer child last onto the stack (it is popped first): shrinks best.t early; the order does not change the answer
+        double ln, lf, rn, rf;
+        const bool hl = accel_slab(A.nodes[nd.left], o, d, ln, lf), hr = accel_slab(A.nodes[nd.right], o, d, rn, rf);
+        if (sp + 2 > 128) return OHit{ false, -1.f, 0.f, 0.f, 0xfffffffeu };   // cannot happen (median splits: depth <= 32); loud if it does
+        if (hl && hr && ln < rn) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+        else { if (hl) stack[sp++] = nd.left; if (hr) stack[sp++] = nd.right; }
+    }
+    return best;
+}
+
 OHit ray_intersect_preliminary(const OScene &sc, const Ray &ray) {
+    if (sc.accel.on) return accel_query<false>(sc, ray);
     OHit best{ false, std::numeric_limits<float>::infinity(), 0.f, 0.f, 0xffffffffu };
     for (uint32_t i = 0; i < sc.tris.size(); ++i) {
         const Tri &tr = sc.tris[i];
@@ -222,6 +352,7 @@ OHit ray_intersect_preliminary(const OScene &sc, const Ray &ray) {
     return best;
 }
 bool ray_test(const OScene &sc, const Ray &ray) {
+    if (sc.accel.on) return accel_query<true>(sc, ray).valid;
     for (const Tri &tr : sc.tris) {
         float t, u, v;
         if (prim_intersect(tr, prim_ctx(sc.view), ray.o, ray.d, ray.mint, ray.maxt, t, u, v)) return true;
@@ -572,6 +703,11 @@ void fill_records(const mi_render_cfg *cfg, SensorRec &sensor, FilmRec &film) {
 } // namespace
 
 extern "C" {
+
+// 0 (default): scene queries by brute force, the definition; 1: through the checker's own spatial index (OAccel above) — same
+// answers (tests/test_oracle_accel.py), needed for the configured sizes of configs 3 / 4. Process-wide, read when a scene is built.
+void orc_set_accel(int on) { g_accel.store(on ? 1 : 0); }
+int orc_get_accel(void) { return g_accel.load(); }
 
 struct orc_stats { uint64_t samples, segments, shadow_rays; double seconds; };
 

@@ -35,6 +35,7 @@ class Oracle:
         L.orc_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_float_p, c_double_p, C.c_int,
                                  c_u32_p, C.c_uint32, C.POINTER(orc_stats)]
         L.orc_render.restype = C.c_int
+        L.orc_set_accel.argtypes = [C.c_int]; L.orc_set_accel.restype = None
         L.orc_trace.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64, C.c_int]
         L.orc_trace.restype = C.c_int
         L.orc_ray_intersect_full.argtypes = [C.POINTER(mi_scene_desc), c_float_p, c_float_p]
@@ -78,6 +79,10 @@ class Oracle:
         L.orc_sample_emitter_direction.restype = C.c_int
         L.orc_pdf_emitter_direction.argtypes = [C.POINTER(mi_scene_desc), C.c_int32, c_float_p, dsp, c_float_p, C.c_uint64]; L.orc_pdf_emitter_direction.restype = C.c_int
         L.orc_emitter_eval.argtypes = [C.POINTER(mi_scene_desc), sip, c_float_p, c_float_p, C.c_uint64]; L.orc_emitter_eval.restype = C.c_int
+
+    def set_accel(self, on):
+        """0: brute-force scene queries (the definition, default); 1: the checker's own spatial index (same answers)"""
+        self.L.orc_set_accel(int(bool(on)))
 
     # ---- renders ----
     def render(self, desc, job, threads=1, want_f64=True, only_blocks=None, onto=None):
