@@ -29,7 +29,9 @@
 namespace miw {
 
 struct BlockReplayArgs {
-    const F2 *log_pos; const F4 *log_val;   // [lane][sample], `spp` entries per lane
+    const F2 *log_pos; const F4 *log_val;   // [lane][sample], `spp` entries per lane (24-byte format), or
+    const U4 *log_rec;                      // the 16-byte records (path.h: LogSink16) with their class tables in `cls`
+    FilmClassView cls;
     const U4 *st;                           // st[lane].w = samples finished by that lane
     uint32_t spp;
     const uint32_t *block_ids;              // row-major block -> spiral id
@@ -70,6 +72,39 @@ MIW_HD void film_block_replay(const FilmRec &f, const BlockReplayArgs &a, uint32
             const float value[5] = { v.x, v.y, v.z, v.w, 1.f };
             block_splat(f, g.px0 + f.crop_x, g.py0 + f.crop_y, g.bw, g.bh, v2(p.x, p.y), value,
                         [acc](int texel, int k, float term) { acc[texel * MIW_FILM_CHANNELS + k] += term; });
+        }
+    }
+}
+
+// Step 1 for the 16-byte records: a sample of pixel (x, y) adds value * (w[cy][ay] * w[cx][ax]) to every texel of the
+// (2 reach + 1)^2 window around the pixel's texel that lies inside the bordered block — the texels outside its footprint
+// get value * 0 = +-0, which leaves a float32 sum as it is (sums start at +0 and can never become -0), the texels inside
+// get the product block_splat() forms, in the same pixel / sample order. The device's k_film_groups does exactly this.
+MIW_HD void film_block_replay16(const FilmRec &f, const BlockReplayArgs &a, uint32_t tile, float *acc) {
+    const uint32_t b = a.tile_list ? a.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(f, a.blocks_x, b);
+    const uint32_t bs2 = 1u << a.bs2_log2;
+    const int reach = a.cls.reach;
+    for (uint32_t q = 0; q < bs2; ++q) {
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        if ((int) x >= g.bw || (int) y >= g.bh) continue;
+        const uint32_t lane = (tile << a.bs2_log2) + q;
+        const uint32_t count = a.st[lane].w;
+        const U4 *rec = a.log_rec + (size_t) lane * a.spp;
+        const int ptx = (int) x + f.border, pty = (int) y + f.border;
+        for (uint32_t j = 0; j < count; ++j) {
+            const U4 r = rec[j];
+            const uint32_t cx = r.w & 255u, cy = (r.w >> 8) & 255u;
+            const float value[5] = { u2f(r.x), u2f(r.y), u2f(r.z), (r.w >> 16) & 1u ? 1.f : 0.f, 1.f };
+            for (int ay = 0; ay <= 2 * reach; ++ay)
+                for (int ax = 0; ax <= 2 * reach; ++ax) {
+                    const int tx = ptx - reach + ax, ty = pty - reach + ay;
+                    if (tx < 0 || ty < 0 || tx >= g.size_x || ty >= g.size_y) continue;
+                    const float w = a.cls.w[cy * MIW_FC_STRIDE + ay] * a.cls.w[cx * MIW_FC_STRIDE + ax];   // wy * wx, :155
+                    float *dst = acc + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
+                    for (int k = 0; k < MIW_FILM_CHANNELS; ++k) dst[k] += value[k] * w;
+                }
         }
     }
 }

@@ -57,9 +57,14 @@ struct LaneQueues {
     F4 *sh_d;      // d.xyz, maxt
     F4 *sh_c;      // pending contribution rgb
     uint32_t *sh_vis; // 1 = unoccluded (written by the any-hit trace)
-    // finished-sample log (24 B/sample), [lane][sample j]: what ImageBlock::put received
-    F2 *log_pos;   // position_sample (x = NaN: sample rejected by imageblock.cpp:85-109)
+    // finished-sample log, [lane][sample j]: what ImageBlock::put received. Two formats, chosen per render by the host:
+    //   log_rec != nullptr   16 B/sample: X, Y, Z, phase class x | class y << 8 | alpha << 16 (film.h: phase classes) —
+    //                        filters the class enumeration covers (box, tent, gaussian, mitchell, catmullrom)
+    //   else                 24 B/sample: position_sample (x = NaN: sample rejected by imageblock.cpp:85-109) + X, Y, Z, alpha
+    F2 *log_pos;
     F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
+    U4 *log_rec;
+    const float *log_thr;   // the 256 phase thresholds (global memory; kernels that stage them in LDS pass their own pointer)
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)
@@ -169,6 +174,24 @@ struct LogSink {
         F2 p; p.x = sample_is_valid(aovs, warn_negative != 0) ? pos.x : __builtin_nanf(""); p.y = pos.y;
         F4 v; v.x = aovs[0]; v.y = aovs[1]; v.z = aovs[2]; v.w = aovs[3];
         log_pos[i] = p; log_val[i] = v;
+    }
+};
+
+// Sink 3: the 16-byte record (film.h: phase classes). `thr` = the 256 thresholds, wherever the caller keeps them (LDS on the
+// device's resident kernels). A rejected sample is logged as class 255 (all weights zero) with zero values, so that the
+// replay needs no branch for it.
+template <typename Thr>
+struct LogSink16 {
+    U4 *log_rec; Thr thr; const FilmRec *film; uint32_t lane, spp;
+    MIW_HD void operator()(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) const {
+        const size_t i = (size_t) lane * spp + sample_idx;
+        U4 r; r.x = r.y = r.z = 0u; r.w = film_pack_meta(MIW_FC_REJECTED, MIW_FC_REJECTED, false);
+        if (sample_is_valid(aovs, film->warn_negative != 0)) {
+            const uint32_t cx = film_class_of(thr, film_phase(*film, pos.x, (int) (pixel & 0xffffu), film->crop_x)),
+                           cy = film_class_of(thr, film_phase(*film, pos.y, (int) (pixel >> 16), film->crop_y));
+            r.x = f2u(aovs[0]); r.y = f2u(aovs[1]); r.z = f2u(aovs[2]); r.w = film_pack_meta(cx, cy, aovs[3] != 0.f);
+        }
+        log_rec[i] = r;
     }
 };
 

@@ -8,6 +8,7 @@
 // a GPU; it is NOT a product fallback and nothing in the package loads it.
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <xmmintrin.h>
 #include <pmmintrin.h>
@@ -16,6 +17,7 @@
 #include "../mitsuba2_amd/csrc/miw/path.h"
 #include "../mitsuba2_amd/csrc/miw/direct.h"
 #include "../mitsuba2_amd/csrc/miw/film_gather.h"
+#include "../mitsuba2_amd/csrc/film_classes.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 #include "../mitsuba2_amd/csrc/bvh4_build.h"
@@ -205,6 +207,50 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
     return 0;
 }
 
+// Phase classes (csrc/miw/film.h, csrc/film_classes.h) against ImageBlock::put itself: for `n` samples (position x, y and the
+// film coordinates of the pixel each one belongs to) the per-texel weights of the 8 x 8 window around the pixel's texel
+// (window texel (a, b) = block texel (t_x - reach + a, t_y - reach + b)), once as the 16-byte record + class tables give
+// them (what LogSink16 / film_block_replay16 / k_film_groups use) and once from block_splat() with the value 1 in the
+// weight channel. out_*: n x 64 floats. Returns the class count, or -1 when the filter has no class tables.
+int emu_film_weights(const mi_render_cfg *cfg, int n, const float *pos_xy, const int32_t *pixel_xy, float *out_classes, float *out_direct, int32_t *out_reach) {
+    FilmRec F; std::memset(&F, 0, sizeof F);
+    F.crop_w = cfg->crop_w; F.crop_h = cfg->crop_h; F.crop_x = cfg->crop_x; F.crop_y = cfg->crop_y;
+    F.block_size = cfg->block_size; F.border = cfg->filter_border; F.radius = cfg->filter_radius;
+    F.scale_factor = (float) MIW_FILTER_RESOLUTION / cfg->filter_radius;
+    std::memcpy(F.lut, cfg->filter_lut, sizeof F.lut);
+    F.warn_negative = 1u;
+    const FilmClasses C = film_classes_build(F);
+    if (!C.ok) return -1;
+    if (out_reach) *out_reach = C.reach;
+    Ftz ftz;
+    for (int s = 0; s < n; ++s) {
+        const int px = pixel_xy[2 * s], py = pixel_xy[2 * s + 1];
+        const V2 pos = v2(pos_xy[2 * s], pos_xy[2 * s + 1]);
+        float *oc = out_classes + (size_t) s * 64, *od = out_direct + (size_t) s * 64;
+        for (int i = 0; i < 64; ++i) oc[i] = od[i] = 0.f;
+        const uint32_t cx = film_class_of(C.thr.data(), film_phase(F, pos.x, px, F.crop_x)),
+                       cy = film_class_of(C.thr.data(), film_phase(F, pos.y, py, F.crop_y));
+        int bx, by, bw, bh;
+        block_of_pixel(F, px, py, bx, by, bw, bh);
+        const int size_x = bw + 2 * F.border, size_y = bh + 2 * F.border;
+        const int ptx = px - F.crop_x - bx + F.border, pty = py - F.crop_y - by + F.border;
+        for (int b = 0; b < 8; ++b)
+            for (int a = 0; a < 8; ++a) {
+                const int tx = ptx - C.reach + a, ty = pty - C.reach + b;
+                if (tx < 0 || ty < 0 || tx >= size_x || ty >= size_y) continue;          // a texel no lane of the replay owns
+                oc[b * 8 + a] = C.w[cy * MIW_FC_STRIDE + b] * C.w[cx * MIW_FC_STRIDE + a];
+            }
+        const float value[5] = { 0.f, 0.f, 0.f, 0.f, 1.f };
+        block_splat(F, bx + F.crop_x, by + F.crop_y, bw, bh, pos, value, [&](int texel, int k, float term) {
+            if (k != 4) return;
+            const int tx = texel % size_x, ty = texel / size_x, a = tx - (ptx - C.reach), b = ty - (pty - C.reach);
+            if (a < 0 || b < 0 || a >= 8 || b >= 8) { od[63] = -1.f; return; }            // outside the window: the test fails on it
+            od[b * 8 + a] += term;
+        });
+    }
+    return (int) C.count;
+}
+
 // the wavefront render loop of mi_render, stage by stage, on the CPU.
 // film64: crop_w*crop_h*5 doubles (film_mode 2: immediate splat, exact sum);
 // film32 (may be NULL): crop_w*crop_h*5 floats (film_mode 1: sample log + ordered gather).
@@ -243,9 +289,16 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     std::vector<U4> st(n_lanes); std::vector<F2> pos(n_lanes); std::vector<uint32_t> pixel(n_lanes), sh_vis(n_lanes);
     LaneQueues Q; Q.tp = tp.data(); Q.res = res.data(); Q.st = st.data(); Q.pos = pos.data(); Q.pixel = pixel.data();
     Q.ray_o = ray_o.data(); Q.ray_d = ray_d.data(); Q.hit = hit.data(); Q.sh_d = sh_d.data(); Q.sh_c = sh_c.data(); Q.sh_vis = sh_vis.data();
-    std::vector<F2> log_pos; std::vector<F4> log_val;
-    if (film32) { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
-    Q.log_pos = log_pos.data(); Q.log_val = log_val.data();
+    // the sample log, in the format the device would pick for this filter (miwave.hip: mi_render): 16-byte records with phase
+    // classes where film_classes_build covers the filter, positions + values (24 bytes) otherwise
+    std::vector<F2> log_pos; std::vector<F4> log_val; std::vector<U4> log_rec;
+    const FilmClasses classes = film_classes_build(P.film);
+    const bool rec16 = classes.ok && !getenv("MIW_FILM_LEGACY");
+    if (film32) {
+        if (rec16) log_rec.resize((size_t) n_lanes * cfg->spp);
+        else { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
+    }
+    Q.log_pos = log_pos.data(); Q.log_val = log_val.data(); Q.log_rec = rec16 ? log_rec.data() : nullptr; Q.log_thr = classes.thr.data();
     size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
     if (!cfg->accumulate) std::memset(film64, 0, film_n * sizeof(double));
 
@@ -296,10 +349,11 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                 if (st[lane].z & LF_DONE) continue;
                 SplatSink<decltype(add)> splat{ &P.film, add };
                 LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
+                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp };
                 bool do_log = film32 != nullptr;
                 auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                     splat(pixel, sample_idx, pos, aovs);
-                    if (do_log) log(pixel, sample_idx, pos, aovs);
+                    if (do_log) { if (rec16) log16(pixel, sample_idx, pos, aovs); else log(pixel, sample_idx, pos, aovs); }
                 };
                 st[lane] = direct ? pixel_render<INTEG_DIRECT>(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt)
                                   : pixel_render(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt);
@@ -328,10 +382,11 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
             LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
+            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);
-                if (do_log) log(pixel, sample_idx, pos, aovs);
+                if (do_log) { if (rec16) log16(pixel, sample_idx, pos, aovs); else log(pixel, sample_idx, pos, aovs); }
             };
             active += (lane_shade(P, sc.view, Q, lane, &cnt, sink) & LF_DONE) ? 0 : 1;
         }
@@ -343,6 +398,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         std::vector<int32_t> block_tile(cfg->block_count, -1);
         for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
         BlockReplayArgs A; A.log_pos = log_pos.data(); A.log_val = log_val.data(); A.st = st.data(); A.spp = cfg->spp;
+        A.log_rec = rec16 ? log_rec.data() : nullptr; A.cls = classes.view();
         A.block_ids = cfg->block_ids; A.block_tile = block_tile.data(); A.tile_list = cfg->tile_list;
         A.blocks_x = blocks_x; A.blocks_y = (cfg->crop_h + bs - 1) / bs;
         uint32_t l2 = 0; while ((1u << l2) < bs2) ++l2;
@@ -350,7 +406,10 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
         A.tile_stride = side * side * MIW_FILM_CHANNELS;
         std::vector<float> tiles((size_t) n_tiles * A.tile_stride, 0.f);
-        for (uint32_t t = 0; t < n_tiles; ++t) film_block_replay(P.film, A, t, tiles.data() + (size_t) t * A.tile_stride);
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            if (rec16) film_block_replay16(P.film, A, t, tiles.data() + (size_t) t * A.tile_stride);       // k_film_groups
+            else film_block_replay(P.film, A, t, tiles.data() + (size_t) t * A.tile_stride);               // k_film_blocks
+        }
         for (int fy = 0; fy < cfg->crop_h; ++fy)
             for (int fx = 0; fx < cfg->crop_w; ++fx)
                 film_merge_texel(P.film, A, tiles.data(), fx, fy, film32 + ((size_t) fy * cfg->crop_w + fx) * 5, cfg->accumulate != 0);

@@ -9,9 +9,10 @@ device's films with these digests (tests/test_gpu_configured.py); nothing here n
   c2    BASELINE configs[1] in full: Cornell box 1920x1080 @ 512 spp, diffuse (1.06e9 samples; ~5 min on 8 cores)
   c3    configs[2]: material balls, 1080p sensor, a 128x128 window at the full 1024 spp over both balls' silhouettes
         (oracle scene queries through its own BVH, orc_set_accel(1); proven == its brute force in tests/test_oracle_accel.py)
-  c4    configs[3]: 911 362-triangle interior, area light + environment map, a 64x32 window at the configured 2048 spp that
-        crosses environment-lit geometry (the window's upper rows look out of the room's open side), and a 2-block shard
-        of the FULL 1080p @ 2048 spp job (the blocks' own ids and seeds) for the full-size log test
+  c4    configs[3]: 911 362-triangle interior, area light + environment map, two 64x32 windows at the configured 2048 spp
+        (the frame's left edge, where pixels look past the room straight into the environment map; conductor / dielectric /
+        diffuse clutter lit through the open ceiling), and a 2-block shard of the FULL 1080p @ 2048 spp job (the blocks' own
+        ids and seeds) for the full-size log test
   fuzz  digests of tools/fuzz_cpu.py recipes 2000..2059 (the device fuzz tier's committed answers)
 Test infrastructure only."""
 import hashlib
@@ -49,9 +50,21 @@ def crop_job(api, scenes, spp, x, y, w, h, n_threads):
 
 
 # the windows / shards the GPU tests render (tests/test_gpu_configured.py imports these)
-C3_WINDOW = (896, 936, 128, 128)          # x, y, w, h on the 1920x1080 sensor: glass ball's and metal ball's silhouettes + floor
-C4_WINDOW = (928, 300, 64, 32)
-C4_FULL_BLOCKS = (0, 1)                   # spiral positions (centre-most first) of the 2-block shard of the full-frame job
+C3_WINDOW = (928, 936, 128, 128)          # x, y, w, h on the 1920x1080 sensor: both balls' silhouettes with the back wall between them
+C4_WINDOWS = {"edge": (0, 520, 64, 32),   # the frame's left edge: columns that look past the room into the environment map + the red wall
+              "clutter": (736, 584, 64, 32)}   # conductor / dielectric / diffuse spheres in front of the back wall, lit through the open ceiling
+C4_FULL_BLOCKS = (0, 1)                   # spiral ids (centre-most first) of the 2-block shard of the full-frame job
+
+
+def full_job_blocks(cfg, ids):
+    """row-major indices and pixel origins of the spiral blocks `ids` of a full-frame job"""
+    n = int(cfg.block_count); bs = int(cfg.block_size); nbx = (int(cfg.crop_w) + bs - 1) // bs
+    table = [int(cfg.block_ids[i]) for i in range(n)]
+    out = []
+    for i in ids:
+        b = table.index(i)
+        out.append((b, (b % nbx) * bs, (b // nbx) * bs))
+    return out
 
 
 def main():
@@ -85,21 +98,27 @@ def main():
         res["c3_window_1024spp"] = film_record(film, st, window=list(C3_WINDOW))
         save(); print("c3: %.0f s, %d samples, %d segments" % (time.time() - t0, st.samples, st.segments), flush=True)
     if "c4" in what:
-        t0 = time.time()
         scene, sensor = scenes.interior_scene(W, H, 2048, device=-1)
-        x, y, w, h = C4_WINDOW
-        job = crop_job(api, scenes, 2048, x, y, w, h, n_threads=128)
         orc.set_accel(1)
-        film, _, st = orc.render(scene.desc(), job, threads=threads, want_f64=False)
-        res["c4_window_2048spp"] = film_record(film, st, window=list(C4_WINDOW), env_hits="see tests/test_gpu_configured.py")
-        save(); print("c4 window: %.0f s, %d samples, %d segments" % (time.time() - t0, st.samples, st.segments), flush=True)
+        for name, (x, y, w, h) in C4_WINDOWS.items():
+            t0 = time.time()
+            job = crop_job(api, scenes, 2048, x, y, w, h, n_threads=128)
+            film, _, st = orc.render(scene.desc(), job, threads=threads, want_f64=False)
+            res["c4_window_%s_2048spp" % name] = film_record(film, st, window=[x, y, w, h])
+            save(); print("c4 window %s: %.0f s, %d samples, %d segments" % (name, time.time() - t0, st.samples, st.segments), flush=True)
+        # two blocks of the FULL 1920x1080 @ 2048 spp job (their own spiral ids and seeds): what the full-size log test compares
+        # the interiors of those blocks with (texels at least `border` = 2 away from the block's edge receive this block's
+        # samples only, in the full frame as in the shard)
         t0 = time.time()
         full = api.PathIntegrator().render_job(sensor)
         film, _, st = orc.render(scene.desc(), full, threads=threads, want_f64=False, only_blocks=np.asarray(C4_FULL_BLOCKS, np.uint32))
-        nz = np.argwhere(np.asarray(film)[..., 4] != 0)
-        y0, x0 = nz.min(0); y1, x1 = nz.max(0) + 1
-        res["c4_full_job_2_blocks_2048spp"] = film_record(np.asarray(film)[y0:y1, x0:x1], st, blocks=list(C4_FULL_BLOCKS), box=[int(x0), int(y0), int(x1), int(y1)])
+        film = np.asarray(film); inner = {}
+        for (b, x0, y0), sid in zip(full_job_blocks(full.cfg, C4_FULL_BLOCKS), C4_FULL_BLOCKS):
+            inner[str(sid)] = dict(block=b, origin=[x0, y0], sha256=digest(film[y0 + 2:y0 + 30, x0 + 2:x0 + 30]),
+                                   mean_y=float(film[y0 + 2:y0 + 30, x0 + 2:x0 + 30, 1].astype(np.float64).mean()))
+        res["c4_full_job_blocks_2048spp"] = dict(samples=int(st.samples), segments=int(st.segments), interiors=inner, oracle_seconds=round(float(st.seconds), 1))
         save(); print("c4 full-job blocks: %.0f s, %d samples" % (time.time() - t0, st.samples), flush=True)
+        orc.set_accel(0)
     if "fuzz" in what:
         import fuzz_cpu
         t0 = time.time()
