@@ -296,9 +296,9 @@ def main():
             ta_name: (agg["ms_ta"], agg["n_ta"], 8.0 * agg["segments"] if pk == 2 else B_TRACE_ANY * agg["shadow"]),
             # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
             path_kernel: (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
-            # ordered film replay: reads the 24 B/sample log, writes the block tiles (k_film_groups after k_film_pack
-            # for footprints <= 4x4, else k_film_blocks)
-            ("k_film_groups" if agg["ms_fp"] > 0 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], 24.0 * agg["samples"]),
+            # ordered film replay: reads the sample log once per texel group, writes the block tiles (k_film_groups over the 16-byte
+            # class records, k_film_blocks over the 24-byte position log of filters without phase classes)
+            ("k_film_groups" if dev.counters().log_record_bytes == 16 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], float(dev.counters().log_record_bytes) * agg["samples"]),
         }
         roofline = None
         if not args.no_profile and (agg["n_shade"] or agg["n_path"]):
@@ -341,7 +341,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured": measured,
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
                 "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
-                                  k_film_merge=round(agg["ms_fm"], 3), k_film_pack=round(agg["ms_fp"], 3), k_init=round(agg["ms_init"], 3)),
+                                  k_film_merge=round(agg["ms_fm"], 3), k_init=round(agg["ms_init"], 3)),
+                "log_bytes": dev.counters().log_bytes, "log_record_bytes": dev.counters().log_record_bytes,
                 "segments_per_sample": s_bar,
                 "pipeline_alg_bytes_per_sample": b_alg,
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),
@@ -377,7 +378,7 @@ def main():
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage" + (" (persistent stream walk kernel with dynamic ray fetch)" if pk == 2 else ""), 2: "resident: path state in registers, geometry in LDS"
                                 if path_kernel == "k_path_resident" else "resident, wave-level phase machine: path + walk state in registers, "
                                 "per-lane LDS stack, nodes / triangles through L1 / L2"}[dev.counters().plan],
-                       "film": {1: "sample log + ordered float32 gather (bit-identical to scalar_rgb order)", 2: "float64 atomics"}[dev.counters().film_mode]},
+                       "film": {1: "sample log (%d B per sample) + ordered float32 gather (bit-identical to scalar_rgb order)" % dev.counters().log_record_bytes, 2: "float64 atomics"}[dev.counters().film_mode]},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         if args.integrator == "direct":

@@ -274,7 +274,11 @@ typedef struct {
                                   quantised tree, per-lane LDS stack), 3 = k_path_phased over the BVH2 (MIW_BVH4=0, A/B switch).
                                   plan 1: 0 = k_trace<closest|any> per list slice, 2 = k_trace_stream (persistent walk kernel
                                   with dynamic ray fetch; ms_trace_closest = its time, ms_trace_any = k_sort_hits) */
-    double ms_film_pack;       /* film_mode 1: k_film_pack (sample records + footprint boxes), part of ms_resolve */
+    double ms_film_pack;       /* always 0 since round 3 (k_film_pack is gone: the render kernels log finished records); kept for layout */
+    uint64_t log_bytes;        /* film_mode 1: bytes of the sample log of the last render (lanes x spp x log_record_bytes)          */
+    uint32_t log_record_bytes; /* 16 = X Y Z + phase classes (filters film_classes.h covers), 24 = position + X Y Z alpha; 0: no log */
+    uint32_t bvh4_on_device;   /* 1: the 4-wide tree of the last mi_bvh_build was collapsed on the device (quality 0)                */
+    double ms_bvh4;            /* part of ms_bvh_build spent producing the 4-wide tree                                               */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -1,5 +1,5 @@
-// Film assembly: k_film_resolve (float64 sums), k_film_blocks (texel patches), k_film_pack + k_film_groups
-// (packed records, 4 x 2 texel groups), k_film_merge.
+// Film assembly: k_film_resolve (float64 sums), k_film_blocks (texel patches, 24-byte position log), k_film_groups
+// (16-byte class records, 4 x 2 texel groups), k_film_merge.
 // Part of the single translation unit csrc/miwave.hip (included there, in this order; not a stand-alone header).
 __global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n, int accumulate) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,122 +135,57 @@ __global__ __launch_bounds__(64) void k_film_blocks(FilmRec F, BlockReplayArgs A
     }
 }
 
-// ---- fast form of step 1 for filters whose footprint is at most 4 x 4 texels (radius <= 2: box, tent,
-// gaussian, mitchell, catmullrom) and blocks of at most 127 bordered texels a side ----
-//
-// k_film_blocks spends one wave-iteration of all 64 texel lanes on every sample of every pixel in reach of
-// the 8x8 patch (144 pixels for 64 texels), although a sample touches 16 texels: 6 % of the lane-iterations add
-// anything. The fast form splits the work in two:
-//   k_film_pack   once per SAMPLE: everything ImageBlock::put derives from the position alone (lo, the clipped
-//                 extent, the discretised weight indices, imageblock.cpp:114-146) is packed into the 8 bytes the
-//                 position occupied in the log: per axis lo (7 bits) | extent (3) | 4 x LUT index (5 each).
-//                 The same pass records, per pixel, the union of its samples' footprints (block texels).
-//   k_film_groups once per (texel GROUP, sample): a wavefront still owns an 8x8 patch, one texel per lane,
-//                 accumulators in registers, but its lanes form independent groups of GW x GH texels. Each
-//                 group walks ITS OWN Morton-ordered list of the pixels whose footprint union overlaps the
-//                 group (25 pixels for a 2x2 group instead of 144), so one wave-iteration serves 64 / (GW*GH)
-//                 (group, sample) pairs; a lane decodes the packed record with a handful of integer ops.
-//                 Sample runs are staged through LDS with coalesced loads, 16 samples per group at a time.
-// Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order,
-// each pixel's samples front to back), so the tiles are bit-identical to k_film_blocks'.
-#define MIW_PK_LO_BITS 7
-#define MIW_PK_MAX_SIDE 127
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t > v ? t : v; }
     return v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = (uint32_t) __shfl_xor((int) v, o, 64); v = t < v ? t : v; }
-    return v;
-}
-
-// one wavefront per pixel (lane i = samples i, i + 64, ...); boxes[lane] = min lo_x | max hi_x << 8 | min lo_y << 16 | max hi_y << 24
-template <bool wide>
-__global__ __launch_bounds__(256) void k_film_pack(FilmRec F, BlockReplayArgs A, uint32_t n_lanes, uint32_t *boxes) {
-    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
-    if (lane >= n_lanes) return;
-    const uint32_t tile = lane >> A.bs2_log2, q = lane & ((1u << A.bs2_log2) - 1u);
-    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    const BlockGeom g = block_geom(F, A.blocks_x, b);
-    uint32_t x, y;
-    morton_decode2(q, x, y);
-    uint32_t count = A.st[lane].w;
-    if ((int) x >= g.bw || (int) y >= g.bh) count = 0;
-    const float kx = (float) (g.px0 + F.crop_x - F.border) + .5f, ky = (float) (g.py0 + F.crop_y - F.border) + .5f;
-    int n = ceil2int((F.radius - 2.f * MIW_RAY_EPSILON) * 2.f);
-    if (n > 4) n = 4;
-    uint2 *recs = reinterpret_cast<uint2 *>(const_cast<F2 *>(A.log_pos)) + (size_t) lane * A.spp;
-    uint32_t min_x = 127u, max_x = 0u, min_y = 127u, max_y = 0u;
-    for (uint32_t j = l; j < count; j += 64u) {
-        const F2 p = A.log_pos[(size_t) lane * A.spp + j];
-        uint32_t w0 = 0u, w1 = 0u;
-        if (p.x == p.x) {                                    // not a rejected sample (imageblock.cpp:98-108)
-            const float posx = p.x - kx, posy = p.y - ky;                            // :114
-            int lo_x, lo_y, nx, ny;
-            if (wide) {
-                lo_x = ceil2int(posx - F.radius); lo_y = ceil2int(posy - F.radius);
-                if (lo_x < 0) lo_x = 0;
-                if (lo_y < 0) lo_y = 0;
-                int hi_x = floor2int(posx + F.radius), hi_y = floor2int(posy + F.radius);
-                if (hi_x > g.size_x - 1) hi_x = g.size_x - 1;
-                if (hi_y > g.size_y - 1) hi_y = g.size_y - 1;
-                nx = hi_x - lo_x + 1; ny = hi_y - lo_y + 1;
-                if (nx > n) nx = n;
-                if (ny > n) ny = n;
-                if (nx < 0) nx = 0;
-                if (ny < 0) ny = 0;
-                const float base_x = (float) lo_x - posx, base_y = (float) lo_y - posy;
-                for (int i = 0; i < 4; ++i) {
-                    if (i < n) {
-                        int ix = (int) abs_((base_x + (float) i) * F.scale_factor),
-                            iy = (int) abs_((base_y + (float) i) * F.scale_factor);
-                        if (ix > MIW_FILTER_RESOLUTION) ix = MIW_FILTER_RESOLUTION;
-                        if (iy > MIW_FILTER_RESOLUTION) iy = MIW_FILTER_RESOLUTION;
-                        w0 |= (uint32_t) ix << (10 + 5 * i); w1 |= (uint32_t) iy << (10 + 5 * i);
-                    }
-                }
-            } else {                                         // box filter, :163-170: one texel, weight 1
-                lo_x = ceil2int(posx - .5f); lo_y = ceil2int(posy - .5f);
-                const bool in = lo_x >= 0 && lo_y >= 0 && lo_x < g.size_x && lo_y < g.size_y;
-                nx = ny = in ? 1 : 0;
-                if (!in) lo_x = lo_y = 0;
-            }
-            if (nx == 0 || ny == 0) { nx = ny = 0; lo_x = lo_y = 0; w0 = w1 = 0u; }
-            else {
-                min_x = min(min_x, (uint32_t) lo_x); max_x = max(max_x, (uint32_t) (lo_x + nx - 1));
-                min_y = min(min_y, (uint32_t) lo_y); max_y = max(max_y, (uint32_t) (lo_y + ny - 1));
-            }
-            w0 |= (uint32_t) lo_x | ((uint32_t) nx << MIW_PK_LO_BITS);
-            w1 |= (uint32_t) lo_y | ((uint32_t) ny << MIW_PK_LO_BITS);
-        }
-        recs[j] = make_uint2(w0, w1);
-    }
-    min_x = wave_min_u32(min_x); max_x = wave_max_u32(max_x); min_y = wave_min_u32(min_y); max_y = wave_max_u32(max_y);
-    if (l == 0) boxes[lane] = min_x | (max_x << 8) | (min_y << 16) | (max_y << 24);
-}
-
+// ---- fast form of step 1 for the filters with phase classes (miw/film.h, film_classes.h: box, tent, gaussian, mitchell,
+// catmullrom) ----
+//
+// k_film_blocks spends one wave-iteration of all 64 texel lanes on every sample of every pixel in reach of the 8x8 patch
+// (144 pixels for 64 texels), although a sample touches 16 texels: 6 % of the lane-iterations add anything. Here a wavefront
+// still owns an 8x8 patch, one texel per lane, accumulators in registers, but its lanes form independent GROUPS of GW x GH
+// texels, and each group walks ITS OWN Morton-ordered list of the pixels within reach of the group (48 pixels for a 4x2
+// group instead of 144), so one wave-iteration serves 64 / (GW*GH) (group, sample) pairs. The render kernels logged 16 bytes
+// per sample — X, Y, Z, phase class x | class y << 8 | alpha << 16 (path.h: LogSink16) — so a lane's work per sample is: read
+// the record (staged through LDS with coalesced 16-byte loads, 16 samples per group per trip, the next trip's loads in
+// flight), look its two weights up in the LDS copy of the class table (a lane knows its offset inside the pixel's window;
+// lanes outside the window read the table's zero column, rejected samples carry the table's zero row), multiply, add.
+// ~17 VALU + 3 LDS reads per (lane, sample); no position decoding, no per-sample footprint test, no k_film_pack pass.
+// Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order, each pixel's
+// samples front to back; a texel outside a sample's footprint adds value * 0 = +-0, which leaves a float32 sum that
+// started at +0 unchanged), so the tiles are bit-identical to k_film_blocks' and to film_block_replay16 (film_gather.h).
 #define MIW_FG_CHUNK 16                /* samples per group staged per trip */
-template <int GW, int GH, bool wide>
-__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, const uint32_t *boxes, float *tiles) {
+#define MIW_FG_WSTRIDE 7               /* LDS stride of a class's weights: offsets 0..4 used, 5..6 zero (6 = "lane outside the window") */
+template <int GW, int GH>
+__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles, uint32_t xcd_swizzle) {
     constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group, groups, groups per patch row
     constexpr int LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
     static_assert(PASSES >= 1, "group too large");
-    __shared__ float s_lut[MIW_FILTER_RESOLUTION + 1];
+    extern __shared__ float s_w[];                           // (count + 1) x MIW_FG_WSTRIDE weights; row `count` = 0
     __shared__ unsigned short s_list[NG][LCAP];
     __shared__ uint32_t s_m[NG];
-    __shared__ uint2 s_rec[NG][MIW_FG_CHUNK + 1];
-    __shared__ float4 s_val[NG][MIW_FG_CHUNK + 1];
+    __shared__ uint4 s_rec[NG][MIW_FG_CHUNK + 1];
     const uint32_t l = threadIdx.x;
-    const uint32_t tile = blockIdx.x / (PA.patches_x * PA.patches_y), patch = blockIdx.x % (PA.patches_x * PA.patches_y);
+    // consecutive workgroup ids go to consecutive XCDs (8 of them, one L2 each): with the swizzle the patches of one block
+    // tile — whose windows share sample rows — run on ONE XCD, next to each other in time
+    uint32_t wg = blockIdx.x;
+    if (xcd_swizzle) { const uint32_t per = gridDim.x >> 3; if (wg < per * 8u) wg = (wg & 7u) * per + (wg >> 3); }
+    const uint32_t tile = wg / (PA.patches_x * PA.patches_y), patch = wg % (PA.patches_x * PA.patches_y);
     const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
     const BlockGeom g = block_geom(F, A.blocks_x, b);
     const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
     if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
     const uint32_t h = l / GL, li = l % GL;
     const int tx = ptx0 + (int) (h % GPX) * GW + (int) (li % GW), ty = pty0 + (int) (h / GPX) * GH + (int) (li / GW);
-    if (l < MIW_FILTER_RESOLUTION + 1) s_lut[l] = F.lut[l];
+    const uint32_t rej = A.cls.count;                        // the zero row (LogSink16 logs rejected samples with class `count`)
+    for (uint32_t i = l; i < (rej + 1u) * MIW_FG_WSTRIDE; i += 64u) {
+        const uint32_t c = i / MIW_FG_WSTRIDE, a = i % MIW_FG_WSTRIDE;
+        s_w[i] = (c < rej && a < MIW_FC_STRIDE) ? A.cls.w[c * MIW_FC_STRIDE + a] : 0.f;
+    }
 
-    // ---- per group: the pixels whose footprint union overlaps the group, in Morton order ----
+    // ---- per group: the pixels within reach of the group, in Morton order ----
+    const int reach = A.cls.reach;
     const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
     uint32_t fill[NG];
 #pragma unroll
@@ -259,16 +194,12 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
         const uint32_t q = q0 + l;
         uint32_t x, y;
         morton_decode2(q, x, y);
-        uint32_t box = 127u | (127u << 16);                  // empty
-        if (q < bs2 && (int) x < g.bw && (int) y < g.bh) box = boxes[lane0 + q];
-        const int bx0 = (int) (box & 255u), bx1 = (int) ((box >> 8) & 255u), by0 = (int) ((box >> 16) & 255u), by1 = (int) (box >> 24);
+        const bool pixel = q < bs2 && (int) x < g.bw && (int) y < g.bh;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int gx0 = ptx0 + (i % GPX) * GW, gy0 = pty0 + (i / GPX) * GH;
-            // window of k_film_blocks (bounds the list) and the exact footprint test
-            const bool in = (int) x >= gx0 - F.border - PA.reach && (int) x <= gx0 + GW - 1 - F.border + PA.reach &&
-                            (int) y >= gy0 - F.border - PA.reach && (int) y <= gy0 + GH - 1 - F.border + PA.reach &&
-                            bx0 <= gx0 + GW - 1 && bx1 >= gx0 && by0 <= gy0 + GH - 1 && by1 >= gy0;
+            const bool in = pixel && (int) x >= gx0 - F.border - reach && (int) x <= gx0 + GW - 1 - F.border + reach &&
+                                     (int) y >= gy0 - F.border - reach && (int) y <= gy0 + GH - 1 - F.border + reach;
             const unsigned long long m = __ballot(in);
             if (in) {
                 const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
@@ -287,9 +218,18 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
     __syncthreads();
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
-    const uint2 *recs = reinterpret_cast<const uint2 *>(A.log_pos);
     const uint32_t my_m = s_m[h];
+    const uint32_t pad_meta = film_pack_meta(rej, rej, false);
     for (uint32_t k = 0; k < max_m; ++k) {
+        // this lane's offsets inside the window of its group's k-th pixel (LDS word offsets into a class's weights)
+        uint32_t ox = 6u, oy = 6u;
+        if (k < my_m) {
+            uint32_t x, y;
+            morton_decode2((uint32_t) s_list[h][k], x, y);
+            const int ax = tx - ((int) x + F.border - reach), ay = ty - ((int) y + F.border - reach);
+            if ((uint32_t) ax <= (uint32_t) (2 * reach)) ox = (uint32_t) ax;
+            if ((uint32_t) ay <= (uint32_t) (2 * reach)) oy = (uint32_t) ay;
+        }
         // staging rows of this step: pass i loads group i * 4 + l / 16, sample l % 16
         size_t row[PASSES]; uint32_t cnt[PASSES];
         uint32_t step_max = 0;
@@ -304,39 +244,29 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
             step_max = cnt[i] > step_max ? cnt[i] : step_max;
         }
         step_max = wave_max_u32(step_max);
-        (void) my_m;
         // the next chunk's loads are in flight while the current one is replayed
         const uint32_t jj = l & 15u;
-        uint2 nr[PASSES]; float4 nv[PASSES];
+        uint4 nr[PASSES];
         auto fetch = [&](uint32_t j0) {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
-                nr[i] = make_uint2(0u, 0u); nv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j0 + jj < cnt[i]) {
-                    nr[i] = recs[row[i] + j0 + jj];
-                    const F4 t = A.log_val[row[i] + j0 + jj];
-                    nv[i] = make_float4(t.x, t.y, t.z, t.w);
-                }
+                nr[i] = make_uint4(0u, 0u, 0u, pad_meta);
+                if (j0 + jj < cnt[i]) { const U4 t = A.log_rec[row[i] + j0 + jj]; nr[i] = make_uint4(t.x, t.y, t.z, t.w); }
             }
         };
         fetch(0);
         for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
-                s_rec[hs][jj] = nr[i]; s_val[hs][jj] = nv[i];
-            }
+            for (int i = 0; i < PASSES; ++i) s_rec[(uint32_t) i * 4u + (l >> 4)][jj] = nr[i];
             if (j0 + MIW_FG_CHUNK < step_max) fetch(j0 + MIW_FG_CHUNK);
             __syncthreads();
 #pragma unroll 4
             for (int s = 0; s < MIW_FG_CHUNK; ++s) {
-                const uint2 r = s_rec[h][s];
-                const float4 v = s_val[h][s];
-                const int xr = tx - (int) (r.x & 127u), yr = ty - (int) (r.y & 127u);
-                const bool hit = (uint32_t) xr < ((r.x >> MIW_PK_LO_BITS) & 7u) && (uint32_t) yr < ((r.y >> MIW_PK_LO_BITS) & 7u);
-                float w = 1.f;
-                if (wide) w = s_lut[(r.y >> (10 + 5 * (yr & 3))) & 31u] * s_lut[(r.x >> (10 + 5 * (xr & 3))) & 31u];   // wy * wx, :155
-                if (hit) { acc0 += v.x * w; acc1 += v.y * w; acc2 += v.z * w; acc3 += v.w * w; acc4 += w; }
+                const uint4 r = s_rec[h][s];
+                const float w = s_w[((r.w >> 8) & 255u) * MIW_FG_WSTRIDE + oy] * s_w[(r.w & 255u) * MIW_FG_WSTRIDE + ox];   // wy * wx, :155
+                acc0 += u2f(r.x) * w; acc1 += u2f(r.y) * w; acc2 += u2f(r.z) * w;
+                acc3 += (r.w & 0x10000u) ? w : 0.f;         // alpha (0 or 1) * w
+                acc4 += w;
             }
             __syncthreads();
         }

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
+    const float *thr = stage_thresholds(smem, cfg, Q.log_rec ? Q.log_thr : nullptr);
     int32_t *stack = reinterpret_cast<int32_t *>(smem + cfg.stack16) + threadIdx.x;
     const BvhNode *gnodes = sc.nodes;
     const Bvh4Node *nodes4 = sc.nodes4;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 #endif
 
     QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+    work.film = &P.film; work.thr = thr;
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
     uint32_t pixel = 0;

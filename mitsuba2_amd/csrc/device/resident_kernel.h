@@ -40,6 +40,7 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // sized to the machine; workgroups that start late find the queue empty and retire.
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
+    const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
             // claim: ballot over the lanes asking, one atomic for all of them
@@ -57,9 +58,14 @@ struct QueueWork {
         }
     }
     __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
-    __device__ __forceinline__ void put(uint32_t, uint32_t sample_idx, V2 pos, const float *aovs) {
-        LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp; sink.warn_negative = warn_negative;
-        sink(0u, sample_idx, pos, aovs);
+    __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
+        if (Q->log_rec) {                                       // wave-uniform: one format per render
+            LogSink16<const float *> sink{ Q->log_rec, thr, film, lane, spp, Q->log_rej };
+            sink(pixel, sample_idx, pos, aovs);
+        } else {
+            LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp; sink.warn_negative = warn_negative;
+            sink(0u, sample_idx, pos, aovs);
+        }
     }
 };
 
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
+    const float *thr = stage_thresholds(smem, cfg, UseLog && Q.log_rec ? Q.log_thr : nullptr);
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+        work.film = &P.film; work.thr = thr;
         if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
         else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {

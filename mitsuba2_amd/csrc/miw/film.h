@@ -110,13 +110,13 @@ MIW_HD void block_splat(const FilmRec &f, int off_x, int off_y, int bw, int bh, 
 // (film_classes.h: all 2^23 + 1 phases through the reference's own float expressions) into
 //   thr[256]     ascending phase thresholds: class c = [thr[c], thr[c + 1]); +inf beyond the last class
 //   w[256][8]    w[c][a] = the weight put() gives texel (pixel's texel - reach + a), 0 outside the footprint;
-//                row 255 = 0 (rejected sample)
+//                rows >= count are 0: a rejected sample is logged with class `count`
 // and the render kernels log 16 bytes per sample — X, Y, Z, class_x | class_y << 8 | alpha << 16 — instead of 8 bytes of
 // position + 16 of value; the film replay looks the two weights up in its LDS copy of w. Same float32 products and
 // sums as block_splat() above, texel for texel (tests/test_film_classes.py; every film parity test runs through it).
 #define MIW_FC_CLASSES 256
 #define MIW_FC_STRIDE 8
-#define MIW_FC_REJECTED 255u
+#define MIW_FC_REJECTED 255u            /* upper bound of the class count */
 struct FilmClassView {
     const float *thr;                   // [256]
     const float *w;                     // [256][8]

@@ -65,6 +65,7 @@ struct LaneQueues {
     F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
     U4 *log_rec;
     const float *log_thr;   // the 256 phase thresholds (global memory; kernels that stage them in LDS pass their own pointer)
+    uint32_t log_rej;       // class index of a rejected sample = the class count (the first all-zero row of the weight table)
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)
@@ -178,14 +179,14 @@ struct LogSink {
 };
 
 // Sink 3: the 16-byte record (film.h: phase classes). `thr` = the 256 thresholds, wherever the caller keeps them (LDS on the
-// device's resident kernels). A rejected sample is logged as class 255 (all weights zero) with zero values, so that the
-// replay needs no branch for it.
+// device's resident kernels). A rejected sample is logged as class `rej` (= the class count: the first all-zero row of the
+// weight table) with zero values, so that the replay needs no branch for it.
 template <typename Thr>
 struct LogSink16 {
-    U4 *log_rec; Thr thr; const FilmRec *film; uint32_t lane, spp;
+    U4 *log_rec; Thr thr; const FilmRec *film; uint32_t lane, spp, rej;
     MIW_HD void operator()(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) const {
         const size_t i = (size_t) lane * spp + sample_idx;
-        U4 r; r.x = r.y = r.z = 0u; r.w = film_pack_meta(MIW_FC_REJECTED, MIW_FC_REJECTED, false);
+        U4 r; r.x = r.y = r.z = 0u; r.w = film_pack_meta(rej, rej, false);
         if (sample_is_valid(aovs, film->warn_negative != 0)) {
             const uint32_t cx = film_class_of(thr, film_phase(*film, pos.x, (int) (pixel & 0xffffu), film->crop_x)),
                            cy = film_class_of(thr, film_phase(*film, pos.y, (int) (pixel >> 16), film->crop_y));

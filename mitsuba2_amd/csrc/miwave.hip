@@ -59,6 +59,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "bvh_build.h"
 #include "bvh4_build.h"
 #include "envmap_build.h"
+#include "film_classes.h"
 #include "lbvh_device.h"
 
 using namespace miw;
@@ -141,7 +142,10 @@ struct mi_ctx {
     DevBuf<F4> q_tp, q_res, q_ray_o, q_ray_d, q_hit, q_sh_d, q_sh_c;
     DevBuf<U4> q_st; DevBuf<F2> q_pos; DevBuf<uint32_t> q_pixel, q_sh_vis;
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
-    DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val; DevBuf<uint32_t> d_boxes;
+    DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;         // 24-byte sample log (filters without phase classes)
+    DevBuf<U4> q_log_rec;                               // 16-byte sample log (miw/film.h: phase classes)
+    FilmClasses classes; FilmRec classes_of{};          // the class tables of the last filter rendered with, and that filter
+    DevBuf<float> d_fc_thr, d_fc_w;
     DevBuf<uint32_t> d_next_pixel; int cu_count = 256;
     DevBuf<uint32_t> d_lists, d_list_counts;    // wavefront plan: 2 parities x WL_LISTS lists / counters
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
@@ -200,7 +204,7 @@ void mi_destroy(mi_ctx *c) {
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
-    c->q_log_pos.release(); c->q_log_val.release(); c->d_boxes.release(); c->d_block_tile.release(); c->d_tiles.release();
+    c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); c->d_fc_thr.release(); c->d_fc_w.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
@@ -808,23 +812,43 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     int film_mode = cfg->film_mode;
     if (film_mode < 0 || film_mode > 2) return fail(c, MI_ERR_INVALID, "render: film_mode must be 0, 1 or 2");
     const size_t log_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
+    // The log format: 16-byte records with phase classes where the host enumeration covers the filter (film_classes.h: box, tent,
+    // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
+    bool rec16 = false;
+    if (film_mode != 2 && bs2 <= 65536u && !getenv("MIW_FILM_LEGACY")) {
+        FilmRec key = P.film; key.crop_w = key.crop_h = key.crop_x = key.crop_y = key.block_size = 0; key.warn_negative = 0;
+        if (!c->classes.ok || memcmp(&key, &c->classes_of, sizeof key) != 0 || !c->d_fc_thr.p) {
+            c->classes = film_classes_build(P.film);             // ~30 ms, once per filter
+            c->classes_of = key;
+            if (c->classes.ok) { HIP_TRY(c, c->d_fc_thr.upload(c->classes.thr, s)); HIP_TRY(c, c->d_fc_w.upload(c->classes.w, s)); HIP_TRY(c, hipStreamSynchronize(s)); }
+        }
+        rec16 = c->classes.ok;
+    }
+    const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
     if (film_mode != 2) {
-        size_t need = log_entries * (sizeof(F2) + sizeof(F4));
-        size_t have = c->q_log_pos.n * sizeof(F2) + c->q_log_val.n * sizeof(F4), free_b = 0, total_b = 0;
+        size_t need = log_entries * rec_bytes;
+        size_t have = c->q_log_pos.n * sizeof(F2) + c->q_log_val.n * sizeof(F4) + c->q_log_rec.n * sizeof(U4), free_b = 0, total_b = 0;
         HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
-        bool fits = need <= have || need <= (size_t) ((double) (free_b + have) * 0.8);
+        bool fits = need <= (size_t) ((double) (free_b + have) * 0.8);
         if (!fits) {
             if (film_mode == 1) return fail(c, MI_ERR_INVALID, "render: sample log needs %zu MiB, only %zu MiB free", need >> 20, free_b >> 20);
-            film_mode = 2;
+            film_mode = 2; rec16 = false;
         } else film_mode = 1;
     }
     if (film_mode == 1) {
-        if (c->q_log_pos.n < log_entries) { c->q_log_pos.release(); c->q_log_val.release(); }
-        HIP_TRY(c, c->q_log_pos.resize(log_entries)); HIP_TRY(c, c->q_log_val.resize(log_entries));
+        if (rec16) {
+            if (c->q_log_rec.n < log_entries) { c->q_log_rec.release(); c->q_log_pos.release(); c->q_log_val.release(); }
+            HIP_TRY(c, c->q_log_rec.resize(log_entries));
+        } else {
+            if (c->q_log_pos.n < log_entries) { c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); }
+            HIP_TRY(c, c->q_log_pos.resize(log_entries)); HIP_TRY(c, c->q_log_val.resize(log_entries));
+        }
     } else {
         HIP_TRY(c, c->d_accum.resize(film_n));
         HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
     }
+    c->counters.log_bytes = film_mode == 1 ? (uint64_t) log_entries * rec_bytes : 0u;
+    c->counters.log_record_bytes = film_mode == 1 ? (uint32_t) rec_bytes : 0u;
     c->counters.film_mode = (uint32_t) film_mode;
     HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
     HIP_TRY(c, hipMemcpyAsync(c->d_block_ids.p, cfg->block_ids, cfg->block_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -837,7 +861,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.tp = c->q_tp.p; Q.res = c->q_res.p; Q.st = c->q_st.p; Q.pos = c->q_pos.p; Q.pixel = c->q_pixel.p;
     Q.ray_o = c->q_ray_o.p; Q.ray_d = c->q_ray_d.p; Q.hit = c->q_hit.p;
     Q.sh_d = c->q_sh_d.p; Q.sh_c = c->q_sh_c.p; Q.sh_vis = c->q_sh_vis.p;
-    Q.log_pos = film_mode == 1 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 ? c->q_log_val.p : nullptr;
+    Q.log_pos = film_mode == 1 && !rec16 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 && !rec16 ? c->q_log_val.p : nullptr;
+    Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count : 0u;
+    // render launches with 16-byte records keep the 256 phase thresholds behind everything else in dynamic LDS
+    TraceLds rcfg = c->lds_cfg; size_t rlds = c->lds_bytes;
+    rcfg.thr16 = (uint32_t) ((rlds + 15) / 16);
+    if (rec16) rlds = (size_t) rcfg.thr16 * 16 + MIW_FC_CLASSES * sizeof(float);
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -869,7 +898,6 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 case 6: K.ms_path += ms; break;
                 case 4: K.ms_film_blocks += ms; K.ms_resolve += ms; break;
                 case 5: K.ms_film_merge += ms; K.ms_resolve += ms; break;
-                case 7: K.ms_film_pack += ms; K.ms_resolve += ms; break;
                 default: K.ms_resolve += ms; break;
             }
         }
@@ -939,7 +967,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 if (tiny && c->diffuse_only && (double) n_lanes < 1.5 * (double) c->cu_count * 4.0 * MIW_BLOCK) wg_per_cu = 3u;
                 if (const char *e = getenv("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * wg_per_cu));
-#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p))
+#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
                 // tree scenes with the LDS-stack walk: the wave-level phase machine (device/phased_kernel.h); MIW_PHASED=0 keeps
@@ -957,11 +985,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the
                 // 4-wide tree (gpurun r2f / r2g, Msamples/s at 1 : 1 -> 3 : 2 -> 2 : 1): balls 844 -> 873 -> 860; interior with its
                 // environment-map lookups 338 -> 348 -> 361. MIW_SHADE_VOTE=num:den overrides (A/B runs).
-                TraceLds ph_cfg = c->lds_cfg;
+                TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
-#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); \
-                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, c->lds_bytes, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); } while (0)
+#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); \
+                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); } while (0)
                 if (phased) {
                     if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, false);
                     else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, true);
@@ -971,16 +999,16 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 }
 #undef MIW_PHASED_LAUNCH
                 else if (direct) {
-                    if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
-                    else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                    if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+                    else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 }
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in
-                else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_PLAIN);
                 else if (tiny) MIW_PATH_LAUNCH(1, MATS_PLAIN);
                 else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_PLAIN);
-                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_PLAIN, true>), pgrid, block, c->lds_bytes, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, c->lds_cfg, end, TA, c->d_next_pixel.p));
+                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_PLAIN, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
             } else if (direct && tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1, MATS_ALL, false, INTEG_DIRECT>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
@@ -1155,6 +1183,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             BlockReplayArgs A;
             A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
+            A.log_rec = rec16 ? c->q_log_rec.p : nullptr;
+            A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
             A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
             A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
             A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
@@ -1167,22 +1197,17 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 PA.reach = (int32_t) floorf(cfg->filter_radius + .5f);
                 const dim3 fgrid(n_tiles * PA.patches_x * PA.patches_y);
                 const bool wide = cfg->filter_radius > 0.5f + MIW_RAY_EPSILON;
-                // footprints of at most 4 x 4 texels: packed records + per-group pixel lists (k_film_pack / k_film_groups)
-                // group shape: 2x2 reads 6.25 sample rows per texel (HBM-bound, 50 ms on C2), 4x4 spends 0.77 wave-iterations
-                // per sample (VALU-bound, 45 ms); 4x2 balances the two (41 ms). MIW_FILM_GROUP = 0 | 2 | 3 | 4 overrides.
-                int group = 3;
-                if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
-                const bool packed = group > 0 && side <= MIW_PK_MAX_SIDE && PA.reach <= 2 &&
-                                    (!wide || ceil2int((cfg->filter_radius - 2.f * MIW_RAY_EPSILON) * 2.f) <= 4);
-                if (packed) {
-                    HIP_TRY(c, c->d_boxes.resize(nl));
-                    const dim3 kgrid((unsigned) ((n_lanes + 3) / 4));
-                    if (wide) MIW_TIMED(7, hipLaunchKernelGGL(k_film_pack<true>, kgrid, dim3(256), 0, s, P.film, A, (uint32_t) n_lanes, c->d_boxes.p));
-                    else      MIW_TIMED(7, hipLaunchKernelGGL(k_film_pack<false>, kgrid, dim3(256), 0, s, P.film, A, (uint32_t) n_lanes, c->d_boxes.p));
-#define MIW_FG_LAUNCH(GW, GH) \
-                    do { if (wide) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH, true>), fgrid, dim3(64), 0, s, P.film, A, PA, c->d_boxes.p, c->d_tiles.p)); \
-                         else      MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH, false>), fgrid, dim3(64), 0, s, P.film, A, PA, c->d_boxes.p, c->d_tiles.p)); } while (0)
-                    if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 3) MIW_FG_LAUNCH(4, 2); else MIW_FG_LAUNCH(2, 2);
+                if (rec16) {
+                    // 16-byte class records -> per-group pixel lists (k_film_groups). Group shape: 2x2 reads 6.25 sample rows per texel,
+                    // 4x4 3.06 but spends 0.77 wave-iterations per sample; 4x2 (4.4 rows, 0.55) balances HBM reads against issue slots.
+                    // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4); MIW_FILM_XCD = 0 | 1: patches of one tile on one XCD.
+                    int group = 3;
+                    if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
+                    uint32_t swz = 1u;
+                    if (const char *e = getenv("MIW_FILM_XCD")) swz = atoi(e) ? 1u : 0u;
+                    const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
+#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz))
+                    if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
 #undef MIW_FG_LAUNCH
                 } else if (wide)
                     MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));

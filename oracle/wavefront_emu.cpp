@@ -298,7 +298,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         if (rec16) log_rec.resize((size_t) n_lanes * cfg->spp);
         else { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
     }
-    Q.log_pos = log_pos.data(); Q.log_val = log_val.data(); Q.log_rec = rec16 ? log_rec.data() : nullptr; Q.log_thr = classes.thr.data();
+    Q.log_pos = log_pos.data(); Q.log_val = log_val.data(); Q.log_rec = rec16 ? log_rec.data() : nullptr; Q.log_thr = classes.thr.data(); Q.log_rej = classes.count;
     size_t film_n = (size_t) cfg->crop_w * cfg->crop_h * 5;
     if (!cfg->accumulate) std::memset(film64, 0, film_n * sizeof(double));
 
@@ -349,7 +349,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                 if (st[lane].z & LF_DONE) continue;
                 SplatSink<decltype(add)> splat{ &P.film, add };
                 LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp };
+                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej };
                 bool do_log = film32 != nullptr;
                 auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                     splat(pixel, sample_idx, pos, aovs);
@@ -382,7 +382,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
             LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp };
+            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);
