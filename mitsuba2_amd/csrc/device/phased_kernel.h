@@ -65,7 +65,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 #endif
 
     QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
-    work.film = &P.film; work.thr = thr;
+    work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
     uint32_t pixel = 0;

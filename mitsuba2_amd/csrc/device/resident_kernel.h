@@ -41,16 +41,31 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
+    // One queue, or one per XCD (nq = 8): workgroup ids go round the 8 XCDs of an MI355X, each with its own 4 MB L2, so a
+    // workgroup's home queue is blockIdx.x & 7 and queue q hands out the q-th eighth of the lanes (tile-major = spiral
+    // order: a compact ring segment of the image) — the rays of one L2 then walk one region of the tree. A lane whose queue
+    // has run dry moves on to the next one (per lane: `q`, `dry`), so the last pixels are still shared by the whole machine.
+    uint32_t nq, per, q, dry;
+    __device__ __forceinline__ void init_queues(uint32_t queues) {
+        nq = queues; per = ((n_lanes + nq - 1u) / nq + 63u) & ~63u; q = nq > 1u ? (blockIdx.x & (nq - 1u)) : 0u; dry = 0;
+    }
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
-            // claim: ballot over the lanes asking, one atomic for all of them
-            const unsigned long long b = __ballot(1);
-            const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+            if (dry >= nq) return false;                        // every queue is empty
+            // the lanes asking now are served queue by queue: this trip, those that ask the leader's queue — one atomic for all of them
+            const unsigned long long all = __ballot(1);
+            const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) all) - 1u;
+            const uint32_t q_lead = (uint32_t) __shfl((int) q, (int) leader, 64);
+            const bool mine = q == q_lead;
+            const unsigned long long b = __ballot(mine);
+            if (!mine) continue;
             uint32_t base = 0;
-            if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
+            if (me == leader) base = atomicAdd(next_pixel + q, (uint32_t) __popcll(b));
             base = (uint32_t) __shfl((int) base, (int) leader, 64);
-            lane = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
-            if (lane >= n_lanes) return false;
+            const uint32_t idx = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
+            const uint32_t lo = q * per, hi = lo + per < n_lanes ? lo + per : n_lanes;
+            if (idx >= per || lo + idx >= hi) { q = q + 1u == nq ? 0u : q + 1u; ++dry; continue; }   // this queue is empty: on to the next
+            lane = lo + idx;
             st = Q->st[lane];
             if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
             pixel = Q->pixel[lane];
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
     };
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
-        work.film = &P.film; work.thr = thr;
+        work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
         if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
         else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {

@@ -13,6 +13,7 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
     uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
     uint32_t shade_num, shade_den;   // k_path_phased's shade vote: shade once n_shade * shade_num >= shade_den * (lanes of the busier walk body)
+    uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
 };
 
@@ -56,12 +57,12 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
     __syncthreads();
 }
 
-// The 256 phase thresholds of the 16-byte sample record (film.h) behind everything else in dynamic LDS: the class search of a
-// finished sample is 2 x 8 dependent reads, which belong in LDS (64-cycle round trips), not in L1.
+// The phase thresholds + bin table of the 16-byte sample record (film.h) behind everything else in dynamic LDS: the class search
+// of a finished sample is two dependent rounds of reads per axis, which belong in LDS (64-cycle round trips), not in L1.
 __device__ __forceinline__ const float *stage_thresholds(uint4 *smem, TraceLds cfg, const float *thr_global) {
     float *t = reinterpret_cast<float *>(smem + cfg.thr16);
     if (thr_global) {
-        for (uint32_t i = threadIdx.x; i < MIW_FC_CLASSES; i += blockDim.x) t[i] = thr_global[i];
+        for (uint32_t i = threadIdx.x; i < MIW_FC_TABLE; i += blockDim.x) t[i] = thr_global[i];
         __syncthreads();
     }
     return t;

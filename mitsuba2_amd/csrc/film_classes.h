@@ -29,7 +29,7 @@ struct FilmClasses {
     bool ok = false;
     uint32_t count = 0;
     int32_t reach = 0, n = 0;
-    std::vector<float> thr, w;          // [256], [256 * 8]
+    std::vector<float> thr, w;          // [MIW_FC_TABLE] (thresholds, +inf padding, first class of every phase bin), [256 * 8]
     FilmClassView view() const { FilmClassView v; v.thr = thr.data(); v.w = w.data(); v.count = count; v.reach = reach; return v; }
 };
 
@@ -43,7 +43,8 @@ inline FilmClasses film_classes_build(const FilmRec &f) {
     const int reach = wide ? -(int) std::ceil(-.5 - (double) r) : 1;        // -min(lo - t) over the phases
     if (wide && f.border < reach) return out;
     if (reach + 1 + n - 1 >= MIW_FC_STRIDE) return out;                       // offsets a = (lo - t) + reach + i must stay below 8
-    out.thr.assign(MIW_FC_CLASSES, std::numeric_limits<float>::infinity());
+    out.thr.assign(MIW_FC_TABLE, std::numeric_limits<float>::infinity());
+    std::vector<int> bin_first(MIW_FC_BINS, -1), bin_last(MIW_FC_BINS, -1);          // first / last class seen in each phase bin
     out.w.assign((size_t) MIW_FC_CLASSES * MIW_FC_STRIDE, 0.f);
     uint32_t count = 0;
     int prev_lo = 0; int prev_ix[4] = { -1, -1, -1, -1 };
@@ -65,6 +66,13 @@ inline FilmClasses film_classes_build(const FilmRec &f) {
             }
         } else lo_rel = (int) std::ceil((double) phi - 0.5);                  // :163: lo = ceil(pos - .5), weight 1
         const bool same = count > 0 && lo_rel == prev_lo && !std::memcmp(ix, prev_ix, sizeof ix);
+        {   // the bin film_class_of() computes for this phase, and the class it belongs to
+            int bin = (int) ((phi + .5f) * (float) MIW_FC_BINS);
+            bin = bin < 0 ? 0 : (bin > MIW_FC_BINS - 1 ? MIW_FC_BINS - 1 : bin);
+            const int cls = (int) (same ? count - 1 : count);
+            if (bin_first[bin] < 0) bin_first[bin] = cls;
+            bin_last[bin] = cls;
+        }
         if (same) continue;
         if (count >= MIW_FC_REJECTED) return out;
         prev_lo = lo_rel; std::memcpy(prev_ix, ix, sizeof ix);
@@ -75,6 +83,14 @@ inline FilmClasses film_classes_build(const FilmRec &f) {
             out.w[(size_t) count * MIW_FC_STRIDE + a] = wide ? f.lut[ix[i]] : 1.f;
         }
         ++count;
+    }
+    // the search table: a bin's first class as a byte; the search walks at most MIW_FC_PER_BIN boundaries from there
+    for (int b = 0; b < MIW_FC_BINS; ++b) {
+        if (bin_first[b] < 0 || bin_last[b] - bin_first[b] > MIW_FC_PER_BIN) return out;
+        uint32_t word; std::memcpy(&word, &out.thr[MIW_FC_CLASSES + MIW_FC_PER_BIN + (b >> 2)], 4);
+        if ((b & 3) == 0) word = 0;
+        word |= (uint32_t) bin_first[b] << (8 * (b & 3));
+        std::memcpy(&out.thr[MIW_FC_CLASSES + MIW_FC_PER_BIN + (b >> 2)], &word, 4);
     }
     out.count = count; out.reach = reach; out.n = n; out.ok = true;
     return out;

@@ -108,7 +108,7 @@ MIW_HD void block_splat(const FilmRec &f, int off_x, int off_y, int bw, int bh, 
 // is clipped, every subtraction on the way is exact). It is a step function of phi with ~70 steps (r = 2; each of the n
 // weight indices moves through ~16 LUT bins as the sample crosses its pixel), so the host enumerates it once per filter
 // (film_classes.h: all 2^23 + 1 phases through the reference's own float expressions) into
-//   thr[256]     ascending phase thresholds: class c = [thr[c], thr[c + 1]); +inf beyond the last class
+//   thr[256]     ascending phase thresholds: class c = [thr[c], thr[c + 1]); +inf beyond the last class (+ the search's bin table)
 //   w[256][8]    w[c][a] = the weight put() gives texel (pixel's texel - reach + a), 0 outside the footprint;
 //                rows >= count are 0: a rejected sample is logged with class `count`
 // and the render kernels log 16 bytes per sample — X, Y, Z, class_x | class_y << 8 | alpha << 16 — instead of 8 bytes of
@@ -117,8 +117,11 @@ MIW_HD void block_splat(const FilmRec &f, int off_x, int off_y, int bw, int bh, 
 #define MIW_FC_CLASSES 256
 #define MIW_FC_STRIDE 8
 #define MIW_FC_REJECTED 255u            /* upper bound of the class count */
+#define MIW_FC_BINS 256                 /* phase bins of the class search */
+#define MIW_FC_PER_BIN 4                /* at most this many class boundaries inside one bin (checked by film_classes_build) */
+#define MIW_FC_TABLE (MIW_FC_CLASSES + MIW_FC_PER_BIN + MIW_FC_BINS / 4)   /* floats: thresholds, +inf padding, the bins' first classes as bytes */
 struct FilmClassView {
-    const float *thr;                   // [256]
+    const float *thr;                   // [MIW_FC_TABLE]: thr[0..255] class thresholds, thr[256..259] = +inf, then 256 bytes: first class of each phase bin
     const float *w;                     // [256][8]
     uint32_t count;                     // classes in use (<= 255)
     int32_t reach;                      // texels a footprint extends to the left of its pixel's texel (2 for r = 2, 1 for box)
@@ -129,13 +132,18 @@ MIW_HD float film_phase(const FilmRec &f, float pos, int pixel, int crop_off) {
     const float p = pos - ((float) (b0 + crop_off - f.border) + .5f);              // block-local position, as block_splat
     return p - (float) (local - b0 + f.border);                                    // exact: both multiples of ulp(p), |result| <= .5
 }
+// The class of a phase: the first class of the phase's bin (1 / 256 wide; a byte table behind the thresholds), then at most
+// MIW_FC_PER_BIN boundaries further — two dependent reads (the second round's four are independent of each other) instead
+// of an 8-step binary search: the sample-finish code runs under divergence almost every iteration of the render kernels
+// (lanes finish their samples at different times), so every instruction in it is paid nearly once per path segment.
 template <typename Thr>
 MIW_HD uint32_t film_class_of(Thr thr, float phi) {
-    uint32_t c = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (uint32_t step = 128u; step; step >>= 1) c += (phi >= thr[c + step]) ? step : 0u;
+    int bin = (int) ((phi + .5f) * (float) MIW_FC_BINS);                           // exact: phi is a multiple of 2^-23 in [-.5, .5]
+    bin = bin < 0 ? 0 : (bin > MIW_FC_BINS - 1 ? MIW_FC_BINS - 1 : bin);
+    const uint32_t word = f2u(thr[MIW_FC_CLASSES + MIW_FC_PER_BIN + (bin >> 2)]);
+    uint32_t c = (word >> (8 * (bin & 3))) & 255u;
+    const float t1 = thr[c + 1], t2 = thr[c + 2], t3 = thr[c + 3], t4 = thr[c + 4];
+    c += (phi >= t1 ? 1u : 0u) + (phi >= t2 ? 1u : 0u) + (phi >= t3 ? 1u : 0u) + (phi >= t4 ? 1u : 0u);
     return c;
 }
 MIW_HD uint32_t film_pack_meta(uint32_t cx, uint32_t cy, bool alpha) { return cx | (cy << 8) | (alpha ? 1u << 16 : 0u); }

@@ -178,6 +178,9 @@ struct LogSink {
     }
 };
 
+#ifndef MIW_LOG_NT
+#define MIW_LOG_NT 0              /* 1: the 16-byte log records are written with streaming (nontemporal) stores */
+#endif
 // Sink 3: the 16-byte record (film.h: phase classes). `thr` = the 256 thresholds, wherever the caller keeps them (LDS on the
 // device's resident kernels). A rejected sample is logged as class `rej` (= the class count: the first all-zero row of the
 // weight table) with zero values, so that the replay needs no branch for it.
@@ -192,7 +195,15 @@ struct LogSink16 {
                            cy = film_class_of(thr, film_phase(*film, pos.y, (int) (pixel >> 16), film->crop_y));
             r.x = f2u(aovs[0]); r.y = f2u(aovs[1]); r.z = f2u(aovs[2]); r.w = film_pack_meta(cx, cy, aovs[3] != 0.f);
         }
+#if defined(__HIP_DEVICE_COMPILE__) && MIW_LOG_NT
+        // streaming store: the record is written once and read much later by the film replay; keeping the half-written 32-byte
+        // sector out of L2's write-back path makes the store cost its own sector and no more (profiles/r03: WRITE_SIZE per sample)
+        typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
+        u4v_ v_; v_.x = r.x; v_.y = r.y; v_.z = r.z; v_.w = r.w;
+        __builtin_nontemporal_store(v_, reinterpret_cast<u4v_ *>(log_rec + i));
+#else
         log_rec[i] = r;
+#endif
     }
 };
 

@@ -61,6 +61,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "envmap_build.h"
 #include "film_classes.h"
 #include "lbvh_device.h"
+#include "bvh4_device.h"
 
 using namespace miw;
 
@@ -445,6 +446,12 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     BvhBuildResult r;                       // host SAH result (nodes kept for the tiny-scene leaf filter)
     uint32_t node_count = 0, tri_count = (uint32_t) c->tris_in.size(), depth = 0;
     bool built_on_device = false;
+    // quality 0: the 4-wide tree is collapsed on the device as well (bvh4_device.h); these say whether that happened
+    bool wide_on_device = false; uint32_t dev4_nodes = 0, dev4_stack = 0;
+    const bool wide_on = !(getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) == 0);
+    int max_fan = 4;
+    if (const char *e = getenv("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
+    double ms_bvh4 = 0.0;
     const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree && c->rects.empty();   // packets are triangles only
     if (quality == 0 && !tiny && tri_count >= 2) {
         // ---- device LBVH (lbvh_device.h) ----
@@ -487,9 +494,32 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        free_tmp();
         node_count = (uint32_t) (n - 1);
         built_on_device = depth <= MIW_BVH_MAX_DEPTH;     // deeper (many coincident centroids): take the SAH builder
+        // ---- the 4-wide tree of the phase machine, collapsed level by level on the device (bvh4_device.h); the heights the
+        // collapse's fit test needs are k_lbvh_fit's. MIW_BVH4_HOST=1 keeps round 2's read-back + host collapse (A/B runs) ----
+        const uint32_t budget4 = MIW_STACK_ENTRIES - 1;    // one entry of slack: the node body's unconditional stores
+        if (built_on_device && wide_on && depth <= budget4 && !getenv("MIW_NO_STACK") && !getenv("MIW_BVH4_HOST")) {
+            auto t4 = std::chrono::steady_clock::now();
+            TmpBuf<Bvh4Item> fa, fb; TmpBuf<Bvh4Levels> lv;
+            HIP_TRY(c, fa.resize(n)); HIP_TRY(c, fb.resize(n)); HIP_TRY(c, lv.resize(1)); HIP_TRY(c, c->d_nodes4.resize(n));
+            Bvh4Levels h; memset(&h, 0, sizeof h); h.count[0] = 1;
+            const Bvh4Item root = { 0, budget4 };
+            HIP_TRY(c, hipMemcpyAsync(lv.p, &h, sizeof h, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(fa.p, &root, sizeof root, hipMemcpyHostToDevice, s));
+            const uint32_t levels = std::min<uint32_t>(depth + 1u, 62u);
+            for (uint32_t L = 0; L < levels; ++L)
+                hipLaunchKernelGGL(k_bvh4_level, grd, blk, 0, s, c->d_nodes.p, d_height.p, (L & 1u) ? fb.p : fa.p, (L & 1u) ? fa.p : fb.p, lv.p,
+                                   c->d_nodes4.p, L, budget4, max_fan);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&h, lv.p, sizeof h, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            for (uint32_t L = 0; L < levels; ++L) dev4_nodes += h.count[L];
+            dev4_stack = h.stack_bound;
+            wide_on_device = !h.failed && h.count[levels] == 0 && dev4_stack <= budget4 && dev4_nodes <= (uint32_t) n;
+            ms_bvh4 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t4).count();
+        }
+        free_tmp();
     }
     std::vector<float> vn;
     if (!built_on_device) {
@@ -574,29 +604,32 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         }
         // The phase machine (plan 2 over a stack-walked tree) walks the 4-wide quantised collapse of this tree (miw/bvh4.h,
         // bvh4_build.h; +10 % on the material balls and the interior against the BVH2 walk). The BVH2 stays for
-        // mi_trace, the scene queries and plan 1; a device-built LBVH is read back for the collapse. MIW_BVH4=0 switches it
+        // mi_trace, the scene queries and plan 1; a device-built LBVH is collapsed on the device (bvh4_device.h, above). MIW_BVH4=0 switches it
         // off (A/B runs), MIW_BVH4_FAN = 2..4 caps the fan-out. A tree the collapse refuses (height above the stack budget,
         // coordinates beyond the quantisation range) is rendered by the lock-step kernel.
-        const bool wide_on = !(getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) == 0);
-        if (c->lds_cfg.stack && wide_on) {
+        if (c->lds_cfg.stack && wide_on && wide_on_device) {
+            v.nodes4 = c->d_nodes4.p; c->nodes4_count = dev4_nodes; c->nodes4_stack = dev4_stack;
+            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4 (device): %u nodes (bvh2 %u), stack bound %u, %.2f ms\n", dev4_nodes, node_count, dev4_stack, ms_bvh4);
+        } else if (c->lds_cfg.stack && wide_on) {
+            auto t4 = std::chrono::steady_clock::now();
             if (built_on_device) {
                 r.nodes.resize(node_count);
                 HIP_TRY(c, hipMemcpy(r.nodes.data(), c->d_nodes.p, (size_t) node_count * sizeof(BvhNode), hipMemcpyDeviceToHost));
             }
-            int fan = 4;
-            if (const char *e = getenv("MIW_BVH4_FAN")) fan = atoi(e);
-            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, fan);   // one entry of slack: the node body's unconditional stores
+            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, max_fan);   // one entry of slack: the node body's unconditional stores
             if (b4.ok) {
                 HIP_TRY(c, c->d_nodes4.upload(b4.nodes, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 v.nodes4 = c->d_nodes4.p; c->nodes4_count = (uint32_t) b4.nodes.size(); c->nodes4_stack = b4.stack_bound;
             }
+            ms_bvh4 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t4).count();
             if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4: %zu nodes (bvh2 %u), depth %u, stack bound %u, ok %d\n", b4.nodes.size(), node_count, b4.depth, b4.stack_bound, (int) b4.ok);
         }
     }
 
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = depth;
+    c->counters.bvh4_on_device = (v.nodes4 && wide_on_device) ? 1u : 0u; c->counters.ms_bvh4 = ms_bvh4;
     c->have_bvh = true;
     return MI_OK;
 }
@@ -866,7 +899,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // render launches with 16-byte records keep the 256 phase thresholds behind everything else in dynamic LDS
     TraceLds rcfg = c->lds_cfg; size_t rlds = c->lds_bytes;
     rcfg.thr16 = (uint32_t) ((rlds + 15) / 16);
-    if (rec16) rlds = (size_t) rcfg.thr16 * 16 + MIW_FC_CLASSES * sizeof(float);
+    if (rec16) rlds = (size_t) rcfg.thr16 * 16 + (MIW_FC_TABLE + 3) / 4 * 16;
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -934,7 +967,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs = bs; A.bs2_log2 = bs2_log2; A.base_seed = cfg->base_seed;
         MIW_TIMED(3, hipLaunchKernelGGL(k_init_pixels, grid, block, 0, s, P, c->q_st.p, c->q_pixel.p, A));
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, c->d_next_pixel.resize(1));
+        HIP_TRY(c, c->d_next_pixel.resize(8));
         const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
         // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
         TileArgs TA; memset(&TA, 0, sizeof TA);
@@ -958,7 +991,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
             if (film_mode == 1) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
-                HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
+                HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, 8 * sizeof(uint32_t), s));
                 // persistent grid: 4 workgroups per CU. The plain-diffuse packet kernel is compiled for 4 waves per SIMD
                 // (123 VGPRs; +8 % over 3 on C2); when the shard holds fewer than ~1.5 pixels per resident lane it is
                 // launched 3 per CU instead, so that lanes refill from the queue rather than idle behind their
@@ -985,6 +1018,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the
                 // 4-wide tree (gpurun r2f / r2g, Msamples/s at 1 : 1 -> 3 : 2 -> 2 : 1): balls 844 -> 873 -> 860; interior with its
                 // environment-map lookups 338 -> 348 -> 361. MIW_SHADE_VOTE=num:den overrides (A/B runs).
+                // pixel queues: one per XCD for the tree kernels (their node / triangle fetches go through the XCD's own L2), one for the
+                // packet kernels (geometry in LDS). MIW_XCD_QUEUES = 0 | 1 overrides.
+                uint32_t queues = phased ? 8u : 1u;
+                if (const char *e = getenv("MIW_XCD_QUEUES")) queues = atoi(e) ? 8u : 1u;
+                rcfg.queues = queues;
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
@@ -1206,7 +1244,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     uint32_t swz = 1u;
                     if (const char *e = getenv("MIW_FILM_XCD")) swz = atoi(e) ? 1u : 0u;
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
-#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz))
+                    // MIW_FILM_DPP=0: the LDS-staged form of the replay (k_film_groups) instead of the register / DPP form (k_film_quads)
+                    const bool dpp = !(getenv("MIW_FILM_DPP") && atoi(getenv("MIW_FILM_DPP")) == 0);
+#define MIW_FG_LAUNCH(GW, GH) do { if (dpp) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz)); \
+                                   else MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz)); } while (0)
                     if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
 #undef MIW_FG_LAUNCH
                 } else if (wide)
