@@ -155,7 +155,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Every texel still sees exactly the reference's sequence of float32 additions (its pixels in Morton order, each pixel's
 // samples front to back; a texel outside a sample's footprint adds value * 0 = +-0, which leaves a float32 sum that
 // started at +0 unchanged), so the tiles are bit-identical to k_film_blocks' and to film_block_replay16 (film_gather.h).
+#ifndef MIW_FG_CHUNK
 #define MIW_FG_CHUNK 16                /* samples per group staged per trip */
+#endif
 #define MIW_FG_WSTRIDE 7               /* LDS stride of a class's weights: offsets 0..4 used, 5..6 zero (6 = "lane outside the window") */
 template <int GW, int GH>
 __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles, uint32_t xcd_swizzle) {
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
             if ((uint32_t) ax <= (uint32_t) (2 * reach)) ox = (uint32_t) ax;
             if ((uint32_t) ay <= (uint32_t) (2 * reach)) oy = (uint32_t) ay;
         }
-        // staging rows of this step: pass i loads group i * 4 + l / 16, sample l % 16
+        // staging rows of this step: pass i loads group i * (64 / CHUNK) + l / CHUNK, sample l % CHUNK
         size_t row[PASSES]; uint32_t cnt[PASSES];
         uint32_t step_max = 0;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            const uint32_t hs = (uint32_t) i * 4u + (l >> 4);
+            const uint32_t hs = (uint32_t) i * (64u / MIW_FG_CHUNK) + l / MIW_FG_CHUNK;
             cnt[i] = 0; row[i] = 0;
             if (k < s_m[hs]) {
                 const uint32_t lane = lane0 + s_list[hs][k];
@@ -244,21 +246,29 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
             step_max = cnt[i] > step_max ? cnt[i] : step_max;
         }
         step_max = wave_max_u32(step_max);
-        // the next chunk's loads are in flight while the current one is replayed
-        const uint32_t jj = l & 15u;
+        // the next chunk's loads are in flight while the current one is replayed. The loads are UNCONDITIONAL (a load inside a
+        // branch is waited for at the branch's end: no overlap) — the index is clamped into the pixel's run (run 0 of the log for a
+        // staging slot without a pixel) and a record past the end of the run gets the zero-weight class when it is staged
+        // (logged values are finite: value * 0 adds nothing)
+        const uint32_t jj = l % MIW_FG_CHUNK;
         uint4 nr[PASSES];
         auto fetch = [&](uint32_t j0) {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
-                nr[i] = make_uint4(0u, 0u, 0u, pad_meta);
-                if (j0 + jj < cnt[i]) { const U4 t = A.log_rec[row[i] + j0 + jj]; nr[i] = make_uint4(t.x, t.y, t.z, t.w); }
+                const uint32_t j = j0 + jj, last = cnt[i] ? cnt[i] - 1u : 0u;
+                const U4 t = A.log_rec[row[i] + (j < last ? j : last)];
+                nr[i] = make_uint4(t.x, t.y, t.z, t.w);
             }
         };
         fetch(0);
         for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) s_rec[(uint32_t) i * 4u + (l >> 4)][jj] = nr[i];
-            if (j0 + MIW_FG_CHUNK < step_max) fetch(j0 + MIW_FG_CHUNK);
+            for (int i = 0; i < PASSES; ++i) {
+                uint4 r = nr[i];
+                r.w = j0 + jj < cnt[i] ? r.w : pad_meta;
+                s_rec[(uint32_t) i * (64u / MIW_FG_CHUNK) + l / MIW_FG_CHUNK][jj] = r;
+            }
+            fetch(j0 + MIW_FG_CHUNK);                         // (also after the last chunk: clamped, one cached record — a branch here would put the wait back)
             __syncthreads();
 #pragma unroll 4
             for (int s = 0; s < MIW_FG_CHUNK; ++s) {
@@ -270,131 +280,6 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
             }
             __syncthreads();
         }
-    }
-    if (tx < g.size_x && ty < g.size_y) {
-        float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;
-        out[0] = acc0; out[1] = acc1; out[2] = acc2; out[3] = acc3; out[4] = acc4;
-    }
-}
-
-// The same replay with the records kept in REGISTERS (the default since the first measurement of the LDS-staged form above:
-// 29.8 ms at C2 with 88 GB read — neither HBM- nor issue-bound but waiting on LDS, three reads per lane and sample of
-// which the 16-byte record, fetched by all 64 lanes from 8 different addresses, is the expensive one). A group is one or
-// more QUADS of lanes; lane j of every quad loads records j, j + 4, j + 8, j + 12 of the group's current 16-sample chunk
-// straight from the log (the quads of a group load the same 64-byte pieces: one request), and a sample reaches the four
-// lanes of its quad as a DPP quad_perm broadcast — folded into the consuming v_mul / v_and — instead of through LDS. What
-// is left in LDS is the class-weight table (two 4-byte reads per lane and sample) and the groups' pixel lists.
-template <int S> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true);
-}
-template <int GW, int GH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_film_quads(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles, uint32_t xcd_swizzle) {
-    constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group (a multiple of 4), groups, groups per patch row
-    constexpr int LCAP = (GW + 4) * (GH + 4);
-    static_assert(GL % 4 == 0, "a group is made of quads");
-    extern __shared__ float s_w[];                           // (count + 1) x MIW_FG_WSTRIDE weights; row `count` = 0
-    __shared__ unsigned short s_list[NG][LCAP];
-    __shared__ uint32_t s_m[NG];
-    const uint32_t l = threadIdx.x;
-    uint32_t wg = blockIdx.x;
-    if (xcd_swizzle) { const uint32_t per = gridDim.x >> 3; if (wg < per * 8u) wg = (wg & 7u) * per + (wg >> 3); }
-    const uint32_t tile = wg / (PA.patches_x * PA.patches_y), patch = wg % (PA.patches_x * PA.patches_y);
-    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
-    const BlockGeom g = block_geom(F, A.blocks_x, b);
-    const int ptx0 = (int) (patch % PA.patches_x) * MIW_FP_SIDE, pty0 = (int) (patch / PA.patches_x) * MIW_FP_SIDE;
-    if (ptx0 >= g.size_x || pty0 >= g.size_y) return;        // clipped edge block: patch outside
-    const uint32_t h = l / GL, li = l % GL;
-    const int tx = ptx0 + (int) (h % GPX) * GW + (int) (li % GW), ty = pty0 + (int) (h / GPX) * GH + (int) (li / GW);
-    const uint32_t rej = A.cls.count;
-    for (uint32_t i = l; i < (rej + 1u) * MIW_FG_WSTRIDE; i += 64u) {
-        const uint32_t c = i / MIW_FG_WSTRIDE, a = i % MIW_FG_WSTRIDE;
-        s_w[i] = (c < rej && a < MIW_FC_STRIDE) ? A.cls.w[c * MIW_FC_STRIDE + a] : 0.f;
-    }
-    // ---- per group: the pixels within reach of the group, in Morton order ----
-    const int reach = A.cls.reach;
-    const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
-    uint32_t fill[NG];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) fill[i] = 0;
-    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
-        const uint32_t q = q0 + l;
-        uint32_t x, y;
-        morton_decode2(q, x, y);
-        const bool pixel = q < bs2 && (int) x < g.bw && (int) y < g.bh;
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int gx0 = ptx0 + (i % GPX) * GW, gy0 = pty0 + (i / GPX) * GH;
-            const bool in = pixel && (int) x >= gx0 - F.border - reach && (int) x <= gx0 + GW - 1 - F.border + reach &&
-                                     (int) y >= gy0 - F.border - reach && (int) y <= gy0 + GH - 1 - F.border + reach;
-            const unsigned long long m = __ballot(in);
-            if (in) {
-                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
-                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
-            }
-            fill[i] += (uint32_t) __popcll(m);
-        }
-    }
-    uint32_t max_m = 0;
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
-        if (l == 0) s_m[i] = m;
-        max_m = m > max_m ? m : max_m;
-    }
-    __syncthreads();
-
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
-    const uint32_t my_m = s_m[h], jq = l & 3u;
-    const uint32_t pad_meta = film_pack_meta(rej, rej, false);
-    for (uint32_t k = 0; k < max_m; ++k) {
-        // the group's k-th pixel: its sample run, and this lane's offsets inside the pixel's window (word offsets into a class's weights)
-        uint32_t ox = 6u, oy = 6u, cnt = 0; size_t row = 0;
-        if (k < my_m) {
-            const uint32_t q = (uint32_t) s_list[h][k];
-            uint32_t x, y;
-            morton_decode2(q, x, y);
-            const int ax = tx - ((int) x + F.border - reach), ay = ty - ((int) y + F.border - reach);
-            if ((uint32_t) ax <= (uint32_t) (2 * reach)) ox = (uint32_t) ax;
-            if ((uint32_t) ay <= (uint32_t) (2 * reach)) oy = (uint32_t) ay;
-            cnt = A.st[lane0 + q].w; row = (size_t) (lane0 + q) * A.spp;
-        }
-        const uint32_t step_max = wave_max_u32(cnt);
-        // Two 8-sample half-chunks in registers, ping-pong: while one is replayed the other one's loads are in flight.
-        // Unconditional loads (a branch around a load ends in a wait: no overlap): the index is clamped into the pixel's run — run
-        // 0 of the log for a lane without a pixel — and a record past the end gets the zero-weight class just before it is
-        // replayed (logged values are finite: value * 0 adds nothing).
-        const uint32_t last = cnt ? cnt - 1u : 0u;
-        auto fetch = [&](uint32_t j0, uint4 *dst) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t j = j0 + 4u * (uint32_t) c + jq;
-                const U4 t = A.log_rec[row + (j < last ? j : last)];
-                dst[c] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        };
-#define MIW_FQ_SAMPLE(V, J0, C, S) do {                                                                                  \
-                const uint32_t raw = quad_bcast<S>(V[C].w);                                                                  \
-                const uint32_t meta = (J0) + 4u * (C) + (S) < cnt ? raw : pad_meta;                                          \
-                const float w = s_w[((meta >> 8) & 255u) * MIW_FG_WSTRIDE + oy] * s_w[(meta & 255u) * MIW_FG_WSTRIDE + ox];  /* wy * wx, :155 */ \
-                acc0 += u2f(quad_bcast<S>(V[C].x)) * w; acc1 += u2f(quad_bcast<S>(V[C].y)) * w; acc2 += u2f(quad_bcast<S>(V[C].z)) * w; \
-                acc3 += (meta & 0x10000u) ? w : 0.f;             /* alpha (0 or 1) * w */                                   \
-                acc4 += w;                                                                                                   \
-            } while (0)
-#define MIW_FQ_HALF(V, J0) do { MIW_FQ_SAMPLE(V, J0, 0, 0); MIW_FQ_SAMPLE(V, J0, 0, 1); MIW_FQ_SAMPLE(V, J0, 0, 2); MIW_FQ_SAMPLE(V, J0, 0, 3); \
-                                MIW_FQ_SAMPLE(V, J0, 1, 0); MIW_FQ_SAMPLE(V, J0, 1, 1); MIW_FQ_SAMPLE(V, J0, 1, 2); MIW_FQ_SAMPLE(V, J0, 1, 3); } while (0)
-        uint4 ra[2], rb[2];
-        // (the compiler barriers pin the loads where they are written: left alone, the loads of a half-chunk sink down to its replay)
-        fetch(0, ra);
-        for (uint32_t j0 = 0; j0 < step_max; j0 += 16u) {
-            fetch(j0 + 8u, rb);
-            asm volatile("" ::: "memory");
-            MIW_FQ_HALF(ra, j0);
-            fetch(j0 + 16u, ra);
-            asm volatile("" ::: "memory");
-            MIW_FQ_HALF(rb, j0 + 8u);
-        }
-#undef MIW_FQ_HALF
-#undef MIW_FQ_SAMPLE
     }
     if (tx < g.size_x && ty < g.size_y) {
         float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) ty * g.size_x + tx) * MIW_FILM_CHANNELS;

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 
     QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
+    __shared__ uint32_t s_prog[MIW_BLOCK / 64];
+    if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
     uint32_t pixel = 0;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         if (n_shade * shade_num >= lead * shade_den && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             MIW_SECTION(6);                                              // everything since the last shade body: walks + votes
+            work.tick(L.sample_idx, mode != PH_OUT && !(L.flags & LF_DONE));
             if (e_shade) {
                 if (!(L.flags & LF_DONE)) {
                     const V3 o = L.ray.o;

@@ -48,6 +48,33 @@ struct QueueWork {
     uint32_t nq, per, q, dry;
     __device__ __forceinline__ void init_queues(uint32_t queues) {
         nq = queues; per = ((n_lanes + nq - 1u) / nq + 63u) & ~63u; q = nq > 1u ? (blockIdx.x & (nq - 1u)) : 0u; dry = 0;
+        ticks = 0; quarter = 0; tail_prio = 0; sample_end_ = spp;
+    }
+    // Least-progress-first among the wavefronts of a SIMD, for shards with about one pixel per resident lane (tail_prio set
+    // by the host): a pixel's samples are one serial PCG32 stream, so such a launch is one pixel deep and lasts as long as its
+    // most expensive pixels, which share their SIMD's issue slots evenly with wavefronts that will be done long before them.
+    // s_setprio makes the SIMD's arbiter prefer the wavefront that is furthest behind (priority 3 in its first quarter of
+    // samples ... 0 in its last): the wavefronts of a SIMD then finish together, at (their total work) / (the SIMD's
+    // throughput), instead of the expensive one running on alone at the end. A stalled high-priority wave still yields its
+    // slots, so throughput is what it was. Evaluated every 16th iteration (one wave-wide minimum of the lanes' sample counters).
+    uint32_t ticks, quarter, tail_prio, sample_end_; uint32_t *prog;      // prog: this wavefront's word in LDS (the wave-wide minimum)
+    __device__ __forceinline__ void tick(uint32_t sample_idx, bool has_pixel) {
+        if (!tail_prio) return;
+        // (called from divergent code: the lanes that just fetched a pixel are not here — so no cross-lane shuffles; the
+        // counter of the first active lane decides, the minimum goes through one LDS atomic per lane)
+        if ((uint32_t) __builtin_amdgcn_readfirstlane((int) ++ticks) & 15u) return;
+        if (has_pixel) atomicMin(prog, sample_idx);
+        const uint32_t v = *prog;
+        *prog = 0xffffffffu;
+        uint32_t qtr = v == 0xffffffffu ? 3u : (4u * v) / (sample_end_ ? sample_end_ : 1u);
+        qtr = (uint32_t) __builtin_amdgcn_readfirstlane((int) (qtr > 3u ? 3u : qtr));
+        if (qtr == quarter) return;
+        quarter = qtr;
+        if (qtr == 0u) __builtin_amdgcn_s_setprio(3); else if (qtr == 1u) __builtin_amdgcn_s_setprio(2);
+        else if (qtr == 2u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+    __device__ __forceinline__ void enable_tail_prio(uint32_t sample_end, uint32_t *wave_word) {
+        tail_prio = 1u; sample_end_ = sample_end; quarter = 0; prog = wave_word; *prog = 0xffffffffu; __builtin_amdgcn_s_setprio(3);
     }
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
@@ -117,6 +144,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
     if (UseLog) {
         QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
         work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
+        __shared__ uint32_t s_prog[MIW_BLOCK / 64];
+        if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
         if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
         else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {

@@ -14,11 +14,15 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
     uint32_t shade_num, shade_den;   // k_path_phased's shade vote: shade once n_shade * shade_num >= shade_den * (lanes of the busier walk body)
     uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
+    uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
-struct alignas(16) LeafBox { float lo[3]; uint32_t mask_lo; float hi[3]; uint32_t mask_hi; };   // mask: one bit per triangle of the leaf (leaf order)
+// The two planes of an axis sit next to each other — lo.x hi.x lo.y hi.y | lo.z hi.z mask — so that one packed fma
+// (v_pk_fma_f32: two IEEE fmas per lane in one issue slot) turns a register pair straight out of the ds_read_b128 into the
+// two slab distances of that axis (leaf_box_test below).
+struct alignas(16) LeafBox { float p[6]; uint32_t mask_lo, mask_hi; };   // p = lo.x hi.x lo.y hi.y lo.z hi.z; mask: one bit per triangle of the leaf (leaf order)
 static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 
 // Triangle packet for the brute-force sweep: p0, e1, e2, prim (48 B = 3 x b128).
@@ -94,6 +98,19 @@ __device__ __forceinline__ bool box_test_fast(const float *lo, const float *hi, 
     // widened like bvh.h's box_test, plus slack for the fma-form rounding
     tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
     tn_out = tn;
+    return tn <= tf && tn <= tmax_wide;
+}
+// The same test on a LeafBox, three packed fmas per ray instead of six scalar ones (same IEEE fma per plane: same distances).
+typedef float miw_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool leaf_box_test(const LeafBox &b, const FastRay &r, float tmax_wide) {
+    const miw_f2 px = { b.p[0], b.p[1] }, py = { b.p[2], b.p[3] }, pz = { b.p[4], b.p[5] };
+    const miw_f2 tx = __builtin_elementwise_fma(px, (miw_f2) { r.inv_d.x, r.inv_d.x }, (miw_f2) { r.neg_o_inv_d.x, r.neg_o_inv_d.x }),
+                 ty = __builtin_elementwise_fma(py, (miw_f2) { r.inv_d.y, r.inv_d.y }, (miw_f2) { r.neg_o_inv_d.y, r.neg_o_inv_d.y }),
+                 tz = __builtin_elementwise_fma(pz, (miw_f2) { r.inv_d.z, r.inv_d.z }, (miw_f2) { r.neg_o_inv_d.z, r.neg_o_inv_d.z });
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)),
+                                     __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), r.mint));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
+    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
     return tn <= tf && tn <= tmax_wide;
 }
 __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t), 2e-6f, t); }
@@ -339,9 +356,8 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
             const Mask bits = Tiny == 2 ? (Mask) b.mask_lo : (Mask) (b.mask_lo | ((unsigned long long) b.mask_hi << 32));
-            float tn;
-            if (box_test_fast(b.lo, b.hi, rE, wideE, tn)) mE |= bits;
-            if (box_test_fast(b.lo, b.hi, rS, wideS, tn)) mS |= bits;
+            if (leaf_box_test(b, rE, wideE)) mE |= bits;
+            if (leaf_box_test(b, rS, wideS)) mS |= bits;
         }
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;

@@ -3,7 +3,8 @@
 // the reference (src/librender/scene_native.inl:3-10); like the host SAH builder it only has to
 // deliver a tree whose traversal result equals brute force (bvh.h), so none of the kd-tree's
 // structure is reproduced. Output format = the SAH builder's: 64-byte BVH2 nodes holding both child
-// boxes + parent links, root = node 0, one triangle per leaf, triangles permuted into leaf order.
+// boxes + parent links, root = node 0, up to 4 triangles per leaf (fat leaves, below), triangles permuted into leaf order.
+// The 4-wide tree of the phase machine is collapsed from it on the device as well (bvh4_device.h).
 //
 // Kernels (hand-written; the key sort itself is rocPRIM's device radix sort via hipCUB — a plain
 // library primitive):
@@ -94,7 +95,12 @@ __device__ __forceinline__ int lbvh_delta(const uint64_t *keys, int n, int i, in
 
 struct LbvhLinks { int32_t left, right, parent; };   // child >= 0: inner node, < 0: ~leaf index
 
-__global__ void k_lbvh_tree(const uint64_t *keys, int n, LbvhLinks *inner, int32_t *leaf_parent) {
+// Fat leaves: an inner node of the radix tree covers a contiguous run of the sorted triangles, so a subtree of at most
+// `max_leaf` triangles can stand in the emitted BVH2 as ONE leaf (first = start of the run, count = its length) — the SAH
+// builder's leaves hold up to 4 triangles too, and a tree of single-triangle leaves has twice the nodes and two more levels
+// (measured with one triangle per leaf: device-LBVH frames 14 % / 25 % slower than SAH frames on the interior / the material
+// balls). span[i] / first[i] = length and start of node i's run; the nodes inside a fat leaf stay in the arrays, unreferenced.
+__global__ void k_lbvh_tree(const uint64_t *keys, int n, LbvhLinks *inner, int32_t *leaf_parent, uint32_t *span, uint32_t *first) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     // direction of the range, then its other end by doubling + binary search (Karras 2012, fig. 4)
@@ -115,6 +121,7 @@ __global__ void k_lbvh_tree(const uint64_t *keys, int n, LbvhLinks *inner, int32
     }
     const int gamma = i + s * d + (d < 0 ? -1 : 0);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
+    span[i] = (uint32_t) (hi - lo + 1); first[i] = (uint32_t) lo;
     const int32_t left = lo == gamma ? ~gamma : gamma, right = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
     inner[i].left = left; inner[i].right = right;
     if (i == 0) inner[0].parent = -1;
@@ -123,7 +130,7 @@ __global__ void k_lbvh_tree(const uint64_t *keys, int n, LbvhLinks *inner, int32
 }
 
 __global__ void k_lbvh_fit(const LbvhLinks *inner, const int32_t *leaf_parent, int n, LbvhBox *boxes, uint32_t *arrivals,
-                           uint32_t *height /* [n-1] */) {
+                           uint32_t *height /* [n-1] */, const uint32_t *span, uint32_t max_leaf) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t node = leaf_parent[i];
@@ -135,21 +142,21 @@ __global__ void k_lbvh_fit(const LbvhLinks *inner, const int32_t *leaf_parent, i
         LbvhBox m;
         for (int k = 0; k < 3; ++k) { m.lo[k] = fminf(a.lo[k], b.lo[k]); m.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
         boxes[node] = m;
-        const uint32_t hl = l >= 0 ? height[l] : 0u, hr = r >= 0 ? height[r] : 0u;
+        const uint32_t hl = (l >= 0 && span[l] > max_leaf) ? height[l] : 0u, hr = (r >= 0 && span[r] > max_leaf) ? height[r] : 0u;   // fat leaves count as leaves
         height[node] = 1u + (hl > hr ? hl : hr);
         node = inner[node].parent;
     }
 }
 
-__global__ void k_lbvh_emit(const LbvhLinks *inner, const LbvhBox *boxes, int n, BvhNode *nodes) {
+__global__ void k_lbvh_emit(const LbvhLinks *inner, const LbvhBox *boxes, int n, BvhNode *nodes, const uint32_t *span, const uint32_t *first, uint32_t max_leaf) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     const int32_t l = inner[i].left, r = inner[i].right;
     const LbvhBox a = boxes[l >= 0 ? l : (n - 1) + ~l], b = boxes[r >= 0 ? r : (n - 1) + ~r];
     BvhNode nd;
     for (int k = 0; k < 3; ++k) { nd.lo0[k] = a.lo[k]; nd.hi0[k] = a.hi[k]; nd.lo1[k] = b.lo[k]; nd.hi1[k] = b.hi[k]; }
-    nd.child0 = l >= 0 ? l : bvh_leaf_code((uint32_t) ~l, 1);
-    nd.child1 = r >= 0 ? r : bvh_leaf_code((uint32_t) ~r, 1);
+    nd.child0 = l >= 0 ? (span[l] > max_leaf ? l : bvh_leaf_code(first[l], span[l])) : bvh_leaf_code((uint32_t) ~l, 1);
+    nd.child1 = r >= 0 ? (span[r] > max_leaf ? r : bvh_leaf_code(first[r], span[r])) : bvh_leaf_code((uint32_t) ~r, 1);
     nd.parent = inner[i].parent; nd.pad = 0;
     nodes[i] = nd;
 }

@@ -67,9 +67,18 @@ MIW_HD void bvh4_test(const Bvh4Node &n, const Ray &r, float tmax_wide, uint32_t
 #pragma unroll
 #endif
     for (int c = 0; c < 4; ++c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // entry and exit distance of an axis as ONE packed fma (v_pk_fma_f32: two IEEE fmas per lane in one issue slot)
+        typedef float f2_ __attribute__((ext_vector_type(2)));
+        const f2_ txx = __builtin_elementwise_fma((f2_) { bvh4_byte(nx, c), bvh4_byte(fx, c) }, (f2_) { ax, ax }, (f2_) { bx, bx }),
+                  tyy = __builtin_elementwise_fma((f2_) { bvh4_byte(ny, c), bvh4_byte(fy, c) }, (f2_) { ay, ay }, (f2_) { by, by }),
+                  tzz = __builtin_elementwise_fma((f2_) { bvh4_byte(nz, c), bvh4_byte(fz, c) }, (f2_) { az, az }, (f2_) { bz, bz });
+        const float tnx = txx.x, tfx = txx.y, tny = tyy.x, tfy = tyy.y, tnz = tzz.x, tfz = tzz.y;
+#else
         const float tnx = __builtin_fmaf(bvh4_byte(nx, c), ax, bx), tfx = __builtin_fmaf(bvh4_byte(fx, c), ax, bx),
                     tny = __builtin_fmaf(bvh4_byte(ny, c), ay, by), tfy = __builtin_fmaf(bvh4_byte(fy, c), ay, by),
                     tnz = __builtin_fmaf(bvh4_byte(nz, c), az, bz), tfz = __builtin_fmaf(bvh4_byte(fz, c), az, bz);
+#endif
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, r.mint));
         float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
         tf = __builtin_fminf(__builtin_fmaf(abs_(tf), 2e-6f, tf), tmax_wide);

@@ -457,15 +457,19 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // ---- device LBVH (lbvh_device.h) ----
         hipStream_t s = c->stream;
         const int n = (int) tri_count;
-        TmpBuf<Tri> d_in; TmpBuf<float> d_vn_in; TmpBuf<uint64_t> d_keys, d_keys_sorted; TmpBuf<uint32_t> d_bounds, d_arrivals, d_height;
+        TmpBuf<Tri> d_in; TmpBuf<float> d_vn_in; TmpBuf<uint64_t> d_keys, d_keys_sorted; TmpBuf<uint32_t> d_bounds, d_arrivals, d_height, d_span, d_first;
+        uint32_t lbvh_leaf = 4u;                               // triangles per leaf, like the SAH builder's; MIW_LBVH_LEAF = 1 .. 16 overrides
+        if (const char *e = getenv("MIW_LBVH_LEAF")) lbvh_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
+        if ((uint32_t) n <= lbvh_leaf) lbvh_leaf = 1u;          // (the root must stay an inner node)
         TmpBuf<LbvhBox> d_boxes; TmpBuf<LbvhLinks> d_inner; TmpBuf<int32_t> d_leaf_parent; TmpBuf<unsigned char> d_tmp;
         auto free_tmp = [&]() { d_in.release(); d_vn_in.release(); d_keys.release(); d_keys_sorted.release(); d_bounds.release();
-                                d_arrivals.release(); d_height.release(); d_boxes.release(); d_inner.release(); d_leaf_parent.release(); d_tmp.release(); };
+                                d_arrivals.release(); d_height.release(); d_boxes.release(); d_inner.release(); d_leaf_parent.release(); d_tmp.release();
+                                d_span.release(); d_first.release(); };
         HIP_TRY(c, d_in.upload(c->tris_in, s));
         if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_in.upload(c->tri_vn_in, s));
         HIP_TRY(c, d_keys.resize(n)); HIP_TRY(c, d_keys_sorted.resize(n)); HIP_TRY(c, d_bounds.resize(6));
         HIP_TRY(c, d_arrivals.resize(n)); HIP_TRY(c, d_height.resize(n)); HIP_TRY(c, d_boxes.resize((size_t) 2 * n));
-        HIP_TRY(c, d_inner.resize(n)); HIP_TRY(c, d_leaf_parent.resize(n));
+        HIP_TRY(c, d_inner.resize(n)); HIP_TRY(c, d_leaf_parent.resize(n)); HIP_TRY(c, d_span.resize(n)); HIP_TRY(c, d_first.resize(n));
         HIP_TRY(c, c->d_nodes.resize(n)); HIP_TRY(c, c->d_tris.resize(n));
         if (!c->tri_vn_in.empty()) HIP_TRY(c, c->d_tri_vn.resize((size_t) n * 9));
         const uint32_t init_bounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
@@ -488,9 +492,9 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         const float pad = 2.f * std::max(1e-5f * m, 1e-30f);
         hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
                            (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
-        hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p);
-        hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_inner.p, d_leaf_parent.p, n, d_boxes.p, d_arrivals.p, d_height.p);
-        hipLaunchKernelGGL(k_lbvh_emit, grd, blk, 0, s, d_inner.p, d_boxes.p, n, c->d_nodes.p);
+        hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p, d_span.p, d_first.p);
+        hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_inner.p, d_leaf_parent.p, n, d_boxes.p, d_arrivals.p, d_height.p, d_span.p, lbvh_leaf);
+        hipLaunchKernelGGL(k_lbvh_emit, grd, blk, 0, s, d_inner.p, d_boxes.p, n, c->d_nodes.p, d_span.p, d_first.p, lbvh_leaf);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -573,7 +577,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             const uint32_t code = (uint32_t) ~child;
             const uint32_t first = code >> 4, count = (code & 15u) + 1u;
             const unsigned long long bits = (count >= 64u ? ~0ull : ((1ull << count) - 1ull)) << first;
-            LeafBox b; memcpy(b.lo, lo, 12); memcpy(b.hi, hi, 12); b.mask_lo = (uint32_t) bits; b.mask_hi = (uint32_t) (bits >> 32);
+            LeafBox b; for (int a = 0; a < 3; ++a) { b.p[2 * a] = lo[a]; b.p[2 * a + 1] = hi[a]; } b.mask_lo = (uint32_t) bits; b.mask_hi = (uint32_t) (bits >> 32);
             leaves.push_back(b);
         };
         for (const BvhNode &n : r.nodes) { add_leaf(n.lo0, n.hi0, n.child0); add_leaf(n.lo1, n.hi1, n.child1); }
@@ -1018,11 +1022,16 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the
                 // 4-wide tree (gpurun r2f / r2g, Msamples/s at 1 : 1 -> 3 : 2 -> 2 : 1): balls 844 -> 873 -> 860; interior with its
                 // environment-map lookups 338 -> 348 -> 361. MIW_SHADE_VOTE=num:den overrides (A/B runs).
-                // pixel queues: one per XCD for the tree kernels (their node / triangle fetches go through the XCD's own L2), one for the
-                // packet kernels (geometry in LDS). MIW_XCD_QUEUES = 0 | 1 overrides.
-                uint32_t queues = phased ? 8u : 1u;
+                // pixel queues: one, or one per XCD (MIW_XCD_QUEUES=1: each XCD's workgroups take pixels from their own eighth of the
+                // lanes, so that the rays of one L2 stay in one region of the image). Measured (profiles/r03): material balls 883 vs
+                // 879 Msamples/s, interior 362 vs 370 — the secondary rays of a closed room go everywhere; off by default.
+                uint32_t queues = 1u;
                 if (const char *e = getenv("MIW_XCD_QUEUES")) queues = atoi(e) ? 8u : 1u;
                 rcfg.queues = queues;
+                // least-progress-first wave priorities (QueueWork::tick) when the shard has about one pixel per resident lane: then the
+                // launch is one pixel deep and its length is set by the most expensive pixels. MIW_TAIL_PRIO = 0 | 1 overrides.
+                rcfg.tail_prio = (double) n_lanes < 1.5 * (double) c->cu_count * 4.0 * MIW_BLOCK ? 1u : 0u;
+                if (const char *e = getenv("MIW_TAIL_PRIO")) rcfg.tail_prio = atoi(e) ? 1u : 0u;
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
@@ -1040,6 +1049,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 }
+                else if (tiny && c->diffuse_only && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_DIFFUSE);   // 32-bit candidate masks (BASELINE config 2: 32 triangles)
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in
                 else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
@@ -1244,10 +1254,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     uint32_t swz = 1u;
                     if (const char *e = getenv("MIW_FILM_XCD")) swz = atoi(e) ? 1u : 0u;
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
-                    // MIW_FILM_DPP=0: the LDS-staged form of the replay (k_film_groups) instead of the register / DPP form (k_film_quads)
-                    const bool dpp = !(getenv("MIW_FILM_DPP") && atoi(getenv("MIW_FILM_DPP")) == 0);
-#define MIW_FG_LAUNCH(GW, GH) do { if (dpp) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz)); \
-                                   else MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz)); } while (0)
+#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz))
                     if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
 #undef MIW_FG_LAUNCH
                 } else if (wide)

@@ -23,4 +23,4 @@ using namespace miw;
 #include "../mitsuba2_amd/csrc/device/trace.h"
 #include "../mitsuba2_amd/csrc/device/wavefront_kernels.h"
 #include "../mitsuba2_amd/csrc/device/resident_kernel.h"
-template __global__ void k_path_resident<true, 1, 1, false, 0u>(RenderParams, SceneView, LaneQueues, double *, Counters *, TraceLds, unsigned int, TileArgs, unsigned int *);
+template __global__ void k_path_resident<true, 2, 1, false, 0u>(RenderParams, SceneView, LaneQueues, double *, Counters *, TraceLds, unsigned int, TileArgs, unsigned int *);
