@@ -279,6 +279,9 @@ typedef struct {
     uint32_t log_record_bytes; /* 16 = X Y Z + phase classes (filters film_classes.h covers), 24 = position + X Y Z alpha; 0: no log */
     uint32_t bvh4_on_device;   /* 1: the 4-wide tree of the last mi_bvh_build was collapsed on the device (quality 0)                */
     double ms_bvh4;            /* part of ms_bvh_build spent producing the 4-wide tree                                               */
+    uint32_t placed;           /* 1: the last render ran a measuring launch + a launch with per-SIMD pixel queues (a shard of at most
+                                  one pixel per resident lane: what one rank of an N-GPU frame renders at N >= 8)                     */
+    uint32_t pad_;
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -38,17 +38,39 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // the next unclaimed one inside the iteration loop (wavefront-aggregated: ballot + one atomic per wave per
 // refill), so no lane waits for the slowest pixel of its wavefront and the launch drains evenly. The grid is
 // sized to the machine; workgroups that start late find the queue empty and retire.
+#ifndef MIW_PLACE_PIECES
+#define MIW_PLACE_PIECES 4
+#endif
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
-    // One queue, or one per XCD (nq = 8): workgroup ids go round the 8 XCDs of an MI355X, each with its own 4 MB L2, so a
-    // workgroup's home queue is blockIdx.x & 7 and queue q hands out the q-th eighth of the lanes (tile-major = spiral
-    // order: a compact ring segment of the image) — the rays of one L2 then walk one region of the tree. A lane whose queue
-    // has run dry moves on to the next one (per lane: `q`, `dry`), so the last pixels are still shared by the whole machine.
-    uint32_t nq, per, q, dry;
+    // One queue over all lanes — or, for shards of at most one pixel per resident lane, PLACED queues (nq = one per SIMD of the
+    // device): such a launch is one pixel deep, the priorities below make the four wavefronts of a SIMD finish together, and what
+    // is left is the imbalance BETWEEN SIMDs (the sum of four random 64-pixel pieces: +-7 %, its maximum over 1024 SIMDs +24 %).
+    // So the host measures every piece's cost in a first short launch (Q->piece_cost: iterations per piece over the first
+    // eighth of the samples), deals the pieces to the SIMDs longest-first (Q->piece_list: four pieces per queue, equal sums)
+    // and the second launch lets a wavefront take its pixels from the queue of the SIMD it runs on: HW_ID / XCC_ID name the
+    // SIMD, the first wavefront to show up on it registers it (Q->simd_ids). A lane whose queue has run dry moves on to the
+    // next one (per lane: `q`, `dry`), so pieces of SIMDs nobody registered are still rendered.
+    uint32_t nq, per, q, dry, t_fetch;
     __device__ __forceinline__ void init_queues(uint32_t queues) {
-        nq = queues; per = ((n_lanes + nq - 1u) / nq + 63u) & ~63u; q = nq > 1u ? (blockIdx.x & (nq - 1u)) : 0u; dry = 0;
+        nq = queues; per = nq > 1u ? MIW_PLACE_PIECES * 64u : n_lanes; q = 0u; dry = 0; t_fetch = 0;
         ticks = 0; quarter = 0; tail_prio = 0; sample_end_ = spp;
+        if (nq > 1u) {
+            const uint32_t hw = (uint32_t) __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)),          // HW_REG_HW_ID: simd [5:4] cu [11:8] sh [12] se [15:13]
+                           xcc = (uint32_t) __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));          // HW_REG_XCC_ID [3:0]
+            const uint32_t key = ((xcc & 15u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+            uint32_t id = 0;
+            if ((threadIdx.x & 63u) == 0u) {
+                id = __hip_atomic_load(Q->simd_ids + 1u + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (id == 0xffffffffu) {
+                    const uint32_t fresh = atomicAdd(Q->simd_ids, 1u);                                     // word 0: the next free queue
+                    const uint32_t old = atomicCAS(Q->simd_ids + 1u + key, 0xffffffffu, fresh);
+                    id = old == 0xffffffffu ? fresh : old;
+                }
+            }
+            q = (uint32_t) __shfl((int) id, 0, 64) % nq;
+        }
     }
     // Least-progress-first among the wavefronts of a SIMD, for shards with about one pixel per resident lane (tail_prio set
     // by the host): a pixel's samples are one serial PCG32 stream, so such a launch is one pixel deep and lasts as long as its
@@ -59,7 +81,7 @@ struct QueueWork {
     // slots, so throughput is what it was. Evaluated every 16th iteration (one wave-wide minimum of the lanes' sample counters).
     uint32_t ticks, quarter, tail_prio, sample_end_; uint32_t *prog;      // prog: this wavefront's word in LDS (the wave-wide minimum)
     __device__ __forceinline__ void tick(uint32_t sample_idx, bool has_pixel) {
-        if (!tail_prio) return;
+        if (!tail_prio) { ++ticks; return; }
         // (called from divergent code: the lanes that just fetched a pixel are not here — so no cross-lane shuffles; the
         // counter of the first active lane decides, the minimum goes through one LDS atomic per lane)
         if ((uint32_t) __builtin_amdgcn_readfirstlane((int) ++ticks) & 15u) return;
@@ -90,16 +112,24 @@ struct QueueWork {
             if (me == leader) base = atomicAdd(next_pixel + q, (uint32_t) __popcll(b));
             base = (uint32_t) __shfl((int) base, (int) leader, 64);
             const uint32_t idx = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
-            const uint32_t lo = q * per, hi = lo + per < n_lanes ? lo + per : n_lanes;
-            if (idx >= per || lo + idx >= hi) { q = q + 1u == nq ? 0u : q + 1u; ++dry; continue; }   // this queue is empty: on to the next
-            lane = lo + idx;
+            uint32_t l = idx;
+            if (nq > 1u) {                                      // placed queues: queue q = up to MIW_PLACE_PIECES pieces of 64 lanes
+                const uint32_t piece = idx < per ? Q->piece_list[q * MIW_PLACE_PIECES + (idx >> 6)] : 0xffffffffu;
+                l = piece == 0xffffffffu ? 0xffffffffu : piece * 64u + (idx & 63u);
+            }
+            if (l >= n_lanes) { q = q + 1u == nq ? 0u : q + 1u; ++dry; continue; }   // this queue is empty: on to the next
+            lane = l;
             st = Q->st[lane];
             if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
             pixel = Q->pixel[lane];
+            t_fetch = ticks;
             return true;
         }
     }
-    __device__ __forceinline__ void store(U4 st) { Q->st[lane] = st; }
+    __device__ __forceinline__ void store(U4 st) {
+        Q->st[lane] = st;
+        if (Q->piece_cost) atomicAdd(Q->piece_cost + (lane >> 6), ticks - t_fetch);   // iterations this pixel took in this launch
+    }
     __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
         if (Q->log_rec) {                                       // wave-uniform: one format per render
             LogSink16<const float *> sink{ Q->log_rec, thr, film, lane, spp, Q->log_rej };

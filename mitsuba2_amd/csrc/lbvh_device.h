@@ -3,7 +3,7 @@
 // the reference (src/librender/scene_native.inl:3-10); like the host SAH builder it only has to
 // deliver a tree whose traversal result equals brute force (bvh.h), so none of the kd-tree's
 // structure is reproduced. Output format = the SAH builder's: 64-byte BVH2 nodes holding both child
-// boxes + parent links, root = node 0, up to 4 triangles per leaf (fat leaves, below), triangles permuted into leaf order.
+// boxes + parent links, root = node 0, up to 2 triangles per leaf by default (fat leaves, below), triangles permuted into leaf order.
 // The 4-wide tree of the phase machine is collapsed from it on the device as well (bvh4_device.h).
 //
 // Kernels (hand-written; the key sort itself is rocPRIM's device radix sort via hipCUB — a plain
@@ -96,10 +96,10 @@ __device__ __forceinline__ int lbvh_delta(const uint64_t *keys, int n, int i, in
 struct LbvhLinks { int32_t left, right, parent; };   // child >= 0: inner node, < 0: ~leaf index
 
 // Fat leaves: an inner node of the radix tree covers a contiguous run of the sorted triangles, so a subtree of at most
-// `max_leaf` triangles can stand in the emitted BVH2 as ONE leaf (first = start of the run, count = its length) — the SAH
-// builder's leaves hold up to 4 triangles too, and a tree of single-triangle leaves has twice the nodes and two more levels
-// (measured with one triangle per leaf: device-LBVH frames 14 % / 25 % slower than SAH frames on the interior / the material
-// balls). span[i] / first[i] = length and start of node i's run; the nodes inside a fat leaf stay in the arrays, unreferenced.
+// `max_leaf` triangles can stand in the emitted BVH2 as ONE leaf (first = start of the run, count = its length): a tree of
+// single-triangle leaves has twice the nodes and one more level. Measured on the 0.9 M-triangle interior (Msamples/s; host
+// SAH 369): 1 triangle per leaf 311, 2 -> 352, 4 -> 334, 8 -> 302; the material balls, whose few huge wall triangles Morton
+// order serves badly whatever the leaf size, stay 25 % behind their SAH tree (676 / 660 / 638 / 616 against 900). span[i] / first[i] = length and start of node i's run; the nodes inside a fat leaf stay in the arrays, unreferenced.
 __global__ void k_lbvh_tree(const uint64_t *keys, int n, LbvhLinks *inner, int32_t *leaf_parent, uint32_t *span, uint32_t *first) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;

@@ -17,7 +17,7 @@
 
 namespace miw {
 
-#define MIW_BVH4_ABSENT ((int32_t) 0x80000000)      /* = MIW_WALK_DONE: never a leaf code */
+#define MIW_BVH4_ABSENT ((int32_t) 0x80000000)      /* = MIW_WALK_DONE: never a leaf code, as leaf codes address fewer than 2^27 triangles (mi_scene_upload refuses more) */
 
 struct alignas(64) Bvh4Node {
     float origin[3];          // lo corner of the node's box

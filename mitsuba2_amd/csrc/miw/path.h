@@ -66,6 +66,9 @@ struct LaneQueues {
     U4 *log_rec;
     const float *log_thr;   // the 256 phase thresholds (global memory; kernels that stage them in LDS pass their own pointer)
     uint32_t log_rej;       // class index of a rejected sample = the class count (the first all-zero row of the weight table)
+    // placed pixel queues of small shards (device/resident_kernel.h: QueueWork): cost of every 64-lane piece (written by the
+    // measuring launch, nullptr otherwise), four pieces per SIMD queue, the SIMD registry (word 0: next id; then by hardware id)
+    uint32_t *piece_cost; const uint32_t *piece_list; uint32_t *simd_ids;
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)

@@ -287,7 +287,11 @@ std::shared_ptr<Mesh> load_ply(const Properties &props) {
 bool PreliminaryIntersection3f::is_valid() const { return t != std::numeric_limits<float>::infinity(); }
 
 Scene::Scene() {}
-Scene::~Scene() { if (m_ctx) mi_destroy(m_ctx); }
+Scene::~Scene() {
+    // the emitters go back to "part of no scene" (they may outlive it: shared_ptr), so that another scene can take them
+    for (const Emitter *e : m_emitter_objs) if (e->m_scene == this) { Emitter *w = const_cast<Emitter *>(e); w->m_scene = nullptr; w->m_index = -1; }
+    if (m_ctx) mi_destroy(m_ctx);
+}
 std::array<float, 6> Scene::bbox() const {
     const float inf = std::numeric_limits<float>::infinity();
     std::array<float, 6> b{ inf, inf, inf, -inf, -inf, -inf };
@@ -490,6 +494,10 @@ void Scene::build(int device, int bvh_quality) {
     if (m_env) m_emitter_objs.insert(m_emitter_objs.begin() + std::min<size_t>(m_env_rec.emitter_index, m_emitter_objs.size()), m_env.get());
     for (size_t i = 0; i < m_emitter_objs.size(); ++i) {
         Emitter *e = const_cast<Emitter *>(m_emitter_objs[i]);
+        // an emitter answers eval / sample_direction / pdf_direction through the ONE scene it is part of (the reference's
+        // emitters hold their shape, never two scenes): sharing it would leave the first scene querying the second's tables
+        if (e->m_scene && e->m_scene != this)
+            Throw("Scene: emitter (or the mesh carrying it) is already part of another scene; build it from its own objects");
         e->m_scene = this; e->m_index = (int32_t) i; e->m_is_env = m_env && e == m_env.get();
     }
     m_built = true;

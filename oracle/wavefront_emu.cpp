@@ -186,6 +186,7 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
                int stack_budget, int max_fan, uint32_t *stats6) {
     EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
     Ftz ftz;
+    if (stack_budget < 1 || stack_budget > 127) return -3;                  // bvh4_intersect's host stack holds 128 entries
     const Bvh4BuildResult b4 = bvh4_collapse(sc.bvh.nodes, (uint32_t) stack_budget, max_fan);
     uint32_t seen = 0;
     if (stats6) { stats6[0] = sc.view.node_count; stats6[1] = (uint32_t) b4.nodes.size(); stats6[2] = b4.depth; stats6[3] = b4.stack_bound; stats6[4] = 0; stats6[5] = b4.ok ? 1u : 0u; }
