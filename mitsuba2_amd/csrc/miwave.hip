@@ -1124,6 +1124,18 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         Counters sum;
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
+        if (K.placed && getenv("MIW_DEBUG")) {                     // how the placed launch went: SIMDs that registered, lanes handed out per queue
+            std::vector<uint32_t> cur(n_simd), ids(1u + (1u << 14)), cost(n_pieces);
+            (void) hipMemcpy(cur.data(), c->d_next_pixel.p, n_simd * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void) hipMemcpy(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void) hipMemcpy(cost.data(), c->d_piece_cost.p, n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            uint32_t keys = 0, key_or = 0, full = 0, over = 0; uint64_t csum = 0; uint32_t cmin = ~0u, cmax = 0;
+            for (uint32_t k = 0; k < (1u << 14); ++k) if (ids[1 + k] != 0xffffffffu) { ++keys; key_or |= k; }
+            for (uint32_t v : cur) { full += v >= 64u * MIW_PLACE_PIECES; over += v > 64u * MIW_PLACE_PIECES; }
+            for (uint32_t v : cost) { csum += v; cmin = std::min(cmin, v); cmax = std::max(cmax, v); }
+            fprintf(stderr, "[miwave] placed queues: %u ids handed out, %u distinct hardware keys (bits used 0x%x), %u of %u queues drained (%u asked beyond their end), "
+                            "piece cost min / mean / max = %u / %.0f / %u iterations\n", ids[0], keys, key_or, full, n_simd, over, cmin, (double) csum / n_pieces, cmax);
+        }
 #if defined(MIW_VERIFY_FILTER)
         {
             unsigned int n = 0; float buf[256];
