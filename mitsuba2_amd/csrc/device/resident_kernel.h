@@ -50,26 +50,21 @@ struct QueueWork {
     // So the host measures every piece's cost in a first short launch (Q->piece_cost: iterations per piece over the first
     // eighth of the samples), deals the pieces to the SIMDs longest-first (Q->piece_list: four pieces per queue, equal sums)
     // and the second launch lets a wavefront take its pixels from the queue of the SIMD it runs on: HW_ID / XCC_ID name the
-    // SIMD, the first wavefront to show up on it registers it (Q->simd_ids). A lane whose queue has run dry moves on to the
-    // next one (per lane: `q`, `dry`), so pieces of SIMDs nobody registered are still rendered.
+    // SIMD (Q->simd_ids: marked present by the measuring launch, numbered by the host). A lane whose queue has run dry moves
+    // on to the next one (per lane: `q`, `dry`), so no piece can be left behind; the first lane that has found every queue
+    // empty raises a flag (simd_ids[0]) that spares the others the scan.
     uint32_t nq, per, q, dry, t_fetch;
     __device__ __forceinline__ void init_queues(uint32_t queues) {
         nq = queues; per = nq > 1u ? MIW_PLACE_PIECES * 64u : n_lanes; q = 0u; dry = 0; t_fetch = 0;
         ticks = 0; quarter = 0; tail_prio = 0; sample_end_ = spp;
-        if (nq > 1u) {
+        if (Q->simd_ids) {
+            // which SIMD this wavefront runs on. The measuring launch only marks the SIMD as present (the host numbers the present
+            // ones 0 .. n - 1 afterwards); the placed launch looks its queue up.
             const uint32_t hw = (uint32_t) __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)),          // HW_REG_HW_ID: simd [5:4] cu [11:8] sh [12] se [15:13]
                            xcc = (uint32_t) __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));          // HW_REG_XCC_ID [3:0]
             const uint32_t key = ((xcc & 15u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
-            uint32_t id = 0;
-            if ((threadIdx.x & 63u) == 0u) {
-                id = __hip_atomic_load(Q->simd_ids + 1u + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (id == 0xffffffffu) {
-                    const uint32_t fresh = atomicAdd(Q->simd_ids, 1u);                                     // word 0: the next free queue
-                    const uint32_t old = atomicCAS(Q->simd_ids + 1u + key, 0xffffffffu, fresh);
-                    id = old == 0xffffffffu ? fresh : old;
-                }
-            }
-            q = (uint32_t) __shfl((int) id, 0, 64) % nq;
+            if (nq > 1u) { const uint32_t id = Q->simd_ids[1u + key]; q = id < nq ? id : key % nq; }
+            else if ((threadIdx.x & 63u) == 0u) Q->simd_ids[1u + key] = 1u;
         }
     }
     // Least-progress-first among the wavefronts of a SIMD, for shards with about one pixel per resident lane (tail_prio set
@@ -100,7 +95,11 @@ struct QueueWork {
     }
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
-            if (dry >= nq) return false;                        // every queue is empty
+            if (dry >= nq) {                                    // every queue is empty: say so to everybody (placed queues: a scan of all
+                if (nq > 1u) Q->simd_ids[0] = 1u;               // of them costs a thousand round trips — once per launch is enough)
+                return false;
+            }
+            if (nq > 1u && __hip_atomic_load(Q->simd_ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { dry = nq; return false; }
             // the lanes asking now are served queue by queue: this trip, those that ask the leader's queue — one atomic for all of them
             const unsigned long long all = __ballot(1);
             const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) all) - 1u;

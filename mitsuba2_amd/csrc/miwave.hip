@@ -989,6 +989,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         if (place) {
             HIP_TRY(c, c->d_piece_cost.resize(n_pieces)); HIP_TRY(c, c->d_piece_list.resize((size_t) n_simd * MIW_PLACE_PIECES)); HIP_TRY(c, c->d_simd_ids.resize(1u + (1u << 14)));
             HIP_TRY(c, hipMemsetAsync(c->d_piece_cost.p, 0, n_pieces * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(c->d_simd_ids.p, 0, c->d_simd_ids.n * sizeof(uint32_t), s));
         }
         // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
         TileArgs TA; memset(&TA, 0, sizeof TA);
@@ -1014,17 +1015,26 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, c->d_next_pixel.n * sizeof(uint32_t), s));
                 rcfg.queues = 1u; Q.piece_cost = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr;
-                if (place && done == 0) { end = measure_end; Q.piece_cost = c->d_piece_cost.p; }       // the measuring launch
+                if (place && done == 0) { end = measure_end; Q.piece_cost = c->d_piece_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch
                 else if (place) {
                     // longest piece first onto the SIMD queue with the smallest sum that still has a free slot
                     std::vector<uint32_t> cost(n_pieces);
                     HIP_TRY(c, hipMemcpyAsync(cost.data(), c->d_piece_cost.p, n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
-                    std::vector<uint32_t> order(n_pieces), list((size_t) n_simd * MIW_PLACE_PIECES, 0xffffffffu), fill(n_simd, 0u);
+                    // the SIMDs the measuring launch ran on, numbered 0 .. nqueues - 1 (simd_ids[1 + hardware key]; word 0 = the "all dry" flag)
+                    std::vector<uint32_t> ids(c->d_simd_ids.n);
+                    HIP_TRY(c, hipMemcpyAsync(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    uint32_t nqueues = 0;
+                    for (size_t k = 1; k < ids.size(); ++k) ids[k] = ids[k] ? nqueues++ : 0xffffffffu;
+                    ids[0] = 0u;
+                    if (nqueues < 2u || (uint64_t) nqueues * MIW_PLACE_PIECES < n_pieces) nqueues = 0;   // (cannot happen on a whole device; then: one queue)
+                    if (nqueues) {
+                    std::vector<uint32_t> order(n_pieces), list((size_t) nqueues * MIW_PLACE_PIECES, 0xffffffffu), fill(nqueues, 0u);
                     for (uint32_t i = 0; i < n_pieces; ++i) order[i] = i;
                     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
                     std::vector<std::pair<uint64_t, uint32_t>> heap;                                       // (sum, queue), smallest sum on top
-                    for (uint32_t qd = 0; qd < n_simd; ++qd) heap.push_back({ 0ull, qd });
+                    for (uint32_t qd = 0; qd < nqueues; ++qd) heap.push_back({ 0ull, qd });
                     auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
                     std::make_heap(heap.begin(), heap.end(), cmp);
                     for (uint32_t i : order) {
@@ -1034,12 +1044,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                         top.first += cost[i];
                         if (fill[top.second] < MIW_PLACE_PIECES) { heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp); }
                     }
+                    HIP_TRY(c, c->d_piece_list.resize(list.size()));
                     HIP_TRY(c, hipMemcpyAsync(c->d_piece_list.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                    HIP_TRY(c, hipMemsetAsync(c->d_simd_ids.p, 0xff, c->d_simd_ids.n * sizeof(uint32_t), s));
-                    HIP_TRY(c, hipMemsetAsync(c->d_simd_ids.p, 0, sizeof(uint32_t), s));
-                    HIP_TRY(c, hipStreamSynchronize(s));                                                     // `list` (host vector) must outlive the copy
-                    rcfg.queues = n_simd; Q.piece_list = c->d_piece_list.p; Q.simd_ids = c->d_simd_ids.p;
+                    HIP_TRY(c, hipMemcpyAsync(c->d_simd_ids.p, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));                                                     // the host vectors must outlive the copies
+                    rcfg.queues = nqueues; Q.piece_list = c->d_piece_list.p; Q.simd_ids = c->d_simd_ids.p;
                     K.placed = 1u;
+                    }
                 }
                 // persistent grid: 4 workgroups per CU. The plain-diffuse packet kernel is compiled for 4 waves per SIMD
                 // (128 VGPRs; +8 % over 3 on C2). (Round 2 launched 3 per CU for shards of about one pixel per resident lane; with the
@@ -1131,9 +1142,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             (void) hipMemcpy(cost.data(), c->d_piece_cost.p, n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost);
             uint32_t keys = 0, key_or = 0, full = 0, over = 0; uint64_t csum = 0; uint32_t cmin = ~0u, cmax = 0;
             for (uint32_t k = 0; k < (1u << 14); ++k) if (ids[1 + k] != 0xffffffffu) { ++keys; key_or |= k; }
+            ids[0] = keys;
             for (uint32_t v : cur) { full += v >= 64u * MIW_PLACE_PIECES; over += v > 64u * MIW_PLACE_PIECES; }
             for (uint32_t v : cost) { csum += v; cmin = std::min(cmin, v); cmax = std::max(cmax, v); }
-            fprintf(stderr, "[miwave] placed queues: %u ids handed out, %u distinct hardware keys (bits used 0x%x), %u of %u queues drained (%u asked beyond their end), "
+            fprintf(stderr, "[miwave] placed queues: %u SIMDs numbered, %u distinct hardware keys (bits used 0x%x), %u of %u queues drained (%u asked beyond their end), "
                             "piece cost min / mean / max = %u / %.0f / %u iterations\n", ids[0], keys, key_or, full, n_simd, over, cmin, (double) csum / n_pieces, cmax);
         }
 #if defined(MIW_VERIFY_FILTER)
