@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #endif
 #define MIW_FG_WSTRIDE 7               /* LDS stride of a class's weights: offsets 0..4 used, 5..6 zero (6 = "lane outside the window") */
 template <int GW, int GH>
-__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles, uint32_t xcd_swizzle) {
+__global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A, PatchArgs PA, float *tiles) {
     constexpr int GL = GW * GH, NG = 64 / GL, GPX = MIW_FP_SIDE / GW;       // lanes per group, groups, groups per patch row
     constexpr int LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
     static_assert(PASSES >= 1, "group too large");
@@ -169,10 +169,9 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
     __shared__ uint32_t s_m[NG];
     __shared__ uint4 s_rec[NG][MIW_FG_CHUNK + 1];
     const uint32_t l = threadIdx.x;
-    // consecutive workgroup ids go to consecutive XCDs (8 of them, one L2 each): with the swizzle the patches of one block
-    // tile — whose windows share sample rows — run on ONE XCD, next to each other in time
-    uint32_t wg = blockIdx.x;
-    if (xcd_swizzle) { const uint32_t per = gridDim.x >> 3; if (wg < per * 8u) wg = (wg & 7u) * per + (wg >> 3); }
+    // (consecutive workgroup ids go to consecutive XCDs, one L2 each; remapping them so that the patches of one block tile —
+    // whose windows share sample rows — run on ONE XCD measured no difference: 29.7 ms either way. Plain mapping.)
+    const uint32_t wg = blockIdx.x;
     const uint32_t tile = wg / (PA.patches_x * PA.patches_y), patch = wg % (PA.patches_x * PA.patches_y);
     const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
     const BlockGeom g = block_geom(F, A.blocks_x, b);

@@ -129,9 +129,6 @@ __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t),
 #ifndef MIW_LDS_TOP
 #define MIW_LDS_TOP 0             /* 1: the first 255 nodes of a tree that does not fit LDS are staged there — a flat-address select per node visit; measured 4 - 12 % slower than plain global loads (the top of the tree lives in L1 / L2 anyway) */
 #endif
-#ifndef MIW_CAND_PAIR
-#define MIW_CAND_PAIR 0           /* 1: the packet kernels' candidate loops test two candidates per trip (both packets read up front) */
-#endif
 #ifndef MIW_TREE_WAVES
 #define MIW_TREE_WAVES 3          /* waves per SIMD the tree-walk kernel is compiled for; 4 (<= 128 VGPRs) spills 23 registers and measured 10-20 % slower on C3 / C4 */
 #endif
@@ -362,41 +359,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
         MIW_SECTION(1);
-#if MIW_CAND_PAIR
-        // two candidates per trip: both 48-byte packets are read from LDS before either Moeller-Trumbore test runs, so a
-        // trip pays one LDS round trip for two tests and the two dependency chains overlap (candidates in ascending packet
-        // order, so the closest-hit / tie rule sees them as the one-per-trip loop does)
-        while (mE != 0) {
-            const uint32_t i1 = lowest(mE);
-            mE &= mE - 1;
-            const bool two = mE != 0;
-            const uint32_t i2 = two ? lowest(mE) : i1;
-            mE &= mE - 1;                                      // 0 stays 0
-            const TriPacket &k1 = pk[i1], &k2 = pk[i2];
-            const V3 a0 = ld3(k1.p0), a1 = ld3(k1.e1), a2 = ld3(k1.e2), b0 = ld3(k2.p0), b1 = ld3(k2.e1), b2 = ld3(k2.e2);
-            const uint32_t pa = k1.prim, pb = k2.prim;
-            float t1, u1, v1, t2, u2, v2;
-            const bool h1 = ray_intersect_triangle_edges(a0, a1, a2, o, dE, mint, maxtE, t1, u1, v1);
-            const bool h2 = ray_intersect_triangle_edges(b0, b1, b2, o, dE, mint, maxtE, t2, u2, v2) && two;
-            if (h1 && (t1 < h.t || (t1 == h.t && pa < h.prim))) { h.t = t1; h.u = u1; h.v = v1; h.tri = i1; h.prim = pa; }
-            if (h2 && (t2 < h.t || (t2 == h.t && pb < h.prim))) { h.t = t2; h.u = u2; h.v = v2; h.tri = i2; h.prim = pb; }
-        }
-        MIW_SECTION(2);
-        uint32_t s_tri = 0; float s_t = 0.f;
-        while (mS != 0) {                                      // any hit of S, two candidates per trip
-            const uint32_t i1 = lowest(mS);
-            mS &= mS - 1;
-            const bool two = mS != 0;
-            const uint32_t i2 = two ? lowest(mS) : i1;
-            mS &= mS - 1;
-            const TriPacket &k1 = pk[i1], &k2 = pk[i2];
-            const V3 a0 = ld3(k1.p0), a1 = ld3(k1.e1), a2 = ld3(k1.e2), b0 = ld3(k2.p0), b1 = ld3(k2.e1), b2 = ld3(k2.e2);
-            float t1, u1, v1, t2, u2, v2;
-            const bool h1 = ray_intersect_triangle_edges(a0, a1, a2, o, dS, mint, maxtS, t1, u1, v1);
-            const bool h2 = ray_intersect_triangle_edges(b0, b1, b2, o, dS, mint, maxtS, t2, u2, v2) && two;
-            if (h1 || h2) { occ = true; mS = 0; s_tri = h1 ? i1 : i2; s_t = h1 ? t1 : t2; }   // the first hit in packet order, as the one-per-trip loop reports
-        }
-#else
         while (mE != 0) {                                      // closest hit of E over its candidates
             const uint32_t i = lowest(mE);
             mE &= mE - 1;
@@ -416,7 +378,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 occ = true; mS = 0; s_tri = i; s_t = t;
             }
         }
-#endif
         // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
         // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
         // through the full sweep with the rule inside, which is what the rule means.

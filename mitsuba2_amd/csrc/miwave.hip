@@ -981,10 +981,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // samples, at least 16) records what every 64-lane piece costs, the pieces are dealt to the SIMDs longest-first, and the
         // rest of the samples run with every wavefront taking its pixels from the queue of the SIMD it sits on (resident_kernel.h:
         // QueueWork). Same samples, same log slots: the film does not change. MIW_PLACE = 0 | 1 overrides.
-        bool place = film_mode == 1 && !direct && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * MIW_PLACE_PIECES * n_simd &&
+        // (only where every pixel of the shard can be resident at once: 4 wavefronts per SIMD for the plain-diffuse packet kernel and
+        // the phase machine over big trees, 3 for the other kernels — a shard larger than that is balanced by the queue itself)
+        const uint32_t res_waves = (c->lds_cfg.brute && c->diffuse_only && !MIW_SPECTRAL) || (!c->lds_cfg.brute && c->view.tri_count >= 200000u) ? 4u : 3u;
+        bool place = film_mode == 1 && !direct && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = getenv("MIW_PLACE")) place = place && atoi(e) != 0;
-        const uint32_t measure_end = place ? std::max<uint32_t>(16u, cfg->spp / 8u) : 0u;
+        uint32_t measure_div = 8u;                                 // the measuring launch runs spp / 8 samples (MIW_PLACE_MEASURE = divisor)
+        if (const char *e = getenv("MIW_PLACE_MEASURE")) measure_div = (uint32_t) std::max(2, atoi(e));
+        const uint32_t measure_end = place ? std::max<uint32_t>(16u, cfg->spp / measure_div) : 0u;
         const uint32_t n_pieces = (n_lanes + 63u) / 64u;
         if (place) {
             HIP_TRY(c, c->d_piece_cost.resize(n_pieces)); HIP_TRY(c, c->d_piece_list.resize((size_t) n_simd * MIW_PLACE_PIECES)); HIP_TRY(c, c->d_simd_ids.resize(1u + (1u << 14)));
@@ -1316,13 +1321,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 if (rec16) {
                     // 16-byte class records -> per-group pixel lists (k_film_groups). Group shape: 2x2 reads 6.25 sample rows per texel,
                     // 4x4 3.06 but spends 0.77 wave-iterations per sample; 4x2 (4.4 rows, 0.55) balances HBM reads against issue slots.
-                    // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4); MIW_FILM_XCD = 0 | 1: patches of one tile on one XCD.
+                    // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4).
                     int group = 3;
                     if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
-                    uint32_t swz = 1u;
-                    if (const char *e = getenv("MIW_FILM_XCD")) swz = atoi(e) ? 1u : 0u;
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
-#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p, swz))
+#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
                     if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
 #undef MIW_FG_LAUNCH
                 } else if (wide)

@@ -608,3 +608,29 @@ def test_device_against_committed_golden_films(native, dev):
         dev.upload(scene.desc())
         film, st = dev.render(job)
         assert st == 0 and np.array_equal(film, g["film_" + key]) and dev.counters().segments == int(g["segments_" + key]), key
+
+
+def test_placed_queues_and_priorities_do_not_change_the_film(native):
+    """What one rank of an 8-GPU frame renders (1/8 of the 1080p tiles: one pixel per resident lane) goes through a measuring
+    launch + per-SIMD pixel queues + least-progress-first wave priorities (csrc/device/resident_kernel.h: QueueWork). All of it is
+    scheduling: the samples and their log slots are the same, so the film must be the plain launch's bit for bit."""
+    import os
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(1920, 1080, 128, device=-1)
+    dev = native.Device(0)
+    dev.upload(scene.desc())
+    integ = native.PathIntegrator(); integ.set_shard(0, 8)
+    job = integ.render_job(sensor)
+    films = {}
+    for name, env in (("default", {}), ("plain", {"MIW_PLACE": "0", "MIW_TAIL_PRIO": "0"})):
+        os.environ.update(env)
+        try:
+            films[name], st = dev.render(job, samples_per_launch=128)
+        finally:
+            for k in env:
+                del os.environ[k]
+        c = dev.counters()
+        assert st == 0 and c.samples > 0
+        assert c.placed == (1 if name == "default" else 0) and c.n_path == (2 if name == "default" else 1)
+    assert np.array_equal(films["default"], films["plain"]) and films["default"][..., 4].max() > 0
+    dev.close()

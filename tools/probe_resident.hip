@@ -1,5 +1,5 @@
 // ISA probe: only the C2 kernel, k_path_resident<true, 1, MATS_DIFFUSE...> (see tools/probe_phased.hip):
-//   cd /tmp/x && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -c -save-temps [-DMIW_CAND_PAIR=1] <repo>/tools/probe_resident.hip
+//   cd /tmp/x && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-flush-denormals-to-zero -c -save-temps <repo>/tools/probe_resident.hip
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <vector>
