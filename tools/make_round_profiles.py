@@ -42,8 +42,9 @@ def bench_line(g, name, label=None, extra=""):
         return "%s: (no line)" % (label or name)
     import re
     m = re.search(r"@ (\d+) spp", j["config"]["workload"])
-    return "%s: %.1f Msamples/s, %.1f ms/frame (%s spp), S = %.2f, kernels ms/frame %s%s" % (
-        label or name, j["value"], j["ms_per_step"], m.group(1) if m else "?", j["roofline"].get("segments_per_sample", float("nan")), per_frame(j), extra)
+    return "%s: %.1f Msamples/s, %.1f ms/frame (%s spp), S = %.2f, kernels ms/frame %s [bvh: %s, %.1f ms]%s" % (
+        label or name, j["value"], j["ms_per_step"], m.group(1) if m else "?", j["roofline"].get("segments_per_sample", float("nan")), per_frame(j),
+        j["config"]["bvh"]["builder"], j["config"]["bvh"]["build_ms"], extra)
 
 
 def pmc_text(g, name):
@@ -109,7 +110,7 @@ def main():
     os.chdir(ROOT)
     g = os.path.join("gpurun_out", tag)
     sha = bench.kernel_src_sha16()
-    head = "# kernel sources sha256[:16] = %s (bench.kernel_src_sha16(): mitsuba2_amd/csrc/**/*.h)" % sha
+    head = "# kernel sources sha256[:16] = %s (bench.kernel_src_sha16(): mitsuba2_amd/csrc/**/*.{h,hip})" % sha
     cmd = "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline%s   (tools/profile_round.sh %s)"
     stats = lambda name: open(glob.glob("%s_%s_trace/*/*kernel_stats.csv" % (g, name))[0]).read().strip()
     pmc_head = "# PMC passes (each counter set in its own run; FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x2 per MI355X_MICROARCH.md §HBM)"
@@ -133,6 +134,14 @@ def main():
         j = last_json(g + "_shard_%d.log" % n)
         if j:
             out.append("1/%d: %.1f ms  %s" % (n, j["ms_per_step"], per_frame(j)))
+    out.append("# scheduling A/B (round 3): the 1/8 shard without the per-SIMD placement (MIW_PLACE=0), without the wave priorities as well "
+               "(MIW_PLACE=0 MIW_TAIL_PRIO=0), with a measuring launch of spp / 16 instead of spp / 8 samples (MIW_PLACE_MEASURE=16); the "
+               "full frame without the priorities (MIW_TAIL_PRIO=0); the full frame on the 24-byte position log + texel-patch replay (MIW_FILM_LEGACY=1)")
+    for name, label in (("shard_8_noplace", "1/8, no placement"), ("shard_8_plain", "1/8, no placement, no priorities"), ("shard_8_measure16", "1/8, measuring launch spp/16"),
+                        ("bench_c2_noprio", "1/1, no priorities"), ("bench_c2_legacy_log", "1/1, 24-byte log")):
+        j = last_json(g + "_%s.log" % name)
+        if j:
+            out.append("%s: %.1f ms  %s" % (label, j["ms_per_step"], per_frame(j)))
     open(path, "w").write("\n".join(out + notes) + "\n")
     traffic["scalar_rgb/cornell/1920x1080@512/plan2/film1/launch512"] = traffic_entry(g, "c2", sha, "profiles/" + os.path.basename(path))
 
@@ -146,8 +155,10 @@ def main():
                pmc_head, pmc_text(g, name), "",
                "# bench lines of the same session: phase machine (default) / lock-step resident kernel (MIW_PHASED=0) / wavefront plan with "
                "the stream walk kernel (--plan 1) / phase machine over the BVH2 instead of the 4-wide tree (MIW_BVH4=0) / shade vote 1 : 1 instead of "
-               "3 : 2 (2 : 1 with an environment map) (MIW_SHADE_VOTE=1:1) / device LBVH (--bvh-quality 0)"]
-        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh"):
+               "3 : 2 (2 : 1 with an environment map) (MIW_SHADE_VOTE=1:1) / device LBVH with its 4-wide tree collapsed on the device (--bvh-quality 0) / "
+               "the same with the collapse on the host after a read-back (MIW_BVH4_HOST=1) / with one triangle per LBVH leaf (MIW_LBVH_LEAF=1); "
+               "bvh build ms in brackets"]
+        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh", "_lbvh_hostcollapse", "_lbvh_leaf1"):
             if os.path.exists("%s_bench_%s%s.log" % (g, name, suffix)):
                 out.append(bench_line(g, "bench_%s%s" % (name, suffix), name + suffix))
         if name == "c3":
@@ -156,11 +167,17 @@ def main():
                 j = last_json(g + "_tess_%d.log" % t)
                 if j:
                     out.append("tess %d: %6d triangles  %.1f Msamples/s  %s" % (t, j["config"]["bvh"]["tris"], j["value"], j["roofline"]["kernel"]))
-            out.append("# tile shards of the 256 spp job: 1/1 = 4 x this frame")
-            for n in (2, 8):
-                j = last_json(g + "_c3_shard_%d.log" % n)
+            out.append("# tile shards of the 256 spp job (1/8 also without the wave priorities, MIW_TAIL_PRIO=0)")
+            for n, suffix in ((2, ""), (8, ""), (8, "_plain")):
+                j = last_json(g + "_c3_shard_%d%s.log" % (n, suffix))
                 if j:
-                    out.append("1/%d: %.1f ms  %s" % (n, j["ms_per_step"], per_frame(j)))
+                    out.append("1/%d%s: %.1f ms  %s" % (n, suffix, j["ms_per_step"], per_frame(j)))
+        if name == "c4":
+            out.append("# 1/8 tile shard of the 64 spp job (and without placement / priorities, MIW_PLACE=0 MIW_TAIL_PRIO=0)")
+            for suffix in ("", "_plain"):
+                j = last_json(g + "_c4_shard_8%s.log" % suffix)
+                if j:
+                    out.append("1/8%s: %.1f ms  %s" % (suffix, j["ms_per_step"], per_frame(j)))
         open(path, "w").write("\n".join(out + notes) + "\n")
         traffic["scalar_rgb/%s/1920x1080@%d/plan2/film1/launch%d" % (key, spp, spp)] = traffic_entry(g, name, sha, "profiles/" + os.path.basename(path))
 
