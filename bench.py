@@ -105,6 +105,74 @@ def cpu_baseline(O, np, scene, make_integrator, sensor, W, H, SPP):
                               "sample": "first %d spiral blocks at %d spp, %d samples, %.1f s" % (n1, SPP, st1.samples, st1.seconds)}}
 
 
+LIVE_PASSES = (("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"),
+               ("SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
+               ("FETCH_SIZE",), ("WRITE_SIZE",))
+
+
+def parse_counter_dirs(dirs):
+    """{kernel base name: {counter: sum over its dispatches, "_dispatches": n}} of rocprofv3 --pmc output directories (csv)"""
+    import csv
+    import glob
+    out = {}
+    for d in dirs:
+        seen = set()
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                e = out.setdefault(k, {})
+                name = r["Counter_Name"] + ("@2" if r["Counter_Name"] == "SQ_WAVE_CYCLES" and d.endswith("pass1") else "")   # (the wave cycles of the SQ_WAIT_ANY pass)
+                e[name] = e.get(name, 0.0) + float(r["Counter_Value"])
+                if d.endswith("pass0") and (k, r["Dispatch_Id"]) not in seen:
+                    seen.add((k, r["Dispatch_Id"])); e["_dispatches"] = e.get("_dispatches", 0) + 1
+    return out
+
+
+def counters_to_entry(c):
+    """HBM bytes and issue statistics of one kernel from its summed counters (per dispatch): FETCH_SIZE / WRITE_SIZE are in KiB,
+    FETCH_SIZE under-reports a wide stream by 2x on gfx950 (MI355X_MICROARCH.md, section HBM); a wave64 VALU instruction
+    occupies a SIMD-32 for 2 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    n = max(int(c.get("_dispatches", 1)), 1)
+    rd, wr = c["FETCH_SIZE"] * 1024 * 2 / n, c["WRITE_SIZE"] * 1024 / n
+    simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+    return {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+            "valu_issue_frac": c["SQ_INSTS_VALU"] * 2.0 / simd_cycles,
+            "lane_util": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+            "wait_mem_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES@2"] if c.get("SQ_WAVE_CYCLES@2") else None}
+
+
+def live_counters(argv_workload, kernel):
+    """The PMC counters of the dominant kernel, collected IN THIS RUN: four rocprofv3 passes (each counter set in its own pass,
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes) over one untimed frame of the same workload in a child process.
+    Returns the traffic.json-style entry of `kernel`, or None when rocprofv3 is not there or a pass fails (the caller then
+    falls back to the committed profile of the same kernel sources)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="miwave_pmc_", dir="/tmp")
+    try:
+        child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
+                 "--no-live-counters"] + argv_workload
+        dirs = []
+        for i, ctrs in enumerate(LIVE_PASSES):
+            d = os.path.join(tmp, "pass%d" % i); dirs.append(d)
+            r = subprocess.run(["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+        c = parse_counter_dirs(dirs).get(kernel)
+        need = ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+        if not c or any(k not in c for k in need):
+            return None
+        return counters_to_entry(c)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def run_extras(api, scenes, dev, film, C):
     """The other BASELINE configurations, OUTSIDE the timed headline and a few seconds each, so that the driver's own bench
     line observes the tree kernels too: configs[2] geometry (material balls, 40 972 triangles) at 64 spp, configs[3] class
@@ -161,6 +229,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not collect the dominant kernel's PMC counters in this run (four "
+                    "rocprofv3 passes over one extra frame in a child process, ~40 s; N = 1 only); roofline.traffic / .measured then come "
+                    "from profiles/traffic.json while the kernel sources still hash to what was profiled")
     ap.add_argument("--no-extras", action="store_true", help="skip the `extras` block (the other BASELINE configurations at a few "
                     "spp each, after the timed headline; only the default N = 1 Cornell run carries it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
@@ -306,25 +377,36 @@ def main():
             ms, n, alg_bytes = kernels[name]
             achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             b_alg = 280.0 * s_bar + 320.0
-            # What the counters say about that kernel (rocprofv3 PMC passes cannot run inside this process): the committed
-            # profiles/traffic.json entry of this exact workload — used only while the kernel sources still hash to what the
-            # profile was taken on (kernel_src_sha16), otherwise the fields stay null rather than go stale.
+            # What the counters say about that kernel: collected in this run (live_counters: rocprofv3 PMC passes over one more frame
+            # in a child process), else the committed profiles/traffic.json entry of this exact workload — used only while the
+            # kernel sources still hash to what the profile was taken on (kernel_src_sha16); otherwise the fields stay null.
             traffic = None; measured = None
-            try:
-                key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, dev.counters().plan,
-                                                                 dev.counters().film_mode, cfg.samples_per_launch)
-                table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                entry = table.get(key, {}).get(name)
-                if entry and world == 1 and table.get(key, {}).get("kernel_src_sha16") == kernel_src_sha16():
-                    traffic = entry["hbm_bytes_per_launch"]
-                    measured = {"source": table[key].get("source"), "hbm_bytes_per_launch": traffic,
-                                # the real bound next to the decreed one: HBM bytes the kernel really moves / its time / 8 TB/s,
-                                # the share of SIMD issue cycles that carried a VALU instruction, the lanes those instructions used
-                                "hbm_measured_frac": traffic / (ms / max(n, 1) * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                                "valu_issue_frac": entry.get("valu_issue_frac"), "lane_use": entry.get("lane_util"),
-                                "wait_mem_frac": entry.get("wait_mem_frac")}
-            except Exception:
-                traffic = None; measured = None
+            entry = None; source = None
+            if world == 1 and not args.no_live_counters and args.shard_of <= 1 and not os.environ.get("MIW_BENCH_NO_LIVE"):
+                workload = ["--width", str(W), "--height", str(H), "--spp", str(SPP), "--scene", args.scene, "--tess", str(args.tess),
+                            "--variant", args.variant, "--bvh-quality", str(args.bvh_quality), "--integrator", args.integrator,
+                            "--plan", str(args.plan), "--film-mode", str(args.film_mode), "--samples-per-launch", str(args.samples_per_launch)]
+                entry = live_counters(workload, name)
+                if entry:
+                    source = "live: 4 rocprofv3 --pmc passes over one frame of this workload, in this run"
+            if entry is None:
+                try:
+                    key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, dev.counters().plan,
+                                                                     dev.counters().film_mode, cfg.samples_per_launch)
+                    table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                    if world == 1 and table.get(key, {}).get("kernel_src_sha16") == kernel_src_sha16():
+                        entry = table.get(key, {}).get(name)
+                        source = "committed: " + str(table[key].get("source"))
+                except Exception:
+                    entry = None
+            if entry:
+                traffic = entry["hbm_bytes_per_launch"]
+                measured = {"source": source, "hbm_bytes_per_launch": traffic,
+                            # the real bound next to the decreed one: HBM bytes the kernel really moves / its time / 8 TB/s,
+                            # the share of SIMD issue cycles that carried a VALU instruction, the lanes those instructions used
+                            "hbm_measured_frac": traffic / (ms / max(n, 1) * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                            "valu_issue_frac": entry.get("valu_issue_frac"), "lane_use": entry.get("lane_util"),
+                            "wait_mem_frac": entry.get("wait_mem_frac")}
             # `bound` names what limits the kernel on the silicon: the vector ALUs (issue slots x lanes per instruction, from the
             # committed PMC passes of these exact kernel sources) unless the measured HBM traffic is the larger fraction;
             # achieved / peak / frac stay the yardstick north_star decrees (ALGORITHMIC queue + splat bytes of SURVEY.md 8d

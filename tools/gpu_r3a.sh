@@ -9,7 +9,7 @@ tail -5 $out/r3a_pytest.log
 timeout 500 python bench.py > $out/r3a_bench_c2.log 2> $out/r3a_bench_c2.err; tail -1 $out/r3a_bench_c2.log | cut -c1-1500
 line() {   # line <label> <env...> -- <bench args>
   label=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
-  env $envs timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/r3a_$label.log 2> $out/r3a_$label.err
+  env $envs timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-counters "$@" > $out/r3a_$label.log 2> $out/r3a_$label.err
   python - "$out/r3a_$label.log" "$label" <<'P'
 import json, sys
 try:
@@ -33,7 +33,7 @@ line shard8_pair MIWAVE_LIB_DIR=$PWD/build_exp/pair -- --shard tiles --shard-of 
 line shard8_wg4 MIW_WG_PER_CU=4 -- --shard tiles --shard-of 8
 line shard8_wg2 MIW_WG_PER_CU=2 -- --shard tiles --shard-of 8
 # traffic of the C2 kernels (each counter set in its own pass, kernel trace only)
-B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-live-counters"
 ( cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/r3a_c2_trace -- $B > $OLDPWD/$out/r3a_c2_trace.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace --output-format csv -d $OLDPWD/$out/r3a_c2_pmc3 -- $B > $OLDPWD/$out/r3a_c2_pmc3.log 2>&1

@@ -14,7 +14,7 @@ except Exception as e:
 P
 line() {   # line <label> <env...> -- <bench args>
   label=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
-  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/r3b_$label.log 2> $out/r3b_$label.err
+  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-counters "$@" > $out/r3b_$label.log 2> $out/r3b_$label.err
   python - "$out/r3b_$label.log" "$label" <<'P'
 import json, sys
 try:
@@ -41,7 +41,7 @@ line c4_lbvh -- --scene interior --spp 16 --bvh-quality 0
 line c4_lbvh_host MIW_BVH4_HOST=1 -- --scene interior --spp 16 --bvh-quality 0
 grep -h "bvh4" $out/r3b_c3_lbvh.err $out/r3b_c4_lbvh.err $out/r3b_c4_lbvh_host.err | head
 # traffic of the C2 kernels (each counter set in its own pass, kernel trace only), default build and the streaming-store build
-B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-live-counters"
 ( cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/r3b_c2_trace -- $B > $OLDPWD/$out/r3b_c2_trace.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace --output-format csv -d $OLDPWD/$out/r3b_c2_pmc3 -- $B > $OLDPWD/$out/r3b_c2_pmc3.log 2>&1

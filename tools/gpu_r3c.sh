@@ -7,7 +7,7 @@ timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 
 tail -4 $out/r3c_pytest.log; grep -E "^(FAILED|ERROR)" $out/r3c_pytest.log | head -20
 line() {   # line <label> <env...> -- <bench args>
   label=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
-  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/r3c_$label.log 2> $out/r3c_$label.err
+  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-counters "$@" > $out/r3c_$label.log 2> $out/r3c_$label.err
   python - "$out/r3c_$label.log" "$label" <<'P'
 import json, sys
 try:
@@ -40,7 +40,7 @@ line c4_lbvh2 MIW_LBVH_LEAF=2 -- --scene interior --spp 16 --bvh-quality 0
 line c4_lbvh8 MIW_LBVH_LEAF=8 -- --scene interior --spp 16 --bvh-quality 0
 grep -h "bvh4" $out/r3c_c3_lbvh.err $out/r3c_c4_lbvh.err | head
 # SQ counters of the C2 kernels (each counter set in its own pass, kernel trace only)
-B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+B="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-live-counters"
 ( cd /tmp
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OLDPWD/$out/r3c_c2_pmc1 -- $B > $OLDPWD/$out/r3c_c2_pmc1.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OLDPWD/$out/r3c_c2_pmc2 -- $B > $OLDPWD/$out/r3c_c2_pmc2.log 2>&1

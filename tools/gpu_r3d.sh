@@ -6,7 +6,7 @@ timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=6 
 tail -4 $out/r3d_pytest.log; grep -E "^(FAILED|ERROR)" $out/r3d_pytest.log | head -20
 line() {   # line <label> <env...> -- <bench args>
   label=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
-  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/r3d_$label.log 2> $out/r3d_$label.err
+  env $envs MIW_DEBUG=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-counters "$@" > $out/r3d_$label.log 2> $out/r3d_$label.err
   python - "$out/r3d_$label.log" "$label" <<'P'
 import json, sys
 try:

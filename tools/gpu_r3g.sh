@@ -3,7 +3,7 @@
 out=gpurun_out; mkdir -p $out
 line() {
   label=$1; shift; envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
-  env $envs timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/r3g_$label.log 2> $out/r3g_$label.err
+  env $envs timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-counters "$@" > $out/r3g_$label.log 2> $out/r3g_$label.err
   python - "$out/r3g_$label.log" "$label" <<'P'
 import json, sys
 try:

@@ -11,6 +11,7 @@ repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
+export MIW_BENCH_NO_LIVE=1     # bench.py's own live PMC passes only in the default line below (these runs ARE the PMC passes)
 pmc() {   # pmc <name> <bench args...>
   name=$1; shift
   B="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $*"
@@ -25,7 +26,7 @@ pmc c2
 pmc c3 --scene matball --spp 64
 pmc c4 --scene interior --spp 16
 cd $repo
-timeout 600 python bench.py > $out/${tag}_bench_c2.log 2>&1
+env -u MIW_BENCH_NO_LIVE timeout 900 python bench.py > $out/${tag}_bench_c2.log 2>&1
 timeout 300 python bench.py --scene matball --spp 1024 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3.log 2>&1
 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --plan 1 > $out/${tag}_bench_c3_plan1.log 2>&1
 MIW_PHASED=0 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_lockstep.log 2>&1
