@@ -30,6 +30,9 @@
 
 enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
+// a lane's stack: its column of the workgroup's entry-major LDS array (slot i of lane l at i * MIW_BLOCK + l: conflict-free)
+struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
+
 #ifndef MIW_PHASE_SPEC
 #define MIW_PHASE_SPEC 1
 #endif
@@ -181,23 +184,11 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             do {
                 MIW_PS(0, count(e_node));
                 if (e_node) {
-                    int32_t next = MIW_WALK_DONE;
                     if (Wide) {
-                        // one 64-byte node = four quantised child boxes (miw/bvh4.h): slab tests, a 5-exchange sort of the
-                        // entry distances, far ... near hits onto the stack, the nearest becomes the next node. The stores
-                        // are unconditional and only `sp` is predicated (a store past the last hit is overwritten by the next
-                        // push; the collapse budgets MIW_STACK_ENTRIES - 1 entries so that it stays inside the lane's column)
-                        const Bvh4Node &n = nodes4[cur];
-                        uint32_t k[4];
-                        int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
-                        bvh4_test(n, r, widen(tmax), k);
-                        bvh4_sort(k, ch);
-                        stack[sp * MIW_BLOCK] = ch[3]; sp += bvh4_key_hit(k[3]) ? 1 : 0;
-                        stack[sp * MIW_BLOCK] = ch[2]; sp += bvh4_key_hit(k[2]) ? 1 : 0;
-                        stack[sp * MIW_BLOCK] = ch[1]; sp += bvh4_key_hit(k[1]) ? 1 : 0;
-                        if (bvh4_key_hit(k[0])) next = ch[0];
-                        else if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                        // one 64-byte node = four quantised child boxes: walk4_node_step (miw/bvh4.h — the CPU checker runs the same function)
+                        walk4_node_step<Spec>(nodes4[cur], r, widen(tmax), cur, sp, tri_i, tri_end, LdsColumn{ stack });
                     } else {
+                        int32_t next = MIW_WALK_DONE;
 #if MIW_LDS_TOP
                         const BvhNode &n = (uint32_t) cur < ns ? lnodes[cur] : gnodes[cur];
 #else
@@ -216,15 +207,15 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                             next = MIW_WALK_DONE;
                             if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
                         }
+                        // a leaf: it becomes the lane's triangle range (if it holds none), and the next stack entry its current node
+                        if (next < 0 && next != MIW_WALK_DONE && (!Spec || tri_i >= tri_end)) {
+                            const uint32_t code = (uint32_t) ~next;
+                            tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
+                            next = MIW_WALK_DONE;
+                            if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
+                        }
+                        cur = next;
                     }
-                    // a leaf: it becomes the lane's triangle range (if it holds none), and the next stack entry its current node
-                    if (next < 0 && next != MIW_WALK_DONE && (!Spec || tri_i >= tri_end)) {
-                        const uint32_t code = (uint32_t) ~next;
-                        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
-                        next = MIW_WALK_DONE;
-                        if (sp != 0) { --sp; next = stack[sp * MIW_BLOCK]; }
-                    }
-                    cur = next;
                 }
                 has_range = tri_i < tri_end;
                 e_node = trav && cur >= 0 && (Spec || !has_range);
@@ -240,30 +231,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 MIW_PS(1, count(e_leaf));
                 if (e_leaf) {
 #if MIW_TRI_PAIR
-                    // two triangles of the range per iteration: both records are fetched before either test runs (the second
-                    // address is clamped into the range, its test predicated), so a multi-triangle leaf costs one round trip
-                    // per pair; the tests run in range order, which is all the closest-hit / any-hit rules ask for
-                    const bool two = tri_i + 1u < tri_end;
-                    const Tri &tr = gtris[tri_i];
-                    const Tri &tr2 = gtris[two ? tri_i + 1u : tri_i];
-                    float t, u, v, t2, u2, v2;
-                    const bool hit1 = prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v);
-                    const bool hit2 = prim_intersect<Analytic>(tr2, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t2, u2, v2) && two;
-                    if (hit1 || hit2) {
-                        if (mode == PH_TRAV_S) {                         // any hit ends the shadow walk
-                            occluded = true; tri_end = 0; cur = MIW_WALK_DONE; sp = 0;
-                        } else {
-                            if (hit1 && (t < best.t || (t == best.t && tr.prim < best.prim))) {
-                                best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
-                                tmax = t;
-                            }
-                            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < best.prim))) {
-                                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u; best.prim = tr2.prim;
-                                tmax = t2;
-                            }
-                        }
-                    }
-                    tri_i += two ? 2u : 1u;
+                    // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
+                    walk4_tri_step<Analytic>([gtris](uint32_t i) -> const Tri & { return gtris[i]; }, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
+                                             mode == PH_TRAV_S, best, tmax, occluded, cur, sp, tri_i, tri_end, LdsColumn{ stack });
 #else
                     const Tri &tr = gtris[tri_i];
                     float t, u, v;
@@ -276,13 +246,13 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         }
                     }
                     ++tri_i;
-#endif
                     if (tri_i >= tri_end && cur < 0 && cur != MIW_WALK_DONE) {   // range drained and the stack handed over another leaf
                         const uint32_t code = (uint32_t) ~cur;
                         tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
                         cur = MIW_WALK_DONE;
                         if (sp != 0) { --sp; cur = stack[sp * MIW_BLOCK]; }
                     }
+#endif
                 }
                 has_range = tri_i < tri_end;
                 e_leaf = trav && has_range;

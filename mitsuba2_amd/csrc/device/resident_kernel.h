@@ -140,10 +140,17 @@ struct QueueWork {
     }
 };
 
+#ifndef MIW_DIRECT_WAVES
+/* Waves per SIMD the direct-integrator kernels are compiled for. At 2 (256 VGPRs) none of them spills, at 3 (168) the MATS_ALL
+   ones keep 60 (packet scenes) / 216 (tree scenes) registers in scratch — and are faster all the same (path kernel of one frame,
+   round-3 session I: Cornell box 92.7 ms against 115.2, material balls 207 / 204, 0.9 M-triangle interior 174 / 227): the
+   spills sit in the prologue and around the BSDF code, the third wave hides the query's latency. */
+#define MIW_DIRECT_WAVES 3
+#endif
 // Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
 // Integ: which SamplingIntegrator::sample the pixel loop runs (path.h / direct.h).
 template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH>
-__global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SP
         work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
         __shared__ uint32_t s_prog[MIW_BLOCK / 64];
         if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
-        if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Analytic>(P, sc, sample_end, work, tr2, &local);
+        if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
         else pixel_stream_render<Mats, Analytic>(P, sc, sample_end, work, tr2, &local);
     } else if (lane < P.n_lanes) {
         U4 st = Q.st[lane];

@@ -95,6 +95,74 @@ MIW_HD void bvh4_sort(uint32_t k[4], int32_t ch[4]) {
 }
 MIW_HD bool bvh4_key_hit(uint32_t key) { return key < 0x7f800000u; }
 
+// ---- the two walk bodies of the wave-level phase machine (device/phased_kernel.h) ---------------------------------------
+// One lane's walk is (cur, sp, leaf range [tri_i, tri_end), best hit, tmax): `cur` >= 0 is a node to visit, < 0 a leaf code still
+// to be taken, MIW_BVH4_ABSENT (= the kernels' MIW_WALK_DONE) nothing. The kernel runs these two functions under its votes; the
+// CPU checker runs the same two under arbitrary schedules (oracle/wavefront_emu.cpp: emu_walk4), so what the device executes per
+// lane is what the CPU tier tests. `stack[i]` is the lane's i-th stack slot (the device: an LDS column, entry-major).
+//
+// Node step: four slab tests, the 5-exchange sort, far ... near hits onto the stack, the nearest becomes the next node. The
+// stores are unconditional and only `sp` is predicated (a store past the last hit is overwritten by the next push): the lane
+// writes up to slot sp + 2, which is why the collapse budgets one entry less than the column holds. A leaf becomes the lane's
+// triangle range if it holds none (Spec: otherwise it stays in `cur` until the range is drained), and the next stack entry the
+// current node.
+template <bool Spec, typename Ray, typename Stack>
+MIW_HD void walk4_node_step(const Bvh4Node &n, const Ray &r, float tmax_wide, int32_t &cur, int32_t &sp, uint32_t &tri_i, uint32_t &tri_end, Stack stack) {
+    int32_t next = MIW_BVH4_ABSENT;
+    uint32_t k[4];
+    int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
+    bvh4_test(n, r, tmax_wide, k);
+    bvh4_sort(k, ch);
+    stack[sp] = ch[3]; sp += bvh4_key_hit(k[3]) ? 1 : 0;
+    stack[sp] = ch[2]; sp += bvh4_key_hit(k[2]) ? 1 : 0;
+    stack[sp] = ch[1]; sp += bvh4_key_hit(k[1]) ? 1 : 0;
+    if (bvh4_key_hit(k[0])) next = ch[0];
+    else if (sp != 0) { --sp; next = stack[sp]; }
+    if (next < 0 && next != MIW_BVH4_ABSENT && (!Spec || tri_i >= tri_end)) {
+        const uint32_t code = (uint32_t) ~next;
+        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
+        next = MIW_BVH4_ABSENT;
+        if (sp != 0) { --sp; next = stack[sp]; }
+    }
+    cur = next;
+}
+
+// Triangle step: two triangles of the lane's range per call — both records are fetched before either test runs (the second
+// address is clamped into the range, its test predicated), so a multi-triangle leaf costs one round trip per pair; the tests run
+// in range order, which is all the closest-hit / any-hit rules ask for. An any-hit walk ends at its first hit (`occluded`); a
+// drained range takes over the leaf the stack handed to `cur`, if any.
+template <bool Analytic, typename TriAt, typename Stack>
+MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best, float &tmax,
+                           bool &occluded, int32_t &cur, int32_t &sp, uint32_t &tri_i, uint32_t &tri_end, Stack stack) {
+    const bool two = tri_i + 1u < tri_end;
+    const Tri &tr = tri_at(tri_i);
+    const Tri &tr2 = tri_at(two ? tri_i + 1u : tri_i);
+    float t, u, v, t2, u2, v2;
+    const bool hit1 = prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v);
+    const bool hit2 = prim_intersect<Analytic>(tr2, ctx, o, d, mint, maxt, t2, u2, v2) && two;
+    if (hit1 || hit2) {
+        if (any_hit) {                                           // any hit ends the shadow walk
+            occluded = true; tri_end = 0; cur = MIW_BVH4_ABSENT; sp = 0;
+        } else {
+            if (hit1 && (t < best.t || (t == best.t && tr.prim < best.prim))) {
+                best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
+                tmax = t;
+            }
+            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < best.prim))) {
+                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u; best.prim = tr2.prim;
+                tmax = t2;
+            }
+        }
+    }
+    tri_i += two ? 2u : 1u;
+    if (tri_i >= tri_end && cur < 0 && cur != MIW_BVH4_ABSENT) {   // range drained and the stack handed over another leaf
+        const uint32_t code = (uint32_t) ~cur;
+        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
+        cur = MIW_BVH4_ABSENT;
+        if (sp != 0) { --sp; cur = stack[sp]; }
+    }
+}
+
 // Reference walk (host array stack): the definition the device bodies of phased_kernel.h restate, run by the CPU checker
 // against brute force. Same observable result as bvh_intersect / brute_intersect.
 template <bool AnyHit, typename TriAt>

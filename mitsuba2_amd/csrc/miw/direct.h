@@ -17,28 +17,17 @@ namespace miw {
 struct DirectPending { Spec bsdf_val; float pdf; bool delta; };
 
 // direct.cpp:113-133: the primary hit. Returns false when the camera sample is complete (a miss).
-template <bool Analytic>
+// `Mats` / `Analytic` as in path.h: MATS_ALL kernels serve scenes with texture coordinates, bitmaps or the extended plugins,
+// MATS_PLAIN the rest (the lookups compiled out); Analytic = false compiles the analytic shapes out.
+template <int Mats, bool Analytic>
 MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, V3 ray_o,
                            SurfaceInteraction &si, BsdfSide &bsdf, Counters *cnt_local) {
-    const uint32_t tri_idx = f2u(h.w);
-    const bool valid = tri_idx != MIW_MISS;
+    const bool valid = f2u(h.w) != MIW_MISS;
     const V3 ray_d = L.ray.d;
     int32_t emitter = -1;
     uint32_t bsdf_index = 0;
     if (valid) {
-        const Tri &tr = sc.tris[tri_idx];
-        const ShapeRec &shape = sc.shapes[tr.shape];
-        if (Analytic && tr.pad) {
-            const AnalyticRec &a = sc.rects[tr.pad - 1u];
-            if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.x, ray_o, ray_d, si);
-            else compute_surface_interaction_rect(a, h.x, h.y, h.z, ray_o, ray_d, si);
-        } else {
-            const float *vn = (shape.flags & 1u) ? sc.tri_vn + 9 * (size_t) tri_idx : nullptr;
-            const float *tc = (shape.flags & SHAPE_HAS_TEXCOORDS) ? sc.tri_uv + 6 * (size_t) tr.prim : nullptr;
-            compute_surface_interaction(ld3(tr.p0), ld3(tr.p1), ld3(tr.p2), vn, tc, h.x, h.y, h.z, ray_d, si);
-        }
-        si.shape = tr.shape; si.prim = tr.prim;
-        emitter = shape.emitter; bsdf_index = shape.bsdf;
+        hit_surface_interaction<Analytic, Mats == MATS_ALL>(sc, f2u(h.w), h.x, h.y, h.z, [ray_o]() { return ray_o; }, ray_d, si, bsdf_index, emitter);
         L.flags |= LF_VALID_RAY;                                  // :114
     }
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;  // scene.h:248-249
@@ -53,16 +42,17 @@ MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs 
 }
 
 // One emitter sample, direct.cpp:137-160. Returns true when a shadow ray is queued in `sh`.
+template <int Mats, bool Analytic>
 MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, LaneRegs &L, const SurfaceInteraction &si,
                                   const BsdfSide &bsdf, ShadowOut &sh, Counters *cnt_local) {
     const DirectRec &D = P.direct;
     DirectionSample ds;
-    Spec emitter_val = sample_emitter_direction(sc, si.p, next_2d(L.rng), ds, L.wl);   // :141-142
+    Spec emitter_val = sample_emitter_direction<Analytic>(sc, si.p, next_2d(L.rng), ds, L.wl);   // :141-142
     if (ds.pdf == 0.f) return false;                              // :143-145
     V3 wo = to_local(si.sh, ds.d);                                // :148
-    const TexCtx tc(L.wl, si.uv, sc.bitmaps, sc.bsdf_tables);
-    Spec bsdf_val = bsdf_side_eval(bsdf, si.wi, wo, tc);          // :150
-    float bsdf_pdf = bsdf_side_pdf(bsdf, si.wi, wo, tc);          // :155
+    const TexCtx tc(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr, Mats == MATS_ALL ? sc.bsdf_tables : nullptr);
+    Spec bsdf_val = bsdf_side_eval<Mats == MATS_ALL>(bsdf, si.wi, wo, tc);   // :150
+    float bsdf_pdf = bsdf_side_pdf<Mats == MATS_ALL>(bsdf, si.wi, wo, tc);   // :155
     float mis = mis_weight(ds.pdf * D.frac_lum, bsdf_pdf * D.frac_bsdf) * D.weight_lum;   // :157-158 (no delta emitters)
     Spec c = mis * bsdf_val * emitter_val;                        // :159
     if (all_zero(c)) return false;
@@ -72,11 +62,13 @@ MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, La
 }
 
 // One BSDF sample, direct.cpp:166-176. Returns true when its ray is queued in L.ray.
+template <int Mats>
 MIW_HD bool direct_bsdf_sample(const SceneView &sc, LaneRegs &L, const SurfaceInteraction &si, const BsdfSide &bsdf, DirectPending &pend) {
     float s1 = next_1d(L.rng);                                    // :166-167 (Clang order: next_1d, then next_2d)
     V2 s2 = next_2d(L.rng);
     BSDFSample bs;
-    pend.bsdf_val = bsdf_side_sample(bsdf, si.wi, s1, s2, bs, TexCtx(L.wl, si.uv, sc.bitmaps, sc.bsdf_tables));
+    pend.bsdf_val = bsdf_side_sample<Mats == MATS_ALL>(bsdf, si.wi, s1, s2, bs, TexCtx(L.wl, si.uv, Mats == MATS_ALL ? sc.bitmaps : nullptr,
+                                                                                   Mats == MATS_ALL ? sc.bsdf_tables : nullptr));
     if (all_zero(pend.bsdf_val)) return false;                    // :170
     pend.pdf = bs.pdf; pend.delta = (bs.sampled_type & BSDF_Delta) != 0;
     L.ray.d = to_world(si.sh, bs.wo);                             // :173-174, interaction.h:58-61
@@ -122,25 +114,30 @@ MIW_HD void direct_bsdf_hit(const RenderParams &P, const SceneView &sc, LaneRegs
             d = d / dist;
             n = sb.sh.n;
         }
-        emitter_pdf = pdf_emitter_direction(sc, (uint32_t) emitter, d, dist, n, ref_p);
+        emitter_pdf = pdf_emitter_direction<Analytic>(sc, (uint32_t) emitter, d, dist, n, ref_p);
     }
     L.res = L.res + pend.bsdf_val * emitter_val * mis_weight(pend.pdf * D.frac_bsdf, emitter_pdf * D.frac_lum) * D.weight_bsdf;   // :193-196
 }
 
 // The sample loop of one pixel stream (cf. pixel_stream_render in path.h: same `work` / `trace2` contract).
-template <bool Analytic = true, typename Work, typename Trace2>
+//
+// Two query sites: the camera ray of every lane in one, the rays that leave the surface point in the other (an inner loop, one trip
+// with the default shading_samples = 1). The lanes of a wavefront stay on the same camera sample, so the rays of the first query
+// are neighbours and the second query sees only lanes that have something to ask (a lane whose camera ray left the scene sits it
+// out); the surface interaction and the BSDF are built after the first query and used up before the second — what crosses the
+// second query is the hit record of the camera ray (4 + 6 registers), from which hit_surface_interaction() rebuilds them, bit for
+// bit, in the rare case that further samples are due from the same point. Against the earlier form (one query site shared by
+// camera and secondary rays, the interaction carried across it) the path kernel of a frame measured 92.7 ms instead of 135.8 on
+// the Cornell box, 207 / 235 on the material balls, 174 / 188 on the 0.9 M-triangle interior (round-3 session I). The kernels
+// still spill at three wavefronts per SIMD; see MIW_DIRECT_WAVES in device/resident_kernel.h for why they stay there.
+template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2>
 MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                        Trace2 trace2, Counters *cnt_local) {
     const uint32_t n_emitter = P.direct.emitter_samples, n_bsdf = P.direct.bsdf_samples;
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
-    uint32_t pixel = 0, ie = 0, ib = 0;
-    bool have = false, primary = true;
-    SurfaceInteraction si; BsdfSide bsdf; DirectPending pend;
-    si.p = si.n = si.wi = v3(0.f); si.sh.n = si.sh.s = si.sh.t = v3(0.f); si.t = 0.f; si.uv = v2(0.f, 0.f); si.shape = si.prim = 0;
-    bsdf.b = sc.bsdfs; bsdf.flip = bsdf.none = false; bsdf.flags = 0;
-    pend.bsdf_val = spec(0.f); pend.pdf = 0.f; pend.delta = false;
-    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
+    uint32_t pixel = 0;
+    bool have = false;
     auto sink = [&work](uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { work.put(px, sample_idx, pos, aovs); };
     for (;;) {
         if (L.flags & LF_DONE) {
@@ -155,38 +152,44 @@ MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &s
             L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
             L.sample_idx = st.w; L.flags = 0;
             lane_begin_sample(P, pixel, L, sample_end);
-            primary = true;
             continue;
         }
-        const V3 o = L.ray.o;
-        const bool has_e = L.ray.maxt >= 0.f;
-        F4 h; bool occluded = false;
-        trace2(o, L.ray.mint, L.ray.d, L.ray.maxt, has_e, sh.d, sh.maxt, sh.has, h, occluded);
-        if (sh.has && !occluded) L.res = L.res + sh.c;             // direct.cpp:159 of the emitter sample in flight
-        sh.has = false;
-        bool more = true;
-        if (primary) {
-            primary = false;
-            more = direct_primary<Analytic>(P, sc, L, h, o, si, bsdf, cnt_local);
-            ie = (bsdf.flags & BSDF_Smooth) ? 0u : n_emitter;      // :134-136: no emitter samples (and no draws) otherwise
-            ib = 0;
-        } else if (has_e) {
-            direct_bsdf_hit<Analytic>(P, sc, L, h, o, pend);
-            L.ray.d = v3(0.f); L.ray.maxt = -1.f;
+        const V3 o0 = L.ray.o, d0 = L.ray.d;
+        F4 h0; bool unused = false;
+        trace2(o0, L.ray.mint, d0, L.ray.maxt, true, v3(0.f), -1.f, false, h0, unused);
+        {
+            SurfaceInteraction si; BsdfSide bsdf;
+            bsdf.b = sc.bsdfs; bsdf.flip = bsdf.none = false; bsdf.flags = 0;
+            if (direct_primary<Mats, Analytic>(P, sc, L, h0, o0, si, bsdf, cnt_local)) {
+                uint32_t ie = (bsdf.flags & BSDF_Smooth) ? 0u : n_emitter, ib = 0;   // :134-136: no emitter samples (and no draws) otherwise
+                for (;;) {
+                    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
+                    DirectPending pend; pend.bsdf_val = spec(0.f); pend.pdf = 0.f; pend.delta = false;
+                    bool queued = false;
+                    while (ie < n_emitter && !queued) { ++ie; queued = direct_emitter_sample<Mats, Analytic>(P, sc, L, si, bsdf, sh, cnt_local); }
+                    if (ie == n_emitter)                           // the last shadow ray travels with the first BSDF-sampled ray
+                        while (ib < n_bsdf && !(L.ray.maxt >= 0.f)) { ++ib; if (direct_bsdf_sample<Mats>(sc, L, si, bsdf, pend)) queued = true; }
+                    if (!queued) break;
+                    const V3 o = L.ray.o;
+                    const bool has_e = L.ray.maxt >= 0.f;
+                    F4 h; bool occluded = false;
+                    trace2(o, L.ray.mint, L.ray.d, L.ray.maxt, has_e, sh.d, sh.maxt, sh.has, h, occluded);
+                    if (sh.has && !occluded) L.res = L.res + sh.c;     // direct.cpp:159 of the emitter sample that was in flight
+                    if (has_e) {
+                        direct_bsdf_hit<Analytic>(P, sc, L, h, o, pend);
+                        L.ray.d = v3(0.f); L.ray.maxt = -1.f;
+                    }
+                    if (ie == n_emitter && ib == n_bsdf) break;
+                    int32_t emitter; uint32_t bsdf_index;              // more samples from this point: the interaction again
+                    hit_surface_interaction<Analytic, Mats == MATS_ALL>(sc, f2u(h0.w), h0.x, h0.y, h0.z, [o0]() { return o0; }, d0, si, bsdf_index, emitter);
+                    bsdf = bsdf_side(sc.bsdfs, bsdf_index, si.wi);
+                }
+            }
         }
-        if (more) {
-            bool queued = false;
-            while (ie < n_emitter && !queued) { ++ie; queued = direct_emitter_sample(P, sc, L, si, bsdf, sh, cnt_local); }
-            if (ie == n_emitter)                                   // the last shadow ray travels with the first BSDF-sampled ray
-                while (ib < n_bsdf && !(L.ray.maxt >= 0.f)) { ++ib; if (direct_bsdf_sample(sc, L, si, bsdf, pend)) queued = true; }
-            more = queued;
-        }
-        if (more) continue;
         lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
         lane_begin_sample(P, pixel, L, sample_end);
-        primary = true;
     }
 }
 

@@ -515,7 +515,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
     }
 }
 
-template <bool Analytic, typename Work, typename Trace2>
+template <int Mats, bool Analytic, typename Work, typename Trace2>
 MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
                                        Trace2 trace2, Counters *cnt_local);     // direct.h
 
@@ -530,7 +530,7 @@ MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixe
         MIW_HD void tick(uint32_t, bool) { }
         MIW_HD void put(uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { sink(px, sample_idx, pos, aovs); }
     } work{ pixel, st, false, sink };
-    if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<true>(P, sc, sample_end, work, trace2, cnt_local);
+    if constexpr (Integ == INTEG_DIRECT) pixel_stream_render_direct<MATS_ALL, true>(P, sc, sample_end, work, trace2, cnt_local);
     else pixel_stream_render(P, sc, sample_end, work, trace2, cnt_local);
     return work.st;
 }

@@ -1106,8 +1106,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 }
 #undef MIW_PHASED_LAUNCH
                 else if (direct) {
-                    if (tiny) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_ALL, false, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
-                    else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+#define MIW_DIRECT_LAUNCH(T, M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, A, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
+                    if (tiny && c->textured) MIW_DIRECT_LAUNCH(1, MATS_ALL, false);
+                    else if (tiny) MIW_DIRECT_LAUNCH(1, MATS_PLAIN, false);
+                    else if (c->textured) MIW_DIRECT_LAUNCH(0, MATS_ALL, true);
+                    else MIW_DIRECT_LAUNCH(0, MATS_PLAIN, true);
+#undef MIW_DIRECT_LAUNCH
                 }
                 else if (tiny && c->diffuse_only && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_DIFFUSE);   // 32-bit candidate masks (BASELINE config 2: 32 triangles)
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);

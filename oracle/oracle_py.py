@@ -44,7 +44,7 @@ class Oracle:
                                 C.c_int, C.c_int, c_u32_p]
         L.emu_trace.restype = C.c_int
         L.emu_trace4.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, c_u32_p]
+                                 C.c_int, C.c_int, C.c_int, C.c_int, c_u32_p, C.c_uint32]
         L.emu_trace4.restype = C.c_int
         L.emu_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_double_p, c_float_p, C.POINTER(C.c_uint64)]
         L.emu_render.restype = C.c_int
@@ -137,10 +137,13 @@ class Oracle:
         out["bvh"] = list(stats)
         return out
 
-    def emu_trace4(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, stack_budget=32, max_fan=4):
-        """The 4-wide quantised tree (csrc/miw/bvh4.h, collapsed by csrc/bvh4_build.h) walked on the CPU."""
+    def emu_trace4(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, stack_budget=32, max_fan=4, schedule=0, spec=True):
+        """The 4-wide quantised tree (csrc/miw/bvh4.h, collapsed by csrc/bvh4_build.h) walked on the CPU: by the reference walk
+        bvh4_intersect (schedule = 0) or by the per-lane bodies of the device's phase machine (walk4_node_step / walk4_tri_step)
+        under a pseudo-random schedule seeded with `schedule` > 0 (spec: the speculating variant the device runs by default)."""
         stats = (C.c_uint32 * 6)()
-        out = self._trace(self.L.emu_trace4, desc, o, d, mint, maxt, any_hit, max_leaf, stack_budget, max_fan, stats)
+        sched = (int(schedule) & 0x7fffffff) | (0 if spec or not schedule else 0x80000000)
+        out = self._trace(self.L.emu_trace4, desc, o, d, mint, maxt, any_hit, max_leaf, stack_budget, max_fan, stats, sched)
         out["bvh4"] = dict(zip(("nodes2", "nodes4", "depth", "stack_bound", "stack_seen", "ok"), list(stats)))
         return out
 

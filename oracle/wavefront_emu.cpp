@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 #include <xmmintrin.h>
 #include <pmmintrin.h>
@@ -154,6 +155,46 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
 }
 // plain IEEE float environment (denormals preserved), see miw_oracle.cpp FtzScope
 struct Ftz { unsigned csr; Ftz() { csr = _mm_getcsr(); _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_OFF); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_OFF); } ~Ftz() { _mm_setcsr(csr); } };
+// One ray through the per-lane bodies of the wave-level phase machine — walk4_node_step / walk4_tri_step of csrc/miw/bvh4.h, the
+// two functions k_path_phased (csrc/device/phased_kernel.h) runs under its votes — with the vote replaced by a coin: whenever a
+// lane could take either body (Spec: it holds an untested leaf range AND a node to descend into) `coin()` picks one, so every
+// interleaving the device can produce is reachable. The stack is the lane's column: `cap` slots, every access checked (the node
+// step stores up to two slots past `sp`; the collapse budgets one slot less than the column holds, csrc/miwave.hip).
+// Returns hit / occluded; *bad is set when a slot outside the column was touched.
+struct EmuColumn {
+    int32_t *p; int32_t cap; bool *bad; uint32_t *deepest;
+    int32_t &operator[](int32_t i) const {
+        if (i < 0 || i >= cap) { *bad = true; return p[cap]; }                 // p holds cap + 1 entries: the last one absorbs strays
+        if ((uint32_t) i + 1u > *deepest) *deepest = (uint32_t) i + 1u;
+        return p[i];
+    }
+};
+template <bool Spec, typename TriAt, typename Coin>
+bool emu_walk4(const Bvh4Node *nodes4, TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best,
+               Coin coin, int32_t cap, bool *bad, uint32_t *deepest) {
+    const SlabRay r = slab_ray_host(o, d, mint);
+    int32_t column[129];                                        // cap <= 128 (emu_trace4 refuses budgets above 127)
+    const EmuColumn stack{ column, cap, bad, deepest };
+    int32_t cur = 0, sp = 0;
+    uint32_t tri_i = 0, tri_end = 0;
+    float tmax = maxt;
+    bool occluded = false;
+    if (!any_hit) { best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu; }   // (an S walk never writes `best`)
+    for (;;) {
+        const bool has_range = tri_i < tri_end;
+        const bool e_node = cur >= 0 && (Spec || !has_range), e_leaf = has_range;       // the predicates of the kernel's vote
+        if (!e_node && !e_leaf) break;                                                   // walk_over
+        if (e_node && (!e_leaf || coin()))
+            walk4_node_step<Spec>(nodes4[cur], r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), cur, sp, tri_i, tri_end, stack);
+        else
+            walk4_tri_step<true>(tri_at, ctx, o, d, mint, maxt, any_hit, best, tmax, occluded, cur, sp, tri_i, tri_end, stack);
+    }
+    return any_hit ? occluded : best.tri != MIW_MISS;
+}
+struct EmuCoin {                                                // xorshift32: the schedule of one test run
+    uint32_t s;
+    bool operator()() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return (s & 1u) != 0; }
+};
 }
 
 extern "C" {
@@ -182,8 +223,11 @@ int emu_trace(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_so
 
 // the 4-wide quantised tree of miw/bvh4.h (collapsed from the same SAH build) over caller rays.
 // stats6: BVH2 nodes, BVH4 nodes, BVH4 depth, exact stack bound, deepest stack any of the rays reached, ok flag
+// schedule: 0 = bvh4_intersect (the reference walk of miw/bvh4.h); > 0 = the phase machine's bodies (emu_walk4) with the
+// schedule seeded by this number, bit 31 clear = Spec (the device default), set = the non-speculating variant; stats6[4] is then
+// the deepest column slot any ray touched, and a touch outside the column (stack_budget + 1 slots, as on the device) returns 2.
 int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_soa *h, uint64_t n, int any_hit, int max_leaf,
-               int stack_budget, int max_fan, uint32_t *stats6) {
+               int stack_budget, int max_fan, uint32_t *stats6, uint32_t schedule) {
     EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
     Ftz ftz;
     if (stack_budget < 1 || stack_budget > 127) return -3;                  // bvh4_intersect's host stack holds 128 entries
@@ -193,10 +237,18 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
     if (!b4.ok) return 1;
     const Tri *tris = sc.view.tris; const PrimCtx rects = prim_ctx(sc.view);
     auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
+    EmuCoin coin{ schedule | 1u }; bool bad = false;
     for (uint64_t i = 0; i < n; ++i) {
         const V3 o = v3(r->ox[i], r->oy[i], r->oz[i]), d = v3(r->dx[i], r->dy[i], r->dz[i]);
         Hit hit; bool ok;
-        if (any_hit) ok = bvh4_intersect<true>(b4.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen);
+        if (schedule) {
+            const bool spec = !(schedule & 0x80000000u);
+            hit.t = MIW_INFINITY; hit.u = hit.v = 0.f; hit.tri = MIW_MISS; hit.prim = 0xffffffffu;
+            ok = spec ? emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, std::ref(coin), stack_budget + 1, &bad, &seen)
+                      : emu_walk4<false>(b4.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, std::ref(coin), stack_budget + 1, &bad, &seen);
+            if (any_hit && ok) { hit.t = 0.f; hit.tri = 0; hit.prim = 0; }           // bvh4_intersect<true>'s convention (which triangle: not part of the contract)
+        }
+        else if (any_hit) ok = bvh4_intersect<true>(b4.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen);
         else ok = bvh4_intersect<false>(b4.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen);
         h->t[i] = ok ? hit.t : MIW_INFINITY;
         if (h->u) h->u[i] = hit.u;
@@ -205,7 +257,7 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
         if (h->shape) h->shape[i] = ok ? tris[hit.tri].shape : 0xffffffffu;
     }
     if (stats6) stats6[4] = seen;
-    return 0;
+    return bad ? 2 : 0;
 }
 
 // Phase classes (csrc/miw/film.h, csrc/film_classes.h) against ImageBlock::put itself: for `n` samples (position x, y and the
@@ -337,12 +389,25 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             st[lane] = lane_seed_state(cfg->base_seed + (uint64_t) cfg->block_ids[b] * bs2 + i);
         }
         const uint32_t per_launch = cfg->samples_per_launch > 0 ? (uint32_t) cfg->samples_per_launch : 128u;
+        // Scenes the device walks with k_path_phased (more triangles than the packet kernels take, a 4-wide collapse that fits the
+        // lane stack) go through the phase machine's own per-lane bodies here too (emu_walk4: an E walk, then the S walk that leaves
+        // `best` alone, each under a pseudo-random body schedule); MIW_EMU_WALK=bvh2 keeps the stackless BVH2 walk for all scenes.
+        Bvh4BuildResult b4;
+        const char *walk_env = getenv("MIW_EMU_WALK");
+        if (sc.view.tri_count > 64u && !(walk_env && !strcmp(walk_env, "bvh2"))) b4 = bvh4_collapse(sc.bvh.nodes, 31u, 4);
+        const bool phased = b4.ok && !b4.nodes.empty();
+        EmuCoin coin{ 0x9e3779b9u }; bool bad_slot = false; uint32_t deepest = 0;
         auto trace2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
-            Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS;
-            if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h, rects); }
-            hE.x = h.t; hE.y = h.u; hE.z = h.v; hE.w = u2f(h.tri);
+            Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
             occS = false;
-            if (hasS) { Hit hs; RayPrep rp = ray_prepare(o, dS, mint, maxtS); occS = bvh_intersect<true>(node_at, tri_at, rp, hs, rects); }
+            if (phased) {
+                if (hasE) emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dE, mint, maxtE, false, h, std::ref(coin), 32, &bad_slot, &deepest);
+                if (hasS) occS = emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dS, mint, maxtS, true, h, std::ref(coin), 32, &bad_slot, &deepest);
+            } else {
+                if (hasE) { RayPrep rp = ray_prepare(o, dE, mint, maxtE); bvh_intersect<false>(node_at, tri_at, rp, h, rects); }
+                if (hasS) { Hit hs; RayPrep rp = ray_prepare(o, dS, mint, maxtS); occS = bvh_intersect<true>(node_at, tri_at, rp, hs, rects); }
+            }
+            hE.x = h.t; hE.y = h.u; hE.z = h.v; hE.w = u2f(h.tri);
         };
         for (uint32_t done = 0; done < cfg->spp; ) {
             const uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
@@ -361,6 +426,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             }
             done = end; ++iterations;
         }
+        if (bad_slot) return -4;                               // a walk touched a slot outside its 32-entry column
     } else
 #if MIW_SPECTRAL
     return -2;                                                 // the HBM-queue plan carries RGB path state

@@ -2,8 +2,10 @@
 
 Its contract is the BVH2's (csrc/miw/bvh.h): over all triangles that pass the exact triangle test inside [mint, maxt], the
 closest hit, ties to the smaller primitive id; any-hit = some triangle passes — i.e. brute force (the scalar oracle's
-orc_trace). The CPU tier walks the very node test / sort / push order the gfx950 node body runs (bvh4_test, bvh4_sort,
-bvh4_intersect) over the host collapse; the GPU tier renders through it (k_path_phased) and compares films with the oracle.
+orc_trace). The CPU tier walks the host collapse twice: by the reference walk (bvh4_intersect) and by the two per-lane bodies
+k_path_phased itself runs (walk4_node_step / walk4_tri_step of csrc/miw/bvh4.h — one definition for the kernel and the checker)
+under pseudo-random body schedules, with every stack access checked against the lane's column; the GPU tier renders through
+the kernel and compares films with the oracle.
 """
 import os
 
@@ -101,6 +103,59 @@ def test_bvh4_big_tree_with_a_binding_stack_budget(native, oracle):
         assert b["nodes4"] < 0.62 * b["nodes2"]                       # ... but the tree is still about half the BVH2
         assert _same(brute, w, any_hit)
     assert np.isfinite(brute["t"]).sum() > 100
+
+
+@pytest.mark.parametrize("spec", [True, False])
+def test_phase_machine_bodies_under_random_schedules(native, oracle, spec):
+    """The node step and the triangle-pair step of the device's phase machine, run per ray under several pseudo-random
+    schedules (whenever a lane could take either body, a coin decides — every interleaving the wave votes can produce is
+    reachable), both the speculating variant (the device default: a lane holding an untested leaf range keeps descending) and
+    the plain one: brute force's answers, no access outside the lane's stack column (budget + 1 slots: the unconditional
+    stores of the node step need the one slot of slack the collapse leaves), never deeper than the collapse's bound + 1."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(32, 32, 1, diffuse_only=False, ball_level=3, device=-1)
+    desc = scene.desc()
+    o, d = _rays(desc, 5000, 11)
+    for any_hit in (False, True):
+        for mint, maxt in ((1e-4, np.inf), (0.0, 150.0)):
+            brute = oracle.trace(desc, o, d, mint, maxt, any_hit=any_hit)
+            for max_leaf, fan, budget, schedule in ((4, 4, 31, 1), (4, 4, 31, 77), (1, 4, 31, 5), (2, 3, 31, 9), (4, 4, 20, 3), (4, 2, 31, 21)):
+                w = oracle.emu_trace4(desc, o, d, mint, maxt, any_hit=any_hit, max_leaf=max_leaf, stack_budget=budget, max_fan=fan,
+                                      schedule=schedule, spec=spec)       # raises if a slot outside the column was touched
+                b = w["bvh4"]
+                assert b["ok"] == 1 and b["stack_bound"] <= budget and b["stack_seen"] <= b["stack_bound"] + 1
+                assert _same(brute, w, any_hit)
+    # the scenes of the degenerate-box / tie test, and a tree whose collapse the device's budget binds
+    scene, _ = scenes.plugin_box(16, 16, 1, device=-1)
+    desc = scene.desc()
+    o, d = _rays(desc, 3000, 9)
+    for any_hit in (False, True):
+        brute = oracle.trace(desc, o, d, 0.0, np.inf, any_hit=any_hit)
+        for max_leaf in (1, 2, 4):
+            assert _same(brute, oracle.emu_trace4(desc, o, d, 0.0, np.inf, any_hit=any_hit, max_leaf=max_leaf, stack_budget=31, schedule=13, spec=spec), any_hit)
+    scene, _ = scenes.interior_scene(32, 32, 1, grid=96, device=-1, env_size=(32, 16))
+    desc = scene.desc()
+    o, d = _rays(desc, 300, 17)
+    for any_hit in (False, True):
+        brute = oracle.trace(desc, o, d, 1e-4, np.inf, any_hit=any_hit)
+        w = oracle.emu_trace4(desc, o, d, 1e-4, np.inf, any_hit=any_hit, stack_budget=31, schedule=2, spec=spec)
+        assert w["bvh4"]["stack_seen"] <= 32 and _same(brute, w, any_hit)
+
+
+def test_emulated_render_walks_trees_with_the_phase_machine_bodies(native, oracle, monkeypatch):
+    """emu_render sends the queries of a tree scene through those bodies (an E walk, then the S walk that must leave the hit
+    record alone): the film is the scalar oracle's, and the same as with the BVH2 walk (MIW_EMU_WALK=bvh2)."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(24, 20, 4, diffuse_only=False, ball_level=2, device=-1)      # 2 x 320-triangle balls: a tree scene
+    job = native.PathIntegrator().render_job(sensor, n_threads=4)
+    job.cfg.plan = 2
+    o32, o64, ost = oracle.render(scene.desc(), job, threads=4)
+    e64, e32, est = oracle.emu_render(scene.desc(), job)
+    assert est[0] == ost.samples and est[1] == ost.segments
+    assert np.array_equal(e32, o32)
+    monkeypatch.setenv("MIW_EMU_WALK", "bvh2")
+    b64, b32, bst = oracle.emu_render(scene.desc(), job)
+    assert np.array_equal(b32, e32) and list(bst)[:3] == list(est)[:3]
 
 
 @pytest.mark.gpu
