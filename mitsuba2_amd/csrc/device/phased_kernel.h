@@ -185,8 +185,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 MIW_PS(0, count(e_node));
                 if (e_node) {
                     if (Wide) {
-                        // one 64-byte node = four quantised child boxes: walk4_node_step (miw/bvh4.h — the CPU checker runs the same function)
-                        walk4_node_step<Spec>(nodes4[cur], r, widen(tmax), cur, sp, tri_i, tri_end, LdsColumn{ stack });
+                        // one 64-byte node = four quantised child boxes: the node step of miw/bvh4.h (the CPU checker runs the same statements)
+                        const LdsColumn column{ stack };
+                        MIW_WALK4_NODE_STEP(Spec, nodes4[cur], r, widen(tmax), cur, sp, tri_i, tri_end, column);
                     } else {
                         int32_t next = MIW_WALK_DONE;
 #if MIW_LDS_TOP

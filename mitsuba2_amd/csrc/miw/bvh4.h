@@ -106,25 +106,30 @@ MIW_HD bool bvh4_key_hit(uint32_t key) { return key < 0x7f800000u; }
 // writes up to slot sp + 2, which is why the collapse budgets one entry less than the column holds. A leaf becomes the lane's
 // triangle range if it holds none (Spec: otherwise it stays in `cur` until the range is drained), and the next stack entry the
 // current node.
+// (A macro, not a function: inlined as a function the same statements cost the 128-VGPR kernel eight more spilled registers and
+// the 0.9 M-triangle interior 1.5 % — round-3 session J; the function below, which the CPU checker calls, expands it as well.)
+#define MIW_WALK4_NODE_STEP(SPEC, n_, r_, tmax_wide_, cur_, sp_, tri_i_, tri_end_, stack_) do {                           \
+        int32_t next_ = MIW_BVH4_ABSENT;                                                                                 \
+        uint32_t k_[4];                                                                                                  \
+        int32_t ch_[4] = { (n_).child[0], (n_).child[1], (n_).child[2], (n_).child[3] };                                 \
+        bvh4_test((n_), (r_), (tmax_wide_), k_);                                                                         \
+        bvh4_sort(k_, ch_);                                                                                              \
+        (stack_)[sp_] = ch_[3]; sp_ += bvh4_key_hit(k_[3]) ? 1 : 0;                                                     \
+        (stack_)[sp_] = ch_[2]; sp_ += bvh4_key_hit(k_[2]) ? 1 : 0;                                                     \
+        (stack_)[sp_] = ch_[1]; sp_ += bvh4_key_hit(k_[1]) ? 1 : 0;                                                     \
+        if (bvh4_key_hit(k_[0])) next_ = ch_[0];                                                                         \
+        else if (sp_ != 0) { --sp_; next_ = (stack_)[sp_]; }                                                             \
+        if (next_ < 0 && next_ != MIW_BVH4_ABSENT && (!(SPEC) || tri_i_ >= tri_end_)) {                                  \
+            const uint32_t code_ = (uint32_t) ~next_;                                                                    \
+            tri_i_ = code_ >> 4; tri_end_ = tri_i_ + (code_ & 15u) + 1u;                                                 \
+            next_ = MIW_BVH4_ABSENT;                                                                                     \
+            if (sp_ != 0) { --sp_; next_ = (stack_)[sp_]; }                                                              \
+        }                                                                                                                \
+        cur_ = next_;                                                                                                    \
+    } while (0)
 template <bool Spec, typename Ray, typename Stack>
 MIW_HD void walk4_node_step(const Bvh4Node &n, const Ray &r, float tmax_wide, int32_t &cur, int32_t &sp, uint32_t &tri_i, uint32_t &tri_end, Stack stack) {
-    int32_t next = MIW_BVH4_ABSENT;
-    uint32_t k[4];
-    int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
-    bvh4_test(n, r, tmax_wide, k);
-    bvh4_sort(k, ch);
-    stack[sp] = ch[3]; sp += bvh4_key_hit(k[3]) ? 1 : 0;
-    stack[sp] = ch[2]; sp += bvh4_key_hit(k[2]) ? 1 : 0;
-    stack[sp] = ch[1]; sp += bvh4_key_hit(k[1]) ? 1 : 0;
-    if (bvh4_key_hit(k[0])) next = ch[0];
-    else if (sp != 0) { --sp; next = stack[sp]; }
-    if (next < 0 && next != MIW_BVH4_ABSENT && (!Spec || tri_i >= tri_end)) {
-        const uint32_t code = (uint32_t) ~next;
-        tri_i = code >> 4; tri_end = tri_i + (code & 15u) + 1u;
-        next = MIW_BVH4_ABSENT;
-        if (sp != 0) { --sp; next = stack[sp]; }
-    }
-    cur = next;
+    MIW_WALK4_NODE_STEP(Spec, n, r, tmax_wide, cur, sp, tri_i, tri_end, stack);
 }
 
 // Triangle step: two triangles of the lane's range per call — both records are fetched before either test runs (the second

@@ -5,9 +5,9 @@
 //   device/resident_kernel.h     plan 2: k_init_pixels, the pixel queue, k_path_resident (path / direct)
 //   device/phased_kernel.h       plan 2 over a tree: k_path_phased (wave-level phase machine: node steps / triangle tests / shade)
 //   device/stream_trace.h        plan 1 over a tree: k_trace_stream (persistent walk kernel, dynamic ray fetch), k_sort_hits
-//   device/film_kernels.h        k_film_resolve, k_film_blocks, k_film_pack, k_film_groups, k_film_merge
+//   device/film_kernels.h        k_film_resolve, k_film_groups (16-byte class records), k_film_blocks (24-byte position log), k_film_merge
 //   device/eval_kernels.h        k_trace_soa (mi_trace), k_eval (mi_eval)
-//   lbvh_device.h                device LBVH builder
+//   lbvh_device.h, bvh4_device.h device LBVH builder, level-synchronous collapse into the 4-wide tree
 // followed here by the host side: context, scene upload, BVH build, mi_trace, mi_render, mi_eval, mi_selftest.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

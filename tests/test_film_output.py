@@ -134,8 +134,9 @@ from conftest import has_gpu  # noqa: E402
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
 @pytest.mark.parametrize("name", ["tent", "mitchell", "catmullrom", "lanczos"])
 def test_device_film_with_every_filter(native, oracle, name):
-    """the replay kernels take the filter as a table: k_film_pack + k_film_groups for footprints up to 4 x 4 texels,
-    k_film_blocks for wider ones — bit-identical to ImageBlock::put's order for every table"""
+    """the replay kernels take the filter as tables: k_film_groups over the 16-byte class records (weights per phase class)
+    where the filter has them, k_film_blocks over the 24-byte position log otherwise (lanczos) — bit-identical to
+    ImageBlock::put's order for every filter"""
     from mitsuba2_amd import scenes
     scene, sensor = scenes.cornell_box(96, 64, 8, device=-1, rfilter=name)
     job = native.PathIntegrator().render_job(sensor)
