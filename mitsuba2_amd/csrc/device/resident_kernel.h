@@ -83,8 +83,11 @@ struct QueueWork {
         if (has_pixel) atomicMin(prog, sample_idx);
         const uint32_t v = *prog;
         *prog = 0xffffffffu;
-        uint32_t qtr = v == 0xffffffffu ? 3u : (4u * v) / (sample_end_ ? sample_end_ : 1u);
-        qtr = (uint32_t) __builtin_amdgcn_readfirstlane((int) (qtr > 3u ? 3u : qtr));
+        // quarter of its samples the slowest lane is in: floor(4 v / sample_end) by comparisons (a division by a kernel argument would
+        // keep its reciprocal in a VGPR for the whole launch)
+        const uint32_t v4 = 4u * v, se = sample_end_;
+        uint32_t qtr = v == 0xffffffffu ? 3u : (v4 >= se ? 1u : 0u) + (v4 >= 2u * se ? 1u : 0u) + (v4 >= 3u * se ? 1u : 0u);
+        qtr = (uint32_t) __builtin_amdgcn_readfirstlane((int) qtr);
         if (qtr == quarter) return;
         quarter = qtr;
         if (qtr == 0u) __builtin_amdgcn_s_setprio(3); else if (qtr == 1u) __builtin_amdgcn_s_setprio(2);
@@ -110,7 +113,8 @@ struct QueueWork {
             uint32_t base = 0;
             if (me == leader) base = atomicAdd(next_pixel + q, (uint32_t) __popcll(b));
             base = (uint32_t) __shfl((int) base, (int) leader, 64);
-            const uint32_t idx = base + (uint32_t) __popcll(b & ((1ull << me) - 1ull));
+            // rank among the asking lanes: v_mbcnt counts the ballot's bits below this lane (no 64-bit lane mask kept in registers)
+            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u));
             uint32_t l = idx;
             if (nq > 1u) {                                      // placed queues: queue q = up to MIW_PLACE_PIECES pieces of 64 lanes
                 const uint32_t piece = idx < per ? Q->piece_list[q * MIW_PLACE_PIECES + (idx >> 6)] : 0xffffffffu;

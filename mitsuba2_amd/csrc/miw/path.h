@@ -87,7 +87,17 @@ struct RenderParams {
     uint32_t integrator;             // INTEG_*
     DirectRec direct;
     uint32_t moment_pass;            // moment.cpp around the integrator: 0 off, 1 values, 2 squares (include/miwave.h)
+    // derived by render_params_prepare(): what every camera sample needs of the records above, as floats — kernel arguments live in
+    // scalar registers, the same values computed in the kernel (int -> float conversions, the fmas of the camera origin) are
+    // loop-invariant VECTOR registers the packet kernel has none to spare for (it spilled twelve)
+    float cam_o[3];                  // sensor_origin(sensor)
+    float crop_f[4];                 // (float) film.crop_x, crop_y, crop_w, crop_h
 };
+MIW_HD void render_params_prepare(RenderParams &P) {
+    const V3 o = sensor_origin(P.sensor);
+    P.cam_o[0] = o.x; P.cam_o[1] = o.y; P.cam_o[2] = o.z;
+    P.crop_f[0] = (float) P.film.crop_x; P.crop_f[1] = (float) P.film.crop_y; P.crop_f[2] = (float) P.film.crop_w; P.crop_f[3] = (float) P.film.crop_h;
+}
 
 // per-launch device counters (mi_get_counters)
 struct Counters {
@@ -126,9 +136,9 @@ MIW_HD void lane_begin_sample(const RenderParams &P, uint32_t pixel, LaneRegs &L
 #else
     (void) wavelength_sample; L.ray_weight = spec(1.f);
 #endif
-    V2 adj = v2((L.pos.x - (float) P.film.crop_x) / (float) P.film.crop_w,    // :254-256
-                (L.pos.y - (float) P.film.crop_y) / (float) P.film.crop_h);
-    L.ray = sensor_sample_ray(P.sensor, adj);            // :258
+    V2 adj = v2((L.pos.x - P.crop_f[0]) / P.crop_f[2],    // :254-256
+                (L.pos.y - P.crop_f[1]) / P.crop_f[3]);
+    L.ray = sensor_sample_ray(P.sensor, adj, v3(P.cam_o[0], P.cam_o[1], P.cam_o[2]));   // :258
     L.tp = spec(1.f); L.res = spec(0.f); L.eta = 1.f; L.prev_pdf = 0.f;   // path.cpp:111-116
     L.flags = 1u | LF_RAY_ACTIVE;                        // depth = 1
 }

@@ -54,6 +54,7 @@ struct SceneView {
     const ShapeRec *shapes; uint32_t shape_count;
     const BsdfRec  *bsdfs;  uint32_t bsdf_count;
     const EmitterRec *emitters; uint32_t emitter_count;
+    float emitter_count_f, emitter_count_inv;       // (float) emitter_count and 1 / it (scene_view_prepare: kernel arguments, not per-launch vector math)
     const float *emit_tri;                          // 9 floats per emitter face
     const float *emit_vnorm;                        // 9 floats per emitter face or nullptr
     const float *emit_pmf, *emit_cdf;
@@ -66,6 +67,10 @@ struct SceneView {
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
     const struct Bvh4Node *nodes4;                  // device only: the 4-wide quantised tree the phase machine walks (bvh4.h) or nullptr
 };
+MIW_HD void scene_view_prepare(SceneView &v) {
+    v.emitter_count_f = (float) v.emitter_count;
+    v.emitter_count_inv = v.emitter_count ? 1.f / (float) v.emitter_count : 0.f;
+}
 
 MIW_HD PrimCtx prim_ctx(const SceneView &sc) { PrimCtx c; c.rects = sc.rects; c.accept_pad = sc.accept_pad; return c; }
 
@@ -224,8 +229,8 @@ MIW_HD Spec sample_emitter_direction(const SceneView &sc, V3 ref_p, V2 sample, D
     uint32_t index = 0;
     float emitter_pdf = 1.f;
     if (sc.emitter_count > 1) {                        // scene.cpp:180-188
-        float n = (float) sc.emitter_count;
-        emitter_pdf = 1.f / n;
+        float n = sc.emitter_count_f;
+        emitter_pdf = sc.emitter_count_inv;
         uint32_t i = (uint32_t) (sample.x * n);
         index = i < sc.emitter_count - 1 ? i : sc.emitter_count - 1;
         sample.x = (sample.x - (float) index * emitter_pdf) * n;
@@ -261,7 +266,7 @@ MIW_HD float emitter_pdf_direction(const SceneView &sc, uint32_t emitter, V3 ds_
 template <bool Analytic = true>
 MIW_HD float pdf_emitter_direction(const SceneView &sc, uint32_t emitter, V3 ds_d, float ds_dist, V3 ds_n, V3 ref_p) {
     float value = emitter_pdf_direction<Analytic>(sc, emitter, ds_d, ds_dist, ds_n, ref_p);
-    if (sc.emitter_count > 1) value = value * (1.f / (float) sc.emitter_count);
+    if (sc.emitter_count > 1) value = value * sc.emitter_count_inv;
     return value;
 }
 
@@ -289,7 +294,10 @@ struct SensorRec {
     float pp_offset[2];          // principal point offset (perspective.cpp:111-116)
 };
 
-MIW_HD Ray sensor_sample_ray(const SensorRec &s, V2 position_sample) {
+// perspective.cpp:186-214. `origin` = sensor_origin(s): the same for every ray, so the render kernels take it from a kernel
+// argument (RenderParams::cam_o) instead of holding three vector registers of loop-invariant fmas.
+MIW_HD V3 sensor_origin(const SensorRec &s) { return xf_point_affine(s.to_world, v3(0.f)); }
+MIW_HD Ray sensor_sample_ray(const SensorRec &s, V2 position_sample, V3 origin) {
     V3 near_p = xf_point_persp(s.sample_to_camera,
                                v3(position_sample.x + s.pp_offset[0],
                                   position_sample.y + s.pp_offset[1], 0.f));
@@ -298,9 +306,10 @@ MIW_HD Ray sensor_sample_ray(const SensorRec &s, V2 position_sample) {
     Ray r;
     r.mint = s.near_clip * inv_z;
     r.maxt = s.far_clip * inv_z;
-    r.o = xf_point_affine(s.to_world, v3(0.f));
+    r.o = origin;
     r.d = xf_vector(s.to_world, d);
     return r;
 }
+MIW_HD Ray sensor_sample_ray(const SensorRec &s, V2 position_sample) { return sensor_sample_ray(s, position_sample, sensor_origin(s)); }
 
 } // namespace miw

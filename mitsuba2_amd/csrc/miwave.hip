@@ -560,6 +560,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.shapes = c->d_shapes.p; v.shape_count = (uint32_t) c->shapes.size();
     v.bsdfs = c->d_bsdfs.p; v.bsdf_count = (uint32_t) c->bsdfs.size();
     v.emitters = c->d_emitters.p; v.emitter_count = (uint32_t) c->emitters.size();
+    scene_view_prepare(v);
     v.emit_tri = c->d_emit_tri.p; v.emit_vnorm = c->emit_vnorm.empty() ? nullptr : c->d_emit_vnorm.p;
     v.emit_pmf = c->d_emit_pmf.p; v.emit_cdf = c->d_emit_cdf.p;
     v.env = c->have_env ? c->d_env.p : nullptr;
@@ -790,6 +791,7 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
     if (cfg->moment_pass) return fail(c, MI_ERR_INVALID, "render: the moment integrator is provided by the scalar_rgb library only");
 #endif
     P.moment_pass = (uint32_t) cfg->moment_pass;
+    render_params_prepare(P);
     return MI_OK;
 }
 

@@ -284,6 +284,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
+    scene_view_prepare(v);
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
     o.accel.on = false;

@@ -146,6 +146,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     v.shapes = o.shapes.data(); v.shape_count = (uint32_t) o.shapes.size();
     v.bsdfs = o.bsdfs.data(); v.bsdf_count = (uint32_t) o.bsdfs.size();
     v.emitters = o.emitters.data(); v.emitter_count = (uint32_t) o.emitters.size();
+    scene_view_prepare(v);
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
     v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr; v.nodes4 = nullptr;
@@ -323,6 +324,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     P.film.warn_negative = cfg->moment_pass ? 0u : 1u;
     P.spp = cfg->spp; P.max_depth = cfg->max_depth; P.rr_depth = cfg->rr_depth;
     P.moment_pass = (uint32_t) cfg->moment_pass;
+    render_params_prepare(P);
     const bool direct = cfg->integrator == MI_INTEGRATOR_DIRECT;
     if (direct) {                                              // fill_params (miwave.hip), direct.cpp:82-103
         const uint32_t ne = cfg->emitter_samples, nb = cfg->bsdf_samples;
