@@ -62,12 +62,12 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     const uint32_t ns = cfg.nodes_staged;
 #endif
     const PrimCtx ctx = prim_ctx(sc);
-    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    LaneCounters local; local.segments = local.samples = local.shadow_rays = 0;
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
 #endif
 
-    QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+    QueueWork<false> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
     __shared__ uint32_t s_prog[MIW_BLOCK / 64];
     if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
@@ -81,14 +81,15 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     // the walk a lane is in: current node (>= 0), pending leaf code (< 0) or DONE; stack depth; untested leaf range; best hit
     int32_t cur = MIW_WALK_DONE, sp = 0;
     uint32_t tri_i = 0, tri_end = 0;
-    float tmax = 0.f, maxt_cur = 0.f;
-    V3 d_cur = v3(0.f);
+    // (direction, maxt and mint of the walk in progress are the path state's own — L.ray for an E walk, sh.d / sh.maxt for an S
+    // walk, selected by `mode` where the triangle body needs them — not copies that would be live through the shade body)
+    float tmax = 0.f;
     FastRay r; r.inv_d = r.neg_o_inv_d = v3(0.f); r.mint = 0.f;
     Hit best; best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
 
     auto begin_walk = [&](V3 d, float maxt) {
         r = fast_ray(L.ray.o, d, L.ray.mint);
-        d_cur = d; maxt_cur = maxt; tmax = maxt;
+        tmax = maxt;
         cur = 0; sp = 0; tri_i = tri_end = 0;
         best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     };
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 if (e_turn) {
                     mode = PH_TRAV_S;
                     r = fast_ray(L.ray.o, sh.d, L.ray.mint);
-                    d_cur = sh.d; maxt_cur = sh.maxt; tmax = sh.maxt;
+                    tmax = sh.maxt;
                     cur = 0; sp = 0; tri_i = tri_end = 0;
                     e_node = true;
                 }
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     if (Wide) {
                         // one 64-byte node = four quantised child boxes: the node step of miw/bvh4.h (the CPU checker runs the same statements)
                         const LdsColumn column{ stack };
-                        MIW_WALK4_NODE_STEP(Spec, nodes4[cur], r, widen(tmax), cur, sp, tri_i, tri_end, column);
+                        FastRay rn; rn.inv_d = r.inv_d; rn.neg_o_inv_d = r.neg_o_inv_d; rn.mint = L.ray.mint;   // (r.mint would be one more register carried through the shade body)
+                        MIW_WALK4_NODE_STEP(Spec, nodes4[cur], rn, widen(tmax), cur, sp, tri_i, tri_end, column);
                     } else {
                         int32_t next = MIW_WALK_DONE;
 #if MIW_LDS_TOP
@@ -231,6 +233,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             do {
                 MIW_PS(1, count(e_leaf));
                 if (e_leaf) {
+                    const bool s_walk = mode == PH_TRAV_S;
+                    const V3 d_cur = s_walk ? sh.d : L.ray.d;
+                    const float maxt_cur = s_walk ? sh.maxt : L.ray.maxt;
 #if MIW_TRI_PAIR
                     // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
                     walk4_tri_step<Analytic>([gtris](uint32_t i) -> const Tri & { return gtris[i]; }, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,

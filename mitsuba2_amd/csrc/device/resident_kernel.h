@@ -41,6 +41,9 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 #ifndef MIW_PLACE_PIECES
 #define MIW_PLACE_PIECES 4
 #endif
+// Placed = false (the tree kernels: placement is a packet-kernel feature, miwave.hip) compiles the queue choice, the dry-queue scan
+// and the cost clock out — four registers less carried through every body of the phase machine.
+template <bool Placed = true>
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
@@ -55,9 +58,9 @@ struct QueueWork {
     // empty raises a flag (simd_ids[0]) that spares the others the scan.
     uint32_t nq, per, q, dry, t_fetch;
     __device__ __forceinline__ void init_queues(uint32_t queues) {
-        nq = queues; per = nq > 1u ? MIW_PLACE_PIECES * 64u : n_lanes; q = 0u; dry = 0; t_fetch = 0;
+        nq = Placed ? queues : 1u; per = nq > 1u ? MIW_PLACE_PIECES * 64u : n_lanes; q = 0u; dry = 0; t_fetch = 0;
         ticks = 0; quarter = 0; tail_prio = 0; sample_end_ = spp;
-        if (Q->simd_ids) {
+        if (Placed && Q->simd_ids) {
             // which SIMD this wavefront runs on. The measuring launch only marks the SIMD as present (the host numbers the present
             // ones 0 .. n - 1 afterwards); the placed launch looks its queue up.
             const uint32_t hw = (uint32_t) __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)),          // HW_REG_HW_ID: simd [5:4] cu [11:8] sh [12] se [15:13]
@@ -98,6 +101,20 @@ struct QueueWork {
     }
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
         for (;;) {
+            if (!Placed) {                                      // one queue: a ballot, one atomic, the lanes' ranks
+                const unsigned long long b = __ballot(1);
+                const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+                uint32_t base = 0;
+                if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
+                base = (uint32_t) __shfl((int) base, (int) leader, 64);
+                const uint32_t l = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u));
+                if (l >= n_lanes) return false;
+                lane = l;
+                st = Q->st[lane];
+                if (st.z & LF_DONE) continue;                   // pixel outside its clipped block, or already complete
+                pixel = Q->pixel[lane];
+                return true;
+            }
             if (dry >= nq) {                                    // every queue is empty: say so to everybody (placed queues: a scan of all
                 if (nq > 1u) Q->simd_ids[0] = 1u;               // of them costs a thousand round trips — once per launch is enough)
                 return false;
@@ -131,7 +148,7 @@ struct QueueWork {
     }
     __device__ __forceinline__ void store(U4 st) {
         Q->st[lane] = st;
-        if (Q->piece_cost) atomicAdd(Q->piece_cost + (lane >> 6), ticks - t_fetch);   // iterations this pixel took in this launch
+        if (Placed && Q->piece_cost) atomicAdd(Q->piece_cost + (lane >> 6), ticks - t_fetch);   // iterations this pixel took in this launch
     }
     __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
         if (Q->log_rec) {                                       // wave-uniform: one format per render
@@ -177,12 +194,12 @@ __global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES
         for (uint32_t i = threadIdx.x; i < T.side * T.side * MIW_FILM_CHANNELS; i += blockDim.x) tile[i] = 0.0;
         __syncthreads();
     }
-    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    LaneCounters local; local.segments = local.samples = local.shadow_rays = 0;
     auto tr2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
         trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
     };
     if (UseLog) {
-        QueueWork work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+        QueueWork<Tiny != 0> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
         work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
         __shared__ uint32_t s_prog[MIW_BLOCK / 64];
         if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     if (threadIdx.x < WL_LISTS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t seg = blockIdx.x * MIW_BLOCK, *cnt_in = in.count + blockIdx.x * WL_LISTS;
-    Counters local; local.segments = local.samples = local.shadow_rays = local.active_lanes = 0;
+    LaneCounters local; local.segments = local.samples = local.shadow_rays = 0;
+    uint32_t active_lane = 0;
     // this workgroup's four material lists, back to back
     uint32_t lane = 0; bool mine = false;
     {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
             SplatSink<FilmAdd> sink; sink.film = &P.film; sink.add = add;
             flags = lane_shade(P, sc, Q, lane, &local, sink);
         }
-        local.active_lanes = (!(flags & LF_DONE) && count_active) ? 1 : 0;
+        active_lane = (!(flags & LF_DONE) && count_active) ? 1u : 0u;
     }
     // next iteration's work: rays to trace, shadow rays to test, samples that only wait for a shadow ray
     const bool alive = mine && !(flags & LF_DONE);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     // MIW_CNT_SHARDS counter records (same-address device atomics serialise at
     // ~12 ns each — 131k waves on one word would cost more than the shading).
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples),
-                       c = wave_sum(local.shadow_rays), d = wave_sum(local.active_lanes);
+                       c = wave_sum(local.shadow_rays), d = wave_sum(active_lane);
     if ((threadIdx.x & 63) == 0) {
         Counters *shard = cnt + ((blockIdx.x * (MIW_BLOCK / 64) + (threadIdx.x >> 6)) & (MIW_CNT_SHARDS - 1));
         if (a) atomicAdd(&shard->segments, a);

@@ -149,12 +149,14 @@ MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
         if (any_hit) {                                           // any hit ends the shadow walk
             occluded = true; tri_end = 0; cur = MIW_BVH4_ABSENT; sp = 0;
         } else {
-            if (hit1 && (t < best.t || (t == best.t && tr.prim < best.prim))) {
-                best.t = t; best.u = u; best.v = v; best.tri = tri_i; best.prim = tr.prim;
+            // (the primitive id of the best hit is looked up when a tie asks for it — about never — rather than carried:
+            // `best.prim` would be one more register live through every body of the phase machine; best.t == t implies a hit)
+            if (hit1 && (t < best.t || (t == best.t && tr.prim < tri_at(best.tri).prim))) {
+                best.t = t; best.u = u; best.v = v; best.tri = tri_i;
                 tmax = t;
             }
-            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < best.prim))) {
-                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u; best.prim = tr2.prim;
+            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < tri_at(best.tri).prim))) {
+                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u;
                 tmax = t2;
             }
         }

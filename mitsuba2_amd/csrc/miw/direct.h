@@ -19,9 +19,9 @@ struct DirectPending { Spec bsdf_val; float pdf; bool delta; };
 // direct.cpp:113-133: the primary hit. Returns false when the camera sample is complete (a miss).
 // `Mats` / `Analytic` as in path.h: MATS_ALL kernels serve scenes with texture coordinates, bitmaps or the extended plugins,
 // MATS_PLAIN the rest (the lookups compiled out); Analytic = false compiles the analytic shapes out.
-template <int Mats, bool Analytic>
+template <int Mats, bool Analytic, typename Cnt>
 MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, V3 ray_o,
-                           SurfaceInteraction &si, BsdfSide &bsdf, Counters *cnt_local) {
+                           SurfaceInteraction &si, BsdfSide &bsdf, Cnt *cnt_local) {
     const bool valid = f2u(h.w) != MIW_MISS;
     const V3 ray_d = L.ray.d;
     int32_t emitter = -1;
@@ -42,9 +42,9 @@ MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs 
 }
 
 // One emitter sample, direct.cpp:137-160. Returns true when a shadow ray is queued in `sh`.
-template <int Mats, bool Analytic>
+template <int Mats, bool Analytic, typename Cnt>
 MIW_HD bool direct_emitter_sample(const RenderParams &P, const SceneView &sc, LaneRegs &L, const SurfaceInteraction &si,
-                                  const BsdfSide &bsdf, ShadowOut &sh, Counters *cnt_local) {
+                                  const BsdfSide &bsdf, ShadowOut &sh, Cnt *cnt_local) {
     const DirectRec &D = P.direct;
     DirectionSample ds;
     Spec emitter_val = sample_emitter_direction<Analytic>(sc, si.p, next_2d(L.rng), ds, L.wl);   // :141-142
@@ -130,9 +130,9 @@ MIW_HD void direct_bsdf_hit(const RenderParams &P, const SceneView &sc, LaneRegs
 // camera and secondary rays, the interaction carried across it) the path kernel of a frame measured 92.7 ms instead of 135.8 on
 // the Cornell box, 207 / 235 on the material balls, 174 / 188 on the 0.9 M-triangle interior (round-3 session I). The kernels
 // still spill at three wavefronts per SIMD; see MIW_DIRECT_WAVES in device/resident_kernel.h for why they stay there.
-template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2>
+template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2, typename Cnt>
 MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
-                                       Trace2 trace2, Counters *cnt_local) {
+                                       Trace2 trace2, Cnt *cnt_local) {
     const uint32_t n_emitter = P.direct.emitter_samples, n_bsdf = P.direct.bsdf_samples;
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;

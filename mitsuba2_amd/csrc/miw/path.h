@@ -106,6 +106,9 @@ struct Counters {
     unsigned long long shadow_rays;
     unsigned long long active_lanes; // lanes not DONE after the last shade pass
 };
+// what one lane counts during one launch (the kernels sum these per wavefront into a Counters shard at the end): 32 bits are
+// plenty for one launch and half the registers — they are live through the whole render loop
+struct LaneCounters { uint32_t segments, samples, shadow_rays; };
 
 MIW_HD float next_1d(PCG32 &r) { return pcg32_next_f32(r); }
 MIW_HD V2 next_2d(PCG32 &r) { float a = pcg32_next_f32(r); float b = pcg32_next_f32(r); return v2(a, b); }
@@ -297,9 +300,9 @@ enum { STEP_CONTINUE = 0,        // extension ray queued in L.ray
 // MATS_TRIO is MATS_PLAIN for scenes whose records are all diffuse / dielectric / roughconductor (BASELINE configs 3, 4).
 enum { MATS_ALL = 0, MATS_DIFFUSE = 1, MATS_PLAIN = 2, MATS_TRIO = 3 };
 // `Analytic` = false compiles the analytic-shape branch out (scenes the caller knows to be triangles only).
-template <int Mats = MATS_ALL, bool Analytic = true, typename PrevO>
+template <int Mats = MATS_ALL, bool Analytic = true, typename PrevO, typename Cnt>
 MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4 h, PrevO prev_o,
-                     ShadowOut &sh, Counters *cnt_local) {
+                     ShadowOut &sh, Cnt *cnt_local) {
     sh.has = false;
     const uint32_t depth = L.flags & LF_DEPTH_MASK;
     const uint32_t tri_idx = f2u(h.w);
@@ -406,9 +409,9 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
 // Returns the lane's new flag word: LF_DONE clear = the lane still has work; LF_RAY_ACTIVE = an
 // extension / primary ray is queued; LF_HAS_SHADOW = a shadow ray is queued; LF_DEAD_PENDING = the
 // sample only waits for that shadow ray (the device builds the next iteration's work lists from these).
-template <typename Sink>
+template <typename Sink, typename Cnt>
 MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const LaneQueues &Q,
-                           uint32_t lane, Counters *cnt_local, Sink sink) {
+                           uint32_t lane, Cnt *cnt_local, Sink sink) {
     LaneRegs L;
     lane_load(Q, lane, L);
     if (L.flags & LF_DONE) return LF_DONE;
@@ -477,9 +480,9 @@ MIW_HD uint32_t lane_shade(const RenderParams &P, const SceneView &sc, const Lan
 // store(st) publishes a pixel's state when its run is over, put(...) is block->put(). A lane that
 // finishes a pixel fetches the next one INSIDE the iteration loop, so the other lanes of its wavefront
 // never wait for it (the device feeds lanes from one shared queue; the CPU checker hands out one pixel).
-template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2>
+template <int Mats = MATS_ALL, bool Analytic = true, typename Work, typename Trace2, typename Cnt>
 MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
-                                Trace2 trace2, Counters *cnt_local) {
+                                Trace2 trace2, Cnt *cnt_local) {
     LaneRegs L;
     L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
     uint32_t pixel = 0;
@@ -525,14 +528,14 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
     }
 }
 
-template <int Mats, bool Analytic, typename Work, typename Trace2>
+template <int Mats, bool Analytic, typename Work, typename Trace2, typename Cnt>
 MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &sc, uint32_t sample_end, Work &work,
-                                       Trace2 trace2, Counters *cnt_local);     // direct.h
+                                       Trace2 trace2, Cnt *cnt_local);     // direct.h
 
 // One pixel, samples [st.w, sample_end): returns the updated st word.
-template <uint32_t Integ = INTEG_PATH, typename Trace2, typename Sink>
+template <uint32_t Integ = INTEG_PATH, typename Trace2, typename Sink, typename Cnt>
 MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixel, U4 st, uint32_t sample_end,
-                       Trace2 trace2, Sink sink, Counters *cnt_local) {
+                       Trace2 trace2, Sink sink, Cnt *cnt_local) {
     struct OnePixel {
         uint32_t pixel; U4 st; bool taken; Sink sink;
         MIW_HD bool fetch(uint32_t &px, U4 &s) { if (taken) return false; taken = true; px = pixel; s = st; return true; }

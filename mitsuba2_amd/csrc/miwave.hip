@@ -983,10 +983,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // samples, at least 16) records what every 64-lane piece costs, the pieces are dealt to the SIMDs longest-first, and the
         // rest of the samples run with every wavefront taking its pixels from the queue of the SIMD it sits on (resident_kernel.h:
         // QueueWork). Same samples, same log slots: the film does not change. MIW_PLACE = 0 | 1 overrides.
-        // (only where every pixel of the shard can be resident at once: 4 wavefronts per SIMD for the plain-diffuse packet kernel and
-        // the phase machine over big trees, 3 for the other kernels — a shard larger than that is balanced by the queue itself)
-        const uint32_t res_waves = (c->lds_cfg.brute && c->diffuse_only && !MIW_SPECTRAL) || (!c->lds_cfg.brute && c->view.tri_count >= 200000u) ? 4u : 3u;
-        bool place = film_mode == 1 && !direct && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
+        // (packet kernels only — QueueWork<Placed> — and only where every pixel of the shard can be resident at once: 4 wavefronts per SIMD
+        // for the plain-diffuse packet kernel, 3 for the others — a shard larger than that is balanced by the queue itself)
+        const uint32_t res_waves = c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u;
+        bool place = film_mode == 1 && !direct && c->lds_cfg.brute && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = getenv("MIW_PLACE")) place = place && atoi(e) != 0;
         uint32_t measure_div = 8u;                                 // the measuring launch runs spp / 8 samples (MIW_PLACE_MEASURE = divisor)
@@ -1078,7 +1078,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel);
                 K.path_kernel = phased ? (c->view.nodes4 ? 1u : 3u) : 0u;
                 // 4 waves per SIMD for big trees (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0); MIW_PHASED_WAVES = 3 | 4 overrides
-                int ph_waves = c->view.tri_count >= 200000u ? 4 : 3;
+                int ph_waves = 4;     // (3 until round 3: with 120 spilled registers the fourth wavefront only paid on big trees; at 20 it pays everywhere — DESIGN.md section 4)
                 if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
                 const dim3 phgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (unsigned) ph_waves));
                 // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the

@@ -190,6 +190,7 @@ bool emu_walk4(const Bvh4Node *nodes4, TriAt tri_at, const PrimCtx &ctx, V3 o, V
         else
             walk4_tri_step<true>(tri_at, ctx, o, d, mint, maxt, any_hit, best, tmax, occluded, cur, sp, tri_i, tri_end, stack);
     }
+    if (!any_hit && best.tri != MIW_MISS) best.prim = tri_at(best.tri).prim;          // (the triangle step does not carry it)
     return any_hit ? occluded : best.tri != MIW_MISS;
 }
 struct EmuCoin {                                                // xorshift32: the schedule of one test run
