@@ -42,8 +42,8 @@ struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](in
 #ifndef MIW_PHASE_END_WEIGHT
 #define MIW_PHASE_END_WEIGHT 4      /* the walk-end body is cheap: it runs once a quarter as many lanes wait for it as for the leading body */
 #endif
-// Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs, no spills) or 4 (128 VGPRs, a few spills in the shade body):
-// big trees, whose node fetches miss L2, gain more from the fourth wave's latency hiding than they lose to the spills.
+// Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs) or 4 (128 VGPRs; the default for every tree since the kernel
+// spills 20 registers at 128 instead of 121: DESIGN.md section 4, "the register diet").
 // Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h (the default) instead of the BVH2 (MIW_BVH4=0:
 // instantiated for the MATS_TRIO kernels only, A/B runs).
 template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = true>

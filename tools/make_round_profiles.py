@@ -125,6 +125,9 @@ def main():
     out.append("c2: %.1f Msamples/s, %.1f ms/frame, kernels ms/frame %s" % (j["value"], j["ms_per_step"], per_frame(j)))
     out.append("    roofline " + json.dumps(j["roofline"]))
     out.append("    cpu_baseline " + json.dumps(j["cpu_baseline"]))
+    j = last_json(g + "_bench_direct_c2.log")
+    if j:
+        out.append("direct integrator (1 + 1 samples), same scene and size: %.1f Msamples/s, %.1f ms/frame, kernels ms/frame %s" % (j["value"], j["ms_per_step"], per_frame(j)))
     for name in ("c5", "c5_diffuse"):
         j = last_json(g + "_bench_%s.log" % name)
         if j:
@@ -156,9 +159,9 @@ def main():
                "# bench lines of the same session: phase machine (default) / lock-step resident kernel (MIW_PHASED=0) / wavefront plan with "
                "the stream walk kernel (--plan 1) / phase machine over the BVH2 instead of the 4-wide tree (MIW_BVH4=0) / shade vote 1 : 1 instead of "
                "3 : 2 (2 : 1 with an environment map) (MIW_SHADE_VOTE=1:1) / device LBVH with its 4-wide tree collapsed on the device (--bvh-quality 0) / "
-               "the same with the collapse on the host after a read-back (MIW_BVH4_HOST=1) / with one triangle per LBVH leaf (MIW_LBVH_LEAF=1); "
-               "bvh build ms in brackets"]
-        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh", "_lbvh_hostcollapse", "_lbvh_leaf1"):
+               "the same with the collapse on the host after a read-back (MIW_BVH4_HOST=1) / with one triangle per LBVH leaf (MIW_LBVH_LEAF=1) / "
+               "three wavefronts per SIMD instead of four (MIW_PHASED_WAVES=3); bvh build ms in brackets"]
+        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh", "_lbvh_hostcollapse", "_lbvh_leaf1", "_w3"):
             if os.path.exists("%s_bench_%s%s.log" % (g, name, suffix)):
                 out.append(bench_line(g, "bench_%s%s" % (name, suffix), name + suffix))
         if name == "c3":

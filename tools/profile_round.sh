@@ -49,6 +49,10 @@ MIW_PLACE=0 MIW_TAIL_PRIO=0 timeout 300 python bench.py --scene interior --spp 6
 MIW_BVH4_HOST=1 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c4_lbvh_hostcollapse.log 2>&1
 MIW_LBVH_LEAF=1 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c4_lbvh_leaf1.log 2>&1
 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c3_lbvh.log 2>&1
+# three wavefronts per SIMD instead of four (the default since the register diet)
+MIW_PHASED_WAVES=3 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_w3.log 2>&1
+MIW_PHASED_WAVES=3 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4_w3.log 2>&1
+timeout 300 python bench.py --integrator direct --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/${tag}_bench_direct_c2.log 2>&1
 # keep the merged artefacts small: traces of the PMC passes are only needed for the per-kernel durations
 find $out -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $out | tail -1
