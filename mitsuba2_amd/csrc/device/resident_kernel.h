@@ -162,8 +162,8 @@ struct QueueWork {
 };
 
 #ifndef MIW_DIRECT_WAVES
-/* Waves per SIMD the direct-integrator kernels are compiled for. At 2 (256 VGPRs) none of them spills, at 3 (168) the MATS_ALL
-   ones keep 60 (packet scenes) / 216 (tree scenes) registers in scratch — and are faster all the same (path kernel of one frame,
+/* Waves per SIMD the direct-integrator kernels are compiled for. At 2 (256 VGPRs) none of them spills, at 3 (168) they keep
+   16 - 108 registers in scratch (60 / 216 in the MATS_ALL ones when this was measured) — and are faster all the same (path kernel of one frame,
    round-3 session I: Cornell box 92.7 ms against 115.2, material balls 207 / 204, 0.9 M-triangle interior 174 / 227): the
    spills sit in the prologue and around the BSDF code, the third wave hides the query's latency. */
 #define MIW_DIRECT_WAVES 3
