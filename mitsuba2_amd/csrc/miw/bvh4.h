@@ -145,22 +145,19 @@ MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
     float t, u, v, t2, u2, v2;
     const bool hit1 = prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v);
     const bool hit2 = prim_intersect<Analytic>(tr2, ctx, o, d, mint, maxt, t2, u2, v2) && two;
-    if (hit1 || hit2) {
-        if (any_hit) {                                           // any hit ends the shadow walk
-            occluded = true; tri_end = 0; cur = MIW_BVH4_ABSENT; sp = 0;
-        } else {
-            // (the primitive id of the best hit is looked up when a tie asks for it — about never — rather than carried:
-            // `best.prim` would be one more register live through every body of the phase machine; best.t == t implies a hit)
-            if (hit1 && (t < best.t || (t == best.t && tr.prim < tri_at(best.tri).prim))) {
-                best.t = t; best.u = u; best.v = v; best.tri = tri_i;
-                tmax = t;
-            }
-            if (hit2 && (t2 < best.t || (t2 == best.t && tr2.prim < tri_at(best.tri).prim))) {
-                best.t = t2; best.u = u2; best.v = v2; best.tri = tri_i + 1u;
-                tmax = t2;
-            }
-        }
-    }
+    // The updates are selects, not branches (the lanes of a wavefront never agree on them); the only branch left is the tie, which
+    // looks the best hit's primitive id up instead of carrying it through every body of the phase machine (about never taken).
+    const bool hit = hit1 | hit2, stop = any_hit & hit;              // any hit ends a shadow walk
+    occluded = occluded | stop;
+    bool take1 = !any_hit & hit1 & (t < best.t);
+    if (!any_hit & hit1 & (t == best.t)) take1 = best.tri == MIW_MISS || tr.prim < tri_at(best.tri).prim;
+    best.t = take1 ? t : best.t; best.u = take1 ? u : best.u; best.v = take1 ? v : best.v; best.tri = take1 ? tri_i : best.tri;
+    tmax = take1 ? t : tmax;
+    bool take2 = !any_hit & hit2 & (t2 < best.t);
+    if (!any_hit & hit2 & (t2 == best.t)) take2 = best.tri == MIW_MISS || tr2.prim < tri_at(best.tri).prim;
+    best.t = take2 ? t2 : best.t; best.u = take2 ? u2 : best.u; best.v = take2 ? v2 : best.v; best.tri = take2 ? tri_i + 1u : best.tri;
+    tmax = take2 ? t2 : tmax;
+    tri_end = stop ? 0u : tri_end; cur = stop ? MIW_BVH4_ABSENT : cur; sp = stop ? 0 : sp;
     tri_i += two ? 2u : 1u;
     if (tri_i >= tri_end && cur < 0 && cur != MIW_BVH4_ABSENT) {   // range drained and the stack handed over another leaf
         const uint32_t code = (uint32_t) ~cur;
