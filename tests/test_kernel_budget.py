@@ -1,0 +1,42 @@
+"""Register budgets of the two kernels the BASELINE configurations run on (no GPU needed: hipcc cross-compiles gfx950).
+
+Round 3 measured what a spilled vector register costs these kernels ("the register diet": the interior
++17 %, the material balls +16 % from 121 -> 12 spilled registers at four wavefronts per SIMD), so the budgets are part of the
+contract: the Cornell packet kernel fits 128 VGPRs (four wavefronts per SIMD) without spilling, the phase machine of configs
+3 / 4 fits them with at most 16 spilled. tools/probe_*.hip instantiate exactly those kernels from the product's headers
+(~12 s each); tools/kernel_resources.py prints the table for every variant."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-flush-denormals-to-zero", "-c",
+         "-Rpass-analysis=kernel-resource-usage"]
+
+
+def _resources(probe, kernel, tmp_path, *defs):
+    out = subprocess.run([HIPCC] + FLAGS + list(defs) + [os.path.join(ROOT, "tools", probe), "-o", str(tmp_path / "probe.o")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for blk in re.split(r"remark: Function Name: ", out.stderr)[1:]:
+        if kernel in blk.split()[0]:
+            val = lambda key: int(re.search(re.escape(key) + r": (\d+)", blk).group(1))
+            return {"vgprs": val("VGPRs"), "spilled": val("VGPRs Spill"), "waves": val("Occupancy [waves/SIMD]")}
+    raise AssertionError("kernel %s not in the remarks of %s" % (kernel, probe))
+
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+
+
+def test_cornell_packet_kernel_fits_four_waves_without_spills(tmp_path):
+    r = _resources("probe_resident.hip", "k_path_residentILb1ELi2ELi1ELb0ELj0E", tmp_path)
+    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] == 0, r
+
+
+def test_phase_machine_of_configs_3_and_4_fits_four_waves(tmp_path):
+    r = _resources("probe_phased.hip", "k_path_phasedILi3ELb0ELb1ELi4ELb1E", tmp_path, "-DMIW_PROBE_C34=1")
+    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 16, r

@@ -24,6 +24,10 @@ using namespace miw;
 #include "../mitsuba2_amd/csrc/device/wavefront_kernels.h"
 #include "../mitsuba2_amd/csrc/device/resident_kernel.h"
 #include "../mitsuba2_amd/csrc/device/phased_kernel.h"
+#if defined(MIW_PROBE_C34)   // only the kernel of BASELINE configs 3 / 4: MATS_TRIO over the 4-wide tree, four wavefronts per SIMD (tests/test_kernel_budget.py)
+template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, true>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+#else
 template __global__ void k_path_phased<MATS_PLAIN, false, MIW_PHASE_SPEC != 0>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #include "../mitsuba2_amd/csrc/device/stream_trace.h"
 template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 3, false>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+#endif
