@@ -15,6 +15,8 @@ Printed: lane-segments per million wave cycles for
     lock-step          max over lanes of (walk E) + max (walk S) + shade per iteration — k_path_resident
     phase machine      the kernel's vote, for several shade-vote ratios num : den (shade once n_shade * num >= den * lead)
     ideal              all lanes always busy: sum of work / 64
+    pooled shading     the next step DESIGN.md section 9 costs: the wavefronts of a workgroup pool their shade-ready lanes in an LDS queue
+                       and shade 64 at a time (see pooled()); per wavefront, so comparable with the rows above
 """
 import argparse
 
@@ -117,6 +119,61 @@ def phase_machine(rng, costs, segments, num, den, p_shadow=0.85):
     return total / t * 1e6
 
 
+def pooled(rng, costs, segments, waves=4, xfer=300.0, p_shadow=0.85):
+    """The step DESIGN.md section 9 costs: the `waves` wavefronts of a workgroup pool their shade-ready lanes. A lane whose walks
+    are over DEPOSITS its path state in an LDS queue (one body run of `xfer` cycles for all such lanes of the wave: ~37 dwords
+    each, wave-wide LDS stores) and becomes empty; empty lanes are REFILLED from the queue of shaded, walk-ready states (`xfer`
+    again); a wavefront that finds 64 deposited states — or whatever is there when it has nothing else to run — runs ONE shade
+    body over them (the usual shade cost, whatever the count) and puts the results on the walk-ready queue. Every wavefront has
+    its own clock (they sit on different SIMDs); the pools are shared and free. Returns lane-segments per million cycles of the
+    slowest wavefront, to be compared with `waves` independent phase machines (the same number: they do not interact)."""
+    W = [[Lane(rng, costs, p_shadow) for _ in range(64)] for _ in range(waves)]
+    for w in W:
+        for l in w:
+            l.begin()                                            # start with every lane walking
+    clock = [0.0] * waves
+    to_shade, ready = 0, 0                                       # states waiting for a shade run / shaded states waiting for a lane
+    done = 0
+    while done < segments:
+        i = min(range(waves), key=lambda k: clock[k])
+        w = W[i]
+        n_node = sum(1 for l in w if l.state == "walk" and l.ops and l.ops[0] == NODE)
+        n_tri = sum(1 for l in w if l.can_tri())
+        n_dep = sum(1 for l in w if l.state == "shade")          # walks over: state to deposit
+        n_empty = sum(1 for l in w if l.state == "empty")
+        lead = max(n_node, n_tri)
+        if to_shade >= 64 or (to_shade > 0 and lead == 0 and n_dep == 0 and ready == 0):
+            k = min(64, to_shade)                                # a full (or the last) shade run out of the pool
+            to_shade -= k; ready += k; done += k
+            clock[i] += costs.shade + 2.0 * xfer
+        elif n_dep > 0 and n_dep * 2 >= lead:                    # deposit once the finished lanes are half the busier walk group
+            for l in w:
+                if l.state == "shade":
+                    l.state = "empty"
+            to_shade += n_dep
+            clock[i] += xfer
+        elif n_empty > 0 and ready > 0 and (n_empty * 2 >= lead or lead == 0):
+            k = min(n_empty, ready)
+            ready -= k
+            for l in w:
+                if k and l.state == "empty":
+                    l.begin(); k -= 1
+            clock[i] += xfer
+        elif n_node >= n_tri and n_node > 0:
+            for l in w:
+                if l.state == "walk" and l.ops and l.ops[0] == NODE:
+                    l.step(NODE)
+            clock[i] += costs.node
+        elif n_tri > 0:
+            for l in w:
+                if l.can_tri():
+                    l.step(TRI)
+            clock[i] += costs.tri
+        else:
+            clock[i] += costs.node                               # nothing to do: wait a beat for the others
+    return done / max(clock) * 1e6
+
+
 def lock_step(rng, costs, segments, p_shadow=0.85):
     t, total = 0.0, 0
 
@@ -157,6 +214,9 @@ def main():
         r = phase_machine(np.random.default_rng(a.seed), c, a.segments, num, den)
         print("phase machine, shade vote %d:%d  %7.1f   (shade once n_shade >= %.2f x the busier walk body)" % (den, num, r, den / num))
     print("ideal (all lanes busy)       %7.1f" % ideal(np.random.default_rng(a.seed), c, a.segments))
+    for xfer in (150.0, 300.0, 600.0):
+        r = pooled(np.random.default_rng(a.seed), c, a.segments * 4, waves=4, xfer=xfer)
+        print("pooled shading, 4 waves, %3.0f cycles per state transfer run: %7.1f per wavefront  (to compare with the phase machine's rows)" % (xfer, r / 4))
 
 
 if __name__ == "__main__":
