@@ -4,8 +4,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--width --height --spp]
 
 A "step" is one complete render of the workload (scene + BVH already resident in
-HBM; the timed region is mi_render + the film reduce). For N > 1 launch with
-torch.distributed.run, one rank per GPU: pixel tiles (spiral blocks) are sharded
+HBM; the timed region is mi_render + the film reduce). N > 1 = one rank per GPU: either launched under
+torch.distributed.run (RANK / WORLD_SIZE in the environment), or `python bench.py --gpus N` alone, which re-executes
+itself under torch.distributed.run with N ranks (spawn_ranks). Pixel tiles (spiral blocks) are sharded
 round-robin over ranks (the N-GPU film equals the 1-GPU film), each rank
 splats into a private full-size float32 film and one RCCL reduce(sum) to rank 0 closes
 the step. `--shard passes` (never chosen automatically) renders the reference's
@@ -173,51 +174,75 @@ def live_counters(argv_workload, kernel):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def run_extras(api, scenes, dev, film, C):
-    """The other BASELINE configurations, OUTSIDE the timed headline and a few seconds each, so that the driver's own bench
-    line observes the tree kernels too: configs[2] geometry (material balls, 40 972 triangles) at 64 spp, configs[3] class
-    (0.9 M-triangle interior, area light + environment map) at 16 spp, configs[4] (scalar_spectral glass-block box) at 64 spp
-    — full 1920x1080 frames, one warm-up frame and one timed frame each (wall clock around mi_render, film on the device).
-    Throughput of these kernels does not depend on spp beyond a few samples per pixel."""
+def run_extras(api, scenes, film, C):
+    """The other BASELINE configurations AS CONFIGURED, outside the timed headline, so that the driver's own bench line observes
+    the tree kernels and the spectral variant at their configured sizes: configs[2] (material balls, 40 972 triangles) at 1024 spp,
+    configs[3] class (0.9 M-triangle interior, area light + environment map) at 2048 spp, configs[4] (scalar_spectral glass-block
+    box) at 512 spp — full 1920x1080 frames, one warm-up frame and one timed frame each (wall clock around mi_render, film on the
+    device; a separate context per scene, so the headline context's counters stay the headline's). ~25 s in all."""
     import torch
     out = {}
 
-    def timed(tag, device, scene, sensor, spp, note):
-        device.upload(scene.desc(), bvh_quality=1)
-        bvh = device.counters()
-        job = api.PathIntegrator().render_job(sensor)
-        cfg = job.cfg
-        cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = 0; cfg.profile = 1; cfg.plan = 0; cfg.samples_per_launch = int(cfg.spp)
-        device.check(device.L.mi_set_stream(device.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ms = []
-        for _ in range(2):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            device.check(device.L.mi_render(device.ctx, C.byref(cfg), C.c_void_p(film.data_ptr())))
-            torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
-        c = device.counters()
-        out[tag] = {"workload": note, "spp": spp, "value": 1920.0 * 1080 * spp / (ms[-1] * 1e-3) / 1e6, "unit": "Msamples/sec",
-                    "ms_per_frame": ms[-1], "ms_first_frame": ms[0], "ms_path_kernel": c.ms_path, "ms_film": c.ms_resolve,
-                    "segments_per_sample": c.segments / max(c.samples, 1),
-                    "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident",
-                    "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris}}
+    def timed(tag, scene, sensor, spp, note):
+        device = api.Device(0)                   # world == 1: the benchmark runs on GPU 0
+        try:
+            device.upload(scene.desc(), bvh_quality=1)
+            bvh = device.counters()
+            job = api.PathIntegrator().render_job(sensor)
+            cfg = job.cfg
+            cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = 0; cfg.profile = 1; cfg.plan = 0; cfg.samples_per_launch = int(cfg.spp)
+            device.check(device.L.mi_set_stream(device.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            ms = []
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                device.check(device.L.mi_render(device.ctx, C.byref(cfg), C.c_void_p(film.data_ptr())))
+                torch.cuda.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+            c = device.counters()
+            out[tag] = {"workload": note, "spp": spp, "value": 1920.0 * 1080 * spp / (ms[-1] * 1e-3) / 1e6, "unit": "Msamples/sec",
+                        "ms_per_frame": ms[-1], "ms_first_frame": ms[0], "ms_path_kernel": c.ms_path, "ms_film": c.ms_resolve,
+                        "samples": int(c.samples), "segments_per_sample": c.segments / max(c.samples, 1),
+                        "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident",
+                        "log_bytes": int(c.log_bytes),
+                        "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris}}
+        finally:
+            device.close()
 
     try:
-        scene, sensor = scenes.cornell_box(1920, 1080, 64, diffuse_only=False, device=-1)
-        timed("c3_matball_64spp", dev, scene, sensor, 64, "BASELINE configs[2] geometry (GGX conductor + bk7 dielectric balls, 40 972 triangles), 1920x1080 @ 64 of its 1024 spp")
-        scene, sensor = scenes.interior_scene(1920, 1080, 16, device=-1)
-        timed("c4_interior_16spp", dev, scene, sensor, 16, "BASELINE configs[3] class (911 362 triangles, area light + 1024x512 environment map), 1920x1080 @ 16 of its 2048 spp")
+        scene, sensor = scenes.cornell_box(1920, 1080, 1024, diffuse_only=False, device=-1)
+        timed("c3_matball_1024spp", scene, sensor, 1024, "BASELINE configs[2] (GGX conductor + bk7 dielectric balls, 40 972 triangles), 1920x1080 @ its 1024 spp")
+        scene, sensor = scenes.interior_scene(1920, 1080, 2048, device=-1)
+        timed("c4_interior_2048spp", scene, sensor, 2048, "BASELINE configs[3] class (911 362 triangles, area light + 1024x512 environment map), 1920x1080 @ its 2048 spp, one GPU")
         if os.path.exists(api.default_srgb_coeff()):
             api.set_variant("scalar_spectral"); api.set_srgb_model(api.default_srgb_coeff())
             try:
-                scene, sensor = scenes.cornell_box(1920, 1080, 64, diffuse_only=True, glass_block=True, device=-1)
-                sdev = api.Device(0)                 # world == 1: the benchmark runs on GPU 0
-                timed("c5_spectral_glassblock_64spp", sdev, scene, sensor, 64, "BASELINE configs[4] (scalar_spectral Cornell box with a bk7 dielectric block), 1920x1080 @ 64 of its 512 spp")
-                sdev.close()
+                scene, sensor = scenes.cornell_box(1920, 1080, 512, diffuse_only=True, glass_block=True, device=-1)
+                timed("c5_spectral_glassblock_512spp", scene, sensor, 512, "BASELINE configs[4] (scalar_spectral Cornell box with a bk7 dielectric block), 1920x1080 @ its 512 spp")
             finally:
                 api.set_variant("scalar_rgb")
     except Exception as e:                    # the headline line must not die with an extra
         out["error"] = repr(e)[:300]
     return out
+
+
+def spawn_command(n, argv, port=None):
+    """`python bench.py --gpus N` without a launcher around it: the command line that runs this file as N ranks of one node
+    (torch.distributed.run, rendezvous on 127.0.0.1 — the container hostname may not resolve), same arguments."""
+    import socket
+    if port is None:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MIW_BENCH_SPAWNED="1")
+    return subprocess.call(spawn_command(n, argv), env=env)
+
+
+def reduce_label(backend):
+    return {"nccl": "RCCL", "gloo": "gloo (host)"}.get(backend, backend)
 
 
 def main():
@@ -237,6 +262,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank path on a box with fewer GPUs than ranks, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--dry-ranks", action="store_true", help="testing only (CPU tier): every rank joins the process group, takes part in one "
+                    "all-reduce and rank 0 prints {n_gpus, ranks_seen}; nothing is rendered")
     ap.add_argument("--shard-of", type=int, default=0, help="testing only (N = 1): render shard 0 of this many — what one rank "
                     "of an N-GPU run executes; `value` then counts only that shard's samples")
     ap.add_argument("--no-profile", action="store_true")
@@ -265,17 +292,35 @@ def main():
                     help="resident plan: samples each pixel advances per launch (-1 = all spp in one launch, 0 = library default)")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    from mitsuba2_amd import api, scenes, _capi
-
+    # N ranks: under a launcher (the driver's torch.distributed.run: WORLD_SIZE is set) this process is one of them; alone with
+    # --gpus N > 1 it becomes the launcher of N ranks of itself
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's rank count is what runs (n_gpus = %d)" % (args.gpus, world, world), file=sys.stderr)
+
+    import torch
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if args.dry_ranks:
+        seen = 1
+        if world > 1:
+            t = torch.ones(1, dtype=torch.int64)
+            if args.backend == "nccl":
+                torch.cuda.set_device(0 if args.share_gpu else local_rank); t = t.cuda()
+            dist.all_reduce(t); seen = int(t.item())
+            dist.barrier(); dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": seen, "backend": args.backend if world > 1 else None,
+                              "reduce": reduce_label(args.backend) if world > 1 else None}), flush=True)
+        return
+    import numpy as np
+    from mitsuba2_amd import api, scenes, _capi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mitsuba2_amd has no CPU fallback")
     if args.share_gpu:
@@ -356,7 +401,8 @@ def main():
             total_samples = float(agg["samples"])
         value = total_samples / elapsed / 1e6
         s_bar = agg["segments"] / max(agg["samples"], 1)
-        pk = dev.counters().path_kernel
+        hc = dev.counters()                      # the headline frames' counters (nothing rendered after them may leak into the line)
+        pk = hc.path_kernel
         path_kernel = "k_path_phased" if pk in (1, 3) else "k_path_resident"
         tc_name, ta_name = ("k_trace_stream", "k_sort_hits") if pk == 2 else ("k_trace<closest>", "k_trace<any>")
         # dominant kernel by summed HIP-event time (rank 0's shard)
@@ -369,7 +415,7 @@ def main():
             path_kernel: (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
             # ordered film replay: reads the sample log once per texel group, writes the block tiles (k_film_groups over the 16-byte
             # class records, k_film_blocks over the 24-byte position log of filters without phase classes)
-            ("k_film_groups" if dev.counters().log_record_bytes == 16 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], float(dev.counters().log_record_bytes) * agg["samples"]),
+            ("k_film_groups" if hc.log_record_bytes == 16 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], float(hc.log_record_bytes) * agg["samples"]),
         }
         roofline = None
         if not args.no_profile and (agg["n_shade"] or agg["n_path"]):
@@ -391,8 +437,8 @@ def main():
                     source = "live: 4 rocprofv3 --pmc passes over one frame of this workload, in this run"
             if entry is None:
                 try:
-                    key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, dev.counters().plan,
-                                                                     dev.counters().film_mode, cfg.samples_per_launch)
+                    key = "%s/%s/%dx%d@%d/plan%d/film%d/launch%d" % (args.variant, args.scene, W, H, SPP, hc.plan,
+                                                                     hc.film_mode, cfg.samples_per_launch)
                     table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                     if world == 1 and table.get(key, {}).get("kernel_src_sha16") == kernel_src_sha16():
                         entry = table.get(key, {}).get(name)
@@ -412,7 +458,7 @@ def main():
             # achieved / peak / frac stay the yardstick north_star decrees (ALGORITHMIC queue + splat bytes of SURVEY.md 8d
             # over the kernel time against 8 TB/s) — a path-tracing kernel that keeps its state in registers moves a few
             # per cent of those bytes for real (`traffic`), so that fraction is a throughput scale, not a bandwidth claim.
-            bound, bound_frac = "hbm", None
+            bound, bound_frac = None, None          # unmeasured (no PMC counters for this run): say so rather than guess
             if measured and measured.get("valu_issue_frac") is not None and measured.get("lane_use") is not None:
                 valu = measured["valu_issue_frac"] * measured["lane_use"]
                 bound, bound_frac = ("valu", valu) if valu >= measured["hbm_measured_frac"] else ("hbm", measured["hbm_measured_frac"])
@@ -424,7 +470,7 @@ def main():
                 "launches": n, "avg_launch_ms": ms / max(n, 1), "alg_bytes_per_launch": alg_bytes / max(n, 1),
                 "kernel_ms": dict({k: round(v[0], 3) for k, v in kernels.items() if v[1]},
                                   k_film_merge=round(agg["ms_fm"], 3), k_init=round(agg["ms_init"], 3)),
-                "log_bytes": dev.counters().log_bytes, "log_record_bytes": dev.counters().log_record_bytes,
+                "log_bytes": hc.log_bytes, "log_record_bytes": hc.log_record_bytes,
                 "segments_per_sample": s_bar,
                 "pipeline_alg_bytes_per_sample": b_alg,
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),
@@ -438,7 +484,7 @@ def main():
         extras = None
         if (not args.no_extras and world == 1 and args.scene == "cornell" and args.variant == "scalar_rgb" and args.shard_of <= 1
                 and args.integrator == "path" and (W, H, SPP) == (1920, 1080, 512)):
-            extras = run_extras(api, scenes, dev, film, C)
+            extras = run_extras(api, scenes, film, C)
         out = {
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -456,11 +502,11 @@ def main():
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
                        "bvh": {"builder": "device LBVH" if bvh.bvh_on_device else "host binned SAH", "build_ms": round(bvh.ms_bvh_build, 3),
                                "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
-                       "parallelism": ("%s-shard x%d + RCCL film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world)) if world > 1 else "single GPU",
+                       "parallelism": ("%s-shard x%d + %s film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world, reduce_label(args.backend))) if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage" + (" (persistent stream walk kernel with dynamic ray fetch)" if pk == 2 else ""), 2: "resident: path state in registers, geometry in LDS"
                                 if path_kernel == "k_path_resident" else "resident, wave-level phase machine: path + walk state in registers, "
-                                "per-lane LDS stack, nodes / triangles through L1 / L2"}[dev.counters().plan],
-                       "film": {1: "sample log (%d B per sample) + ordered float32 gather (bit-identical to scalar_rgb order)" % dev.counters().log_record_bytes, 2: "float64 atomics"}[dev.counters().film_mode]},
+                                "per-lane LDS stack, nodes / triangles through L1 / L2"}[hc.plan],
+                       "film": {1: "sample log (%d B per sample) + ordered float32 gather (bit-identical to scalar_rgb order)" % hc.log_record_bytes, 2: "float64 atomics"}[hc.film_mode]},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         if args.integrator == "direct":

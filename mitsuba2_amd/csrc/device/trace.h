@@ -16,6 +16,9 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
     uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
+    // k_path_phased's class-batched shade vote: shade-ready lanes of shade class c (bsdf.h: 1 = delta lobes, 2 = microfacet) join a
+    // shade run only once cls_min[c - 1] of them wait in the wavefront, or after cls_skip runs went by without them (0 / 1: always)
+    uint32_t cls_min1, cls_min2, cls_skip;
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
@@ -29,6 +32,13 @@ static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
 static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 
+#ifndef MIW_MERGED_CANDIDATES
+#define MIW_MERGED_CANDIDATES 0     /* 1: trace2 pops the E and the S candidates of a lane in ONE loop (A/B builds) */
+#endif
+#ifndef MIW_OCTANT_BOXES
+#define MIW_OCTANT_BOXES 1          /* 1: the leaf boxes of a tiny scene are staged once per ray octant, entry / exit plane of every axis side by side (leaf_box_test_octant); 0: one copy, min / max per axis */
+#endif
+#define MIW_LEAF_BOX_COPIES (MIW_OCTANT_BOXES ? 8u : 1u)
 __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
     if (cfg.brute) {
         TriPacket *dst = reinterpret_cast<TriPacket *>(smem);
@@ -43,9 +53,24 @@ __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, 
         // leaf boxes of the SAH tree behind the packets (k_path_resident's candidate filter)
         uint4 *dst_b = smem + sc.tri_count * (sizeof(TriPacket) / 16);
         const uint4 *src_b = reinterpret_cast<const uint4 *>(sc.leaf_boxes);
+#if MIW_OCTANT_BOXES
+        // eight copies per leaf, one per ray octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, copy o at slot 8 * leaf + o: per
+        // axis the plane the ray ENTERS through first, then the one it leaves through. A lane reads the copy of its ray's octant —
+        // eight different 32-byte slots of one 256-byte row: every LDS bank once, no conflict.
+        for (uint32_t i = threadIdx.x; i < cfg.leaves * 8u; i += blockDim.x) {
+            const LeafBox b = reinterpret_cast<const LeafBox *>(sc.leaf_boxes)[i >> 3];
+            const uint32_t o = i & 7u;
+            LeafBox k;
+            for (int a = 0; a < 3; ++a) { const bool neg = (o >> a) & 1u; k.p[2 * a] = b.p[2 * a + (neg ? 1 : 0)]; k.p[2 * a + 1] = b.p[2 * a + (neg ? 0 : 1)]; }
+            k.mask_lo = b.mask_lo; k.mask_hi = b.mask_hi;
+            reinterpret_cast<LeafBox *>(dst_b)[i] = k;
+        }
+        (void) src_b;
+#else
         for (uint32_t i = threadIdx.x; i < cfg.leaves * (sizeof(LeafBox) / 16); i += blockDim.x) dst_b[i] = src_b[i];
+#endif
         // per-packet vertex bounds grown by accept_pad (shape.h: the accept rule), 24 B each, behind the boxes
-        float *dst_t = reinterpret_cast<float *>(dst_b + cfg.leaves * (sizeof(LeafBox) / 16));
+        float *dst_t = reinterpret_cast<float *>(dst_b + cfg.leaves * MIW_LEAF_BOX_COPIES * (sizeof(LeafBox) / 16));
         const float *src_t = reinterpret_cast<const float *>(sc.tri_bounds);
         for (uint32_t i = threadIdx.x; i < sc.tri_count * 6u; i += blockDim.x) dst_t[i] = src_t[i];
         __syncthreads();
@@ -112,6 +137,22 @@ __device__ __forceinline__ bool leaf_box_test(const LeafBox &b, const FastRay &r
     float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
     tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
     return tn <= tf && tn <= tmax_wide;
+}
+// The same test on the copy of a LeafBox staged for the ray's octant (stage_to_lds): p = entry.x exit.x entry.y exit.y entry.z exit.z,
+// so the packed fma of an axis yields (entry distance, exit distance) and the six min / max of the test above fall away. t(plane) =
+// fma(plane, inv_d, -o * inv_d) is monotone in the plane with the sign of inv_d, so these ARE the minima / maxima of the other form.
+__device__ __forceinline__ bool leaf_box_test_octant(const LeafBox &b, const FastRay &r, float tmax_wide) {
+    const miw_f2 px = { b.p[0], b.p[1] }, py = { b.p[2], b.p[3] }, pz = { b.p[4], b.p[5] };
+    const miw_f2 tx = __builtin_elementwise_fma(px, (miw_f2) { r.inv_d.x, r.inv_d.x }, (miw_f2) { r.neg_o_inv_d.x, r.neg_o_inv_d.x }),
+                 ty = __builtin_elementwise_fma(py, (miw_f2) { r.inv_d.y, r.inv_d.y }, (miw_f2) { r.neg_o_inv_d.y, r.neg_o_inv_d.y }),
+                 tz = __builtin_elementwise_fma(pz, (miw_f2) { r.inv_d.z, r.inv_d.z }, (miw_f2) { r.neg_o_inv_d.z, r.neg_o_inv_d.z });
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), __builtin_fmaxf(tz.x, r.mint));
+    float tf = __builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y);
+    tf = __builtin_fmaf(abs_(tf), 2e-6f, tf);
+    return tn <= tf && tn <= tmax_wide;
+}
+__device__ __forceinline__ uint32_t ray_octant(const FastRay &r) {
+    return (r.inv_d.x < 0.f ? 1u : 0u) | (r.inv_d.y < 0.f ? 2u : 0u) | (r.inv_d.z < 0.f ? 4u : 0u);
 }
 __device__ __forceinline__ float widen(float t) { return __builtin_fmaf(abs_(t), 2e-6f, t); }
 
@@ -259,7 +300,7 @@ __device__ __forceinline__ bool bvh_intersect_ww(NodeAt node_at, TriAt tri_at, i
 
 // per-packet vertex bounds of a tiny scene, staged behind the leaf boxes (stage_to_lds)
 __device__ __forceinline__ const TriBounds *packet_bounds(const SceneView &sc, TraceLds cfg, const uint4 *smem) {
-    return reinterpret_cast<const TriBounds *>(smem + sc.tri_count * (sizeof(TriPacket) / 16) + cfg.leaves * (sizeof(LeafBox) / 16));
+    return reinterpret_cast<const TriBounds *>(smem + sc.tri_count * (sizeof(TriPacket) / 16) + cfg.leaves * MIW_LEAF_BOX_COPIES * (sizeof(LeafBox) / 16));
 }
 // Tiny scenes without a candidate filter: every lane sweeps every packet — wave-uniform LDS addresses
 // (broadcast reads, no bank conflicts), no divergence. Same accept rule as bvh.h: min t, ties -> smaller prim id.
@@ -350,15 +391,45 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         const FastRay rE = fast_ray(o, dE, mint), rS = fast_ray(o, dS, mint);
         const float wideE = widen(maxtE), wideS = widen(maxtS);
         Mask mE = 0, mS = 0;
+#if MIW_OCTANT_BOXES
+        const LeafBox *lbE = lb + ray_octant(rE), *lbS = lb + ray_octant(rS);   // each ray reads the copies of its own octant
+        for (uint32_t i = 0; i < cfg.leaves; ++i) {
+            const LeafBox &bE = lbE[8u * i], &bS = lbS[8u * i];
+            const Mask bits = Tiny == 2 ? (Mask) bE.mask_lo : (Mask) (bE.mask_lo | ((unsigned long long) bE.mask_hi << 32));
+            if (leaf_box_test_octant(bE, rE, wideE)) mE |= bits;
+            if (leaf_box_test_octant(bS, rS, wideS)) mS |= bits;
+        }
+#else
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
             const Mask bits = Tiny == 2 ? (Mask) b.mask_lo : (Mask) (b.mask_lo | ((unsigned long long) b.mask_hi << 32));
             if (leaf_box_test(b, rE, wideE)) mE |= bits;
             if (leaf_box_test(b, rS, wideS)) mS |= bits;
         }
+#endif
         if (!hasE) mE = 0;
         if (!hasS) mS = 0;
         MIW_SECTION(1);
+        uint32_t s_tri = 0; float s_t = 0.f;
+#if MIW_MERGED_CANDIDATES
+        // ONE candidate loop: a lane pops its E candidates, then its S candidates — the wavefront iterates max over lanes of
+        // (nE + nS) times instead of max(nE) + max(nS) (the sum of two counts spreads less than either); a trip costs a dozen
+        // selects more (direction, maxt, which result it updates). Same tests in the same per-lane order: same result.
+        while ((mE | mS) != 0) {
+            const bool isE = mE != 0;
+            const Mask m = isE ? mE : mS;
+            const uint32_t i = lowest(m);
+            mE = isE ? (mE & (mE - 1)) : mE; mS = isE ? mS : (mS & (mS - 1));
+            const V3 d = v3(isE ? dE.x : dS.x, isE ? dE.y : dS.y, isE ? dE.z : dS.z);
+            const TriPacket &k = pk[i];
+            float t, u, v;
+            const bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, isE ? maxtE : maxtS, t, u, v);
+            const bool take = isE & hit && (t < h.t || (t == h.t && k.prim < h.prim));
+            h.t = take ? t : h.t; h.u = take ? u : h.u; h.v = take ? v : h.v; h.tri = take ? i : h.tri; h.prim = take ? k.prim : h.prim;
+            const bool stop = !isE & hit;                      // any hit ends the shadow query
+            occ = occ | stop; mS = stop ? (Mask) 0 : mS; s_tri = stop ? i : s_tri; s_t = stop ? t : s_t;
+        }
+#else
         while (mE != 0) {                                      // closest hit of E over its candidates
             const uint32_t i = lowest(mE);
             mE &= mE - 1;
@@ -368,7 +439,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
         }
         MIW_SECTION(2);
-        uint32_t s_tri = 0; float s_t = 0.f;
         while (mS != 0) {                                      // any hit of S
             const uint32_t i = lowest(mS);
             mS &= mS - 1;
@@ -378,6 +448,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 occ = true; mS = 0; s_tri = i; s_t = t;
             }
         }
+#endif
         // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
         // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
         // through the full sweep with the rule inside, which is what the rule means.

@@ -146,7 +146,7 @@ struct mi_ctx {
     DevBuf<double> d_accum; DevBuf<unsigned char> d_out;
     DevBuf<F2> q_log_pos; DevBuf<F4> q_log_val;         // 24-byte sample log (filters without phase classes)
     DevBuf<U4> q_log_rec;                               // 16-byte sample log (miw/film.h: phase classes)
-    FilmClasses classes; FilmRec classes_of{};          // the class tables of the last filter rendered with, and that filter
+    FilmClasses classes; FilmRec classes_of{}; bool classes_valid = false;   // the class tables of the last filter rendered with (ok or refused), and that filter
     DevBuf<float> d_fc_thr, d_fc_w;
     DevBuf<uint32_t> d_next_pixel; int cu_count = 256;
     DevBuf<uint32_t> d_piece_cost, d_piece_list, d_simd_ids;   // placed pixel queues of small shards (resident_kernel.h: QueueWork)
@@ -328,6 +328,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         }
         c->bsdfs[i] = r;
     }
+    // the shade class of every triangle's BSDF rides in the top bits of Tri::pad (shape.h; the phase machine's shade vote batches by it)
+    for (Tri &t : c->tris_in) t.pad = tri_analytic(t) | (bsdf_shade_class(c->bsdfs[c->shapes[t.shape].bsdf].type) << MIW_TRI_CLASS_SHIFT);
     c->diffuse_only = true;
     for (const BsdfRec &r : c->bsdfs) if (r.type != BSDF_TYPE_DIFFUSE || (r.flags & BSDF_REC_TWOSIDED)) c->diffuse_only = false;
     if (!c->tri_uv_in.empty()) c->diffuse_only = false;          // texture coordinates steer the shading frame (mesh.cpp:492-511)
@@ -594,7 +596,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         HIP_TRY(c, c->d_tri_bounds.upload(bounds, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         v.tri_bounds = c->d_tri_bounds.p;
-        c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * sizeof(LeafBox) + v.tri_count * sizeof(TriBounds);
+        c->lds_bytes = v.tri_count * sizeof(TriPacket) + leaves.size() * MIW_LEAF_BOX_COPIES * sizeof(LeafBox) + v.tri_count * sizeof(TriBounds);   // (trace.h: stage_to_lds)
     } else {
         // A whole tree that fits 16 KiB could be walked out of LDS with the stackless trail walk; measured (r02 triangle-count
         // series: 172 triangles, 375 Msamples/s that way against 850 with the LDS-stack walk of the phase machine, whose
@@ -623,7 +625,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 r.nodes.resize(node_count);
                 HIP_TRY(c, hipMemcpy(r.nodes.data(), c->d_nodes.p, (size_t) node_count * sizeof(BvhNode), hipMemcpyDeviceToHost));
             }
-            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, max_fan);   // one entry of slack: the node body's unconditional stores
+            Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, max_fan);   // one entry of slack: the node body's unconditional stores
+            if (const char *e = getenv("MIW_BVH4_ORDER")) if (atoi(e) == 1) bvh4_reorder_depth_first(b4);   // A/B: depth-first node order
             if (b4.ok) {
                 HIP_TRY(c, c->d_nodes4.upload(b4.nodes, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -857,10 +860,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
     bool rec16 = false;
     if (film_mode != 2 && bs2 <= 65536u && !getenv("MIW_FILM_LEGACY")) {
-        FilmRec key = P.film; key.crop_w = key.crop_h = key.crop_x = key.crop_y = key.block_size = 0; key.warn_negative = 0;
-        if (!c->classes.ok || memcmp(&key, &c->classes_of, sizeof key) != 0 || !c->d_fc_thr.p) {
+        // the cache key: the filter's fields only, in a zero-filled record (padding bytes of a stack copy would make memcmp miss)
+        FilmRec key; memset(&key, 0, sizeof key);
+        key.border = P.film.border; key.radius = P.film.radius; key.scale_factor = P.film.scale_factor; memcpy(key.lut, P.film.lut, sizeof key.lut);
+        // (a filter the enumeration refuses is remembered as well — classes_valid — instead of being enumerated again by every render)
+        if (!c->classes_valid || memcmp(&key, &c->classes_of, sizeof key) != 0 || (c->classes.ok && !c->d_fc_thr.p)) {
             c->classes = film_classes_build(P.film);             // ~30 ms, once per filter
-            c->classes_of = key;
+            c->classes_of = key; c->classes_valid = true;
             if (c->classes.ok) { HIP_TRY(c, c->d_fc_thr.upload(c->classes.thr, s)); HIP_TRY(c, c->d_fc_w.upload(c->classes.w, s)); HIP_TRY(c, hipStreamSynchronize(s)); }
         }
         rec16 = c->classes.ok;
@@ -986,8 +992,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // (packet kernels only — QueueWork<Placed> — and only where every pixel of the shard can be resident at once: 4 wavefronts per SIMD
         // for the plain-diffuse packet kernel, 3 for the others — a shard larger than that is balanced by the queue itself)
         const uint32_t res_waves = c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u;
+        // (n_lanes % 64: a partial last piece would let its missing lanes read "queue dry" while the queue still holds pieces — QueueWork::fetch)
         bool place = film_mode == 1 && !direct && c->lds_cfg.brute && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
-                     cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
+                     n_lanes % 64u == 0u && cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = getenv("MIW_PLACE")) place = place && atoi(e) != 0;
         uint32_t measure_div = 8u;                                 // the measuring launch runs spp / 8 samples (MIW_PLACE_MEASURE = divisor)
         if (const char *e = getenv("MIW_PLACE_MEASURE")) measure_div = (uint32_t) std::max(2, atoi(e));
@@ -1097,6 +1104,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
+                // the class-batched shade vote (phased_kernel.h): lanes whose hit needs the delta-lobe / microfacet code wait until this many
+                // of their class are ready in the wavefront, at most `skip` shade runs. MIW_CLASS_BATCH=min1:min2:skip overrides (1:1:0 = off).
+                ph_cfg.cls_min1 = 6; ph_cfg.cls_min2 = 8; ph_cfg.cls_skip = 4;
+                if (const char *e = getenv("MIW_CLASS_BATCH")) { int a = 0, b = 0, k = 0; if (sscanf(e, "%d:%d:%d", &a, &b, &k) == 3 && a > 0 && b > 0 && k >= 0) { ph_cfg.cls_min1 = (uint32_t) a; ph_cfg.cls_min2 = (uint32_t) b; ph_cfg.cls_skip = (uint32_t) k; } }
 #define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); \
                                      else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); } while (0)
                 if (phased) {

@@ -32,6 +32,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -332,7 +334,10 @@ OHit accel_query(const OScene &sc, const Ray &ray) {
         // nearer child last onto the stack (it is popped first): shrinks best.t early; the order does not change the answer
         double ln, lf, rn, rf;
         const bool hl = accel_slab(A.nodes[nd.left], o, d, ln, lf), hr = accel_slab(A.nodes[nd.right], o, d, rn, rf);
-        if (sp + 2 > 128) return OHit{ false, -1.f, 0.f, 0.f, 0xfffffffeu };   // cannot happen (median splits: depth <= 32); loud if it does
+        if (sp + 2 > 128) {                                            // cannot happen (median splits: depth <= 32); a checker must not answer "miss" if it does
+            fprintf(stderr, "[miw_oracle] accel_query: traversal stack overflow (index deeper than 128 entries) - aborting, no golden answer may come from this run\n");
+            abort();
+        }
         if (hl && hr && ln < rn) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
         else { if (hl) stack[sp++] = nd.left; if (hr) stack[sp++] = nd.right; }
     }

@@ -1,0 +1,50 @@
+"""bench.py's N-rank path without a launcher around it: `python bench.py --gpus N` must become N ranks.
+
+CPU tier: `--dry-ranks` makes every rank join the process group (gloo here), take part in one all-reduce and rank 0 print
+what it saw — the same self-spawn, rendezvous and rank bookkeeping the GPU run goes through, with nothing rendered."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE json line, from rank 0
+    return json.loads(lines[0]), r.stderr
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    j, _ = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--dry-ranks"])
+    assert j == {"n_gpus": 2, "ranks_seen": 2, "backend": "gloo", "reduce": "gloo (host)"}
+
+
+def test_one_gpu_is_one_process():
+    j, _ = _run(["--gpus", "1", "--dry-ranks"])
+    assert j["n_gpus"] == 1 and j["ranks_seen"] == 1 and j["reduce"] is None
+
+
+def test_under_a_launcher_the_launchers_rank_count_runs():
+    """the driver's form: torch.distributed.run around bench.py --gpus N — no second spawn, n_gpus = WORLD_SIZE"""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(2, ["--gpus", "2", "--backend", "gloo", "--dry-ranks"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "127.0.0.1" in cmd and cmd.count("--gpus") == 1
+    e = dict(os.environ); e.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_reduce_is_labelled_by_the_backend_in_use():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.reduce_label("nccl") == "RCCL" and "gloo" in bench.reduce_label("gloo")

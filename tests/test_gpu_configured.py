@@ -13,6 +13,8 @@ digests of the float32 film + sample / segment counts. Here the device renders t
       into the environment map next to the red wall; conductor / dielectric / diffuse clutter lit through the open ceiling),
       and the FULL 1080p frame at 2048 spp — 4.25e9 samples, a 68 GB sample log — whose two centre-most blocks must carry the
       oracle's texels
+  C5  the scalar_spectral glass-block box, the FULL 1920x1080 @ 512 spp frame (round 4: tests/golden/round4.json,
+      make_golden_r4.py — 1.06e9 samples of 4 wavelengths each, the oracle's film digest + 27 band digests + counts)
   fuzz  sixty recipes of tools/fuzz_cpu.py (random rooms, every plugin, both tree builders, both plans)
 """
 import hashlib
@@ -28,6 +30,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "round3.json")))
+GOLD4 = json.load(open(os.path.join(ROOT, "tests", "golden", "round4.json")))
 W, H = 1920, 1080
 
 
@@ -64,6 +67,23 @@ def test_c2_full_frame_is_the_oracles(native):
     finally:
         del os.environ["MIW_FILM_LEGACY"]
     assert st == 0 and dev.counters().log_record_bytes == 24 and np.array_equal(legacy, film)
+    dev.close()
+
+
+def test_c5_full_frame_is_the_oracles(spectral):
+    """BASELINE config 5 as configured: scalar_spectral, Cornell box with a bk7 dielectric block, all 2 073 600 pixels x 512 samples
+    (include/mitsuba/core/spectrum.h:148-314 on top of integrator.cpp:181-288 — wavelength sampling, sRGB upsampling, CIE matching)"""
+    from mitsuba2_amd import scenes
+    rec = GOLD4["c5_full_1920x1080_512spp_spectral"]
+    scene, sensor = scenes.cornell_box(W, H, 512, diffuse_only=True, glass_block=True, device=-1)
+    dev = spectral.Device(0)
+    dev.upload(scene.desc())
+    film, st = dev.render(spectral.PathIntegrator().render_job(sensor))
+    c = dev.counters()
+    assert st == 0 and c.plan == 2 and c.film_mode == 1 and c.log_record_bytes == 16
+    assert (c.samples, c.segments) == (rec["samples"], rec["segments"]) and c.samples == W * H * 512
+    assert 0 < c.shadow_rays <= rec["shadow_rays"]           # the device skips shadow rays that carry a zero contribution
+    _assert_film(film, rec, "C5 scalar_spectral 1920x1080 @ 512 spp")
     dev.close()
 
 
