@@ -268,7 +268,7 @@ typedef struct {
     double ms_path;            /* plan 2: HIP-event time of the k_path_resident launches  */
     uint64_t n_path;
     double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
-    uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran the device LBVH builder    */
+    uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran a device builder (bvh_builder says which) */
     uint32_t path_kernel;      /* last render. plan 2: 0 = k_path_resident (lock-step lanes: packet scenes, direct integrator,
                                   float64 film, trees the 4-wide collapse refuses), 1 = k_path_phased (wave-level phase machine over the 4-wide
                                   quantised tree, per-lane LDS stack), 3 = k_path_phased over the BVH2 (MIW_BVH4=0, A/B switch).
@@ -281,7 +281,8 @@ typedef struct {
     double ms_bvh4;            /* part of ms_bvh_build spent producing the 4-wide tree                                               */
     uint32_t placed;           /* 1: the last render ran a measuring launch + a launch with per-SIMD pixel queues (a shard of at most
                                   one pixel per resident lane: what one rank of an N-GPU frame renders at N >= 8)                     */
-    uint32_t pad_;
+    uint32_t bvh_builder;      /* the last mi_bvh_build: 0 = host binned SAH (quality 1), 1 = device LBVH (radix tree), 2 = device PLOC
+                                  (Morton order + surface-area clustering: quality 0 since round 4)                                   */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */
@@ -301,8 +302,9 @@ mi_status mi_set_stream(mi_ctx *ctx, void *hip_stream);
  * (Mesh::build_pmf, src/librender/mesh.cpp:285-312) */
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 /* Scene::accel_init_cpu (src/librender/scene_native.inl:3-10): build the BVH.
- * quality 0 = LBVH built on the device (Morton sort + Karras radix tree + bottom-up fit),
- * 1 = binned SAH built on the host (better trees; the default of the host layer).
+ * quality 0 = built on the device: PLOC (csrc/ploc_device.h: Morton sort + rounds of surface-area clustering; the radix-tree
+ * LBVH of csrc/lbvh_device.h with MIW_DEVICE_BUILDER=lbvh), collapsed on the device into the 4-wide tree the render kernels walk;
+ * 1 = binned SAH built on the host (the default of the host layer).
  * Scenes of <= 64 triangles are traced by a brute-force sweep over LDS-resident
  * triangle packets instead of the tree; OR in MI_BVH_FORCE_TREE to walk the tree
  * anyway (tests). */

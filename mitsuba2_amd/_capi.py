@@ -122,7 +122,7 @@ class mi_counters(C.Structure):
                 ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double),
                 ("bvh_on_device", C.c_uint32), ("path_kernel", C.c_uint32), ("ms_film_pack", C.c_double),
                 ("log_bytes", C.c_uint64), ("log_record_bytes", C.c_uint32), ("bvh4_on_device", C.c_uint32), ("ms_bvh4", C.c_double),
-                ("placed", C.c_uint32), ("pad_", C.c_uint32)]
+                ("placed", C.c_uint32), ("bvh_builder", C.c_uint32)]
 
 
 MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1

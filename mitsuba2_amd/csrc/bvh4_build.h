@@ -171,29 +171,4 @@ inline Bvh4BuildResult bvh4_collapse(const std::vector<BvhNode> &n2, uint32_t st
     return out;
 }
 
-// The same tree with its nodes renumbered in depth-first preorder (children in slot order): a subtree becomes one contiguous run
-// of the array, so the lines a walk touches below a node lie together (the breadth-first order above keeps the four children of a
-// node together and everything else a level apart). Node contents are untouched; only the child references change.
-inline void bvh4_reorder_depth_first(Bvh4BuildResult &b) {
-    const size_t n = b.nodes.size();
-    if (!b.ok || n < 2) return;
-    std::vector<int32_t> new_index(n, -1), stack; std::vector<int32_t> order; order.reserve(n);
-    stack.push_back(0);
-    while (!stack.empty()) {
-        const int32_t i = stack.back(); stack.pop_back();
-        new_index[i] = (int32_t) order.size(); order.push_back(i);
-        const Bvh4Node &nd = b.nodes[i];
-        const uint32_t k = nd.exps >> 24;
-        for (uint32_t c = k; c-- > 0;) if (nd.child[c] >= 0) stack.push_back(nd.child[c]);
-    }
-    std::vector<Bvh4Node> out(n);
-    for (size_t j = 0; j < order.size(); ++j) {
-        Bvh4Node nd = b.nodes[order[j]];
-        const uint32_t k = nd.exps >> 24;
-        for (uint32_t c = 0; c < k; ++c) if (nd.child[c] >= 0) nd.child[c] = new_index[nd.child[c]];
-        out[j] = nd;
-    }
-    b.nodes.swap(out);
-}
-
 } // namespace miw

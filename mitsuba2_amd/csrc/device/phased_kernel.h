@@ -39,12 +39,6 @@ struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](in
 #ifndef MIW_TRI_PAIR
 #define MIW_TRI_PAIR 1              /* 1: the triangle body tests two triangles of a leaf range per iteration (both fetched up front: +2 - 4 %); 0: one */
 #endif
-#ifndef MIW_TRI_NT
-#define MIW_TRI_NT 0                /* 1: the triangle body fetches its records with non-temporal loads (A/B builds: triangles stream, nodes are re-used) */
-#endif
-#ifndef MIW_CLASS_VOTE
-#define MIW_CLASS_VOTE 1            /* 1: the shade vote batches the expensive BSDF classes (below); 0: every shade-ready lane joins every shade run */
-#endif
 #ifndef MIW_PHASE_END_WEIGHT
 #define MIW_PHASE_END_WEIGHT 4      /* the walk-end body is cheap: it runs once a quarter as many lanes wait for it as for the leading body */
 #endif
@@ -52,7 +46,10 @@ struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](in
 // spills 20 registers at 128 instead of 121: DESIGN.md section 4, "the register diet").
 // Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h (the default) instead of the BVH2 (MIW_BVH4=0:
 // instantiated for the MATS_TRIO kernels only, A/B runs).
-template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = true>
+// Placed: the pixel queue is QueueWork<true> (resident_kernel.h) — shards of about one pixel per resident lane: a measuring launch,
+// then every wavefront takes pixels of about equal cost from the queue of its SIMD. The full-frame kernel keeps Placed = false
+// and the four registers the queue choice costs.
+template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = true, bool Placed = false>
 __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -73,7 +70,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
 #endif
 
-    QueueWork<false> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+    QueueWork<Placed, true> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
     __shared__ uint32_t s_prog[MIW_BLOCK / 64];
     if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
@@ -112,19 +109,6 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     // shade once the shade-ready lanes outnumber the busier walk body num : den (host: 3 : 2, 2 : 1 with an environment map —
     // a shade run costs ~2 200 instruction slots whatever its lane count, a walk step ~100 - 200, so shade runs are worth filling)
     const int shade_num = (int) cfg.shade_num, shade_den = (int) cfg.shade_den;
-    // The class-batched vote (MIW_CLASS_VOTE). One divergent shade body serves every BSDF plugin of the scene: a run costs the sum
-    // of the code of every class PRESENT among its lanes, whatever their number — a single rough-conductor lane makes the wavefront
-    // pay for the microfacet evaluation, the visible-normal sampling and the conductor Fresnel term (about half of the run). The
-    // reference's own GPU mode evaluates each BSDF over a coherent array (integrator.cpp:140-172, path.cpp:153-178 under gpu_*).
-    // Here the class of a lane's hit (shape.h: tri_shade_class, carried in best.prim by the triangle step) is known when its walk
-    // ends, so the vote lets the lanes of an expensive class wait — walking lanes are not held up, a waiting lane only idles —
-    // until cls_min of them are ready in this wavefront (or cls_skip shade runs went by: nobody starves), and a run without
-    // them skips their code by an empty exec mask. Per-lane arithmetic and log slots are untouched: the same film.
-    // (thresholds packed into one scalar register — min1 | min2 << 8 | skip << 16 — and one skip counter for both classes: the
-    // kernel is at its SGPR limit, and a spilled scalar costs a lane read in every vote)
-    const uint32_t cls_pack = (cfg.cls_min1 & 0xffu) | ((cfg.cls_min2 & 0xffu) << 8) | ((cfg.cls_skip & 0xffu) << 16);
-    uint32_t skipped = 0;
-
     for (;;) {
         // ---- the vote: which lanes are ready for which body ----
         const bool trav = (mode - 1u) < 2u;
@@ -138,39 +122,22 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         const bool e_shade = mode == PH_SHADE || (walk_over && !e_turn);
         const int n_turn = count(e_turn);
         int n_node = count(e_node) + n_turn, n_leaf = count(e_leaf);
-        const int n_all = count(e_shade);
+        const int n_shade = count(e_shade);
         const int n_end = 0;
-        if ((n_node | n_leaf | n_all) == 0) break;
+        if ((n_node | n_leaf | n_shade) == 0) break;
         const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
-#if MIW_CLASS_VOTE
-        // which classes join the next shade run, and with how many lanes (fresh lanes, finished shadow walks of dead paths and misses
-        // run no BSDF code: class 0)
-        const uint32_t cls = (mode == PH_SHADE || dead_pending) ? 0u : best.tri >> MIW_TRI_CLASS_SHIFT;      // (a miss: 15)
-        const int n_c1 = count(e_shade && cls == 1u), n_c2 = count(e_shade && cls == 2u);
-        const bool overdue = skipped >= (cls_pack >> 16) || lead == 0;
-        const bool run1 = n_c1 >= (int) (cls_pack & 0xffu) || overdue, run2 = n_c2 >= (int) ((cls_pack >> 8) & 0xffu) || overdue;
-        const int n_shade = n_all - (run1 ? 0 : n_c1) - (run2 ? 0 : n_c2);
-        const bool e_now = e_shade && (cls == 1u ? run1 : (cls == 2u ? run2 : true));
-#else
-        const int n_shade = n_all;
-        const bool e_now = e_shade;
-#endif
 
         if (n_shade * shade_num >= lead * shade_den && n_shade > 0) {
-#if MIW_CLASS_VOTE
-            skipped = ((run1 || n_c1 == 0) && (run2 || n_c2 == 0)) ? 0u : skipped + 1u;
-#endif
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             MIW_SECTION(6);                                              // everything since the last shade body: walks + votes
             work.tick(L.sample_idx, mode != PH_OUT && !(L.flags & LF_DONE));
-            if (e_now) {
+            if (e_shade) {
                 if (!(L.flags & LF_DONE)) {
                     const V3 o = L.ray.o;
                     if (sh.has && !occluded) L.res = L.res + sh.c;          // path.cpp:171 of the previous vertex
                     sh.has = false; occluded = false;
                     int rstep = STEP_FINISHED;
-                    F4 hitE; hitE.x = best.t; hitE.y = best.u; hitE.z = best.v;                          // of the E walk (unused when dead_pending)
-                    hitE.w = u2f(MIW_CLASS_VOTE && best.tri != MIW_MISS ? best.tri & MIW_HIT_TRI_MASK : best.tri);
+                    F4 hitE; hitE.x = best.t; hitE.y = best.u; hitE.z = best.v; hitE.w = u2f(best.tri);   // of the E walk (unused when dead_pending)
                     if (!dead_pending) rstep = path_step<Mats, Analytic>(P, sc, L, hitE, [o]() { return o; }, sh, &local);
                     if (!dead_pending && rstep == STEP_DEAD_PENDING) dead_pending = true;   // one more pass for its shadow ray
                     else if (dead_pending || rstep == STEP_FINISHED) {
@@ -273,20 +240,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     const float maxt_cur = s_walk ? sh.maxt : L.ray.maxt;
 #if MIW_TRI_PAIR
                     // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
-#if MIW_TRI_NT
-                    auto tri_at = [gtris](uint32_t i) -> Tri {
-                        typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
-                        const u4v_ *p_ = reinterpret_cast<const u4v_ *>(gtris + i);
-                        const u4v_ a_ = __builtin_nontemporal_load(p_), b_ = __builtin_nontemporal_load(p_ + 1), c_ = __builtin_nontemporal_load(p_ + 2);
-                        Tri t_;
-                        t_.p0[0] = u2f(a_.x); t_.p0[1] = u2f(a_.y); t_.p0[2] = u2f(a_.z); t_.p1[0] = u2f(a_.w); t_.p1[1] = u2f(b_.x); t_.p1[2] = u2f(b_.y);
-                        t_.p2[0] = u2f(b_.z); t_.p2[1] = u2f(b_.w); t_.p2[2] = u2f(c_.x); t_.shape = c_.y; t_.prim = c_.z; t_.pad = c_.w;
-                        return t_;
-                    };
-#else
-                    auto tri_at = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
-#endif
-                    walk4_tri_step<Analytic, MIW_CLASS_VOTE != 0>(tri_at, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
+                    walk4_tri_step<Analytic>([gtris](uint32_t i) -> const Tri & { return gtris[i]; }, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
                                              mode == PH_TRAV_S, best, tmax, occluded, cur, sp, tri_i, tri_end, LdsColumn{ stack });
 #else
                     const Tri &tr = gtris[tri_i];

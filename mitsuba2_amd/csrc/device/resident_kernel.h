@@ -41,18 +41,23 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 #ifndef MIW_PLACE_PIECES
 #define MIW_PLACE_PIECES 4
 #endif
-// Placed = false (the tree kernels: placement is a packet-kernel feature, miwave.hip) compiles the queue choice, the dry-queue scan
-// and the cost clock out — four registers less carried through every body of the phase machine.
-template <bool Placed = true>
+// Placed = false (the full-frame instantiations of the tree kernels) compiles the queue choice, the dry-queue scan and the cost
+// clock out — four registers less carried through every body of the phase machine; shards of about one pixel per resident lane
+// get the Placed = true instantiation of their kernel. Clock: a pixel's cost is the time it held its lane (s_memtime, the phase
+// machine: its lanes do not iterate together) instead of the wavefront's iterations while it did (the lock-step packet kernel).
+template <bool Placed = true, bool Clock = false>
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
     // One queue over all lanes — or, for shards of at most one pixel per resident lane, PLACED queues (nq = one per SIMD of the
     // device): such a launch is one pixel deep, the priorities below make the four wavefronts of a SIMD finish together, and what
     // is left is the imbalance BETWEEN SIMDs (the sum of four random 64-pixel pieces: +-7 %, its maximum over 1024 SIMDs +24 %).
-    // So the host measures every piece's cost in a first short launch (Q->piece_cost: iterations per piece over the first
-    // eighth of the samples), deals the pieces to the SIMDs longest-first (Q->piece_list: four pieces per queue, equal sums)
-    // and the second launch lets a wavefront take its pixels from the queue of the SIMD it runs on: HW_ID / XCC_ID name the
+    // So a first short launch measures what every PIXEL costs (Q->lane_cost: over the first eighth of the samples), the device
+    // sorts the lanes by it (Q->lane_sorted) and cuts the sorted list into pieces of 64 — consecutive entries (the pixels of a
+    // wavefront cost about the same and finish together) or every pieces-th entry (every wavefront gets its share of the dear
+    // pixels; LaneQueues::piece_a / piece_b, chosen by mi_render) — round 3 dealt the pieces of the image as they lay — the host
+    // deals the pieces to the SIMDs longest-first (Q->piece_list: four pieces per
+    // queue, equal sums) and the second launch lets a wavefront take its pixels from the queue of the SIMD it runs on: HW_ID / XCC_ID name the
     // SIMD (Q->simd_ids: marked present by the measuring launch, numbered by the host). A lane whose queue has run dry moves
     // on to the next one (per lane: `q`, `dry`), so no piece can be left behind; the first lane that has found every queue
     // empty raises a flag (simd_ids[0]) that spares the others the scan.
@@ -133,22 +138,26 @@ struct QueueWork {
             // rank among the asking lanes: v_mbcnt counts the ballot's bits below this lane (no 64-bit lane mask kept in registers)
             const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u));
             uint32_t l = idx;
-            if (nq > 1u) {                                      // placed queues: queue q = up to MIW_PLACE_PIECES pieces of 64 lanes
+            if (nq > 1u) {                                      // placed queues: queue q = up to MIW_PLACE_PIECES pieces of 64 sorted lanes
                 const uint32_t piece = idx < per ? Q->piece_list[q * MIW_PLACE_PIECES + (idx >> 6)] : 0xffffffffu;
-                l = piece == 0xffffffffu ? 0xffffffffu : piece * 64u + (idx & 63u);
-            }
-            if (l >= n_lanes) { q = q + 1u == nq ? 0u : q + 1u; ++dry; continue; }   // this queue is empty: on to the next
+                if (piece == 0xffffffffu) { q = q + 1u == nq ? 0u : q + 1u; ++dry; continue; }   // this queue is empty: on to the next
+                l = Q->lane_sorted[piece * Q->piece_a + (idx & 63u) * Q->piece_b];
+                if (l >= n_lanes) continue;                     // a slot past the end of the partial last piece: ask the same queue again
+            } else if (l >= n_lanes) { ++dry; continue; }
             lane = l;
             st = Q->st[lane];
             if (st.z & LF_DONE) continue;                       // pixel outside its clipped block, or already complete
             pixel = Q->pixel[lane];
-            t_fetch = ticks;
+            if (Placed) t_fetch = cost_clock();
             return true;
         }
     }
+    __device__ __forceinline__ uint32_t cost_clock() const {
+        return Clock ? (uint32_t) (__builtin_amdgcn_s_memtime() >> 8) : ticks;      // units of 256 shader cycles, or wavefront iterations
+    }
     __device__ __forceinline__ void store(U4 st) {
         Q->st[lane] = st;
-        if (Placed && Q->piece_cost) atomicAdd(Q->piece_cost + (lane >> 6), ticks - t_fetch);   // iterations this pixel took in this launch
+        if (Placed && Q->lane_cost) Q->lane_cost[lane] = cost_clock() - t_fetch + 1u;   // what this pixel cost in this (the measuring) launch
     }
     __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
         if (Q->log_rec) {                                       // wave-uniform: one format per render

@@ -16,9 +16,6 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
     uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
-    // k_path_phased's class-batched shade vote: shade-ready lanes of shade class c (bsdf.h: 1 = delta lobes, 2 = microfacet) join a
-    // shade run only once cls_min[c - 1] of them wait in the wavefront, or after cls_skip runs went by without them (0 / 1: always)
-    uint32_t cls_min1, cls_min2, cls_skip;
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
@@ -32,9 +29,6 @@ static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
 static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 
-#ifndef MIW_MERGED_CANDIDATES
-#define MIW_MERGED_CANDIDATES 0     /* 1: trace2 pops the E and the S candidates of a lane in ONE loop (A/B builds) */
-#endif
 #ifndef MIW_OCTANT_BOXES
 #define MIW_OCTANT_BOXES 1          /* 1: the leaf boxes of a tiny scene are staged once per ray octant, entry / exit plane of every axis side by side (leaf_box_test_octant); 0: one copy, min / max per axis */
 #endif
@@ -411,25 +405,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (!hasS) mS = 0;
         MIW_SECTION(1);
         uint32_t s_tri = 0; float s_t = 0.f;
-#if MIW_MERGED_CANDIDATES
-        // ONE candidate loop: a lane pops its E candidates, then its S candidates — the wavefront iterates max over lanes of
-        // (nE + nS) times instead of max(nE) + max(nS) (the sum of two counts spreads less than either); a trip costs a dozen
-        // selects more (direction, maxt, which result it updates). Same tests in the same per-lane order: same result.
-        while ((mE | mS) != 0) {
-            const bool isE = mE != 0;
-            const Mask m = isE ? mE : mS;
-            const uint32_t i = lowest(m);
-            mE = isE ? (mE & (mE - 1)) : mE; mS = isE ? mS : (mS & (mS - 1));
-            const V3 d = v3(isE ? dE.x : dS.x, isE ? dE.y : dS.y, isE ? dE.z : dS.z);
-            const TriPacket &k = pk[i];
-            float t, u, v;
-            const bool hit = ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, d, mint, isE ? maxtE : maxtS, t, u, v);
-            const bool take = isE & hit && (t < h.t || (t == h.t && k.prim < h.prim));
-            h.t = take ? t : h.t; h.u = take ? u : h.u; h.v = take ? v : h.v; h.tri = take ? i : h.tri; h.prim = take ? k.prim : h.prim;
-            const bool stop = !isE & hit;                      // any hit ends the shadow query
-            occ = occ | stop; mS = stop ? (Mask) 0 : mS; s_tri = stop ? i : s_tri; s_t = stop ? t : s_t;
-        }
-#else
         while (mE != 0) {                                      // closest hit of E over its candidates
             const uint32_t i = lowest(mE);
             mE &= mE - 1;
@@ -448,7 +423,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 occ = true; mS = 0; s_tri = i; s_t = t;
             }
         }
-#endif
         // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
         // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
         // through the full sweep with the rule inside, which is what the rule means.

@@ -65,15 +65,6 @@ MIW_HD uint32_t bsdf_tex_slots(uint32_t type) {
             type == BSDF_TYPE_ROUGHPLASTIC) ? 2u : 3u;
 }
 
-// Shade class of a plugin: what a shade run of the phase machine pays for when ONE lane of the class takes part
-// (device/phased_kernel.h batches the expensive classes). 0: smooth diffuse (and every hit that runs no BSDF code);
-// 1: the delta lobes (dielectric, conductor, plastic); 2: the microfacet plugins (GGX / Beckmann evaluation + visible-normal sampling)
-enum : uint32_t { SHADE_CLASS_DIFFUSE = 0, SHADE_CLASS_DELTA = 1, SHADE_CLASS_ROUGH = 2, SHADE_CLASS_COUNT = 3 };
-MIW_HD uint32_t bsdf_shade_class(uint32_t type) {
-    return type == BSDF_TYPE_DIFFUSE ? SHADE_CLASS_DIFFUSE
-         : (type == BSDF_TYPE_DIELECTRIC || type == BSDF_TYPE_CONDUCTOR || type == BSDF_TYPE_PLASTIC) ? SHADE_CLASS_DELTA : SHADE_CLASS_ROUGH;
-}
-
 MIW_HD uint32_t bsdf_flags(const BsdfRec &b) {
     switch (b.type) {
         case BSDF_TYPE_DIFFUSE:    return BSDF_DiffuseReflection;

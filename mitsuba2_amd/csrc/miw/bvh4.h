@@ -136,10 +136,7 @@ MIW_HD void walk4_node_step(const Bvh4Node &n, const Ray &r, float tmax_wide, in
 // address is clamped into the range, its test predicated), so a multi-triangle leaf costs one round trip per pair; the tests run
 // in range order, which is all the closest-hit / any-hit rules ask for. An any-hit walk ends at its first hit (`occluded`); a
 // drained range takes over the leaf the stack handed to `cur`, if any.
-// Cls: the top four bits of `best.tri` carry the shade class of the best hit's triangle (shape.h: tri_shade_class; triangle indices
-// stay below 2^27, mi_scene_upload) — the record is in registers when the hit is taken, the phase machine's shade vote reads the
-// class (device/phased_kernel.h) and strips it before the index is used (MIW_MISS keeps all bits set: class 15).
-template <bool Analytic, bool Cls = false, typename TriAt, typename Stack>
+template <bool Analytic, typename TriAt, typename Stack>
 MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best, float &tmax,
                            bool &occluded, int32_t &cur, int32_t &sp, uint32_t &tri_i, uint32_t &tri_end, Stack stack) {
     const bool two = tri_i + 1u < tri_end;
@@ -153,14 +150,12 @@ MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
     const bool hit = hit1 | hit2, stop = any_hit & hit;              // any hit ends a shadow walk
     occluded = occluded | stop;
     bool take1 = !any_hit & hit1 & (t < best.t);
-    if (!any_hit & hit1 & (t == best.t)) take1 = best.tri == MIW_MISS || tr.prim < tri_at(Cls ? best.tri & MIW_HIT_TRI_MASK : best.tri).prim;
-    best.t = take1 ? t : best.t; best.u = take1 ? u : best.u; best.v = take1 ? v : best.v;
-    best.tri = take1 ? (Cls ? tri_i | (tr.pad & ~MIW_HIT_TRI_MASK) : tri_i) : best.tri;
+    if (!any_hit & hit1 & (t == best.t)) take1 = best.tri == MIW_MISS || tr.prim < tri_at(best.tri).prim;
+    best.t = take1 ? t : best.t; best.u = take1 ? u : best.u; best.v = take1 ? v : best.v; best.tri = take1 ? tri_i : best.tri;
     tmax = take1 ? t : tmax;
     bool take2 = !any_hit & hit2 & (t2 < best.t);
-    if (!any_hit & hit2 & (t2 == best.t)) take2 = best.tri == MIW_MISS || tr2.prim < tri_at(Cls ? best.tri & MIW_HIT_TRI_MASK : best.tri).prim;
-    best.t = take2 ? t2 : best.t; best.u = take2 ? u2 : best.u; best.v = take2 ? v2 : best.v;
-    best.tri = take2 ? (Cls ? (tri_i + 1u) | (tr2.pad & ~MIW_HIT_TRI_MASK) : tri_i + 1u) : best.tri;
+    if (!any_hit & hit2 & (t2 == best.t)) take2 = best.tri == MIW_MISS || tr2.prim < tri_at(best.tri).prim;
+    best.t = take2 ? t2 : best.t; best.u = take2 ? u2 : best.u; best.v = take2 ? v2 : best.v; best.tri = take2 ? tri_i + 1u : best.tri;
     tmax = take2 ? t2 : tmax;
     tri_end = stop ? 0u : tri_end; cur = stop ? MIW_BVH4_ABSENT : cur; sp = stop ? 0 : sp;
     tri_i += two ? 2u : 1u;

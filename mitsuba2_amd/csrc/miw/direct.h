@@ -91,8 +91,8 @@ MIW_HD void direct_bsdf_hit(const RenderParams &P, const SceneView &sc, LaneRegs
         const ShapeRec &shape = sc.shapes[tr.shape];
         emitter = shape.emitter;
         if (emitter < 0) return;                                  // :178-179
-        if (Analytic && tri_analytic(tr)) {
-            const AnalyticRec &a = sc.rects[tri_analytic(tr) - 1u];
+        if (Analytic && tr.pad) {
+            const AnalyticRec &a = sc.rects[tr.pad - 1u];
             if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, h.x, ref_p, ray_d, sb);
             else compute_surface_interaction_rect(a, h.x, h.y, h.z, ref_p, ray_d, sb);
         } else {

@@ -66,9 +66,13 @@ struct LaneQueues {
     U4 *log_rec;
     const float *log_thr;   // the 256 phase thresholds (global memory; kernels that stage them in LDS pass their own pointer)
     uint32_t log_rej;       // class index of a rejected sample = the class count (the first all-zero row of the weight table)
-    // placed pixel queues of small shards (device/resident_kernel.h: QueueWork): cost of every 64-lane piece (written by the
-    // measuring launch, nullptr otherwise), four pieces per SIMD queue, the SIMD registry (word 0: next id; then by hardware id)
-    uint32_t *piece_cost; const uint32_t *piece_list; uint32_t *simd_ids;
+    // placed pixel queues of small shards (device/resident_kernel.h: QueueWork): what every pixel cost (written by the measuring
+    // launch, nullptr otherwise), the lanes sorted by that cost (64 consecutive entries = one piece: pixels of about equal cost
+    // share a wavefront), four pieces per SIMD queue, the SIMD registry (word 0: "all dry" flag; then by hardware id)
+    // piece k's j-th lane is lane_sorted[k * piece_a + j * piece_b]: (64, 1) — a piece is 64 consecutive sorted lanes, its pixels cost
+    // about the same and finish together — or (1, pieces) — a piece takes every pieces-th sorted lane, one pixel of every cost
+    // stratum (which cut a launch gets: mi_render, by measurement)
+    uint32_t *lane_cost; const uint32_t *lane_sorted; const uint32_t *piece_list; uint32_t *simd_ids; uint32_t piece_a, piece_b;
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)

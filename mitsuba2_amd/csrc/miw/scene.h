@@ -84,8 +84,8 @@ MIW_HD void hit_surface_interaction(const SceneView &sc, uint32_t tri_idx, float
                                     SurfaceInteraction &si, uint32_t &bsdf_index, int32_t &emitter) {
     const Tri &tr = sc.tris[tri_idx];
     const ShapeRec &shape = sc.shapes[tr.shape];
-    if (Analytic && tri_analytic(tr)) {                  // analytic shape: its own compute_surface_interaction
-        const AnalyticRec &a = sc.rects[tri_analytic(tr) - 1u];
+    if (Analytic && tr.pad) {                            // analytic shape: its own compute_surface_interaction
+        const AnalyticRec &a = sc.rects[tr.pad - 1u];
         if (a.kind == ANALYTIC_SPHERE) compute_surface_interaction_sphere(a, t, ray_o(), ray_d, si);
         else compute_surface_interaction_rect(a, t, u, v, ray_o(), ray_d, si);
     } else {

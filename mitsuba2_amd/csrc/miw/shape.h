@@ -22,16 +22,10 @@ struct Tri {
     float p0[3], p1[3], p2[3];
     uint32_t shape;      // index into the shape table
     uint32_t prim;       // global primitive id (scene order) — closest-hit tie break
-    uint32_t pad;        // bits 0..27 — 0: a mesh triangle. k > 0: one of the two bounding triangles of analytic rectangle k - 1
+    uint32_t pad;        // 0: a mesh triangle. k > 0: one of the two bounding triangles of analytic rectangle k - 1
                          // (AnalyticRec table): the BVH builders see ordinary triangles, the leaf test runs the
                          // rectangle's own intersection routine (both halves give the same answer)
-                         // bits 28..31 — shade class of the shape's BSDF (bsdf.h: bsdf_shade_class), written by the device's scene
-                         // upload: what the phase machine's shade vote batches by (device/phased_kernel.h); 0 elsewhere
 };
-#define MIW_TRI_CLASS_SHIFT 28
-#define MIW_HIT_TRI_MASK ((1u << MIW_TRI_CLASS_SHIFT) - 1u)       /* a hit's triangle index when its top bits carry the class (bvh4.h: walk4_tri_step<.., Cls>) */
-MIW_HD uint32_t tri_analytic(const Tri &tr) { return tr.pad & ((1u << MIW_TRI_CLASS_SHIFT) - 1u); }   // 0: triangle; k: AnalyticRec k - 1
-MIW_HD uint32_t tri_shade_class(const Tri &tr) { return tr.pad >> MIW_TRI_CLASS_SHIFT; }
 
 // Analytic shapes. kind 0 = rectangle (src/shapes/rectangle.cpp): [-1, 1]^2 in z = 0 of object space;
 // kind 1 = sphere (src/shapes/sphere.cpp). 4x4 matrices column-major.
@@ -167,8 +161,8 @@ MIW_HD bool ray_intersect_sphere(const AnalyticRec &r, V3 o_, V3 d_, float mint_
 template <bool Analytic = true>
 MIW_HD bool prim_intersect(const Tri &tr, PrimCtx ctx, V3 o, V3 d, float mint, float maxt,
                            float &t, float &u, float &v) {
-    if (Analytic && tri_analytic(tr)) {
-        const AnalyticRec &a = ctx.rects[tri_analytic(tr) - 1u];
+    if (Analytic && tr.pad) {
+        const AnalyticRec &a = ctx.rects[tr.pad - 1u];
         return a.kind == ANALYTIC_SPHERE ? ray_intersect_sphere(a, o, d, mint, maxt, t, u, v)
                                          : ray_intersect_rectangle(a, o, d, mint, maxt, t, u, v);
     }

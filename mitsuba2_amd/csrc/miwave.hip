@@ -61,6 +61,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "envmap_build.h"
 #include "film_classes.h"
 #include "lbvh_device.h"
+#include "ploc_device.h"
 #include "bvh4_device.h"
 
 using namespace miw;
@@ -83,6 +84,8 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #include "device/stream_trace.h"
 #include "device/film_kernels.h"
 #include "device/eval_kernels.h"
+
+__global__ void k_iota(uint32_t *out, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = i; }
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -149,7 +152,8 @@ struct mi_ctx {
     FilmClasses classes; FilmRec classes_of{}; bool classes_valid = false;   // the class tables of the last filter rendered with (ok or refused), and that filter
     DevBuf<float> d_fc_thr, d_fc_w;
     DevBuf<uint32_t> d_next_pixel; int cu_count = 256;
-    DevBuf<uint32_t> d_piece_cost, d_piece_list, d_simd_ids;   // placed pixel queues of small shards (resident_kernel.h: QueueWork)
+    DevBuf<uint32_t> d_lane_cost, d_cost_sorted, d_lane_iota, d_lane_sorted, d_piece_list, d_simd_ids;   // placed pixel queues of small shards (resident_kernel.h: QueueWork)
+    DevBuf<unsigned char> d_place_tmp;
     DevBuf<uint32_t> d_lists, d_list_counts;    // wavefront plan: 2 parities x WL_LISTS lists / counters
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
     DevBuf<Counters> d_cnt;
@@ -206,7 +210,7 @@ void mi_destroy(mi_ctx *c) {
     c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_nodes4.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
-    c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_piece_cost.release(); c->d_piece_list.release(); c->d_simd_ids.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
+    c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lane_cost.release(); c->d_cost_sorted.release(); c->d_lane_iota.release(); c->d_lane_sorted.release(); c->d_place_tmp.release(); c->d_piece_list.release(); c->d_simd_ids.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
     c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); c->d_fc_thr.release(); c->d_fc_w.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
@@ -328,8 +332,6 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         }
         c->bsdfs[i] = r;
     }
-    // the shade class of every triangle's BSDF rides in the top bits of Tri::pad (shape.h; the phase machine's shade vote batches by it)
-    for (Tri &t : c->tris_in) t.pad = tri_analytic(t) | (bsdf_shade_class(c->bsdfs[c->shapes[t.shape].bsdf].type) << MIW_TRI_CLASS_SHIFT);
     c->diffuse_only = true;
     for (const BsdfRec &r : c->bsdfs) if (r.type != BSDF_TYPE_DIFFUSE || (r.flags & BSDF_REC_TWOSIDED)) c->diffuse_only = false;
     if (!c->tri_uv_in.empty()) c->diffuse_only = false;          // texture coordinates steer the shading frame (mesh.cpp:492-511)
@@ -494,14 +496,71 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         float m = 0.f;
         for (int k = 0; k < 6; ++k) { uint32_t o = hb[k]; float f = u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); m = std::max(m, std::fabs(f)); }
         const float pad = 2.f * std::max(1e-5f * m, 1e-30f);
-        hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
-                           (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
-        hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p, d_span.p, d_first.p);
-        hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_inner.p, d_leaf_parent.p, n, d_boxes.p, d_arrivals.p, d_height.p, d_span.p, lbvh_leaf);
-        hipLaunchKernelGGL(k_lbvh_emit, grd, blk, 0, s, d_inner.p, d_boxes.p, n, c->d_nodes.p, d_span.p, d_first.p, lbvh_leaf);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        // The topology: PLOC (ploc_device.h — Morton order + surface-area clustering: the default since round 4) or the radix tree of
+        // lbvh_device.h (MIW_DEVICE_BUILDER=lbvh: A/B runs, and the fallback should the clustering not finish). Both deliver BvhNode
+        // records with root 0, triangles in leaf order and the BVH2 heights (d_height) the 4-wide collapse below asks for.
+        bool use_ploc = !(getenv("MIW_DEVICE_BUILDER") && !strcmp(getenv("MIW_DEVICE_BUILDER"), "lbvh"));
+        uint32_t ploc_rounds = 0;
+        if (use_ploc) {
+            uint32_t radius = 16u;
+            if (const char *e = getenv("MIW_PLOC_RADIUS")) radius = (uint32_t) std::min(64, std::max(1, atoi(e)));
+            const uint32_t un = (uint32_t) n;
+            TmpBuf<Tri> d_sorted; TmpBuf<float> d_vn_sorted; TmpBuf<uint32_t> d_count, d_ca, d_cb, d_partner, d_offset; TmpBuf<int32_t> d_left, d_right, d_parent;
+            TmpBuf<unsigned long long> d_flags, d_scan; TmpBuf<PlocState> d_state; TmpBuf<unsigned char> d_scan_tmp;
+            HIP_TRY(c, d_sorted.resize(un)); if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_sorted.resize((size_t) un * 9));
+            HIP_TRY(c, d_count.resize(2 * (size_t) un)); HIP_TRY(c, d_parent.resize(2 * (size_t) un)); HIP_TRY(c, d_left.resize(un)); HIP_TRY(c, d_right.resize(un));
+            HIP_TRY(c, d_ca.resize(un)); HIP_TRY(c, d_cb.resize(un)); HIP_TRY(c, d_partner.resize(un)); HIP_TRY(c, d_offset.resize(2 * (size_t) un));
+            HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_scan.resize(un)); HIP_TRY(c, d_state.resize(2));
+            size_t scan_bytes = 0;
+            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags.p, d_scan.p, n, s));
+            HIP_TRY(c, d_scan_tmp.resize(scan_bytes + 16));
+            hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
+                               un, pad, d_sorted.p, c->tri_vn_in.empty() ? (float *) nullptr : d_vn_sorted.p, d_boxes.p);
+            hipLaunchKernelGGL(k_ploc_init, dim3((2u * un + 255u) / 256u), blk, 0, s, un, d_ca.p, d_count.p, d_parent.p, d_state.p);
+            PlocTree T{ reinterpret_cast<PlocBox *>(d_boxes.p), d_count.p, d_left.p, d_right.p, d_parent.p, d_height.p };
+            uint32_t bound = un; bool done = false;
+            for (uint32_t round = 0; round < 1024u && !done; round += 8u) {
+                for (uint32_t k = 0; k < 8u; ++k) {                // eight rounds between two looks at the cluster count
+                    const uint32_t t = round + k;
+                    const PlocState *st = d_state.p + (t & 1u); PlocState *st_next = d_state.p + ((t + 1u) & 1u);
+                    const uint32_t *cur = (t & 1u) ? d_cb.p : d_ca.p; uint32_t *nxt = (t & 1u) ? d_ca.p : d_cb.p;
+                    const dim3 g((bound + 255u) / 256u);
+                    hipLaunchKernelGGL(k_ploc_partner, g, blk, 0, s, st, cur, reinterpret_cast<const PlocBox *>(d_boxes.p), radius, d_partner.p);
+                    hipLaunchKernelGGL(k_ploc_flags, g, blk, 0, s, st, d_partner.p, bound, d_flags.p);
+                    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_scan.p, (int) bound, s));
+                    hipLaunchKernelGGL(k_ploc_apply, g, blk, 0, s, st, st_next, cur, d_partner.p, d_scan.p, un, lbvh_leaf, T, nxt);
+                }
+                PlocState h;
+                HIP_TRY(c, hipMemcpyAsync(&h, d_state.p + ((round + 8u) & 1u), sizeof h, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                ploc_rounds = round + 8u;
+                bound = h.m; done = h.m <= 1u && h.created == un - 1u;
+            }
+            HIP_TRY(c, hipGetLastError());
+            if (done) {
+                hipLaunchKernelGGL(k_ploc_offsets, dim3((2u * un + 255u) / 256u), blk, 0, s, T, un, d_offset.p);
+                hipLaunchKernelGGL(k_ploc_scatter, grd, blk, 0, s, d_sorted.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_sorted.p, d_offset.p, un,
+                                   c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p);
+                hipLaunchKernelGGL(k_ploc_emit, grd, blk, 0, s, T, d_offset.p, un, lbvh_leaf, c->d_nodes.p);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));              // (the temporaries above go out of scope here)
+            } else use_ploc = false;                               // cannot happen (every round merges at least one pair); then: the radix tree
+        }
+        if (!use_ploc) {
+            HIP_TRY(c, hipMemsetAsync(d_height.p, 0, (size_t) n * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
+                               (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
+            hipLaunchKernelGGL(k_lbvh_tree, grd, blk, 0, s, d_keys_sorted.p, n, d_inner.p, d_leaf_parent.p, d_span.p, d_first.p);
+            hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_inner.p, d_leaf_parent.p, n, d_boxes.p, d_arrivals.p, d_height.p, d_span.p, lbvh_leaf);
+            hipLaunchKernelGGL(k_lbvh_emit, grd, blk, 0, s, d_inner.p, d_boxes.p, n, c->d_nodes.p, d_span.p, d_first.p, lbvh_leaf);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        c->counters.bvh_builder = use_ploc ? 2u : 1u;
+        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] device builder: %s, %u triangles, height %u%s\n", use_ploc ? "PLOC" : "LBVH", (uint32_t) n, depth,
+                                         use_ploc ? (", " + std::to_string(ploc_rounds) + " rounds enqueued").c_str() : "");
         node_count = (uint32_t) (n - 1);
         built_on_device = depth <= MIW_BVH_MAX_DEPTH;     // deeper (many coincident centroids): take the SAH builder
         // ---- the 4-wide tree of the phase machine, collapsed level by level on the device (bvh4_device.h); the heights the
@@ -549,6 +608,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         node_count = (uint32_t) r.nodes.size(); tri_count = (uint32_t) r.tris.size(); depth = r.depth;
     }
     c->counters.bvh_on_device = built_on_device ? 1u : 0u;
+    if (!built_on_device) c->counters.bvh_builder = 0u;
 
     SceneView &v = c->view;
     v.accept_pad = scene_pad_unit(c->tris_in);                // shape.h: the bounds rule of every triangle hit
@@ -625,8 +685,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 r.nodes.resize(node_count);
                 HIP_TRY(c, hipMemcpy(r.nodes.data(), c->d_nodes.p, (size_t) node_count * sizeof(BvhNode), hipMemcpyDeviceToHost));
             }
-            Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, max_fan);   // one entry of slack: the node body's unconditional stores
-            if (const char *e = getenv("MIW_BVH4_ORDER")) if (atoi(e) == 1) bvh4_reorder_depth_first(b4);   // A/B: depth-first node order
+            const Bvh4BuildResult b4 = bvh4_collapse(r.nodes, MIW_STACK_ENTRIES - 1, max_fan);   // one entry of slack: the node body's unconditional stores
             if (b4.ok) {
                 HIP_TRY(c, c->d_nodes4.upload(b4.nodes, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -909,7 +968,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.ray_o = c->q_ray_o.p; Q.ray_d = c->q_ray_d.p; Q.hit = c->q_hit.p;
     Q.sh_d = c->q_sh_d.p; Q.sh_c = c->q_sh_c.p; Q.sh_vis = c->q_sh_vis.p;
     Q.log_pos = film_mode == 1 && !rec16 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 && !rec16 ? c->q_log_val.p : nullptr;
-    Q.piece_cost = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr;
+    Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr; Q.piece_a = 64u; Q.piece_b = 1u;
     Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count : 0u;
     // render launches with 16-byte records keep the 256 phase thresholds behind everything else in dynamic LDS
     TraceLds rcfg = c->lds_cfg; size_t rlds = c->lds_bytes;
@@ -991,19 +1050,36 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // QueueWork). Same samples, same log slots: the film does not change. MIW_PLACE = 0 | 1 overrides.
         // (packet kernels only — QueueWork<Placed> — and only where every pixel of the shard can be resident at once: 4 wavefronts per SIMD
         // for the plain-diffuse packet kernel, 3 for the others — a shard larger than that is balanced by the queue itself)
-        const uint32_t res_waves = c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u;
-        // (n_lanes % 64: a partial last piece would let its missing lanes read "queue dry" while the queue still holds pieces — QueueWork::fetch)
-        bool place = film_mode == 1 && !direct && c->lds_cfg.brute && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
-                     n_lanes % 64u == 0u && cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
+        // Which path kernel runs (decided here because placement depends on it): tree scenes with the LDS-stack walk get the wave-level
+        // phase machine (device/phased_kernel.h; MIW_PHASED=0 keeps the lock-step kernel, MIW_TRIO=0 the full BSDF table: A/B runs)
+        const bool tiny = c->lds_cfg.brute != 0;
+        const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
+        const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
+        const bool trio_kernel = c->trio && trio_on && c->rects.empty() && !c->textured;   // 52 KB of code instead of 84
+        const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel);
+        // 4 waves per SIMD for every tree (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0 before the register diet, +8 % after); MIW_PHASED_WAVES = 3 | 4 overrides
+        int ph_waves = 4;
+        if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
+        const bool phased_placeable = phased && c->view.nodes4 != nullptr && ph_waves == 4;     // (the Placed instantiations: the 4-wide tree at four waves per SIMD)
+        const uint32_t res_waves = phased ? (uint32_t) ph_waves : (c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u);
+        bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
+                     cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = getenv("MIW_PLACE")) place = place && atoi(e) != 0;
         uint32_t measure_div = 8u;                                 // the measuring launch runs spp / 8 samples (MIW_PLACE_MEASURE = divisor)
         if (const char *e = getenv("MIW_PLACE_MEASURE")) measure_div = (uint32_t) std::max(2, atoi(e));
         const uint32_t measure_end = place ? std::max<uint32_t>(16u, cfg->spp / measure_div) : 0u;
         const uint32_t n_pieces = (n_lanes + 63u) / 64u;
+        size_t place_tmp_bytes = 0;
         if (place) {
-            HIP_TRY(c, c->d_piece_cost.resize(n_pieces)); HIP_TRY(c, c->d_piece_list.resize((size_t) n_simd * MIW_PLACE_PIECES)); HIP_TRY(c, c->d_simd_ids.resize(1u + (1u << 14)));
-            HIP_TRY(c, hipMemsetAsync(c->d_piece_cost.p, 0, n_pieces * sizeof(uint32_t), s));
+            HIP_TRY(c, c->d_lane_cost.resize(n_lanes)); HIP_TRY(c, c->d_cost_sorted.resize(n_lanes)); HIP_TRY(c, c->d_lane_iota.resize(n_lanes));
+            HIP_TRY(c, c->d_lane_sorted.resize((size_t) n_pieces * 64u));
+            HIP_TRY(c, c->d_piece_list.resize((size_t) n_simd * MIW_PLACE_PIECES)); HIP_TRY(c, c->d_simd_ids.resize(1u + (1u << 14)));
+            HIP_TRY(c, hipMemsetAsync(c->d_lane_cost.p, 0, n_lanes * sizeof(uint32_t), s));      // (lanes without a pixel never report: cost 0, sorted last)
+            HIP_TRY(c, hipMemsetAsync(c->d_lane_sorted.p, 0xff, (size_t) n_pieces * 64u * sizeof(uint32_t), s));
             HIP_TRY(c, hipMemsetAsync(c->d_simd_ids.p, 0, c->d_simd_ids.n * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_iota, dim3((n_lanes + 255u) / 256u), dim3(256), 0, s, c->d_lane_iota.p, n_lanes);
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (int) n_lanes, 0, 32, s));
+            HIP_TRY(c, c->d_place_tmp.resize(place_tmp_bytes + 16));
         }
         // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
         TileArgs TA; memset(&TA, 0, sizeof TA);
@@ -1020,7 +1096,6 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_resident<false, 0, MATS_ALL, true, INTEG_DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (c->lds_bytes + tile_bytes)));
             }
         }
-        const bool tiny = c->lds_cfg.brute != 0;
         const uint32_t sync_every = 8;
         uint32_t launches = 0;
         for (uint32_t done = 0; done < cfg->spp; ) {
@@ -1028,13 +1103,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             if (film_mode == 1) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, c->d_next_pixel.n * sizeof(uint32_t), s));
-                rcfg.queues = 1u; Q.piece_cost = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr;
-                if (place && done == 0) { end = measure_end; Q.piece_cost = c->d_piece_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch
+                rcfg.queues = 1u; Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr;
+                if (place && done == 0) { end = measure_end; Q.lane_cost = c->d_lane_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch
                 else if (place) {
-                    // longest piece first onto the SIMD queue with the smallest sum that still has a free slot
+                    // the lanes by what their pixel cost, dearest first (device radix sort), cut into pieces of 64: consecutive sorted lanes
+                    // (the pixels of a wavefront cost about the same and finish together), or every pieces-th one (one pixel of every cost
+                    // stratum per wavefront). Either way a piece's cost is that of its first (dearest) lane.
+                    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(c->d_place_tmp.p, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (int) n_lanes, 0, 32, s));
+                    // Which cut: measured on rank 0's 1/8 shard (gpurun r4b, path kernel ms at 256 / 128 / 512 spp; no placement -> consecutive
+                    // -> spread): material balls 99.3 -> 90.7 -> 104.9, 0.9 M-triangle interior 130.8 -> 131.0 -> 120.9, Cornell packets
+                    // 40.0 -> 36.7 -> 44.3. Consecutive pieces keep the dear pixels in few wavefronts, which the priorities then favour; the
+                    // interior — every pixel dear, its walks bound by memory latency, tree and triangles beyond the L2s — gains from every
+                    // wavefront carrying the same mix. Rule: spread when the tree does not fit the aggregate L2 (32 MB). MIW_PLACE_SPREAD = 0 | 1 overrides.
+                    bool spread = phased && ((size_t) c->nodes4_count * sizeof(Bvh4Node) + (size_t) c->view.tri_count * sizeof(Tri)) > ((size_t) 32 << 20);
+                    if (const char *e = getenv("MIW_PLACE_SPREAD")) spread = atoi(e) != 0;
+                    Q.piece_a = spread ? 1u : 64u; Q.piece_b = spread ? n_pieces : 1u;
                     std::vector<uint32_t> cost(n_pieces);
-                    HIP_TRY(c, hipMemcpyAsync(cost.data(), c->d_piece_cost.p, n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipMemcpy2DAsync(cost.data(), sizeof(uint32_t), c->d_cost_sorted.p, Q.piece_a * sizeof(uint32_t), sizeof(uint32_t), n_pieces, hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
+                    // longest piece first onto the SIMD queue with the smallest sum that still has a free slot
                     // the SIMDs the measuring launch ran on, numbered 0 .. nqueues - 1 (simd_ids[1 + hardware key]; word 0 = the "all dry" flag)
                     std::vector<uint32_t> ids(c->d_simd_ids.n);
                     HIP_TRY(c, hipMemcpyAsync(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1062,7 +1149,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     HIP_TRY(c, hipMemcpyAsync(c->d_piece_list.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     HIP_TRY(c, hipMemcpyAsync(c->d_simd_ids.p, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     HIP_TRY(c, hipStreamSynchronize(s));                                                     // the host vectors must outlive the copies
-                    rcfg.queues = nqueues; Q.piece_list = c->d_piece_list.p; Q.simd_ids = c->d_simd_ids.p;
+                    rcfg.queues = nqueues; Q.piece_list = c->d_piece_list.p; Q.lane_sorted = c->d_lane_sorted.p; Q.simd_ids = c->d_simd_ids.p;
                     K.placed = 1u;
                     }
                 }
@@ -1076,17 +1163,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
-                // tree scenes with the LDS-stack walk: the wave-level phase machine (device/phased_kernel.h); MIW_PHASED=0 keeps
-                // the lock-step kernel (A/B runs)
-                const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
-                // the phase machine over the 4-wide tree; MIW_BVH4=0 keeps the BVH2 node body for the MATS_TRIO class (configs 3 / 4: A/B runs)
-                const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
-                const bool trio_kernel = c->trio && trio_on && c->rects.empty() && !c->textured;   // 52 KB of code instead of 84
-                const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel);
+                // (`phased`, `trio_kernel`, `ph_waves`: decided above the loop; MIW_BVH4=0 keeps the BVH2 node body for the MATS_TRIO class: A/B runs)
                 K.path_kernel = phased ? (c->view.nodes4 ? 1u : 3u) : 0u;
-                // 4 waves per SIMD for big trees (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0); MIW_PHASED_WAVES = 3 | 4 overrides
-                int ph_waves = 4;     // (3 until round 3: with 120 spilled registers the fourth wavefront only paid on big trees; at 20 it pays everywhere — DESIGN.md section 4)
-                if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
                 const dim3 phgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (unsigned) ph_waves));
                 // the shade vote (phased_kernel.h): shade once n_shade * num >= den * (lanes of the busier walk body). Measured on the
                 // 4-wide tree (gpurun r2f / r2g, Msamples/s at 1 : 1 -> 3 : 2 -> 2 : 1): balls 844 -> 873 -> 860; interior with its
@@ -1104,13 +1182,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
-                // the class-batched shade vote (phased_kernel.h): lanes whose hit needs the delta-lobe / microfacet code wait until this many
-                // of their class are ready in the wavefront, at most `skip` shade runs. MIW_CLASS_BATCH=min1:min2:skip overrides (1:1:0 = off).
-                ph_cfg.cls_min1 = 6; ph_cfg.cls_min2 = 8; ph_cfg.cls_skip = 4;
-                if (const char *e = getenv("MIW_CLASS_BATCH")) { int a = 0, b = 0, k = 0; if (sscanf(e, "%d:%d:%d", &a, &b, &k) == 3 && a > 0 && b > 0 && k >= 0) { ph_cfg.cls_min1 = (uint32_t) a; ph_cfg.cls_min2 = (uint32_t) b; ph_cfg.cls_skip = (uint32_t) k; } }
-#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 4, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); \
-                                     else MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, 3, W>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p)); } while (0)
-                if (phased) {
+#define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
+#define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_PHASED_LAUNCH_(M, A, 4, W, false); else MIW_PHASED_LAUNCH_(M, A, 3, W, false); } while (0)
+                if (phased && place) {                           // a shard of about one pixel per resident lane: the Placed instantiations (measuring, then placed launch)
+                    if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, true, true);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, true, true);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH_(MATS_PLAIN, false, 4, true, true);
+                    else MIW_PHASED_LAUNCH_(MATS_PLAIN, true, 4, true, true);
+                } else if (phased) {
                     if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, false);
                     else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, true);
                     else if (trio_kernel) MIW_PHASED_LAUNCH(MATS_TRIO, false, true);
@@ -1118,6 +1197,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     else MIW_PHASED_LAUNCH(MATS_PLAIN, true, true);
                 }
 #undef MIW_PHASED_LAUNCH
+#undef MIW_PHASED_LAUNCH_
                 else if (direct) {
 #define MIW_DIRECT_LAUNCH(T, M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, A, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                     if (tiny && c->textured) MIW_DIRECT_LAUNCH(1, MATS_ALL, false);
@@ -1161,14 +1241,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             std::vector<uint32_t> cur(n_simd), ids(1u + (1u << 14)), cost(n_pieces);
             (void) hipMemcpy(cur.data(), c->d_next_pixel.p, n_simd * sizeof(uint32_t), hipMemcpyDeviceToHost);
             (void) hipMemcpy(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            (void) hipMemcpy(cost.data(), c->d_piece_cost.p, n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void) hipMemcpy2D(cost.data(), sizeof(uint32_t), c->d_cost_sorted.p, Q.piece_a * sizeof(uint32_t), sizeof(uint32_t), n_pieces, hipMemcpyDeviceToHost);
             uint32_t keys = 0, key_or = 0, full = 0, over = 0; uint64_t csum = 0; uint32_t cmin = ~0u, cmax = 0;
             for (uint32_t k = 0; k < (1u << 14); ++k) if (ids[1 + k] != 0xffffffffu) { ++keys; key_or |= k; }
             ids[0] = keys;
             for (uint32_t v : cur) { full += v >= 64u * MIW_PLACE_PIECES; over += v > 64u * MIW_PLACE_PIECES; }
             for (uint32_t v : cost) { csum += v; cmin = std::min(cmin, v); cmax = std::max(cmax, v); }
             fprintf(stderr, "[miwave] placed queues: %u SIMDs numbered, %u distinct hardware keys (bits used 0x%x), %u of %u queues drained (%u asked beyond their end), "
-                            "piece cost min / mean / max = %u / %.0f / %u iterations\n", ids[0], keys, key_or, full, n_simd, over, cmin, (double) csum / n_pieces, cmax);
+                            "cost of the dearest pixel of a piece min / mean / max = %u / %.0f / %u (iterations, or 256-cycle units)\n", ids[0], keys, key_or, full, n_simd, over, cmin, (double) csum / n_pieces, cmax);
         }
 #if defined(MIW_VERIFY_FILTER)
         {

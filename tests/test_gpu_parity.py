@@ -610,15 +610,19 @@ def test_device_against_committed_golden_films(native, dev):
         assert st == 0 and np.array_equal(film, g["film_" + key]) and dev.counters().segments == int(g["segments_" + key]), key
 
 
-def test_placed_queues_and_priorities_do_not_change_the_film(native):
+@pytest.mark.parametrize("which", ["packets", "tree", "tree_lbvh"])
+def test_placed_queues_and_priorities_do_not_change_the_film(native, which):
     """What one rank of an 8-GPU frame renders (1/8 of the 1080p tiles: one pixel per resident lane) goes through a measuring
-    launch + per-SIMD pixel queues + least-progress-first wave priorities (csrc/device/resident_kernel.h: QueueWork). All of it is
-    scheduling: the samples and their log slots are the same, so the film must be the plain launch's bit for bit."""
+    launch + a device sort of the pixels by cost + per-SIMD pixel queues + least-progress-first wave priorities
+    (csrc/device/resident_kernel.h: QueueWork). All of it is scheduling: the samples and their log slots are the same, so the film
+    must be the plain launch's bit for bit — for the packet kernel (Cornell box) and for the phase machine's Placed instantiation
+    (material balls: SAH tree and device-built tree)."""
     import os
     from mitsuba2_amd import scenes
-    scene, sensor = scenes.cornell_box(1920, 1080, 128, device=-1)
+    scene, sensor = scenes.cornell_box(1920, 1080, 128, diffuse_only=(which == "packets"), device=-1)
     dev = native.Device(0)
-    dev.upload(scene.desc())
+    dev.upload(scene.desc(), bvh_quality=0 if which == "tree_lbvh" else 1)
+    assert dev.counters().bvh_tris == (32 if which == "packets" else 40972)
     integ = native.PathIntegrator(); integ.set_shard(0, 8)
     job = integ.render_job(sensor)
     films = {}
