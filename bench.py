@@ -186,7 +186,7 @@ def run_extras(api, scenes, film, C):
     def timed(tag, scene, sensor, spp, note):
         device = api.Device(0)                   # world == 1: the benchmark runs on GPU 0
         try:
-            device.upload(scene.desc(), bvh_quality=1)
+            device.upload(scene.desc())
             bvh = device.counters()
             job = api.PathIntegrator().render_job(sensor)
             cfg = job.cfg
@@ -203,7 +203,7 @@ def run_extras(api, scenes, film, C):
                         "samples": int(c.samples), "segments_per_sample": c.segments / max(c.samples, 1),
                         "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident",
                         "log_bytes": int(c.log_bytes),
-                        "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 2: "device PLOC"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris}}
+                        "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris}}
         finally:
             device.close()
 
@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
                     help="scalar_spectral = BASELINE configs[4] (4 wavelengths per sample; needs mitsuba2_amd/data/srgb.coeff or "
                          "MIWAVE_SRGB_COEFF = the reference's data/srgb.coeff)")
-    ap.add_argument("--bvh-quality", type=int, default=1, help="1 = host binned SAH (default), 0 = built on the device (PLOC; MIW_DEVICE_BUILDER=lbvh: the radix tree)")
+    ap.add_argument("--bvh-quality", type=int, default=0, help="0 = the binned-SAH tree built on the device (csrc/sah_device.h: the default; + 64 = MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3), 1 = the same tree built by the host recursion")
     ap.add_argument("--shard", default="auto", choices=["auto", "tiles", "passes"],
                     help="how N ranks split the frame. tiles (the north star's partition; what auto picks, always): spiral blocks dealt "
                          "round-robin, every rank renders all spp of its pixels; the N-GPU film equals the 1-GPU film. passes (explicit "
@@ -500,7 +500,7 @@ def main():
                                     "material balls in the Cornell box (GGX rough conductor + bk7 dielectric icospheres, " + str(bvh.bvh_tris) +
                                     " triangles, shading normals), %dx%d @ %d spp, path integrator max_depth=-1 rr_depth=5, "
                                     "gaussian rfilter, independent sampler seed 0") % (W, H, SPP),
-                       "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 2: "device PLOC"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 3),
+                       "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 3),
                                "nodes": bvh.bvh_nodes, "tris": bvh.bvh_tris, "depth": bvh.bvh_depth},
                        "parallelism": ("%s-shard x%d + %s film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world, reduce_label(args.backend))) if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage" + (" (persistent stream walk kernel with dynamic ray fetch)" if pk == 2 else ""), 2: "resident: path state in registers, geometry in LDS"

@@ -281,8 +281,9 @@ typedef struct {
     double ms_bvh4;            /* part of ms_bvh_build spent producing the 4-wide tree                                               */
     uint32_t placed;           /* 1: the last render ran a measuring launch + a launch with per-SIMD pixel queues (a shard of at most
                                   one pixel per resident lane: what one rank of an N-GPU frame renders at N >= 8)                     */
-    uint32_t bvh_builder;      /* the last mi_bvh_build: 0 = host binned SAH (quality 1), 1 = device LBVH (radix tree), 2 = device PLOC
-                                  (Morton order + surface-area clustering: quality 0 since round 4)                                   */
+    uint32_t bvh_builder;      /* the last mi_bvh_build: 0 = host binned SAH (quality 1, or a scene the device sweep hands back), 3 = the same
+                                  tree built on the device level by level (csrc/sah_device.h: quality 0 since round 4), 1 = device LBVH
+                                  (radix tree over Morton codes: MIW_DEVICE_BUILDER=lbvh, A/B runs)                                      */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */
@@ -302,14 +303,16 @@ mi_status mi_set_stream(mi_ctx *ctx, void *hip_stream);
  * (Mesh::build_pmf, src/librender/mesh.cpp:285-312) */
 mi_status mi_scene_upload(mi_ctx *ctx, const mi_scene_desc *scene);
 /* Scene::accel_init_cpu (src/librender/scene_native.inl:3-10): build the BVH.
- * quality 0 = built on the device: PLOC (csrc/ploc_device.h: Morton sort + rounds of surface-area clustering; the radix-tree
- * LBVH of csrc/lbvh_device.h with MIW_DEVICE_BUILDER=lbvh), collapsed on the device into the 4-wide tree the render kernels walk;
- * 1 = binned SAH built on the host (the default of the host layer).
+ * quality 1 = binned SAH built on the host (csrc/bvh_build.h); quality 0 = THE SAME TREE built on the device level by level
+ * (csrc/sah_device.h; MIW_DEVICE_BUILDER=lbvh: the radix tree of rounds 2 - 3, A/B runs) and collapsed on the device into the 4-wide
+ * tree the render kernels walk. A scene the level sweep hands back (coincident centroids) gets the host builder.
  * Scenes of <= 64 triangles are traced by a brute-force sweep over LDS-resident
  * triangle packets instead of the tree; OR in MI_BVH_FORCE_TREE to walk the tree
  * anyway (tests). */
 enum { MI_BVH_FORCE_TREE = 0x10,       /* walk the tree even for <= 64 triangles                  */
-       MI_BVH_NO_LEAF_FILTER = 0x20 };  /* resident plan: sweep every triangle, no leaf-box filter (tests) */
+       MI_BVH_NO_LEAF_FILTER = 0x20,    /* resident plan: sweep every triangle, no leaf-box filter (tests) */
+       MI_BVH_RADIX_TREE = 0x40 };      /* quality 0 only: the radix-tree builder over Morton codes (csrc/lbvh_device.h) instead of the
+                                           SAH level sweep — ANOTHER tree, same answers (tests, A/B runs)   */
 mi_status mi_bvh_build(mi_ctx *ctx, int32_t quality);
 
 /* Scene::ray_intersect_preliminary (any_hit = 0) / Scene::ray_test (any_hit = 1),

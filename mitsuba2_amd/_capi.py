@@ -126,6 +126,7 @@ class mi_counters(C.Structure):
 
 
 MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1
+MI_BVH_FORCE_TREE, MI_BVH_NO_LEAF_FILTER, MI_BVH_RADIX_TREE = 0x10, 0x20, 0x40      # flags of mi_bvh_build's quality argument
 MI_OK, MI_ERR_INVALID, MI_ERR_DEVICE, MI_ERR_STATE, MI_ERR_CANCELLED = 0, -1, -2, -3, -4
 MI_EVAL = dict(PCG32=0, SINCOS=1, COSINE_HEMISPHERE=2, BSDF=3, FRESNEL=4, CAMERA_RAY=5, EMITTER_SAMPLE=6,
                FP_SEMANTICS=7, SPECIAL=8, ENVMAP=9, INVTRIG=10, SPECTRUM=11, TEXTURE=12)

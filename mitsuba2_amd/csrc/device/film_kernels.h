@@ -286,6 +286,154 @@ __global__ __launch_bounds__(64) void k_film_groups(FilmRec F, BlockReplayArgs A
     }
 }
 
+// ---- the same replay with a COLUMN of texels per lane (round 4) ----
+//
+// k_film_groups is bound by its LDS reads (profiles/r03: 63 % LDS-array cycles): per (texel, sample) one 16-byte record and two
+// weights. A lane that owns the GH texels of one column of its group reads the record and the x weight ONCE for all of them —
+// 1 + 1 + GH reads per GH texel-samples instead of 3 GH — and the unpacking of the record is shared as well. A group is still GW x GH
+// texels with its own Morton-ordered pixel list, now GW lanes wide, so a wavefront serves 64 / GW groups; the groups of a block tile
+// are numbered row-major and dealt to the wavefronts sixteen at a time (no 8 x 8 patch geometry: a 36 x 36 tile is 9 x 18 groups of
+// 4 x 2 = 11 wavefronts with 14 idle group slots, against 25 patches of which 9 hang over the tile's edge). Every texel sees the same
+// float32 additions in the same order as before (its group's pixels in Morton order, each pixel's samples front to back;
+// w = wy * wx): the tiles are bit-identical to k_film_groups' and k_film_blocks'.
+template <int GW, int GH>
+__global__ __launch_bounds__(64) void k_film_columns(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = groups per tile row / column */, float *tiles) {
+    constexpr int NG = 64 / GW, LCAP = (GW + 4) * (GH + 4), PASSES = NG * MIW_FG_CHUNK / 64;
+    static_assert(PASSES >= 1 && 64 % GW == 0, "group shape");
+    extern __shared__ float s_w[];                           // (count + 1) x MIW_FG_WSTRIDE weights; row `count` = 0
+    __shared__ unsigned short s_list[NG][LCAP];
+    __shared__ uint32_t s_m[NG];
+    __shared__ uint4 s_rec[NG][MIW_FG_CHUNK + 1];
+    const uint32_t l = threadIdx.x;
+    const uint32_t n_groups = PA.patches_x * PA.patches_y, waves_per_tile = (n_groups + NG - 1) / NG;
+    const uint32_t tile = blockIdx.x / waves_per_tile, gid0 = (blockIdx.x % waves_per_tile) * NG;
+    const uint32_t b = A.tile_list ? A.tile_list[tile] : tile;
+    const BlockGeom g = block_geom(F, A.blocks_x, b);
+    const uint32_t h = l / GW, li = l % GW;
+    const uint32_t my_gid = gid0 + h;
+    const int tx = (int) (my_gid % PA.patches_x) * GW + (int) li, ty0 = (int) (my_gid / PA.patches_x) * GH;
+    const uint32_t rej = A.cls.count;                        // the zero row (LogSink16 logs rejected samples with class `count`)
+    for (uint32_t i = l; i < (rej + 1u) * MIW_FG_WSTRIDE; i += 64u) {
+        const uint32_t c = i / MIW_FG_WSTRIDE, a = i % MIW_FG_WSTRIDE;
+        s_w[i] = (c < rej && a < MIW_FC_STRIDE) ? A.cls.w[c * MIW_FC_STRIDE + a] : 0.f;
+    }
+    // ---- per group: the pixels within reach of the group, in Morton order ----
+    const int reach = A.cls.reach;
+    const uint32_t bs2 = 1u << A.bs2_log2, lane0 = tile << A.bs2_log2;
+    uint32_t fill[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) fill[i] = 0;
+    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
+        const uint32_t q = q0 + l;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        const bool pixel = q < bs2 && (int) x < g.bw && (int) y < g.bh;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const uint32_t gid = gid0 + (uint32_t) i;
+            const int gx0 = (int) (gid % PA.patches_x) * GW, gy0 = (int) (gid / PA.patches_x) * GH;
+            const bool in = pixel && gid < n_groups && gx0 < g.size_x && gy0 < g.size_y &&
+                            (int) x >= gx0 - F.border - reach && (int) x <= gx0 + GW - 1 - F.border + reach &&
+                            (int) y >= gy0 - F.border - reach && (int) y <= gy0 + GH - 1 - F.border + reach;
+            const unsigned long long m = __ballot(in);
+            if (in) {
+                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
+                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
+            }
+            fill[i] += (uint32_t) __popcll(m);
+        }
+    }
+    uint32_t max_m = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
+        if (l == 0) s_m[i] = m;
+        max_m = m > max_m ? m : max_m;
+    }
+    __syncthreads();
+
+    float acc[GH][MIW_FILM_CHANNELS];
+#pragma unroll
+    for (int r = 0; r < GH; ++r)
+#pragma unroll
+        for (int k = 0; k < MIW_FILM_CHANNELS; ++k) acc[r][k] = 0.f;
+    const uint32_t my_m = s_m[h];
+    const uint32_t pad_meta = film_pack_meta(rej, rej, false);
+    for (uint32_t k = 0; k < max_m; ++k) {
+        // this lane's offsets inside the window of its group's k-th pixel (LDS word offsets into a class's weights): one column, GH rows
+        uint32_t ox = 6u, oy[GH];
+#pragma unroll
+        for (int r = 0; r < GH; ++r) oy[r] = 6u;
+        if (k < my_m) {
+            uint32_t x, y;
+            morton_decode2((uint32_t) s_list[h][k], x, y);
+            const int ax = tx - ((int) x + F.border - reach), ay = ty0 - ((int) y + F.border - reach);
+            if ((uint32_t) ax <= (uint32_t) (2 * reach)) ox = (uint32_t) ax;
+#pragma unroll
+            for (int r = 0; r < GH; ++r) if ((uint32_t) (ay + r) <= (uint32_t) (2 * reach)) oy[r] = (uint32_t) (ay + r);
+        }
+        // staging rows of this step: pass i loads group i * (64 / CHUNK) + l / CHUNK, sample l % CHUNK
+        size_t row[PASSES]; uint32_t cnt[PASSES];
+        uint32_t step_max = 0;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const uint32_t hs = (uint32_t) i * (64u / MIW_FG_CHUNK) + l / MIW_FG_CHUNK;
+            cnt[i] = 0; row[i] = 0;
+            if (k < s_m[hs]) {
+                const uint32_t lane = lane0 + s_list[hs][k];
+                cnt[i] = A.st[lane].w; row[i] = (size_t) lane * A.spp;
+            }
+            step_max = cnt[i] > step_max ? cnt[i] : step_max;
+        }
+        step_max = wave_max_u32(step_max);
+        // (the next chunk's loads are in flight while the current one is replayed; unconditional, clamped — as in k_film_groups)
+        const uint32_t jj = l % MIW_FG_CHUNK;
+        uint4 nr[PASSES];
+        auto fetch = [&](uint32_t j0) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const uint32_t j = j0 + jj, last = cnt[i] ? cnt[i] - 1u : 0u;
+                const U4 t = A.log_rec[row[i] + (j < last ? j : last)];
+                nr[i] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        };
+        fetch(0);
+        for (uint32_t j0 = 0; j0 < step_max; j0 += MIW_FG_CHUNK) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                uint4 r = nr[i];
+                r.w = j0 + jj < cnt[i] ? r.w : pad_meta;
+                s_rec[(uint32_t) i * (64u / MIW_FG_CHUNK) + l / MIW_FG_CHUNK][jj] = r;
+            }
+            fetch(j0 + MIW_FG_CHUNK);
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < MIW_FG_CHUNK; ++s) {
+                const uint4 r = s_rec[h][s];
+                const float wx = s_w[(r.w & 255u) * MIW_FG_WSTRIDE + ox];
+                const float *wy = s_w + ((r.w >> 8) & 255u) * MIW_FG_WSTRIDE;
+                const float vx = u2f(r.x), vy = u2f(r.y), vz = u2f(r.z);
+                const bool alpha = (r.w & 0x10000u) != 0u;
+#pragma unroll
+                for (int q = 0; q < GH; ++q) {
+                    const float w = wy[oy[q]] * wx;                          // wy * wx, imageblock.cpp:155
+                    acc[q][0] += vx * w; acc[q][1] += vy * w; acc[q][2] += vz * w;
+                    acc[q][3] += alpha ? w : 0.f;                            // alpha (0 or 1) * w
+                    acc[q][4] += w;
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GH; ++r)
+        if (my_gid < n_groups && tx < g.size_x && ty0 + r < g.size_y) {
+            float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) (ty0 + r) * g.size_x + tx) * MIW_FILM_CHANNELS;
+#pragma unroll
+            for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = acc[r][k];
+        }
+}
+
 // step 2: every film texel sums the block tiles covering it, ascending block id
 __global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64, int accumulate) {
     int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;

@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "envmap_build.h"
 #include "film_classes.h"
 #include "lbvh_device.h"
-#include "ploc_device.h"
+#include "sah_device.h"
 #include "bvh4_device.h"
 
 using namespace miw;
@@ -445,7 +445,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (!c->have_scene) return fail(c, MI_ERR_STATE, "mi_bvh_build: no scene uploaded");
     const bool force_tree = (quality & MI_BVH_FORCE_TREE) != 0;
     const int32_t quality_flags = quality;
-    quality &= ~(MI_BVH_FORCE_TREE | MI_BVH_NO_LEAF_FILTER);
+    quality &= ~(MI_BVH_FORCE_TREE | MI_BVH_NO_LEAF_FILTER | MI_BVH_RADIX_TREE);
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
@@ -473,81 +473,95 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                                 d_span.release(); d_first.release(); };
         HIP_TRY(c, d_in.upload(c->tris_in, s));
         if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_in.upload(c->tri_vn_in, s));
-        HIP_TRY(c, d_keys.resize(n)); HIP_TRY(c, d_keys_sorted.resize(n)); HIP_TRY(c, d_bounds.resize(6));
-        HIP_TRY(c, d_arrivals.resize(n)); HIP_TRY(c, d_height.resize(n)); HIP_TRY(c, d_boxes.resize((size_t) 2 * n));
-        HIP_TRY(c, d_inner.resize(n)); HIP_TRY(c, d_leaf_parent.resize(n)); HIP_TRY(c, d_span.resize(n)); HIP_TRY(c, d_first.resize(n));
-        HIP_TRY(c, c->d_nodes.resize(n)); HIP_TRY(c, c->d_tris.resize(n));
+        HIP_TRY(c, c->d_nodes.resize(n)); HIP_TRY(c, c->d_tris.resize(n)); HIP_TRY(c, d_height.resize(n));
         if (!c->tri_vn_in.empty()) HIP_TRY(c, c->d_tri_vn.resize((size_t) n * 9));
-        const uint32_t init_bounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-        HIP_TRY(c, hipMemcpyAsync(d_bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipMemsetAsync(d_arrivals.p, 0, (size_t) n * sizeof(uint32_t), s));
-        HIP_TRY(c, hipMemsetAsync(d_height.p, 0, (size_t) n * sizeof(uint32_t), s));
         const dim3 blk(256), grd((unsigned) ((n + 255) / 256));
-        hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<unsigned>(grd.x, 1024u)), blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p);
-        hipLaunchKernelGGL(k_lbvh_morton, grd, blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p, d_keys.p);
-        size_t tmp_bytes = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
-        HIP_TRY(c, d_tmp.resize(tmp_bytes + 16));
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
-        // box padding (bvh.h, bvh_build.h: scene_pad_unit): 2e-5 x the largest |coordinate|
-        uint32_t hb[6];
-        HIP_TRY(c, hipMemcpyAsync(hb, d_bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        float m = 0.f;
-        for (int k = 0; k < 6; ++k) { uint32_t o = hb[k]; float f = u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); m = std::max(m, std::fabs(f)); }
-        const float pad = 2.f * std::max(1e-5f * m, 1e-30f);
-        // The topology: PLOC (ploc_device.h — Morton order + surface-area clustering: the default since round 4) or the radix tree of
-        // lbvh_device.h (MIW_DEVICE_BUILDER=lbvh: A/B runs, and the fallback should the clustering not finish). Both deliver BvhNode
-        // records with root 0, triangles in leaf order and the BVH2 heights (d_height) the 4-wide collapse below asks for.
-        bool use_ploc = !(getenv("MIW_DEVICE_BUILDER") && !strcmp(getenv("MIW_DEVICE_BUILDER"), "lbvh"));
-        uint32_t ploc_rounds = 0;
-        if (use_ploc) {
-            uint32_t radius = 16u;
-            if (const char *e = getenv("MIW_PLOC_RADIUS")) radius = (uint32_t) std::min(64, std::max(1, atoi(e)));
-            const uint32_t un = (uint32_t) n;
-            TmpBuf<Tri> d_sorted; TmpBuf<float> d_vn_sorted; TmpBuf<uint32_t> d_count, d_ca, d_cb, d_partner, d_offset; TmpBuf<int32_t> d_left, d_right, d_parent;
-            TmpBuf<unsigned long long> d_flags, d_scan; TmpBuf<PlocState> d_state; TmpBuf<unsigned char> d_scan_tmp;
-            HIP_TRY(c, d_sorted.resize(un)); if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_sorted.resize((size_t) un * 9));
-            HIP_TRY(c, d_count.resize(2 * (size_t) un)); HIP_TRY(c, d_parent.resize(2 * (size_t) un)); HIP_TRY(c, d_left.resize(un)); HIP_TRY(c, d_right.resize(un));
-            HIP_TRY(c, d_ca.resize(un)); HIP_TRY(c, d_cb.resize(un)); HIP_TRY(c, d_partner.resize(un)); HIP_TRY(c, d_offset.resize(2 * (size_t) un));
-            HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_scan.resize(un)); HIP_TRY(c, d_state.resize(2));
+        // Which device builder. Default: the level-by-level binned-SAH sweep (sah_device.h) — the host builder's tree, node for node.
+        // MI_BVH_RADIX_TREE / MIW_DEVICE_BUILDER=lbvh: the radix tree over Morton codes of rounds 2 - 3 (lbvh_device.h; measured 7 % / 16 % behind the SAH
+        // tree on the interior / the material balls: A/B runs). A scene the sweep hands back (need_host: coincident centroids) takes
+        // the host builder, like quality 1.
+        enum { DEV_SAH = 0, DEV_LBVH = 1 } dev_builder = (quality_flags & MI_BVH_RADIX_TREE) ? DEV_LBVH : DEV_SAH;
+        if (const char *e = getenv("MIW_DEVICE_BUILDER")) dev_builder = !strcmp(e, "lbvh") ? DEV_LBVH : DEV_SAH;
+        bool sah_need_host = false;
+        if (dev_builder == DEV_SAH) {
+            const uint32_t un = (uint32_t) n, max_leaf = 4u;              // (bvh_build_sah's default leaf size: the same tree)
+            const float pad = 2.f * scene_pad_unit(c->tris_in);
+            TmpBuf<SahPrim> d_prim; TmpBuf<uint32_t> d_ia, d_ib, d_flags, d_rank; TmpBuf<SahCand> d_ca, d_cb; TmpBuf<SahDecision> d_dec; TmpBuf<SahState> d_state;
+            TmpBuf<unsigned char> d_scan_tmp;
+            HIP_TRY(c, d_prim.resize(un)); HIP_TRY(c, d_ia.resize(un)); HIP_TRY(c, d_ib.resize(un)); HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_rank.resize(un));
+            HIP_TRY(c, d_ca.resize(un)); HIP_TRY(c, d_cb.resize(un)); HIP_TRY(c, d_dec.resize(un)); HIP_TRY(c, d_state.resize(1));
             size_t scan_bytes = 0;
-            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags.p, d_scan.p, n, s));
+            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags.p, d_rank.p, n, s));
             HIP_TRY(c, d_scan_tmp.resize(scan_bytes + 16));
-            hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
-                               un, pad, d_sorted.p, c->tri_vn_in.empty() ? (float *) nullptr : d_vn_sorted.p, d_boxes.p);
-            hipLaunchKernelGGL(k_ploc_init, dim3((2u * un + 255u) / 256u), blk, 0, s, un, d_ca.p, d_count.p, d_parent.p, d_state.p);
-            PlocTree T{ reinterpret_cast<PlocBox *>(d_boxes.p), d_count.p, d_left.p, d_right.p, d_parent.p, d_height.p };
-            uint32_t bound = un; bool done = false;
-            for (uint32_t round = 0; round < 1024u && !done; round += 8u) {
-                for (uint32_t k = 0; k < 8u; ++k) {                // eight rounds between two looks at the cluster count
-                    const uint32_t t = round + k;
-                    const PlocState *st = d_state.p + (t & 1u); PlocState *st_next = d_state.p + ((t + 1u) & 1u);
-                    const uint32_t *cur = (t & 1u) ? d_cb.p : d_ca.p; uint32_t *nxt = (t & 1u) ? d_ca.p : d_cb.p;
-                    const dim3 g((bound + 255u) / 256u);
-                    hipLaunchKernelGGL(k_ploc_partner, g, blk, 0, s, st, cur, reinterpret_cast<const PlocBox *>(d_boxes.p), radius, d_partner.p);
-                    hipLaunchKernelGGL(k_ploc_flags, g, blk, 0, s, st, d_partner.p, bound, d_flags.p);
-                    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_scan.p, (int) bound, s));
-                    hipLaunchKernelGGL(k_ploc_apply, g, blk, 0, s, st, st_next, cur, d_partner.p, d_scan.p, un, lbvh_leaf, T, nxt);
-                }
-                PlocState h;
-                HIP_TRY(c, hipMemcpyAsync(&h, d_state.p + ((round + 8u) & 1u), sizeof h, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const auto t_setup = std::chrono::steady_clock::now();     // (uploads and allocations behind us)
+            hipLaunchKernelGGL(k_sah_prims, grd, blk, 0, s, d_in.p, un, pad, d_prim.p, d_ia.p);
+            const SahCand root = { 0u, un, -1, 0u };
+            HIP_TRY(c, hipMemcpyAsync(d_ca.p, &root, sizeof root, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemsetAsync(d_state.p, 0, sizeof(SahState), s));
+            std::vector<uint32_t> level_start{ 0u };
+            uint32_t n_cand = 1u, base = 0u, level = 0u;
+            while (n_cand > 0u && !sah_need_host) {
+                const SahCand *cur = (level & 1u) ? d_cb.p : d_ca.p; SahCand *nxt = (level & 1u) ? d_ca.p : d_cb.p;
+                const uint32_t *ic = (level & 1u) ? d_ib.p : d_ia.p; uint32_t *in = (level & 1u) ? d_ia.p : d_ib.p;
+                const bool big = n_cand <= 512u;                         // few, large candidates: 1024 threads each; many: one wavefront each
+                if (big) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p);
+                else     hipLaunchKernelGGL(k_sah_decide<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p);
+                HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_rank.p, (int) n_cand, s));
+                hipLaunchKernelGGL(k_sah_totals, dim3(1), dim3(1), 0, s, d_flags.p, d_rank.p, n_cand, d_state.p);
+                if (big) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt);
+                else     hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt);
+                SahState h;
+                HIP_TRY(c, hipMemcpyAsync(&h, d_state.p, sizeof h, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
-                ploc_rounds = round + 8u;
-                bound = h.m; done = h.m <= 1u && h.created == un - 1u;
-            }
-            HIP_TRY(c, hipGetLastError());
-            if (done) {
-                hipLaunchKernelGGL(k_ploc_offsets, dim3((2u * un + 255u) / 256u), blk, 0, s, T, un, d_offset.p);
-                hipLaunchKernelGGL(k_ploc_scatter, grd, blk, 0, s, d_sorted.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_sorted.p, d_offset.p, un,
-                                   c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p);
-                hipLaunchKernelGGL(k_ploc_emit, grd, blk, 0, s, T, d_offset.p, un, lbvh_leaf, c->d_nodes.p);
                 HIP_TRY(c, hipGetLastError());
-                HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));              // (the temporaries above go out of scope here)
-            } else use_ploc = false;                               // cannot happen (every round merges at least one pair); then: the radix tree
-        }
-        if (!use_ploc) {
+                sah_need_host = h.need_host != 0u || level >= 62u || (uint64_t) base + h.n_inner > (uint64_t) un - 1u;
+                depth = level;
+                base += h.n_inner; level_start.push_back(base);
+                n_cand = 2u * h.n_inner; ++level;
+            }
+            const auto t_levels = std::chrono::steady_clock::now();
+            if (!sah_need_host) {
+                for (size_t L = level_start.size() - 1; L-- > 0;) {
+                    const uint32_t cnt = level_start[L + 1] - level_start[L];
+                    if (cnt) hipLaunchKernelGGL(k_sah_heights, dim3((cnt + 255u) / 256u), blk, 0, s, c->d_nodes.p, level_start[L], level_start[L + 1], d_height.p);
+                }
+                const uint32_t *idx_final = (level & 1u) ? d_ib.p : d_ia.p;
+                hipLaunchKernelGGL(k_sah_gather, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, idx_final, un,
+                                   c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipStreamSynchronize(s));
+                node_count = base;
+                built_on_device = true;
+                c->counters.bvh_builder = 3u;
+                if (getenv("MIW_DEBUG")) {
+                    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                    fprintf(stderr, "[miwave] device builder: binned SAH by levels, %u triangles, %u inner nodes, depth %u; upload + allocations %.2f ms, %u levels %.2f ms, heights + gather %.2f ms\n",
+                            un, node_count, depth, ms(t0, t_setup), level, ms(t_setup, t_levels), ms(t_levels, std::chrono::steady_clock::now()));
+                }
+            }
+        } else {
+            HIP_TRY(c, d_keys.resize(n)); HIP_TRY(c, d_keys_sorted.resize(n)); HIP_TRY(c, d_bounds.resize(6));
+            HIP_TRY(c, d_arrivals.resize(n)); HIP_TRY(c, d_boxes.resize((size_t) 2 * n));
+            HIP_TRY(c, d_inner.resize(n)); HIP_TRY(c, d_leaf_parent.resize(n)); HIP_TRY(c, d_span.resize(n)); HIP_TRY(c, d_first.resize(n));
+            const uint32_t init_bounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+            HIP_TRY(c, hipMemcpyAsync(d_bounds.p, init_bounds, sizeof init_bounds, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemsetAsync(d_arrivals.p, 0, (size_t) n * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(d_height.p, 0, (size_t) n * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<unsigned>(grd.x, 1024u)), blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p);
+            hipLaunchKernelGGL(k_lbvh_morton, grd, blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p, d_keys.p);
+            size_t tmp_bytes = 0;
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+            HIP_TRY(c, d_tmp.resize(tmp_bytes + 16));
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+            // box padding (bvh.h, bvh_build.h: scene_pad_unit): 2e-5 x the largest |coordinate|
+            uint32_t hb[6];
+            HIP_TRY(c, hipMemcpyAsync(hb, d_bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            float m = 0.f;
+            for (int k = 0; k < 6; ++k) { uint32_t o = hb[k]; float f = u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); m = std::max(m, std::fabs(f)); }
+            const float pad = 2.f * std::max(1e-5f * m, 1e-30f);
+            // the radix tree over the Morton order (lbvh_device.h)
             HIP_TRY(c, hipMemsetAsync(d_height.p, 0, (size_t) n * sizeof(uint32_t), s));
             hipLaunchKernelGGL(k_lbvh_leaves, grd, blk, 0, s, d_in.p, c->tri_vn_in.empty() ? (const float *) nullptr : d_vn_in.p, d_keys_sorted.p,
                                (uint32_t) n, pad, c->d_tris.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn.p, d_boxes.p);
@@ -557,14 +571,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-        }
-        c->counters.bvh_builder = use_ploc ? 2u : 1u;
-        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] device builder: %s, %u triangles, height %u%s\n", use_ploc ? "PLOC" : "LBVH", (uint32_t) n, depth,
-                                         use_ploc ? (", " + std::to_string(ploc_rounds) + " rounds enqueued").c_str() : "");
+            c->counters.bvh_builder = 1u;
+            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] device builder: LBVH, %u triangles, height %u\n", (uint32_t) n, depth);
         node_count = (uint32_t) (n - 1);
         built_on_device = depth <= MIW_BVH_MAX_DEPTH;     // deeper (many coincident centroids): take the SAH builder
+        }
         // ---- the 4-wide tree of the phase machine, collapsed level by level on the device (bvh4_device.h); the heights the
-        // collapse's fit test needs are k_lbvh_fit's. MIW_BVH4_HOST=1 keeps round 2's read-back + host collapse (A/B runs) ----
+        // collapse's fit test needs are the builder's (k_sah_heights / k_lbvh_fit). MIW_BVH4_HOST=1 keeps round 2's read-back + host collapse (A/B runs) ----
         const uint32_t budget4 = MIW_STACK_ENTRIES - 1;    // one entry of slack: the node body's unconditional stores
         if (built_on_device && wide_on && depth <= budget4 && !getenv("MIW_NO_STACK") && !getenv("MIW_BVH4_HOST")) {
             auto t4 = std::chrono::steady_clock::now();
@@ -1423,7 +1436,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
 #define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
-                    if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
+                    // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups)
+#define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
+                                   const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
+                                   MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
+                    int columns = 42;
+                    if (const char *e = getenv("MIW_FILM_COLUMNS")) columns = atoi(e);
+                    if (columns == 42) MIW_FC_LAUNCH(4, 2); else if (columns == 44) MIW_FC_LAUNCH(4, 4); else if (columns == 82) MIW_FC_LAUNCH(8, 2);
+                    else if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
+#undef MIW_FC_LAUNCH
 #undef MIW_FG_LAUNCH
                 } else if (wide)
                     MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));

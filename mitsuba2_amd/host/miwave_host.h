@@ -470,7 +470,7 @@ public:
     void add_emitter(std::shared_ptr<EnvironmentMapEmitter> env);
     const EnvironmentMapEmitter *environment() const { return m_env.get(); }   // scene.h:150-151
     // finishes construction: default BSDFs (shape.cpp:75-81), flatten, upload, build accel (scene.cpp:94-97)
-    void build(int device = 0, int bvh_quality = 1);
+    void build(int device = 0, int bvh_quality = 0);   // 0: the binned-SAH tree built on the device (csrc/sah_device.h), 1: by the host recursion
     const std::vector<std::shared_ptr<Mesh>> &shapes() const { return m_shapes; }
     size_t emitter_count() const { return m_emitters.size(); }
     std::array<float, 6> bbox() const;                         // Scene::bbox(): union of the shapes' boxes

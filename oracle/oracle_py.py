@@ -46,8 +46,7 @@ class Oracle:
         L.emu_trace4.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
                                  C.c_int, C.c_int, C.c_int, C.c_int, c_u32_p, C.c_uint32]
         L.emu_trace4.restype = C.c_int
-        L.emu_set_builder.argtypes = [C.c_int, C.c_uint32]; L.emu_set_builder.restype = None
-        L.emu_bvh_stats.argtypes = [C.POINTER(mi_scene_desc), C.c_int, c_u32_p, c_double_p]; L.emu_bvh_stats.restype = C.c_int
+        L.emu_sah_levels_check.argtypes = [C.POINTER(mi_scene_desc), C.c_int, c_u32_p]; L.emu_sah_levels_check.restype = C.c_int
         L.emu_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_double_p, c_float_p, C.POINTER(C.c_uint64)]
         L.emu_render.restype = C.c_int
         L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]; L.orc_tea_float32.restype = C.c_float
@@ -139,17 +138,14 @@ class Oracle:
         out["bvh"] = list(stats)
         return out
 
-    def emu_set_builder(self, builder, ploc_radius=16):
-        """0: the emulator builds its trees with the binned-SAH host builder (default); 1: with the host run of the PLOC builder
-        (csrc/ploc_build.h — the per-element steps of the device builder behind mi_bvh_build quality 0)"""
-        self.L.emu_set_builder(int(builder), int(ploc_radius))
-
-    def emu_bvh_stats(self, desc, max_leaf=4):
-        stats = (C.c_uint32 * 7)(); cost = C.c_double(0)
-        if self.L.emu_bvh_stats(desc, int(max_leaf), stats, C.byref(cost)) != 0:
-            raise RuntimeError("emu_bvh_stats failed")
-        d = dict(zip(("nodes", "tris", "depth", "rounds", "in_leaves", "wrong", "bad_box"), list(stats)))
-        d["sah_cost"] = cost.value
+    def emu_sah_levels_check(self, desc, max_leaf=4):
+        """the level-by-level binned-SAH builder (csrc/sah_levels.h, what the device runs) against the recursive host builder"""
+        stats = (C.c_uint32 * 6)()
+        rc = self.L.emu_sah_levels_check(desc, int(max_leaf), stats)
+        if rc < 0:
+            raise RuntimeError("emu_sah_levels_check failed")
+        d = dict(zip(("nodes_recursive", "nodes_levels", "node_diff", "depth_recursive", "depth_levels", "leaf_diff"), list(stats)))
+        d["need_host"] = rc == 1
         return d
 
     def emu_trace4(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, stack_budget=32, max_fan=4, schedule=0, spec=True):

@@ -22,7 +22,7 @@
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 #include "../mitsuba2_amd/csrc/bvh4_build.h"
-#include "../mitsuba2_amd/csrc/ploc_build.h"
+#include "../mitsuba2_amd/csrc/sah_levels.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
 #include "../mitsuba2_amd/csrc/rect_build.h"
 #include "../mitsuba2_amd/csrc/texture_build.h"
@@ -39,10 +39,6 @@ struct EmuScene {
     SceneView view{};
 };
 
-// which host builder emu_build uses: 0 = binned SAH (bvh_build.h), 1 = PLOC (ploc_build.h: the per-element steps of the device
-// builder of mi_bvh_build quality 0, run in plain loops)
-static int g_emu_builder = 0;
-static uint32_t g_emu_ploc_radius = 16;
 bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     o.tris_in.assign(s->face_count, Tri{});
     o.shapes.resize(s->shape_count);
@@ -135,8 +131,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
         if (!o.env.ok) return false;
         o.env.rec.data = o.env.data.data(); o.env.rec.levels = o.env.levels.data();
     }
-    if (g_emu_builder == 1) o.bvh = ploc_build_host(o.tris_in, -1.f, (uint32_t) max_leaf, g_emu_ploc_radius);
-    else o.bvh = bvh_build_sah(o.tris_in, -1.f, (uint32_t) max_leaf);
+    o.bvh = bvh_build_sah(o.tris_in, -1.f, (uint32_t) max_leaf);
     if (!o.vn_in.empty()) {
         o.vn_leaf.resize(o.vn_in.size());
         for (size_t i = 0; i < o.bvh.order.size(); ++i) std::memcpy(&o.vn_leaf[i * 9], &o.vn_in[(size_t) o.bvh.order[i] * 9], 36);
@@ -207,50 +202,35 @@ struct EmuCoin {                                                // xorshift32: t
 
 extern "C" {
 
-void emu_set_builder(int builder, uint32_t ploc_radius) { g_emu_builder = builder; g_emu_ploc_radius = ploc_radius ? ploc_radius : 16u; }
-
-// What the selected host builder makes of the scene's triangles: stats7 = inner nodes, triangles, depth (BVH2 height), PLOC rounds,
-// triangles found in leaves, triangles found twice or never (must be 0), leaf boxes that do not contain their triangles (must be 0);
-// *sah_cost = bvh2_sah_cost (ploc_build.h).
-int emu_bvh_stats(const mi_scene_desc *scene, int max_leaf, uint32_t *stats7, double *sah_cost) {
+// The level-by-level restatement of the binned-SAH builder (csrc/sah_levels.h: what the device builder runs) against the recursive
+// host builder (csrc/bvh_build.h) on the scene's triangles. stats6 = inner nodes (recursive), inner nodes (levels), node records that
+// differ (must be 0), depth (recursive), depth (levels), leaf ranges whose triangle SETS differ (must be 0); returns 1 when the level
+// sweep asks for the host builder (need_host), 0 otherwise.
+int emu_sah_levels_check(const mi_scene_desc *scene, int max_leaf, uint32_t *stats6) {
     EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
-    const std::vector<BvhNode> &nodes = sc.bvh.nodes;
-    const uint32_t n = (uint32_t) sc.bvh.tris.size();
-    std::vector<uint32_t> seen(n, 0u); uint32_t in_leaves = 0, bad_box = 0, rounds = 0;
-    if (g_emu_builder == 1) rounds = ploc_build_host(sc.tris_in, -1.f, (uint32_t) max_leaf, g_emu_ploc_radius).rounds;
-    std::vector<int32_t> stack{ 0 };
-    while (!stack.empty()) {
-        const BvhNode &nd = nodes[stack.back()]; stack.pop_back();
-        const int32_t ch[2] = { nd.child0, nd.child1 }; const float *lo[2] = { nd.lo0, nd.lo1 }, *hi[2] = { nd.hi0, nd.hi1 };
-        for (int k = 0; k < 2; ++k) {
-            if (!(lo[k][0] <= hi[k][0])) continue;
-            if (ch[k] >= 0) {
-                stack.push_back(ch[k]);
-                const BvhNode &c = nodes[ch[k]];                     // a child's two boxes lie inside the box its parent holds for it
-                for (int a = 0; a < 3; ++a) {
-                    if ((c.lo0[a] <= c.hi0[a] && (c.lo0[a] < lo[k][a] || c.hi0[a] > hi[k][a])) || (c.lo1[a] <= c.hi1[a] && (c.lo1[a] < lo[k][a] || c.hi1[a] > hi[k][a]))) { ++bad_box; break; }
-                }
-                continue;
-            }
-            const uint32_t code = (uint32_t) ~ch[k], first = code >> 4, count = (code & 15u) + 1u;
-            for (uint32_t i = first; i < first + count && i < n; ++i) {
-                seen[i]++; ++in_leaves;
-                const Tri &t = sc.bvh.tris[i];
-                for (int a = 0; a < 3; ++a) {
-                    const float tl = std::min(t.p0[a], std::min(t.p1[a], t.p2[a])), th = std::max(t.p0[a], std::max(t.p1[a], t.p2[a]));
-                    if (tl < lo[k][a] || th > hi[k][a]) { ++bad_box; break; }
-                }
+    const SahLevelsResult lv = sah_build_levels_host(sc.tris_in, -1.f, (uint32_t) max_leaf);
+    const BvhBuildResult &ref = sc.bvh;
+    uint32_t diff = 0, leaf_diff = 0;
+    if (!lv.need_host) {
+        const size_t m = std::min(ref.nodes.size(), lv.nodes.size());
+        for (size_t i = 0; i < m; ++i) diff += std::memcmp(&ref.nodes[i], &lv.nodes[i], sizeof(BvhNode)) != 0;
+        diff += (uint32_t) (std::max(ref.nodes.size(), lv.nodes.size()) - m);
+        for (size_t i = 0; i < m; ++i) {
+            const int32_t ch[2] = { ref.nodes[i].child0, ref.nodes[i].child1 };
+            for (int k = 0; k < 2; ++k) {
+                if (ch[k] >= 0) continue;
+                const uint32_t code = (uint32_t) ~ch[k], first = code >> 4, count = (code & 15u) + 1u;
+                std::vector<uint32_t> a(ref.order.begin() + first, ref.order.begin() + first + count), b(lv.order.begin() + first, lv.order.begin() + first + count);
+                std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+                leaf_diff += a != b;
             }
         }
+        // the heights the 4-wide collapse takes from the builder == the ones it computes itself from the nodes
+        const std::vector<uint32_t> h2 = bvh2_heights(lv.nodes);
+        for (size_t i = 0; i < lv.nodes.size(); ++i) diff += h2[i] != lv.height[i];
     }
-    uint32_t wrong = 0;
-    for (uint32_t i = 0; i < n; ++i) wrong += seen[i] != 1u;
-    std::vector<uint32_t> order_seen(n, 0u);                              // `order` is a permutation and tris[i] is input triangle order[i]
-    for (uint32_t i = 0; i < n; ++i) { if (sc.bvh.order[i] < n) order_seen[sc.bvh.order[i]]++; if (std::memcmp(&sc.bvh.tris[i], &sc.tris_in[sc.bvh.order[i] < n ? sc.bvh.order[i] : 0], sizeof(Tri))) ++wrong; }
-    for (uint32_t i = 0; i < n; ++i) wrong += order_seen[i] != 1u;
-    if (stats7) { stats7[0] = (uint32_t) nodes.size(); stats7[1] = n; stats7[2] = sc.bvh.depth; stats7[3] = rounds; stats7[4] = in_leaves; stats7[5] = wrong; stats7[6] = bad_box; }
-    if (sah_cost) *sah_cost = bvh2_sah_cost(nodes);
-    return 0;
+    if (stats6) { stats6[0] = (uint32_t) ref.nodes.size(); stats6[1] = (uint32_t) lv.nodes.size(); stats6[2] = diff; stats6[3] = ref.depth; stats6[4] = lv.depth; stats6[5] = leaf_diff; }
+    return lv.need_host ? 1 : 0;
 }
 
 // stackless BVH (host SAH build, `max_leaf` triangles per leaf) over caller rays

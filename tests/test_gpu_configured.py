@@ -96,10 +96,10 @@ def test_c3_window_at_1024spp_is_the_oracles(native):
     scene, _ = scenes.cornell_box(W, H, 1024, diffuse_only=False, device=-1)
     job = G.crop_job(native, scenes, 1024, x, y, w, h, n_threads=256)
     dev = native.Device(0)
-    for quality in (1, 0):
+    for quality in (1, 0, 0x40):                                        # host recursion, the same tree built on the device, the radix tree
         dev.upload(scene.desc(), bvh_quality=quality)
         c = dev.counters()
-        assert c.bvh_tris == 40972 and c.bvh_on_device == (0 if quality else 1)
+        assert c.bvh_tris == 40972 and c.bvh_builder == {1: 0, 0: 3, 0x40: 1}[quality]
         film, st = dev.render(job)
         c = dev.counters()
         assert st == 0 and c.plan == 2 and c.path_kernel == 1 and c.film_mode == 1
@@ -173,7 +173,7 @@ def test_fuzz_recipes_on_the_device(native, first):
         ikw = dict(ikw); ikw.pop("samples_per_pass", None)
         integ = native.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else native.PathIntegrator
         job = integ(**ikw).render_job(sensor)
-        for quality in (1, 0):
+        for quality in (0, 0x40):                                       # the SAH tree built on the device, the radix tree
             dev.upload(scene.desc(), bvh_quality=quality)
             for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):      # the direct integrator runs on the resident plan
                 film, st = dev.render(job, plan=plan)

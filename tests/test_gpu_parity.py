@@ -182,9 +182,9 @@ def test_device_lbvh_matches_brute_force(native, oracle, n_tri):
     v[3:12] = v[0:9]                                    # coincident triangles: identical Morton codes, t ties
     scene = api.Scene([api.Mesh("soup", v, f)]).build(-1)
     d = native.Device(0)
-    d.upload(scene.desc(), bvh_quality=0)
+    d.upload(scene.desc(), bvh_quality=0x40)            # MI_BVH_RADIX_TREE: the radix tree over the Morton codes
     c = d.counters()
-    assert c.bvh_on_device == 1 and c.bvh_tris == n_tri and c.bvh_nodes == n_tri - 1 and 10 < c.bvh_depth <= 62
+    assert c.bvh_on_device == 1 and c.bvh_builder == 1 and c.bvh_tris == n_tri and c.bvh_nodes == n_tri - 1 and 10 < c.bvh_depth <= 62
     rng = np.random.default_rng(22)
     n = 4000
     o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
@@ -477,7 +477,7 @@ def test_resident_leaf_filter_equals_full_sweep(native, oracle):
     assert inner.sum() == 12 * 28 * 28 and np.array_equal(films[0][inner], o32[inner])
 
 
-@pytest.mark.parametrize("quality", [1, 0])
+@pytest.mark.parametrize("quality", [0, 0x40])
 def test_interior_scene_crop_parity(native, oracle, quality):
     """BASELINE config 4 class at full geometric scale (911 362 triangles, area light + environment map, all three
     BSDFs with shading normals): a 24 x 16 crop window rendered on the device (SAH and device-LBVH trees, LDS-stack
@@ -489,7 +489,7 @@ def test_interior_scene_crop_parity(native, oracle, quality):
     d = native.Device(0)
     d.upload(scene.desc(), bvh_quality=quality)
     c = d.counters()
-    assert c.bvh_tris == 911362 and c.bvh_on_device == (1 if quality == 0 else 0)
+    assert c.bvh_tris == 911362 and c.bvh_builder == (3 if quality == 0 else 1)
     g32, st = d.render(job)
     c = d.counters()
     assert st == 0 and c.samples == ost.samples == 24 * 16 * 2 and c.segments == ost.segments
@@ -579,16 +579,16 @@ def test_full_size_c3_structures_agree(native, oracle):
     scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=False, device=-1)
     job = native.PathIntegrator().render_job(sensor)
     dev = native.Device(0)
-    dev.upload(scene.desc())                                       # host binned SAH
+    dev.upload(scene.desc())                                       # the binned-SAH tree (built on the device)
     a, st = dev.render(job)
     ca = dev.counters()
-    assert st == 0 and ca.samples == W * H * SPP and ca.plan == 2 and ca.bvh_on_device == 0 and ca.bvh_tris == 40972
+    assert st == 0 and ca.samples == W * H * SPP and ca.plan == 2 and ca.bvh_builder == 3 and ca.bvh_tris == 40972
     p1, _ = dev.render(job, plan=1)
     assert dev.counters().plan == 1 and np.array_equal(p1, a)
-    dev.upload(scene.desc(), bvh_quality=0)                        # device LBVH: another tree, same answers
+    dev.upload(scene.desc(), bvh_quality=0x40)                     # MI_BVH_RADIX_TREE: another tree, same answers
     b, _ = dev.render(job)
     cb = dev.counters()
-    assert cb.bvh_on_device == 1 and cb.segments == ca.segments and np.array_equal(b, a)
+    assert cb.bvh_builder == 1 and cb.segments == ca.segments and np.array_equal(b, a)
     assert np.isfinite(a).all() and 3.0 < ca.segments / ca.samples < 5.0
     dev.close()
 
@@ -621,7 +621,7 @@ def test_placed_queues_and_priorities_do_not_change_the_film(native, which):
     from mitsuba2_amd import scenes
     scene, sensor = scenes.cornell_box(1920, 1080, 128, diffuse_only=(which == "packets"), device=-1)
     dev = native.Device(0)
-    dev.upload(scene.desc(), bvh_quality=0 if which == "tree_lbvh" else 1)
+    dev.upload(scene.desc(), bvh_quality=0x40 if which == "tree_lbvh" else 0)
     assert dev.counters().bvh_tris == (32 if which == "packets" else 40972)
     integ = native.PathIntegrator(); integ.set_shard(0, 8)
     job = integ.render_job(sensor)
@@ -637,4 +637,37 @@ def test_placed_queues_and_priorities_do_not_change_the_film(native, which):
         assert st == 0 and c.samples > 0
         assert c.placed == (1 if name == "default" else 0) and c.n_path == (2 if name == "default" else 1)
     assert np.array_equal(films["default"], films["plain"]) and films["default"][..., 4].max() > 0
+    dev.close()
+
+
+@pytest.mark.parametrize("which", ["matball", "interior"])
+def test_device_builder_builds_the_host_builders_tree(native, which):
+    """mi_bvh_build quality 0 (csrc/sah_device.h: the binned-SAH builder run level by level on the GPU) against quality 1 (the host
+    recursion, csrc/bvh_build.h): same inner-node count, same depth, the 4-wide tree collapsed on the device, and the same film —
+    on the 41 k-triangle material balls and the 0.9 M-triangle interior (ShapeKDTree::build's place, src/librender/scene_native.inl:3-10;
+    the reference's GPU mode builds on the device, include/mitsuba/render/optix/shapes.h:72-167)."""
+    import sys
+    from mitsuba2_amd import scenes
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_r3 as G
+    if which == "matball":
+        scene, _ = scenes.cornell_box(1920, 1080, 16, diffuse_only=False, device=-1)
+        x, y, w, h = G.C3_WINDOW
+    else:
+        scene, _ = scenes.interior_scene(1920, 1080, 16, device=-1)
+        x, y, w, h = G.C4_WINDOWS["clutter"]
+    job = G.crop_job(native, scenes, 16, x, y, w, h, n_threads=64)
+    dev = native.Device(0)
+    got = {}
+    for quality in (1, 0, 0):                                          # (the second quality-0 build: a warm one, for the time)
+        dev.upload(scene.desc(), bvh_quality=quality)
+        c = dev.counters()
+        film, st = dev.render(job)
+        assert st == 0
+        got[quality] = (c.bvh_nodes, c.bvh_tris, c.bvh_depth, film, c.bvh_builder, c.bvh_on_device, c.bvh4_on_device, c.ms_bvh_build, dev.counters().segments)
+    host, device = got[1], got[0]
+    assert host[4] == 0 and host[5] == 0 and device[4] == 3 and device[5] == 1 and device[6] == 1
+    assert device[:3] == host[:3] and device[8] == host[8]
+    assert np.array_equal(device[3], host[3])
+    assert device[7] < (60.0 if which == "interior" else 30.0), "device build took %.1f ms" % device[7]
     dev.close()

@@ -144,7 +144,7 @@ def test_rect_box_device_equals_oracle(native, oracle):
     o = rng.uniform(20, 530, (n, 3)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
     ref = oracle.trace(scene.desc(), o, d)
-    for quality in (1, 0):
+    for quality in (1, 0, 0x40):
         dev.upload(scene.desc(), bvh_quality=quality)
         got = dev.trace(o, d)
         for k in ("t", "u", "v", "prim"):

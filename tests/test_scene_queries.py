@@ -119,7 +119,7 @@ def test_ray_intersect_c_abi_equals_oracle(native, oracle):
         desc = scene.desc()
         (o, d, mint, maxt), _ = _second_bounce_rays(oracle, desc, *_camera_rays(sensor, 3000, 5), seed=6)
         want = oracle.ray_intersect(desc, o, d, mint, maxt)
-        for quality in (1, 0, 1 | 0x10):                           # SAH, device LBVH, forced tree walk
+        for quality in (1, 0, 0x40, 1 | 0x10):                     # host / device SAH builder, radix tree, forced tree walk
             dev.upload(desc, bvh_quality=quality)
             _bits_equal(dev.ray_intersect(o, d, mint, maxt), want)
         assert np.isfinite(want["t"]).sum() > 2000 and (want["emitter_index"] >= 0).any(), name

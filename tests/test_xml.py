@@ -257,7 +257,7 @@ def test_xml_scene_with_obj_and_ply_files_renders_on_the_device(native, oracle, 
     assert c.samples == ost.samples == 96 * 64 * 8 and c.segments == ost.segments and c.bvh_tris == 724
     assert np.array_equal(film, o32)
     dev = native.Device(0)
-    for quality in (1, 0):                                               # and through the raw C ABI, SAH and device LBVH
+    for quality in (1, 0, 0x40):                                         # and through the raw C ABI: host / device SAH builder, radix tree
         dev.upload(scene.desc(), bvh_quality=quality)
         g, st = dev.render(job)
         assert st == 0 and np.array_equal(g, o32)

@@ -41,7 +41,7 @@ def main():
         integ = api.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else api.PathIntegrator
         job = integ(**ikw).render_job(sensor)
         o32, _, ost = orc.render(scene.desc(), job, threads=os.cpu_count() or 8, want_f64=False)
-        for quality in (1, 0):
+        for quality in (0, 0x40):
             dev.upload(scene.desc(), bvh_quality=quality)
             for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):     # the direct integrator runs on the resident plan
                 g, st = dev.render(job, plan=plan)

@@ -17,43 +17,15 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e, flush=True)
 P
 }
-echo "== parity: device builder (PLOC) through the fuzz tier, the C3 window, the full-size crops; placed queues"
-timeout 900 python -m pytest tests/test_gpu_configured.py -x -q -k "fuzz or c3_window" 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "placed_queues" 2>&1 | tail -3
-C3="--scene matball --spp 256 --steps 2 --warmup 1"
-C4="--scene interior --spp 32 --steps 2 --warmup 1"
-echo "== builders"
-run c3_sah       - -- $C3
-run c3_r03       r03 -- $C3
-run c3_ploc      - MIW_DEBUG=1 -- $C3 --bvh-quality 0
-run c3_ploc_r8   - MIW_PLOC_RADIUS=8 -- $C3 --bvh-quality 0
-run c3_ploc_l4   - MIW_LBVH_LEAF=4 -- $C3 --bvh-quality 0
-run c3_lbvh      - MIW_DEVICE_BUILDER=lbvh -- $C3 --bvh-quality 0
-run c4_sah       - -- $C4
-run c4_r03       r03 -- $C4
-run c4_ploc      - MIW_DEBUG=1 -- $C4 --bvh-quality 0
-run c4_ploc_r8   - MIW_PLOC_RADIUS=8 -- $C4 --bvh-quality 0
-run c4_ploc_r32  - MIW_PLOC_RADIUS=32 -- $C4 --bvh-quality 0
-run c4_ploc_l4   - MIW_LBVH_LEAF=4 -- $C4 --bvh-quality 0
-run c4_ploc_l1   - MIW_LBVH_LEAF=1 -- $C4 --bvh-quality 0
-run c4_lbvh      - MIW_DEVICE_BUILDER=lbvh -- $C4 --bvh-quality 0
-grep -h "device builder\|bvh4" $out/${tag}_c3_ploc.err $out/${tag}_c4_ploc.err | head
-echo "== 1/8 shards: spread (phase machine default) / contiguous pieces / no placement"
-S3="--scene matball --spp 256 --steps 2 --warmup 1 --shard tiles --shard-of 8"
-S4="--scene interior --spp 128 --steps 2 --warmup 1 --shard tiles --shard-of 8"
-run sh_c3         - -- $S3
-run sh_c3_contig  - MIW_PLACE_SPREAD=0 -- $S3
-run sh_c3_plain   - MIW_PLACE=0 -- $S3
-run sh_c3_noprio  - MIW_TAIL_PRIO=0 -- $S3
-run sh_c4         - -- $S4
-run sh_c4_contig  - MIW_PLACE_SPREAD=0 -- $S4
-run sh_c4_plain   - MIW_PLACE=0 -- $S4
-run sh_c4_noprio  - MIW_TAIL_PRIO=0 -- $S4
-run sh_c4_m4      - MIW_PLACE_MEASURE=4 -- $S4
-run sh_c2         - -- --steps 3 --warmup 1 --shard tiles --shard-of 8
-run sh_c2_spread  - MIW_PLACE_SPREAD=1 -- --steps 3 --warmup 1 --shard tiles --shard-of 8
-run c3_full256    - -- --scene matball --spp 256 --steps 1 --warmup 1
-run c4_full128    - -- --scene interior --spp 128 --steps 1 --warmup 1
-run c2_full       - -- --steps 3 --warmup 1
+echo "== film replay variants (C2, 3 steps)"
+run c2_cols42   - -- --steps 3 --warmup 1
+run c2_cols44   - MIW_FILM_COLUMNS=44 -- --steps 3 --warmup 1
+run c2_cols82   - MIW_FILM_COLUMNS=82 -- --steps 3 --warmup 1
+run c2_groups   - MIW_FILM_COLUMNS=0 -- --steps 3 --warmup 1
+echo "== device build timing"
+run c4_dev   - MIW_DEBUG=1 -- --scene interior --spp 32 --steps 2 --warmup 1
+run c3_dev   - MIW_DEBUG=1 -- --scene matball --spp 256 --steps 2 --warmup 1
+grep -h "device builder\|bvh4" $out/${tag}_c3_dev.err $out/${tag}_c4_dev.err | head
+echo "== the whole GPU tier"
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
 du -sh $out | tail -1
