@@ -449,6 +449,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (quality != 1 && quality != 0) return fail(c, MI_ERR_INVALID, "mi_bvh_build: quality must be 0 or 1");
     auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
+    const float pad_unit = scene_pad_unit(c->tris_in);        // 1e-5 x the largest |coordinate| (bvh_build.h): boxes grow by two units, the accept rule by one
     BvhBuildResult r;                       // host SAH result (nodes kept for the tiny-scene leaf filter)
     uint32_t node_count = 0, tri_count = (uint32_t) c->tris_in.size(), depth = 0;
     bool built_on_device = false;
@@ -485,7 +486,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         bool sah_need_host = false;
         if (dev_builder == DEV_SAH) {
             const uint32_t un = (uint32_t) n, max_leaf = 4u;              // (bvh_build_sah's default leaf size: the same tree)
-            const float pad = 2.f * scene_pad_unit(c->tris_in);
+            const float pad = 2.f * pad_unit;
             TmpBuf<SahPrim> d_prim; TmpBuf<uint32_t> d_ia, d_ib, d_flags, d_rank; TmpBuf<SahCand> d_ca, d_cb; TmpBuf<SahDecision> d_dec; TmpBuf<SahState> d_state;
             TmpBuf<unsigned char> d_scan_tmp;
             HIP_TRY(c, d_prim.resize(un)); HIP_TRY(c, d_ia.resize(un)); HIP_TRY(c, d_ib.resize(un)); HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_rank.resize(un));
@@ -501,21 +502,29 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             HIP_TRY(c, hipMemsetAsync(d_state.p, 0, sizeof(SahState), s));
             std::vector<uint32_t> level_start{ 0u };
             uint32_t n_cand = 1u, base = 0u, level = 0u;
+            bool big_left = true;                                        // candidates of more than MIW_SAH_BIG triangles in the current level
             while (n_cand > 0u && !sah_need_host) {
                 const SahCand *cur = (level & 1u) ? d_cb.p : d_ca.p; SahCand *nxt = (level & 1u) ? d_ca.p : d_cb.p;
                 const uint32_t *ic = (level & 1u) ? d_ib.p : d_ia.p; uint32_t *in = (level & 1u) ? d_ia.p : d_ib.p;
-                const bool big = n_cand <= 512u;                         // few, large candidates: 1024 threads each; many: one wavefront each
-                if (big) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p);
-                else     hipLaunchKernelGGL(k_sah_decide<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p);
+                // few candidates: 1024 threads each. Many: one wavefront each — except those above MIW_SAH_BIG triangles (an unbalanced
+                // split leaves a 100 k-triangle candidate next to thousands of small ones twelve levels down; one wavefront on it cost
+                // 15 ms), which a second launch of the 1024-thread kernel takes; `big_left` (read back with the level's totals) says
+                // whether the level holds any.
+                const bool all_big = n_cand <= 512u;
+                const uint32_t none = 0u, all = 0xffffffffu;
+                if (all_big || big_left) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, all_big ? none : MIW_SAH_BIG, all);
+                if (!all_big) hipLaunchKernelGGL(k_sah_decide<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, none, big_left ? MIW_SAH_BIG : all);
                 HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_rank.p, (int) n_cand, s));
                 hipLaunchKernelGGL(k_sah_totals, dim3(1), dim3(1), 0, s, d_flags.p, d_rank.p, n_cand, d_state.p);
-                if (big) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt);
-                else     hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt);
+                if (all_big || big_left) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, all_big ? none : MIW_SAH_BIG, all);
+                if (!all_big) hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, none, big_left ? MIW_SAH_BIG : all);
                 SahState h;
                 HIP_TRY(c, hipMemcpyAsync(&h, d_state.p, sizeof h, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 HIP_TRY(c, hipGetLastError());
                 sah_need_host = h.need_host != 0u || level >= 62u || (uint64_t) base + h.n_inner > (uint64_t) un - 1u;
+                big_left = h.max_count > MIW_SAH_BIG;
+                if (big_left) HIP_TRY(c, hipMemsetAsync(&d_state.p->max_count, 0, sizeof(uint32_t), s));     // (counts the next level afresh)
                 depth = level;
                 base += h.n_inner; level_start.push_back(base);
                 n_cand = 2u * h.n_inner; ++level;
@@ -624,7 +633,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (!built_on_device) c->counters.bvh_builder = 0u;
 
     SceneView &v = c->view;
-    v.accept_pad = scene_pad_unit(c->tris_in);                // shape.h: the bounds rule of every triangle hit
+    v.accept_pad = pad_unit;                                  // shape.h: the bounds rule of every triangle hit
     v.tri_bounds = nullptr;
     v.nodes = c->d_nodes.p; v.node_count = node_count;
     v.tris = c->d_tris.p; v.tri_count = tri_count;

@@ -1,5 +1,6 @@
 // Device run of the level-by-level binned-SAH builder (sah_levels.h): mi_bvh_build quality 0. One WORKGROUP per candidate of the
-// current level — 1024 threads while a level holds few, large candidates (the top of the tree), one wavefront once it holds many —
+// current level — 1024 threads for a candidate of more than 8192 triangles or while a level holds at most 512 candidates, one
+// wavefront otherwise (a level that mixes sizes is launched twice, each launch skipping the other's candidates) —
 // running the steps of sah_levels.h with their reductions in LDS:
 //   k_sah_prims     per triangle: padded box + box centre (48-byte record), the identity index array
 //   k_sah_decide    per candidate: box + centroid box of its range (wave shuffles, then ordered-uint LDS atomics), 3 x 16 bins in
@@ -22,7 +23,8 @@ namespace miw {
 
 struct alignas(16) SahPrim { float lo[3], hi[3], cen[3]; uint32_t pad[3]; };
 static_assert(sizeof(SahPrim) == 48, "SahPrim must be 48 bytes");
-struct SahState { uint32_t n_inner, need_host; };
+struct SahState { uint32_t n_inner, need_host, max_count; };     // max_count: the largest candidate of the NEXT level (k_sah_apply)
+#define MIW_SAH_BIG 2048u          /* candidates above this many triangles get a 1024-thread workgroup whatever the level holds */
 
 __global__ void k_sah_prims(const Tri *tris, uint32_t n, float pad, SahPrim *prim, uint32_t *idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,13 +38,19 @@ __global__ void k_sah_prims(const Tri *tris, uint32_t n, float pad, SahPrim *pri
 
 template <int BS>
 __global__ __launch_bounds__(BS) void k_sah_decide(const SahCand *cand, uint32_t n_cand, const uint32_t *idx, const SahPrim *prim, uint32_t level,
-                                                    uint32_t max_leaf, SahDecision *dec, uint32_t *flags, SahState *state) {
+                                                    uint32_t max_leaf, SahDecision *dec, uint32_t *flags, SahState *state, uint32_t count_lo, uint32_t count_hi) {
     __shared__ uint32_t s_box[12];                                            // box lo, box hi, centroid lo, centroid hi (ordered uints)
     __shared__ uint32_t s_lo[3][MIW_SAH_BINS][3], s_hi[3][MIW_SAH_BINS][3], s_cnt[3][MIW_SAH_BINS];
+    // (the sixteen wavefronts of a 1024-thread workgroup bin into their OWN copy first — 16 bins x 3 axes is what 1024 threads' atomics
+    // would otherwise queue up on — and fold the copies into s_lo / s_hi / s_cnt afterwards)
+    constexpr int NWB = BS / 64;
+    __shared__ uint32_t w_lo[NWB > 1 ? NWB : 1][3][MIW_SAH_BINS][3], w_hi[NWB > 1 ? NWB : 1][3][MIW_SAH_BINS][3], w_cnt[NWB > 1 ? NWB : 1][3][MIW_SAH_BINS];
     __shared__ float s_cost[3]; __shared__ int s_bin[3];
+    __shared__ float s_ra[3][MIW_SAH_BINS]; __shared__ uint32_t s_rc[3][MIW_SAH_BINS];     // the sweep's suffix areas / counts
     const uint32_t j = blockIdx.x;
     if (j >= n_cand) return;
     const SahCand c = cand[j];
+    if (c.count <= count_lo || c.count > count_hi) return;                    // (the other launch of this level takes it: a level is run twice when it mixes sizes)
     const uint32_t t = threadIdx.x, o_inf = lbvh_f2o(MIW_INFINITY), o_ninf = lbvh_f2o(-MIW_INFINITY);
     if (t < 12) s_box[t] = (t % 6u) < 3u ? o_inf : o_ninf;
     for (uint32_t k = t; k < 3u * MIW_SAH_BINS; k += BS) {
@@ -50,15 +58,30 @@ __global__ __launch_bounds__(BS) void k_sah_decide(const SahCand *cand, uint32_t
         for (int q = 0; q < 3; ++q) { s_lo[a][b][q] = o_inf; s_hi[a][b][q] = o_ninf; }
         s_cnt[a][b] = 0u;
     }
+    if (NWB > 1)
+        for (uint32_t k = t; k < (uint32_t) NWB * 3u * MIW_SAH_BINS; k += BS) {
+            const uint32_t ww = k / (3u * MIW_SAH_BINS), a = (k / MIW_SAH_BINS) % 3u, b = k % MIW_SAH_BINS;
+            for (int q = 0; q < 3; ++q) { w_lo[ww][a][b][q] = o_inf; w_hi[ww][a][b][q] = o_ninf; }
+            w_cnt[ww][a][b] = 0u;
+        }
     __syncthreads();
     // ---- the range's padded box and centroid box ----
     float v[12] = { MIW_INFINITY, MIW_INFINITY, MIW_INFINITY, -MIW_INFINITY, -MIW_INFINITY, -MIW_INFINITY,
                     MIW_INFINITY, MIW_INFINITY, MIW_INFINITY, -MIW_INFINITY, -MIW_INFINITY, -MIW_INFINITY };
-    for (uint32_t i = c.first + t; i < c.first + c.count; i += BS) {
-        const SahPrim p = prim[idx[i]];
-        for (int a = 0; a < 3; ++a) {
-            v[a] = fminf(v[a], p.lo[a]); v[3 + a] = fmaxf(v[3 + a], p.hi[a]);
-            v[6 + a] = fminf(v[6 + a], p.cen[a]); v[9 + a] = fmaxf(v[9 + a], p.cen[a]);
+    // (a thread's trip is idx -> record, two dependent loads a microsecond each: four independent chains per trip, or the top
+    // levels — one workgroup on 0.9 M triangles — are nothing but that latency)
+    const uint32_t end = c.first + c.count;
+    for (uint32_t i0 = c.first + t; i0 < end; i0 += 4u * BS) {
+        uint32_t id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t i = i0 + (uint32_t) k * BS; id[k] = idx[i < end ? i : end - 1u]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const SahPrim p = prim[id[k]];                                    // (a clamped slot repeats the range's last triangle: min / max do not mind)
+            for (int a = 0; a < 3; ++a) {
+                v[a] = fminf(v[a], p.lo[a]); v[3 + a] = fmaxf(v[3 + a], p.hi[a]);
+                v[6 + a] = fminf(v[6 + a], p.cen[a]); v[9 + a] = fmaxf(v[9 + a], p.cen[a]);
+            }
         }
     }
     for (int q = 0; q < 12; ++q)
@@ -75,26 +98,44 @@ __global__ __launch_bounds__(BS) void k_sah_decide(const SahCand *cand, uint32_t
     bool swept[3]; float scale[3];
     for (int a = 0; a < 3; ++a) { swept[a] = sah_axis_swept(cbox, a, c.count, level); scale[a] = swept[a] ? MIW_SAH_BINS / (cbox.hi[a] - cbox.lo[a]) : 0.f; }
     if (swept[0] || swept[1] || swept[2])
-        for (uint32_t i = c.first + t; i < c.first + c.count; i += BS) {
-            const SahPrim p = prim[idx[i]];
-            for (int a = 0; a < 3; ++a) {
-                if (!swept[a]) continue;
-                const int b = sah_bin(p.cen[a], cbox.lo[a], scale[a]);
-                for (int q = 0; q < 3; ++q) { atomicMin(&s_lo[a][b][q], lbvh_f2o(p.lo[q])); atomicMax(&s_hi[a][b][q], lbvh_f2o(p.hi[q])); }
-                atomicAdd(&s_cnt[a][b], 1u);
+        for (uint32_t i0 = c.first + t; i0 < end; i0 += 4u * BS) {
+            uint32_t id[4]; SahPrim p4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const uint32_t i = i0 + (uint32_t) k * BS; id[k] = idx[i < end ? i : end - 1u]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p4[k] = prim[id[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + (uint32_t) k * BS >= end) continue;                  // (a clamped slot must not be counted twice)
+                const SahPrim &p = p4[k];
+                for (int a = 0; a < 3; ++a) {
+                    if (!swept[a]) continue;
+                    const int b = sah_bin(p.cen[a], cbox.lo[a], scale[a]);
+                    uint32_t *lo = NWB > 1 ? w_lo[t >> 6][a][b] : s_lo[a][b], *hi = NWB > 1 ? w_hi[t >> 6][a][b] : s_hi[a][b];
+                    for (int q = 0; q < 3; ++q) { atomicMin(&lo[q], lbvh_f2o(p.lo[q])); atomicMax(&hi[q], lbvh_f2o(p.hi[q])); }
+                    atomicAdd(NWB > 1 ? &w_cnt[t >> 6][a][b] : &s_cnt[a][b], 1u);
+                }
             }
         }
     __syncthreads();
+    if (NWB > 1) {                                                            // fold the wavefronts' copies (min / max / sum: order-free)
+        for (uint32_t k = t; k < 3u * MIW_SAH_BINS; k += BS) {
+            const uint32_t a = k / MIW_SAH_BINS, b = k % MIW_SAH_BINS;
+            uint32_t n = 0u, l3[3] = { o_inf, o_inf, o_inf }, h3[3] = { o_ninf, o_ninf, o_ninf };
+            for (int ww = 0; ww < NWB; ++ww) {
+                n += w_cnt[ww][a][b];
+                for (int q = 0; q < 3; ++q) { l3[q] = l3[q] < w_lo[ww][a][b][q] ? l3[q] : w_lo[ww][a][b][q]; h3[q] = h3[q] > w_hi[ww][a][b][q] ? h3[q] : w_hi[ww][a][b][q]; }
+            }
+            s_cnt[a][b] = n;
+            for (int q = 0; q < 3; ++q) { s_lo[a][b][q] = l3[q]; s_hi[a][b][q] = h3[q]; }
+        }
+        __syncthreads();
+    }
     if (t < 3u) {                                                             // one thread per axis: the sweep
         float cost = MIW_INFINITY; int bin = -1;
-        if (swept[t]) {
-            SahBox bb[MIW_SAH_BINS]; uint32_t bc[MIW_SAH_BINS];
-            for (int b = 0; b < MIW_SAH_BINS; ++b) {
-                for (int q = 0; q < 3; ++q) { bb[b].lo[q] = lbvh_o2f(s_lo[t][b][q]); bb[b].hi[q] = lbvh_o2f(s_hi[t][b][q]); }
-                bc[b] = s_cnt[t][b];
-            }
-            sah_sweep_axis(bb, bc, cost, bin);
-        }
+        if (swept[t])
+            sah_sweep_axis([&](int b) { SahBox x; for (int q = 0; q < 3; ++q) { x.lo[q] = lbvh_o2f(s_lo[t][b][q]); x.hi[q] = lbvh_o2f(s_hi[t][b][q]); } return x; },
+                           [&](int b) { return s_cnt[t][b]; }, s_ra[t], s_rc[t], cost, bin);
         s_cost[t] = cost; s_bin[t] = bin;
     }
     __syncthreads();
@@ -114,12 +155,15 @@ __global__ void k_sah_totals(const uint32_t *flags, const uint32_t *rank, uint32
 
 template <int BS>
 __global__ __launch_bounds__(BS) void k_sah_apply(const SahCand *cand, uint32_t n_cand, const uint32_t *idx, uint32_t *idx_next, const SahPrim *prim,
-                                                   const SahDecision *dec, const uint32_t *rank, uint32_t base, BvhNode *nodes, SahCand *cand_next) {
+                                                   const SahDecision *dec, const uint32_t *rank, uint32_t base, BvhNode *nodes, SahCand *cand_next,
+                                                   SahState *state, uint32_t count_lo, uint32_t count_hi) {
     constexpr int NW = BS / 64;
     __shared__ uint32_t s_l[NW], s_v[NW];
     const uint32_t j = blockIdx.x;
     if (j >= n_cand) return;
-    const SahCand c = cand[j]; const SahDecision d = dec[j];
+    const SahCand c = cand[j];
+    if (c.count <= count_lo || c.count > count_hi) return;
+    const SahDecision d = dec[j];
     const uint32_t t = threadIdx.x, w = t >> 6;
     const int32_t me = (int32_t) (base + rank[j]);
     if (t == 0u) {
@@ -127,22 +171,36 @@ __global__ __launch_bounds__(BS) void k_sah_apply(const SahCand *cand, uint32_t 
         if (d.split) {
             cand_next[2u * rank[j]] = SahCand{ c.first, d.n_left, me, 0u };
             cand_next[2u * rank[j] + 1u] = SahCand{ c.first + d.n_left, c.count - d.n_left, me, 1u };
+            const uint32_t larger = d.n_left > c.count - d.n_left ? d.n_left : c.count - d.n_left;
+            if (larger > MIW_SAH_BIG) atomicMax(&state->max_count, larger);
         }
     }
     if (!d.split) { for (uint32_t i = c.first + t; i < c.first + c.count; i += BS) idx_next[i] = idx[i]; return; }
+    // stable partition, 4 BS positions per trip: a thread takes four consecutive positions (four independent idx -> centroid load
+    // chains), a wavefront 256, the workgroup's wavefronts consecutive runs; ranks from four ballots + a prefix over the wavefronts
     uint32_t l_base = c.first, r_base = c.first + d.n_left;
-    for (uint32_t i0 = 0; i0 < c.count; i0 += BS) {                           // stable partition, BS positions per trip
-        const bool valid = i0 + t < c.count;
-        const uint32_t id = valid ? idx[c.first + i0 + t] : 0u;
-        const bool left = valid && sah_bin(prim[id].cen[d.axis], d.clo, d.scale) <= (int) d.bin;
-        const unsigned long long bl = __ballot(left), bv = __ballot(valid);
-        if ((t & 63u) == 0u) { s_l[w] = (uint32_t) __popcll(bl); s_v[w] = (uint32_t) __popcll(bv); }
+    for (uint32_t i0 = 0; i0 < c.count; i0 += 4u * BS) {
+        uint32_t id[4]; bool valid[4], left[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t p = i0 + 4u * t + (uint32_t) k; valid[k] = p < c.count; id[k] = valid[k] ? idx[c.first + p] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) left[k] = valid[k] && sah_bin(prim[id[k]].cen[d.axis], d.clo, d.scale) <= (int) d.bin;
+        const unsigned long long below = (1ull << (t & 63u)) - 1ull;
+        uint32_t rl = 0, rv = 0, wl = 0, wv = 0;                              // lefts / valid positions before this thread in its wavefront; the wavefront's totals
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long bl = __ballot(left[k]), bv = __ballot(valid[k]);
+            rl += (uint32_t) __popcll(bl & below); rv += (uint32_t) __popcll(bv & below);
+            wl += (uint32_t) __popcll(bl); wv += (uint32_t) __popcll(bv);
+        }
+        if ((t & 63u) == 0u) { s_l[w] = wl; s_v[w] = wv; }
         __syncthreads();
         uint32_t pl = 0, pv = 0, tl = 0, tv = 0;
         for (int k = 0; k < NW; ++k) { const uint32_t a = s_l[k], b = s_v[k]; if ((uint32_t) k < w) { pl += a; pv += b; } tl += a; tv += b; }
-        const unsigned long long below = (1ull << (t & 63u)) - 1ull;
-        const uint32_t rl = (uint32_t) __popcll(bl & below), rv = (uint32_t) __popcll(bv & below);
-        if (valid) idx_next[left ? l_base + pl + rl : r_base + (pv - pl) + (rv - rl)] = id;
+        uint32_t at_l = l_base + pl + rl, at_r = r_base + (pv - pl) + (rv - rl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (valid[k]) { if (left[k]) idx_next[at_l++] = id[k]; else idx_next[at_r++] = id[k]; }
         l_base += tl; r_base += tv - tl;
         __syncthreads();
     }

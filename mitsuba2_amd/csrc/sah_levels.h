@@ -47,14 +47,17 @@ MIW_HD int sah_bin(float c, float lo, float scale) {
     return b > MIW_SAH_BINS - 1 ? MIW_SAH_BINS - 1 : b;
 }
 // One axis of the sweep (bvh_build.h: the two passes over the bins): the cheapest split of this axis, first bin on ties.
-MIW_HD void sah_sweep_axis(const SahBox *bb, const uint32_t *bc, float &best_cost, int &best_bin) {
-    float right_area[MIW_SAH_BINS]; uint32_t right_cnt[MIW_SAH_BINS];
+// box_at(b) / cnt_at(b) hand out bin b and right_area / right_cnt hold the suffix pass (the host passes arrays; the device decodes
+// its LDS bins in place and keeps the suffixes in LDS as well: a first version with thread-local arrays spent ~1 ms per LEVEL in
+// three threads' scratch-memory accesses).
+template <typename BoxAt, typename CntAt>
+MIW_HD void sah_sweep_axis(BoxAt box_at, CntAt cnt_at, float *right_area, uint32_t *right_cnt, float &best_cost, int &best_bin) {
     SahBox acc; sah_box_reset(acc); uint32_t c = 0;
-    for (int b = MIW_SAH_BINS - 1; b > 0; --b) { sah_box_expand(acc, bb[b]); c += bc[b]; right_area[b] = sah_half_area(acc); right_cnt[b] = c; }
+    for (int b = MIW_SAH_BINS - 1; b > 0; --b) { sah_box_expand(acc, box_at(b)); c += cnt_at(b); right_area[b] = sah_half_area(acc); right_cnt[b] = c; }
     sah_box_reset(acc); c = 0;
     best_cost = MIW_INFINITY; best_bin = -1;
     for (int b = 0; b < MIW_SAH_BINS - 1; ++b) {
-        sah_box_expand(acc, bb[b]); c += bc[b];
+        sah_box_expand(acc, box_at(b)); c += cnt_at(b);
         if (c == 0 || right_cnt[b + 1] == 0) continue;
         const float cost = sah_half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
         if (cost < best_cost) { best_cost = cost; best_bin = b; }
@@ -136,7 +139,8 @@ inline SahLevelsResult sah_build_levels_host(const std::vector<Tri> &tris, float
                     const int b = sah_bin(cen[3 * (size_t) idx[i] + a], cbox.lo[a], scale);
                     sah_box_expand(bins.box[a][b], pbox[idx[i]]); bins.cnt[a][b]++;
                 }
-                sah_sweep_axis(bins.box[a], bins.cnt[a], cost[a], bin[a]);
+                float right_area[MIW_SAH_BINS]; uint32_t right_cnt[MIW_SAH_BINS];
+                sah_sweep_axis([&](int b) -> const SahBox & { return bins.box[a][b]; }, [&](int b) { return bins.cnt[a][b]; }, right_area, right_cnt, cost[a], bin[a]);
             }
             const int r = sah_decide(box, cbox, c.count, max_leaf, cost, bin, dec[j]);
             if (r == 2 || (level == 0 && r == 0)) { out.need_host = true; return out; }   // (a single-leaf scene: the host builder wraps it)

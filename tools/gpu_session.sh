@@ -11,21 +11,28 @@ run() {  # run <label> <lib dir or -> <env...> -- <bench args...>
 import json, sys
 try:
     j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    b = j["config"]["bvh"]
-    print("%-30s %9.1f Msamples/s  step %8.2f ms  %s  [%s %.1f ms, depth %s]" % (sys.argv[2], j["value"], j["ms_per_step"], (j.get("roofline") or {}).get("kernel_ms"), b["builder"], b["build_ms"], b["depth"]), flush=True)
+    print("%-30s %9.1f Msamples/s  step %8.2f ms  %s" % (sys.argv[2], j["value"], j["ms_per_step"], (j.get("roofline") or {}).get("kernel_ms")), flush=True)
 except Exception as e:
     print(sys.argv[2], "FAILED", e, flush=True)
 P
 }
-echo "== film replay variants (C2, 3 steps)"
-run c2_cols42   - -- --steps 3 --warmup 1
-run c2_cols44   - MIW_FILM_COLUMNS=44 -- --steps 3 --warmup 1
-run c2_cols82   - MIW_FILM_COLUMNS=82 -- --steps 3 --warmup 1
-run c2_groups   - MIW_FILM_COLUMNS=0 -- --steps 3 --warmup 1
-echo "== device build timing"
-run c4_dev   - MIW_DEBUG=1 -- --scene interior --spp 32 --steps 2 --warmup 1
-run c3_dev   - MIW_DEBUG=1 -- --scene matball --spp 256 --steps 2 --warmup 1
-grep -h "device builder\|bvh4" $out/${tag}_c3_dev.err $out/${tag}_c4_dev.err | head
-echo "== the whole GPU tier"
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
-du -sh $out | tail -1
+echo "== device build timing (per-wave bins, 4-per-thread partition, BIG 2048)"
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configured.py -x -q -k "device_builder or fuzz or c3_window" 2>&1 | tail -3
+MIW_DEBUG=1 timeout 300 python - <<'P' 2>&1 | grep -v "amdgpu.ids\|bvh4"
+import time
+from mitsuba2_amd import api, scenes
+api.host_lib()
+for name, mk in (("matball", lambda: scenes.cornell_box(1920, 1080, 16, diffuse_only=False, device=-1)), ("interior", lambda: scenes.interior_scene(1920, 1080, 16, device=-1))):
+    scene, _ = mk()
+    dev = api.Device(0)
+    for rep in range(3):
+        t0 = time.perf_counter(); dev.upload(scene.desc()); t = (time.perf_counter() - t0) * 1e3
+        c = dev.counters()
+        print("%s build %d: mi_scene_upload + mi_bvh_build %.1f ms wall, ms_bvh_build %.1f, builder %d, nodes %d depth %d" % (name, rep, t, c.ms_bvh_build, c.bvh_builder, c.bvh_nodes, c.bvh_depth), flush=True)
+    dev.close()
+P
+C3="--scene matball --spp 256 --steps 2 --warmup 1"
+C4="--scene interior --spp 32 --steps 2 --warmup 1"
+echo "== shade vote num:den (shade once n_shade * num >= lead * den; defaults 2:3, with an environment map 2:4)"
+for v in 2:3 1:2 2:5; do run c3_vote_$v - MIW_SHADE_VOTE=$v -- $C3; done
+for v in 2:4 2:5 1:3; do run c4_vote_$v - MIW_SHADE_VOTE=$v -- $C4; done

@@ -125,26 +125,14 @@ def main():
     out.append("c2: %.1f Msamples/s, %.1f ms/frame, kernels ms/frame %s" % (j["value"], j["ms_per_step"], per_frame(j)))
     out.append("    roofline " + json.dumps(j["roofline"]))
     out.append("    cpu_baseline " + json.dumps(j["cpu_baseline"]))
-    j = last_json(g + "_bench_direct_c2.log")
-    if j:
-        out.append("direct integrator (1 + 1 samples), same scene and size: %.1f Msamples/s, %.1f ms/frame, kernels ms/frame %s" % (j["value"], j["ms_per_step"], per_frame(j)))
-    for name in ("c5", "c5_diffuse"):
-        j = last_json(g + "_bench_%s.log" % name)
-        if j:
-            out.append("%s: %.1f Msamples/s, %.1f ms/frame, kernels ms/frame %s" % (name, j["value"], j["ms_per_step"], per_frame(j)))
+    out.append("# the other lines of the session, named as tools/profile_round.sh names them (what each name stands for is written there)")
+    for f in sorted(glob.glob(g + "_bench_c2_*.log") + glob.glob(g + "_bench_direct_c2.log") + glob.glob(g + "_bench_c5*.log")):
+        out.append(bench_line(g, os.path.basename(f)[len(tag) + 1:-4]))
     out.append("# tile-shard table (bench.py --shard tiles --shard-of N: rank 0's share of an N-GPU job on one GPU), ms/frame")
-    for n in (1, 2, 4, 8):
-        j = last_json(g + "_shard_%d.log" % n)
+    for f in sorted(glob.glob(g + "_shard_*.log")):
+        j = last_json(f)
         if j:
-            out.append("1/%d: %.1f ms  %s" % (n, j["ms_per_step"], per_frame(j)))
-    out.append("# scheduling A/B (round 3): the 1/8 shard without the per-SIMD placement (MIW_PLACE=0), without the wave priorities as well "
-               "(MIW_PLACE=0 MIW_TAIL_PRIO=0), with a measuring launch of spp / 16 instead of spp / 8 samples (MIW_PLACE_MEASURE=16); the "
-               "full frame without the priorities (MIW_TAIL_PRIO=0); the full frame on the 24-byte position log + texel-patch replay (MIW_FILM_LEGACY=1)")
-    for name, label in (("shard_8_noplace", "1/8, no placement"), ("shard_8_plain", "1/8, no placement, no priorities"), ("shard_8_measure16", "1/8, measuring launch spp/16"),
-                        ("bench_c2_noprio", "1/1, no priorities"), ("bench_c2_legacy_log", "1/1, 24-byte log")):
-        j = last_json(g + "_%s.log" % name)
-        if j:
-            out.append("%s: %.1f ms  %s" % (label, j["ms_per_step"], per_frame(j)))
+            out.append("%s: %.2f ms  %s" % (os.path.basename(f)[len(tag) + 1:-4], j["ms_per_step"], per_frame(j)))
     open(path, "w").write("\n".join(out + notes) + "\n")
     traffic["scalar_rgb/cornell/1920x1080@512/plan2/film1/launch512"] = traffic_entry(g, "c2", sha, "profiles/" + os.path.basename(path))
 
@@ -156,31 +144,22 @@ def main():
         notes = kept_notes(path)
         out = [head, cmd % (" --scene %s --spp %d" % (key, spp), tag), "# %s — kernel_stats.csv verbatim" % title, stats(name), "",
                pmc_head, pmc_text(g, name), "",
-               "# bench lines of the same session: phase machine (default) / lock-step resident kernel (MIW_PHASED=0) / wavefront plan with "
-               "the stream walk kernel (--plan 1) / phase machine over the BVH2 instead of the 4-wide tree (MIW_BVH4=0) / shade vote 1 : 1 instead of "
-               "3 : 2 (2 : 1 with an environment map) (MIW_SHADE_VOTE=1:1) / device LBVH with its 4-wide tree collapsed on the device (--bvh-quality 0) / "
-               "the same with the collapse on the host after a read-back (MIW_BVH4_HOST=1) / with one triangle per LBVH leaf (MIW_LBVH_LEAF=1) / "
-               "three wavefronts per SIMD instead of four (MIW_PHASED_WAVES=3); bvh build ms in brackets"]
-        for suffix in ("", "_lockstep", "_plan1", "_bvh2", "_vote11", "_lbvh", "_lbvh_hostcollapse", "_lbvh_leaf1", "_w3"):
-            if os.path.exists("%s_bench_%s%s.log" % (g, name, suffix)):
-                out.append(bench_line(g, "bench_%s%s" % (name, suffix), name + suffix))
+               "# bench lines of the same session, named as tools/profile_round.sh names them (bvh builder and build ms in brackets)"]
+        for f in sorted(glob.glob("%s_bench_%s*.log" % (g, name))):
+            out.append(bench_line(g, os.path.basename(f)[len(tag) + 1:-4]))
+        if name == "c4" and os.path.exists(g + "_bench_c4.err"):
+            out += ["#   " + l.strip() for l in open(g + "_bench_c4.err") if "device builder" in l or "bvh4" in l]
         if name == "c3":
             out.append("# triangle-count series (bench.py --scene matball --tess t --spp 128): 52 triangles = packet kernel; from 172 on the phase machine")
             for t in range(5):
                 j = last_json(g + "_tess_%d.log" % t)
                 if j:
                     out.append("tess %d: %6d triangles  %.1f Msamples/s  %s" % (t, j["config"]["bvh"]["tris"], j["value"], j["roofline"]["kernel"]))
-            out.append("# tile shards of the 256 spp job (1/8 also without the wave priorities, MIW_TAIL_PRIO=0)")
-            for n, suffix in ((2, ""), (8, ""), (8, "_plain")):
-                j = last_json(g + "_c3_shard_%d%s.log" % (n, suffix))
-                if j:
-                    out.append("1/%d%s: %.1f ms  %s" % (n, suffix, j["ms_per_step"], per_frame(j)))
-        if name == "c4":
-            out.append("# 1/8 tile shard of the 64 spp job (and without placement / priorities, MIW_PLACE=0 MIW_TAIL_PRIO=0)")
-            for suffix in ("", "_plain"):
-                j = last_json(g + "_c4_shard_8%s.log" % suffix)
-                if j:
-                    out.append("1/8%s: %.1f ms  %s" % (suffix, j["ms_per_step"], per_frame(j)))
+        out.append("# rank 0's tile shards on one GPU (names: tools/profile_round.sh), ms/frame")
+        for f in sorted(glob.glob("%s_%s_shard_*.log" % (g, name))):
+            j = last_json(f)
+            if j:
+                out.append("%s: %.2f ms  %s" % (os.path.basename(f)[len(tag) + 1:-4], j["ms_per_step"], per_frame(j)))
         open(path, "w").write("\n".join(out + notes) + "\n")
         traffic["scalar_rgb/%s/1920x1080@%d/plan2/film1/launch%d" % (key, spp, spp)] = traffic_entry(g, name, sha, "profiles/" + os.path.basename(path))
 

@@ -2,11 +2,12 @@
 # One GPU-box session that produces everything profiles/ and DESIGN.md §5 quote:
 #   rocprofv3 kernel trace + stats and PMC passes (each counter set in its own run, never combined with a trace domain
 #   other than --kernel-trace; SQ / TCC / GRBM counters only — the TA / TCP / TD groups hang rocprofv3 on this pool) of
-#   C2 (the default bench), C3 (material balls) and the C4-class interior; the bench lines of C2 (with the CPU baseline),
-#   C3, C4 (SAH and device LBVH), C5, the triangle-count series, the wavefront plan, and the tile-shard table.
-# Usage (from the repo root, on the GPU box):  bash tools/profile_round.sh r03
+#   C2 (the default bench), C3 (material balls) and the C4-class interior; the bench lines of C2 (the default line: CPU baseline,
+#   live counters, extras at the configured spp), C3, C4 (device-built SAH tree, host-built, radix tree), C5, the triangle-count
+#   series, the wavefront plan and the tile-shard tables of C2 / C3 / C4.
+# Usage (from the repo root, on the GPU box):  bash tools/profile_round.sh r04
 # Outputs under gpurun_out/<tag>_*; tools/make_round_profiles.py <tag> turns them into profiles/<tag>_* and profiles/traffic.json.
-tag=${1:-r03}
+tag=${1:-r04}
 repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p $out
@@ -26,33 +27,44 @@ pmc c2
 pmc c3 --scene matball --spp 64
 pmc c4 --scene interior --spp 16
 cd $repo
-env -u MIW_BENCH_NO_LIVE timeout 900 python bench.py > $out/${tag}_bench_c2.log 2>&1
-timeout 300 python bench.py --scene matball --spp 1024 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3.log 2>&1
-timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --plan 1 > $out/${tag}_bench_c3_plan1.log 2>&1
-MIW_PHASED=0 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_lockstep.log 2>&1
-timeout 300 python bench.py --variant scalar_spectral --scene glassblock --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c5.log 2>&1
-timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4.log 2>&1
-timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c4_lbvh.log 2>&1
+line() {  # line <name> [ENV=VAL ...] -- <bench args...>: one bench line into $out/${tag}_<name>.log
+  local name=$1; shift
+  local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 400 python bench.py --no-cpu-baseline --no-extras "$@" > $out/${tag}_${name}.log 2> $out/${tag}_${name}.err
+}
+env -u MIW_BENCH_NO_LIVE timeout 900 python bench.py > $out/${tag}_bench_c2.log 2> $out/${tag}_bench_c2.err      # THE default line: live counters, CPU leg, extras at the configured spp
+C3="--scene matball --steps 1 --warmup 1"; C4="--scene interior --steps 1 --warmup 1"
+line bench_c3 -- $C3 --spp 1024                                   # configs[2] as configured
+line bench_c3_plan1 -- $C3 --spp 256 --plan 1                     # wavefront plan (stream walk kernel)
+line bench_c3_lockstep MIW_PHASED=0 -- $C3 --spp 256              # lock-step resident kernel over the tree
+line bench_c3_hostsah -- $C3 --spp 256 --bvh-quality 1            # the same tree built by the host recursion
+line bench_c3_lbvh -- $C3 --spp 256 --bvh-quality 64              # MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3
+line bench_c3_w3 MIW_PHASED_WAVES=3 -- $C3 --spp 256              # three wavefronts per SIMD
+line bench_c5 -- --variant scalar_spectral --scene glassblock --steps 1 --warmup 1
+line bench_c4 MIW_DEBUG=1 -- $C4 --spp 32                         # configs[3] class, device-built SAH tree (the default); .err: the builder's timing
+line bench_c4_hostsah -- $C4 --spp 32 --bvh-quality 1
+line bench_c4_lbvh -- $C4 --spp 32 --bvh-quality 64
+line bench_c4_w3 MIW_PHASED_WAVES=3 -- $C4 --spp 32
+line bench_direct_c2 -- --integrator direct --steps 2 --warmup 1
+line bench_c2_noprio MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1
+line bench_c2_legacy_log MIW_FILM_LEGACY=1 -- --steps 2 --warmup 1          # 24-byte position log + texel-patch replay
+line bench_c2_film_groups MIW_FILM_COLUMNS=0 -- --steps 2 --warmup 1        # round 3's one-texel-per-lane film replay
 # the triangle-count series between the packet kernels (<= 64 triangles) and config 3 (icosphere levels 0..4 of the two balls)
-for t in 0 1 2 3 4; do timeout 200 python bench.py --scene matball --tess $t --spp 128 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_tess_$t.log 2>&1; done
-for so in 1 2 4 8; do timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --shard tiles --shard-of $so > $out/${tag}_shard_$so.log 2>&1; done
-# the 1/8 shard without the per-SIMD placement, without the priorities as well, and with a shorter measuring launch
-MIW_PLACE=0 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --shard tiles --shard-of 8 > $out/${tag}_shard_8_noplace.log 2>&1
-MIW_PLACE=0 MIW_TAIL_PRIO=0 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --shard tiles --shard-of 8 > $out/${tag}_shard_8_plain.log 2>&1
-MIW_PLACE_MEASURE=16 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --shard tiles --shard-of 8 > $out/${tag}_shard_8_measure16.log 2>&1
-MIW_TAIL_PRIO=0 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/${tag}_bench_c2_noprio.log 2>&1
-MIW_FILM_LEGACY=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/${tag}_bench_c2_legacy_log.log 2>&1
-for so in 2 8; do timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --shard tiles --shard-of $so > $out/${tag}_c3_shard_$so.log 2>&1; done
-MIW_TAIL_PRIO=0 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --shard tiles --shard-of 8 > $out/${tag}_c3_shard_8_plain.log 2>&1
-timeout 300 python bench.py --scene interior --spp 64 --steps 1 --warmup 1 --no-cpu-baseline --shard tiles --shard-of 8 > $out/${tag}_c4_shard_8.log 2>&1
-MIW_PLACE=0 MIW_TAIL_PRIO=0 timeout 300 python bench.py --scene interior --spp 64 --steps 1 --warmup 1 --no-cpu-baseline --shard tiles --shard-of 8 > $out/${tag}_c4_shard_8_plain.log 2>&1
-MIW_BVH4_HOST=1 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c4_lbvh_hostcollapse.log 2>&1
-MIW_LBVH_LEAF=1 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c4_lbvh_leaf1.log 2>&1
-timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline --bvh-quality 0 > $out/${tag}_bench_c3_lbvh.log 2>&1
-# three wavefronts per SIMD instead of four (the default since the register diet)
-MIW_PHASED_WAVES=3 timeout 300 python bench.py --scene matball --spp 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c3_w3.log 2>&1
-MIW_PHASED_WAVES=3 timeout 400 python bench.py --scene interior --spp 32 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_c4_w3.log 2>&1
-timeout 300 python bench.py --integrator direct --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/${tag}_bench_direct_c2.log 2>&1
+for t in 0 1 2 3 4; do line tess_$t -- --scene matball --tess $t --spp 128 --steps 1 --warmup 1; done
+# rank 0's tile shard of an N-GPU frame on one GPU: C2 (512 spp), C3 (256 spp), C4 class (128 spp); the 1/8 shard also without the
+# sorted placement (MIW_PLACE=0), without the wave priorities as well, and with the other cut of the sorted list (MIW_PLACE_SPREAD)
+for so in 1 2 4 8; do line shard_$so -- --steps 2 --warmup 1 --shard tiles --shard-of $so; done
+line shard_8_noplace MIW_PLACE=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
+line shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
+line shard_8_spread MIW_PLACE_SPREAD=1 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
+for so in 1 2 8; do line c3_shard_$so -- $C3 --spp 256 --shard tiles --shard-of $so; done
+line c3_shard_8_noplace MIW_PLACE=0 -- $C3 --spp 256 --shard tiles --shard-of 8
+line c3_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C3 --spp 256 --shard tiles --shard-of 8
+line c3_shard_8_spread MIW_PLACE_SPREAD=1 -- $C3 --spp 256 --shard tiles --shard-of 8
+for so in 1 8; do line c4_shard_$so -- $C4 --spp 128 --shard tiles --shard-of $so; done
+line c4_shard_8_noplace MIW_PLACE=0 -- $C4 --spp 128 --shard tiles --shard-of 8
+line c4_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C4 --spp 128 --shard tiles --shard-of 8
+line c4_shard_8_contiguous MIW_PLACE_SPREAD=0 -- $C4 --spp 128 --shard tiles --shard-of 8
 # keep the merged artefacts small: traces of the PMC passes are only needed for the per-kernel durations
 find $out -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $out | tail -1
