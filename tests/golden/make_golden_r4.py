@@ -5,7 +5,12 @@ dielectric block — compared with the oracle AS CONFIGURED: the FULL 1920x1080 
 each; round 3 compared a 64x64 window). The spectral oracle (oracle/miw_oracle.cpp built with -DMIW_SPECTRAL=1: integrator.cpp:181-288
 / path.cpp:100-211 with spectrum.h:148-314's wavelength sampling and CIE matching) is run HERE once, brute-force scene queries
 (34 triangles), and what it produced is committed as digests: sha256 of the float32 film (whole film + per band of 40 rows) and
-the sample / segment / shadow-ray counts. tests/test_gpu_configured.py compares the device's film with them. Test infrastructure only."""
+the sample / segment / shadow-ray counts. tests/test_gpu_configured.py compares the device's film with them. 
+  c3    (second session of round 4) BASELINE configs[2] in full as well: the material balls (40 972 triangles, GGX conductor +
+        bk7 dielectric), the FULL 1920x1080 frame at the configured 1024 spp (2.12e9 samples; round 3 compared a 128x128 window).
+        Oracle scene queries through its own spatial index (orc_set_accel(1); == its brute force: tests/test_oracle_accel.py).
+        Hours of host time, once:  python tests/golden/make_golden_r4.py c3 [threads]
+Test infrastructure only."""
 import json
 import os
 import sys
@@ -18,12 +23,12 @@ W, H = 1920, 1080
 
 
 def main():
-    what = set(sys.argv[1:]) or {"c5"}
+    what = set(a for a in sys.argv[1:] if not a.isdigit()) or {"c5"}
     from make_golden_r3 import film_record
     from mitsuba2_amd import api, scenes, build
     build.build_all(oracle=True)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
-    threads = os.cpu_count() or 8
+    threads = next((int(a) for a in sys.argv[1:] if a.isdigit()), os.cpu_count() or 8)
     if "c5" in what:
         import oracle_py
         t0 = time.time()
@@ -40,6 +45,20 @@ def main():
         res["c5_full_1920x1080_512spp_spectral"] = film_record(film, st)
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
         print("c5: %.0f s, %d samples, %d segments" % (time.time() - t0, st.samples, st.segments), flush=True)
+    if "c3" in what:
+        import oracle_py
+        t0 = time.time()
+        api.host_lib()
+        orc = oracle_py.load()
+        scene, sensor = scenes.cornell_box(W, H, 1024, diffuse_only=False, device=-1)
+        job = api.PathIntegrator().render_job(sensor)
+        orc.set_accel(1)
+        film, _, st = orc.render(scene.desc(), job, threads=threads, want_f64=False)
+        orc.set_accel(0)
+        res = json.load(open(OUT)) if os.path.exists(OUT) else res
+        res["c3_full_1920x1080_1024spp"] = film_record(film, st)
+        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+        print("c3: %.0f s, %d samples, %d segments" % (time.time() - t0, st.samples, st.segments), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ own spatial index, which tests/test_oracle_accel.py proves equal to brute force)
 digests of the float32 film + sample / segment counts. Here the device renders the same jobs and must reproduce them bit for bit:
 
   C2  the FULL 1920x1080 @ 512 spp frame (1.06e9 samples), digest of the whole film and of its 27 bands of 40 rows
-  C3  41 k-triangle material balls, a 128x128 window over both silhouettes at the full 1024 spp: SAH tree, device LBVH
+  C3  41 k-triangle material balls: the FULL 1920x1080 @ 1024 spp frame (2.12e9 samples; round 4, second session); a 128x128 window over both silhouettes at the full 1024 spp: SAH tree, device LBVH
       (collapsed to the 4-wide tree on the device), wavefront plan
   C4  0.9 M-triangle interior + environment map at its configured 2048 spp: two 64x32 windows (pixels that look straight
       into the environment map next to the red wall; conductor / dielectric / diffuse clutter lit through the open ceiling),
@@ -84,6 +84,27 @@ def test_c5_full_frame_is_the_oracles(spectral):
     assert (c.samples, c.segments) == (rec["samples"], rec["segments"]) and c.samples == W * H * 512
     assert 0 < c.shadow_rays <= rec["shadow_rays"]           # the device skips shadow rays that carry a zero contribution
     _assert_film(film, rec, "C5 scalar_spectral 1920x1080 @ 512 spp")
+    dev.close()
+
+
+def test_c3_full_frame_is_the_oracles(native):
+    """BASELINE config 3 as configured: the material balls (40 972 triangles, roughconductor + dielectric), all 2 073 600 pixels x
+    1024 samples, on the default (device-built SAH) tree through the phase machine — the oracle's digest, bands and counts
+    (tests/golden/make_golden_r4.py c3; round 3 pinned a 128x128 window only)"""
+    from mitsuba2_amd import scenes
+    rec = GOLD4.get("c3_full_1920x1080_1024spp")
+    if rec is None:
+        pytest.skip("tests/golden/round4.json holds no full-frame C3 record")
+    scene, sensor = scenes.cornell_box(W, H, 1024, diffuse_only=False, device=-1)
+    dev = native.Device(0)
+    dev.upload(scene.desc())
+    c = dev.counters()
+    assert c.bvh_tris == 40972 and c.bvh_builder == 3
+    film, st = dev.render(native.PathIntegrator().render_job(sensor))
+    c = dev.counters()
+    assert st == 0 and c.plan == 2 and c.path_kernel == 1 and c.film_mode == 1 and c.log_record_bytes == 16
+    assert (c.samples, c.segments) == (rec["samples"], rec["segments"]) and c.samples == W * H * 1024
+    _assert_film(film, rec, "C3 1920x1080 @ 1024 spp")
     dev.close()
 
 

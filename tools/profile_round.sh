@@ -5,7 +5,7 @@
 #   C2 (the default bench), C3 (material balls) and the C4-class interior; the bench lines of C2 (the default line: CPU baseline,
 #   live counters, extras at the configured spp), C3, C4 (device-built SAH tree, host-built, radix tree), C5, the triangle-count
 #   series, the wavefront plan and the tile-shard tables of C2 / C3 / C4.
-# Usage (from the repo root, on the GPU box):  bash tools/profile_round.sh r04
+# Usage (from the repo root, on the GPU box):  [LEAN=1] bash tools/profile_round.sh r04   (LEAN skips the A/B lines of knobs that are not defaults)
 # Outputs under gpurun_out/<tag>_*; tools/make_round_profiles.py <tag> turns them into profiles/<tag>_* and profiles/traffic.json.
 tag=${1:-r04}
 repo=$(pwd)
@@ -36,34 +36,34 @@ env -u MIW_BENCH_NO_LIVE timeout 900 python bench.py > $out/${tag}_bench_c2.log 
 C3="--scene matball --steps 1 --warmup 1"; C4="--scene interior --steps 1 --warmup 1"
 line bench_c3 -- $C3 --spp 1024                                   # configs[2] as configured
 line bench_c3_plan1 -- $C3 --spp 256 --plan 1                     # wavefront plan (stream walk kernel)
-line bench_c3_lockstep MIW_PHASED=0 -- $C3 --spp 256              # lock-step resident kernel over the tree
+[ -n "$LEAN" ] || { line bench_c3_lockstep MIW_PHASED=0 -- $C3 --spp 256; }   # lock-step resident kernel over the tree
 line bench_c3_hostsah -- $C3 --spp 256 --bvh-quality 1            # the same tree built by the host recursion
 line bench_c3_lbvh -- $C3 --spp 256 --bvh-quality 64              # MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3
-line bench_c3_w3 MIW_PHASED_WAVES=3 -- $C3 --spp 256              # three wavefronts per SIMD
+[ -n "$LEAN" ] || { line bench_c3_w3 MIW_PHASED_WAVES=3 -- $C3 --spp 256; }   # three wavefronts per SIMD
 line bench_c5 -- --variant scalar_spectral --scene glassblock --steps 1 --warmup 1
 line bench_c4 MIW_DEBUG=1 -- $C4 --spp 32                         # configs[3] class, device-built SAH tree (the default); .err: the builder's timing
 line bench_c4_hostsah -- $C4 --spp 32 --bvh-quality 1
 line bench_c4_lbvh -- $C4 --spp 32 --bvh-quality 64
-line bench_c4_w3 MIW_PHASED_WAVES=3 -- $C4 --spp 32
+[ -n "$LEAN" ] || { line bench_c4_w3 MIW_PHASED_WAVES=3 -- $C4 --spp 32; }
 line bench_direct_c2 -- --integrator direct --steps 2 --warmup 1
-line bench_c2_noprio MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1
-line bench_c2_legacy_log MIW_FILM_LEGACY=1 -- --steps 2 --warmup 1          # 24-byte position log + texel-patch replay
-line bench_c2_film_groups MIW_FILM_COLUMNS=0 -- --steps 2 --warmup 1        # round 3's one-texel-per-lane film replay
+[ -n "$LEAN" ] || { line bench_c2_noprio MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1; }
+[ -n "$LEAN" ] || { line bench_c2_legacy_log MIW_FILM_LEGACY=1 -- --steps 2 --warmup 1; }   # 24-byte position log + texel-patch replay
+[ -n "$LEAN" ] || { line bench_c2_film_groups MIW_FILM_COLUMNS=0 -- --steps 2 --warmup 1; }   # round 3's one-texel-per-lane film replay
 # the triangle-count series between the packet kernels (<= 64 triangles) and config 3 (icosphere levels 0..4 of the two balls)
-for t in 0 1 2 3 4; do line tess_$t -- --scene matball --tess $t --spp 128 --steps 1 --warmup 1; done
+[ -n "$LEAN" ] || { for t in 0 1 2 3 4; do line tess_$t -- --scene matball --tess $t --spp 128 --steps 1 --warmup 1; done; }
 # rank 0's tile shard of an N-GPU frame on one GPU: C2 (512 spp), C3 (256 spp), C4 class (128 spp); the 1/8 shard also without the
 # sorted placement (MIW_PLACE=0), without the wave priorities as well, and with the other cut of the sorted list (MIW_PLACE_SPREAD)
 for so in 1 2 4 8; do line shard_$so -- --steps 2 --warmup 1 --shard tiles --shard-of $so; done
 line shard_8_noplace MIW_PLACE=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
-line shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
+[ -n "$LEAN" ] || { line shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8; }
 line shard_8_spread MIW_PLACE_SPREAD=1 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
 for so in 1 2 8; do line c3_shard_$so -- $C3 --spp 256 --shard tiles --shard-of $so; done
 line c3_shard_8_noplace MIW_PLACE=0 -- $C3 --spp 256 --shard tiles --shard-of 8
-line c3_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C3 --spp 256 --shard tiles --shard-of 8
+[ -n "$LEAN" ] || { line c3_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C3 --spp 256 --shard tiles --shard-of 8; }
 line c3_shard_8_spread MIW_PLACE_SPREAD=1 -- $C3 --spp 256 --shard tiles --shard-of 8
 for so in 1 8; do line c4_shard_$so -- $C4 --spp 128 --shard tiles --shard-of $so; done
 line c4_shard_8_noplace MIW_PLACE=0 -- $C4 --spp 128 --shard tiles --shard-of 8
-line c4_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C4 --spp 128 --shard tiles --shard-of 8
+[ -n "$LEAN" ] || { line c4_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C4 --spp 128 --shard tiles --shard-of 8; }
 line c4_shard_8_contiguous MIW_PLACE_SPREAD=0 -- $C4 --spp 128 --shard tiles --shard-of 8
 # keep the merged artefacts small: traces of the PMC passes are only needed for the per-kernel durations
 find $out -name "*.db" -size +20M -delete 2>/dev/null
