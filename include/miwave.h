@@ -129,6 +129,12 @@ typedef struct {          /* environment map, src/emitters/envmap.cpp (one per s
                                               applies the (1 + RayEpsilon) enlargement itself)  */
     uint32_t emitter_index;                /* position among the scene's emitters (Scene::m_emitters order,
                                               scene.cpp:38-60): area emitters at or after it shift up by one */
+    const float *density;                  /* NULL, or width * height floats: the array the sampling warp is built from
+                                              (envmap.cpp:81-116: luminance(rgb) * sin(theta) per texel). The scalar_spectral
+                                              library REQUIRES it: there `rgba` holds what the reference's constructor stores
+                                              instead of colours — per texel the three coefficients of the sRGB upsampling model
+                                              of rgb / max(1e-8, scale) and scale = 2 * hmax(rgb) (envmap.cpp:101-110) — from
+                                              which the luminance cannot be recovered. NULL in scalar_rgb: computed from `rgba` */
 } mi_envmap;
 
 /* Rectangle(props): [-1, 1]^2 in the z = 0 plane of object space, normal +z, placed by to_world
@@ -385,8 +391,8 @@ enum {
     MI_EVAL_EMITTER_SAMPLE = 6,   /* in: ref.xyz, u1, u2 [+ wavelengths[4]] out: d.xyz,dist,pdf,p.xyz,n.xyz,value[N] (11 + N) */
     MI_EVAL_FP_SEMANTICS = 7,     /* in: a,b,c                           out: a+b,a*b,a/b,sqrt|a|,fma(a,b,c),1/a,min,max (8) */
     MI_EVAL_SPECIAL = 8,          /* in: x                               out: exp, log, erf, erfinv (miw/special.h)   */
-    MI_EVAL_ENVMAP = 9,           /* in: d.xyz (world), ref.xyz, u1, u2 (8)
-                                     out: eval.rgb, pdf_direction, sample{d.xyz, dist, pdf, spec.rgb} (12)          */
+    MI_EVAL_ENVMAP = 9,           /* in: d.xyz (world), ref.xyz, u1, u2 (8) [+ wavelengths[4] in the spectral library]
+                                     out: eval[N], pdf_direction, sample{d.xyz, dist, pdf, spec[N]} (6 + 2N)         */
     MI_EVAL_INVTRIG = 10,         /* in: y, x                            out: atan2(y,x), acos(x), asin(x) (3)       */
     MI_EVAL_SPECTRUM = 11,        /* spectral library only. in: wavelength sample, c0,c1,c2, d65 scale (5)
                                      out: wavelengths[4], weights[4], srgb[4], srgb_d65[4], xyz of weight*srgb_d65 (19) */

@@ -37,7 +37,8 @@ class mi_emitter(C.Structure):
 
 class mi_envmap(C.Structure):
     _fields_ = [("rgba", c_float_p), ("width", C.c_uint32), ("height", C.c_uint32), ("scale", C.c_float),
-                ("to_world", C.c_float * 16), ("bsphere_radius", C.c_float), ("emitter_index", C.c_uint32)]
+                ("to_world", C.c_float * 16), ("bsphere_radius", C.c_float), ("emitter_index", C.c_uint32),
+                ("density", c_float_p)]
 
 
 class mi_rectangle(C.Structure):
@@ -148,6 +149,8 @@ def eval_strides(op, channels=3):
         return 10 + extra, 7 + 2 * channels
     if op == 6:
         return 5 + extra, 11 + channels
+    if op == 9:
+        return 8 + extra, 6 + 2 * channels
     if op == 11:
         return 5, 19
     if op == 12:

@@ -99,7 +99,7 @@ __global__ void k_emitter_eval(SceneView sc, const mi_surface_interaction *si, c
     Spec value = spec(0.f);
     if (r.emitter_index >= 0 && (uint32_t) r.emitter_index < sc.emitter_count) {
         const EmitterRec &e = sc.emitters[r.emitter_index];
-        if (e.type == EMITTER_ENVMAP) { if (sc.env) value = env_eval_spec(*sc.env, -ld3(r.wi)); }   // envmap.cpp:137: v = to_local(-si.wi)
+        if (e.type == EMITTER_ENVMAP) { if (sc.env) value = env_eval_spec(*sc.env, -ld3(r.wi), wl); }   // envmap.cpp:137: v = to_local(-si.wi)
         else value = emitter_eval(e, ld3(r.wi), wl);
     }
     const float *vf = reinterpret_cast<const float *>(&value);
@@ -161,17 +161,22 @@ __global__ void k_eval(int op, RenderParams P, SceneView sc, const float *in, in
             o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
         } break;
         case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
-#if !MIW_SPECTRAL
-        case MI_EVAL_ENVMAP: {
+        case MI_EVAL_ENVMAP: {           // spectral builds: in[8..11] = wavelengths; eval and spec have MIW_SPEC_N channels
             if (!sc.env) break;
+            Wavelengths wl;
+#if MIW_SPECTRAL
+            for (int k = 0; k < 4; ++k) wl.l[k] = a[8 + k];
+#endif
             V3 d = v3(a[0], a[1], a[2]);
-            V3 e = env_eval(*sc.env, d); o[0] = e.x; o[1] = e.y; o[2] = e.z;
-            o[3] = env_pdf_direction(*sc.env, d);
+            const Spec e = env_eval_spec(*sc.env, d, wl);
             V3 sd, sp, sn; float dist, pdf;
-            V3 spec = env_sample_direction(*sc.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
-            o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
+            const Spec ss = env_sample_direction_spec(*sc.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn, wl);
+            const float *ef = reinterpret_cast<const float *>(&e), *sf = reinterpret_cast<const float *>(&ss);
+            for (int k = 0; k < MIW_SPEC_N; ++k) { o[k] = ef[k]; o[MIW_SPEC_N + 6 + k] = sf[k]; }
+            o[MIW_SPEC_N] = env_pdf_direction(*sc.env, d);
+            o[MIW_SPEC_N + 1] = sd.x; o[MIW_SPEC_N + 2] = sd.y; o[MIW_SPEC_N + 3] = sd.z; o[MIW_SPEC_N + 4] = dist; o[MIW_SPEC_N + 5] = pdf;
         } break;
-#else
+#if MIW_SPECTRAL
         case MI_EVAL_SPECTRUM: {         // in: wavelength sample, c0, c1, c2 (srgb coefficients), d65 scale
             Wavelengths wl; Spec wt;
             sample_wavelengths(a[0], wl, wt);

@@ -33,12 +33,6 @@ static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 #define MIW_OCTANT_BOXES 1          /* 1: the leaf boxes of a tiny scene are staged once per ray octant, entry / exit plane of every axis side by side (leaf_box_test_octant); 0: one copy, min / max per axis */
 #endif
 #define MIW_LEAF_BOX_COPIES (MIW_OCTANT_BOXES ? 8u : 1u)
-#ifndef MIW_BOX_PIPE
-#define MIW_BOX_PIPE 0              /* 1: the leaf-box pass of trace2 reads leaf i + 1's boxes while it tests leaf i's */
-#endif
-#ifndef MIW_CAND_PIPE
-#define MIW_CAND_PIPE 0             /* 1: the E candidate loop of trace2 reads the next candidate's packet while it tests the current one; 2: the S loop as well */
-#endif
 __device__ __forceinline__ void stage_to_lds(const SceneView &sc, TraceLds cfg, uint4 *smem) {
     if (cfg.brute) {
         TriPacket *dst = reinterpret_cast<TriPacket *>(smem);
@@ -393,26 +387,12 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         Mask mE = 0, mS = 0;
 #if MIW_OCTANT_BOXES
         const LeafBox *lbE = lb + ray_octant(rE), *lbS = lb + ray_octant(rS);   // each ray reads the copies of its own octant
-#if MIW_BOX_PIPE
-        {   // software-pipelined: the boxes of leaf i + 1 are read from LDS while leaf i is tested
-            LeafBox bE = lbE[0], bS = lbS[0];
-            for (uint32_t i = 0; i < cfg.leaves; ++i) {
-                const uint32_t in = i + 1u < cfg.leaves ? i + 1u : i;
-                const LeafBox nE = lbE[8u * in], nS = lbS[8u * in];
-                const Mask bits = Tiny == 2 ? (Mask) bE.mask_lo : (Mask) (bE.mask_lo | ((unsigned long long) bE.mask_hi << 32));
-                if (leaf_box_test_octant(bE, rE, wideE)) mE |= bits;
-                if (leaf_box_test_octant(bS, rS, wideS)) mS |= bits;
-                bE = nE; bS = nS;
-            }
-        }
-#else
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &bE = lbE[8u * i], &bS = lbS[8u * i];
             const Mask bits = Tiny == 2 ? (Mask) bE.mask_lo : (Mask) (bE.mask_lo | ((unsigned long long) bE.mask_hi << 32));
             if (leaf_box_test_octant(bE, rE, wideE)) mE |= bits;
             if (leaf_box_test_octant(bS, rS, wideS)) mS |= bits;
         }
-#endif
 #else
         for (uint32_t i = 0; i < cfg.leaves; ++i) {
             const LeafBox &b = lb[i];                              // wave-uniform address
@@ -425,25 +405,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (!hasS) mS = 0;
         MIW_SECTION(1);
         uint32_t s_tri = 0; float s_t = 0.f;
-#if MIW_CAND_PIPE
-        // software-pipelined: the packet of the NEXT candidate is read from LDS while the current one is tested (per-lane
-        // LDS addresses: ~200 cycles of latency per trip otherwise, with four wavefronts to hide it)
-        if (mE != 0) {
-            uint32_t i = lowest(mE);
-            mE &= mE - 1;
-            TriPacket k = pk[i];
-            for (;;) {
-                const uint32_t i_next = mE != 0 ? lowest(mE) : i;
-                const TriPacket kn = pk[i_next];
-                float t, u, v;
-                if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
-                    (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
-                if (mE == 0) break;
-                mE &= mE - 1;
-                k = kn; i = i_next;
-            }
-        }
-#else
         while (mE != 0) {                                      // closest hit of E over its candidates
             const uint32_t i = lowest(mE);
             mE &= mE - 1;
@@ -452,26 +413,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
             if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dE, mint, maxtE, t, u, v) &&
                 (t < h.t || (t == h.t && k.prim < h.prim))) { h.t = t; h.u = u; h.v = v; h.tri = i; h.prim = k.prim; }
         }
-#endif
         MIW_SECTION(2);
-#if MIW_CAND_PIPE >= 2
-        if (mS != 0) {                                         // any hit of S, pipelined like the E loop
-            uint32_t i = lowest(mS);
-            mS &= mS - 1;
-            TriPacket k = pk[i];
-            for (;;) {
-                const uint32_t i_next = mS != 0 ? lowest(mS) : i;
-                const TriPacket kn = pk[i_next];
-                float t, u, v;
-                if (ray_intersect_triangle_edges(ld3(k.p0), ld3(k.e1), ld3(k.e2), o, dS, mint, maxtS, t, u, v)) {
-                    occ = true; mS = 0; s_tri = i; s_t = t;
-                }
-                if (mS == 0) break;
-                mS &= mS - 1;
-                k = kn; i = i_next;
-            }
-        }
-#else
         while (mS != 0) {                                      // any hit of S
             const uint32_t i = lowest(mS);
             mS &= mS - 1;
@@ -481,7 +423,6 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
                 occ = true; mS = 0; s_tri = i; s_t = t;
             }
         }
-#endif
         // The accept rule of shape.h, applied lazily: the loops above ran the bare Moeller-Trumbore test; only the
         // winners are checked against their triangle's bounds. A phantom (about one query in 10^9) sends its lane
         // through the full sweep with the rule inside, which is what the rule means.

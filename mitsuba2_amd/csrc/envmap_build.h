@@ -114,6 +114,6 @@ inline EnvmapTables envmap_build_from_density(const mi_envmap &e, const float *d
     return t;
 }
 
-inline EnvmapTables envmap_build(const mi_envmap &e) { return envmap_build_from_density(e, nullptr); }
+inline EnvmapTables envmap_build(const mi_envmap &e) { return envmap_build_from_density(e, e.density); }
 
 } // namespace miw

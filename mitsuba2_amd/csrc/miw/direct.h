@@ -32,7 +32,7 @@ MIW_HD bool direct_primary(const RenderParams &P, const SceneView &sc, LaneRegs 
     }
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;  // scene.h:248-249
     if (!P.direct.hide_emitters && emitter >= 0)                  // :119-123
-        L.res = L.res + (valid ? emitter_eval(sc.emitters[emitter], si.wi, L.wl) : env_eval_spec(*sc.env, ray_d));
+        L.res = L.res + (valid ? emitter_eval(sc.emitters[emitter], si.wi, L.wl) : env_eval_spec(*sc.env, ray_d, L.wl));
     if (!valid) return false;                                     // :125-127
     if (cnt_local) cnt_local->segments++;
     bsdf = bsdf_side(sc.bsdfs, bsdf_index, si.wi);                // :132
@@ -103,7 +103,7 @@ MIW_HD void direct_bsdf_hit(const RenderParams &P, const SceneView &sc, LaneRegs
     }
     else if (sc.env) emitter = (int32_t) sc.env->emitter_index;
     if (emitter < 0) return;
-    Spec emitter_val = valid ? emitter_eval(sc.emitters[emitter], sb.wi, L.wl) : env_eval_spec(*sc.env, ray_d);   // :182
+    Spec emitter_val = valid ? emitter_eval(sc.emitters[emitter], sb.wi, L.wl) : env_eval_spec(*sc.env, ray_d, L.wl);   // :182
     float emitter_pdf = 0.f;                                      // :187-191
     if (!pend.delta) {
         // DirectionSample3f ds(si_bsdf, si), records.h:167-173 (d = -wi = ray.d for a miss)

@@ -341,7 +341,7 @@ MIW_HD int path_step(const RenderParams &P, const SceneView &sc, LaneRegs &L, F4
             }
             emission_weight = mis_weight(L.prev_pdf, emitter_pdf);
         }
-        Spec radiance = valid ? emitter_eval(sc.emitters[emitter], si.wi, L.wl) : env_eval_spec(*sc.env, ray_d);
+        Spec radiance = valid ? emitter_eval(sc.emitters[emitter], si.wi, L.wl) : env_eval_spec(*sc.env, ray_d, L.wl);
         L.res = L.res + emission_weight * L.tp * radiance;
     }
 

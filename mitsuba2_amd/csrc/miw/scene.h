@@ -170,18 +170,61 @@ MIW_HD float sphere_pdf_direction(const AnalyticRec &r, V3 ref_p, V3 ds_d, float
                                            : r.inv_area * sqr(ds_dist) / abs_dot(ds_d, ds_n);
 }
 
-// The environment map is an RGB-build feature this round (its spectral branch upsamples every texel
-// through srgb_model_fetch, envmap.cpp:104-110): spectral scenes carrying one are rejected at upload.
+// The environment map behind the Spectrum type of the build. scalar_rgb: the texel colours (envmap.h). scalar_spectral
+// (eval_spectrum's spectral branch, envmap.cpp:286-306): a texel holds the three coefficients of the sRGB upsampling model of its
+// normalised colour and the scale 2 * hmax(rgb) (the constructor, :101-110; mi_envmap::rgba arrives in that form); the four texels
+// around uv are evaluated at the sample's wavelengths, spectra and scales are interpolated separately, and the result is
+// s * D65(lambda) * f * m_scale with m_d65 = Texture::D65(1.f).
 #if MIW_SPECTRAL
-MIW_HD Spec env_sample_direction_spec(const EnvmapRec &, V3, V2, V3 &d, float &dist, float &pdf, V3 &p, V3 &n) {
-    d = p = n = v3(0.f); dist = 0.f; pdf = 0.f; return spec(0.f);
+MIW_HD Spec env_eval_uv_spec(const EnvmapRec &e, V2 uv, const Wavelengths &wl) {
+    uv.x *= (float) (e.width - 1u); uv.y *= (float) (e.height - 1u);
+    uint32_t px = (uint32_t) uv.x, py = (uint32_t) uv.y;
+    if (px > e.width - 2u) px = e.width - 2u;
+    if (py > e.height - 2u) py = e.height - 2u;
+    const float w1x = uv.x - (float) px, w1y = uv.y - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const float *p = e.data + 4 * ((size_t) px + (size_t) py * e.width);
+    const float *q = p + 4 * (size_t) e.width;
+    const float f0 = fmadd(w0x, p[3], w1x * p[7]), f1 = fmadd(w0x, q[3], w1x * q[7]);      // :296-297
+    const float f = fmadd(w0y, f0, w1y * f1);                                              // :300
+    Spec r;
+    for (int i = 0; i < MIW_SPEC_N; ++i) {
+        const float l = wl.l[i];
+        const float s00 = srgb_model_eval(p, l), s10 = srgb_model_eval(p + 4, l),          // :289-292
+                    s01 = srgb_model_eval(q, l), s11 = srgb_model_eval(q + 4, l);
+        const float s0 = fmadd(w0x, s00, w1x * s10), s1 = fmadd(w0x, s01, w1x * s11);      // :294-295
+        const float sv = fmadd(w0y, s0, w1y * s1);                                         // :299
+        const float wp = d65_eval(1.f * (1.f / 10568.f), l);                               // :303-305, d65.cpp:61-62
+        r.c[i] = sv * wp * f * e.scale;                                                    // :307
+    }
+    return r;
 }
-MIW_HD Spec env_eval_spec(const EnvmapRec &, V3) { return spec(0.f); }
+MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d_world, const Wavelengths &wl) {
+    return env_eval_uv_spec(e, env_dir_to_uv(xf_vector(e.to_local, d_world)), wl);        // envmap.cpp:134-146
+}
+// EnvironmentMapEmitter::sample_direction, envmap.cpp:157-190: env_sample_direction of envmap.h with the spectral lookup
+MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d_out, float &dist_out, float &pdf_out,
+                                      V3 &p_out, V3 &n_out, const Wavelengths &wl) {
+    float pdf;
+    V2 uv = hier2d_sample(e, sample, pdf);
+    float theta = uv.y * MIW_PI, phi = uv.x * (2.f * MIW_PI);
+    float st, ct, sp, cp;
+    sincos_(theta, st, ct); sincos_(phi, sp, cp);
+    V3 d = v3(cp * st, sp * st, ct);
+    d = v3(d.y, d.z, -d.x);
+    float dist = 2.f * e.radius;
+    float inv_sin_theta = env_inv_sin_theta(d);
+    d = xf_vector(e.to_world, d);
+    p_out = ref_p + d * dist;
+    n_out = -d;
+    float ds_pdf = pdf > 0.f ? pdf * inv_sin_theta * (1.f / (2.f * sqr(MIW_PI))) : 0.f;
+    d_out = d; dist_out = dist; pdf_out = ds_pdf;
+    return env_eval_uv_spec(e, uv, wl) / ds_pdf;
+}
 #else
-MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d, float &dist, float &pdf, V3 &p, V3 &n) {
+MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d, float &dist, float &pdf, V3 &p, V3 &n, const Wavelengths &) {
     return env_sample_direction(e, ref_p, sample, d, dist, pdf, p, n);
 }
-MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d) { return env_eval(e, d); }
+MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d, const Wavelengths &) { return env_eval(e, d); }
 #endif
 
 // Endpoint::sample_direction of emitter `index` (endpoint.h:119-139): AreaLight (area.cpp:121-166 +
@@ -193,7 +236,7 @@ MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref
     Spec value;
     ds.emitter = index;
     if (e.type == EMITTER_ENVMAP) {
-        value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n);
+        value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n, wl);
     } else {
         if (Analytic && (e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
             sphere_sample_direction(sc.rects[e.tri_first], ref_p, sample, ds);      // the sphere's own sample_direction

@@ -47,7 +47,7 @@ MIW_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
 MIW_HD bool ray_intersect_triangle_edges(V3 p0, V3 e1, V3 e2, V3 o, V3 d, float mint, float maxt,
                                          float &t_out, float &u_out, float &v_out) {
     V3 pvec = cross(d, e2);
-    float inv_det = rcp(dot(e1, pvec));
+    float inv_det = rcp_loop(dot(e1, pvec));
     V3 tvec = o - p0;
     float u = dot(tvec, pvec) * inv_det;
     bool active = u >= 0.f && u <= 1.f;

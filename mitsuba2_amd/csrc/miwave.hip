@@ -412,7 +412,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->have_env = false;
 #if MIW_SPECTRAL
-    if (s->envmap) return fail(c, MI_ERR_INVALID, "envmap: not available in the scalar_spectral library this round");
+    if (s->envmap && !s->envmap->density)
+        return fail(c, MI_ERR_INVALID, "envmap: the scalar_spectral library needs mi_envmap::density (its texels are model coefficients, include/miwave.h)");
 #endif
     if (s->envmap) {
         EnvmapTables t = envmap_build(*s->envmap);
@@ -1510,8 +1511,9 @@ __global__ void k_selftest_rcp(unsigned long long *mismatches) {
     for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
         const float x = u2f((uint32_t) i);
         volatile float one = 1.f;                               // keeps the division a division
-        const float ref = one / x, got = miw::rcp(x);
+        const float ref = one / x, got = miw::rcp(x), got_l = miw::rcp_loop(x);
         if (f2u(ref) != f2u(got) && !(ref != ref && got != got)) ++bad;
+        if (f2u(ref) != f2u(got_l) && !(ref != ref && got_l != got_l)) ++bad;
     }
     bad = wave_sum(bad);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);

@@ -391,11 +391,12 @@ public:
     uint32_t height() const { return m_height; }
     float scale() const { return m_scale; }
     const Transform4f &world_transform() const { return m_to_world; }
-    const std::vector<float> &data() const { return m_data; }
+    const std::vector<float> &data() const { return m_data; }        // m_data: RGBA, or (scalar_spectral) c0 c1 c2 scale per texel, :101-110
+    const std::vector<float> &density() const { return m_density; }  // scalar_spectral: luminance(rgb) * sin(theta), :113 (empty in scalar_rgb)
 private:
     float m_scale; Transform4f m_to_world;
     uint32_t m_width = 0, m_height = 0;
-    std::vector<float> m_data;
+    std::vector<float> m_data, m_density;
 };
 
 class Mesh {                                                  // include/mitsuba/render/mesh.h

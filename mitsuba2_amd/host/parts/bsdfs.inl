@@ -438,4 +438,21 @@ void EnvironmentMapEmitter::set_bitmap(uint32_t width, uint32_t height, const fl
     if (width < 2 || height < 2 || !rgba) Throw("envmap: the bitmap must be at least 2x2");
     m_width = width; m_height = height;
     m_data.assign(rgba, rgba + (size_t) width * height * 4);
+#if MIW_SPECTRAL
+    // envmap.cpp:86-116, the spectral branch: every texel becomes the coefficients of the sRGB upsampling model of its colour
+    // scaled to a highest component of 50 % + that scale; the sampling density is taken from the colour before it is replaced.
+    m_density.resize((size_t) width * height);
+    for (uint32_t y = 0; y < height; ++y) {
+        const float sin_theta = std::sin((float) y / (float) (height - 1) * 3.14159265358979323846f);   // :87-88 (float pi)
+        for (uint32_t x = 0; x < width; ++x) {
+            float *p = m_data.data() + 4 * ((size_t) y * width + x);
+            const float lum = p[0] * 0.212671f + p[1] * 0.715160f + p[2] * 0.072169f;                    // mitsuba::luminance, spectrum.h
+            const float scale = std::max(p[0], std::max(p[1], p[2])) * 2.f;                               // :106
+            const float r = 1.f / std::max(1e-8f, scale);                                                 // rgb / scalar = rgb * rcp(scalar)
+            const auto cf = srgb_model_fetch(Color3f{ p[0] * r, p[1] * r, p[2] * r });                    // :107-108
+            m_density[(size_t) y * width + x] = lum * sin_theta;                                          // :113
+            p[0] = cf[0]; p[1] = cf[1]; p[2] = cf[2]; p[3] = scale;
+        }
+    }
+#endif
 }

@@ -473,6 +473,7 @@ void Scene::build(int device, int bvh_quality) {
         if (m_env->data().empty()) Throw("envmap: no bitmap set");
         m_env_rec.rgba = m_env->data().data(); m_env_rec.width = m_env->width(); m_env_rec.height = m_env->height();
         m_env_rec.scale = m_env->scale();
+        m_env_rec.density = m_env->density().empty() ? nullptr : m_env->density().data();
         std::memcpy(m_env_rec.to_world, m_env->world_transform().m, 64);
         // emitter order (scene.cpp:38-60): area lights of the shapes added before the envmap come first
         uint32_t before = 0;

@@ -262,6 +262,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     if (s->envmap && s->envmap->emitter_index >= s->emitter_count) push_env();
     if (s->envmap) {
+        if (MIW_SPECTRAL && !s->envmap->density) return false;     // as the product: coefficient texels need their sampling density (include/miwave.h)
         o.env = envmap_build(*s->envmap);
         if (!o.env.ok) return false;
         o.env.rec.data = o.env.data.data(); o.env.rec.levels = o.env.levels.data();
@@ -414,7 +415,7 @@ void path_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelengths 
         if (emitter >= 0) {                              // :126-129
             if (active) {
                 Spec radiance = si_valid ? emitter_eval(sc.emitters[emitter], si.wi, wl)  // area.cpp:63-71
-                                         : env_eval_spec(*view.env, miss_d);             // envmap.cpp:134-146
+                                         : env_eval_spec(*view.env, miss_d, wl);             // envmap.cpp:134-146
                 result = result + emission_weight * throughput * radiance;
             }
         }
@@ -521,7 +522,7 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
     if (!D.hide_emitters) {                              // :119-123
         int32_t emitter_vis = valid_ray ? sc.shapes[si.shape].emitter : env_id;
         if (emitter_vis >= 0)
-            result = result + (valid_ray ? emitter_eval(sc.emitters[emitter_vis], si.wi, wl) : env_eval_spec(*view.env, ray.d));
+            result = result + (valid_ray ? emitter_eval(sc.emitters[emitter_vis], si.wi, wl) : env_eval_spec(*view.env, ray.d, wl));
     }
     if (!valid_ray) { result_out = result; valid_ray_out = false; return; }   // :125-127
     stats.segments++;
@@ -564,7 +565,7 @@ void direct_sample(const OScene &sc, Sampler &sampler, Ray ray, const Wavelength
         bool hit = ray_intersect(sc, next, si_bsdf);
         int32_t emitter = hit ? sc.shapes[si_bsdf.shape].emitter : env_id;   // :177
         if (emitter < 0) continue;                       // :178
-        Spec emitter_val = hit ? emitter_eval(sc.emitters[emitter], si_bsdf.wi, wl) : env_eval_spec(*view.env, next.d);   // :181
+        Spec emitter_val = hit ? emitter_eval(sc.emitters[emitter], si_bsdf.wi, wl) : env_eval_spec(*view.env, next.d, wl);   // :181
         // DirectionSample3f ds(si_bsdf, si), records.h:167-173
         V3 d = next.d; float dist = 0.f; V3 n = v3(0.f);
         if (hit) {
@@ -978,7 +979,7 @@ int orc_emitter_eval(const mi_scene_desc *scene, const mi_surface_interaction *s
         Spec value = spec(0.f);
         if (r.emitter_index >= 0 && (uint32_t) r.emitter_index < sc.view.emitter_count) {
             const EmitterRec &e = sc.view.emitters[r.emitter_index];
-            if (e.type == EMITTER_ENVMAP) { if (sc.view.env) value = env_eval_spec(*sc.view.env, -ld3(r.wi)); }
+            if (e.type == EMITTER_ENVMAP) { if (sc.view.env) value = env_eval_spec(*sc.view.env, -ld3(r.wi), wl); }
             else value = emitter_eval(e, ld3(r.wi), wl);
         }
         const float *vf = reinterpret_cast<const float *>(&value);
@@ -1161,17 +1162,22 @@ int orc_eval(int op, const mi_scene_desc *scene, const mi_render_cfg *cfg, const
                 o[4] = fmadd(x, y, z); o[5] = rcp(x); o[6] = min_(x, y); o[7] = max_(x, y);
             } break;
             case MI_EVAL_SPECIAL: o[0] = exp_(a[0]); o[1] = log_(a[0]); o[2] = erf_(a[0]); o[3] = erfinv_(a[0]); break;
-#if !MIW_SPECTRAL
             case MI_EVAL_ENVMAP: {
                 if (!have_scene || !sc.view.env) return -1;
+                Wavelengths wl;
+#if MIW_SPECTRAL
+                for (int k = 0; k < 4; ++k) wl.l[k] = a[8 + k];
+#endif
                 V3 d = v3(a[0], a[1], a[2]);
-                V3 e = env_eval(*sc.view.env, d); o[0] = e.x; o[1] = e.y; o[2] = e.z;
-                o[3] = env_pdf_direction(*sc.view.env, d);
+                const Spec e = env_eval_spec(*sc.view.env, d, wl);
                 V3 sd, sp, sn; float dist, pdf;
-                V3 spec = env_sample_direction(*sc.view.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn);
-                o[4] = sd.x; o[5] = sd.y; o[6] = sd.z; o[7] = dist; o[8] = pdf; o[9] = spec.x; o[10] = spec.y; o[11] = spec.z;
-        } break;
-    #else
+                const Spec ss = env_sample_direction_spec(*sc.view.env, v3(a[3], a[4], a[5]), v2(a[6], a[7]), sd, dist, pdf, sp, sn, wl);
+                const float *ef = reinterpret_cast<const float *>(&e), *sf = reinterpret_cast<const float *>(&ss);
+            for (int k = 0; k < MIW_SPEC_N; ++k) { o[k] = ef[k]; o[MIW_SPEC_N + 6 + k] = sf[k]; }
+                o[MIW_SPEC_N] = env_pdf_direction(*sc.view.env, d);
+                o[MIW_SPEC_N + 1] = sd.x; o[MIW_SPEC_N + 2] = sd.y; o[MIW_SPEC_N + 3] = sd.z; o[MIW_SPEC_N + 4] = dist; o[MIW_SPEC_N + 5] = pdf;
+            } break;
+#if MIW_SPECTRAL
             case MI_EVAL_SPECTRUM: {
                 Wavelengths wl; Spec wt;
                 sample_wavelengths(a[0], wl, wt);

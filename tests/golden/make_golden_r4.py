@@ -59,6 +59,33 @@ def main():
         res["c3_full_1920x1080_1024spp"] = film_record(film, st)
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
         print("c3: %.0f s, %d samples, %d segments" % (time.time() - t0, st.samples, st.segments), flush=True)
+    if "c4blocks" in what:
+        # 22 more blocks of the FULL 1920x1080 @ 2048 spp job of config 4 (round 3 pinned the two centre-most): every 97th spiral id.
+        # A block's interior (texels >= border = 2 from its edge; clipped blocks: from the image's edge as well) receives that
+        # block's samples only, in the full frame as in this shard.
+        import numpy as np
+        import oracle_py
+        from make_golden_r3 import digest, full_job_blocks
+        t0 = time.time()
+        api.host_lib()
+        orc = oracle_py.load()
+        scene, sensor = scenes.interior_scene(W, H, 2048, device=-1)
+        full = api.PathIntegrator().render_job(sensor)
+        ids = list(range(2, int(full.cfg.block_count), 97))
+        orc.set_accel(1)
+        film, _, st = orc.render(scene.desc(), full, threads=threads, want_f64=False, only_blocks=np.asarray(ids, np.uint32))
+        orc.set_accel(0)
+        film = np.asarray(film); inner = {}
+        for (b, x0, y0), sid in zip(full_job_blocks(full.cfg, ids), ids):
+            w = min(28, W - 2 - (x0 + 2)); h = min(28, H - 2 - (y0 + 2))     # clipped edge blocks: stay 2 texels inside the image too
+            if w <= 0 or h <= 0:
+                continue
+            tile = film[y0 + 2:y0 + 2 + h, x0 + 2:x0 + 2 + w]
+            inner[str(sid)] = dict(block=b, origin=[x0, y0], size=[w, h], sha256=digest(tile), mean_y=float(tile[..., 1].astype(np.float64).mean()))
+        res = json.load(open(OUT)) if os.path.exists(OUT) else res
+        res["c4_full_job_more_blocks_2048spp"] = dict(samples=int(st.samples), segments=int(st.segments), interiors=inner, oracle_seconds=round(float(st.seconds), 1))
+        json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+        print("c4 blocks: %.0f s, %d blocks, %d samples" % (time.time() - t0, len(inner), st.samples), flush=True)
 
 
 if __name__ == "__main__":

@@ -174,6 +174,16 @@ def test_c4_full_frame_at_2048spp_through_the_sample_log(native):
         assert (b, [x0, y0]) == (want["block"], want["origin"])
         inner = film[y0 + 2:y0 + 30, x0 + 2:x0 + 30]
         assert digest(inner) == want["sha256"], "block %d: mean Y %.9g vs the oracle's %.9g" % (sid, float(inner[..., 1].astype(np.float64).mean()), want["mean_y"])
+    # round 4, second session: 22 more blocks of the same frame, every 97th of the spiral from its centre to the image's corners
+    # (tests/golden/make_golden_r4.py c4blocks) — the walls, the clutter, the open ceiling, pixels that see the environment map
+    more = GOLD4.get("c4_full_job_more_blocks_2048spp")
+    if more:
+        ids = [int(k) for k in more["interiors"]]
+        for sid, (b, x0, y0) in zip(ids, G.full_job_blocks(job.cfg, ids)):
+            want = more["interiors"][str(sid)]
+            assert (b, [x0, y0]) == (want["block"], want["origin"])
+            inner = film[y0 + 2:y0 + 2 + want["size"][1], x0 + 2:x0 + 2 + want["size"][0]]
+            assert digest(inner) == want["sha256"], "block %d: mean Y %.9g vs the oracle's %.9g" % (sid, float(inner[..., 1].astype(np.float64).mean()), want["mean_y"])
     dev.close()
 
 

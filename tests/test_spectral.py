@@ -165,6 +165,109 @@ def test_spectral_render_agrees_with_rgb_render(native, spectral, oracle_spectra
     assert np.allclose(ms, mr, rtol=0.08), (ms, mr)
 
 
+# ---- the environment map in the spectral variant (round 4; src/emitters/envmap.cpp:86-116, :269-307) -----------------------------
+def _srgb_model_eval64(c, lam):
+    """include/mitsuba/render/srgb.h:9-23 in float64"""
+    v = (c[..., 0:1] * lam + c[..., 1:2]) * lam + c[..., 2:3]
+    return np.maximum(0.0, 0.5 * v / np.sqrt(v * v + 1.0) + 0.5)
+
+
+def test_spectral_environment_map_against_float64_restatement(spectral, oracle_spectral):
+    """The constructor's texel conversion (every texel -> coefficients of the sRGB model of rgb / max(1e-8, 2 hmax(rgb)) + that
+    scale; the warp's density from the colour BEFORE the conversion) and eval_spectrum's spectral branch (four texels evaluated at
+    the sample's wavelengths, spectra and scales interpolated separately, times D65(lambda) times m_scale), restated here in
+    float64 numpy from the reference source; D65 itself through the checker's d65 leaf, which test_d65_spot_check pins on the
+    reference's values. sample_direction through its contract: value * pdf == eval at the sampled direction."""
+    import math
+    from mitsuba2_amd import scenes
+    Wd, Hd, scale = 40, 20, 1.3
+    img = scenes.sky_envmap(Wd, Hd).astype(np.float32)
+    env = spectral.EnvMap(img, scale=scale)
+    v = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2], [0, 3, 0]], np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2], [0, 1, 4]], np.uint32)
+    scene = spectral.Scene([spectral.Mesh("m", v, f, bsdf=spectral.BSDF("diffuse", reflectance=(0.5, 0.5, 0.5)))], envmap=env).build(-1)
+    rec = scene.desc().contents.envmap.contents
+    data = np.ctypeslib.as_array(rec.rgba, (Hd, Wd, 4)).astype(np.float64)
+    dens = np.ctypeslib.as_array(rec.density, (Hd, Wd)).astype(np.float64)
+    # the constructor: scale = 2 hmax, coefficients of the normalised colour (host srgb_model_fetch: pinned on the reference's
+    # rgb2spec by test_srgb_model_fetch_matches_reference_rgb2spec), density = luminance * sin(theta)
+    rgb = img[..., :3].astype(np.float64)
+    assert np.allclose(data[..., 3], 2 * rgb.max(-1), rtol=1e-6)
+    lum = rgb @ np.array([0.212671, 0.715160, 0.072169])
+    assert np.allclose(dens, lum * np.sin(np.arange(Hd) / (Hd - 1) * math.pi)[:, None], rtol=2e-6, atol=1e-7)
+    for (y, x) in ((0, 0), (7, 13), (19, 39), (10, 20)):
+        nrm = img[y, x, :3] * (np.float32(1) / max(np.float32(1e-8), np.float32(2) * img[y, x, :3].max()))
+        c = spectral.BSDF("diffuse", reflectance=tuple(float(q) for q in nrm)).record().tex[0].v[:3]   # the host's srgb_model_fetch
+        assert np.allclose(data[y, x, :3], np.array(c, np.float64), rtol=1e-5, atol=1e-9), (y, x)
+    rng = np.random.default_rng(17)
+    n = 300
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    wl = rng.uniform(365, 825, (n, 4))
+    x = np.concatenate([d, rng.uniform(-1, 1, (n, 3)), rng.random((n, 2)), wl], 1).astype(np.float32)
+    out = oracle_spectral.eval(9, x, scene.desc()).astype(np.float64)
+    assert out.shape[1] == 14
+
+    def d65(lam):
+        return float(_spec(oracle_spectral, 1, [1.0 / 10568.0, lam], 1)[0])
+
+    def eval64(uv, lams):
+        xx, yy = uv[0] * (Wd - 1), uv[1] * (Hd - 1)
+        px, py = min(int(xx), Wd - 2), min(int(yy), Hd - 2)
+        w1x, w1y = xx - px, yy - py
+        t = data[py:py + 2, px:px + 2]
+        s = _srgb_model_eval64(t[..., :3][..., None, :], np.asarray(lams)[:, None])[..., 0]      # [2, 2, 4 wavelengths]
+        sv = (1 - w1y) * ((1 - w1x) * s[0, 0] + w1x * s[0, 1]) + w1y * ((1 - w1x) * s[1, 0] + w1x * s[1, 1])
+        fv = (1 - w1y) * ((1 - w1x) * t[0, 0, 3] + w1x * t[0, 1, 3]) + w1y * ((1 - w1x) * t[1, 0, 3] + w1x * t[1, 1, 3])
+        return sv * np.array([d65(l) for l in lams]) * fv * scale
+
+    def to_uv(dl):
+        uv = np.array([math.atan2(dl[0], -dl[2]) / (2 * math.pi), math.acos(max(-1.0, min(1.0, dl[1]))) / math.pi])
+        return uv - np.floor(uv)
+
+    checked = 0
+    for xi, o in zip(x.astype(np.float64), out):
+        uv = to_uv(xi[0:3])
+        if min(uv[0], 1 - uv[0]) < 1e-3 or abs(xi[1]) > 0.999:
+            continue
+        lams = xi[8:12]
+        assert np.allclose(o[0:4], eval64(uv, lams), rtol=5e-4, atol=1e-7), (xi[:3], o[:4], eval64(uv, lams))
+        sd, pdf, sv = o[5:8], o[9], o[10:14]
+        suv = to_uv(sd / np.linalg.norm(sd))
+        if min(suv[0], 1 - suv[0]) < 1e-3 or abs(sd[1]) > 0.999 or pdf <= 0:
+            continue
+        assert np.allclose(sv * pdf, eval64(suv, lams), rtol=3e-3, atol=1e-6)
+        checked += 1
+    assert checked > 200
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(with_area_light=False, envmap_after=0, env_scale=0.5)])
+def test_spectral_environment_map_resident_plan_equals_scalar_oracle(spectral, oracle_spectral, kw):
+    """the open box under the synthetic sky, scalar_spectral: the resident sample loop (CPU run of the device stages) against the
+    scalar restatement — misses evaluate the map (path.cpp:126-129), emitter sampling goes through its warp (envmap.cpp:157-190)"""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.open_box(36, 28, 6, device=-1, **kw)
+    assert scene.desc().contents.envmap.contents.density
+    job, o32, o64, st, e64, e32, est = _both(spectral, oracle_spectral, scene, sensor)
+    assert est[0] == st.samples == 36 * 28 * 6 and est[1] == st.segments
+    assert np.array_equal(e32, o32) and np.isfinite(o32).all() and o32[..., 1].mean() > 0
+    assert np.array_equal(e64.astype(np.float32), o64.astype(np.float32))
+
+
+def test_spectral_library_refuses_an_environment_map_without_its_density(spectral, oracle_spectral):
+    """mi_envmap::density is required where the texels are coefficients (include/miwave.h): the checker mirrors the refusal"""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.open_box(16, 16, 1, device=-1)
+    rec = scene.desc().contents.envmap.contents
+    keep = rec.density
+    rec.density = None
+    try:
+        job = spectral.PathIntegrator().render_job(sensor)
+        with pytest.raises(RuntimeError):
+            oracle_spectral.render(scene.desc(), job, threads=1, want_f64=False)
+    finally:
+        rec.density = keep
+
+
 # ---- GPU: libmiwave_spectral.so against the spectral oracle --------------------------------------------------------
 @pytest.mark.gpu
 def test_gpu_spectral_leaf_functions_bit_exact(spectral, oracle_spectral):
@@ -225,3 +328,36 @@ def test_gpu_spectral_render_parity(spectral, oracle_spectral, diffuse_only):
             q32, st = d.render(j2)
             assert st == 0 and d.counters().segments == rst.segments and np.array_equal(q32, r32)
     d.close()
+
+
+@pytest.mark.gpu
+def test_gpu_spectral_environment_map_bit_exact(spectral, oracle_spectral):
+    """round 4: the environment map in libmiwave_spectral.so (envmap.cpp:86-116 conversion on the host, :269-307 on the device):
+    leaf functions and whole renders against the spectral oracle, bit for bit"""
+    from mitsuba2_amd import scenes
+    rng = np.random.default_rng(23)
+    d = spectral.Device(0)
+    for kw in (dict(), dict(with_area_light=False, envmap_after=0, env_scale=0.5)):
+        scene, sensor = scenes.open_box(64, 48, 8, device=-1, ball_level=2, **kw)
+        d.upload(scene.desc())
+        n = 4096
+        dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        x = np.concatenate([dirs, rng.uniform(50, 500, (n, 3)), rng.random((n, 2)), rng.uniform(360, 830, (n, 4))], 1).astype(np.float32)
+        g = d.eval(9, x); o = oracle_spectral.eval(9, x, desc=scene.desc())
+        assert g.shape[1] == 14 and np.array_equal(g.view(np.uint32), o.view(np.uint32)) and (g[:, :4] >= 0).all() and g[:, :4].max() > 0
+        job = spectral.PathIntegrator().render_job(sensor)
+        o32, _, ost = oracle_spectral.render(scene.desc(), job, threads=8, want_f64=False)
+        g32, st = d.render(job)
+        c = d.counters()
+        assert st == 0 and c.plan == 2 and c.film_mode == 1 and (c.samples, c.segments) == (ost.samples, ost.segments)
+        assert np.array_equal(g32, o32) and g32[..., 1].mean() > 0
+    # without its density the spectral library refuses the map (its texels are coefficients)
+    rec = scene.desc().contents.envmap.contents
+    keep = rec.density; rec.density = None
+    try:
+        with pytest.raises(RuntimeError, match="density"):
+            d.upload(scene.desc())
+    finally:
+        rec.density = keep
+    d.close()
+
