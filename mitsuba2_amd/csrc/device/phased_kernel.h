@@ -33,6 +33,9 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 // a lane's stack: its column of the workgroup's entry-major LDS array (slot i of lane l at i * MIW_BLOCK + l: conflict-free)
 struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
 
+#ifndef MIW_PIN_TREE_PTRS
+#define MIW_PIN_TREE_PTRS 1           /* 1: node / triangle table pointers of the walk bodies kept in registers (below); C3 +1.5 %, gpurun r4e */
+#endif
 #ifndef MIW_PHASE_SPEC
 #define MIW_PHASE_SPEC 1
 #endif
@@ -60,6 +63,31 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     const Bvh4Node *nodes4 = sc.nodes4;
     const Tri *gtris = sc.tris;
     (void) gnodes; (void) nodes4;
+#if MIW_PIN_TREE_PTRS && defined(__HIP_DEVICE_COMPILE__)
+    // The walk bodies read these two pointers on every trip, in front of the load every trip waits for. Left to itself the
+    // compiler (short of SGPRs) re-reads them from the kernel arguments inside the loops — an s_load + s_waitcnt on the critical
+    // path of every node step. Made opaque here they are values it has to KEEP: in SGPRs or, spilled, in a VGPR lane (v_readlane:
+    // a couple of cycles instead of a scalar-cache round trip). An opaque pointer is a generic one, so the records are read
+    // through explicitly global pointers to 16-byte vectors (global_load_dwordx4, as before) and handed on by value.
+    typedef uint32_t miw_u4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) miw_u4 *GlobalU4;
+    GlobalU4 nodes4_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes4), tris_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.tris);
+    asm volatile("" : "+s"(nodes4_g));
+    asm volatile("" : "+s"(tris_g));
+    auto node4_at = [nodes4_g](int32_t i) -> Bvh4Node {
+        GlobalU4 p = nodes4_g + 4 * (size_t) (uint32_t) i;
+        miw_u4 q[4] = { p[0], p[1], p[2], p[3] };
+        Bvh4Node n; __builtin_memcpy(&n, q, sizeof n); return n;
+    };
+    auto tri_at_g = [tris_g](uint32_t i) -> Tri {
+        GlobalU4 p = tris_g + 3 * (size_t) i;
+        miw_u4 q[3] = { p[0], p[1], p[2] };
+        Tri t; __builtin_memcpy(&t, q, sizeof t); return t;
+    };
+#else
+    auto node4_at = [nodes4](int32_t i) -> const Bvh4Node & { return nodes4[i]; };
+    auto tri_at_g = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
+#endif
 #if MIW_LDS_TOP
     const BvhNode *lnodes = reinterpret_cast<const BvhNode *>(smem);
     const uint32_t ns = cfg.nodes_staged;
@@ -191,7 +219,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         // one 64-byte node = four quantised child boxes: the node step of miw/bvh4.h (the CPU checker runs the same statements)
                         const LdsColumn column{ stack };
                         FastRay rn; rn.inv_d = r.inv_d; rn.neg_o_inv_d = r.neg_o_inv_d; rn.mint = L.ray.mint;   // (r.mint would be one more register carried through the shade body)
-                        MIW_WALK4_NODE_STEP(Spec, nodes4[cur], rn, widen(tmax), cur, sp, tri_i, tri_end, column);
+                        const auto &nd = node4_at(cur);
+                        MIW_WALK4_NODE_STEP(Spec, nd, rn, widen(tmax), cur, sp, tri_i, tri_end, column);
                     } else {
                         int32_t next = MIW_WALK_DONE;
 #if MIW_LDS_TOP
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     const float maxt_cur = s_walk ? sh.maxt : L.ray.maxt;
 #if MIW_TRI_PAIR
                     // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
-                    walk4_tri_step<Analytic>([gtris](uint32_t i) -> const Tri & { return gtris[i]; }, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
+                    walk4_tri_step<Analytic>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
                                              mode == PH_TRAV_S, best, tmax, occluded, cur, sp, tri_i, tri_end, LdsColumn{ stack });
 #else
                     const Tri &tr = gtris[tri_i];

@@ -405,7 +405,9 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (!hasS) mS = 0;
         MIW_SECTION(1);
         uint32_t s_tri = 0; float s_t = 0.f;
+        MIW_WALK_STATS_DECL;                                   // debug builds: candidate tests per ray and the loops' SIMT efficiency
         while (mE != 0) {                                      // closest hit of E over its candidates
+            MIW_WALK_STATS_STEP(0);
             const uint32_t i = lowest(mE);
             mE &= mE - 1;
             const TriPacket &k = pk[i];
@@ -415,6 +417,7 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         }
         MIW_SECTION(2);
         while (mS != 0) {                                      // any hit of S
+            MIW_WALK_STATS_STEP(1);
             const uint32_t i = lowest(mS);
             mS &= mS - 1;
             const TriPacket &k = pk[i];
@@ -429,6 +432,10 @@ __device__ __forceinline__ void trace2(const SceneView &sc, TraceLds cfg, const 
         if (h.tri != MIW_MISS && !hit_in_bounds(tb[h.tri], o, dE, h.t)) trace_brute<false>(sc, cfg, smem, o, dE, mint, maxtE, h);
         if (occ && !hit_in_bounds(tb[s_tri], o, dS, s_t)) { Hit hs; occ = trace_brute<true>(sc, cfg, smem, o, dS, mint, maxtS, hs); }
         MIW_SECTION(3);
+#if defined(MIW_WALK_STATS)
+        atomicAdd(&g_walk_stats[1], ws_lane_[0]); atomicAdd(&g_walk_statsf[1], ws_wave_[0]); if (hasE) atomicAdd(&g_walk_stats[2], 1ull);
+        atomicAdd(&g_walk_stats[5], ws_lane_[1]); atomicAdd(&g_walk_statsf[5], ws_wave_[1]); if (hasS) atomicAdd(&g_walk_stats[6], 1ull);
+#endif
 #if defined(MIW_VERIFY_FILTER)
         {   // debug builds: every filtered query against the full sweep; mismatching rays go to g_verify
             Hit hb; bool occ_b = false;

@@ -3,7 +3,8 @@
 Round 3 measured what a spilled vector register costs these kernels ("the register diet": the interior
 +17 %, the material balls +16 % from 121 -> 12 spilled registers at four wavefronts per SIMD), so the budgets are part of the
 contract: the Cornell packet kernel fits 128 VGPRs (four wavefronts per SIMD) without spilling, the phase machine of configs
-3 / 4 fits them with at most 16 spilled. tools/probe_*.hip instantiate exactly those kernels from the product's headers
+3 / 4 fits them with at most 20 spilled (12 until round 4's pinned tree pointers, which cost eight more in the shade body and
+still measured +1.5 % on the material balls: gpurun r4e). tools/probe_*.hip instantiate exactly those kernels from the product's headers
 (~12 s each); tools/kernel_resources.py prints the table for every variant."""
 import os
 import re
@@ -39,4 +40,4 @@ def test_cornell_packet_kernel_fits_four_waves_without_spills(tmp_path):
 
 def test_phase_machine_of_configs_3_and_4_fits_four_waves(tmp_path):
     r = _resources("probe_phased.hip", "k_path_phasedILi3ELb0ELb1ELi4ELb1E", tmp_path, "-DMIW_PROBE_C34=1")
-    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 16, r
+    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 20, r

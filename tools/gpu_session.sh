@@ -1,9 +1,8 @@
 #!/bin/bash
 # One GPU session of round 4 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
-# This one: the GPU tier on the working tree (spectral environment map, rcp_loop in the packet kernel's Moeller-Trumbore test, the
-# C3 full-frame digest when it is there), then C2 / C5 of the working tree against the library of HEAD (build_exp/head).
+# This one: MIW_PIN_TREE_PTRS=1 (the phase machine's node / triangle pointers kept in registers instead of re-read from the kernel
+# arguments on every trip) against the in-tree library on C3 and C4, three runs each, + the tree parity tests on the variant.
 tag=${1:-s}; out=gpurun_out; mkdir -p $out
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $out/${tag}_pytest_gpu.txt; cat $out/${tag}_pytest_gpu.txt | tail -4
 B="--no-cpu-baseline --no-extras --no-live-counters"
 run() {  # run <label> <lib dir or -> <env...> -- <bench args...>
   local label=$1 lib=$2; shift 2
@@ -19,11 +18,10 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e, flush=True)
 P
 }
-for rep in 1 2; do
-  run c2_head_$rep head -- --steps 3 --warmup 1
-  run c2_tree_$rep - -- --steps 3 --warmup 1
+for rep in 1 2 3; do
+  for v in - pin; do
+    run c3_${v}_$rep $v -- --scene matball --spp 256 --steps 2 --warmup 1
+    run c4_${v}_$rep $v -- --scene interior --spp 64 --steps 2 --warmup 1
+  done
 done
-run c5_tree - -- --variant scalar_spectral --scene glassblock --steps 2 --warmup 1
-run c3_tree - -- --scene matball --spp 256 --steps 2 --warmup 1
-run c4_tree - -- --scene interior --spp 32 --steps 2 --warmup 1
-run c4_head head -- --scene interior --spp 32 --steps 2 --warmup 1
+MIWAVE_LIB_DIR=$PWD/build_exp/pin timeout 600 python -m pytest tests/test_gpu_configured.py -x -q -k "c3_window or c4_windows" 2>&1 | tail -2
