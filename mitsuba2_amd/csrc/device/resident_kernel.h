@@ -170,9 +170,6 @@ struct QueueWork {
     }
 };
 
-#ifndef MIW_PIN_SCENE_PTRS
-#define MIW_PIN_SCENE_PTRS 0
-#endif
 #ifndef MIW_DIRECT_WAVES
 /* Waves per SIMD the direct-integrator kernels are compiled for. At 2 (256 VGPRs) none of them spills, at 3 (168) they keep
    16 - 108 registers in scratch (60 / 216 in the MATS_ALL ones when this was measured) — and are faster all the same (path kernel of one frame,
@@ -188,13 +185,6 @@ __global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
     const float *thr = stage_thresholds(smem, cfg, UseLog && Q.log_rec ? Q.log_thr : nullptr);
-#if MIW_PIN_SCENE_PTRS && defined(__HIP_DEVICE_COMPILE__)
-    // (experiment) the scene tables' pointers as opaque register values instead of kernel arguments the compiler re-reads at every use
-    if (Tiny) {
-        asm volatile("" : "+s"(sc.tris)); asm volatile("" : "+s"(sc.shapes)); asm volatile("" : "+s"(sc.bsdfs)); asm volatile("" : "+s"(sc.emitters));
-        asm volatile("" : "+s"(sc.emit_tri)); asm volatile("" : "+s"(sc.emit_pmf)); asm volatile("" : "+s"(sc.emit_cdf));
-    }
-#endif
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
 #endif
