@@ -16,6 +16,8 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
     uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
+    uint32_t tab16;         // packet kernels and the phase machine: uint4 offset of the scene's small tables in dynamic LDS (stage_tables)
+    uint32_t tab_words[7];  // dwords of: shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf (0: that table is absent)
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
@@ -29,6 +31,9 @@ static_assert(sizeof(LeafBox) == 32, "LeafBox must be 32 bytes");
 struct alignas(16) TriPacket { float p0[3], e1[3], e2[3]; uint32_t prim; uint32_t pad[2]; };
 static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 
+#ifndef MIW_LDS_TABLES
+#define MIW_LDS_TABLES 1            /* 1: packet kernels and the phase machine read the scene's small tables from LDS (stage_tables) */
+#endif
 #ifndef MIW_OCTANT_BOXES
 #define MIW_OCTANT_BOXES 1          /* 1: the leaf boxes of a tiny scene are staged once per ray octant, entry / exit plane of every axis side by side (leaf_box_test_octant); 0: one copy, min / max per axis */
 #endif
@@ -89,6 +94,34 @@ __device__ __forceinline__ const float *stage_thresholds(uint4 *smem, TraceLds c
         __syncthreads();
     }
     return t;
+}
+
+// The scene's small tables — shape, BSDF and emitter records, the emitters' face tables — copied behind everything else in dynamic
+// LDS, and the kernel's SceneView pointed at the copies (round 4). What path_step reads between two scene queries is a handful
+// of DEPENDENT lookups (triangle -> shape -> BSDF record; emitter record -> CDF -> face); from global memory each is a round trip
+// through the CU's request path, which the tree walks keep full (a shade run of the phase machine: ~30 k cycles on the material
+// balls, ~82 k on the interior for ~2 k instruction slots). From LDS they are ds_reads. Unconditional for the
+// kernels that call it (the pointers must not be a choice between address spaces): the host launches those kernels only when
+// the tables fit (mi_render / mi_bvh_build), the lock-step tree kernels read the tables from global memory as before.
+__device__ __forceinline__ void stage_tables(SceneView &sc, const TraceLds &cfg, uint4 *smem) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem + cfg.tab16);
+    const uint32_t *src[7] = { reinterpret_cast<const uint32_t *>(sc.shapes), reinterpret_cast<const uint32_t *>(sc.bsdfs), reinterpret_cast<const uint32_t *>(sc.emitters),
+                               reinterpret_cast<const uint32_t *>(sc.emit_tri), reinterpret_cast<const uint32_t *>(sc.emit_vnorm),
+                               reinterpret_cast<const uint32_t *>(sc.emit_pmf), reinterpret_cast<const uint32_t *>(sc.emit_cdf) };
+    uint32_t *at[7];
+    uint32_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint32_t n = cfg.tab_words[k];
+        at[k] = dst + off;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[off + i] = src[k][i];
+        off += (n + 3u) & ~3u;                                  // every table starts on a 16-byte boundary
+    }
+    __syncthreads();
+    sc.shapes = reinterpret_cast<const ShapeRec *>(at[0]); sc.bsdfs = reinterpret_cast<const BsdfRec *>(at[1]); sc.emitters = reinterpret_cast<const EmitterRec *>(at[2]);
+    sc.emit_tri = reinterpret_cast<const float *>(at[3]);
+    sc.emit_vnorm = reinterpret_cast<const float *>(at[4]);          // (read only for emitters whose flags say so; 0 words when absent)
+    sc.emit_pmf = reinterpret_cast<const float *>(at[5]); sc.emit_cdf = reinterpret_cast<const float *>(at[6]);
 }
 
 // Candidate-box test shared by the tiny-scene filter (trace2) and the stack traversal below: the slab

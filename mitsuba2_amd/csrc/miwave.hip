@@ -441,6 +441,18 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 }
 
 // ---- BVH build ------------------------------------------------------------------------
+// dwords of the tables stage_tables() copies into LDS (shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf), each
+// padded to 16 bytes; returns the bytes of the block
+#define MIW_LDS_PER_WORKGROUP (40u * 1024u)       /* 160 KB per CU / four workgroups of 256 (four wavefronts per SIMD) */
+static size_t lds_table_bytes(const mi_ctx *c, uint32_t words[7]) {
+    words[0] = (uint32_t) (c->shapes.size() * sizeof(ShapeRec) / 4); words[1] = (uint32_t) (c->bsdfs.size() * sizeof(BsdfRec) / 4);
+    words[2] = (uint32_t) (c->emitters.size() * sizeof(EmitterRec) / 4);
+    words[3] = (uint32_t) c->emit_tri.size(); words[4] = (uint32_t) c->emit_vnorm.size(); words[5] = (uint32_t) c->emit_pmf.size(); words[6] = (uint32_t) c->emit_cdf.size();
+    size_t total = 0;
+    for (int k = 0; k < 7; ++k) total += ((size_t) words[k] + 3u) / 4u * 16u;
+    return total;
+}
+
 mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     if (!c) return MI_ERR_INVALID;
     if (!c->have_scene) return fail(c, MI_ERR_STATE, "mi_bvh_build: no scene uploaded");
@@ -460,7 +472,11 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     int max_fan = 4;
     if (const char *e = getenv("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
     double ms_bvh4 = 0.0;
-    const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree && c->rects.empty();   // packets are triangles only
+    uint32_t tab_words_[7];
+    // (the packet kernels read the scene's small tables from LDS: a scene of <= 64 triangles whose tables would not fit beside the
+    // packets — dozens of unused BSDF records — is walked as a tree instead)
+    const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree && c->rects.empty() &&   // packets are triangles only
+                      (!MIW_LDS_TABLES || lds_table_bytes(c, tab_words_) <= 24u * 1024u);
     if (quality == 0 && !tiny && tri_count >= 2) {
         // ---- device LBVH (lbvh_device.h) ----
         hipStream_t s = c->stream;
@@ -997,6 +1013,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     TraceLds rcfg = c->lds_cfg; size_t rlds = c->lds_bytes;
     rcfg.thr16 = (uint32_t) ((rlds + 15) / 16);
     if (rec16) rlds = (size_t) rcfg.thr16 * 16 + (MIW_FC_TABLE + 3) / 4 * 16;
+    // the scene's small tables behind that (trace.h: stage_tables). The kernels that stage them keep four workgroups per CU
+    // (160 KB / 4), so the tables have to fit what the stack / the packets and the thresholds leave of 40 KB; a scene whose tables
+    // do not takes the lock-step tree kernels, which read them from global memory (tables_fit; mi_bvh_build applies the same bound
+    // before it declares a scene tiny).
+    rcfg.tab16 = (uint32_t) ((rlds + 15) / 16);
+    const size_t table_bytes = lds_table_bytes(c, rcfg.tab_words);
+    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= MIW_LDS_PER_WORKGROUP;
+    if (tables_fit) rlds = (size_t) rcfg.tab16 * 16 + table_bytes;
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -1079,7 +1103,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
         const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
         const bool trio_kernel = c->trio && trio_on && c->rects.empty() && !c->textured;   // 52 KB of code instead of 84
-        const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel);
+        const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel) && (tables_fit || !MIW_LDS_TABLES);
         // 4 waves per SIMD for every tree (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0 before the register diet, +8 % after); MIW_PHASED_WAVES = 3 | 4 overrides
         int ph_waves = 4;
         if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;

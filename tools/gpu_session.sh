@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session of round 4 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
-# This one: MIW_PIN_TREE_PTRS=1 (the phase machine's node / triangle pointers kept in registers instead of re-read from the kernel
-# arguments on every trip) against the in-tree library on C3 and C4, three runs each, + the tree parity tests on the variant.
+# This one: MIW_LDS_TABLES (the scene's small tables read from LDS by the packet kernels and the phase machine; in-tree library)
+# against the same sources built with -DMIW_LDS_TABLES=0 (build_exp/notab), then the whole GPU tier on the in-tree library.
 tag=${1:-s}; out=gpurun_out; mkdir -p $out
 B="--no-cpu-baseline --no-extras --no-live-counters"
 run() {  # run <label> <lib dir or -> <env...> -- <bench args...>
@@ -18,10 +18,14 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e, flush=True)
 P
 }
-for rep in 1 2 3; do
-  for v in - pin; do
+for rep in 1 2; do
+  for v in notab -; do
+    run c2_${v}_$rep $v -- --steps 3 --warmup 1
     run c3_${v}_$rep $v -- --scene matball --spp 256 --steps 2 --warmup 1
     run c4_${v}_$rep $v -- --scene interior --spp 64 --steps 2 --warmup 1
   done
 done
-MIWAVE_LIB_DIR=$PWD/build_exp/pin timeout 600 python -m pytest tests/test_gpu_configured.py -x -q -k "c3_window or c4_windows" 2>&1 | tail -2
+run c5_tree - -- --variant scalar_spectral --scene glassblock --steps 2 --warmup 1
+run direct_tree - -- --integrator direct --steps 2 --warmup 1
+run direct_notab notab -- --integrator direct --steps 2 --warmup 1
+(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $out/${tag}_pytest_gpu.txt; tail -4 $out/${tag}_pytest_gpu.txt
