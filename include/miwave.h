@@ -276,7 +276,7 @@ typedef struct {
     double ms_film_blocks, ms_film_merge;   /* split of ms_resolve for film_mode 1       */
     uint32_t bvh_on_device;    /* 1: the last mi_bvh_build ran a device builder (bvh_builder says which) */
     uint32_t path_kernel;      /* last render. plan 2: 0 = k_path_resident (lock-step lanes: packet scenes, direct integrator,
-                                  float64 film, trees the 4-wide collapse refuses), 1 = k_path_phased (wave-level phase machine over the 4-wide
+                                  float64 film, trees the 4-wide collapse refuses, scenes whose shape / BSDF / emitter tables do not fit a workgroup's LDS), 1 = k_path_phased (wave-level phase machine over the 4-wide
                                   quantised tree, per-lane LDS stack), 3 = k_path_phased over the BVH2 (MIW_BVH4=0, A/B switch).
                                   plan 1: 0 = k_trace<closest|any> per list slice, 2 = k_trace_stream (persistent walk kernel
                                   with dynamic ray fetch; ms_trace_closest = its time, ms_trace_any = k_sort_hits) */

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     stage_to_lds(sc, cfg, smem);
     const float *thr = stage_thresholds(smem, cfg, Q.log_rec ? Q.log_thr : nullptr);
 #if MIW_LDS_TABLES
-    stage_tables(sc, cfg, smem);
+    stage_tables<false>(sc, cfg, smem);
 #endif
     int32_t *stack = reinterpret_cast<int32_t *>(smem + cfg.stack16) + threadIdx.x;
     const BvhNode *gnodes = sc.nodes;

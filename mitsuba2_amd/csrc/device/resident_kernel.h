@@ -186,7 +186,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES
     stage_to_lds(sc, cfg, smem);
     const float *thr = stage_thresholds(smem, cfg, UseLog && Q.log_rec ? Q.log_thr : nullptr);
 #if MIW_LDS_TABLES
-    if constexpr (UseLog && Tiny != 0) stage_tables(sc, cfg, smem);
+    if constexpr (UseLog && Tiny != 0) stage_tables<true>(sc, cfg, smem);
 #endif
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }

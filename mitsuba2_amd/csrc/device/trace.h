@@ -17,7 +17,8 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS
     uint32_t tab16;         // packet kernels and the phase machine: uint4 offset of the scene's small tables in dynamic LDS (stage_tables)
-    uint32_t tab_words[7];  // dwords of: shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf (0: that table is absent)
+    uint32_t tab_words[10]; // dwords of: shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf; packet kernels also: tris, tri_vn, tri_uv (0: absent)
+    uint32_t env_top_count, env_top_base, env_top_words;   // the environment warp's top levels behind the tables (envmap.h: EnvTop); 0: none
 };
 
 // Padded bounding box of one BVH leaf (consecutive triangles in leaf order) + their 64-bit candidate mask, 32 B = 2 x b128.
@@ -103,25 +104,38 @@ __device__ __forceinline__ const float *stage_thresholds(uint4 *smem, TraceLds c
 // balls, ~82 k on the interior for ~2 k instruction slots). From LDS they are ds_reads. Unconditional for the
 // kernels that call it (the pointers must not be a choice between address spaces): the host launches those kernels only when
 // the tables fit (mi_render / mi_bvh_build), the lock-step tree kernels read the tables from global memory as before.
+template <bool WithTris>     // packet scenes (<= 64 triangles): the triangle records the shading reads, their vertex normals and texture coordinates too
 __device__ __forceinline__ void stage_tables(SceneView &sc, const TraceLds &cfg, uint4 *smem) {
+    constexpr int N = WithTris ? 10 : 7;
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem + cfg.tab16);
-    const uint32_t *src[7] = { reinterpret_cast<const uint32_t *>(sc.shapes), reinterpret_cast<const uint32_t *>(sc.bsdfs), reinterpret_cast<const uint32_t *>(sc.emitters),
-                               reinterpret_cast<const uint32_t *>(sc.emit_tri), reinterpret_cast<const uint32_t *>(sc.emit_vnorm),
-                               reinterpret_cast<const uint32_t *>(sc.emit_pmf), reinterpret_cast<const uint32_t *>(sc.emit_cdf) };
-    uint32_t *at[7];
+    const uint32_t *src[10] = { reinterpret_cast<const uint32_t *>(sc.shapes), reinterpret_cast<const uint32_t *>(sc.bsdfs), reinterpret_cast<const uint32_t *>(sc.emitters),
+                                reinterpret_cast<const uint32_t *>(sc.emit_tri), reinterpret_cast<const uint32_t *>(sc.emit_vnorm),
+                                reinterpret_cast<const uint32_t *>(sc.emit_pmf), reinterpret_cast<const uint32_t *>(sc.emit_cdf),
+                                reinterpret_cast<const uint32_t *>(sc.tris), reinterpret_cast<const uint32_t *>(sc.tri_vn), reinterpret_cast<const uint32_t *>(sc.tri_uv) };
+    uint32_t *at[10];
     uint32_t off = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < N; ++k) {
         const uint32_t n = cfg.tab_words[k];
         at[k] = dst + off;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[off + i] = src[k][i];
         off += (n + 3u) & ~3u;                                  // every table starts on a 16-byte boundary
     }
+    // the smallest levels of the environment map's sampling hierarchy (the first steps of hier2d_sample's chain of dependent reads)
+    uint32_t *env_at = dst + off;
+    if (cfg.env_top_words) {
+        const uint32_t *lv = reinterpret_cast<const uint32_t *>(sc.env->levels) + cfg.env_top_base;
+        for (uint32_t i = threadIdx.x; i < cfg.env_top_words; i += blockDim.x) env_at[i] = lv[i];
+    }
+    sc.env_top = reinterpret_cast<const float *>(env_at); sc.env_top_count = cfg.env_top_count; sc.env_top_base = cfg.env_top_base;
     __syncthreads();
     sc.shapes = reinterpret_cast<const ShapeRec *>(at[0]); sc.bsdfs = reinterpret_cast<const BsdfRec *>(at[1]); sc.emitters = reinterpret_cast<const EmitterRec *>(at[2]);
     sc.emit_tri = reinterpret_cast<const float *>(at[3]);
     sc.emit_vnorm = reinterpret_cast<const float *>(at[4]);          // (read only for emitters whose flags say so; 0 words when absent)
     sc.emit_pmf = reinterpret_cast<const float *>(at[5]); sc.emit_cdf = reinterpret_cast<const float *>(at[6]);
+    if (WithTris) {                                                  // (tri_vn / tri_uv: read only for shapes whose flags say so)
+        sc.tris = reinterpret_cast<const Tri *>(at[7]); sc.tri_vn = reinterpret_cast<const float *>(at[8]); sc.tri_uv = reinterpret_cast<const float *>(at[9]);
+    }
 }
 
 // Candidate-box test shared by the tiny-scene filter (trace2) and the stack traversal below: the slab

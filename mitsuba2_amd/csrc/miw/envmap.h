@@ -59,14 +59,19 @@ MIW_HD uint32_t hier2d_index(uint32_t x, uint32_t y, uint32_t width) {
     return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width);
 }
 
+// A second copy of the hierarchy's TOP levels (the smallest ones: levels n_levels - count .. n_levels - 1, `base` = float offset
+// of the first of them in EnvmapRec::levels): the device kernels that stage tables in LDS (device/trace.h: stage_tables) read the
+// first steps of the warp from there — the same floats, so the same sample. count == 0 (everywhere else): no such copy.
+struct EnvTop { const float *p; uint32_t count, base; };
+MIW_HD EnvTop env_top_none() { EnvTop t; t.p = nullptr; t.count = 0; t.base = 0; return t; }
+
 // Hierarchical2D::sample, distr_2d.h:470-558 (Dimension = 0: no conditional parameters)
-MIW_HD V2 hier2d_sample(const EnvmapRec &e, V2 sample, float &pdf) {
+MIW_HD V2 hier2d_sample(const EnvmapRec &e, V2 sample, float &pdf, EnvTop top = env_top_none()) {
     sample.x = clamp_(sample.x, 0.f, 1.f); sample.y = clamp_(sample.y, 0.f, 1.f);
     uint32_t ox = 0, oy = 0;
-    for (int l = (int) e.n_levels - 2; l > 0; --l) {
-        const float *lv = e.levels + e.level_offset[l];
+    auto descend = [&](const float *lv, uint32_t width) {           // one level of the hierarchy, :487-527
         ox <<= 1; oy <<= 1;
-        uint32_t i = hier2d_index(ox, oy, e.level_width[l]);
+        uint32_t i = hier2d_index(ox, oy, width);
         float v00 = lv[i], v10 = lv[i + 1], v01 = lv[i + 2], v11 = lv[i + 3];
         sample.x = clamp_(sample.x, 0.f, 1.f); sample.y = clamp_(sample.y, 0.f, 1.f);
         // select the row
@@ -82,7 +87,10 @@ MIW_HD V2 hier2d_sample(const EnvmapRec &e, V2 sample, float &pdf) {
         if (mask) sample.x -= c0;
         sample.x /= mask ? c1 : c0;
         if (mask) ox += 1u;
-    }
+    };
+    int l = (int) e.n_levels - 2;
+    for (; l > 0 && l >= (int) e.n_levels - (int) top.count; --l) descend(top.p + (e.level_offset[l] - top.base), e.level_width[l]);
+    for (; l > 0; --l) descend(e.levels + e.level_offset[l], e.level_width[l]);
     const float *l0 = e.levels + e.level_offset[0];
     uint32_t w = e.level_width[0], i = ox + oy * w;
     float v00 = l0[i], v10 = l0[i + 1], v01 = l0[i + w], v11 = l0[i + w + 1];
@@ -140,9 +148,9 @@ MIW_HD float env_inv_sin_theta(V3 d) {
 
 // EnvironmentMapEmitter::sample_direction, envmap.cpp:157-190. Returns radiance / pdf.
 MIW_HD V3 env_sample_direction(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d_out, float &dist_out, float &pdf_out,
-                               V3 &p_out, V3 &n_out) {
+                               V3 &p_out, V3 &n_out, EnvTop top = env_top_none()) {
     float pdf;
-    V2 uv = hier2d_sample(e, sample, pdf);
+    V2 uv = hier2d_sample(e, sample, pdf, top);
     float theta = uv.y * MIW_PI, phi = uv.x * (2.f * MIW_PI);
     float st, ct, sp, cp;
     sincos_(theta, st, ct); sincos_(phi, sp, cp);          // math::sphdir, math.h:48-57

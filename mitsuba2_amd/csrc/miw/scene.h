@@ -66,7 +66,9 @@ struct SceneView {
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
     const struct Bvh4Node *nodes4;                  // device only: the 4-wide quantised tree the phase machine walks (bvh4.h) or nullptr
+    const float *env_top; uint32_t env_top_count, env_top_base;   // device only: the environment warp's top levels in LDS (envmap.h: EnvTop); count 0: none
 };
+MIW_HD EnvTop env_top(const SceneView &sc) { EnvTop t; t.p = sc.env_top; t.count = sc.env_top_count; t.base = sc.env_top_base; return t; }
 MIW_HD void scene_view_prepare(SceneView &v) {
     v.emitter_count_f = (float) v.emitter_count;
     v.emitter_count_inv = v.emitter_count ? 1.f / (float) v.emitter_count : 0.f;
@@ -203,9 +205,9 @@ MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d_world, const Wavelengths &wl)
 }
 // EnvironmentMapEmitter::sample_direction, envmap.cpp:157-190: env_sample_direction of envmap.h with the spectral lookup
 MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d_out, float &dist_out, float &pdf_out,
-                                      V3 &p_out, V3 &n_out, const Wavelengths &wl) {
+                                      V3 &p_out, V3 &n_out, const Wavelengths &wl, EnvTop top = env_top_none()) {
     float pdf;
-    V2 uv = hier2d_sample(e, sample, pdf);
+    V2 uv = hier2d_sample(e, sample, pdf, top);
     float theta = uv.y * MIW_PI, phi = uv.x * (2.f * MIW_PI);
     float st, ct, sp, cp;
     sincos_(theta, st, ct); sincos_(phi, sp, cp);
@@ -221,8 +223,9 @@ MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V
     return env_eval_uv_spec(e, uv, wl) / ds_pdf;
 }
 #else
-MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d, float &dist, float &pdf, V3 &p, V3 &n, const Wavelengths &) {
-    return env_sample_direction(e, ref_p, sample, d, dist, pdf, p, n);
+MIW_HD Spec env_sample_direction_spec(const EnvmapRec &e, V3 ref_p, V2 sample, V3 &d, float &dist, float &pdf, V3 &p, V3 &n, const Wavelengths &,
+                                      EnvTop top = env_top_none()) {
+    return env_sample_direction(e, ref_p, sample, d, dist, pdf, p, n, top);
 }
 MIW_HD Spec env_eval_spec(const EnvmapRec &e, V3 d, const Wavelengths &) { return env_eval(e, d); }
 #endif
@@ -236,7 +239,7 @@ MIW_HD Spec emitter_sample_direction(const SceneView &sc, uint32_t index, V3 ref
     Spec value;
     ds.emitter = index;
     if (e.type == EMITTER_ENVMAP) {
-        value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n, wl);
+        value = env_sample_direction_spec(*sc.env, ref_p, sample, ds.d, ds.dist, ds.pdf, ds.p, ds.n, wl, env_top(sc));
     } else {
         if (Analytic && (e.flags & 2u) && sc.rects[e.tri_first].kind == ANALYTIC_SPHERE) {
             sphere_sample_direction(sc.rects[e.tri_first], ref_p, sample, ds);      // the sphere's own sample_direction

@@ -138,7 +138,7 @@ struct mi_ctx {
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<AnalyticRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds; DevBuf<Bvh4Node> d_nodes4; uint32_t nodes4_count = 0, nodes4_stack = 0;
-    DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env;
+    DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env; EnvmapRec env_host{}; size_t env_levels_total = 0;   // (host copy of the record: level offsets for the LDS staging)
     bool have_env = false;
     SceneView view{};
     TraceLds lds_cfg{}; size_t lds_bytes = 0;
@@ -421,6 +421,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
         HIP_TRY(c, c->d_env_data.upload(t.data, c->stream));
         HIP_TRY(c, c->d_env_levels.upload(t.levels, c->stream));
         t.rec.data = c->d_env_data.p; t.rec.levels = c->d_env_levels.p;
+        c->env_host = t.rec; c->env_levels_total = t.levels.size();
         std::vector<EnvmapRec> one(1, t.rec);
         HIP_TRY(c, c->d_env.upload(one, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -444,12 +445,15 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 // dwords of the tables stage_tables() copies into LDS (shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf), each
 // padded to 16 bytes; returns the bytes of the block
 #define MIW_LDS_PER_WORKGROUP (40u * 1024u)       /* 160 KB per CU / four workgroups of 256 (four wavefronts per SIMD) */
-static size_t lds_table_bytes(const mi_ctx *c, uint32_t words[7]) {
+static size_t lds_table_bytes(const mi_ctx *c, uint32_t words[10], bool with_tris) {
     words[0] = (uint32_t) (c->shapes.size() * sizeof(ShapeRec) / 4); words[1] = (uint32_t) (c->bsdfs.size() * sizeof(BsdfRec) / 4);
     words[2] = (uint32_t) (c->emitters.size() * sizeof(EmitterRec) / 4);
     words[3] = (uint32_t) c->emit_tri.size(); words[4] = (uint32_t) c->emit_vnorm.size(); words[5] = (uint32_t) c->emit_pmf.size(); words[6] = (uint32_t) c->emit_cdf.size();
+    // packet scenes: the triangle records (leaf order), their vertex normals and per-face texture coordinates as well
+    words[7] = with_tris ? (uint32_t) (c->tris_in.size() * sizeof(Tri) / 4) : 0u;
+    words[8] = with_tris ? (uint32_t) c->tri_vn_in.size() : 0u; words[9] = with_tris ? (uint32_t) c->tri_uv_in.size() : 0u;
     size_t total = 0;
-    for (int k = 0; k < 7; ++k) total += ((size_t) words[k] + 3u) / 4u * 16u;
+    for (int k = 0; k < 10; ++k) total += ((size_t) words[k] + 3u) / 4u * 16u;
     return total;
 }
 
@@ -472,11 +476,11 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     int max_fan = 4;
     if (const char *e = getenv("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
     double ms_bvh4 = 0.0;
-    uint32_t tab_words_[7];
+    uint32_t tab_words_[10];
     // (the packet kernels read the scene's small tables from LDS: a scene of <= 64 triangles whose tables would not fit beside the
     // packets — dozens of unused BSDF records — is walked as a tree instead)
     const bool tiny = c->tris_in.size() <= MIW_BRUTE_MAX_TRIS && !force_tree && c->rects.empty() &&   // packets are triangles only
-                      (!MIW_LDS_TABLES || lds_table_bytes(c, tab_words_) <= 24u * 1024u);
+                      (!MIW_LDS_TABLES || lds_table_bytes(c, tab_words_, true) <= 24u * 1024u);
     if (quality == 0 && !tiny && tri_count >= 2) {
         // ---- device LBVH (lbvh_device.h) ----
         hipStream_t s = c->stream;
@@ -665,6 +669,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     v.emit_tri = c->d_emit_tri.p; v.emit_vnorm = c->emit_vnorm.empty() ? nullptr : c->d_emit_vnorm.p;
     v.emit_pmf = c->d_emit_pmf.p; v.emit_cdf = c->d_emit_cdf.p;
     v.env = c->have_env ? c->d_env.p : nullptr;
+    v.env_top = nullptr; v.env_top_count = v.env_top_base = 0;      // (set inside the kernels that stage them: trace.h stage_tables)
     v.rects = c->rects.empty() ? nullptr : c->d_rects.p; v.rect_count = (uint32_t) c->rects.size();
 
     // LDS plan: whole scene if it fits in 16 KiB (keeps 8 workgroups/CU resident),
@@ -1018,8 +1023,23 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // do not takes the lock-step tree kernels, which read them from global memory (tables_fit; mi_bvh_build applies the same bound
     // before it declares a scene tiny).
     rcfg.tab16 = (uint32_t) ((rlds + 15) / 16);
-    const size_t table_bytes = lds_table_bytes(c, rcfg.tab_words);
+    size_t table_bytes = lds_table_bytes(c, rcfg.tab_words, c->lds_cfg.brute != 0);
     const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= MIW_LDS_PER_WORKGROUP;
+    rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0;
+    if (tables_fit && c->have_env) {
+        // ... and as many of the environment warp's smallest levels as fit what is left (at most 4 KB): levels are stored from the
+        // largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
+        const EnvmapRec &e = c->env_host;
+        const size_t room = std::min<size_t>(4096, MIW_LDS_PER_WORKGROUP - ((size_t) rcfg.tab16 * 16 + table_bytes));
+        uint32_t count = 0;
+        while (count + 1 < e.n_levels && ((size_t) c->env_levels_total - e.level_offset[e.n_levels - 1 - count]) * 4 <= room) ++count;
+        if (count) {
+            rcfg.env_top_count = count; rcfg.env_top_base = e.level_offset[e.n_levels - count];
+            rcfg.env_top_words = (uint32_t) (c->env_levels_total - rcfg.env_top_base);
+            table_bytes += ((size_t) rcfg.env_top_words + 3) / 4 * 16;
+        }
+    }
+    if (getenv("MIW_ENV_TOP") && atoi(getenv("MIW_ENV_TOP")) == 0) { table_bytes -= ((size_t) rcfg.env_top_words + 3) / 4 * 16; rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0; }
     if (tables_fit) rlds = (size_t) rcfg.tab16 * 16 + table_bytes;
 
     mi_counters &K = c->counters;

@@ -269,6 +269,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
     }
     SceneView &v = o.view;
     v.env = s->envmap ? &o.env.rec : nullptr;
+    v.env_top = nullptr; v.env_top_count = v.env_top_base = 0;
     v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
     {   // shape.h: the bounds rule of every triangle hit; same extent as the product (mesh vertices + rectangle corners)
         std::vector<Tri> ext;

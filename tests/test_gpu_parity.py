@@ -671,3 +671,37 @@ def test_device_builder_builds_the_host_builders_tree(native, which):
     assert np.array_equal(device[3], host[3])
     assert device[7] < (60.0 if which == "interior" else 30.0), "device build took %.1f ms" % device[7]
     dev.close()
+
+
+def test_scene_tables_that_do_not_fit_lds_take_the_lock_step_kernels(native, oracle):
+    """round 4: the phase machine and the packet kernels read the scene's small tables (shape / BSDF / emitter records) from LDS
+    (device/trace.h: stage_tables). A scene whose tables exceed what the stack leaves of a workgroup's 40 KB — here 330 meshes
+    with a BSDF each, 47 KB of records — must still render the oracle's film: through the lock-step tree kernel, which reads
+    the tables from global memory (counters().path_kernel 0 instead of 1)."""
+    from mitsuba2_amd import scenes
+    rng = np.random.default_rng(41)
+    meshes = [m for m in scenes.cornell_box_meshes(True, 1)]
+    for i in range(330):                                            # confetti: one small triangle and one diffuse BSDF each
+        c = np.array([rng.uniform(60, 490), rng.uniform(20, 520), rng.uniform(60, 490)])
+        v = (c + rng.normal(0, 12, (3, 3))).astype(np.float32)
+        meshes.append(native.Mesh("confetti%d" % i, v, np.array([[0, 1, 2]], np.uint32),
+                                  bsdf=native.BSDF("diffuse", reflectance=tuple(float(x) for x in rng.uniform(0.1, 0.9, 3)))))
+    scene = native.Scene(meshes).build(-1)
+    assert scene.desc().contents.bsdf_count >= 330
+    sensor = scenes.cornell_sensor(48, 40, 6)
+    job = native.PathIntegrator().render_job(sensor)
+    o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
+    d = native.Device(0)
+    d.upload(scene.desc())
+    g32, st = d.render(job)
+    c = d.counters()
+    assert st == 0 and c.plan == 2 and c.path_kernel == 0 and (c.samples, c.segments) == (ost.samples, ost.segments)
+    assert np.array_equal(g32, o32)
+    d.close()
+    # the same room without the confetti (forced onto the tree kernels): tables of a few hundred bytes -> the phase machine
+    scene2, _ = scenes.cornell_box(48, 40, 6, diffuse_only=False, device=-1, ball_level=2)
+    d = native.Device(0)
+    d.upload(scene2.desc())
+    g, st = d.render(job)
+    assert st == 0 and d.counters().path_kernel == 1
+    d.close()
