@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU session of round 4 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
-# This one: MIW_LDS_TABLES (the scene's small tables read from LDS by the packet kernels and the phase machine; in-tree library)
-# against the same sources built with -DMIW_LDS_TABLES=0 (build_exp/notab), then the whole GPU tier on the in-tree library.
+# This one: the environment warp's top levels in LDS (MIW_ENV_TOP=0 switches the staging off at run time) on C4, the packet kernels
+# with their triangle records in LDS (C2, C5, direct: against r4f's numbers), the shade vote re-swept on the cheaper shade body,
+# then the whole GPU tier.
 tag=${1:-s}; out=gpurun_out; mkdir -p $out
 B="--no-cpu-baseline --no-extras --no-live-counters"
 run() {  # run <label> <lib dir or -> <env...> -- <bench args...>
@@ -18,14 +19,16 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e, flush=True)
 P
 }
+C3="--scene matball --spp 256 --steps 2 --warmup 1"; C4="--scene interior --spp 64 --steps 2 --warmup 1"
 for rep in 1 2; do
-  for v in notab -; do
-    run c2_${v}_$rep $v -- --steps 3 --warmup 1
-    run c3_${v}_$rep $v -- --scene matball --spp 256 --steps 2 --warmup 1
-    run c4_${v}_$rep $v -- --scene interior --spp 64 --steps 2 --warmup 1
-  done
+  run c4_envtop_$rep - -- $C4
+  run c4_noenvtop_$rep - MIW_ENV_TOP=0 -- $C4
 done
-run c5_tree - -- --variant scalar_spectral --scene glassblock --steps 2 --warmup 1
-run direct_tree - -- --integrator direct --steps 2 --warmup 1
-run direct_notab notab -- --integrator direct --steps 2 --warmup 1
+run c2_1 - -- --steps 3 --warmup 1
+run c2_2 - -- --steps 3 --warmup 1
+run c5 - -- --variant scalar_spectral --scene glassblock --steps 2 --warmup 1
+run direct - -- --integrator direct --steps 2 --warmup 1
+run c3 - -- $C3
+for v in 1:1 3:4 1:2; do run c3_vote_$v - MIW_SHADE_VOTE=$v -- $C3; done
+for v in 2:3 1:3 2:5; do run c4_vote_$v - MIW_SHADE_VOTE=$v -- $C4; done
 (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $out/${tag}_pytest_gpu.txt; tail -4 $out/${tag}_pytest_gpu.txt
