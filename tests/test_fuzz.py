@@ -22,3 +22,15 @@ def test_random_scenes_staged_emulator_equals_scalar_restatement(native, oracle,
     for seed in range(first, first + 8):
         ok, recipe, segs = fuzz_cpu.run_case(native, scenes, oracle, seed)
         assert ok, (seed, segs, recipe)
+
+
+@pytest.mark.parametrize("first", [7000, 8000])
+def test_random_scenes_in_the_spectral_variant(spectral, oracle_spectral, first):
+    """the same recipes under scalar_spectral (round 4: every plugin, bitmaps and the environment map exist there too): the CPU run
+    of the resident sample loop == the spectral restatement, bit for bit"""
+    import fuzz_cpu
+    from mitsuba2_amd import scenes
+    for seed in range(first, first + 6):
+        ok, recipe, segs = fuzz_cpu.run_case(spectral, scenes, oracle_spectral, seed, resident_only=True)
+        assert ok, (seed, segs, recipe)
+

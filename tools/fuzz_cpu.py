@@ -160,13 +160,15 @@ def make_case(api, scenes, seed):
     return scene, sensor, ikw, recipe, (scene, shapes, env, film, sampler)
 
 
-def run_case(api, scenes, orc, seed):
+def run_case(api, scenes, orc, seed, resident_only=False):
+    """resident_only: the scalar_spectral libraries have no HBM-queue plan (path.h: RGB path state) — its recipes take the resident plan"""
     scene, sensor, ikw, recipe, keep = make_case(api, scenes, seed)
     ikw = dict(ikw)
     integ = (api.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else api.PathIntegrator)(**ikw)
     passes = integ.pass_count(sensor)
     gp = np.random.default_rng(seed + 99)
     plan2, per_launch = bool(gp.random() < 0.5), int(gp.integers(1, 9))
+    plan2 = plan2 or resident_only
     recipe.append("plan %s" % ("2, %d samples per launch" % per_launch if plan2 else "1"))
     o_acc, e_acc = (None, None), (None, None)                    # (f32, f64) of the oracle, (f64, f32) of the emulator
     segs = [0, 0]
