@@ -23,13 +23,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=20)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--variant", default="scalar_rgb", choices=["scalar_rgb", "scalar_spectral"],
+                    help="scalar_spectral: libmiwave_spectral.so against the spectral restatement (resident plan only: that build has no HBM-queue plan)")
     a = ap.parse_args()
     from mitsuba2_amd import api, scenes, build
     build.build_all(oracle=True)
+    spectral = a.variant == "scalar_spectral"
+    if spectral:
+        api.set_variant("scalar_spectral"); api.set_srgb_model(api.default_srgb_coeff())
     api.host_lib()
     import fuzz_cpu
     import oracle_py
-    orc = oracle_py.load()
+    orc = oracle_py.load(a.variant)
     bad = 0
     dev = api.Device(0)
     for seed in range(a.first, a.first + a.seeds):
@@ -43,7 +48,7 @@ def main():
         o32, _, ost = orc.render(scene.desc(), job, threads=os.cpu_count() or 8, want_f64=False)
         for quality in (0, 0x40):
             dev.upload(scene.desc(), bvh_quality=quality)
-            for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):     # the direct integrator runs on the resident plan
+            for plan in ((2,) if job.cfg.integrator == 1 or spectral else (2, 1)):     # the direct integrator runs on the resident plan
                 g, st = dev.render(job, plan=plan)
                 c = dev.counters()
                 ok = st == 0 and c.samples == ost.samples and c.segments == ost.segments and np.array_equal(g, o32)
@@ -52,7 +57,7 @@ def main():
                     print("seed %d MISMATCH (bvh quality %d, plan %d, status %d, segments %d vs %d)\n    %s" %
                           (seed, quality, plan, st, c.segments, ost.segments, "\n    ".join(recipe)))
     dev.close()
-    print("%d seeds, %d mismatches" % (a.seeds, bad))
+    print("%s: %d seeds, %d mismatches" % (a.variant, a.seeds, bad))
     sys.exit(1 if bad else 0)
 
 
