@@ -371,14 +371,16 @@ dist.finalize()
 '''
 
 
-def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path):
+@pytest.mark.parametrize("world", [2, 3])        # 3: the 6 spiral blocks of the 96 x 64 job split 2 / 2 / 2 round-robin, an odd rank count
+def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path, world):
     from mitsuba2_amd import scenes
     out = str(tmp_path / "film.npy")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % dict(root=ROOT, out=out))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    port = str(29533 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
+                        "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     scene, sensor = scenes.cornell_box(96, 64, 3, device=-1)
     full = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=4)[1]
