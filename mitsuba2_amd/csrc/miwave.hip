@@ -676,7 +676,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // otherwise the top of the tree only.
     size_t all = (size_t) node_count * sizeof(BvhNode) + (size_t) tri_count * sizeof(Tri);
     c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr; v.nodes4 = nullptr; c->nodes4_count = c->nodes4_stack = 0;
-    if (!force_tree && v.tri_count > 0 && v.tri_count <= MIW_BRUTE_MAX_TRIS && c->rects.empty()) {
+    if (tiny && v.tri_count > 0) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
         // the SAH leaves (padded boxes, <= 4 triangles each) become the resident plan's candidate filter
@@ -1024,13 +1024,16 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // before it declares a scene tiny).
     rcfg.tab16 = (uint32_t) ((rlds + 15) / 16);
     size_t table_bytes = lds_table_bytes(c, rcfg.tab_words, c->lds_cfg.brute != 0);
-    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= MIW_LDS_PER_WORKGROUP;
+    // (packet scenes always stage: mi_bvh_build bounded their tables by 24 KB, which with the packets, boxes and thresholds stays
+    // inside the 64 KB a workgroup may ask for — at fewer workgroups per CU past 40 KB)
+    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : MIW_LDS_PER_WORKGROUP);
     rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0;
     if (tables_fit && c->have_env) {
         // ... and as many of the environment warp's smallest levels as fit what is left (at most 4 KB): levels are stored from the
         // largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
         const EnvmapRec &e = c->env_host;
-        const size_t room = std::min<size_t>(4096, MIW_LDS_PER_WORKGROUP - ((size_t) rcfg.tab16 * 16 + table_bytes));
+        const size_t used = (size_t) rcfg.tab16 * 16 + table_bytes;
+        const size_t room = used < MIW_LDS_PER_WORKGROUP ? std::min<size_t>(4096, MIW_LDS_PER_WORKGROUP - used) : 0;
         uint32_t count = 0;
         while (count + 1 < e.n_levels && ((size_t) c->env_levels_total - e.level_offset[e.n_levels - 1 - count]) * 4 <= room) ++count;
         if (count) {
