@@ -1016,7 +1016,9 @@ void orc_microfacet(int op, uint32_t type, float au, float av, int sample_visibl
         default: { V3 m; float pdf; mf_sample(d, w, v2(m_or_u[0], m_or_u[1]), m, pdf); out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = pdf; }
     }
 }
-// Hierarchical2D<Float, 0> over caller data (w x h floats): op 0 = sample(xy) -> x, y, pdf ; op 1 = eval(xy) -> pdf
+// Hierarchical2D<Float, 0> over caller data (w x h floats): op 0 = sample(xy) -> x, y, pdf ; op 1 = eval(xy) -> pdf ;
+// op 100 + k = sample(xy) with the hierarchy's k smallest levels read through a SEPARATE copy (envmap.h: EnvTop — what the device
+// kernels do with their LDS copy of those levels): must be the sample of op 0, bit for bit, for every k
 int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *xy, float *out3) {
     FtzScope f;
     // reuse the envmap table builder on a grey bitmap whose luminance * sin(theta) equals `data` is not possible in
@@ -1031,6 +1033,19 @@ int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *x
     if (!t.ok) return -1;
     t.rec.data = t.data.data(); t.rec.levels = t.levels.data();
     if (op == 0) { float pdf; V2 r = hier2d_sample(t.rec, v2(xy[0], xy[1]), pdf); out3[0] = r.x; out3[1] = r.y; out3[2] = pdf; }
+    else if (op >= 100) {
+        const uint32_t k = (uint32_t) (op - 100);
+        if (k >= t.rec.n_levels) return -2;
+        EnvTop top = env_top_none();
+        std::vector<float> copy;
+        if (k) {
+            top.base = t.rec.level_offset[t.rec.n_levels - k]; top.count = k;
+            copy.assign(t.levels.begin() + top.base, t.levels.end());
+            top.p = copy.data();
+            for (size_t i = top.base; i < t.levels.size(); ++i) t.levels[i] = -1e30f;     // the originals of those levels must not be read
+        }
+        float pdf; V2 r = hier2d_sample(t.rec, v2(xy[0], xy[1]), pdf, top); out3[0] = r.x; out3[1] = r.y; out3[2] = pdf;
+    }
     else out3[0] = hier2d_eval(t.rec, v2(xy[0], xy[1]));
     return 0;
 }

@@ -659,3 +659,32 @@ def test_perspective_fov_axis(native, direction, fov):
     for axis in ("y", "smaller"):
         check(axis, [(0.5, 0.0), (0.5, 1.0)])
     check("diagonal", [(0.0, 0.0), (0.0, 1.0), (1.0, 0.0), (1.0, 1.0)])
+
+
+def test_hier2d_sample_through_a_copy_of_its_top_levels(oracle):
+    """envmap.h EnvTop (round 4): the device kernels read the warp's smallest levels from a copy in LDS. The two-loop form of
+    hier2d_sample must give the sample of the one-array form for every number of copied levels, bit for bit (the checker poisons
+    the originals of the copied levels, so a read from the wrong array cannot go unnoticed)."""
+    rng = np.random.default_rng(8)
+    for (h, w) in ((16, 32), (33, 20), (7, 50)):
+        d = (rng.random((h, w)) ** 3 + 0.01).astype(np.float32)
+        pts = rng.random((40, 2)).astype(np.float32)
+        ref = []
+        for xy in pts:
+            out = np.zeros(3, np.float32)
+            assert oracle.L.orc_hier2d(fp(d), w, h, 0, fp(np.ascontiguousarray(xy)), fp(out)) == 0
+            ref.append(out.copy())
+        k = 1
+        while True:
+            out = np.zeros(3, np.float32)
+            rc = oracle.L.orc_hier2d(fp(d), w, h, 100 + k, fp(np.ascontiguousarray(pts[0])), fp(out))
+            if rc == -2:
+                break
+            assert rc == 0
+            for xy, want in zip(pts, ref):
+                out = np.zeros(3, np.float32)
+                assert oracle.L.orc_hier2d(fp(d), w, h, 100 + k, fp(np.ascontiguousarray(xy)), fp(out)) == 0
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (h, w, k, xy)
+            k += 1
+        assert k >= 4
+
