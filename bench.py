@@ -201,9 +201,10 @@ def run_extras(api, scenes, film, C):
             out[tag] = {"workload": note, "spp": spp, "value": 1920.0 * 1080 * spp / (ms[-1] * 1e-3) / 1e6, "unit": "Msamples/sec",
                         "ms_per_frame": ms[-1], "ms_first_frame": ms[0], "ms_path_kernel": c.ms_path, "ms_film": c.ms_resolve,
                         "samples": int(c.samples), "segments_per_sample": c.segments / max(c.samples, 1),
-                        "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident",
+                        "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident", "tree_width": int(c.tree_width),
                         "log_bytes": int(c.log_bytes),
-                        "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris}}
+                        "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris,
+                                "nodes2": bvh.bvh_nodes, "nodes8": bvh.bvh8_nodes, "depth8": bvh.bvh8_depth, "ms_bvh4": round(bvh.ms_bvh4, 2), "ms_bvh8": round(bvh.ms_bvh8, 2)}}
         finally:
             device.close()
 
@@ -241,6 +242,13 @@ def spawn_ranks(n, argv):
     return subprocess.call(spawn_command(n, argv), env=env)
 
 
+def film_kernel_name(log_record_bytes):
+    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_COLUMNS switch)"""
+    if log_record_bytes != 16:
+        return "k_film_blocks"
+    return "k_film_groups" if os.environ.get("MIW_FILM_COLUMNS") == "0" else "k_film_columns"
+
+
 def reduce_label(backend):
     return {"nccl": "RCCL", "gloo": "gloo (host)"}.get(backend, backend)
 
@@ -264,8 +272,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--dry-ranks", action="store_true", help="testing only (CPU tier): every rank joins the process group, takes part in one "
                     "all-reduce and rank 0 prints {n_gpus, ranks_seen}; nothing is rendered")
-    ap.add_argument("--shard-of", type=int, default=0, help="testing only (N = 1): render shard 0 of this many — what one rank "
-                    "of an N-GPU run executes; `value` then counts only that shard's samples")
+    ap.add_argument("--shard-of", type=int, default=0, help="testing only (N = 1): render one shard of this many — what one rank "
+                    "of an N-GPU run executes (--shard-index says which, default 0); `value` then counts only that shard's samples")
+    ap.add_argument("--shard-index", type=int, default=0, help="with --shard-of N: the rank whose shard is rendered (0 .. N - 1); "
+                    "tools/shard_table.py renders all of them and reports the slowest, which is what an N-GPU frame lasts")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--film-mode", type=int, default=0, help="0 auto, 1 sample log + ordered gather, 2 float64 atomics")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "matball", "interior", "glassblock"],
@@ -353,7 +363,9 @@ def main():
         integ = make_integrator()
         integ.set_shard(rank, world)
         if args.shard_of > 1 and world == 1:
-            integ.set_shard(0, args.shard_of)
+            if not 0 <= args.shard_index < args.shard_of:
+                raise SystemExit("bench.py: --shard-index must lie in 0 .. --shard-of - 1")
+            integ.set_shard(args.shard_index, args.shard_of)
         job = integ.render_job(sensor)
     cfg = job.cfg
     cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = args.film_mode; cfg.profile = 0 if args.no_profile else 1
@@ -413,9 +425,10 @@ def main():
             ta_name: (agg["ms_ta"], agg["n_ta"], 8.0 * agg["segments"] if pk == 2 else B_TRACE_ANY * agg["shadow"]),
             # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
             path_kernel: (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
-            # ordered film replay: reads the sample log once per texel group, writes the block tiles (k_film_groups over the 16-byte
-            # class records, k_film_blocks over the 24-byte position log of filters without phase classes)
-            ("k_film_groups" if hc.log_record_bytes == 16 else "k_film_blocks"): (agg["ms_fb"], agg["n_film"], float(hc.log_record_bytes) * agg["samples"]),
+            # ordered film replay: reads the sample log once per texel group, writes the block tiles (k_film_columns<4,2> over the
+            # 16-byte class records — k_film_groups, its round-3 predecessor, only with MIW_FILM_COLUMNS=0 —, k_film_blocks over the
+            # 24-byte position log of filters without phase classes)
+            film_kernel_name(hc.log_record_bytes): (agg["ms_fb"], agg["n_film"], float(hc.log_record_bytes) * agg["samples"]),
         }
         roofline = None
         if not args.no_profile and (agg["n_shade"] or agg["n_path"]):
@@ -490,6 +503,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "variant": args.variant, "integrator": args.integrator, "shard": shard if world > 1 or args.shard_of > 1 else None,
+            "shard_index": args.shard_index if args.shard_of > 1 and world == 1 else None,
             "config": {"workload": ("Cornell box (32 triangles), %dx%d @ %d spp, diffuse-only BSDFs, path integrator "
                                     "max_depth=-1 rr_depth=5, gaussian rfilter, independent sampler seed 0" if args.scene == "cornell" else
                                     "Cornell box with a bk7 dielectric block (34 triangles), %dx%d @ %d spp, path integrator max_depth=-1 "
@@ -505,7 +519,7 @@ def main():
                        "parallelism": ("%s-shard x%d + %s film reduce" % ("tile" if shard == "tiles" else "pass (samples_per_pass = spp / %d)" % world, world, reduce_label(args.backend))) if world > 1 else "single GPU",
                        "plan": {1: "wavefront: SoA queues in HBM, one kernel per stage" + (" (persistent stream walk kernel with dynamic ray fetch)" if pk == 2 else ""), 2: "resident: path state in registers, geometry in LDS"
                                 if path_kernel == "k_path_resident" else "resident, wave-level phase machine: path + walk state in registers, "
-                                "per-lane LDS stack, nodes / triangles through L1 / L2"}[hc.plan],
+                                "per-lane LDS stack, nodes / triangles through L1 / L2" + (" (%d-wide quantised tree)" % hc.tree_width if hc.tree_width else "")}[hc.plan],
                        "film": {1: "sample log (%d B per sample) + ordered float32 gather (bit-identical to scalar_rgb order)" % hc.log_record_bytes, 2: "float64 atomics"}[hc.film_mode]},
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }

@@ -290,6 +290,18 @@ typedef struct {
     uint32_t bvh_builder;      /* the last mi_bvh_build: 0 = host binned SAH (quality 1, or a scene the device sweep hands back), 3 = the same
                                   tree built on the device level by level (csrc/sah_device.h: quality 0 since round 4), 1 = device LBVH
                                   (radix tree over Morton codes: MIW_DEVICE_BUILDER=lbvh, A/B runs)                                      */
+    /* ---- round 5 (appended: the fields above keep their offsets) ---- */
+    uint32_t tree_width;       /* last render through k_path_phased: 8, 4 or 2 = the tree its node body walked (8: csrc/miw/bvh8.h,
+                                  the default wherever mi_bvh_build produced it); 0: another kernel                                       */
+    uint32_t bvh8_nodes;       /* the last mi_bvh_build: nodes of the 8-wide tree; 0: none (packet scene, radix tree, refused, MIW_BVH8=0) */
+    uint32_t bvh8_depth;       /* its levels = the walk's worst-case stack entries + 1 (<= 16)                                           */
+    uint32_t bvh8_on_device;   /* 1: programme + collapse + triangle gather ran on the device (quality 0)                                */
+    double ms_bvh8;            /* part of ms_bvh_build spent on it                                                                       */
+    /* placed launches (`placed` above): what the measuring launch found — the cost of the dearest pixel and the mean over the
+     * shard's pixels, in wavefront iterations (place_cost_unit 0: packet kernel) or units of 256 shader clocks (1: phase machine),
+     * over place_measure_spp samples per pixel; place_max_pixel = x | y << 16 of that pixel. 0 when the last render was not placed. */
+    uint32_t place_cost_max, place_cost_unit, place_max_pixel, place_measure_spp;
+    double place_cost_mean;
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -123,7 +123,10 @@ class mi_counters(C.Structure):
                 ("ms_film_blocks", C.c_double), ("ms_film_merge", C.c_double),
                 ("bvh_on_device", C.c_uint32), ("path_kernel", C.c_uint32), ("ms_film_pack", C.c_double),
                 ("log_bytes", C.c_uint64), ("log_record_bytes", C.c_uint32), ("bvh4_on_device", C.c_uint32), ("ms_bvh4", C.c_double),
-                ("placed", C.c_uint32), ("bvh_builder", C.c_uint32)]
+                ("placed", C.c_uint32), ("bvh_builder", C.c_uint32),
+                ("tree_width", C.c_uint32), ("bvh8_nodes", C.c_uint32), ("bvh8_depth", C.c_uint32), ("bvh8_on_device", C.c_uint32), ("ms_bvh8", C.c_double),
+                ("place_cost_max", C.c_uint32), ("place_cost_unit", C.c_uint32), ("place_max_pixel", C.c_uint32), ("place_measure_spp", C.c_uint32),
+                ("place_cost_mean", C.c_double)]
 
 
 MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1

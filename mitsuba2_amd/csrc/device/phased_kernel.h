@@ -32,6 +32,8 @@ enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 // a lane's stack: its column of the workgroup's entry-major LDS array (slot i of lane l at i * MIW_BLOCK + l: conflict-free)
 struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
+// the 8-wide walk's column: MIW_BVH8_STACK node groups of 8 bytes (ds_write_b64 / ds_read_b64; the same 128 bytes per lane)
+struct LdsColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
 
 #ifndef MIW_PIN_TREE_PTRS
 #define MIW_PIN_TREE_PTRS 1           /* 1: node / triangle table pointers of the walk bodies kept in registers (below); C3 +1.5 %, gpurun r4e */
@@ -47,12 +49,13 @@ struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](in
 #endif
 // Waves = waves per SIMD the kernel is compiled for: 3 (168 VGPRs) or 4 (128 VGPRs; the default for every tree since the kernel
 // spills 20 registers at 128 instead of 121: DESIGN.md section 4, "the register diet").
-// Wide = the node body steps through the 4-wide quantised tree of miw/bvh4.h (the default) instead of the BVH2 (MIW_BVH4=0:
-// instantiated for the MATS_TRIO kernels only, A/B runs).
+// Wide = which tree the node body steps through: 2 = the 8-wide quantised tree of miw/bvh8.h (80-byte nodes, node / triangle GROUPS
+// as walk state, triangles in the tree's own order: the default since round 5), 1 = the 4-wide quantised tree of miw/bvh4.h (trees the
+// 8-wide collapse refuses, the radix tree, MIW_BVH8=0: A/B runs), 0 = the BVH2 (MIW_BVH4=0: instantiated for the MATS_TRIO kernels only).
 // Placed: the pixel queue is QueueWork<true> (resident_kernel.h) — shards of about one pixel per resident lane: a measuring launch,
 // then every wavefront takes pixels of about equal cost from the queue of its SIMD. The full-frame kernel keeps Placed = false
 // and the four registers the queue choice costs.
-template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, bool Wide = true, bool Placed = false>
+template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, int Wide = 1, bool Placed = false>
 __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
@@ -62,6 +65,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     stage_tables<false>(sc, cfg, smem);
 #endif
     int32_t *stack = reinterpret_cast<int32_t *>(smem + cfg.stack16) + threadIdx.x;
+    U2 *stack8 = reinterpret_cast<U2 *>(smem + cfg.stack16) + threadIdx.x;
+    (void) stack8;
     const BvhNode *gnodes = sc.nodes;
     const Bvh4Node *nodes4 = sc.nodes4;
     const Tri *gtris = sc.tris;
@@ -75,12 +80,18 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     typedef uint32_t miw_u4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) miw_u4 *GlobalU4;
     GlobalU4 nodes4_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes4), tris_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.tris);
-    asm volatile("" : "+s"(nodes4_g));
+    GlobalU4 nodes8_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes8);
+    if (Wide == 2) asm volatile("" : "+s"(nodes8_g)); else asm volatile("" : "+s"(nodes4_g));
     asm volatile("" : "+s"(tris_g));
     auto node4_at = [nodes4_g](int32_t i) -> Bvh4Node {
         GlobalU4 p = nodes4_g + 4 * (size_t) (uint32_t) i;
         miw_u4 q[4] = { p[0], p[1], p[2], p[3] };
         Bvh4Node n; __builtin_memcpy(&n, q, sizeof n); return n;
+    };
+    auto node8_at = [nodes8_g](uint32_t i) -> Bvh8Node {           // five 16-byte requests
+        GlobalU4 p = nodes8_g + 5 * (size_t) i;
+        miw_u4 q[5] = { p[0], p[1], p[2], p[3], p[4] };
+        Bvh8Node n; __builtin_memcpy(&n, q, sizeof n); return n;
     };
     auto tri_at_g = [tris_g](uint32_t i) -> Tri {
         GlobalU4 p = tris_g + 3 * (size_t) i;
@@ -89,6 +100,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     };
 #else
     auto node4_at = [nodes4](int32_t i) -> const Bvh4Node & { return nodes4[i]; };
+    const Bvh8Node *nodes8 = sc.nodes8;
+    auto node8_at = [nodes8](uint32_t i) -> const Bvh8Node & { return nodes8[i]; };
     auto tri_at_g = [gtris](uint32_t i) -> const Tri & { return gtris[i]; };
 #endif
 #if MIW_LDS_TOP
@@ -115,6 +128,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     // the walk a lane is in: current node (>= 0), pending leaf code (< 0) or DONE; stack depth; untested leaf range; best hit
     int32_t cur = MIW_WALK_DONE, sp = 0;
     uint32_t tri_i = 0, tri_end = 0;
+    // Wide == 2: the walk is two groups (miw/bvh8.h): node group (gb, gm: pending slots | imask | octant | stack depth), triangle group (tb, tm)
+    Walk8 w8; w8.gb = 0u; w8.gm = 0u; w8.tb = 0u; w8.tm = 0u;
     // (direction, maxt and mint of the walk in progress are the path state's own — L.ray for an E walk, sh.d / sh.maxt for an S
     // walk, selected by `mode` where the triangle body needs them — not copies that would be live through the shade body)
     float tmax = 0.f;
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     auto begin_walk = [&](V3 d, float maxt) {
         r = fast_ray(L.ray.o, d, L.ray.mint);
         tmax = maxt;
-        cur = 0; sp = 0; tri_i = tri_end = 0;
+        if (Wide == 2) walk8_begin(w8, r); else { cur = 0; sp = 0; tri_i = tri_end = 0; }
         best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     };
 
@@ -143,12 +158,12 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     for (;;) {
         // ---- the vote: which lanes are ready for which body ----
         const bool trav = (mode - 1u) < 2u;
-        bool has_range = tri_i < tri_end;
+        bool has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
         bool e_leaf = trav && has_range;
-        bool e_node = trav && cur >= 0 && (Spec || !has_range);
+        bool e_node = trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range));
         // a walk that is over: an E walk with a shadow ray queued turns into the S walk at the next entry to the node body
         // (`e_turn`; the hit record stays in `best`, which an S walk never writes), every other one is ready to shade
-        const bool walk_over = trav && !has_range && cur == MIW_WALK_DONE;
+        const bool walk_over = trav && (Wide == 2 ? walk8_over(w8) : !has_range && cur == MIW_WALK_DONE);
         const bool e_turn = walk_over && mode == PH_TRAV_E && sh.has;
         const bool e_shade = mode == PH_SHADE || (walk_over && !e_turn);
         const int n_turn = count(e_turn);
@@ -210,7 +225,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     mode = PH_TRAV_S;
                     r = fast_ray(L.ray.o, sh.d, L.ray.mint);
                     tmax = sh.maxt;
-                    cur = 0; sp = 0; tri_i = tri_end = 0;
+                    if (Wide == 2) walk8_begin(w8, r); else { cur = 0; sp = 0; tri_i = tri_end = 0; }
                     e_node = true;
                 }
                 MIW_PS(2, n_turn);
@@ -218,7 +233,12 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             do {
                 MIW_PS(0, count(e_node));
                 if (e_node) {
-                    if (Wide) {
+                    if (Wide == 2) {
+                        // one 80-byte node = eight quantised child boxes: the node step of miw/bvh8.h (the CPU checker runs the same statements)
+                        FastRay rn; rn.inv_d = r.inv_d; rn.neg_o_inv_d = r.neg_o_inv_d; rn.mint = L.ray.mint;
+                        const auto &nd = node8_at(walk8_next_node(w8));
+                        walk8_node_step(nd, rn, widen(tmax), w8, LdsColumn8{ stack8 });
+                    } else if (Wide) {
                         // one 64-byte node = four quantised child boxes: the node step of miw/bvh4.h (the CPU checker runs the same statements)
                         const LdsColumn column{ stack };
                         FastRay rn; rn.inv_d = r.inv_d; rn.neg_o_inv_d = r.neg_o_inv_d; rn.mint = L.ray.mint;   // (r.mint would be one more register carried through the shade body)
@@ -254,8 +274,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         cur = next;
                     }
                 }
-                has_range = tri_i < tri_end;
-                e_node = trav && cur >= 0 && (Spec || !has_range);
+                has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
+                e_node = trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range));
                 const int now = count(e_node);
                 n_leaf = count(trav && has_range);
                 n_gone = n_node - now;                                   // lanes of this burst now at a leaf / at their walk's end
@@ -271,10 +291,16 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     const V3 d_cur = s_walk ? sh.d : L.ray.d;
                     const float maxt_cur = s_walk ? sh.maxt : L.ray.maxt;
 #if MIW_TRI_PAIR
+                    if (Wide == 2) {
+                        // the two lowest pending triangles of the lane's triangle group (miw/bvh8.h); a drained group hands over to the next node group
+                        // (the node step leaves a non-empty node group behind whenever the stack holds one: nothing to pop here)
+                        walk8_tri_step<Analytic>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, mode == PH_TRAV_S, best, tmax, occluded, w8);
+                    } else
                     // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
                     walk4_tri_step<Analytic>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
                                              mode == PH_TRAV_S, best, tmax, occluded, cur, sp, tri_i, tri_end, LdsColumn{ stack });
 #else
+                    static_assert(Wide != 2, "the 8-wide walk has the pair step only");
                     const Tri &tr = gtris[tri_i];
                     float t, u, v;
                     if (prim_intersect<Analytic>(tr, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, t, u, v)) {
@@ -294,10 +320,10 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     }
 #endif
                 }
-                has_range = tri_i < tri_end;
+                has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
                 e_leaf = trav && has_range;
                 const int now = count(e_leaf);
-                n_node = count(trav && cur >= 0 && (Spec || !has_range));
+                n_node = count(trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range)));
                 if (now <= n_node || now < others || now == 0) break;
             } while (true);
         }

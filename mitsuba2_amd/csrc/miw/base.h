@@ -97,6 +97,7 @@ struct V3 { float x, y, z; };
 struct alignas(16) F4 { float x, y, z, w; };
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 struct alignas(8)  F2 { float x, y; };
+struct alignas(8)  U2 { uint32_t x, y; };
 
 MIW_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 MIW_HD V3 v3(float s) { return v3(s, s, s); }

@@ -171,7 +171,7 @@ MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
 // against brute force. Same observable result as bvh_intersect / brute_intersect.
 template <bool AnyHit, typename TriAt>
 MIW_HD bool bvh4_intersect(const Bvh4Node *nodes, TriAt tri_at, V3 o, V3 d, float mint, float maxt, Hit &best, PrimCtx ctx,
-                           uint32_t *max_stack_seen = nullptr) {
+                           uint32_t *max_stack_seen = nullptr, uint64_t *steps = nullptr) {
     best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
     const SlabRay r = slab_ray_host(o, d, mint);
     float tmax = maxt;
@@ -184,11 +184,13 @@ MIW_HD bool bvh4_intersect(const Bvh4Node *nodes, TriAt tri_at, V3 o, V3 d, floa
             int32_t ch[4] = { n.child[0], n.child[1], n.child[2], n.child[3] };
             bvh4_test(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), k);
             bvh4_sort(k, ch);
+            if (steps) steps[0]++;
             for (int i = 3; i >= 1; --i) if (bvh4_key_hit(k[i])) stack[sp++] = ch[i];                    // far ... near
             if (max_stack_seen && (uint32_t) sp > *max_stack_seen) *max_stack_seen = (uint32_t) sp;
             if (bvh4_key_hit(k[0])) { cur = ch[0]; continue; }
         } else {
             const uint32_t code = (uint32_t) ~cur, first = code >> 4, count = (code & 15u) + 1u;
+            if (steps) steps[1] += count;
             for (uint32_t i = 0; i < count; ++i) {
                 const Tri &tr = tri_at(first + i);
                 float t, u, v;

@@ -66,6 +66,7 @@ struct SceneView {
     const void *tri_bounds;                         // device only: TriBounds per packet of a tiny scene (miwave.hip)
     const void *leaf_boxes;                         // device only: padded SAH leaf boxes of a tiny scene (miwave.hip)
     const struct Bvh4Node *nodes4;                  // device only: the 4-wide quantised tree the phase machine walks (bvh4.h) or nullptr
+    const struct Bvh8Node *nodes8;                  // device only: the 8-wide quantised tree (bvh8.h) of a view whose tris / tri_vn are in that tree's order, or nullptr
     const float *env_top; uint32_t env_top_count, env_top_base;   // device only: the environment warp's top levels in LDS (envmap.h: EnvTop); count 0: none
 };
 MIW_HD EnvTop env_top(const SceneView &sc) { EnvTop t; t.p = sc.env_top; t.count = sc.env_top_count; t.base = sc.env_top_base; return t; }

@@ -63,6 +63,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "lbvh_device.h"
 #include "sah_device.h"
 #include "bvh4_device.h"
+#include "bvh8_device.h"
 
 using namespace miw;
 
@@ -138,6 +139,7 @@ struct mi_ctx {
     DevBuf<ShapeRec> d_shapes; DevBuf<BsdfRec> d_bsdfs; DevBuf<EmitterRec> d_emitters; DevBuf<AnalyticRec> d_rects;
     DevBuf<float> d_emit_tri, d_emit_vnorm, d_emit_pmf, d_emit_cdf;
     DevBuf<LeafBox> d_leaf_boxes; DevBuf<TriBounds> d_tri_bounds; DevBuf<Bvh4Node> d_nodes4; uint32_t nodes4_count = 0, nodes4_stack = 0;
+    DevBuf<Bvh8Node> d_nodes8; DevBuf<Tri> d_tris8; DevBuf<float> d_tri_vn8; uint32_t nodes8_count = 0, nodes8_depth = 0;   // the 8-wide tree (miw/bvh8.h) and the triangles / vertex normals in its order
     DevBuf<float> d_env_data, d_env_levels; DevBuf<EnvmapRec> d_env; EnvmapRec env_host{}; size_t env_levels_total = 0;   // (host copy of the record: level offsets for the LDS staging)
     bool have_env = false;
     SceneView view{};
@@ -207,7 +209,7 @@ void mi_destroy(mi_ctx *c) {
     (void) hipSetDevice(c->device);
     (void) hipDeviceSynchronize();
     c->d_nodes.release(); c->d_tris.release(); c->d_tri_vn.release(); c->d_tri_uv.release(); c->d_bitmap_data.release(); c->d_bitmaps.release(); c->d_bsdf_tables.release(); c->d_shapes.release(); c->d_rects.release(); c->d_bsdfs.release();
-    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_nodes4.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
+    c->d_emitters.release(); c->d_leaf_boxes.release(); c->d_tri_bounds.release(); c->d_nodes4.release(); c->d_nodes8.release(); c->d_tris8.release(); c->d_tri_vn8.release(); c->d_env_data.release(); c->d_env_levels.release(); c->d_env.release(); c->d_emit_tri.release(); c->d_emit_vnorm.release(); c->d_emit_pmf.release(); c->d_emit_cdf.release();
     c->q_tp.release(); c->q_res.release(); c->q_ray_o.release(); c->q_ray_d.release(); c->q_hit.release();
     c->q_sh_d.release(); c->q_sh_c.release(); c->q_st.release(); c->q_pos.release(); c->q_pixel.release(); c->q_sh_vis.release();
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lane_cost.release(); c->d_cost_sorted.release(); c->d_lane_iota.release(); c->d_lane_sorted.release(); c->d_place_tmp.release(); c->d_piece_list.release(); c->d_simd_ids.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
@@ -473,6 +475,10 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // quality 0: the 4-wide tree is collapsed on the device as well (bvh4_device.h); these say whether that happened
     bool wide_on_device = false; uint32_t dev4_nodes = 0, dev4_stack = 0;
     const bool wide_on = !(getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) == 0);
+    // the 8-wide tree (the phase machine's default since round 5): off with MIW_BVH8=0, and whenever the 4-wide walk is asked for by name
+    const bool wide8_on = wide_on && !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0) && !getenv("MIW_BVH4_FAN");
+    uint32_t dev8_nodes = 0, dev8_depth = 0; double ms_bvh8 = 0.0;
+    std::vector<uint32_t> sah_level_start;                    // the device SAH builder's level table (first node of every level)
     int max_fan = 4;
     if (const char *e = getenv("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
     double ms_bvh4 = 0.0;
@@ -563,6 +569,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 HIP_TRY(c, hipStreamSynchronize(s));
                 node_count = base;
                 built_on_device = true;
+                sah_level_start = level_start;
                 c->counters.bvh_builder = 3u;
                 if (getenv("MIW_DEBUG")) {
                     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -629,6 +636,37 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             wide_on_device = !h.failed && h.count[levels] == 0 && dev4_stack <= budget4 && dev4_nodes <= (uint32_t) n;
             ms_bvh4 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t4).count();
         }
+        // ---- the 8-wide tree (miw/bvh8.h) from the same BVH2, on the device as well (bvh8_device.h): the programme bottom-up over the
+        // builder's levels, the collapse top-down, triangles + vertex normals gathered into the tree's order. SAH sweep only (the
+        // radix tree has no level table: it keeps the 4-wide tree). MIW_BVH8=0 / MIW_BVH4=0 / MIW_BVH4_FAN switch it off (A/B runs). ----
+        if (built_on_device && dev_builder == DEV_SAH && wide8_on && !getenv("MIW_NO_STACK")) {
+            auto t8 = std::chrono::steady_clock::now();
+            TmpBuf<Bvh8Dp> d_dp; TmpBuf<int32_t> ga, gb; TmpBuf<Bvh8Levels> lv8; TmpBuf<uint32_t> d_perm;
+            HIP_TRY(c, d_dp.resize(node_count)); HIP_TRY(c, ga.resize(n)); HIP_TRY(c, gb.resize(n)); HIP_TRY(c, lv8.resize(1)); HIP_TRY(c, d_perm.resize(n));
+            HIP_TRY(c, c->d_nodes8.resize(n)); HIP_TRY(c, c->d_tris8.resize(n));
+            if (!c->tri_vn_in.empty()) HIP_TRY(c, c->d_tri_vn8.resize((size_t) n * 9));
+            for (size_t L = sah_level_start.size() - 1; L-- > 0;) {
+                const uint32_t cnt = sah_level_start[L + 1] - sah_level_start[L];
+                if (cnt) hipLaunchKernelGGL(k_bvh8_dp, dim3((cnt + 255u) / 256u), blk, 0, s, c->d_nodes.p, d_dp.p, sah_level_start[L], sah_level_start[L + 1]);
+            }
+            Bvh8Levels h8; memset(&h8, 0, sizeof h8); h8.count[0] = 1;
+            const int32_t root8 = 0;
+            HIP_TRY(c, hipMemcpyAsync(lv8.p, &h8, sizeof h8, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(ga.p, &root8, sizeof root8, hipMemcpyHostToDevice, s));
+            const uint32_t levels8 = std::min<uint32_t>(depth + 1u, 62u);
+            for (uint32_t L = 0; L < levels8; ++L)
+                hipLaunchKernelGGL(k_bvh8_level, grd, blk, 0, s, c->d_nodes.p, d_dp.p, (L & 1u) ? gb.p : ga.p, (L & 1u) ? ga.p : gb.p, lv8.p,
+                                   c->d_nodes8.p, d_perm.p, L, (uint32_t) n, (uint32_t) n);
+            hipLaunchKernelGGL(k_bvh8_gather, grd, blk, 0, s, c->d_tris.p, c->tri_vn_in.empty() ? (const float *) nullptr : c->d_tri_vn.p, d_perm.p, (uint32_t) n,
+                               c->d_tris8.p, c->tri_vn_in.empty() ? (float *) nullptr : c->d_tri_vn8.p);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&h8, lv8.p, sizeof h8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            uint32_t nn = 0, dd = 0;
+            for (uint32_t L = 0; L < levels8; ++L) { nn += h8.count[L]; dd += h8.count[L] ? 1u : 0u; }
+            if (!h8.failed && h8.count[levels8] == 0 && h8.tri_next == (uint32_t) n && dd <= MIW_BVH8_STACK && nn <= (uint32_t) n) { dev8_nodes = nn; dev8_depth = dd; }
+            ms_bvh8 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t8).count();
+        }
         free_tmp();
     }
     std::vector<float> vn;
@@ -676,6 +714,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     // otherwise the top of the tree only.
     size_t all = (size_t) node_count * sizeof(BvhNode) + (size_t) tri_count * sizeof(Tri);
     c->lds_cfg.brute = 0; c->lds_cfg.leaves = 0; c->lds_cfg.stack = 0; c->lds_cfg.stack16 = 0; v.leaf_boxes = nullptr; v.nodes4 = nullptr; c->nodes4_count = c->nodes4_stack = 0;
+    v.nodes8 = nullptr; c->nodes8_count = c->nodes8_depth = 0; bool wide8_on_device = false;
     if (tiny && v.tri_count > 0) {
         // tiny scene (Cornell class): a branch-free sweep over LDS triangle packets beats any tree walk
         c->lds_cfg.brute = 1; c->lds_cfg.nodes_staged = 0; c->lds_cfg.tris_staged = v.tri_count;
@@ -738,11 +777,32 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             ms_bvh4 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t4).count();
             if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4: %zu nodes (bvh2 %u), depth %u, stack bound %u, ok %d\n", b4.nodes.size(), node_count, b4.depth, b4.stack_bound, (int) b4.ok);
         }
+        // The 8-wide tree (miw/bvh8.h; walked instead of the 4-wide one whenever it exists — mi_render, MIW_BVH8=0 at render time keeps
+        // the 4-wide walk): collapsed on the device above, or here on the host from the host-built BVH2 (quality 1). c->view keeps
+        // the BVH2's triangle order; mi_render hands the phase machine a view whose tris / tri_vn are d_tris8 / d_tri_vn8.
+        if (c->lds_cfg.stack && v.nodes4 && dev8_nodes) {
+            c->nodes8_count = dev8_nodes; c->nodes8_depth = dev8_depth; wide8_on_device = true;
+            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8 (device): %u nodes (bvh2 %u, bvh4 %u), depth %u, %.2f ms\n", dev8_nodes, node_count, c->nodes4_count, dev8_depth, ms_bvh8);
+        } else if (c->lds_cfg.stack && v.nodes4 && wide8_on && !built_on_device) {
+            auto t8 = std::chrono::steady_clock::now();
+            const Bvh8BuildResult b8 = bvh8_collapse(r.nodes, tri_count);
+            if (b8.ok) {
+                std::vector<Tri> t8v(b8.perm.size()); std::vector<float> vn8;
+                for (size_t i = 0; i < t8v.size(); ++i) t8v[i] = r.tris[b8.perm[i]];
+                if (!vn.empty()) { vn8.resize(vn.size()); for (size_t i = 0; i < t8v.size(); ++i) memcpy(&vn8[i * 9], &vn[(size_t) b8.perm[i] * 9], 36); }
+                HIP_TRY(c, c->d_nodes8.upload(b8.nodes, c->stream)); HIP_TRY(c, c->d_tris8.upload(t8v, c->stream)); HIP_TRY(c, c->d_tri_vn8.upload(vn8, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->nodes8_count = (uint32_t) b8.nodes.size(); c->nodes8_depth = b8.depth;
+            }
+            ms_bvh8 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t8).count();
+            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8: %zu nodes (bvh2 %u), depth %u, ok %d, %.2f ms\n", b8.nodes.size(), node_count, b8.depth, (int) b8.ok, ms_bvh8);
+        }
     }
 
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = depth;
     c->counters.bvh4_on_device = (v.nodes4 && wide_on_device) ? 1u : 0u; c->counters.ms_bvh4 = ms_bvh4;
+    c->counters.bvh8_nodes = c->nodes8_count; c->counters.bvh8_depth = c->nodes8_depth; c->counters.bvh8_on_device = wide8_on_device ? 1u : 0u; c->counters.ms_bvh8 = ms_bvh8;
     c->have_bvh = true;
     return MI_OK;
 }
@@ -1048,7 +1108,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
 
     // event pool for per-launch timing
     struct Stamp { int cls; size_t e0, e1; };
@@ -1131,6 +1191,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         int ph_waves = 4;
         if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
         const bool phased_placeable = phased && c->view.nodes4 != nullptr && ph_waves == 4;     // (the Placed instantiations: the 4-wide tree at four waves per SIMD)
+        // the 8-wide tree whenever mi_bvh_build produced one (four waves per SIMD only; MIW_BVH8=0 here keeps the 4-wide walk: A/B runs in one process)
+        const bool phased8 = phased_placeable && c->nodes8_count != 0u && !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0);
+        SceneView view8 = c->view;
+        if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
         const uint32_t res_waves = phased ? (uint32_t) ph_waves : (c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u);
         bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
@@ -1185,12 +1249,23 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // 40.0 -> 36.7 -> 44.3. Consecutive pieces keep the dear pixels in few wavefronts, which the priorities then favour; the
                     // interior — every pixel dear, its walks bound by memory latency, tree and triangles beyond the L2s — gains from every
                     // wavefront carrying the same mix. Rule: spread when the tree does not fit the aggregate L2 (32 MB). MIW_PLACE_SPREAD = 0 | 1 overrides.
-                    bool spread = phased && ((size_t) c->nodes4_count * sizeof(Bvh4Node) + (size_t) c->view.tri_count * sizeof(Tri)) > ((size_t) 32 << 20);
+                    bool spread = phased && ((phased8 ? (size_t) c->nodes8_count * sizeof(Bvh8Node) : (size_t) c->nodes4_count * sizeof(Bvh4Node)) + (size_t) c->view.tri_count * sizeof(Tri)) > ((size_t) 32 << 20);
                     if (const char *e = getenv("MIW_PLACE_SPREAD")) spread = atoi(e) != 0;
                     Q.piece_a = spread ? 1u : 64u; Q.piece_b = spread ? n_pieces : 1u;
                     std::vector<uint32_t> cost(n_pieces);
                     HIP_TRY(c, hipMemcpy2DAsync(cost.data(), sizeof(uint32_t), c->d_cost_sorted.p, Q.piece_a * sizeof(uint32_t), sizeof(uint32_t), n_pieces, hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
+                    if (cfg->profile) {        // what the measuring launch found (mi_counters::place_*): the shard's dearest pixel and the mean
+                        std::vector<uint32_t> all(n_lanes); uint32_t first_lane = 0, px = 0;
+                        HIP_TRY(c, hipMemcpyAsync(all.data(), c->d_cost_sorted.p, (size_t) n_lanes * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipMemcpyAsync(&first_lane, c->d_lane_sorted.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(c, hipStreamSynchronize(s));
+                        if (first_lane < n_lanes) HIP_TRY(c, hipMemcpy(&px, c->q_pixel.p + first_lane, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                        double sum = 0.0; uint32_t with = 0;
+                        for (uint32_t v : all) if (v) { sum += (double) v; ++with; }
+                        K.place_cost_max = all.empty() ? 0u : all[0]; K.place_cost_mean = with ? sum / with : 0.0; K.place_max_pixel = px;
+                        K.place_cost_unit = phased ? 1u : 0u; K.place_measure_spp = measure_end;
+                    }
                     // longest piece first onto the SIMD queue with the smallest sum that still has a free slot
                     // the SIMDs the measuring launch ran on, numbered 0 .. nqueues - 1 (simd_ids[1 + hardware key]; word 0 = the "all dry" flag)
                     std::vector<uint32_t> ids(c->d_simd_ids.n);
@@ -1252,19 +1327,30 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
-#define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
+#define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, (W) == 2 ? view8 : c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
 #define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_PHASED_LAUNCH_(M, A, 4, W, false); else MIW_PHASED_LAUNCH_(M, A, 3, W, false); } while (0)
-                if (phased && place) {                           // a shard of about one pixel per resident lane: the Placed instantiations (measuring, then placed launch)
-                    if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, true, true);
-                    else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, true, true);
-                    else if (c->rects.empty()) MIW_PHASED_LAUNCH_(MATS_PLAIN, false, 4, true, true);
-                    else MIW_PHASED_LAUNCH_(MATS_PLAIN, true, 4, true, true);
+                K.tree_width = phased ? (phased8 ? 8u : (c->view.nodes4 ? 4u : 2u)) : 0u;
+                if (phased8 && place) {
+                    if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 2, true);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, 2, true);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH_(MATS_PLAIN, false, 4, 2, true);
+                    else MIW_PHASED_LAUNCH_(MATS_PLAIN, true, 4, 2, true);
+                } else if (phased8) {
+                    if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 2, false);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, 2, false);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH_(MATS_PLAIN, false, 4, 2, false);
+                    else MIW_PHASED_LAUNCH_(MATS_PLAIN, true, 4, 2, false);
+                } else if (phased && place) {                           // a shard of about one pixel per resident lane: the Placed instantiations (measuring, then placed launch)
+                    if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 1, true);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, 1, true);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH_(MATS_PLAIN, false, 4, 1, true);
+                    else MIW_PHASED_LAUNCH_(MATS_PLAIN, true, 4, 1, true);
                 } else if (phased) {
-                    if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, false);
-                    else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, true);
-                    else if (trio_kernel) MIW_PHASED_LAUNCH(MATS_TRIO, false, true);
-                    else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false, true);
-                    else MIW_PHASED_LAUNCH(MATS_PLAIN, true, true);
+                    if (!c->view.nodes4) MIW_PHASED_LAUNCH(MATS_TRIO, false, 0);
+                    else if (c->textured) MIW_PHASED_LAUNCH(MATS_ALL, true, 1);
+                    else if (trio_kernel) MIW_PHASED_LAUNCH(MATS_TRIO, false, 1);
+                    else if (c->rects.empty()) MIW_PHASED_LAUNCH(MATS_PLAIN, false, 1);
+                    else MIW_PHASED_LAUNCH(MATS_PLAIN, true, 1);
                 }
 #undef MIW_PHASED_LAUNCH
 #undef MIW_PHASED_LAUNCH_

@@ -278,7 +278,7 @@ bool build_scene(const mi_scene_desc *s, OScene &o) {
         v.accept_pad = scene_pad_unit(ext);
     }
     v.tri_bounds = nullptr;
-    v.leaf_boxes = nullptr; v.nodes4 = nullptr;
+    v.leaf_boxes = nullptr; v.nodes4 = nullptr; v.nodes8 = nullptr;
     v.nodes = nullptr; v.node_count = 0;
     v.tris = o.tris.data(); v.tri_count = (uint32_t) o.tris.size();
     v.tri_vn = o.tri_vn.empty() ? nullptr : o.tri_vn.data();

@@ -46,6 +46,9 @@ class Oracle:
         L.emu_trace4.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
                                  C.c_int, C.c_int, C.c_int, C.c_int, c_u32_p, C.c_uint32]
         L.emu_trace4.restype = C.c_int
+        L.emu_trace8.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), C.c_uint64,
+                                 C.c_int, C.c_int, C.c_int, c_u32_p, C.c_uint32, C.c_int]
+        L.emu_trace8.restype = C.c_int
         L.emu_sah_levels_check.argtypes = [C.POINTER(mi_scene_desc), C.c_int, c_u32_p]; L.emu_sah_levels_check.restype = C.c_int
         L.emu_render.argtypes = [C.POINTER(mi_scene_desc), C.POINTER(mi_render_cfg), c_double_p, c_float_p, C.POINTER(C.c_uint64)]
         L.emu_render.restype = C.c_int
@@ -156,6 +159,19 @@ class Oracle:
         sched = (int(schedule) & 0x7fffffff) | (0 if spec or not schedule else 0x80000000)
         out = self._trace(self.L.emu_trace4, desc, o, d, mint, maxt, any_hit, max_leaf, stack_budget, max_fan, stats, sched)
         out["bvh4"] = dict(zip(("nodes2", "nodes4", "depth", "stack_bound", "stack_seen", "ok"), list(stats)))
+        return out
+
+    def emu_trace8(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, max_fan=8, schedule=0, compare4=False):
+        """The 8-wide quantised tree (csrc/miw/bvh8.h, collapsed by csrc/bvh8_build.h, triangles in the tree's own order) walked on
+        the CPU: by the reference walk bvh8_intersect (schedule = 0) or by the per-lane bodies of the device's phase machine
+        (walk8_node_step / walk8_tri_step; schedule > 0), every stack-column access checked. out["bvh8"]: node / depth / step
+        counts (+ the 4-wide reference walk's counts over the same rays with compare4)."""
+        stats = (C.c_uint32 * 15)()
+        out = self._trace(self.L.emu_trace8, desc, o, d, mint, maxt, any_hit, max_leaf, max_fan, stats, int(schedule), int(bool(compare4)))
+        st = list(stats)
+        out["bvh8"] = dict(nodes2=st[0], nodes8=st[1], depth=st[2], stack_seen=st[3], ok=st[4], node_steps=st[5] | st[6] << 32,
+                           tri_tests=st[7] | st[8] << 32, tri_steps=st[9] | st[10] << 32, node_steps4=st[11] | st[12] << 32,
+                           tri_tests4=st[13] | st[14] << 32)
         return out
 
     def ray_intersect_full(self, desc, ray8):

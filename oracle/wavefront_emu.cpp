@@ -22,6 +22,7 @@
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/bvh_build.h"
 #include "../mitsuba2_amd/csrc/bvh4_build.h"
+#include "../mitsuba2_amd/csrc/bvh8_build.h"
 #include "../mitsuba2_amd/csrc/sah_levels.h"
 #include "../mitsuba2_amd/csrc/envmap_build.h"
 #include "../mitsuba2_amd/csrc/rect_build.h"
@@ -150,7 +151,7 @@ bool emu_build(const mi_scene_desc *s, EmuScene &o, int max_leaf) {
     scene_view_prepare(v);
     v.emit_tri = o.emit_tri.data(); v.emit_vnorm = emit_normals ? o.emit_vnorm.data() : nullptr;
     v.emit_pmf = o.emit_pmf.data(); v.emit_cdf = o.emit_cdf.data();
-    v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr; v.nodes4 = nullptr;
+    v.env = s->envmap ? &o.env.rec : nullptr; v.leaf_boxes = nullptr; v.nodes4 = nullptr; v.nodes8 = nullptr;
     v.rects = o.rects.empty() ? nullptr : o.rects.data(); v.rect_count = (uint32_t) o.rects.size();
     v.accept_pad = scene_pad_unit(o.tris_in); v.tri_bounds = nullptr;
     return true;
@@ -198,6 +199,40 @@ struct EmuCoin {                                                // xorshift32: t
     uint32_t s;
     bool operator()() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return (s & 1u) != 0; }
 };
+// The same for the 8-wide tree: walk8_node_step / walk8_tri_step of csrc/miw/bvh8.h, the bodies k_path_phased<NodeKind 8> runs. A lane
+// is ready for exactly one body at a time (triangles before nodes), so there is no coin to toss inside one walk; the column
+// (MIW_BVH8_STACK entries of 8 bytes) is checked on every access like the 4-wide one.
+struct EmuColumn8 {
+    U2 *p; int32_t cap; bool *bad; uint32_t *deepest;
+    U2 &operator[](int32_t i) const {
+        if (i < 0 || i >= cap) { *bad = true; return p[cap]; }
+        if ((uint32_t) i + 1u > *deepest) *deepest = (uint32_t) i + 1u;
+        return p[i];
+    }
+};
+template <typename TriAt>
+bool emu_walk8(const Bvh8Node *nodes8, TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best,
+               int32_t cap, bool *bad, uint32_t *deepest, uint64_t *steps) {
+    const SlabRay r = slab_ray_host(o, d, mint);
+    U2 column[MIW_BVH8_STACK + 1];
+    const EmuColumn8 stack{ column, cap, bad, deepest };
+    Walk8 w; walk8_begin(w, r);
+    float tmax = maxt;
+    bool occluded = false;
+    if (!any_hit) { best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu; }
+    while (!walk8_over(w)) {
+        if (walk8_node_ready(w)) {
+            const Bvh8Node &n = nodes8[walk8_next_node(w)];
+            walk8_node_step(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), w, stack);
+            if (steps) steps[0]++;
+        } else if (walk8_tri_ready(w)) {
+            walk8_tri_step<true>(tri_at, ctx, o, d, mint, maxt, any_hit, best, tmax, occluded, w);
+            if (steps) steps[2]++;
+        } else { *bad = true; break; }                          // neither over nor ready: a state the bodies must not produce
+    }
+    if (!any_hit && best.tri != MIW_MISS) best.prim = tri_at(best.tri).prim;
+    return any_hit ? occluded : best.tri != MIW_MISS;
+}
 }
 
 extern "C" {
@@ -291,6 +326,56 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
         if (h->shape) h->shape[i] = ok ? tris[hit.tri].shape : 0xffffffffu;
     }
     if (stats6) stats6[4] = seen;
+    return bad ? 2 : 0;
+}
+
+// the 8-wide quantised tree of miw/bvh8.h (collapsed from the same SAH build; triangles in the tree's own order) over caller rays.
+// stats8: BVH2 nodes, BVH8 nodes, BVH8 depth, deepest stack any ray reached, ok flag, then as 64-bit pairs (lo, hi): node steps,
+// triangles handed to the triangle test, triangle-pair steps (schedule > 0 only).
+// schedule: 0 = bvh8_intersect (the reference walk); > 0 = the phase machine's bodies (emu_walk8), every column access checked (2 = a stray access).
+// compare4 != 0: the 4-wide reference walk runs over the same rays as well and its node / triangle counts go to stats8[11..14].
+int emu_trace8(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_soa *h, uint64_t n, int any_hit, int max_leaf,
+               int max_fan, uint32_t *stats8, uint32_t schedule, int compare4) {
+    EmuScene sc; if (!emu_build(scene, sc, max_leaf)) return -1;
+    Ftz ftz;
+    const Bvh8BuildResult b8 = bvh8_collapse(sc.bvh.nodes, sc.view.tri_count, max_fan);
+    uint32_t seen = 0; uint64_t steps[3] = { 0, 0, 0 }, steps4[2] = { 0, 0 };
+    if (stats8) { std::memset(stats8, 0, 15 * sizeof(uint32_t)); stats8[0] = sc.view.node_count; stats8[1] = (uint32_t) b8.nodes.size(); stats8[2] = b8.depth; stats8[4] = b8.ok ? 1u : 0u; }
+    if (!b8.ok) return 1;
+    std::vector<Tri> tris8(b8.perm.size());
+    for (size_t i = 0; i < tris8.size(); ++i) tris8[i] = sc.view.tris[b8.perm[i]];
+    const Tri *tris = tris8.data(); const PrimCtx rects = prim_ctx(sc.view);
+    auto tri_at = [tris](uint32_t i) -> const Tri & { return tris[i]; };
+    Bvh4BuildResult b4; const Tri *tris2 = sc.view.tris;
+    auto tri_at2 = [tris2](uint32_t i) -> const Tri & { return tris2[i]; };
+    if (compare4) b4 = bvh4_collapse(sc.bvh.nodes, 64u, 4);
+    bool bad = false;
+    for (uint64_t i = 0; i < n; ++i) {
+        const V3 o = v3(r->ox[i], r->oy[i], r->oz[i]), d = v3(r->dx[i], r->dy[i], r->dz[i]);
+        Hit hit; bool ok;
+        if (schedule) {
+            hit.t = MIW_INFINITY; hit.u = hit.v = 0.f; hit.tri = MIW_MISS; hit.prim = 0xffffffffu;
+            ok = emu_walk8(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps);
+            if (any_hit && ok) { hit.t = 0.f; hit.tri = 0; hit.prim = 0; }
+        }
+        else if (any_hit) ok = bvh8_intersect<true>(b8.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen, steps);
+        else ok = bvh8_intersect<false>(b8.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen, steps);
+        if (compare4 && b4.ok) {
+            Hit h4;
+            if (any_hit) bvh4_intersect<true>(b4.nodes.data(), tri_at2, o, d, r->mint[i], r->maxt[i], h4, rects, nullptr, steps4);
+            else bvh4_intersect<false>(b4.nodes.data(), tri_at2, o, d, r->mint[i], r->maxt[i], h4, rects, nullptr, steps4);
+        }
+        h->t[i] = ok ? hit.t : MIW_INFINITY;
+        if (h->u) h->u[i] = hit.u;
+        if (h->v) h->v[i] = hit.v;
+        if (h->prim) h->prim[i] = ok ? hit.prim : 0xffffffffu;
+        if (h->shape) h->shape[i] = ok ? tris[hit.tri].shape : 0xffffffffu;
+    }
+    if (stats8) {
+        stats8[3] = seen;
+        for (int k = 0; k < 3; ++k) { stats8[5 + 2 * k] = (uint32_t) steps[k]; stats8[6 + 2 * k] = (uint32_t) (steps[k] >> 32); }
+        for (int k = 0; k < 2; ++k) { stats8[11 + 2 * k] = (uint32_t) steps4[k]; stats8[12 + 2 * k] = (uint32_t) (steps4[k] >> 32); }
+    }
     return bad ? 2 : 0;
 }
 
@@ -427,15 +512,38 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         // Scenes the device walks with k_path_phased (more triangles than the packet kernels take, a 4-wide collapse that fits the
         // lane stack) go through the phase machine's own per-lane bodies here too (emu_walk4: an E walk, then the S walk that leaves
         // `best` alone, each under a pseudo-random body schedule); MIW_EMU_WALK=bvh2 keeps the stackless BVH2 walk for all scenes.
-        Bvh4BuildResult b4;
+        // Since round 5 the device's default tree is the 8-wide one (miw/bvh8.h: walk8_node_step / walk8_tri_step, triangles and vertex
+        // normals in that tree's order): emu_walk8 over a view with the permuted arrays; MIW_EMU_WALK=bvh4 keeps the 4-wide bodies.
+        Bvh4BuildResult b4; Bvh8BuildResult b8;
         const char *walk_env = getenv("MIW_EMU_WALK");
-        if (sc.view.tri_count > 64u && !(walk_env && !strcmp(walk_env, "bvh2"))) b4 = bvh4_collapse(sc.bvh.nodes, 31u, 4);
+        const bool want_tree = sc.view.tri_count > 64u && !(walk_env && !strcmp(walk_env, "bvh2"));
+        if (want_tree && !(walk_env && !strcmp(walk_env, "bvh4"))) b8 = bvh8_collapse(sc.bvh.nodes, sc.view.tri_count);
+        const bool phased8 = b8.ok && !b8.nodes.empty();
+        if (want_tree && !phased8) b4 = bvh4_collapse(sc.bvh.nodes, 31u, 4);
         const bool phased = b4.ok && !b4.nodes.empty();
+        std::vector<Tri> tris8; std::vector<float> vn8;
+        SceneView view8 = sc.view;
+        if (phased8) {
+            tris8.resize(b8.perm.size());
+            for (size_t i = 0; i < tris8.size(); ++i) tris8[i] = sc.view.tris[b8.perm[i]];
+            view8.tris = tris8.data();
+            if (sc.view.tri_vn) {
+                vn8.resize(tris8.size() * 9);
+                for (size_t i = 0; i < tris8.size(); ++i) std::memcpy(&vn8[i * 9], sc.view.tri_vn + (size_t) b8.perm[i] * 9, 36);
+                view8.tri_vn = vn8.data();
+            }
+        }
+        const SceneView &V = phased8 ? view8 : sc.view;
+        const Tri *tris_w = V.tris;
+        auto tri_at_w = [tris_w](uint32_t i) -> const Tri & { return tris_w[i]; };
         EmuCoin coin{ 0x9e3779b9u }; bool bad_slot = false; uint32_t deepest = 0;
         auto trace2 = [&](V3 o, float mint, V3 dE, float maxtE, bool hasE, V3 dS, float maxtS, bool hasS, F4 &hE, bool &occS) {
             Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
             occS = false;
-            if (phased) {
+            if (phased8) {
+                if (hasE) emu_walk8(b8.nodes.data(), tri_at_w, rects, o, dE, mint, maxtE, false, h, MIW_BVH8_STACK, &bad_slot, &deepest, nullptr);
+                if (hasS) occS = emu_walk8(b8.nodes.data(), tri_at_w, rects, o, dS, mint, maxtS, true, h, MIW_BVH8_STACK, &bad_slot, &deepest, nullptr);
+            } else if (phased) {
                 if (hasE) emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dE, mint, maxtE, false, h, std::ref(coin), 32, &bad_slot, &deepest);
                 if (hasS) occS = emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dS, mint, maxtS, true, h, std::ref(coin), 32, &bad_slot, &deepest);
             } else {
@@ -456,8 +564,8 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                     splat(pixel, sample_idx, pos, aovs);
                     if (do_log) { if (rec16) log16(pixel, sample_idx, pos, aovs); else log(pixel, sample_idx, pos, aovs); }
                 };
-                st[lane] = direct ? pixel_render<INTEG_DIRECT>(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt)
-                                  : pixel_render(P, sc.view, pixel[lane], st[lane], end, trace2, sink, &cnt);
+                st[lane] = direct ? pixel_render<INTEG_DIRECT>(P, V, pixel[lane], st[lane], end, trace2, sink, &cnt)
+                                  : pixel_render(P, V, pixel[lane], st[lane], end, trace2, sink, &cnt);
             }
             done = end; ++iterations;
         }

@@ -15,6 +15,7 @@
 #include "../mitsuba2_amd/csrc/miw/film.h"
 #include "../mitsuba2_amd/csrc/miw/bvh.h"
 #include "../mitsuba2_amd/csrc/miw/bvh4.h"
+#include "../mitsuba2_amd/csrc/miw/bvh8.h"
 #include "../mitsuba2_amd/csrc/miw/path.h"
 #include "../mitsuba2_amd/csrc/miw/direct.h"
 using namespace miw;
@@ -24,10 +25,11 @@ using namespace miw;
 #include "../mitsuba2_amd/csrc/device/wavefront_kernels.h"
 #include "../mitsuba2_amd/csrc/device/resident_kernel.h"
 #include "../mitsuba2_amd/csrc/device/phased_kernel.h"
-#if defined(MIW_PROBE_C34)   // only the kernel of BASELINE configs 3 / 4: MATS_TRIO over the 4-wide tree, four wavefronts per SIMD (tests/test_kernel_budget.py)
-template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, true>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+#if defined(MIW_PROBE_C34)   // only the kernels of BASELINE configs 3 / 4: MATS_TRIO over the 8-wide tree (round 5) and its 4-wide twin, four wavefronts per SIMD (tests/test_kernel_budget.py)
+template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 2>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 1>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #else
 template __global__ void k_path_phased<MATS_PLAIN, false, MIW_PHASE_SPEC != 0>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #include "../mitsuba2_amd/csrc/device/stream_trace.h"
-template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 3, false>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 3, 0>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #endif
