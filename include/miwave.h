@@ -387,6 +387,22 @@ mi_status mi_render(mi_ctx *ctx, const mi_render_cfg *cfg, void *film);
 /* Integrator::cancel() — may be called from another thread */
 mi_status mi_cancel(mi_ctx *ctx);
 
+/* ---- N-GPU frames inside ONE process (round 5; SURVEY.md section 8e: pixel-tile shards + one film reduce) ----------------
+ * The reference renders a frame with one call in one process (include/mitsuba/render/integrator.h:42). Over N GPUs that is:
+ * one context per GPU (the scene uploaded to each), every context renders its shard (mi_render_cfg::tile_list) with
+ * film_on_device = 1 into a device film of its own, then ONE reduce sums the films onto the root's.
+ *   mi_film_alloc     `count` zeroed floats on ctx's device (a film = crop_w * crop_h * 5)
+ *   mi_film_reduce    films[i] (resident on ctxs[i]'s device) summed onto films[root], in place. All devices distinct: RCCL
+ *                     (ncclCommInitAll communicators cached per device list, one grouped ncclReduce over xGMI; librccl is
+ *                     dlopen'ed on first use); contexts sharing a device, or no RCCL (MIW_RCCL=0): added in rank order by a
+ *                     device kernel. *how (may be NULL) says which. Synchronous: waits for the contexts' streams before and after.
+ *   mi_film_download  a device film to host memory. */
+enum { MI_REDUCE_NONE = 0, MI_REDUCE_DEVICE_ADD = 1, MI_REDUCE_RCCL = 2 };
+mi_status mi_film_alloc(mi_ctx *ctx, uint64_t count, void **device_film);
+void      mi_film_free(mi_ctx *ctx, void *device_film);
+mi_status mi_film_download(mi_ctx *ctx, const void *device_film, float *host, uint64_t count);
+mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uint64_t count, int32_t root, int32_t *how);
+
 mi_status   mi_get_counters(mi_ctx *ctx, mi_counters *out);
 const char *mi_last_error(mi_ctx *ctx);
 

@@ -139,7 +139,8 @@ MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (
 # every symbol include/miwave.h declares (tests check that the library exports all of them)
 MI_SYMBOLS = ["mi_spectrum_channels", "mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
               "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval", "mi_selftest",
-              "mi_ray_intersect", "mi_sample_emitter_direction", "mi_pdf_emitter_direction", "mi_emitter_eval"]
+              "mi_ray_intersect", "mi_sample_emitter_direction", "mi_pdf_emitter_direction", "mi_emitter_eval",
+              "mi_film_alloc", "mi_film_free", "mi_film_download", "mi_film_reduce"]
 
 
 VARIANT_SUFFIX = {"scalar_rgb": "", "scalar_spectral": "_spectral"}
@@ -229,6 +230,8 @@ def load_host_lib(variant="scalar_rgb"):
         "mih_load_xml": (i32, [cp, i32, cp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mih_scene_create": (vp, []), "mih_scene_destroy": (None, [vp]),
         "mih_scene_add_shape": (i32, [vp, vp]), "mih_scene_build": (i32, [vp, i32, i32]),
+        "mih_scene_build_multi": (i32, [vp, C.POINTER(C.c_int), i32, i32]), "mih_scene_device_count": (i32, [vp]),
+        "mih_render_multi": (i32, [vp, vp, vp, C.POINTER(C.c_int)]), "mih_integrator_last_reduce": (i32, [vp]),
         "mih_scene_desc": (C.POINTER(mi_scene_desc), [vp]), "mih_scene_ctx": (vp, [vp]),
         "mih_scene_ray_intersect": (i32, [vp, C.POINTER(mi_rays_soa), C.POINTER(mi_hits_soa), u64]),
         "mih_scene_ray_test": (i32, [vp, C.POINTER(mi_rays_soa), c_float_p, u64]),

@@ -41,6 +41,9 @@ struct LdsColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) 
 #ifndef MIW_PHASE_SPEC
 #define MIW_PHASE_SPEC 1
 #endif
+#ifndef MIW_W8_SPEC
+#define MIW_W8_SPEC 0               /* 1: the 8-wide walk speculates as well (a second pending triangle group, miw/bvh8.h) */
+#endif
 #ifndef MIW_TRI_PAIR
 #define MIW_TRI_PAIR 1              /* 1: the triangle body tests two triangles of a leaf range per iteration (both fetched up front: +2 - 4 %); 0: one */
 #endif
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     int32_t cur = MIW_WALK_DONE, sp = 0;
     uint32_t tri_i = 0, tri_end = 0;
     // Wide == 2: the walk is two groups (miw/bvh8.h): node group (gb, gm: pending slots | imask | octant | stack depth), triangle group (tb, tm)
-    Walk8 w8; w8.gb = 0u; w8.gm = 0u; w8.tb = 0u; w8.tm = 0u;
+    Walk8 w8; w8.gb = 0u; w8.gm = 0u; w8.tb = 0u; w8.tm = 0u; w8.tb2 = 0u; w8.tm2 = 0u;
+    constexpr bool Spec8 = Spec && (MIW_W8_SPEC != 0);
     // (direction, maxt and mint of the walk in progress are the path state's own — L.ray for an E walk, sh.d / sh.maxt for an S
     // walk, selected by `mode` where the triangle body needs them — not copies that would be live through the shade body)
     float tmax = 0.f;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         const bool trav = (mode - 1u) < 2u;
         bool has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
         bool e_leaf = trav && has_range;
-        bool e_node = trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range));
+        bool e_node = trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range));
         // a walk that is over: an E walk with a shadow ray queued turns into the S walk at the next entry to the node body
         // (`e_turn`; the hit record stays in `best`, which an S walk never writes), every other one is ready to shade
         const bool walk_over = trav && (Wide == 2 ? walk8_over(w8) : !has_range && cur == MIW_WALK_DONE);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         // one 80-byte node = eight quantised child boxes: the node step of miw/bvh8.h (the CPU checker runs the same statements)
                         FastRay rn; rn.inv_d = r.inv_d; rn.neg_o_inv_d = r.neg_o_inv_d; rn.mint = L.ray.mint;
                         const auto &nd = node8_at(walk8_next_node(w8));
-                        walk8_node_step(nd, rn, widen(tmax), w8, LdsColumn8{ stack8 });
+                        walk8_node_step<Spec8>(nd, rn, widen(tmax), w8, LdsColumn8{ stack8 });
                     } else if (Wide) {
                         // one 64-byte node = four quantised child boxes: the node step of miw/bvh4.h (the CPU checker runs the same statements)
                         const LdsColumn column{ stack };
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     }
                 }
                 has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
-                e_node = trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range));
+                e_node = trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range));
                 const int now = count(e_node);
                 n_leaf = count(trav && has_range);
                 n_gone = n_node - now;                                   // lanes of this burst now at a leaf / at their walk's end
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     if (Wide == 2) {
                         // the two lowest pending triangles of the lane's triangle group (miw/bvh8.h); a drained group hands over to the next node group
                         // (the node step leaves a non-empty node group behind whenever the stack holds one: nothing to pop here)
-                        walk8_tri_step<Analytic>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, mode == PH_TRAV_S, best, tmax, occluded, w8);
+                        walk8_tri_step<Analytic, Spec8>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur, mode == PH_TRAV_S, best, tmax, occluded, w8);
                     } else
                     // two triangles of the lane's range per trip: walk4_tri_step (miw/bvh4.h — shared with the CPU checker)
                     walk4_tri_step<Analytic>(tri_at_g, ctx, L.ray.o, d_cur, L.ray.mint, maxt_cur,
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
                 e_leaf = trav && has_range;
                 const int now = count(e_leaf);
-                n_node = count(trav && (Wide == 2 ? walk8_node_ready(w8) : cur >= 0 && (Spec || !has_range)));
+                n_node = count(trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range)));
                 if (now <= n_node || now < others || now == 0) break;
             } while (true);
         }

@@ -110,15 +110,17 @@ MIW_HD void bvh8_test(const Bvh8Node &n, const Ray &r, float tmax_wide, uint32_t
 // tested. Walk over: no pending slot, no pending triangle, sp == 0. `stack[i]` = the lane's i-th entry (U2: x = gb, y = low 16 bits of gm).
 // A lane takes a node step only while its triangle group is empty (triangles first: a hit shrinks tmax before the walk descends).
 // Invariant between steps: the node group is empty only if the stack is (the node step pops when its node had no inner hit).
-struct Walk8 { uint32_t gb, gm, tb, tm; };
+// Spec (the speculating variant, like the 4-wide walk's): a lane holding an untested triangle group may keep descending; the
+// triangles a further node hands it wait in a SECOND group (tb2, tm2) and the lane stalls only while both are full.
+struct Walk8 { uint32_t gb, gm, tb, tm, tb2, tm2; };
 #define MIW_W8_PENDING(gm_) ((gm_) & 0xffu)
 #define MIW_W8_SP(gm_) (((gm_) >> 24) & 31u)
 template <typename Ray> MIW_HD void walk8_begin(Walk8 &w, const Ray &r) {
     const uint32_t oct = bvh8_octant(r);
     // the root as a group of one: node 0 = child_base 0 + rank 0; pending bit 0 stands for slot `oct`, whose rank under imask = 1 << oct is 0
-    w.gb = 0u; w.gm = 1u | ((1u << oct) << 8) | (oct << 16); w.tb = 0u; w.tm = 0u;
+    w.gb = 0u; w.gm = 1u | ((1u << oct) << 8) | (oct << 16); w.tb = 0u; w.tm = 0u; w.tb2 = 0u; w.tm2 = 0u;
 }
-MIW_HD bool walk8_node_ready(const Walk8 &w) { return MIW_W8_PENDING(w.gm) != 0u && w.tm == 0u; }
+template <bool Spec = false> MIW_HD bool walk8_node_ready(const Walk8 &w) { return MIW_W8_PENDING(w.gm) != 0u && (Spec ? w.tm2 : w.tm) == 0u; }
 MIW_HD bool walk8_tri_ready(const Walk8 &w) { return w.tm != 0u; }
 MIW_HD bool walk8_over(const Walk8 &w) { return (w.gm & 0x1f0000ffu) == 0u && w.tm == 0u; }
 // the node the next node step of `w` fetches (the kernel issues the five loads, then calls walk8_node_step with the record)
@@ -134,7 +136,7 @@ template <typename Stack> MIW_HD void walk8_pop(Walk8 &w, Stack stack) {
         w.gb = e.x; w.gm = (w.gm & 0x00070000u) | (e.y & 0xffffu) | (sp << 24);
     }
 }
-template <typename Ray, typename Stack>
+template <bool Spec = false, typename Ray, typename Stack>
 MIW_HD void walk8_node_step(const Bvh8Node &n, const Ray &r, float tmax_wide, Walk8 &w, Stack stack) {
     const uint32_t oct = (w.gm >> 16) & 7u;
     uint32_t sp = MIW_W8_SP(w.gm);
@@ -146,13 +148,17 @@ MIW_HD void walk8_node_step(const Bvh8Node &n, const Ray &r, float tmax_wide, Wa
     bvh8_test(n, r, tmax_wide, hits, tris);
     const uint32_t imask = n.exps >> 24;
     const uint32_t inner = bvh8_permute(hits & imask, oct);
-    w.tb = n.tri_base; w.tm = tris;
+    if (Spec) {                                                       // (T2 non-empty implies T non-empty: the first group fills first)
+        const bool first = w.tm == 0u;
+        w.tb2 = first ? w.tb2 : n.tri_base; w.tm2 = first ? 0u : tris;
+        w.tb = first ? n.tri_base : w.tb; w.tm = first ? tris : w.tm;
+    } else { w.tb = n.tri_base; w.tm = tris; }
     w.gb = n.child_base; w.gm = (oct << 16) | (imask << 8) | inner | (sp << 24);
     walk8_pop(w, stack);
 }
 // Triangle step: the two lowest pending triangles of the group, both records fetched up front; otherwise walk4_tri_step's
 // rules (tests in ascending order, ties to the smaller primitive id, any hit ends a shadow walk).
-template <bool Analytic, typename TriAt>
+template <bool Analytic, bool Spec = false, typename TriAt>
 MIW_HD void walk8_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best, float &tmax,
                            bool &occluded, Walk8 &w) {
     const uint32_t i1 = bvh8_ctz(w.tm);
@@ -177,6 +183,10 @@ MIW_HD void walk8_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
     best.t = take2 ? t2 : best.t; best.u = take2 ? u2 : best.u; best.v = take2 ? v2 : best.v; best.tri = take2 ? a2 : best.tri;
     tmax = take2 ? t2 : tmax;
     w.tm = stop ? 0u : rest;
+    if (Spec) {                                                       // a drained first group hands over to the second
+        const bool drained = w.tm == 0u;
+        w.tb = drained ? w.tb2 : w.tb; w.tm = drained ? (stop ? 0u : w.tm2) : w.tm; w.tm2 = drained ? 0u : w.tm2;
+    }
     w.gm = stop ? (w.gm & 0x00070000u) : w.gm;                         // an occluded shadow walk is over: no pending slots, empty stack
 }
 

@@ -64,6 +64,7 @@ __device__ __forceinline__ unsigned long long *miw_sec_buf() { __shared__ unsign
 #include "sah_device.h"
 #include "bvh4_device.h"
 #include "bvh8_device.h"
+#include "film_reduce.h"
 
 using namespace miw;
 
@@ -228,6 +229,86 @@ mi_status mi_cancel(mi_ctx *c) { if (!c) return MI_ERR_INVALID; c->cancel.store(
 mi_status mi_get_counters(mi_ctx *c, mi_counters *out) {
     if (!c || !out) return MI_ERR_INVALID;
     *out = c->counters;
+    return MI_OK;
+}
+
+// ---- N-GPU frames inside one process: device films and their reduce (film_reduce.h) ------------------------------
+mi_status mi_film_alloc(mi_ctx *c, uint64_t count, void **film) {
+    if (!c || !film) return MI_ERR_INVALID;
+    *film = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *p = nullptr;
+    HIP_TRY(c, hipMalloc((void **) &p, std::max<uint64_t>(count, 1) * sizeof(float)));
+    hipError_t e = hipMemsetAsync(p, 0, count * sizeof(float), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void) hipFree(p); return fail(c, MI_ERR_DEVICE, "mi_film_alloc: %s", hipGetErrorString(e)); }
+    *film = p;
+    return MI_OK;
+}
+void mi_film_free(mi_ctx *c, void *film) {
+    if (!c || !film) return;
+    (void) hipSetDevice(c->device);
+    (void) hipFree(film);
+}
+mi_status mi_film_download(mi_ctx *c, const void *film, float *host, uint64_t count) {
+    if (!c || !film || !host) return MI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(host, film, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uint64_t count, int32_t root, int32_t *how) {
+    if (how) *how = MI_REDUCE_NONE;
+    if (!ctxs || !films || n < 1 || root < 0 || root >= n) return MI_ERR_INVALID;
+    for (int32_t i = 0; i < n; ++i) if (!ctxs[i] || !films[i]) return MI_ERR_INVALID;
+    mi_ctx *r = ctxs[root];
+    // everything the contexts still have in flight on their streams lands first
+    for (int32_t i = 0; i < n; ++i) { HIP_TRY(r, hipSetDevice(ctxs[i]->device)); HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream)); }
+    if (n == 1 || count == 0) return MI_OK;
+    std::vector<int> devs(n);
+    bool distinct = true;
+    for (int32_t i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int32_t j = 0; j < i; ++j) distinct = distinct && devs[j] != devs[i]; }
+    if (distinct) {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (g_rccl.load()) {
+            auto it = g_rccl_comms.find(devs);
+            if (it == g_rccl_comms.end()) {
+                std::vector<ncclComm_t> comms(n);
+                const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), n, devs.data());
+                if (rc != ncclSuccess) return fail(r, MI_ERR_DEVICE, "mi_film_reduce: ncclCommInitAll: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+                it = g_rccl_comms.emplace(devs, comms).first;
+            }
+            ncclResult_t rc = g_rccl.GroupStart();
+            for (int32_t i = 0; i < n && rc == ncclSuccess; ++i) {
+                HIP_TRY(r, hipSetDevice(devs[i]));
+                rc = g_rccl.Reduce(films[i], films[i], (size_t) count, ncclFloat, ncclSum, root, it->second[i], ctxs[i]->stream);
+            }
+            const ncclResult_t re = g_rccl.GroupEnd();
+            if (rc == ncclSuccess) rc = re;
+            if (rc != ncclSuccess) return fail(r, MI_ERR_DEVICE, "mi_film_reduce: ncclReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+            for (int32_t i = 0; i < n; ++i) { HIP_TRY(r, hipSetDevice(devs[i])); HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream)); }
+            HIP_TRY(r, hipSetDevice(r->device));
+            if (how) *how = MI_REDUCE_RCCL;
+            return MI_OK;
+        }
+    }
+    // rank-ordered device add onto the root's film (contexts sharing a device, or no RCCL)
+    HIP_TRY(r, hipSetDevice(r->device));
+    TmpBuf<float> stage;
+    const dim3 blk(256), grd((unsigned) ((count + 255) / 256));
+    for (int32_t i = 0; i < n; ++i) {
+        if (i == root) continue;
+        const float *src = (const float *) films[i];
+        if (ctxs[i]->device != r->device) {
+            HIP_TRY(r, stage.resize(count));
+            HIP_TRY(r, hipMemcpyPeerAsync(stage.p, r->device, films[i], ctxs[i]->device, count * sizeof(float), r->stream));
+            src = stage.p;
+        }
+        hipLaunchKernelGGL(k_film_add, grd, blk, 0, r->stream, (float *) films[root], src, count);
+    }
+    HIP_TRY(r, hipGetLastError());
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    if (how) *how = MI_REDUCE_DEVICE_ADD;
     return MI_OK;
 }
 

@@ -23,6 +23,8 @@
 #include <vector>
 #include <array>
 #include <atomic>
+#include <mutex>
+#include <thread>
 
 #include "../../include/miwave.h"
 
@@ -472,6 +474,14 @@ public:
     const EnvironmentMapEmitter *environment() const { return m_env.get(); }   // scene.h:150-151
     // finishes construction: default BSDFs (shape.cpp:75-81), flatten, upload, build accel (scene.cpp:94-97)
     void build(int device = 0, int bvh_quality = 0);   // 0: the binned-SAH tree built on the device (csrc/sah_device.h), 1: by the host recursion
+    // The same scene resident on SEVERAL GPUs of the node (round 5): one context per entry of `devices` (devices[0] = the primary,
+    // ctx(); an index may repeat — several contexts on one GPU, which is how the single-GPU test tier runs the path), uploads and
+    // BVH builds in parallel. SamplingIntegrator::render(scene, sensor) then shards the frame's tiles over the contexts and
+    // closes it with one film reduce (mi_film_reduce: RCCL over xGMI between distinct GPUs) — still ONE call in ONE process,
+    // like the reference's Integrator::render (include/mitsuba/render/integrator.h:42).
+    void build(const std::vector<int> &devices, int bvh_quality = 0);
+    size_t device_count() const { return m_ctx ? 1 + m_replicas.size() : 0; }
+    mi_ctx *ctx(size_t i) const { return i == 0 ? m_ctx : m_replicas.at(i - 1); }
     const std::vector<std::shared_ptr<Mesh>> &shapes() const { return m_shapes; }
     size_t emitter_count() const { return m_emitters.size(); }
     std::array<float, 6> bbox() const;                         // Scene::bbox(): union of the shapes' boxes
@@ -505,6 +515,7 @@ private:
     std::shared_ptr<EnvironmentMapEmitter> m_env; size_t m_env_after_shapes = 0; mi_envmap m_env_rec{};
     mi_scene_desc m_desc{};
     mi_ctx *m_ctx = nullptr;
+    std::vector<mi_ctx *> m_replicas;                          // the contexts of devices[1..] of a multi-GPU build
     bool m_built = false;
 };
 
@@ -524,6 +535,8 @@ public:
     // pixel-tile shard for multi-GPU: this process renders blocks with
     // (spiral index % world_size) == rank; the film holds the partial sum.
     void set_shard(uint32_t rank, uint32_t world_size) { m_rank = rank; m_world = world_size; }
+    // how the last render() over a multi-GPU scene (Scene::build(devices)) summed its partial films: MI_REDUCE_* of include/miwave.h
+    int last_reduce() const { return m_last_reduce; }
     // fills everything SamplingIntegrator::render derives on the host
     // for pass `pass` of pass_count(sensor) (samples_per_pass < sample_count, integrator.cpp:75-86). Passes are
     // in execution order; like spiral.cpp:41 the first pass rendered carries the highest block-id offset: pass p's blocks carry ids (n_passes - 1 - p) * block_count + spiral counter
@@ -532,6 +545,10 @@ public:
     void make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
                          std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
                          uint32_t n_threads_hint = 1, uint32_t pass = 0) const;
+    // the same for an explicit (rank, world): context r of a multi-GPU scene renders shard (m_rank * n + r, m_world * n)
+    void make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+                         std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
+                         uint32_t n_threads_hint, uint32_t pass, uint32_t rank, uint32_t world) const;
     uint32_t pass_count(const PerspectiveCamera *sensor) const;
     const mi_counters &counters() const { return m_counters; }
     void set_profile(bool p) { m_profile = p; }
@@ -543,6 +560,10 @@ public:
     // all passes of one job into `film5` (crop_w * crop_h * 5 floats); moment_pass = mi_render_cfg::moment_pass
     bool render_passes(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass);
 protected:
+    // one pass of a frame over the contexts of a multi-GPU scene: every context its shard on its own host thread, then the film reduce
+    bool render_pass_multi(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass, uint32_t pass);
+    int m_last_reduce = 0;
+    std::mutex m_active_mutex; std::vector<mi_ctx *> m_active_multi;
     uint32_t m_block_size; uint32_t m_samples_per_pass; float m_timeout; bool m_hide_emitters;
     uint32_t m_rank = 0, m_world = 1;
     bool m_profile = false;

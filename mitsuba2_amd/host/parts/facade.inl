@@ -170,6 +170,12 @@ void mih_scene_destroy(void *s) { delete (Box<Scene> *) s; }
 int mih_scene_add_shape(void *s, void *m) { MIH_TRY ((Box<Scene> *) s)->p->add_shape(((Box<Mesh> *) m)->p); return 0; MIH_CATCH(-1) }
 // device < 0: flatten only (no GPU needed); otherwise upload + build the BVH
 int mih_scene_build(void *s, int device, int quality) { MIH_TRY ((Box<Scene> *) s)->p->build(device, quality); return 0; MIH_CATCH(-1) }
+// Scene::build(devices): one context per entry (an index may repeat), uploads + BVH builds in parallel; the integrators then render
+// a frame over all of them with one call (mih_integrator_render / mih_render_multi)
+int mih_scene_build_multi(void *s, const int *devices, int n, int quality) {
+    MIH_TRY ((Box<Scene> *) s)->p->build(std::vector<int>(devices, devices + (n > 0 ? n : 0)), quality); return 0; MIH_CATCH(-1)
+}
+int mih_scene_device_count(void *s) { return (int) ((Box<Scene> *) s)->p->device_count(); }
 const mi_scene_desc *mih_scene_desc(void *s) { return &((Box<Scene> *) s)->p->desc(); }
 mi_ctx *mih_scene_ctx(void *s) { return ((Box<Scene> *) s)->p->ctx(); }
 int mih_scene_ray_intersect(void *s, const mi_rays_soa *rays, const mi_hits_soa *hits, uint64_t n) {
@@ -325,6 +331,18 @@ void mih_integrator_cancel(void *i) { ((Box<SamplingIntegrator> *) i)->p->cancel
 int mih_integrator_render(void *i, void *scene, void *sensor) {
     MIH_TRY return ((Box<SamplingIntegrator> *) i)->p->render(((Box<Scene> *) scene)->p.get(), ((Box<PerspectiveCamera> *) sensor)->p.get()) ? 1 : 0; MIH_CATCH(-1)
 }
+// SamplingIntegrator::render over a scene built on several GPUs (mih_scene_build_multi): tile shards on one host thread per context,
+// one film reduce. Same return values as mih_integrator_render (which takes this path by itself for such a scene); *how = MI_REDUCE_*.
+int mih_render_multi(void *i, void *scene, void *sensor, int *how) {
+    MIH_TRY
+        Scene *sc = ((Box<Scene> *) scene)->p.get();
+        if (sc->device_count() < 2) throw std::runtime_error("mih_render_multi: the scene was not built on several contexts (mih_scene_build_multi)");
+        SamplingIntegrator *it = ((Box<SamplingIntegrator> *) i)->p.get();
+        const bool done = it->render(sc, ((Box<PerspectiveCamera> *) sensor)->p.get());
+        if (how) *how = it->last_reduce();
+        return done ? 1 : 0; MIH_CATCH(-1)
+}
+int mih_integrator_last_reduce(void *i) { return ((Box<SamplingIntegrator> *) i)->p->last_reduce(); }
 int mih_integrator_counters(void *i, mi_counters *out) { *out = ((Box<SamplingIntegrator> *) i)->p->counters(); return 0; }
 // Host-side job description (no GPU needed). block_ids / tiles must hold `capacity` entries.
 int mih_make_render_cfg(void *i, void *sensor, mi_render_cfg *cfg, uint32_t *block_ids, uint32_t *tiles, uint32_t capacity, uint32_t n_threads) {

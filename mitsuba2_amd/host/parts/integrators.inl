@@ -42,7 +42,11 @@ std::shared_ptr<SamplingIntegrator> make_integrator(const Properties &props) {
     if (props.plugin_name() == "direct") return std::make_shared<DirectIntegrator>(props);
     Throw("Plugin \"" + props.plugin_name() + "\" not found!");
 }
-void SamplingIntegrator::cancel() { mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c); }
+void SamplingIntegrator::cancel() {
+    mi_ctx *c = m_active_ctx.load(); if (c) mi_cancel(c);
+    std::lock_guard<std::mutex> lock(m_active_mutex);          // a multi-GPU frame: every context of it
+    for (mi_ctx *m : m_active_multi) mi_cancel(m);
+}
 
 // integrator.cpp:75-86
 static size_t samples_per_pass_of(uint32_t samples_per_pass, size_t total_spp) {
@@ -58,6 +62,11 @@ uint32_t SamplingIntegrator::pass_count(const PerspectiveCamera *sensor) const {
 void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
                                      std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
                                      uint32_t n_threads, uint32_t pass) const {
+    make_render_cfg(sensor, cfg, block_ids, tiles, n_threads, pass, m_rank, m_world);
+}
+void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_render_cfg &cfg,
+                                     std::vector<uint32_t> &block_ids, std::vector<uint32_t> &tiles,
+                                     uint32_t n_threads, uint32_t pass, uint32_t m_rank, uint32_t m_world) const {
     std::memset(&cfg, 0, sizeof cfg);
     const Film *film = sensor->film().get();
     auto cs = film->crop_size(); auto co = film->crop_offset();
@@ -114,9 +123,82 @@ void SamplingIntegrator::make_render_cfg(const PerspectiveCamera *sensor, mi_ren
     cfg.plan = m_plan;
 }
 
+// One pass of a frame over the N contexts of a multi-GPU scene (Scene::build(devices)) — SURVEY.md section 8(e) inside one
+// process: context r renders tile shard (m_rank * N + r) of (m_world * N) (the spiral blocks with id % world == rank, all spp of
+// their pixels, global block-id -> seed table: the film does not depend on N) on its own host thread into a film on its own
+// device; mi_film_reduce sums the N films onto context 0's (RCCL over xGMI between distinct GPUs, a rank-ordered device add when
+// contexts share a GPU); the root's film comes down once. Passes after the first are added to `film5` on the host (the reference
+// accumulates them in the film the same way, integrator.cpp:100-131; with several GPUs the per-pass partial sums exist only after
+// the reduce). Counters: work summed over the contexts, times = the slowest context's.
+bool SamplingIntegrator::render_pass_multi(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass, uint32_t pass) {
+    const size_t n = scene->device_count();
+    struct Rank { mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles; void *film = nullptr; mi_status st = MI_OK; std::string err; mi_counters cnt{}; };
+    std::vector<Rank> ranks(n);
+    uint64_t count = 0;
+    auto release = [&]() { for (size_t r = 0; r < n; ++r) if (ranks[r].film) { mi_film_free(scene->ctx(r), ranks[r].film); ranks[r].film = nullptr; } };
+    for (size_t r = 0; r < n; ++r) {
+        Rank &k = ranks[r];
+        make_render_cfg(sensor, k.cfg, k.block_ids, k.tiles, 1, pass, m_rank * (uint32_t) n + (uint32_t) r, m_world * (uint32_t) n);
+        k.cfg.moment_pass = moment_pass; k.cfg.film_on_device = 1; k.cfg.film_f64 = 0; k.cfg.accumulate = 0;
+        count = (uint64_t) k.cfg.crop_w * k.cfg.crop_h * 5;
+        if (mi_film_alloc(scene->ctx(r), count, &k.film) != MI_OK) { const std::string e = mi_last_error(scene->ctx(r)); release(); Throw("mi_film_alloc: " + e); }
+    }
+    { std::lock_guard<std::mutex> lock(m_active_mutex); for (size_t r = 0; r < n; ++r) m_active_multi.push_back(scene->ctx(r)); }
+    std::vector<std::thread> pool;
+    for (size_t r = 0; r < n; ++r)
+        pool.emplace_back([&, r]() {
+            Rank &k = ranks[r];
+            k.st = mi_render(scene->ctx(r), &k.cfg, k.film);
+            if (k.st != MI_OK && k.st != MI_ERR_CANCELLED) k.err = mi_last_error(scene->ctx(r));
+            mi_get_counters(scene->ctx(r), &k.cnt);
+        });
+    for (auto &t : pool) t.join();
+    { std::lock_guard<std::mutex> lock(m_active_mutex); m_active_multi.clear(); }
+    bool cancelled = false;
+    for (size_t r = 0; r < n; ++r) {
+        if (ranks[r].st == MI_ERR_CANCELLED) cancelled = true;
+        else if (ranks[r].st != MI_OK) { const std::string e = ranks[r].err; release(); Throw("mi_render (context " + std::to_string(r) + "): " + e); }
+    }
+    std::vector<mi_ctx *> ctxs(n); std::vector<void *> films(n);
+    for (size_t r = 0; r < n; ++r) { ctxs[r] = scene->ctx(r); films[r] = ranks[r].film; }
+    int32_t how = MI_REDUCE_NONE;
+    if (mi_film_reduce(ctxs.data(), films.data(), (int32_t) n, count, 0, &how) != MI_OK) { const std::string e = mi_last_error(ctxs[0]); release(); Throw("mi_film_reduce: " + e); }
+    m_last_reduce = how;
+    if (pass == 0) {
+        if (mi_film_download(ctxs[0], films[0], film5, count) != MI_OK) { const std::string e = mi_last_error(ctxs[0]); release(); Throw("mi_film_download: " + e); }
+    } else {
+        std::vector<float> tmp(count);
+        if (mi_film_download(ctxs[0], films[0], tmp.data(), count) != MI_OK) { const std::string e = mi_last_error(ctxs[0]); release(); Throw("mi_film_download: " + e); }
+        for (uint64_t i = 0; i < count; ++i) film5[i] += tmp[i];
+    }
+    release();
+    m_counters = ranks[0].cnt;
+    for (size_t r = 1; r < n; ++r) {
+        const mi_counters &c = ranks[r].cnt;
+        m_counters.samples += c.samples; m_counters.segments += c.segments; m_counters.shadow_rays += c.shadow_rays;
+        m_counters.iterations += c.iterations; m_counters.lanes += c.lanes;
+        m_counters.ms_render = std::max(m_counters.ms_render, c.ms_render); m_counters.ms_path = std::max(m_counters.ms_path, c.ms_path);
+        m_counters.ms_resolve = std::max(m_counters.ms_resolve, c.ms_resolve);
+    }
+    return !cancelled;
+}
+
 bool SamplingIntegrator::render_passes(Scene *scene, PerspectiveCamera *sensor, float *film5, int moment_pass) {
     const uint32_t passes = pass_count(sensor);
     mi_counters total{};
+    if (scene->device_count() > 1) {                            // a multi-GPU scene: every pass sharded over its contexts
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const bool done = render_pass_multi(scene, sensor, film5, moment_pass, pass);
+            if (pass > 0) {
+                m_counters.samples += total.samples; m_counters.segments += total.segments; m_counters.shadow_rays += total.shadow_rays;
+                m_counters.iterations += total.iterations; m_counters.ms_render += total.ms_render;
+            }
+            total = m_counters;
+            if (!done) return false;
+        }
+        return true;
+    }
+    m_last_reduce = MI_REDUCE_NONE;
     for (uint32_t pass = 0; pass < passes; ++pass) {
         mi_render_cfg cfg; std::vector<uint32_t> block_ids, tiles;
         make_render_cfg(sensor, cfg, block_ids, tiles, 1, pass);

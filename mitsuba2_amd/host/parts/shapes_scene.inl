@@ -290,6 +290,7 @@ Scene::Scene() {}
 Scene::~Scene() {
     // the emitters go back to "part of no scene" (they may outlive it: shared_ptr), so that another scene can take them
     for (const Emitter *e : m_emitter_objs) if (e->m_scene == this) { Emitter *w = const_cast<Emitter *>(e); w->m_scene = nullptr; w->m_index = -1; }
+    for (mi_ctx *c : m_replicas) mi_destroy(c);
     if (m_ctx) mi_destroy(m_ctx);
 }
 std::array<float, 6> Scene::bbox() const {
@@ -509,6 +510,29 @@ void Scene::build(int device, int bvh_quality) {
     }
     if (mi_scene_upload(m_ctx, &m_desc) != MI_OK) Throw(std::string("mi_scene_upload: ") + mi_last_error(m_ctx));
     if (mi_bvh_build(m_ctx, bvh_quality) != MI_OK) Throw(std::string("mi_bvh_build: ") + mi_last_error(m_ctx));
+}
+void Scene::build(const std::vector<int> &devices, int bvh_quality) {
+    if (devices.empty()) Throw("Scene::build: empty device list");
+    for (int d : devices) if (d < 0) Throw("Scene::build: a multi-GPU build needs device indices >= 0");
+    for (mi_ctx *c : m_replicas) mi_destroy(c);                // a rebuild starts from the primary alone
+    m_replicas.clear();
+    build(devices[0], bvh_quality);                            // flatten + the primary context
+    // the replicas: created here (mi_create is cheap), uploaded and built each on its own thread — the contexts share nothing
+    std::vector<std::string> errors(devices.size());
+    for (size_t i = 1; i < devices.size(); ++i) {
+        mi_ctx *c = nullptr;
+        if (mi_create(devices[i], &c) != MI_OK) Throw(std::string("mi_create failed: ") + mi_last_error(nullptr));
+        m_replicas.push_back(c);
+    }
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < devices.size(); ++i)
+        pool.emplace_back([this, i, bvh_quality, &errors]() {
+            mi_ctx *c = m_replicas[i - 1];
+            if (mi_scene_upload(c, &m_desc) != MI_OK) { errors[i] = std::string("mi_scene_upload: ") + mi_last_error(c); return; }
+            if (mi_bvh_build(c, bvh_quality) != MI_OK) errors[i] = std::string("mi_bvh_build: ") + mi_last_error(c);
+        });
+    for (auto &t : pool) t.join();
+    for (const std::string &e : errors) if (!e.empty()) Throw(e);
 }
 void Scene::ray_intersect_preliminary(const mi_rays_soa &rays, const mi_hits_soa &hits, uint64_t n) const {
     if (!m_ctx) Throw("Scene: not built on a device");

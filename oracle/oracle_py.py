@@ -161,13 +161,14 @@ class Oracle:
         out["bvh4"] = dict(zip(("nodes2", "nodes4", "depth", "stack_bound", "stack_seen", "ok"), list(stats)))
         return out
 
-    def emu_trace8(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, max_fan=8, schedule=0, compare4=False):
+    def emu_trace8(self, desc, o, d, mint=0.0, maxt=np.inf, any_hit=False, max_leaf=4, max_fan=8, schedule=0, compare4=False, spec=False):
         """The 8-wide quantised tree (csrc/miw/bvh8.h, collapsed by csrc/bvh8_build.h, triangles in the tree's own order) walked on
         the CPU: by the reference walk bvh8_intersect (schedule = 0) or by the per-lane bodies of the device's phase machine
         (walk8_node_step / walk8_tri_step; schedule > 0), every stack-column access checked. out["bvh8"]: node / depth / step
         counts (+ the 4-wide reference walk's counts over the same rays with compare4)."""
         stats = (C.c_uint32 * 15)()
-        out = self._trace(self.L.emu_trace8, desc, o, d, mint, maxt, any_hit, max_leaf, max_fan, stats, int(schedule), int(bool(compare4)))
+        sched = (int(schedule) & 0x7fffffff) | (0x80000000 if spec and schedule else 0)
+        out = self._trace(self.L.emu_trace8, desc, o, d, mint, maxt, any_hit, max_leaf, max_fan, stats, sched, int(bool(compare4)))
         st = list(stats)
         out["bvh8"] = dict(nodes2=st[0], nodes8=st[1], depth=st[2], stack_seen=st[3], ok=st[4], node_steps=st[5] | st[6] << 32,
                            tri_tests=st[7] | st[8] << 32, tri_steps=st[9] | st[10] << 32, node_steps4=st[11] | st[12] << 32,

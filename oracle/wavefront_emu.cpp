@@ -210,9 +210,9 @@ struct EmuColumn8 {
         return p[i];
     }
 };
-template <typename TriAt>
+template <bool Spec = false, typename TriAt>
 bool emu_walk8(const Bvh8Node *nodes8, TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best,
-               int32_t cap, bool *bad, uint32_t *deepest, uint64_t *steps) {
+               int32_t cap, bool *bad, uint32_t *deepest, uint64_t *steps, EmuCoin *coin = nullptr) {
     const SlabRay r = slab_ray_host(o, d, mint);
     U2 column[MIW_BVH8_STACK + 1];
     const EmuColumn8 stack{ column, cap, bad, deepest };
@@ -221,12 +221,13 @@ bool emu_walk8(const Bvh8Node *nodes8, TriAt tri_at, const PrimCtx &ctx, V3 o, V
     bool occluded = false;
     if (!any_hit) { best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu; }
     while (!walk8_over(w)) {
-        if (walk8_node_ready(w)) {
+        // (Spec: a lane may be ready for both bodies — the coin decides, so every interleaving the wave votes can produce is reachable)
+        if (walk8_node_ready<Spec>(w) && (!walk8_tri_ready(w) || !coin || (*coin)())) {
             const Bvh8Node &n = nodes8[walk8_next_node(w)];
-            walk8_node_step(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), w, stack);
+            walk8_node_step<Spec>(n, r, __builtin_fmaf(abs_(tmax), 2e-6f, tmax), w, stack);
             if (steps) steps[0]++;
         } else if (walk8_tri_ready(w)) {
-            walk8_tri_step<true>(tri_at, ctx, o, d, mint, maxt, any_hit, best, tmax, occluded, w);
+            walk8_tri_step<true, Spec>(tri_at, ctx, o, d, mint, maxt, any_hit, best, tmax, occluded, w);
             if (steps) steps[2]++;
         } else { *bad = true; break; }                          // neither over nor ready: a state the bodies must not produce
     }
@@ -332,7 +333,8 @@ int emu_trace4(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
 // the 8-wide quantised tree of miw/bvh8.h (collapsed from the same SAH build; triangles in the tree's own order) over caller rays.
 // stats8: BVH2 nodes, BVH8 nodes, BVH8 depth, deepest stack any ray reached, ok flag, then as 64-bit pairs (lo, hi): node steps,
 // triangles handed to the triangle test, triangle-pair steps (schedule > 0 only).
-// schedule: 0 = bvh8_intersect (the reference walk); > 0 = the phase machine's bodies (emu_walk8), every column access checked (2 = a stray access).
+// schedule: 0 = bvh8_intersect (the reference walk); > 0 = the phase machine's bodies (emu_walk8), every column access checked (2 = a stray
+// access); bit 31 set = the speculating variant (MIW_W8_SPEC: a second pending triangle group) under a pseudo-random body schedule.
 // compare4 != 0: the 4-wide reference walk runs over the same rays as well and its node / triangle counts go to stats8[11..14].
 int emu_trace8(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_soa *h, uint64_t n, int any_hit, int max_leaf,
                int max_fan, uint32_t *stats8, uint32_t schedule, int compare4) {
@@ -355,7 +357,9 @@ int emu_trace8(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
         Hit hit; bool ok;
         if (schedule) {
             hit.t = MIW_INFINITY; hit.u = hit.v = 0.f; hit.tri = MIW_MISS; hit.prim = 0xffffffffu;
-            ok = emu_walk8(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps);
+            EmuCoin coin{ schedule | 1u };
+            ok = (schedule & 0x80000000u) ? emu_walk8<true>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps, &coin)
+                                          : emu_walk8<false>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps);
             if (any_hit && ok) { hit.t = 0.f; hit.tri = 0; hit.prim = 0; }
         }
         else if (any_hit) ok = bvh8_intersect<true>(b8.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen, steps);

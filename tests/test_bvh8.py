@@ -69,6 +69,22 @@ def test_bvh8_ties_and_degenerate_boxes(native, oracle):
                 assert _same(brute, oracle.emu_trace8(desc, o, d, 0.0, np.inf, any_hit=any_hit, max_leaf=max_leaf, schedule=schedule), any_hit)
 
 
+def test_bvh8_speculating_bodies_under_random_schedules(native, oracle):
+    """The speculating variant of the two bodies (MIW_W8_SPEC: a lane holding an untested triangle group keeps descending, the next
+    node's triangles wait in a second group): whenever a lane could take either body a coin decides — brute force's answers
+    under every schedule tried, no access outside the column."""
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(32, 32, 1, diffuse_only=False, ball_level=3, device=-1)
+    desc = scene.desc()
+    o, d = _rays(desc, 2500, 11)
+    for any_hit in (False, True):
+        for mint, maxt in ((1e-4, np.inf), (0.0, 150.0)):
+            brute = oracle.trace(desc, o, d, mint, maxt, any_hit=any_hit)
+            for max_leaf, schedule in ((4, 1), (4, 77), (1, 5), (2, 9)):
+                w = oracle.emu_trace8(desc, o, d, mint, maxt, any_hit=any_hit, max_leaf=max_leaf, schedule=schedule, spec=True)
+                assert w["bvh8"]["stack_seen"] <= w["bvh8"]["depth"] and _same(brute, w, any_hit)
+
+
 def test_bvh8_refuses_leaves_it_cannot_name(native, oracle):
     """A leaf slot names its run in one byte (count <= 4): a BVH2 built with larger leaves is refused (the device then keeps
     the 4-wide tree)."""

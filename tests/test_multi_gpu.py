@@ -1,0 +1,81 @@
+"""One frame over several GPUs from ONE process (the reference's contract is one call, one process:
+include/mitsuba/render/integrator.h:42): Scene::build(devices) puts the scene on N contexts, SamplingIntegrator::render shards the
+spiral blocks over them (one host thread per context, the global block-id -> seed table) and closes the frame with mi_film_reduce —
+RCCL between distinct GPUs, a rank-ordered device add when contexts share a GPU (which is what a one-GPU box can run).
+
+CPU tier: the shard bookkeeping (context r of N under an outer shard (rank, world) renders shard (rank * N + r, world * N): every
+block exactly once) and the loud failure without a device. GPU tier: three contexts on device 0 against the rank-ordered float32
+sum of the three shard films (bit for bit) and against the one-context film (equal wherever one block covers a texel).
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+
+def test_contexts_of_a_multi_gpu_frame_partition_the_blocks(native):
+    from mitsuba2_amd import scenes
+    _, sensor = scenes.cornell_box(200, 120, 2, device=-1)
+    one = native.PathIntegrator().render_job(sensor)
+    n_blocks = int(one.cfg.block_count)
+    for world, n in ((1, 3), (2, 4), (1, 8)):
+        seen = []
+        for rank in range(world):
+            for r in range(n):
+                integ = native.PathIntegrator(); integ.set_shard(rank * n + r, world * n)
+                job = integ.render_job(sensor)
+                tiles = [int(job.cfg.tile_list[i]) for i in range(int(job.cfg.tile_count))]
+                ids = sorted(int(job.cfg.block_ids[t]) for t in tiles)
+                assert ids == list(range(rank * n + r, n_blocks, world * n))      # interleaved over the spiral order, same ids as the 1-GPU job
+                seen += tiles
+        assert sorted(seen) == list(range(n_blocks))
+
+
+@pytest.mark.skipif(has_gpu(), reason="the no-device behaviour")
+def test_multi_gpu_build_without_a_device_fails_loudly(native):
+    from mitsuba2_amd import scenes
+    scene, _ = scenes.cornell_box(32, 32, 1, device=-1)
+    assert scene.device_count() == 0
+    with pytest.raises(RuntimeError):
+        scene.build([0, 0])
+    with pytest.raises(RuntimeError):
+        scene.build([])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("tree", [False, True])
+def test_one_process_frame_over_three_contexts(native, oracle, tree):
+    from mitsuba2_amd import scenes
+    W, H, SPP, N = 160, 96, 8, 3
+    scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=not tree, ball_level=3, device=-1)
+    # the one-context film and the three shard films, each rendered alone
+    dev = native.Device(0)
+    try:
+        dev.upload(scene.desc())
+        full, st = dev.render(native.PathIntegrator().render_job(sensor))
+        assert st == 0
+        total = dev.counters()
+        parts = []
+        for r in range(N):
+            integ = native.PathIntegrator(); integ.set_shard(r, N)
+            p, st = dev.render(integ.render_job(sensor))
+            assert st == 0
+            parts.append(p.astype(np.float32))
+    finally:
+        dev.close()
+    want = (parts[0] + parts[1]) + parts[2]                       # what the device add computes: onto the root's film, in rank order
+    scene.build([0] * N)
+    assert scene.device_count() == N
+    integ = native.PathIntegrator()
+    assert integ.render(scene, sensor) is True
+    film = sensor.film.data((H, W, 5))
+    assert integ.last_reduce() == 1                                # contexts share the GPU: MI_REDUCE_DEVICE_ADD
+    c = integ.counters()
+    assert (c.samples, c.segments, c.shadow_rays) == (total.samples, total.segments, total.shadow_rays)
+    assert np.array_equal(film, want)
+    same = film == full                                            # texels under one block: exact; block borders: association of <= 4 partials
+    assert same.mean() > 0.7 and np.abs(film - full).max() <= 4e-6 * np.abs(full).max()
+    o32, _, ost = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=8, want_f64=False)
+    assert ost.samples == c.samples and ost.segments == c.segments
+    assert np.array_equal(full, o32)

@@ -55,6 +55,7 @@ def main():
                     old = {k: os.environ.get(k) for k in kv}
                     os.environ.update(kv)
                     try:
+                        print("[ab] %s | %s | rep %d" % (name, v or "(defaults)", rep), file=sys.stderr, flush=True)
                         torch.cuda.synchronize(); t0 = time.perf_counter()
                         dev.check(dev.L.mi_render(dev.ctx, C.byref(cfg), C.c_void_p(film.data_ptr())))
                         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
