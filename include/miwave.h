@@ -134,7 +134,9 @@ typedef struct {          /* environment map, src/emitters/envmap.cpp (one per s
                                               library REQUIRES it: there `rgba` holds what the reference's constructor stores
                                               instead of colours — per texel the three coefficients of the sRGB upsampling model
                                               of rgb / max(1e-8, scale) and scale = 2 * hmax(rgb) (envmap.cpp:101-110) — from
-                                              which the luminance cannot be recovered. NULL in scalar_rgb: computed from `rgba` */
+                                              which the luminance cannot be recovered. scalar_rgb: IGNORED (computed from `rgba`;
+                                              the member was appended in round 4 — the struct grew by one pointer: callers built
+                                              against the older header must be recompiled for the scalar_spectral library only) */
 } mi_envmap;
 
 /* Rectangle(props): [-1, 1]^2 in the z = 0 plane of object space, normal +z, placed by to_world

@@ -31,6 +31,40 @@
 enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
 
 // a lane's stack: its column of the workgroup's entry-major LDS array (slot i of lane l at i * MIW_BLOCK + l: conflict-free)
+// The triangle records in global memory as the walk bodies read them: 48 bytes = three 16-byte loads through an explicitly global
+// pointer. tri_fetch2 (miw/bvh4.h: the two records of a triangle step) issues all six loads before it waits — inline assembly, as
+// the compiler orders two plain reads "first record, wait, second record" to save registers (one more round trip per triangle
+// step). vmcnt counts in issue order, so loads the compiler has in flight around these only make the wait longer, never shorter.
+typedef uint32_t miw_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) miw_u4 *GlobalU4;
+struct GlobalTris {
+    GlobalU4 p;
+    __device__ __forceinline__ Tri operator()(uint32_t i) const {
+        GlobalU4 a = p + 3 * (size_t) i;
+        miw_u4 q[3] = { a[0], a[1], a[2] };
+        Tri t; __builtin_memcpy(&t, q, sizeof t); return t;
+    }
+};
+#ifndef MIW_TRI_FETCH2_ASM
+#define MIW_TRI_FETCH2_ASM 1
+#endif
+__device__ __forceinline__ void tri_fetch2(const GlobalTris &g, uint32_t a, uint32_t b, Tri &ta, Tri &tb) {
+#if MIW_TRI_FETCH2_ASM && defined(__HIP_DEVICE_COMPILE__)
+    GlobalU4 pa = g.p + 3 * (size_t) a, pb = g.p + 3 * (size_t) b;
+    miw_u4 q[6];
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[0]) : "v"(pa));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[1]) : "v"(pa));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(q[2]) : "v"(pa));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[3]) : "v"(pb));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[4]) : "v"(pb));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(q[5]) : "v"(pb));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+    __builtin_memcpy(&ta, &q[0], sizeof ta); __builtin_memcpy(&tb, &q[3], sizeof tb);
+#else
+    ta = g(a); tb = g(b);
+#endif
+}
+
 struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
 // the 8-wide walk's column: MIW_BVH8_STACK node groups of 8 bytes (ds_write_b64 / ds_read_b64; the same 128 bytes per lane)
 struct LdsColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
@@ -80,8 +114,6 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     // path of every node step. Made opaque here they are values it has to KEEP: in SGPRs or, spilled, in a VGPR lane (v_readlane:
     // a couple of cycles instead of a scalar-cache round trip). An opaque pointer is a generic one, so the records are read
     // through explicitly global pointers to 16-byte vectors (global_load_dwordx4, as before) and handed on by value.
-    typedef uint32_t miw_u4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) miw_u4 *GlobalU4;
     GlobalU4 nodes4_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes4), tris_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.tris);
     GlobalU4 nodes8_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes8);
     if (Wide == 2) asm volatile("" : "+s"(nodes8_g)); else asm volatile("" : "+s"(nodes4_g));
@@ -96,11 +128,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         miw_u4 q[5] = { p[0], p[1], p[2], p[3], p[4] };
         Bvh8Node n; __builtin_memcpy(&n, q, sizeof n); return n;
     };
-    auto tri_at_g = [tris_g](uint32_t i) -> Tri {
-        GlobalU4 p = tris_g + 3 * (size_t) i;
-        miw_u4 q[3] = { p[0], p[1], p[2] };
-        Tri t; __builtin_memcpy(&t, q, sizeof t); return t;
-    };
+    const GlobalTris tri_at_g{ tris_g };
 #else
     auto node4_at = [nodes4](int32_t i) -> const Bvh4Node & { return nodes4[i]; };
     const Bvh8Node *nodes8 = sc.nodes8;

@@ -114,6 +114,15 @@ inline EnvmapTables envmap_build_from_density(const mi_envmap &e, const float *d
     return t;
 }
 
-inline EnvmapTables envmap_build(const mi_envmap &e) { return envmap_build_from_density(e, e.density); }
+// mi_envmap::density is the scalar_spectral library's input (there the texels are coefficients: include/miwave.h). The scalar_rgb
+// library computes the array from `rgba` and does NOT read the field: a C caller compiled against the round-3 header (no such
+// member) or with an uninitialised struct hands over whatever lies behind bsphere_radius / emitter_index.
+inline EnvmapTables envmap_build(const mi_envmap &e) {
+#if MIW_SPECTRAL
+    return envmap_build_from_density(e, e.density);
+#else
+    return envmap_build_from_density(e, nullptr);
+#endif
+}
 
 } // namespace miw

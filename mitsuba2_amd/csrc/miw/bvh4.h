@@ -136,12 +136,17 @@ MIW_HD void walk4_node_step(const Bvh4Node &n, const Ray &r, float tmax_wide, in
 // address is clamped into the range, its test predicated), so a multi-triangle leaf costs one round trip per pair; the tests run
 // in range order, which is all the closest-hit / any-hit rules ask for. An any-hit walk ends at its first hit (`occluded`); a
 // drained range takes over the leaf the stack handed to `cur`, if any.
+// the two records of a triangle step. (The device's accessor over global memory has its own overload, device/phased_kernel.h:
+// written as two plain reads the compiler — minimising live registers — issues the second record's loads only after it has
+// waited for the first's, one more round trip per step, round-5 ISA reading; the overload issues all six loads, then waits once.)
+template <typename TriAt> MIW_HD void tri_fetch2(TriAt tri_at, uint32_t a, uint32_t b, Tri &ta, Tri &tb) { ta = tri_at(a); tb = tri_at(b); }
+
 template <bool Analytic, typename TriAt, typename Stack>
 MIW_HD void walk4_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float mint, float maxt, bool any_hit, Hit &best, float &tmax,
                            bool &occluded, int32_t &cur, int32_t &sp, uint32_t &tri_i, uint32_t &tri_end, Stack stack) {
     const bool two = tri_i + 1u < tri_end;
-    const Tri &tr = tri_at(tri_i);
-    const Tri &tr2 = tri_at(two ? tri_i + 1u : tri_i);
+    Tri tr, tr2;
+    tri_fetch2(tri_at, tri_i, two ? tri_i + 1u : tri_i, tr, tr2);
     float t, u, v, t2, u2, v2;
     const bool hit1 = prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v);
     const bool hit2 = prim_intersect<Analytic>(tr2, ctx, o, d, mint, maxt, t2, u2, v2) && two;

@@ -167,8 +167,8 @@ MIW_HD void walk8_tri_step(TriAt tri_at, const PrimCtx &ctx, V3 o, V3 d, float m
     const uint32_t i2 = two ? bvh8_ctz(rest) : i1;
     rest = rest & (rest - 1u);                                        // (0 & anything = 0 when there was no second one)
     const uint32_t a1 = w.tb + i1, a2 = w.tb + i2;
-    const Tri &tr = tri_at(a1);
-    const Tri &tr2 = tri_at(a2);
+    Tri tr, tr2;
+    tri_fetch2(tri_at, a1, a2, tr, tr2);                              // (miw/bvh4.h; the device's accessor issues the six loads together)
     float t, u, v, t2, u2, v2;
     const bool hit1 = prim_intersect<Analytic>(tr, ctx, o, d, mint, maxt, t, u, v);
     const bool hit2 = prim_intersect<Analytic>(tr2, ctx, o, d, mint, maxt, t2, u2, v2) && two;

@@ -528,6 +528,8 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 // dwords of the tables stage_tables() copies into LDS (shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf), each
 // padded to 16 bytes; returns the bytes of the block
 #define MIW_LDS_PER_WORKGROUP (40u * 1024u)       /* 160 KB per CU / four workgroups of 256 (four wavefronts per SIMD) */
+#define MIW_LDS_STATIC 0u                         /* static __shared__ of k_path_phased: s_prog, 16 bytes — inside the granule below */
+#define MIW_LDS_GRANULE 512u                      /* LDS is handed out in granules: dynamic + static, rounded up, must stay inside 40 KB */
 static size_t lds_table_bytes(const mi_ctx *c, uint32_t words[10], bool with_tris) {
     words[0] = (uint32_t) (c->shapes.size() * sizeof(ShapeRec) / 4); words[1] = (uint32_t) (c->bsdfs.size() * sizeof(BsdfRec) / 4);
     words[2] = (uint32_t) (c->emitters.size() * sizeof(EmitterRec) / 4);
@@ -590,13 +592,16 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // tree on the interior / the material balls: A/B runs). A scene the sweep hands back (need_host: coincident centroids) takes
         // the host builder, like quality 1.
         enum { DEV_SAH = 0, DEV_LBVH = 1 } dev_builder = (quality_flags & MI_BVH_RADIX_TREE) ? DEV_LBVH : DEV_SAH;
-        if (const char *e = getenv("MIW_DEVICE_BUILDER")) dev_builder = !strcmp(e, "lbvh") ? DEV_LBVH : DEV_SAH;
+        if (const char *e = getenv("MIW_DEVICE_BUILDER")) {        // only the two names override the flag; anything else leaves the caller's choice alone
+            if (!strcmp(e, "lbvh")) dev_builder = DEV_LBVH; else if (!strcmp(e, "sah")) dev_builder = DEV_SAH;
+        }
         bool sah_need_host = false;
         if (dev_builder == DEV_SAH) {
             const uint32_t un = (uint32_t) n, max_leaf = 4u;              // (bvh_build_sah's default leaf size: the same tree)
             const float pad = 2.f * pad_unit;
             TmpBuf<SahPrim> d_prim; TmpBuf<uint32_t> d_ia, d_ib, d_flags, d_rank; TmpBuf<SahCand> d_ca, d_cb; TmpBuf<SahDecision> d_dec; TmpBuf<SahState> d_state;
-            TmpBuf<unsigned char> d_scan_tmp;
+            TmpBuf<unsigned char> d_scan_tmp; TmpBuf<SahHuge> d_huge;
+            HIP_TRY(c, d_huge.resize(MIW_SAH_HUGE_CANDS));
             HIP_TRY(c, d_prim.resize(un)); HIP_TRY(c, d_ia.resize(un)); HIP_TRY(c, d_ib.resize(un)); HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_rank.resize(un));
             HIP_TRY(c, d_ca.resize(un)); HIP_TRY(c, d_cb.resize(un)); HIP_TRY(c, d_dec.resize(un)); HIP_TRY(c, d_state.resize(1));
             size_t scan_bytes = 0;
@@ -611,6 +616,8 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             std::vector<uint32_t> level_start{ 0u };
             uint32_t n_cand = 1u, base = 0u, level = 0u;
             bool big_left = true;                                        // candidates of more than MIW_SAH_BIG triangles in the current level
+            uint32_t level_max = un;                                     // the largest candidate of the current level (0: none above MIW_SAH_BIG)
+            const bool huge_on = !(getenv("MIW_SAH_HUGE") && atoi(getenv("MIW_SAH_HUGE")) == 0);     // MIW_SAH_HUGE=0: one workgroup per candidate, as round 4 (A/B runs)
             while (n_cand > 0u && !sah_need_host) {
                 const SahCand *cur = (level & 1u) ? d_cb.p : d_ca.p; SahCand *nxt = (level & 1u) ? d_ca.p : d_cb.p;
                 const uint32_t *ic = (level & 1u) ? d_ib.p : d_ia.p; uint32_t *in = (level & 1u) ? d_ia.p : d_ib.p;
@@ -620,18 +627,28 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 // whether the level holds any.
                 const bool all_big = n_cand <= 512u;
                 const uint32_t none = 0u, all = 0xffffffffu;
-                if (all_big || big_left) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, all_big ? none : MIW_SAH_BIG, all);
+                // candidates above MIW_SAH_HUGE triangles: sliced over several workgroups (sah_device.h: k_sah_huge_*), the others as before
+                const bool huge = huge_on && level_max > MIW_SAH_HUGE && n_cand <= MIW_SAH_HUGE_CANDS;
+                if (huge) {
+                    const dim3 hgrid(n_cand, (level_max + MIW_SAH_SLICE - 1u) / MIW_SAH_SLICE);
+                    const uint32_t words = n_cand * (uint32_t) (sizeof(SahHuge) / 4u);
+                    hipLaunchKernelGGL(k_sah_huge_init, dim3((words + 255u) / 256u), dim3(256), 0, s, d_huge.p, n_cand);
+                    hipLaunchKernelGGL(k_sah_huge_box, hgrid, dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, d_huge.p);
+                    hipLaunchKernelGGL(k_sah_huge_bins, hgrid, dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, d_huge.p);
+                    hipLaunchKernelGGL(k_sah_huge_finish, dim3(n_cand), dim3(64), 0, s, cur, n_cand, level, max_leaf, d_huge.p, d_dec.p, d_flags.p, d_state.p);
+                }
+                if (all_big || big_left) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, all_big ? none : MIW_SAH_BIG, huge ? MIW_SAH_HUGE : all);
                 if (!all_big) hipLaunchKernelGGL(k_sah_decide<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, none, big_left ? MIW_SAH_BIG : all);
                 HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_rank.p, (int) n_cand, s));
                 hipLaunchKernelGGL(k_sah_totals, dim3(1), dim3(1), 0, s, d_flags.p, d_rank.p, n_cand, d_state.p);
-                if (all_big || big_left) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, all_big ? none : MIW_SAH_BIG, all);
-                if (!all_big) hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, none, big_left ? MIW_SAH_BIG : all);
+                if (all_big || big_left) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, all_big ? none : MIW_SAH_BIG, all, un);
+                if (!all_big) hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, none, big_left ? MIW_SAH_BIG : all, un);
                 SahState h;
                 HIP_TRY(c, hipMemcpyAsync(&h, d_state.p, sizeof h, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 HIP_TRY(c, hipGetLastError());
                 sah_need_host = h.need_host != 0u || level >= 62u || (uint64_t) base + h.n_inner > (uint64_t) un - 1u;
-                big_left = h.max_count > MIW_SAH_BIG;
+                big_left = h.max_count > MIW_SAH_BIG; level_max = h.max_count;
                 if (big_left) HIP_TRY(c, hipMemsetAsync(&d_state.p->max_count, 0, sizeof(uint32_t), s));     // (counts the next level afresh)
                 depth = level;
                 base += h.n_inner; level_start.push_back(base);
@@ -1167,14 +1184,17 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     size_t table_bytes = lds_table_bytes(c, rcfg.tab_words, c->lds_cfg.brute != 0);
     // (packet scenes always stage: mi_bvh_build bounded their tables by 24 KB, which with the packets, boxes and thresholds stays
     // inside the 64 KB a workgroup may ask for — at fewer workgroups per CU past 40 KB)
-    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : MIW_LDS_PER_WORKGROUP);
+    // (a tree scene keeps four workgroups per CU only if its dynamic LDS + the phase machine's static words (s_prog, section buffer:
+    // MIW_LDS_STATIC) + one allocation granule stay inside 40 KB)
+    const size_t lds_budget = MIW_LDS_PER_WORKGROUP - MIW_LDS_STATIC - MIW_LDS_GRANULE;
+    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : lds_budget);
     rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0;
     if (tables_fit && c->have_env) {
         // ... and as many of the environment warp's smallest levels as fit what is left (at most 4 KB): levels are stored from the
         // largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
         const EnvmapRec &e = c->env_host;
         const size_t used = (size_t) rcfg.tab16 * 16 + table_bytes;
-        const size_t room = used < MIW_LDS_PER_WORKGROUP ? std::min<size_t>(4096, MIW_LDS_PER_WORKGROUP - used) : 0;
+        const size_t room = used < lds_budget ? std::min<size_t>(4096, lds_budget - used) : 0;
         uint32_t count = 0;
         while (count + 1 < e.n_levels && ((size_t) c->env_levels_total - e.level_offset[e.n_levels - 1 - count]) * 4 <= room) ++count;
         if (count) {
@@ -1184,7 +1204,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
     }
     if (getenv("MIW_ENV_TOP") && atoi(getenv("MIW_ENV_TOP")) == 0) { table_bytes -= ((size_t) rcfg.env_top_words + 3) / 4 * 16; rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0; }
+    // (only the kernels that call stage_tables ask for those bytes: the phase machine and the packet kernels — `rlds`; the lock-step
+    // tree kernels, which read the tables from global memory, launch with `rlds_plain`: ADVICE r04)
+    const size_t rlds_plain = rlds;
     if (tables_fit) rlds = (size_t) rcfg.tab16 * 16 + table_bytes;
+    if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu\n",
+                                     rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget);
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -1386,7 +1411,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 unsigned wg_per_cu = 4u;
                 if (const char *e = getenv("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * wg_per_cu));
-#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
+#define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, (T) != 0 ? rlds : rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
                 // (`phased`, `trio_kernel`, `ph_waves`: decided above the loop; MIW_BVH4=0 keeps the BVH2 node body for the MATS_TRIO class: A/B runs)
@@ -1436,7 +1461,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #undef MIW_PHASED_LAUNCH
 #undef MIW_PHASED_LAUNCH_
                 else if (direct) {
-#define MIW_DIRECT_LAUNCH(T, M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, A, INTEG_DIRECT>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
+#define MIW_DIRECT_LAUNCH(T, M, A) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, A, INTEG_DIRECT>), pgrid, block, (T) != 0 ? rlds : rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                     if (tiny && c->textured) MIW_DIRECT_LAUNCH(1, MATS_ALL, false);
                     else if (tiny) MIW_DIRECT_LAUNCH(1, MATS_PLAIN, false);
                     else if (c->textured) MIW_DIRECT_LAUNCH(0, MATS_ALL, true);
@@ -1446,11 +1471,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 else if (tiny && c->diffuse_only && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_DIFFUSE);   // 32-bit candidate masks (BASELINE config 2: 32 triangles)
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in
-                else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+                else if (!tiny && c->textured) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_ALL, true>), pgrid, block, rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 else if (tiny && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_PLAIN);
                 else if (tiny) MIW_PATH_LAUNCH(1, MATS_PLAIN);
                 else if (c->rects.empty()) MIW_PATH_LAUNCH(0, MATS_PLAIN);
-                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_PLAIN, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+                else MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 0, MATS_PLAIN, true>), pgrid, block, rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
 #undef MIW_PATH_LAUNCH
             } else if (direct && tiny)
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1, MATS_ALL, false, INTEG_DIRECT>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));

@@ -377,7 +377,9 @@ def test_gloo_world_size_2_sharded_render(native, oracle, tmp_path, world):
     out = str(tmp_path / "film.npy")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % dict(root=ROOT, out=out))
-    port = str(29533 + world)
+    import socket
+    with socket.socket() as so:                                  # a free port, as bench.spawn_command picks one (a fixed one collides with a parallel run)
+        so.bind(("127.0.0.1", 0)); port = str(so.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
                         "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)

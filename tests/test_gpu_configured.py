@@ -93,8 +93,7 @@ def test_c3_full_frame_is_the_oracles(native):
     (tests/golden/make_golden_r4.py c3; round 3 pinned a 128x128 window only)"""
     from mitsuba2_amd import scenes
     rec = GOLD4.get("c3_full_1920x1080_1024spp")
-    if rec is None:
-        pytest.skip("tests/golden/round4.json holds no full-frame C3 record")
+    assert rec is not None, "tests/golden/round4.json holds no full-frame C3 record (python tests/golden/make_golden_r4.py c3)"
     scene, sensor = scenes.cornell_box(W, H, 1024, diffuse_only=False, device=-1)
     dev = native.Device(0)
     dev.upload(scene.desc())
@@ -177,13 +176,13 @@ def test_c4_full_frame_at_2048spp_through_the_sample_log(native):
     # round 4, second session: 22 more blocks of the same frame, every 97th of the spiral from its centre to the image's corners
     # (tests/golden/make_golden_r4.py c4blocks) — the walls, the clutter, the open ceiling, pixels that see the environment map
     more = GOLD4.get("c4_full_job_more_blocks_2048spp")
-    if more:
-        ids = [int(k) for k in more["interiors"]]
-        for sid, (b, x0, y0) in zip(ids, G.full_job_blocks(job.cfg, ids)):
-            want = more["interiors"][str(sid)]
-            assert (b, [x0, y0]) == (want["block"], want["origin"])
-            inner = film[y0 + 2:y0 + 2 + want["size"][1], x0 + 2:x0 + 2 + want["size"][0]]
-            assert digest(inner) == want["sha256"], "block %d: mean Y %.9g vs the oracle's %.9g" % (sid, float(inner[..., 1].astype(np.float64).mean()), want["mean_y"])
+    assert more is not None, "tests/golden/round4.json holds no c4_full_job_more_blocks_2048spp record (python tests/golden/make_golden_r4.py c4blocks)"
+    ids = [int(k) for k in more["interiors"]]
+    for sid, (b, x0, y0) in zip(ids, G.full_job_blocks(job.cfg, ids)):
+        want = more["interiors"][str(sid)]
+        assert (b, [x0, y0]) == (want["block"], want["origin"])
+        inner = film[y0 + 2:y0 + 2 + want["size"][1], x0 + 2:x0 + 2 + want["size"][0]]
+        assert digest(inner) == want["sha256"], "block %d: mean Y %.9g vs the oracle's %.9g" % (sid, float(inner[..., 1].astype(np.float64).mean()), want["mean_y"])
     dev.close()
 
 
@@ -204,7 +203,7 @@ def test_fuzz_recipes_on_the_device(native, first):
         ikw = dict(ikw); ikw.pop("samples_per_pass", None)
         integ = native.DirectIntegrator if ikw.pop("integrator", "path") == "direct" else native.PathIntegrator
         job = integ(**ikw).render_job(sensor)
-        for quality in (0, 0x40):                                       # the SAH tree built on the device, the radix tree
+        for quality in ((0, 0x40, 1) if seed == FUZZ[first] else (0, 0x40)):   # the SAH tree built on the device, the radix tree; the first recipe of every slice on the host-built tree as well
             dev.upload(scene.desc(), bvh_quality=quality)
             for plan in ((2,) if job.cfg.integrator == 1 else (2, 1)):      # the direct integrator runs on the resident plan
                 film, st = dev.render(job, plan=plan)
