@@ -72,7 +72,12 @@ inline EnvmapTables envmap_build_from_density(const mi_envmap &e, const float *d
     if (dims.size() > MIW_ENV_MAX_LEVELS) return t;
     r.n_levels = (uint32_t) dims.size();
     size_t total = 0;
-    for (size_t l = 0; l < dims.size(); ++l) { r.level_offset[l] = (uint32_t) total; r.level_width[l] = dims[l].w; total += (size_t) dims[l].w * dims[l].h; }
+    // (level 0, the W x H data array, is padded to a multiple of four floats so that every level >= 1 — even widths and heights —
+    // starts on a 16-byte boundary: hier2d_sample reads block pairs of those levels as 16-byte words)
+    for (size_t l = 0; l < dims.size(); ++l) {
+        r.level_offset[l] = (uint32_t) total; r.level_width[l] = dims[l].w; r.level_height[l] = dims[l].h;
+        total += ((size_t) dims[l].w * dims[l].h + 3u) / 4u * 4u;
+    }
     t.levels.assign(total, 0.f);
     float *l0 = t.levels.data() + r.level_offset[0], *l1 = t.levels.data() + r.level_offset[1];
     // integrate the linear interpolant, distr_2d.h:424-436

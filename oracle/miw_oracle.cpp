@@ -1017,6 +1017,7 @@ void orc_microfacet(int op, uint32_t type, float au, float av, int sample_visibl
     }
 }
 // Hierarchical2D<Float, 0> over caller data (w x h floats): op 0 = sample(xy) -> x, y, pdf ; op 1 = eval(xy) -> pdf ;
+// op 200 + k = the same through hier2d_sample<Paired = false>, one level per lookup (round 5: the default reads two levels per lookup);
 // op 100 + k = sample(xy) with the hierarchy's k smallest levels read through a SEPARATE copy (envmap.h: EnvTop — what the device
 // kernels do with their LDS copy of those levels): must be the sample of op 0, bit for bit, for every k
 int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *xy, float *out3) {
@@ -1034,7 +1035,8 @@ int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *x
     t.rec.data = t.data.data(); t.rec.levels = t.levels.data();
     if (op == 0) { float pdf; V2 r = hier2d_sample(t.rec, v2(xy[0], xy[1]), pdf); out3[0] = r.x; out3[1] = r.y; out3[2] = pdf; }
     else if (op >= 100) {
-        const uint32_t k = (uint32_t) (op - 100);
+        const bool plain = op >= 200;                               // op 200 + k: the one-level-per-fetch descent (Paired = false), the definition the paired form must equal
+        const uint32_t k = (uint32_t) (op - (plain ? 200 : 100));
         if (k >= t.rec.n_levels) return -2;
         EnvTop top = env_top_none();
         std::vector<float> copy;
@@ -1044,7 +1046,8 @@ int orc_hier2d(const float *data, uint32_t w, uint32_t h, int op, const float *x
             top.p = copy.data();
             for (size_t i = top.base; i < t.levels.size(); ++i) t.levels[i] = -1e30f;     // the originals of those levels must not be read
         }
-        float pdf; V2 r = hier2d_sample(t.rec, v2(xy[0], xy[1]), pdf, top); out3[0] = r.x; out3[1] = r.y; out3[2] = pdf;
+        float pdf; V2 r = plain ? hier2d_sample<false>(t.rec, v2(xy[0], xy[1]), pdf, top) : hier2d_sample<true>(t.rec, v2(xy[0], xy[1]), pdf, top);
+        out3[0] = r.x; out3[1] = r.y; out3[2] = pdf;
     }
     else out3[0] = hier2d_eval(t.rec, v2(xy[0], xy[1]));
     return 0;

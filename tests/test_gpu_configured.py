@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "round3.json")))
 GOLD4 = json.load(open(os.path.join(ROOT, "tests", "golden", "round4.json")))
+GOLD5 = json.load(open(os.path.join(ROOT, "tests", "golden", "round5.json")))       # round 5: the whole C4 frame (make_golden_r5.py)
 W, H = 1920, 1080
 
 
@@ -183,6 +184,23 @@ def test_c4_full_frame_at_2048spp_through_the_sample_log(native):
         assert (b, [x0, y0]) == (want["block"], want["origin"])
         inner = film[y0 + 2:y0 + 2 + want["size"][1], x0 + 2:x0 + 2 + want["size"][0]]
         assert digest(inner) == want["sha256"], "block %d: mean Y %.9g vs the oracle's %.9g" % (sid, float(inner[..., 1].astype(np.float64).mean()), want["mean_y"])
+    # round 5: the oracle ran the WHOLE frame (tests/golden/make_golden_r5.py: 2040 spiral blocks in checkpointed chunks, 4.25e9
+    # samples through its spatial index, hours of host time): the film's digest, its 27 band digests, the sample / segment /
+    # shadow-ray counts and the interior of every block. (A run that was cut short commits the blocks it finished under
+    # c4_full_job_first_blocks_2048spp: their interiors are final, and are compared instead.)
+    rec5 = GOLD5.get("c4_full_1920x1080_2048spp") or GOLD5.get("c4_full_job_first_blocks_2048spp")
+    assert rec5 is not None, "tests/golden/round5.json holds no C4 full-frame record (python tests/golden/make_golden_r5.py c4full)"
+    ids = sorted(int(k) for k in rec5["interiors"])
+    bad = []
+    for sid, (b, x0, y0) in zip(ids, G.full_job_blocks(job.cfg, ids)):
+        want = rec5["interiors"][str(sid)]
+        assert (b, [x0, y0]) == (want["block"], want["origin"])
+        if digest(film[y0 + 2:y0 + 2 + want["size"][1], x0 + 2:x0 + 2 + want["size"][0]]) != want["sha256"]:
+            bad.append(sid)
+    assert not bad, "%d of %d block interiors differ from the oracle's: spiral ids %s ..." % (len(bad), len(ids), bad[:12])
+    if "sha256" in rec5:
+        assert (c.samples, c.segments) == (rec5["samples"], rec5["segments"]) and 0 < c.shadow_rays <= rec5["shadow_rays"]
+        _assert_film(film, rec5, "C4 full frame @ 2048 spp")
     dev.close()
 
 

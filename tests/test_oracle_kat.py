@@ -688,3 +688,29 @@ def test_hier2d_sample_through_a_copy_of_its_top_levels(oracle):
             k += 1
         assert k >= 4
 
+
+
+def test_hier2d_two_levels_per_lookup_equals_the_one_level_descent(oracle):
+    """envmap.h MIW_ENV_PAIRED (round 5): hier2d_sample recomputes a level's block from the four child blocks of the level below
+    (the constructor's own float32 sums, distr_2d.h:445-461) and reads the bilinear patch's corners with level 1 — half the
+    dependent lookups of the device's shade body. Same sample and pdf as the one-level-per-lookup descent (op 200), bit for bit:
+    power-of-two maps, odd sizes whose padded blocks must read as zeros, thin maps, with and without copied top levels."""
+    rng = np.random.default_rng(21)
+    for (h, w) in ((16, 32), (33, 20), (7, 50), (64, 128), (5, 5), (2, 2), (3, 9), (130, 67)):
+        d = (rng.random((h, w)) ** 4 + 0.003).astype(np.float32)
+        d[rng.random((h, w)) < 0.1] = 0.0                          # empty texels: zero-mass blocks next to the chosen ones
+        pts = np.vstack([rng.random((60, 2)), [[0.0, 0.0], [1.0, 1.0], [0.0, 1.0], [0.999999, 0.5]]]).astype(np.float32)
+        k = 0
+        while True:
+            a = np.zeros(3, np.float32)
+            rc = oracle.L.orc_hier2d(fp(d), w, h, 200 + k, fp(np.ascontiguousarray(pts[0])), fp(a))
+            if rc == -2:
+                break
+            assert rc == 0
+            for xy in pts:
+                a = np.zeros(3, np.float32); b = np.zeros(3, np.float32)
+                assert oracle.L.orc_hier2d(fp(d), w, h, 200 + k, fp(np.ascontiguousarray(xy)), fp(a)) == 0
+                assert oracle.L.orc_hier2d(fp(d), w, h, 100 + k, fp(np.ascontiguousarray(xy)), fp(b)) == 0
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (h, w, k, xy, a, b)
+            k += 1
+        assert k >= 2
