@@ -1172,44 +1172,59 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.log_pos = film_mode == 1 && !rec16 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 && !rec16 ? c->q_log_val.p : nullptr;
     Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr; Q.piece_a = 64u; Q.piece_b = 1u;
     Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count : 0u;
-    // render launches with 16-byte records keep the 256 phase thresholds behind everything else in dynamic LDS
-    TraceLds rcfg = c->lds_cfg; size_t rlds = c->lds_bytes;
-    rcfg.thr16 = (uint32_t) ((rlds + 15) / 16);
-    if (rec16) rlds = (size_t) rcfg.thr16 * 16 + (MIW_FC_TABLE + 3) / 4 * 16;
-    // the scene's small tables behind that (trace.h: stage_tables). The kernels that stage them keep four workgroups per CU
-    // (160 KB / 4), so the tables have to fit what the stack / the packets and the thresholds leave of 40 KB; a scene whose tables
-    // do not takes the lock-step tree kernels, which read them from global memory (tables_fit; mi_bvh_build applies the same bound
-    // before it declares a scene tiny).
-    rcfg.tab16 = (uint32_t) ((rlds + 15) / 16);
-    size_t table_bytes = lds_table_bytes(c, rcfg.tab_words, c->lds_cfg.brute != 0);
-    // (packet scenes always stage: mi_bvh_build bounded their tables by 24 KB, which with the packets, boxes and thresholds stays
-    // inside the 64 KB a workgroup may ask for — at fewer workgroups per CU past 40 KB)
-    // (a tree scene keeps four workgroups per CU only if its dynamic LDS + the phase machine's static words (s_prog, section buffer:
-    // MIW_LDS_STATIC) + one allocation granule stay inside 40 KB)
+    // ---- dynamic LDS of the render launches: [staged geometry | per-lane stack][256 phase thresholds (16-byte records)][the scene's
+    // small tables + the environment warp's smallest levels (trace.h: stage_tables)]. The kernels that stage the tables keep four
+    // workgroups per CU (160 KB / 4), so everything has to fit 40 KB less one allocation granule; a scene whose tables do not takes
+    // the lock-step tree kernels, which read them from global memory (tables_fit; mi_bvh_build applies the same bound before it
+    // declares a scene tiny). The 8-wide walk's stack is one 8-byte entry per LEVEL of its tree (miw/bvh8.h): a launch that will
+    // run it sizes the column by the tree's depth instead of the 4-wide walk's 32 x 4 bytes, and the bytes that frees go to more
+    // levels of the environment warp (round 5: the 0.9 M-triangle interior, depth 10 -> 20 KB of stack, warp levels down to 64 x 32).
+    struct LdsLayout { TraceLds cfg; size_t rlds, rlds_plain, table_bytes; bool tables_fit; };
     const size_t lds_budget = MIW_LDS_PER_WORKGROUP - MIW_LDS_STATIC - MIW_LDS_GRANULE;
-    const bool tables_fit = (size_t) rcfg.tab16 * 16 + table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : lds_budget);
-    rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0;
-    if (tables_fit && c->have_env) {
-        // ... and as many of the environment warp's smallest levels as fit what is left (at most 4 KB): levels are stored from the
-        // largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
-        const EnvmapRec &e = c->env_host;
-        const size_t used = (size_t) rcfg.tab16 * 16 + table_bytes;
-        const size_t room = used < lds_budget ? std::min<size_t>(4096, lds_budget - used) : 0;
-        uint32_t count = 0;
-        while (count + 1 < e.n_levels && ((size_t) c->env_levels_total - e.level_offset[e.n_levels - 1 - count]) * 4 <= room) ++count;
-        if (count) {
-            rcfg.env_top_count = count; rcfg.env_top_base = e.level_offset[e.n_levels - count];
-            rcfg.env_top_words = (uint32_t) (c->env_levels_total - rcfg.env_top_base);
-            table_bytes += ((size_t) rcfg.env_top_words + 3) / 4 * 16;
+    auto lay_out = [&](size_t base, size_t env_cap) {
+        LdsLayout L; L.cfg = c->lds_cfg; L.rlds = base;
+        L.cfg.thr16 = (uint32_t) ((L.rlds + 15) / 16);
+        if (rec16) L.rlds = (size_t) L.cfg.thr16 * 16 + (MIW_FC_TABLE + 3) / 4 * 16;
+        L.cfg.tab16 = (uint32_t) ((L.rlds + 15) / 16);
+        L.table_bytes = lds_table_bytes(c, L.cfg.tab_words, c->lds_cfg.brute != 0);
+        // (packet scenes always stage: mi_bvh_build bounded their tables by 24 KB, which with the packets, boxes and thresholds stays
+        // inside the 64 KB a workgroup may ask for — at fewer workgroups per CU past 40 KB)
+        L.tables_fit = (size_t) L.cfg.tab16 * 16 + L.table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : lds_budget);
+        L.cfg.env_top_count = L.cfg.env_top_base = L.cfg.env_top_words = 0;
+        if (L.tables_fit && c->have_env && !(getenv("MIW_ENV_TOP") && atoi(getenv("MIW_ENV_TOP")) == 0)) {
+            // ... and as many of the environment warp's smallest levels as fit what is left (at most env_cap): levels are stored from
+            // the largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
+            const EnvmapRec &e = c->env_host;
+            const size_t used = (size_t) L.cfg.tab16 * 16 + L.table_bytes;
+            const size_t room = used < lds_budget ? std::min<size_t>(env_cap, lds_budget - used) : 0;
+            uint32_t count = 0;
+            while (count + 1 < e.n_levels && ((size_t) c->env_levels_total - e.level_offset[e.n_levels - 1 - count]) * 4 <= room) ++count;
+            if (count) {
+                L.cfg.env_top_count = count; L.cfg.env_top_base = e.level_offset[e.n_levels - count];
+                L.cfg.env_top_words = (uint32_t) (c->env_levels_total - L.cfg.env_top_base);
+                L.table_bytes += ((size_t) L.cfg.env_top_words + 3) / 4 * 16;
+            }
         }
+        // (only the kernels that call stage_tables ask for the table bytes: the phase machine and the packet kernels — `rlds`; the
+        // lock-step tree kernels, which read the tables from global memory, launch with `rlds_plain`: ADVICE r04)
+        L.rlds_plain = L.rlds;
+        if (L.tables_fit) L.rlds = (size_t) L.cfg.tab16 * 16 + L.table_bytes;
+        return L;
+    };
+    LdsLayout lay = lay_out(c->lds_bytes, 4096);
+    // will this render walk the 8-wide tree? (the conditions mi_render applies below, known here already; MIW_BVH8=0 keeps the 4-wide walk)
+    const bool pre8 = plan == 2 && cfg->integrator != MI_INTEGRATOR_DIRECT && !c->lds_cfg.brute && c->lds_cfg.stack && c->view.nodes4 && c->nodes8_count != 0u &&
+                      !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0) && !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0) &&
+                      !(getenv("MIW_PHASED_WAVES") && atoi(getenv("MIW_PHASED_WAVES")) != 4) && film_mode == 1;
+    bool stack8_sized = false;
+    if (pre8 && !(getenv("MIW_STACK8_FULL") && atoi(getenv("MIW_STACK8_FULL")) != 0)) {
+        const size_t base8 = (size_t) c->lds_cfg.stack16 * 16 + (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * MIW_BLOCK * sizeof(U2);
+        const LdsLayout lay8 = lay_out(base8, 12288);
+        if (lay8.tables_fit && base8 <= c->lds_bytes) { lay = lay8; stack8_sized = true; }
     }
-    if (getenv("MIW_ENV_TOP") && atoi(getenv("MIW_ENV_TOP")) == 0) { table_bytes -= ((size_t) rcfg.env_top_words + 3) / 4 * 16; rcfg.env_top_count = rcfg.env_top_base = rcfg.env_top_words = 0; }
-    // (only the kernels that call stage_tables ask for those bytes: the phase machine and the packet kernels — `rlds`; the lock-step
-    // tree kernels, which read the tables from global memory, launch with `rlds_plain`: ADVICE r04)
-    const size_t rlds_plain = rlds;
-    if (tables_fit) rlds = (size_t) rcfg.tab16 * 16 + table_bytes;
-    if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu\n",
-                                     rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget);
+    TraceLds rcfg = lay.cfg; size_t rlds = lay.rlds; const size_t rlds_plain = lay.rlds_plain, table_bytes = lay.table_bytes; const bool tables_fit = lay.tables_fit;
+    if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu%s\n",
+                                     rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget, stack8_sized ? "; stack sized for the 8-wide tree's depth" : "");
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
@@ -1299,6 +1314,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         const bool phased_placeable = phased && c->view.nodes4 != nullptr && ph_waves == 4;     // (the Placed instantiations: the 4-wide tree at four waves per SIMD)
         // the 8-wide tree whenever mi_bvh_build produced one (four waves per SIMD only; MIW_BVH8=0 here keeps the 4-wide walk: A/B runs in one process)
         const bool phased8 = phased_placeable && c->nodes8_count != 0u && !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0);
+        if (stack8_sized && !phased8) return fail(c, MI_ERR_STATE, "render: the LDS stack was sized for the 8-wide walk, which this launch does not run");
         SceneView view8 = c->view;
         if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
         const uint32_t res_waves = phased ? (uint32_t) ph_waves : (c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u);

@@ -352,14 +352,15 @@ int emu_trace8(const mi_scene_desc *scene, const mi_rays_soa *r, const mi_hits_s
     auto tri_at2 = [tris2](uint32_t i) -> const Tri & { return tris2[i]; };
     if (compare4) b4 = bvh4_collapse(sc.bvh.nodes, 64u, 4);
     bool bad = false;
+    const int32_t cap8 = (int32_t) std::max<uint32_t>(b8.depth, 2u);      // the column mi_render gives the walk: one entry per level of the tree
     for (uint64_t i = 0; i < n; ++i) {
         const V3 o = v3(r->ox[i], r->oy[i], r->oz[i]), d = v3(r->dx[i], r->dy[i], r->dz[i]);
         Hit hit; bool ok;
         if (schedule) {
             hit.t = MIW_INFINITY; hit.u = hit.v = 0.f; hit.tri = MIW_MISS; hit.prim = 0xffffffffu;
             EmuCoin coin{ schedule | 1u };
-            ok = (schedule & 0x80000000u) ? emu_walk8<true>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps, &coin)
-                                          : emu_walk8<false>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, MIW_BVH8_STACK, &bad, &seen, steps);
+            ok = (schedule & 0x80000000u) ? emu_walk8<true>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, cap8, &bad, &seen, steps, &coin)
+                                          : emu_walk8<false>(b8.nodes.data(), tri_at, rects, o, d, r->mint[i], r->maxt[i], any_hit != 0, hit, cap8, &bad, &seen, steps);
             if (any_hit && ok) { hit.t = 0.f; hit.tri = 0; hit.prim = 0; }
         }
         else if (any_hit) ok = bvh8_intersect<true>(b8.nodes.data(), tri_at, o, d, r->mint[i], r->maxt[i], hit, rects, &seen, steps);
@@ -545,8 +546,10 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
             Hit h; h.t = MIW_INFINITY; h.u = h.v = 0.f; h.tri = MIW_MISS; h.prim = 0xffffffffu;
             occS = false;
             if (phased8) {
-                if (hasE) emu_walk8(b8.nodes.data(), tri_at_w, rects, o, dE, mint, maxtE, false, h, MIW_BVH8_STACK, &bad_slot, &deepest, nullptr);
-                if (hasS) occS = emu_walk8(b8.nodes.data(), tri_at_w, rects, o, dS, mint, maxtS, true, h, MIW_BVH8_STACK, &bad_slot, &deepest, nullptr);
+                // (the speculating bodies under a pseudo-random schedule — the device default, MIW_W8_SPEC — in a column of exactly `depth`
+                // entries, as mi_render sizes it)
+                if (hasE) emu_walk8<true>(b8.nodes.data(), tri_at_w, rects, o, dE, mint, maxtE, false, h, (int32_t) std::max<uint32_t>(b8.depth, 2u), &bad_slot, &deepest, nullptr, &coin);
+                if (hasS) occS = emu_walk8<true>(b8.nodes.data(), tri_at_w, rects, o, dS, mint, maxtS, true, h, (int32_t) std::max<uint32_t>(b8.depth, 2u), &bad_slot, &deepest, nullptr, &coin);
             } else if (phased) {
                 if (hasE) emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dE, mint, maxtE, false, h, std::ref(coin), 32, &bad_slot, &deepest);
                 if (hasS) occS = emu_walk4<true>(b4.nodes.data(), tri_at, rects, o, dS, mint, maxtS, true, h, std::ref(coin), 32, &bad_slot, &deepest);

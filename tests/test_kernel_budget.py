@@ -40,6 +40,8 @@ def test_cornell_packet_kernel_fits_four_waves_without_spills(tmp_path):
 
 def test_phase_machine_of_configs_3_and_4_fits_four_waves(tmp_path):
     r = _resources("probe_phased.hip", "k_path_phasedILi3ELb0ELb1ELi4ELi2E", tmp_path, "-DMIW_PROBE_C34=1")     # over the 8-wide tree: what runs since round 5
-    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 12, r
+    # (8 spilled without the second pending triangle group, 24 with it — MIW_W8_SPEC, the default: measured +2.7 % / +3.5 % on configs 3 / 4
+    # over the non-speculating walk WITH these spills, gpurun r5b / r5d)
+    assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 24, r
     r = _resources("probe_phased.hip", "k_path_phasedILi3ELb0ELb1ELi4ELi1E", tmp_path, "-DMIW_PROBE_C34=1")     # its 4-wide twin (MIW_BVH8=0, trees the 8-wide collapse refuses)
     assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 20, r
