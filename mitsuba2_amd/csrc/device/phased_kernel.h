@@ -187,6 +187,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     // shade once the shade-ready lanes outnumber the busier walk body num : den (host: 3 : 2, 2 : 1 with an environment map —
     // a shade run costs ~2 200 instruction slots whatever its lane count, a walk step ~100 - 200, so shade runs are worth filling)
     const int shade_num = (int) cfg.shade_num, shade_den = (int) cfg.shade_den;
+    const int nx_c = (int) cfg.node_exit, tx_c = (int) cfg.tri_exit;
     for (;;) {
         // ---- the vote: which lanes are ready for which body ----
         const bool trav = (mode - 1u) < 2u;
@@ -251,7 +252,6 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             // ---------------- node steps: an inner loop that owns cur, sp and the leaf range only; it runs while the node
             // lanes remain the largest group (lanes that reach a leaf or the end of their walk drop out of it) ----------------
             const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;
-            int n_gone = 0;
             if (n_turn > 0) {                                            // E walks that ended with a shadow ray queued: start the S walk
                 if (e_turn) {
                     mode = PH_TRAV_S;
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 e_node = trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range));
                 const int now = count(e_node);
                 n_leaf = count(trav && has_range);
-                n_gone = n_node - now;                                   // lanes of this burst now at a leaf / at their walk's end
-                if (now < n_leaf || now < others + n_gone / 2 || now == 0) break;
+                // hand over once the node lanes are clearly outnumbered: by the leaf lanes 2 : 1, or by the waiting lanes nx_c : 1 (host: 1, with an
+                // environment map 2). (The loops of rounds 3 - 4 left at now < leaf lanes and bounced between the bodies: C3 +4 %, C4 +3 %, gpurun r5f - r5h.)
+                if (2 * now < n_leaf || nx_c * now < others || now == 0) break;
             } while (true);
         } else {
             // ---------------- triangle tests: same shape; owns the best hit, tmax, the leaf range, cur and sp ----------------
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 e_leaf = trav && has_range;
                 const int now = count(e_leaf);
                 n_node = count(trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range)));
-                if (now <= n_node || now < others || now == 0) break;
+                if (2 * now <= n_node || tx_c * now < others || now == 0) break;
             } while (true);
         }
     }

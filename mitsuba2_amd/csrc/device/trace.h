@@ -13,6 +13,8 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t stack;         // 1: tree walk with a per-lane LDS stack (MIW_STACK_ENTRIES x 256 dwords) at stack16
     uint32_t stack16;       // uint4 offset of the stack area in dynamic LDS
     uint32_t shade_num, shade_den;   // k_path_phased's shade vote: shade once n_shade * shade_num >= shade_den * (lanes of the busier walk body)
+    uint32_t node_exit, tri_exit;    // k_path_phased: a walk loop hands over once the lanes still in it are outnumbered 2 : 1 by the other walk body's, or
+                            // node_exit : 1 / tri_exit : 1 by the lanes waiting for another body (phased_kernel.h)
     uint32_t queues;        // render kernels fed from the shared pixel queue: 1 queue, or 8 (one per XCD; resident_kernel.h: QueueWork)
     uint32_t tail_prio;     // 1: least-progress-first wave priorities (QueueWork::tick) — shards of about one pixel per resident lane
     uint32_t thr16;         // render kernels that log 16-byte records: uint4 offset of the 256 phase thresholds (film.h) in dynamic LDS

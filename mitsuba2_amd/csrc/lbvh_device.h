@@ -17,7 +17,7 @@
 //   k_lbvh_emit     inner nodes -> BvhNode records
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include "miw/scene.h"
 #include "miw/bvh.h"
 

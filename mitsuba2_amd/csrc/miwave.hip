@@ -605,7 +605,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             HIP_TRY(c, d_prim.resize(un)); HIP_TRY(c, d_ia.resize(un)); HIP_TRY(c, d_ib.resize(un)); HIP_TRY(c, d_flags.resize(un)); HIP_TRY(c, d_rank.resize(un));
             HIP_TRY(c, d_ca.resize(un)); HIP_TRY(c, d_cb.resize(un)); HIP_TRY(c, d_dec.resize(un)); HIP_TRY(c, d_state.resize(1));
             size_t scan_bytes = 0;
-            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags.p, d_rank.p, n, s));
+            HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, d_flags.p, d_rank.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), s));
             HIP_TRY(c, d_scan_tmp.resize(scan_bytes + 16));
             HIP_TRY(c, hipStreamSynchronize(s));
             const auto t_setup = std::chrono::steady_clock::now();     // (uploads and allocations behind us)
@@ -639,7 +639,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 }
                 if (all_big || big_left) hipLaunchKernelGGL(k_sah_decide<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, all_big ? none : MIW_SAH_BIG, huge ? MIW_SAH_HUGE : all);
                 if (!all_big) hipLaunchKernelGGL(k_sah_decide<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, d_prim.p, level, max_leaf, d_dec.p, d_flags.p, d_state.p, none, big_left ? MIW_SAH_BIG : all);
-                HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_flags.p, d_rank.p, (int) n_cand, s));
+                HIP_TRY(c, rocprim::exclusive_scan(d_scan_tmp.p, scan_bytes, d_flags.p, d_rank.p, 0u, (size_t) n_cand, rocprim::plus<uint32_t>(), s));
                 hipLaunchKernelGGL(k_sah_totals, dim3(1), dim3(1), 0, s, d_flags.p, d_rank.p, n_cand, d_state.p);
                 if (all_big || big_left) hipLaunchKernelGGL(k_sah_apply<1024>, dim3(n_cand), dim3(1024), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, all_big ? none : MIW_SAH_BIG, all, un);
                 if (!all_big) hipLaunchKernelGGL(k_sah_apply<64>, dim3(n_cand), dim3(64), 0, s, cur, n_cand, ic, in, d_prim.p, d_dec.p, d_rank.p, base, c->d_nodes.p, nxt, d_state.p, none, big_left ? MIW_SAH_BIG : all, un);
@@ -686,9 +686,9 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<unsigned>(grd.x, 1024u)), blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p);
             hipLaunchKernelGGL(k_lbvh_morton, grd, blk, 0, s, d_in.p, (uint32_t) n, d_bounds.p, d_keys.p);
             size_t tmp_bytes = 0;
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+            HIP_TRY(c, rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.p, d_keys_sorted.p, (size_t) n, 0u, 64u, s));
             HIP_TRY(c, d_tmp.resize(tmp_bytes + 16));
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, n, 0, 64, s));
+            HIP_TRY(c, rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.p, d_keys_sorted.p, (size_t) n, 0u, 64u, s));
             // box padding (bvh.h, bvh_build.h: scene_pad_unit): 2e-5 x the largest |coordinate|
             uint32_t hb[6];
             HIP_TRY(c, hipMemcpyAsync(hb, d_bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
@@ -1334,7 +1334,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             HIP_TRY(c, hipMemsetAsync(c->d_lane_sorted.p, 0xff, (size_t) n_pieces * 64u * sizeof(uint32_t), s));
             HIP_TRY(c, hipMemsetAsync(c->d_simd_ids.p, 0, c->d_simd_ids.n * sizeof(uint32_t), s));
             hipLaunchKernelGGL(k_iota, dim3((n_lanes + 255u) / 256u), dim3(256), 0, s, c->d_lane_iota.p, n_lanes);
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(nullptr, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (int) n_lanes, 0, 32, s));
+            HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (size_t) n_lanes, 0u, 32u, s));
             HIP_TRY(c, c->d_place_tmp.resize(place_tmp_bytes + 16));
         }
         // film_mode 2: workgroup-local float64 tile in LDS (needs 16x16-pixel workgroups: block_size >= 16)
@@ -1365,7 +1365,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // the lanes by what their pixel cost, dearest first (device radix sort), cut into pieces of 64: consecutive sorted lanes
                     // (the pixels of a wavefront cost about the same and finish together), or every pieces-th one (one pixel of every cost
                     // stratum per wavefront). Either way a piece's cost is that of its first (dearest) lane.
-                    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairsDescending(c->d_place_tmp.p, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (int) n_lanes, 0, 32, s));
+                    HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->d_place_tmp.p, place_tmp_bytes, c->d_lane_cost.p, c->d_cost_sorted.p, c->d_lane_iota.p, c->d_lane_sorted.p, (size_t) n_lanes, 0u, 32u, s));
                     // Which cut: measured on rank 0's 1/8 shard (gpurun r4b, path kernel ms at 256 / 128 / 512 spp; no placement -> consecutive
                     // -> spread): material balls 99.3 -> 90.7 -> 104.9, 0.9 M-triangle interior 130.8 -> 131.0 -> 120.9, Cornell packets
                     // 40.0 -> 36.7 -> 44.3. Consecutive pieces keep the dear pixels in few wavefronts, which the priorities then favour; the
@@ -1449,6 +1449,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
                 if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
+                // when the walk loops hand over (phased_kernel.h): a loop runs on until its lanes are outnumbered 2 : 1 by the other walk body's, or
+                // node_exit : 1 / tri_exit : 1 by the lanes waiting for another body. Measured on the 8-wide walk (gpurun r5f - r5h, Msamples/s,
+                // material balls / interior): rounds 3 - 4's rule (1 : 1 against the other body, waiting + half the lanes that left) 1 119 / 463;
+                // 2 : 1 with node 1, triangle 1 -> 1 161 / 471; triangle 2 -> 1 174 / 472; node 2 -> 1 147 / 478; node 2, triangle 3 -> . / 481
+                // (the interior's shade runs are long: loops that wait for them less often win there). MIW_LOOP_EXIT=node:triangle overrides.
+                ph_cfg.node_exit = c->have_env ? 2u : 1u; ph_cfg.tri_exit = c->have_env ? 3u : 2u;
+                if (const char *e = getenv("MIW_LOOP_EXIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a >= 0 && b >= 0) { ph_cfg.node_exit = (uint32_t) a; ph_cfg.tri_exit = (uint32_t) b; } }
 #define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, (W) == 2 ? view8 : c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
 #define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_PHASED_LAUNCH_(M, A, 4, W, false); else MIW_PHASED_LAUNCH_(M, A, 3, W, false); } while (0)
                 K.tree_width = phased ? (phased8 ? 8u : (c->view.nodes4 ? 4u : 2u)) : 0u;

@@ -5,7 +5,7 @@
 //   k_sah_prims     per triangle: padded box + box centre (48-byte record), the identity index array
 //   k_sah_decide    per candidate: box + centroid box of its range (wave shuffles, then ordered-uint LDS atomics), 3 x 16 bins in
 //                   LDS (min / max / count atomics), one thread per axis runs sah_sweep_axis, thread 0 runs sah_decide
-//   hipcub::DeviceScan::ExclusiveSum over the split flags  -> the breadth-first number of every new inner node
+//   rocprim::exclusive_scan over the split flags  -> the breadth-first number of every new inner node
 //   k_sah_apply     per candidate: sah_link (box + child reference into the parent's BvhNode), stable partition of its range into
 //                   the next level's index array (ballots + a prefix over the workgroup's wavefronts), the two child candidates
 //   k_sah_heights   per level, bottom-up: the BVH2 heights the 4-wide collapse asks for
@@ -15,7 +15,7 @@
 // compares node counts, depth and films).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include "sah_levels.h"
 #include "lbvh_device.h"
 

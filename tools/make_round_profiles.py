@@ -148,7 +148,11 @@ def main():
         for f in sorted(glob.glob("%s_bench_%s*.log" % (g, name))):
             out.append(bench_line(g, os.path.basename(f)[len(tag) + 1:-4]))
         if name == "c4" and os.path.exists(g + "_bench_c4.err"):
-            out += ["#   " + l.strip() for l in open(g + "_bench_c4.err") if "device builder" in l or "bvh4" in l]
+            out += ["#   " + l.strip() for l in open(g + "_bench_c4.err") if "device builder" in l or "bvh4" in l or "bvh8" in l or "LDS per" in l]
+        if name == "c4" and os.path.exists(g + "_bench_c4_sah_r4.err"):
+            out += ["#   MIW_SAH_HUGE=0 (one workgroup per candidate, round 4's launch shape): " + l.strip() for l in open(g + "_bench_c4_sah_r4.err") if "device builder" in l]
+        if name == "c4" and glob.glob(g + "_c4bvh4_pmc1"):
+            out += ["", "# the same workload through the 4-wide walk of the same build (MIW_BVH8=0): PMC passes", pmc_text(g, "c4bvh4")]
         if name == "c3":
             out.append("# triangle-count series (bench.py --scene matball --tess t --spp 128): 52 triangles = packet kernel; from 172 on the phase machine")
             for t in range(5):
@@ -163,6 +167,11 @@ def main():
         open(path, "w").write("\n".join(out + notes) + "\n")
         traffic["scalar_rgb/%s/1920x1080@%d/plan2/film1/launch%d" % (key, spp, spp)] = traffic_entry(g, name, sha, "profiles/" + os.path.basename(path))
 
+    # every rank's tile shard of an 8-GPU frame + the floor (tools/shard_table.py, same session)
+    if os.path.exists(g + "_shards.txt"):
+        open(os.path.join(ROOT, "profiles", "%s_shards.txt" % tag), "w").write(head + "\n" + open(g + "_shards.txt").read())
+    if os.path.exists(g + "_bench_c2.log"):
+        open(os.path.join(ROOT, "profiles", "%s_bench_default_line.json" % tag), "w").write(open(g + "_bench_c2.log").read().strip().splitlines()[-1] + "\n")
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print("kernel_src_sha16", sha)
 

@@ -4,7 +4,7 @@
 #   other than --kernel-trace; SQ / TCC / GRBM counters only — the TA / TCP / TD groups hang rocprofv3 on this pool) of
 #   C2 (the default bench), C3 (material balls) and the C4-class interior; the bench lines of C2 (the default line: CPU baseline,
 #   live counters, extras at the configured spp), C3, C4 (device-built SAH tree, host-built, radix tree), C5, the triangle-count
-#   series, the wavefront plan and the tile-shard tables of C2 / C3 / C4.
+#   series, the wavefront plan and every rank's tile shard of an 8-GPU frame of C2 / C3 / C4 (tools/shard_table.py).
 # Usage (from the repo root, on the GPU box):  [LEAN=1] bash tools/profile_round.sh r04   (LEAN skips the A/B lines of knobs that are not defaults)
 # Outputs under gpurun_out/<tag>_*; tools/make_round_profiles.py <tag> turns them into profiles/<tag>_* and profiles/traffic.json.
 tag=${1:-r04}
@@ -13,7 +13,7 @@ out=$repo/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 export MIW_BENCH_NO_LIVE=1     # bench.py's own live PMC passes only in the default line below (these runs ARE the PMC passes)
-pmc() {   # pmc <name> <bench args...>
+pmc() {   # [ENV=VAL] pmc <name> <bench args...>  (the environment of the call reaches bench.py)
   name=$1; shift
   B="python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $*"
   ( cd /tmp
@@ -26,6 +26,7 @@ pmc() {   # pmc <name> <bench args...>
 pmc c2
 pmc c3 --scene matball --spp 64
 pmc c4 --scene interior --spp 16
+MIW_BVH8=0 pmc c4bvh4 --scene interior --spp 16          # the 4-wide twin of the same build: traffic and wait share against the 8-wide walk's
 cd $repo
 line() {  # line <name> [ENV=VAL ...] -- <bench args...>: one bench line into $out/${tag}_<name>.log
   local name=$1; shift
@@ -35,37 +36,22 @@ line() {  # line <name> [ENV=VAL ...] -- <bench args...>: one bench line into $o
 env -u MIW_BENCH_NO_LIVE timeout 900 python bench.py > $out/${tag}_bench_c2.log 2> $out/${tag}_bench_c2.err      # THE default line: live counters, CPU leg, extras at the configured spp
 C3="--scene matball --steps 1 --warmup 1"; C4="--scene interior --steps 1 --warmup 1"
 line bench_c3 -- $C3 --spp 1024                                   # configs[2] as configured
+line bench_c3_bvh4 MIW_BVH8=0 -- $C3 --spp 256                    # the 4-wide walk (round 4's tree) on the same build
 line bench_c3_plan1 -- $C3 --spp 256 --plan 1                     # wavefront plan (stream walk kernel)
-[ -n "$LEAN" ] || { line bench_c3_lockstep MIW_PHASED=0 -- $C3 --spp 256; }   # lock-step resident kernel over the tree
-line bench_c3_hostsah -- $C3 --spp 256 --bvh-quality 1            # the same tree built by the host recursion
-line bench_c3_lbvh -- $C3 --spp 256 --bvh-quality 64              # MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3
-[ -n "$LEAN" ] || { line bench_c3_w3 MIW_PHASED_WAVES=3 -- $C3 --spp 256; }   # three wavefronts per SIMD
+line bench_c3_hostsah -- $C3 --spp 256 --bvh-quality 1            # the same trees built / collapsed by the host
+line bench_c3_lbvh -- $C3 --spp 256 --bvh-quality 64              # MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3 (4-wide walk)
 line bench_c5 -- --variant scalar_spectral --scene glassblock --steps 1 --warmup 1
 line bench_c4 MIW_DEBUG=1 -- $C4 --spp 32                         # configs[3] class, device-built SAH tree (the default); .err: the builder's timing
+line bench_c4_bvh4 MIW_BVH8=0 -- $C4 --spp 32
 line bench_c4_hostsah -- $C4 --spp 32 --bvh-quality 1
 line bench_c4_lbvh -- $C4 --spp 32 --bvh-quality 64
-[ -n "$LEAN" ] || { line bench_c4_w3 MIW_PHASED_WAVES=3 -- $C4 --spp 32; }
+line bench_c4_sah_r4 MIW_SAH_HUGE=0 MIW_DEBUG=1 -- $C4 --spp 16   # the builder with one workgroup per candidate (round 4's launch shape): build ms
 line bench_direct_c2 -- --integrator direct --steps 2 --warmup 1
-[ -n "$LEAN" ] || { line bench_c2_noprio MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1; }
-[ -n "$LEAN" ] || { line bench_c2_legacy_log MIW_FILM_LEGACY=1 -- --steps 2 --warmup 1; }   # 24-byte position log + texel-patch replay
-[ -n "$LEAN" ] || { line bench_c2_film_groups MIW_FILM_COLUMNS=0 -- --steps 2 --warmup 1; }   # round 3's one-texel-per-lane film replay
-# the triangle-count series between the packet kernels (<= 64 triangles) and config 3 (icosphere levels 0..4 of the two balls)
 [ -n "$LEAN" ] || { for t in 0 1 2 3 4; do line tess_$t -- --scene matball --tess $t --spp 128 --steps 1 --warmup 1; done; }
-# rank 0's tile shard of an N-GPU frame on one GPU: C2 (512 spp), C3 (256 spp), C4 class (128 spp); the 1/8 shard also without the
-# sorted placement (MIW_PLACE=0), without the wave priorities as well, and with the other cut of the sorted list (MIW_PLACE_SPREAD)
-for so in 1 2 4 8; do line shard_$so -- --steps 2 --warmup 1 --shard tiles --shard-of $so; done
-line shard_8_noplace MIW_PLACE=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
-[ -n "$LEAN" ] || { line shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- --steps 2 --warmup 1 --shard tiles --shard-of 8; }
-line shard_8_spread MIW_PLACE_SPREAD=1 -- --steps 2 --warmup 1 --shard tiles --shard-of 8
-for so in 1 2 8; do line c3_shard_$so -- $C3 --spp 256 --shard tiles --shard-of $so; done
-line c3_shard_8_noplace MIW_PLACE=0 -- $C3 --spp 256 --shard tiles --shard-of 8
-[ -n "$LEAN" ] || { line c3_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C3 --spp 256 --shard tiles --shard-of 8; }
-line c3_shard_8_spread MIW_PLACE_SPREAD=1 -- $C3 --spp 256 --shard tiles --shard-of 8
-for so in 1 8; do line c4_shard_$so -- $C4 --spp 128 --shard tiles --shard-of $so; done
-line c4_shard_8_noplace MIW_PLACE=0 -- $C4 --spp 128 --shard tiles --shard-of 8
-[ -n "$LEAN" ] || { line c4_shard_8_plain MIW_PLACE=0 MIW_TAIL_PRIO=0 -- $C4 --spp 128 --shard tiles --shard-of 8; }
-line c4_shard_8_contiguous MIW_PLACE_SPREAD=0 -- $C4 --spp 128 --shard tiles --shard-of 8
+# every rank's tile shard of an 8-GPU frame, at the configured spp, + the floor (tools/shard_table.py)
+timeout 900 python tools/shard_table.py --out $out/${tag}_shards.txt --json $out/${tag}_shards.json > $out/${tag}_shards.log 2>&1
 # keep the merged artefacts small: traces of the PMC passes are only needed for the per-kernel durations
 find $out -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $out | tail -1
-for f in $out/${tag}_bench_*.log $out/${tag}_tess_*.log $out/${tag}_shard_*.log $out/${tag}_c3_shard_*.log $out/${tag}_c4_shard_*.log; do echo "== $f"; tail -1 $f | cut -c1-330; done
+for f in $out/${tag}_bench_*.log; do echo "== $f"; tail -1 $f | cut -c1-330; done
+tail -50 $out/${tag}_shards.txt
