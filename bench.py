@@ -186,6 +186,12 @@ def run_extras(api, scenes, film, C):
     def timed(tag, scene, sensor, spp, note):
         device = api.Device(0)                   # world == 1: the benchmark runs on GPU 0
         try:
+            # The tree is built twice and the SECOND build is quoted: the first device work after the previous configuration's context was
+            # torn down (a 34 GB sample log after the material balls) stalls ~250 ms in one of the builder's host -> device uploads —
+            # whichever comes first, and only in this order of events (gpurun r5l / r5m: "vertex-normal upload 268.9 ms" of a 277 ms
+            # set-up; the same build in any other order: set-up 5 - 7 ms, tools/build_times.py). Both times are in the record.
+            device.upload(scene.desc())
+            first_build_ms = device.counters().ms_bvh_build
             device.upload(scene.desc())
             bvh = device.counters()
             job = api.PathIntegrator().render_job(sensor)
@@ -204,7 +210,8 @@ def run_extras(api, scenes, film, C):
                         "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident", "tree_width": int(c.tree_width),
                         "log_bytes": int(c.log_bytes),
                         "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris,
-                                "nodes2": bvh.bvh_nodes, "nodes8": bvh.bvh8_nodes, "depth8": bvh.bvh8_depth, "ms_bvh4": round(bvh.ms_bvh4, 2), "ms_bvh8": round(bvh.ms_bvh8, 2)}}
+                                "nodes2": bvh.bvh_nodes, "nodes8": bvh.bvh8_nodes, "depth8": bvh.bvh8_depth, "ms_bvh4": round(bvh.ms_bvh4, 2), "ms_bvh8": round(bvh.ms_bvh8, 2),
+                                "build_ms_first_in_this_context": round(first_build_ms, 1)}}
         finally:
             device.close()
 

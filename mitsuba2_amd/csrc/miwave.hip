@@ -582,10 +582,22 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         auto free_tmp = [&]() { d_in.release(); d_vn_in.release(); d_keys.release(); d_keys_sorted.release(); d_bounds.release();
                                 d_arrivals.release(); d_height.release(); d_boxes.release(); d_inner.release(); d_leaf_parent.release(); d_tmp.release();
                                 d_span.release(); d_first.release(); };
+        // MIW_DEBUG_ALLOC=1: where the set-up time of a build goes (stderr, ms since the previous mark)
+        auto lap_t = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!getenv("MIW_DEBUG_ALLOC")) return;
+            (void) hipStreamSynchronize(s);
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[miwave]   build set-up: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+            lap_t = now;
+        };
         HIP_TRY(c, d_in.upload(c->tris_in, s));
+        lap("triangle upload");
         if (!c->tri_vn_in.empty()) HIP_TRY(c, d_vn_in.upload(c->tri_vn_in, s));
+        lap("vertex-normal upload");
         HIP_TRY(c, c->d_nodes.resize(n)); HIP_TRY(c, c->d_tris.resize(n)); HIP_TRY(c, d_height.resize(n));
         if (!c->tri_vn_in.empty()) HIP_TRY(c, c->d_tri_vn.resize((size_t) n * 9));
+        lap("node / triangle buffers");
         const dim3 blk(256), grd((unsigned) ((n + 255) / 256));
         // Which device builder. Default: the level-by-level binned-SAH sweep (sah_device.h) — the host builder's tree, node for node.
         // MI_BVH_RADIX_TREE / MIW_DEVICE_BUILDER=lbvh: the radix tree over Morton codes of rounds 2 - 3 (lbvh_device.h; measured 7 % / 16 % behind the SAH
@@ -607,6 +619,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             size_t scan_bytes = 0;
             HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, d_flags.p, d_rank.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), s));
             HIP_TRY(c, d_scan_tmp.resize(scan_bytes + 16));
+            lap("builder temporaries");
             HIP_TRY(c, hipStreamSynchronize(s));
             const auto t_setup = std::chrono::steady_clock::now();     // (uploads and allocations behind us)
             hipLaunchKernelGGL(k_sah_prims, grd, blk, 0, s, d_in.p, un, pad, d_prim.p, d_ia.p);

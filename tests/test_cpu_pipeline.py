@@ -505,3 +505,22 @@ def test_golden_digest_of_the_spectral_glass_block(spectral, oracle_spectral):
     got = mk.compute(spectral, scenes, oracle_spectral, mk.spectral_cases(spectral, scenes))
     for key, rec in got.items():
         assert rec["sha256"] == want[key]["sha256"] and rec["segments"] == want[key]["segments"], (key, rec, want[key])
+
+
+def test_oracle_render_in_chunks_of_blocks_is_the_one_call_render(native, oracle):
+    """tests/golden/make_golden_r5.py renders the 4.25e9-sample frame of config 4 in checkpointed chunks of consecutive spiral ids:
+    every chunk one orc_render(only_blocks = ids, accumulate = 1) onto the film of the chunks before it. The blocks are merged in
+    ascending id inside a call (miw_oracle.cpp: film_put in job order), so the chunked film goes through exactly the float32
+    additions of the one-call film — bit for bit, with the same sample / segment / shadow-ray totals."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(200, 120, 3, diffuse_only=False, ball_level=1, device=-1)
+    job = native.PathIntegrator().render_job(sensor)
+    n = int(job.cfg.block_count)
+    one, _, st1 = oracle.render(scene.desc(), job, threads=4, want_f64=False)
+    job.cfg.accumulate = 1
+    film = np.zeros_like(one); seg = sam = sha = 0
+    for lo in range(0, n, 5):
+        ids = np.arange(lo, min(lo + 5, n), dtype=np.uint32)
+        film, _, st = oracle.render(scene.desc(), job, threads=3, want_f64=False, only_blocks=ids, onto=(film, None))
+        film = np.array(film); seg += st.segments; sam += st.samples; sha += st.shadow_rays
+    assert np.array_equal(film, one) and (sam, seg, sha) == (st1.samples, st1.segments, st1.shadow_rays)

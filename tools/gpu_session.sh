@@ -1,7 +1,9 @@
 #!/bin/bash
-# One GPU session of round 5 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
-# This one (r05): the round's profile session (tools/profile_round.sh: kernel stats, PMC passes, bench lines, every rank's shard),
-# then the whole GPU tier.
-tag=${1:-r05}; out=gpurun_out; mkdir -p $out
-LEAN=1 bash tools/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1; tail -75 $out/${tag}_profile_round.log
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^$" | tail -12) > $out/${tag}_pytest_gpu.txt; tail -6 $out/${tag}_pytest_gpu.txt
+tag=${1:-r5m}; out=gpurun_out; mkdir -p $out
+MIW_DEBUG=1 MIW_DEBUG_ALLOC=1 timeout 600 python bench.py --no-cpu-baseline --no-live-counters > $out/${tag}_bench.log 2> $out/${tag}_bench.err
+grep "build set-up: triangle\|device builder" $out/${tag}_bench.err
+python - <<'P'
+import json
+j=json.loads(open("gpurun_out/r5m_bench.log").read().strip().splitlines()[-1])
+print(j["value"], {k:(v["bvh"]["build_ms"], v["bvh"]["first_allocation_after_the_previous_context_ms"]) for k,v in j["extras"].items() if isinstance(v,dict)})
+P
