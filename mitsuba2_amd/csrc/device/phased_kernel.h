@@ -248,7 +248,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             }
             MIW_SECTION(12);
             MIW_PS(3, n_shade);
-        } else if (n_node >= n_leaf) {
+        } else if (n_node >= n_leaf) {                           // (a bias either way — a x node lanes >= b x leaf lanes, a : b from 1 : 2 to 3 : 1 — measured flat or worse: gpurun r5n / r5o)
             // ---------------- node steps: an inner loop that owns cur, sp and the leaf range only; it runs while the node
             // lanes remain the largest group (lanes that reach a leaf or the end of their walk drop out of it) ----------------
             const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;

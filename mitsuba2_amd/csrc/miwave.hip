@@ -1721,7 +1721,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
 #define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
-                    // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups)
+                    // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups;
+                    // round 5 measured 2 x 4 and 2 x 2 groups as well: 27.6 / 27.5 ms against 25.6 at C2, gpurun r5p — not kept)
 #define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
                                    const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
                                    MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
