@@ -609,7 +609,9 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         }
         bool sah_need_host = false;
         if (dev_builder == DEV_SAH) {
-            const uint32_t un = (uint32_t) n, max_leaf = 4u;              // (bvh_build_sah's default leaf size: the same tree)
+            uint32_t max_leaf = 4u;                                        // (bvh_build_sah's default leaf size: the same tree; MIW_MAX_LEAF overrides on both sides)
+            if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
+            const uint32_t un = (uint32_t) n;
             const float pad = 2.f * pad_unit;
             TmpBuf<SahPrim> d_prim; TmpBuf<uint32_t> d_ia, d_ib, d_flags, d_rank; TmpBuf<SahCand> d_ca, d_cb; TmpBuf<SahDecision> d_dec; TmpBuf<SahState> d_state;
             TmpBuf<unsigned char> d_scan_tmp; TmpBuf<SahHuge> d_huge;

@@ -1,4 +1,8 @@
 #!/bin/bash
-# r5p: film replay group shapes (k_film_columns<GW, GH>): 4x2 (default), 2x4, 2x2 on C2
-tag=${1:-r5p}; out=gpurun_out; mkdir -p $out
-timeout 900 python tools/ab_render.py --scenes cornell:512 --reps 2 --set "" --set MIW_FILM_COLUMNS=24 --set MIW_FILM_COLUMNS=22 --set MIW_FILM_COLUMNS=44 > $out/${tag}.txt 2> $out/${tag}.err; cat $out/${tag}.txt; tail -3 $out/${tag}.err
+# One GPU session of round 5 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
+# This one (r05): the round's profile session (tools/profile_round.sh: kernel stats, PMC passes, bench lines, every rank's shard),
+# smoke(), then the whole GPU tier.
+tag=${1:-r05}; out=gpurun_out; mkdir -p $out
+LEAN=1 bash tools/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1; tail -75 $out/${tag}_profile_round.log
+python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.txt 2>&1; tail -3 $out/${tag}_smoke.txt
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^$" | tail -12) > $out/${tag}_pytest_gpu.txt; tail -6 $out/${tag}_pytest_gpu.txt
