@@ -264,7 +264,11 @@ mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uin
     mi_ctx *r = ctxs[root];
     // everything the contexts still have in flight on their streams lands first
     for (int32_t i = 0; i < n; ++i) { HIP_TRY(r, hipSetDevice(ctxs[i]->device)); HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream)); }
-    if (n == 1 || count == 0) return MI_OK;
+    // (one context: nothing to add — unless MIW_RCCL_FORCE=1 asks for the RCCL branch anyway: a communicator of one rank, an in-place
+    // reduce that leaves the film as it is. That is how the branch — dlopen, ncclCommInitAll, the grouped ncclReduce, the stream
+    // waits — runs on a one-GPU box: tests/test_multi_gpu.py)
+    const bool force_rccl = getenv("MIW_RCCL_FORCE") && atoi(getenv("MIW_RCCL_FORCE")) != 0;
+    if (count == 0 || (n == 1 && !force_rccl)) return MI_OK;
     std::vector<int> devs(n);
     bool distinct = true;
     for (int32_t i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int32_t j = 0; j < i; ++j) distinct = distinct && devs[j] != devs[i]; }
@@ -292,6 +296,7 @@ mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uin
             return MI_OK;
         }
     }
+    if (n == 1) return MI_OK;                                   // (MIW_RCCL_FORCE without RCCL)
     // rank-ordered device add onto the root's film (contexts sharing a device, or no RCCL)
     HIP_TRY(r, hipSetDevice(r->device));
     TmpBuf<float> stage;

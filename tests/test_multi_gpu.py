@@ -79,3 +79,39 @@ def test_one_process_frame_over_three_contexts(native, oracle, tree):
     o32, _, ost = oracle.render(scene.desc(), native.PathIntegrator().render_job(sensor), threads=8, want_f64=False)
     assert ost.samples == c.samples and ost.segments == c.segments
     assert np.array_equal(full, o32)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_rccl_branch_of_the_film_reduce_runs_on_one_gpu(native, monkeypatch):
+    """The RCCL branch of mi_film_reduce (librccl by dlopen, ncclCommInitAll, one grouped ncclReduce(sum, float32) in place on the
+    root, the stream waits) needs distinct GPUs to be CHOSEN; with MIW_RCCL_FORCE=1 it also runs for one context — a communicator
+    of one rank, whose in-place reduce must leave the film bit for bit as it was. What a one-GPU box can check of that branch: the
+    library loads, the symbols resolve, the calls succeed in this process next to HIP."""
+    import ctypes as C
+    dev = native.Device(0)
+    try:
+        L = dev.L
+        n = 1920 * 1080 * 5
+        L.mi_film_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]; L.mi_film_alloc.restype = C.c_int
+        L.mi_film_free.argtypes = [C.c_void_p, C.c_void_p]; L.mi_film_free.restype = None
+        L.mi_film_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_uint64]; L.mi_film_download.restype = C.c_int
+        L.mi_film_reduce.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]; L.mi_film_reduce.restype = C.c_int
+        film = C.c_void_p()
+        assert L.mi_film_alloc(dev.ctx, n, C.byref(film)) == 0 and film.value
+        ramp = np.arange(n, dtype=np.float32) * np.float32(0.25)          # something recognisable in the film (exact: n < 2^24)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; hip.hipMemcpy.restype = C.c_int
+        assert hip.hipMemcpy(film, ramp.ctypes.data_as(C.c_void_p), n * 4, 1) == 0          # hipMemcpyHostToDevice
+        ctxs = (C.c_void_p * 1)(dev.ctx); films = (C.c_void_p * 1)(film); how = C.c_int32(-1)
+        assert L.mi_film_reduce(ctxs, films, 1, n, 0, C.byref(how)) == 0 and how.value == 0          # one context: nothing to do
+        monkeypatch.setenv("MIW_RCCL_FORCE", "1")
+        st = L.mi_film_reduce(ctxs, films, 1, n, 0, C.byref(how))
+        assert st == 0, dev.L.mi_last_error(dev.ctx)
+        assert how.value == 2, "the RCCL branch did not run (librccl missing on this box?)"          # MI_REDUCE_RCCL
+        out = np.zeros(n, np.float32)
+        assert L.mi_film_download(dev.ctx, film, out.ctypes.data_as(C.POINTER(C.c_float)), n) == 0
+        assert np.array_equal(out, ramp)
+        L.mi_film_free(dev.ctx, film)
+    finally:
+        dev.close()

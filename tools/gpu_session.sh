@@ -1,10 +1,9 @@
 #!/bin/bash
-# r5r: instruction-cache counters of the phase machine (57.7 KB of code against a 64 KB instruction cache shared by two CUs)
-tag=${1:-r5r}; out=$(pwd)/gpurun_out; mkdir -p $out
-export TMPDIR=/tmp MIW_BENCH_NO_LIVE=1
-repo=$(pwd)
-for sc in "c3 --scene matball --spp 64" "c4 --scene interior --spp 16" "c2 --spp 128"; do
-  set -- $sc; name=$1; shift
-  ( cd /tmp; timeout 150 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/${tag}_${name}_icache -- python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $* > $out/${tag}_${name}_icache.log 2>&1; echo "rc $?" )
-done
-for n in c3 c4 c2; do python tools/rocprof_summary.py pmc $out/${tag}_${n}_icache; done 2>&1 | grep "k_path" | cut -c1-300
+# One GPU session of round 5 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
+# This one (r05): the round's profile session (tools/profile_round.sh: kernel stats, PMC passes, bench lines, every rank's shard),
+# smoke(), then the whole GPU tier.
+tag=${1:-r05}; out=$(pwd)/gpurun_out; mkdir -p $out
+rm -rf $out/${tag}_*_pmc[1-4] $out/${tag}_*_trace          # (a second session under the same tag must not add its counters to the first's)
+LEAN=1 bash tools/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1; tail -75 $out/${tag}_profile_round.log
+python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.txt 2>&1; tail -3 $out/${tag}_smoke.txt
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^$" | tail -12) > $out/${tag}_pytest_gpu.txt; tail -6 $out/${tag}_pytest_gpu.txt
