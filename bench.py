@@ -250,10 +250,16 @@ def spawn_ranks(n, argv):
 
 
 def film_kernel_name(log_record_bytes):
-    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_COLUMNS switch)"""
+    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_QUADS / MIW_FILM_COLUMNS switches)"""
     if log_record_bytes != 16:
         return "k_film_blocks"
-    return "k_film_groups" if os.environ.get("MIW_FILM_COLUMNS") == "0" else "k_film_columns"
+    env = os.environ
+    quads = env.get("MIW_FILM_COLUMNS") is None and env.get("MIW_FILM_GROUP") is None
+    if env.get("MIW_FILM_QUADS") is not None:
+        quads = env["MIW_FILM_QUADS"] not in ("0", "")
+    if quads:
+        return "k_film_quads"
+    return "k_film_groups" if env.get("MIW_FILM_COLUMNS") == "0" else "k_film_columns"
 
 
 def reduce_label(backend):

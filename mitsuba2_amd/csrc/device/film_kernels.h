@@ -434,6 +434,199 @@ __global__ __launch_bounds__(64) void k_film_columns(FilmRec F, BlockReplayArgs 
         }
 }
 
+// ---- the group replay without the record's trip through LDS (round 5) ----
+//
+// k_film_columns<4,2> is bound by the LDS pipe (one 16-byte record + three weights per lane and sample, the staging writes, two
+// barriers per trip) and behind that by VALU issue: ~24 vector instructions per (lane, sample) of which 9 are the sums. Here a
+// group of GW x GH texels is GW lanes INSIDE A DPP QUAD (GW = 2: two groups per quad; GW = 4: one), a lane owning a column of GH
+// texels:
+//  * lane li of a group loads the records GW i + li of a trip straight into registers (the group's loads are GW x 16 contiguous
+//    bytes) and DECODES ITS OWN records once — the byte offsets of the two class rows in the LDS weight table, alpha as a float —
+//    so the decoding costs 1 / GW per sample; a record past the end of its run gets the table's zero row;
+//  * every record then reaches the group's other lanes by quad_perm DPP operands: X, Y, Z and alpha as v_mov_b32_dpp, the two
+//    row offsets inside the v_add_u32_dpp that forms the lane's LDS addresses (row offset + the lane's place in the window);
+//  * what is left for the LDS is the class table: one x weight per lane and sample and the GH y weights of its column
+//    (neighbours in a class's row, which carries zeros in front and behind: "row outside the window" is an index, not a select);
+//  * the sums are packed float32 instructions over pairs of rows (v_pk_mul_f32 / v_pk_add_f32: two IEEE products / sums each).
+// A column of 4 texels under a 2-wide group (the default, k_film_quads<2, 4>) walks a 6 x 8 pixel window for 8 texels: the same
+// 48 pixels per group as 4 x 2, i.e. the same log traffic, but ~31 vector instructions per (lane, sample) serve FOUR texels
+// (4 x 2 in this form: ~18 for two; k_film_columns<4, 2>: ~24 + the staging for two).
+// Groups are numbered through ALL tiles (a wave takes 64 / GW consecutive groups, which may straddle two tiles): 36 x 36
+// texels are 162 groups, and whole waves per tile would leave one lane in six idle.
+// No staging buffer, no barrier in the loop; a pixel's count comes from an LDS table filled once per wavefront, so the first
+// trip of the NEXT pixel is in flight during the last trip of this one. The float32 additions of a texel are k_film_columns'
+// (its group's pixels in Morton order, each pixel's samples front to back, w = wy * wx, value * w, alpha (0 or 1) * w): the tiles
+// are bit-identical.
+// LDS layout of a class's weights here, for columns of GH texels: GH - 1 zeros, w[0 .. 2 reach], zeros up to an odd stride of 5 + 2 GH
+// (at least GH + 1 behind the window: "every row of the column outside the window" is the index 5 + GH - 1)
+#define MIW_FQ_WSTRIDE(GH) (5 + 2 * (GH))
+#ifndef MIW_FQ_FENCE
+#define MIW_FQ_FENCE 1
+#endif
+typedef const __attribute__((address_space(3))) float miw_lds_cf;
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm_u32(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
+template <int GW, int GH, int U>
+__global__ __launch_bounds__(64) void k_film_quads(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = groups per tile row / column */, uint32_t n_tiles, float *tiles) {
+    constexpr int NG = 64 / GW, LCAP = (GW + 4) * (GH + 4), TRIP = U * GW /* U records per lane and trip */, WS = MIW_FQ_WSTRIDE(GH), LEAD = GH - 1;
+    static_assert(GW == 2 || GW == 4, "a group lives inside a DPP quad");
+    static_assert(GH % 2 == 0, "rows are summed in pairs");
+    extern __shared__ float s_w[];                           // (count + 1) x WS weights; row `count` = 0
+    __shared__ unsigned short s_list[NG][LCAP];
+    __shared__ uint32_t s_cnt[NG][LCAP];
+    __shared__ uint32_t s_m[NG];
+    const uint32_t l = threadIdx.x;
+    const uint32_t n_groups = PA.patches_x * PA.patches_y;   // per tile; >= NG (the host launches k_film_columns otherwise): a wave meets two tiles at most
+    const uint32_t G0 = blockIdx.x * (uint32_t) NG, tile0 = G0 / n_groups, r0 = G0 % n_groups;
+    const uint32_t h = l / GW, li = l % GW;
+    const bool mine_second = r0 + h >= n_groups;
+    const uint32_t tile = tile0 + (mine_second ? 1u : 0u), my_gid = r0 + h - (mine_second ? n_groups : 0u);
+    const bool my_live = tile < n_tiles;
+    const BlockGeom g0 = block_geom(F, A.blocks_x, A.tile_list ? A.tile_list[tile0 < n_tiles ? tile0 : 0u] : tile0);
+    const BlockGeom g1 = block_geom(F, A.blocks_x, A.tile_list ? A.tile_list[tile0 + 1u < n_tiles ? tile0 + 1u : 0u] : tile0 + 1u);
+    const BlockGeom g = mine_second ? g1 : g0;
+    const int tx = (int) (my_gid % PA.patches_x) * GW + (int) li, ty0 = (int) (my_gid / PA.patches_x) * GH;
+    const uint32_t rej = A.cls.count;                        // the zero row (LogSink16 logs rejected samples with class `count`)
+    const int reach = A.cls.reach;
+    for (uint32_t i = l; i < (rej + 1u) * WS; i += 64u) {
+        const uint32_t c = i / WS, a = i % WS;
+        s_w[i] = (c < rej && a >= (uint32_t) LEAD && a <= (uint32_t) LEAD + 2u * (uint32_t) reach) ? A.cls.w[c * MIW_FC_STRIDE + a - LEAD] : 0.f;
+    }
+    // ---- per group: the pixels within reach of the group, in Morton order (as k_film_columns) ----
+    const uint32_t bs2 = 1u << A.bs2_log2;
+    const uint32_t gx_first = r0 % PA.patches_x, gy_first = r0 / PA.patches_x;
+    uint32_t fill[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) fill[i] = 0;
+    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
+        const uint32_t q = q0 + l;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        const bool pixel0 = q < bs2 && (int) x < g0.bw && (int) y < g0.bh, pixel1 = q < bs2 && (int) x < g1.bw && (int) y < g1.bh;
+        uint32_t gx = gx_first, gy = gy_first;
+        bool second = false;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int gx0 = (int) gx * GW, gy0 = (int) gy * GH;
+            const bool live = (second ? tile0 + 1u : tile0) < n_tiles && gx0 < (second ? g1.size_x : g0.size_x) && gy0 < (second ? g1.size_y : g0.size_y);
+            const bool in = (second ? pixel1 : pixel0) && live &&
+                            (int) x >= gx0 - F.border - reach && (int) x <= gx0 + GW - 1 - F.border + reach &&
+                            (int) y >= gy0 - F.border - reach && (int) y <= gy0 + GH - 1 - F.border + reach;
+            const unsigned long long m = __ballot(in);
+            if (in) {
+                const uint32_t at = fill[i] + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
+                if (at < (uint32_t) LCAP) s_list[i][at] = (unsigned short) q;
+            }
+            fill[i] += (uint32_t) __popcll(m);
+            if (++gx == PA.patches_x) { gx = 0; if (++gy == PA.patches_y) { gy = 0; second = true; } }
+        }
+    }
+    uint32_t max_m = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const uint32_t m = fill[i] < (uint32_t) LCAP ? fill[i] : (uint32_t) LCAP;
+        if (l == 0) s_m[i] = m;
+        max_m = m > max_m ? m : max_m;
+    }
+    __syncthreads();
+    const uint32_t lane0 = tile << A.bs2_log2;
+    for (uint32_t i = l; i < (uint32_t) (NG * LCAP); i += 64u) {          // every listed pixel's number of logged samples, once
+        const uint32_t gi = i / LCAP, k = i % LCAP;
+        const uint32_t t = tile0 + (r0 + gi >= n_groups ? 1u : 0u);
+        s_cnt[gi][k] = k < s_m[gi] ? A.st[(t << A.bs2_log2) + s_list[gi][k]].w : 0u;
+    }
+    __syncthreads();
+
+    float acc[GH][MIW_FILM_CHANNELS];
+#pragma unroll
+    for (int r = 0; r < GH; ++r)
+#pragma unroll
+        for (int k = 0; k < MIW_FILM_CHANNELS; ++k) acc[r][k] = 0.f;
+    const uint32_t my_m = s_m[h];
+    const uint32_t w_base = (uint32_t) (uintptr_t) (miw_lds_cf *) s_w;
+    const uint32_t off_rej = rej * (uint32_t) (WS * 4);
+    // a step = the k-th pixel of every group. Per lane: the pixel's run in the log, its count, the LDS byte address of the lane's
+    // x weight and of its column's first y weight inside class 0's row (the zeros in front of and behind the window: "outside")
+    struct Step { const U4 *run; uint32_t cnt, bx, by; };
+    auto step_of = [&](uint32_t k) {
+        Step s; s.run = A.log_rec; s.cnt = 0u; s.bx = w_base + 4u * (5u + LEAD); s.by = s.bx;
+        if (k < my_m) {
+            const uint32_t q = s_list[h][k];
+            uint32_t x, y;
+            morton_decode2(q, x, y);
+            const int ax = tx - ((int) x + F.border - reach), ay = ty0 - ((int) y + F.border - reach);
+            if ((uint32_t) ax <= (uint32_t) (2 * reach)) s.bx = w_base + 4u * (uint32_t) (ax + LEAD);
+            if ((uint32_t) (ay + LEAD) <= (uint32_t) (2 * reach + LEAD)) s.by = w_base + 4u * (uint32_t) (ay + LEAD);
+            s.cnt = s_cnt[h][k]; s.run = A.log_rec + (size_t) (lane0 + q) * A.spp;
+        }
+        return s;
+    };
+    // the loads are unconditional and clamped into the run (a record past its end gets the zero row when it is decoded; logged
+    // values are finite: value * 0 adds nothing), so nothing waits at a branch's end. Record i of the next trip is requested as
+    // soon as record i of this trip has been decoded: most of a trip to arrive, no second buffer
+    uint4 nxt[U];
+    auto fetch_one = [&](int i, const U4 *run, uint32_t last, uint32_t j0) {
+        const uint32_t j = j0 + (uint32_t) (GW * i) + li;
+        const U4 t = run[j < last ? j : last];
+        nxt[i] = make_uint4(t.x, t.y, t.z, t.w);
+    };
+    auto fetch = [&](const U4 *run, uint32_t cnt, uint32_t j0) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            fetch_one(i, run, cnt ? cnt - 1u : 0u, j0);
+            __builtin_amdgcn_sched_barrier(0);           // record 0 first, as inside the loop: its consumer then waits for vmcnt(U - 1), not for all of them
+        }
+    };
+    Step cur = step_of(0);
+    fetch(cur.run, cur.cnt, 0u);
+    for (uint32_t k = 0; k < max_m; ++k) {
+        const uint32_t step_max = wave_max_u32(cur.cnt);
+        const Step nx = step_of(k + 1u);
+        for (uint32_t j0 = 0; j0 < step_max; j0 += (uint32_t) TRIP) {
+            const bool last_trip = j0 + (uint32_t) TRIP >= step_max;                  // (wave-uniform) then: the next pixel's first trip
+            const U4 *t_run = last_trip ? nx.run : cur.run;
+            const uint32_t t_cnt = last_trip ? nx.cnt : cur.cnt, t_last = t_cnt ? t_cnt - 1u : 0u, t_j0 = last_trip ? 0u : j0 + (uint32_t) TRIP;
+            auto one = [&](float vx, float vy, float vz, float va, uint32_t ax, uint32_t ay) {
+                const float wx = *(miw_lds_cf *) (uintptr_t) ax;
+                miw_lds_cf *wy = (miw_lds_cf *) (uintptr_t) ay;
+#pragma unroll
+                for (int q = 0; q < GH; ++q) {
+                    const float w = wy[q] * wx;                              // wy * wx, imageblock.cpp:155
+                    acc[q][0] += vx * w; acc[q][1] += vy * w; acc[q][2] += vz * w;
+                    acc[q][3] += va * w;                                     // alpha (0 or 1) * w
+                    acc[q][4] += w;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                // this lane's record of the quartet: decoded once, for the whole group
+                const uint4 r = nxt[i];
+                const bool valid = j0 + (uint32_t) (GW * i) + li < cur.cnt;
+                const uint32_t ox = valid ? (r.w & 255u) * (uint32_t) (WS * 4) : off_rej, oy = valid ? ((r.w >> 8) & 255u) * (uint32_t) (WS * 4) : off_rej;
+                const uint32_t af = (r.w & 0x10000u) ? 0x3f800000u : 0u;
+                fetch_one(i, t_run, t_last, t_j0);                                 // (after the copy-out: into the same registers)
+#define MIW_FQ_ONE(C) one(u2f(quad_perm_u32<C>(r.x)), u2f(quad_perm_u32<C>(r.y)), u2f(quad_perm_u32<C>(r.z)), u2f(quad_perm_u32<C>(af)), \
+                          quad_perm_u32<C>(ox) + cur.bx, quad_perm_u32<C>(oy) + cur.by)
+                if (GW == 4) { MIW_FQ_ONE(0x00); MIW_FQ_ONE(0x55); MIW_FQ_ONE(0xAA); MIW_FQ_ONE(0xFF); }
+                else { MIW_FQ_ONE(0xA0); MIW_FQ_ONE(0xF5); }                       // quad_perm [0,0,2,2], [1,1,3,3]: the pair's first / second lane
+#undef MIW_FQ_ONE
+#if MIW_FQ_FENCE
+                __builtin_amdgcn_sched_barrier(0);                                 // one record's samples at a time: the scheduler otherwise spreads all of a trip's broadcasts out first (registers)
+#endif
+            }
+        }
+        if (step_max == 0u) fetch(nx.run, nx.cnt, 0u);                             // (a step without samples consumed nothing)
+        cur = nx;
+    }
+#pragma unroll
+    for (int r = 0; r < GH; ++r)
+        if (my_live && tx < g.size_x && ty0 + r < g.size_y) {
+            float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) (ty0 + r) * g.size_x + tx) * MIW_FILM_CHANNELS;
+#pragma unroll
+            for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = acc[r][k];
+        }
+}
+
 // step 2: every film texel sums the block tiles covering it, ascending block id
 __global__ void k_film_merge(FilmRec F, BlockReplayArgs A, const float *tiles, float *out32, double *out64, int accumulate) {
     int fx = (int) (blockIdx.x * blockDim.x + threadIdx.x), fy = (int) blockIdx.y;

@@ -1733,9 +1733,28 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
                                    const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
                                    MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
+                    // round 5: groups of 2 x 4 texels inside DPP quads, the records broadcast by quad_perm operands instead of staged through
+                    // LDS (k_film_quads<2, 4>, the default; MIW_FILM_QUADS = 42 / 28 / 44: other group shapes, = 0: the kernels below — also
+                    // taken when a tile has fewer groups than a wavefront takes, i.e. tiny blocks)
                     int columns = 42;
                     if (const char *e = getenv("MIW_FILM_COLUMNS")) columns = atoi(e);
-                    if (columns == 42) MIW_FC_LAUNCH(4, 2); else if (columns == 44) MIW_FC_LAUNCH(4, 4); else if (columns == 82) MIW_FC_LAUNCH(8, 2);
+                    int quads = getenv("MIW_FILM_COLUMNS") == nullptr && getenv("MIW_FILM_GROUP") == nullptr ? 24 : 0;
+                    if (const char *e = getenv("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 24 : atoi(e);
+                    if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
+                    const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
+                    if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
+                    if (quads) {
+                        PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
+                        const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);
+                        const size_t qbytes = (size_t) (c->classes.count + 1u) * (size_t) (5u + 2u * qh) * sizeof(float);
+#define MIW_FQ_LAUNCH(GW, GH, U) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH, U>), dim3(waves), dim3(64), qbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p))
+                        int fq_u = 4;
+                        if (const char *e = getenv("MIW_FQ_U")) fq_u = atoi(e);
+                        if (quads == 24) { if (fq_u == 8) MIW_FQ_LAUNCH(2, 4, 8); else if (fq_u == 2) MIW_FQ_LAUNCH(2, 4, 2); else MIW_FQ_LAUNCH(2, 4, 4); }
+                        else if (quads == 42) { if (fq_u == 8) MIW_FQ_LAUNCH(4, 2, 8); else MIW_FQ_LAUNCH(4, 2, 4); }
+                        else if (quads == 28) MIW_FQ_LAUNCH(2, 8, 4); else MIW_FQ_LAUNCH(4, 4, 4);
+#undef MIW_FQ_LAUNCH
+                    } else if (columns == 42) MIW_FC_LAUNCH(4, 2); else if (columns == 44) MIW_FC_LAUNCH(4, 4); else if (columns == 82) MIW_FC_LAUNCH(8, 2);
                     else if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
 #undef MIW_FC_LAUNCH
 #undef MIW_FG_LAUNCH

@@ -52,9 +52,14 @@ def test_reduce_is_labelled_by_the_backend_in_use():
 
 def test_bench_names_the_film_kernel_that_runs(monkeypatch):
     """VERDICT r04 (measurement hygiene 12): the line's kernel_ms named k_film_groups while k_film_columns<4,2> ran. The label follows
-    the log format and the MIW_FILM_COLUMNS switch mi_render reads (csrc/miwave.hip)."""
+    the log format and the MIW_FILM_QUADS / MIW_FILM_COLUMNS switches mi_render reads (csrc/miwave.hip)."""
     import bench
-    monkeypatch.delenv("MIW_FILM_COLUMNS", raising=False)
-    assert bench.film_kernel_name(16) == "k_film_columns" and bench.film_kernel_name(24) == "k_film_blocks"
+    for k in ("MIW_FILM_COLUMNS", "MIW_FILM_GROUP", "MIW_FILM_QUADS"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.film_kernel_name(16) == "k_film_quads" and bench.film_kernel_name(24) == "k_film_blocks"
+    monkeypatch.setenv("MIW_FILM_QUADS", "0")
+    assert bench.film_kernel_name(16) == "k_film_columns"
     monkeypatch.setenv("MIW_FILM_COLUMNS", "0")
     assert bench.film_kernel_name(16) == "k_film_groups"
+    monkeypatch.delenv("MIW_FILM_QUADS")
+    assert bench.film_kernel_name(16) == "k_film_groups"                      # naming a column / group shape selects those kernels

@@ -265,6 +265,31 @@ def test_render_float32_film_and_host_classes(native, oracle, cbox):
     assert c.samples == 96 * 64 * 8 and c.bvh_tris == 32
 
 
+@pytest.mark.parametrize("rfilter", ["gaussian", "tent", "box", "mitchell", "catmullrom"])
+def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
+    """The ordered film (film_mode 1) through k_film_quads (the default: 2 x 4 texel groups inside DPP quads; and its 4 x 2, 2 x 8, 4 x 4
+    shapes), k_film_columns<4,2> and k_film_groups: the same float32 additions per texel, so the same film bit for bit, and the oracle's. A ragged film with a crop
+    window, 11 spp (trips of 16 records end inside a run)."""
+    from mitsuba2_amd import scenes
+    films = {}
+    for name, env in (("quads", {}), ("quads42", {"MIW_FILM_QUADS": "42"}), ("quads28", {"MIW_FILM_QUADS": "28"}), ("quads44", {"MIW_FILM_QUADS": "44"}),
+                      ("columns", {"MIW_FILM_QUADS": "0"}), ("groups", {"MIW_FILM_COLUMNS": "0"})):
+        for k in ("MIW_FILM_QUADS", "MIW_FILM_COLUMNS", "MIW_FILM_GROUP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scene, sensor = scenes.cornell_box(150, 83, 11, device=0, seed=77, rfilter=rfilter,
+                                           crop_offset_x=7, crop_offset_y=2, crop_width=131, crop_height=70)
+        integ = native.PathIntegrator()
+        assert integ.render(scene, sensor) is True
+        films[name] = sensor.film.data((70, 131, 5)).copy()
+        if name == "quads":
+            o32, _, _ = oracle.render(scene.desc(), integ.render_job(sensor), threads=8)
+    assert np.array_equal(films["quads"], o32)
+    for name in films:
+        assert np.array_equal(films[name], o32), name
+
+
 def test_render_samples_per_pass(native, oracle, dev):
     """samples_per_pass < sample_count (integrator.cpp:75-86) through the host classes: three passes of 2 spp, each
     seeded from its own block ids and accumulated onto the film (mi_render_cfg::accumulate) == the oracle run the
