@@ -250,10 +250,15 @@ def spawn_ranks(n, argv):
 
 
 def film_kernel_name(log_record_bytes):
-    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_QUADS / MIW_FILM_COLUMNS switches)"""
+    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_LANES / _QUADS / _COLUMNS switches)"""
     if log_record_bytes != 16:
         return "k_film_blocks"
     env = os.environ
+    lanes = all(env.get(k) is None for k in ("MIW_FILM_COLUMNS", "MIW_FILM_GROUP", "MIW_FILM_QUADS"))
+    if env.get("MIW_FILM_LANES") is not None:
+        lanes = env["MIW_FILM_LANES"] not in ("0", "")
+    if lanes:
+        return "k_film_lanes"
     quads = env.get("MIW_FILM_COLUMNS") is None and env.get("MIW_FILM_GROUP") is None
     if env.get("MIW_FILM_QUADS") is not None:
         quads = env["MIW_FILM_QUADS"] not in ("0", "")

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_film_columns(FilmRec F, BlockReplayArgs 
 // (at least GH + 1 behind the window: "every row of the column outside the window" is the index 5 + GH - 1)
 #define MIW_FQ_WSTRIDE(GH) (5 + 2 * (GH))
 #ifndef MIW_FQ_FENCE
-#define MIW_FQ_FENCE 1
+#define MIW_FQ_FENCE 0
 #endif
 typedef const __attribute__((address_space(3))) float miw_lds_cf;
 template <int CTRL>
@@ -625,6 +625,209 @@ __global__ __launch_bounds__(64) void k_film_quads(FilmRec F, BlockReplayArgs A,
 #pragma unroll
             for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = acc[r][k];
         }
+}
+
+// ---- one texel block per lane (round 5, the default for the filters with class tables) ----
+//
+// PMC passes over k_film_quads<2, 4> (profiles/r05_film_*): the SIMDs issue an instruction in ~96 % of their cycles, ~38 per (lane,
+// sample) for four texels of which 25 / 48 lie in the sample's footprint — the replay is bound by instruction issue, and most of
+// what it issues multiplies by a zero weight. Here
+//  * a LANE owns a block of 4 x 4 texels of one tile (80 sums in registers) and streams the samples of the 8 x 8 pixels within
+//    reach itself: no records shared between lanes, so nothing to broadcast, and a pixel's run is read by 4 blocks instead of 6
+//    groups (log traffic x 4 instead of x 6);
+//  * a WAVEFRONT is the same block position in 64 consecutive tiles: all its lanes are at the same tile-relative pixel at every
+//    step (tiles are aligned to the block size, so the Morton order of a window is the same in every tile), hence which of the
+//    block's rows and columns the pixel's footprint covers is WAVE-UNIFORM: the pixel's run is replayed by a copy of the sample loop
+//    specialised for that range of rows and of column pairs (30 copies, a jump per pixel), which issues the products and sums of
+//    the covered texels only — 20 x 12 of 32 x 16 (row, column pair) slots over a window, 47 % of the block's 64 x 8;
+//  * sums and products are packed float32 over pairs of columns (v_pk_mul_f32 / v_pk_add_f32, two IEEE operations each).
+// Lanes of a clipped tile (the film's last row / column of blocks) idle through the pixels their block does not have.
+// The float32 additions of a texel are those of the other replay kernels (the tile's pixels in Morton order, each pixel's samples
+// front to back, w = wy * wx, value * w, alpha (0 or 1) * w; a covered texel outside a sample's own footprint — a pair's second
+// column — adds value * 0): the tiles are bit-identical.
+typedef float miw_f2 __attribute__((ext_vector_type(2)));
+#define MIW_FL_BS 4
+#ifndef MIW_FL_FENCE
+#define MIW_FL_FENCE 0
+#endif
+#ifndef MIW_FL_ASM
+#define MIW_FL_ASM 1
+#endif
+// sum += x, both halves, IN PLACE: written as the instruction so that the 40 register pairs of sums stay where they are through all
+// the copies of the sample loop (as plain C++ the compiler gives every copy's sums registers of its own and moves them at each
+// loop's end: 298 registers, one wavefront per SIMD)
+__device__ __forceinline__ void film_pk_acc(miw_f2 &sum, const miw_f2 x) {
+#if MIW_FL_ASM
+    asm("v_pk_add_f32 %0, %0, %1" : "+v"(sum) : "v"(x));
+#else
+    sum += x;
+#endif
+}
+template <int R0, int R1, int P0, int P1, int U>
+__device__ __forceinline__ void film_lanes_pixel(miw_f2 (&acc)[MIW_FL_BS][MIW_FL_BS / 2][MIW_FILM_CHANNELS], uint4 (&nxt)[U], uint32_t cnt,
+                                                 const U4 *n_run, uint32_t n_cnt, const U4 *run, uint32_t step_max,
+                                                 uint32_t bxa, uint32_t bya, uint32_t off_rej, uint32_t js) {
+    constexpr uint32_t WS4 = MIW_FQ_WSTRIDE(MIW_FL_BS) * 4;
+    for (uint32_t j0 = 0; j0 < step_max; j0 += (uint32_t) U) {
+        const bool last_trip = j0 + (uint32_t) U >= step_max;                    // (wave-uniform) then: the next pixel's first trip
+        const U4 *t_run = last_trip ? n_run : run;
+        const uint32_t t_cnt = last_trip ? n_cnt : cnt, t_last = t_cnt ? t_cnt - 1u : 0u, t_j0 = last_trip ? 0u : j0 + (uint32_t) U;
+        // this trip's records move out of the landing registers and the next trip's U loads are issued TOGETHER: a lane's U records
+        // are 16 U contiguous bytes of its own tile's log, and the 64 lanes of a load touch 64 different cache lines — issued apart
+        // (one load per consumed record) every one of them fetches its line's sector from L2 again (measured: 2 x slower than
+        // k_film_quads); issued back to back the line is fetched once
+        uint4 rec[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) rec[i] = nxt[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t j = t_j0 + (uint32_t) i;
+            const U4 t = t_run[(j < t_last ? j : t_last) * js];
+            nxt[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint4 r = rec[i];
+            const bool valid = j0 + (uint32_t) i < cnt;
+            const uint32_t ox = valid ? (r.w & 255u) * WS4 : off_rej, oy = valid ? ((r.w >> 8) & 255u) * WS4 : off_rej;
+            const float af = (r.w & 0x10000u) ? 1.f : 0.f, vx = u2f(r.x), vy = u2f(r.y), vz = u2f(r.z);
+            miw_lds_cf *px = (miw_lds_cf *) (uintptr_t) (ox + bxa), *py = (miw_lds_cf *) (uintptr_t) (oy + bya);
+            miw_f2 wx[MIW_FL_BS / 2];
+#pragma unroll
+            for (int p = P0; p <= P1; ++p) { wx[p].x = px[2 * p]; wx[p].y = px[2 * p + 1]; }
+#pragma unroll
+            for (int q = R0; q <= R1; ++q) {
+                const float wy = py[q];
+#pragma unroll
+                for (int p = P0; p <= P1; ++p) {
+                    const miw_f2 w = wy * wx[p];                                  // wy * wx, imageblock.cpp:155
+                    film_pk_acc(acc[q][p][0], vx * w); film_pk_acc(acc[q][p][1], vy * w); film_pk_acc(acc[q][p][2], vz * w);
+                    film_pk_acc(acc[q][p][3], af * w);                            // alpha (0 or 1) * w
+                    film_pk_acc(acc[q][p][4], w);
+                }
+#if MIW_FL_FENCE
+                __builtin_amdgcn_sched_barrier(0);                                // one row of one sample at a time (registers: the scheduler otherwise forms a trip's products first)
+#endif
+            }
+        }
+    }
+}
+#ifndef MIW_FL_WAVES
+#define MIW_FL_WAVES 3
+#endif
+template <int U>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES, 8))) void k_film_lanes(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = texel blocks per tile row / column */, uint32_t n_tiles, float *tiles) {
+    constexpr int BS = MIW_FL_BS, WS = MIW_FQ_WSTRIDE(MIW_FL_BS), LEAD = BS - 1, LCAP = 64;
+    extern __shared__ float s_w[];                           // (count + 1) x WS weights; row `count` = 0
+    __shared__ unsigned short s_list[LCAP];
+    const uint32_t l = threadIdx.x;
+    const uint32_t n_pos = PA.patches_x * PA.patches_y;
+    const uint32_t tw = blockIdx.x / n_pos, pos = blockIdx.x % n_pos;
+    const int tx0 = (int) (pos % PA.patches_x) * BS, ty0 = (int) (pos / PA.patches_x) * BS;      // (wave-uniform) the block inside its tile
+    const uint32_t tile = tw * 64u + l;
+    const bool live = tile < n_tiles;
+    const BlockGeom g = block_geom(F, A.blocks_x, live ? (A.tile_list ? A.tile_list[tile] : tile) : 0u);
+    const uint32_t rej = A.cls.count;                        // the zero row (LogSink16 logs rejected samples with class `count`)
+    const int reach = A.cls.reach;                           // <= 2 (the host launches the other kernels otherwise)
+    for (uint32_t i = l; i < (rej + 1u) * WS; i += 64u) {
+        const uint32_t c = i / WS, a = i % WS;
+        s_w[i] = (c < rej && a >= (uint32_t) LEAD && a <= (uint32_t) LEAD + 2u * (uint32_t) reach) ? A.cls.w[c * MIW_FC_STRIDE + a - LEAD] : 0.f;
+    }
+    // ---- the pixels within reach of the block, in Morton order: the same list in every tile ----
+    const uint32_t bs2 = 1u << A.bs2_log2;
+    uint32_t fill = 0;
+    for (uint32_t q0 = 0; q0 < bs2; q0 += 64u) {
+        const uint32_t q = q0 + l;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        const bool in = q < bs2 && (int) x >= tx0 - F.border - reach && (int) x <= tx0 + BS - 1 - F.border + reach &&
+                        (int) y >= ty0 - F.border - reach && (int) y <= ty0 + BS - 1 - F.border + reach;
+        const unsigned long long m = __ballot(in);
+        if (in) {
+            const uint32_t at = fill + (uint32_t) __popcll(m & ((1ull << l) - 1ull));
+            if (at < (uint32_t) LCAP) s_list[at] = (unsigned short) q;
+        }
+        fill += (uint32_t) __popcll(m);
+    }
+    const uint32_t n_list = fill < (uint32_t) LCAP ? fill : (uint32_t) LCAP;
+    __syncthreads();
+
+    miw_f2 acc[BS][BS / 2][MIW_FILM_CHANNELS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int p = 0; p < BS / 2; ++p)
+#pragma unroll
+            for (int k = 0; k < MIW_FILM_CHANNELS; ++k) acc[r][p][k] = (miw_f2) (0.f);
+    const uint32_t w_base = (uint32_t) (uintptr_t) (miw_lds_cf *) s_w;
+    const uint32_t off_rej = rej * (uint32_t) (WS * 4);
+    // the log: [lane][sample], or (A.log_il, path.h: log_index) the logs of the wave's 64 tiles interleaved record by record — then
+    // the 64 records a load fetches are 1 KB of consecutive bytes
+    const uint32_t lane0 = tile << A.bs2_log2;
+    const uint32_t js = A.log_il ? 64u : 1u;
+    // a step = the k-th pixel of the list, in every tile of the wave. Per lane: the pixel's run in its tile's log and its count
+    struct Step { const U4 *run; uint32_t cnt; };
+    auto pixel_at = [&](uint32_t k) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) (k < n_list ? (uint32_t) s_list[k] : 0u)); };
+    auto step_of = [&](uint32_t k, uint32_t q) {
+        Step s; s.run = A.log_rec; s.cnt = 0u;
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        if (k < n_list && live && (int) x < g.bw && (int) y < g.bh) { s.cnt = A.st[lane0 + q].w; s.run = A.log_rec + log_index(A.log_il, lane0 + q, A.spp, 0u); }
+        return s;
+    };
+    uint4 nxt[U];
+    auto fetch = [&](const U4 *run, uint32_t cnt) {
+        const uint32_t last = cnt ? cnt - 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const U4 t = run[((uint32_t) i < last ? (uint32_t) i : last) * js];
+            nxt[i] = make_uint4(t.x, t.y, t.z, t.w);
+            __builtin_amdgcn_sched_barrier(0);           // record 0 first, as inside the loop
+        }
+    };
+    uint32_t q = pixel_at(0u);
+    Step cur = step_of(0u, q);
+    fetch(cur.run, cur.cnt);
+    for (uint32_t k = 0; k < n_list; ++k) {
+        const uint32_t step_max = (uint32_t) __builtin_amdgcn_readfirstlane((int) wave_max_u32(cur.cnt));   // (a scalar for the compiler: the sample loops are uniform loops)
+        const uint32_t qn = pixel_at(k + 1u);
+        const Step nx = step_of(k + 1u, qn);
+        uint32_t x, y;
+        morton_decode2(q, x, y);
+        // texel column tx0 + c takes the weight w[ax + c] of the pixel's window (0 <= ax + c <= 2 reach), rows alike
+        const int ax = tx0 - ((int) x + F.border - reach), ay = ty0 - ((int) y + F.border - reach);
+        const int c0 = ax < 0 ? -ax : 0, c1 = 2 * reach - ax < BS - 1 ? 2 * reach - ax : BS - 1;
+        const int r0 = ay < 0 ? -ay : 0, r1 = 2 * reach - ay < BS - 1 ? 2 * reach - ay : BS - 1;
+        const uint32_t bxa = w_base + 4u * (uint32_t) (LEAD + ax), bya = w_base + 4u * (uint32_t) (LEAD + ay);
+        const int code = __builtin_amdgcn_readfirstlane(((r0 * 4 + r1) * 2 + (c0 >> 1)) * 2 + (c1 >> 1));
+#define MIW_FL_CASE(R0, R1, P0, P1) case ((R0 * 4 + R1) * 2 + P0) * 2 + P1: \
+            film_lanes_pixel<R0, R1, P0, P1, U>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js); break;
+#define MIW_FL_ROWS(R0, R1) MIW_FL_CASE(R0, R1, 0, 0) MIW_FL_CASE(R0, R1, 0, 1) MIW_FL_CASE(R0, R1, 1, 1)
+#if MIW_FL_ONECASE
+        (void) code; film_lanes_pixel<0, 3, 0, 1, U>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js);
+#else
+        switch (code) {
+            MIW_FL_ROWS(0, 0) MIW_FL_ROWS(0, 1) MIW_FL_ROWS(0, 2) MIW_FL_ROWS(0, 3) MIW_FL_ROWS(1, 1) MIW_FL_ROWS(1, 2) MIW_FL_ROWS(1, 3)
+            MIW_FL_ROWS(2, 2) MIW_FL_ROWS(2, 3) MIW_FL_ROWS(3, 3)
+            default: break;
+        }
+#endif
+#undef MIW_FL_ROWS
+#undef MIW_FL_CASE
+        if (step_max == 0u) fetch(nx.run, nx.cnt);                                 // (a step without samples consumed nothing)
+        cur = nx; q = qn;
+    }
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c)
+            if (live && tx0 + c < g.size_x && ty0 + r < g.size_y) {
+                float *out = tiles + (size_t) tile * A.tile_stride + ((size_t) (ty0 + r) * g.size_x + (tx0 + c)) * MIW_FILM_CHANNELS;
+#pragma unroll
+                for (int k = 0; k < MIW_FILM_CHANNELS; ++k) out[k] = (c & 1) ? acc[r][c / 2][k].y : acc[r][c / 2][k].x;
+            }
 }
 
 // step 2: every film texel sums the block tiles covering it, ascending block id

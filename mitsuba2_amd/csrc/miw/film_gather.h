@@ -31,6 +31,7 @@ namespace miw {
 struct BlockReplayArgs {
     const F2 *log_pos; const F4 *log_val;   // [lane][sample], `spp` entries per lane (24-byte format), or
     const U4 *log_rec;                      // the 16-byte records (path.h: LogSink16) with their class tables in `cls`
+    uint32_t log_il = 0;                    // path.h: log_index (0: [lane][sample]; else the tile-interleaved layout k_film_lanes reads)
     FilmClassView cls;
     const U4 *st;                           // st[lane].w = samples finished by that lane
     uint32_t spp;

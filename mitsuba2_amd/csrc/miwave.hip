@@ -1136,7 +1136,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // film mode: sample log + ordered gather if the log fits, else float64 atomics
     int film_mode = cfg->film_mode;
     if (film_mode < 0 || film_mode > 2) return fail(c, MI_ERR_INVALID, "render: film_mode must be 0, 1 or 2");
-    const size_t log_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
+    const size_t log_lanes_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
     // The log format: 16-byte records with phase classes where the host enumeration covers the filter (film_classes.h: box, tent,
     // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
     bool rec16 = false;
@@ -1152,6 +1152,14 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
         rec16 = c->classes.ok;
     }
+    // The replay kernel for the 16-byte records (device/film_kernels.h): k_film_lanes — one 4 x 4 texel block per lane, a wavefront = one
+    // block position in 64 consecutive tiles — wants those tiles' logs interleaved record by record (path.h: log_index), so the
+    // choice is made before the render kernels write the log. MIW_FILM_LANES = 0, or naming another kernel's shape
+    // (MIW_FILM_QUADS / _COLUMNS / _GROUP), keeps [lane][sample] and the group kernels; MIW_FILM_LANES = 2: k_film_lanes over [lane][sample].
+    int film_lanes = rec16 && c->classes.reach <= 2 && !getenv("MIW_FILM_COLUMNS") && !getenv("MIW_FILM_GROUP") && !getenv("MIW_FILM_QUADS") ? 1 : 0;
+    if (const char *e = getenv("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
+    const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
+    const size_t log_entries = log_il ? (size_t) ((n_tiles + 63u) / 64u * 64u) * bs2 * std::max<uint32_t>(cfg->spp, 1) : log_lanes_entries;
     const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
     if (film_mode != 2) {
         size_t need = log_entries * rec_bytes;
@@ -1192,6 +1200,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.log_pos = film_mode == 1 && !rec16 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 && !rec16 ? c->q_log_val.p : nullptr;
     Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr; Q.piece_a = 64u; Q.piece_b = 1u;
     Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count : 0u;
+    Q.log_il = Q.log_rec ? log_il : 0u;
     // ---- dynamic LDS of the render launches: [staged geometry | per-lane stack][256 phase thresholds (16-byte records)][the scene's
     // small tables + the environment warp's smallest levels (trace.h: stage_tables)]. The kernels that stage the tables keep four
     // workgroups per CU (160 KB / 4), so everything has to fit 40 KB less one allocation granule; a scene whose tables do not takes
@@ -1706,7 +1715,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             BlockReplayArgs A;
             A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
-            A.log_rec = rec16 ? c->q_log_rec.p : nullptr;
+            A.log_rec = rec16 ? c->q_log_rec.p : nullptr; A.log_il = rec16 ? log_il : 0u;
             A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
             A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
             A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
@@ -1743,7 +1752,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
                     const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
                     if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
-                    if (quads) {
+                    // round 5, the default: one 4 x 4 texel block per lane, a wavefront = one block position in 64 tiles, the sample loop specialised
+                    // for the rows / column pairs a pixel's footprint covers (k_film_lanes; MIW_FILM_LANES = 0: the kernels below)
+                    const bool lanes = film_lanes != 0;
+                    if (lanes) {
+                        PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
+                        const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
+                        const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
+                        MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<4>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                    } else if (quads) {
                         PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
                         const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);
                         const size_t qbytes = (size_t) (c->classes.count + 1u) * (size_t) (5u + 2u * qh) * sizeof(float);

@@ -565,7 +565,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                 if (st[lane].z & LF_DONE) continue;
                 SplatSink<decltype(add)> splat{ &P.film, add };
                 LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej };
+                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, 0u };
                 bool do_log = film32 != nullptr;
                 auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                     splat(pixel, sample_idx, pos, aovs);
@@ -599,7 +599,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
             LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej };
+            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, 0u };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);

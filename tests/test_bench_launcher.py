@@ -54,9 +54,12 @@ def test_bench_names_the_film_kernel_that_runs(monkeypatch):
     """VERDICT r04 (measurement hygiene 12): the line's kernel_ms named k_film_groups while k_film_columns<4,2> ran. The label follows
     the log format and the MIW_FILM_QUADS / MIW_FILM_COLUMNS switches mi_render reads (csrc/miwave.hip)."""
     import bench
-    for k in ("MIW_FILM_COLUMNS", "MIW_FILM_GROUP", "MIW_FILM_QUADS"):
+    for k in ("MIW_FILM_COLUMNS", "MIW_FILM_GROUP", "MIW_FILM_QUADS", "MIW_FILM_LANES"):
         monkeypatch.delenv(k, raising=False)
-    assert bench.film_kernel_name(16) == "k_film_quads" and bench.film_kernel_name(24) == "k_film_blocks"
+    assert bench.film_kernel_name(16) == "k_film_lanes" and bench.film_kernel_name(24) == "k_film_blocks"
+    monkeypatch.setenv("MIW_FILM_LANES", "0")
+    assert bench.film_kernel_name(16) == "k_film_quads"
+    monkeypatch.delenv("MIW_FILM_LANES")
     monkeypatch.setenv("MIW_FILM_QUADS", "0")
     assert bench.film_kernel_name(16) == "k_film_columns"
     monkeypatch.setenv("MIW_FILM_COLUMNS", "0")

@@ -267,14 +267,14 @@ def test_render_float32_film_and_host_classes(native, oracle, cbox):
 
 @pytest.mark.parametrize("rfilter", ["gaussian", "tent", "box", "mitchell", "catmullrom"])
 def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
-    """The ordered film (film_mode 1) through k_film_quads (the default: 2 x 4 texel groups inside DPP quads; and its 4 x 2, 2 x 8, 4 x 4
-    shapes), k_film_columns<4,2> and k_film_groups: the same float32 additions per texel, so the same film bit for bit, and the oracle's. A ragged film with a crop
+    """The ordered film (film_mode 1) through k_film_lanes (the default: a 4 x 4 texel block per lane, the sample loop specialised per
+    footprint), k_film_quads (2 x 4 texel groups inside DPP quads; and its 4 x 2, 2 x 8, 4 x 4 shapes), k_film_columns<4,2> and k_film_groups: the same float32 additions per texel, so the same film bit for bit, and the oracle's. A ragged film with a crop
     window, 11 spp (trips of 16 records end inside a run)."""
     from mitsuba2_amd import scenes
     films = {}
-    for name, env in (("quads", {}), ("quads42", {"MIW_FILM_QUADS": "42"}), ("quads28", {"MIW_FILM_QUADS": "28"}), ("quads44", {"MIW_FILM_QUADS": "44"}),
+    for name, env in (("lanes", {}), ("quads", {"MIW_FILM_QUADS": "24"}), ("quads42", {"MIW_FILM_QUADS": "42"}), ("quads28", {"MIW_FILM_QUADS": "28"}), ("quads44", {"MIW_FILM_QUADS": "44"}),
                       ("columns", {"MIW_FILM_QUADS": "0"}), ("groups", {"MIW_FILM_COLUMNS": "0"})):
-        for k in ("MIW_FILM_QUADS", "MIW_FILM_COLUMNS", "MIW_FILM_GROUP"):
+        for k in ("MIW_FILM_LANES", "MIW_FILM_QUADS", "MIW_FILM_COLUMNS", "MIW_FILM_GROUP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -283,7 +283,7 @@ def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
         integ = native.PathIntegrator()
         assert integ.render(scene, sensor) is True
         films[name] = sensor.film.data((70, 131, 5)).copy()
-        if name == "quads":
+        if name == "lanes":
             o32, _, _ = oracle.render(scene.desc(), integ.render_job(sensor), threads=8)
     assert np.array_equal(films["quads"], o32)
     for name in films:
