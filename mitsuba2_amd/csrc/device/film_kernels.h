@@ -629,9 +629,9 @@ __global__ __launch_bounds__(64) void k_film_quads(FilmRec F, BlockReplayArgs A,
 
 // ---- one texel block per lane (round 5, the default for the filters with class tables) ----
 //
-// PMC passes over k_film_quads<2, 4> (profiles/r05_film_*): the SIMDs issue an instruction in ~96 % of their cycles, ~38 per (lane,
-// sample) for four texels of which 25 / 48 lie in the sample's footprint — the replay is bound by instruction issue, and most of
-// what it issues multiplies by a zero weight. Here
+// PMC passes over k_film_quads<2, 4> (profiles/r05_experiments.txt): the SIMDs issue an instruction in ~96 % of their cycles, ~38 per
+// (lane, sample) for four texels of which 25 / 48 lie in the sample's footprint — that replay is bound by instruction issue, and
+// most of what it issues multiplies by a zero weight. Here
 //  * a LANE owns a block of 4 x 4 texels of one tile (80 sums in registers) and streams the samples of the 8 x 8 pixels within
 //    reach itself: no records shared between lanes, so nothing to broadcast, and a pixel's run is read by 4 blocks instead of 6
 //    groups (log traffic x 4 instead of x 6);
@@ -640,11 +640,18 @@ __global__ __launch_bounds__(64) void k_film_quads(FilmRec F, BlockReplayArgs A,
 //    block's rows and columns the pixel's footprint covers is WAVE-UNIFORM: the pixel's run is replayed by a copy of the sample loop
 //    specialised for that range of rows and of column pairs (30 copies, a jump per pixel), which issues the products and sums of
 //    the covered texels only — 20 x 12 of 32 x 16 (row, column pair) slots over a window, 47 % of the block's 64 x 8;
-//  * sums and products are packed float32 over pairs of columns (v_pk_mul_f32 / v_pk_add_f32, two IEEE operations each).
+//  * sums and products are packed float32 over pairs of columns (v_pk_mul_f32 / v_pk_add_f32, two IEEE operations each);
+//  * the 64 lanes of a load read 64 different tiles' logs: over [lane][sample] that is 64 cache lines 8 MB apart per load (measured:
+//    36.8 ms at C2, against 11.3 ms with the loads pointed at one run), so the render kernels write the log INTERLEAVED over the
+//    wave's 64 tiles when this kernel will replay it (miw/film.h: log_index — [tile / 64][pixel][sample][tile % 64]): a load is 1 KB
+//    of consecutive bytes, a trip's U loads 4 KB. 17.1 ms at C2 (k_film_quads<2, 4> 23.3, k_film_columns<4, 2> 26.7), the render
+//    kernel's time unchanged.
 // Lanes of a clipped tile (the film's last row / column of blocks) idle through the pixels their block does not have.
 // The float32 additions of a texel are those of the other replay kernels (the tile's pixels in Morton order, each pixel's samples
 // front to back, w = wy * wx, value * w, alpha (0 or 1) * w; a covered texel outside a sample's own footprint — a pair's second
 // column — adds value * 0): the tiles are bit-identical.
+// Registers: 80 sums + 2 x 16 record words + the sample's products; compiled for three wavefronts per SIMD (168 registers), what the
+// compiler keeps in scratch is moved around the sample loops (once per pixel step), never inside one (tests/test_kernel_budget.py).
 typedef float miw_f2 __attribute__((ext_vector_type(2)));
 #define MIW_FL_BS 4
 #ifndef MIW_FL_FENCE
@@ -805,15 +812,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES
 #define MIW_FL_CASE(R0, R1, P0, P1) case ((R0 * 4 + R1) * 2 + P0) * 2 + P1: \
             film_lanes_pixel<R0, R1, P0, P1, U>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js); break;
 #define MIW_FL_ROWS(R0, R1) MIW_FL_CASE(R0, R1, 0, 0) MIW_FL_CASE(R0, R1, 0, 1) MIW_FL_CASE(R0, R1, 1, 1)
-#if MIW_FL_ONECASE
-        (void) code; film_lanes_pixel<0, 3, 0, 1, U>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js);
-#else
         switch (code) {
             MIW_FL_ROWS(0, 0) MIW_FL_ROWS(0, 1) MIW_FL_ROWS(0, 2) MIW_FL_ROWS(0, 3) MIW_FL_ROWS(1, 1) MIW_FL_ROWS(1, 2) MIW_FL_ROWS(1, 3)
             MIW_FL_ROWS(2, 2) MIW_FL_ROWS(2, 3) MIW_FL_ROWS(3, 3)
             default: break;
         }
-#endif
 #undef MIW_FL_ROWS
 #undef MIW_FL_CASE
         if (step_max == 0u) fetch(nx.run, nx.cnt);                                 // (a step without samples consumed nothing)

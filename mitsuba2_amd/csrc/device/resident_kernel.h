@@ -161,7 +161,7 @@ struct QueueWork {
     }
     __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
         if (Q->log_rec) {                                       // wave-uniform: one format per render
-            LogSink16<const float *> sink{ Q->log_rec, thr, film, lane, spp, Q->log_rej, Q->log_il };
+            LogSink16<const float *> sink{ Q->log_rec, thr, film, lane, spp, Q->log_rej & 255u, Q->log_rej >> 8 };   // (log_rej: the class count | log_il << 8 — one uniform, the phase machine has no scalar register to spare)
             sink(pixel, sample_idx, pos, aovs);
         } else {
             LogSink sink; sink.log_pos = Q->log_pos; sink.log_val = Q->log_val; sink.lane = lane; sink.spp = spp; sink.warn_negative = warn_negative;

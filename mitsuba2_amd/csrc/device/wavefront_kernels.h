@@ -161,7 +161,7 @@ __global__ __launch_bounds__(MIW_BLOCK) void k_shade(RenderParams P, SceneView s
     uint32_t flags = LF_DONE;
     if (mine) {
         if (UseLog && Q.log_rec) {                              // 16-byte records; the thresholds through L1 (plan 1 is not the fast path)
-            LogSink16<const float *> sink{ Q.log_rec, Q.log_thr, &P.film, lane, P.spp, Q.log_rej, Q.log_il };
+            LogSink16<const float *> sink{ Q.log_rec, Q.log_thr, &P.film, lane, P.spp, Q.log_rej & 255u, Q.log_rej >> 8 };
             flags = lane_shade(P, sc, Q, lane, &local, sink);
         } else if (UseLog) {
             LogSink sink; sink.log_pos = Q.log_pos; sink.log_val = Q.log_val; sink.lane = lane; sink.spp = P.spp; sink.warn_negative = P.film.warn_negative;

@@ -146,6 +146,21 @@ MIW_HD uint32_t film_class_of(Thr thr, float phi) {
     c += (phi >= t1 ? 1u : 0u) + (phi >= t2 ? 1u : 0u) + (phi >= t3 ? 1u : 0u) + (phi >= t4 ? 1u : 0u);
     return c;
 }
+// Where lane's j-th 16-byte record lives. il = 0: [lane][j]. il = 1 + log2(lanes per tile), chosen by mi_render when the film will be
+// replayed by k_film_lanes (device/film_kernels.h: a wavefront = the same texel block of 64 consecutive tiles, each lane streaming its
+// own tile's runs): [tile / 64][pixel of the tile][j][tile % 64] — the 64 records a replay load fetches are 1 KB of consecutive bytes
+// instead of 64 cache lines 8 MB apart. For the kernel that writes the log the change is neutral: a pixel's consecutive records are
+// 1 KB apart instead of adjacent, but they were never written together (a lane finishes a sample every few hundred microseconds).
+MIW_HD size_t log_index(uint32_t il, uint32_t lane, uint32_t spp, uint32_t j) {
+    if (!il) return (size_t) lane * spp + j;
+    const uint32_t sh = il - 1u;
+    const uint32_t hi = ((lane >> (sh + 6u)) << sh) | (lane & ((1u << sh) - 1u));       // (tile / 64, pixel)
+    return (((size_t) hi * spp + j) << 6) | (size_t) ((lane >> sh) & 63u);              // ... record j, tile % 64
+}
+// records the log must hold for n_tiles tiles of 2^sh lanes (the interleaved layout pads to whole groups of 64 tiles)
+MIW_HD size_t log_capacity(uint32_t il, uint32_t n_tiles, uint32_t lanes_per_tile, uint32_t spp) {
+    return (size_t) (il ? (n_tiles + 63u) / 64u * 64u : n_tiles) * lanes_per_tile * spp;
+}
 MIW_HD uint32_t film_pack_meta(uint32_t cx, uint32_t cy, bool alpha) { return cx | (cy << 8) | (alpha ? 1u << 16 : 0u); }
 
 // The spiral block a pixel belongs to (spiral.cpp:43-45): bordered-block origin and clipped size

@@ -92,10 +92,9 @@ MIW_HD void film_block_replay16(const FilmRec &f, const BlockReplayArgs &a, uint
         if ((int) x >= g.bw || (int) y >= g.bh) continue;
         const uint32_t lane = (tile << a.bs2_log2) + q;
         const uint32_t count = a.st[lane].w;
-        const U4 *rec = a.log_rec + (size_t) lane * a.spp;
         const int ptx = (int) x + f.border, pty = (int) y + f.border;
         for (uint32_t j = 0; j < count; ++j) {
-            const U4 r = rec[j];
+            const U4 r = a.log_rec[log_index(a.log_il, lane, a.spp, j)];
             const uint32_t cx = r.w & 255u, cy = (r.w >> 8) & 255u;
             const float value[5] = { u2f(r.x), u2f(r.y), u2f(r.z), (r.w >> 16) & 1u ? 1.f : 0.f, 1.f };
             for (int ay = 0; ay <= 2 * reach; ++ay)

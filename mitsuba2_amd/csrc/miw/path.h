@@ -64,9 +64,8 @@ struct LaneQueues {
     F2 *log_pos;
     F4 *log_val;   // X, Y, Z, alpha   (weight channel W is the constant 1)
     U4 *log_rec;
-    uint32_t log_il = 0;    // 0: log_rec is [lane][sample j]; else 1 + log2(lanes per tile): the logs of 64 consecutive tiles interleaved record by record (log_index)
     const float *log_thr;   // the 256 phase thresholds (global memory; kernels that stage them in LDS pass their own pointer)
-    uint32_t log_rej;       // class index of a rejected sample = the class count (the first all-zero row of the weight table)
+    uint32_t log_rej;       // bits 0-7: class index of a rejected sample = the class count (the first all-zero row of the weight table); bits 8+: the log's layout (log_index's il: 0 = [lane][sample j])
     // placed pixel queues of small shards (device/resident_kernel.h: QueueWork): what every pixel cost (written by the measuring
     // launch, nullptr otherwise), the lanes sorted by that cost (64 consecutive entries = one piece: pixels of about equal cost
     // share a wavefront), four pieces per SIMD queue, the SIMD registry (word 0: "all dry" flag; then by hardware id)
@@ -205,16 +204,6 @@ struct LogSink {
 // Sink 3: the 16-byte record (film.h: phase classes). `thr` = the 256 thresholds, wherever the caller keeps them (LDS on the
 // device's resident kernels). A rejected sample is logged as class `rej` (= the class count: the first all-zero row of the
 // weight table) with zero values, so that the replay needs no branch for it.
-// Where lane's j-th 16-byte record lives. il = 0: [lane][j]. il = 1 + log2(lanes per tile), chosen by mi_render when the film will be
-// replayed by k_film_lanes (device/film_kernels.h: a wavefront = the same texel block of 64 consecutive tiles, each lane streaming its
-// own tile's runs): [tile / 64][pixel of the tile][j][tile % 64] — the 64 records a replay load fetches are 1 KB of consecutive bytes
-// instead of 64 cache lines 8 MB apart. For the kernel that writes the log the change is neutral: a pixel's consecutive records are
-// 1 KB apart instead of adjacent, but they were never written together (a lane finishes a sample every few hundred microseconds).
-MIW_HD size_t log_index(uint32_t il, uint32_t lane, uint32_t spp, uint32_t j) {
-    if (!il) return (size_t) lane * spp + j;
-    const uint32_t sh = il - 1u, tile = lane >> sh, q = lane & ((1u << sh) - 1u);
-    return ((((size_t) (((tile >> 6) << sh) + q)) * spp + j) << 6) | (size_t) (tile & 63u);
-}
 template <typename Thr>
 struct LogSink16 {
     U4 *log_rec; Thr thr; const FilmRec *film; uint32_t lane, spp, rej, il;

@@ -1159,7 +1159,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     int film_lanes = rec16 && c->classes.reach <= 2 && !getenv("MIW_FILM_COLUMNS") && !getenv("MIW_FILM_GROUP") && !getenv("MIW_FILM_QUADS") ? 1 : 0;
     if (const char *e = getenv("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
     const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
-    const size_t log_entries = log_il ? (size_t) ((n_tiles + 63u) / 64u * 64u) * bs2 * std::max<uint32_t>(cfg->spp, 1) : log_lanes_entries;
+    const size_t log_entries = log_il ? log_capacity(log_il, n_tiles, bs2, std::max<uint32_t>(cfg->spp, 1)) : log_lanes_entries;
     const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
     if (film_mode != 2) {
         size_t need = log_entries * rec_bytes;
@@ -1199,8 +1199,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     Q.sh_d = c->q_sh_d.p; Q.sh_c = c->q_sh_c.p; Q.sh_vis = c->q_sh_vis.p;
     Q.log_pos = film_mode == 1 && !rec16 ? c->q_log_pos.p : nullptr; Q.log_val = film_mode == 1 && !rec16 ? c->q_log_val.p : nullptr;
     Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr; Q.piece_a = 64u; Q.piece_b = 1u;
-    Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count : 0u;
-    Q.log_il = Q.log_rec ? log_il : 0u;
+    Q.log_rec = film_mode == 1 && rec16 ? c->q_log_rec.p : nullptr; Q.log_thr = rec16 ? c->d_fc_thr.p : nullptr; Q.log_rej = rec16 ? c->classes.count | ((film_mode == 1 ? log_il : 0u) << 8) : 0u;
     // ---- dynamic LDS of the render launches: [staged geometry | per-lane stack][256 phase thresholds (16-byte records)][the scene's
     // small tables + the environment warp's smallest levels (trace.h: stage_tables)]. The kernels that stage the tables keep four
     // workgroups per CU (160 KB / 4), so everything has to fit 40 KB less one allocation granule; a scene whose tables do not takes
@@ -1759,7 +1758,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                         PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
                         const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
                         const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
-                        MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<4>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        int fl_u = 4;                                     // records per lane and trip (MIW_FL_U = 8: two cache-line sectors per lane in flight)
+                        if (const char *e = getenv("MIW_FL_U")) fl_u = atoi(e);
+                        if (fl_u == 8) MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<8>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        else MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<4>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
                     } else if (quads) {
                         PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
                         const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);

@@ -472,8 +472,10 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
     std::vector<F2> log_pos; std::vector<F4> log_val; std::vector<U4> log_rec;
     const FilmClasses classes = film_classes_build(P.film);
     const bool rec16 = classes.ok && !getenv("MIW_FILM_LEGACY");
+    // MIW_EMU_LOG_IL=1: the tile-interleaved log (miw/film.h: log_index) the device writes for k_film_lanes — same film
+    const uint32_t log_il = rec16 && getenv("MIW_EMU_LOG_IL") && atoi(getenv("MIW_EMU_LOG_IL")) ? [&] { uint32_t l = 0; while ((1u << l) < bs2) ++l; return l + 1u; }() : 0u;
     if (film32) {
-        if (rec16) log_rec.resize((size_t) n_lanes * cfg->spp);
+        if (rec16) log_rec.resize(log_capacity(log_il, n_tiles, bs2, cfg->spp));
         else { log_pos.resize((size_t) n_lanes * cfg->spp); log_val.resize((size_t) n_lanes * cfg->spp); }
     }
     Q.log_pos = log_pos.data(); Q.log_val = log_val.data(); Q.log_rec = rec16 ? log_rec.data() : nullptr; Q.log_thr = classes.thr.data(); Q.log_rej = classes.count;
@@ -565,7 +567,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
                 if (st[lane].z & LF_DONE) continue;
                 SplatSink<decltype(add)> splat{ &P.film, add };
                 LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, 0u };
+                LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, log_il };
                 bool do_log = film32 != nullptr;
                 auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                     splat(pixel, sample_idx, pos, aovs);
@@ -599,7 +601,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         for (uint32_t lane = 0; lane < n_lanes; ++lane) {      // k_shade (both film modes at once)
             SplatSink<decltype(add)> splat{ &P.film, add };
             LogSink log{ Q.log_pos, Q.log_val, lane, cfg->spp, P.film.warn_negative };
-            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, 0u };
+            LogSink16<const float *> log16{ Q.log_rec, Q.log_thr, &P.film, lane, cfg->spp, Q.log_rej, log_il };
             bool do_log = film32 != nullptr;
             auto sink = [&](uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
                 splat(pixel, sample_idx, pos, aovs);
@@ -615,7 +617,7 @@ int emu_render(const mi_scene_desc *scene, const mi_render_cfg *cfg, double *fil
         std::vector<int32_t> block_tile(cfg->block_count, -1);
         for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
         BlockReplayArgs A; A.log_pos = log_pos.data(); A.log_val = log_val.data(); A.st = st.data(); A.spp = cfg->spp;
-        A.log_rec = rec16 ? log_rec.data() : nullptr; A.cls = classes.view();
+        A.log_rec = rec16 ? log_rec.data() : nullptr; A.log_il = log_il; A.cls = classes.view();
         A.block_ids = cfg->block_ids; A.block_tile = block_tile.data(); A.tile_list = cfg->tile_list;
         A.blocks_x = blocks_x; A.blocks_y = (cfg->crop_h + bs - 1) / bs;
         uint32_t l2 = 0; while ((1u << l2) < bs2) ++l2;

@@ -439,6 +439,25 @@ def test_tiny_blocks_of_a_many_threaded_render(native, oracle, rfilter):
     assert sizes == [(32, 1), (4, 16), (2, 64), (1, 256)]
 
 
+@pytest.mark.parametrize("shape", [(150, 83, 32), (16, 16, 2), (700, 40, 8)])
+def test_tile_interleaved_sample_log_is_the_same_film(native, oracle, monkeypatch, shape):
+    """The device writes the 16-byte sample log interleaved over groups of 64 tiles when k_film_lanes will replay it (miw/film.h:
+    log_index, [tile / 64][pixel][sample][tile % 64], padded to whole groups). The CPU twin of the lane stages writes and replays
+    the same layout through the same header (MIW_EMU_LOG_IL=1): log_index is a bijection into log_capacity and the film is the
+    [lane][sample] film and the oracle's — with fewer than 64 tiles, with exactly one tile per pixel, with more than one group."""
+    from mitsuba2_amd import scenes
+    w, h, bs = shape
+    scene, sensor = scenes.cornell_box(w, h, 3, device=-1, seed=5)
+    job = native.PathIntegrator().render_job(sensor, n_threads=1 if bs == 32 else (64 if bs == 2 else 400))
+    assert job.cfg.block_size == bs, job.cfg.block_size
+    o32, o64, st = oracle.render(scene.desc(), job, threads=4)
+    monkeypatch.delenv("MIW_EMU_LOG_IL", raising=False)
+    a64, a32, ast = oracle.emu_render(scene.desc(), job)
+    monkeypatch.setenv("MIW_EMU_LOG_IL", "1")
+    b64, b32, bst = oracle.emu_render(scene.desc(), job)
+    assert np.array_equal(a32, o32) and np.array_equal(b32, o32) and list(ast) == list(bst)
+
+
 def test_more_ranks_than_blocks_leaves_empty_shards_empty(native, oracle):
     """A 64x48 frame has 4 spiral blocks; with 8 ranks, ranks 4..7 hold no block. Their job must say so (non-NULL
     tile_list, tile_count == 0 — a NULL list means "all blocks" to mi_render) and render nothing, so that the film

@@ -45,3 +45,34 @@ def test_phase_machine_of_configs_3_and_4_fits_four_waves(tmp_path):
     assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 24, r
     r = _resources("probe_phased.hip", "k_path_phasedILi3ELb0ELb1ELi4ELi1E", tmp_path, "-DMIW_PROBE_C34=1")     # its 4-wide twin (MIW_BVH8=0, trees the 8-wide collapse refuses)
     assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] <= 20, r
+
+
+def test_film_replay_keeps_its_sample_loops_free_of_scratch(tmp_path):
+    """k_film_lanes (device/film_kernels.h): 80 sums + two buffers of record words per lane, compiled for three wavefronts per SIMD.
+    What does not fit 168 registers is moved around the 30 specialised sample loops (once per pixel step of ~500 samples), never inside
+    one: every innermost loop of the kernel's ISA is free of scratch_ instructions."""
+    out = subprocess.run([HIPCC] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-S", os.path.join(ROOT, "tools", "probe_film.hip"),
+                          "--cuda-device-only", "-o", str(tmp_path / "probe.s")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = open(tmp_path / "probe.s").read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z12k_film_lanesILi4E"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    meta = "\n".join(lines)
+    blk = meta[meta.index(".name:           _Z12k_film_lanesILi4E"):]
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 168
+    loops = 0
+    for i, l in enumerate(body):
+        if "Inner Loop Header: Depth=2" not in l:
+            continue
+        j = i
+        while not re.match(r"^\.LBB\d+_\d+:", body[j]):
+            j -= 1
+        label = body[j].split(":")[0]
+        k = j + 1
+        while not ("s_cbranch" in body[k] and label in body[k]):
+            k += 1
+        assert not any("scratch_" in b for b in body[j:k]), "scratch traffic inside the sample loop at %s" % label
+        assert sum("v_pk_add_f32" in b for b in body[j:k]) >= 20                 # (it is a sample loop: >= 4 samples x one row x one column pair)
+        loops += 1
+    assert loops == 30                                                           # 10 row ranges x 3 column-pair ranges
