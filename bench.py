@@ -249,22 +249,15 @@ def spawn_ranks(n, argv):
     return subprocess.call(spawn_command(n, argv), env=env)
 
 
-def film_kernel_name(log_record_bytes):
-    """the replay kernel mi_render launches for this log format (csrc/miwave.hip: the MIW_FILM_LANES / _QUADS / _COLUMNS switches)"""
+FILM_KERNELS = {0: "k_film_blocks", 1: "k_film_groups", 2: "k_film_columns", 3: "k_film_quads", 4: "k_film_lanes"}
+
+
+def film_kernel_name(log_record_bytes, film_kernel):
+    """the block replay mi_render launched (mi_counters::film_kernel; csrc/miwave.hip chooses by the log format, the shard's tile count
+    and the MIW_FILM_* switches)"""
     if log_record_bytes != 16:
         return "k_film_blocks"
-    env = os.environ
-    lanes = all(env.get(k) is None for k in ("MIW_FILM_COLUMNS", "MIW_FILM_GROUP", "MIW_FILM_QUADS"))
-    if env.get("MIW_FILM_LANES") is not None:
-        lanes = env["MIW_FILM_LANES"] not in ("0", "")
-    if lanes:
-        return "k_film_lanes"
-    quads = env.get("MIW_FILM_COLUMNS") is None and env.get("MIW_FILM_GROUP") is None
-    if env.get("MIW_FILM_QUADS") is not None:
-        quads = env["MIW_FILM_QUADS"] not in ("0", "")
-    if quads:
-        return "k_film_quads"
-    return "k_film_groups" if env.get("MIW_FILM_COLUMNS") == "0" else "k_film_columns"
+    return FILM_KERNELS.get(int(film_kernel), "k_film_%d" % film_kernel)
 
 
 def reduce_label(backend):
@@ -443,10 +436,9 @@ def main():
             ta_name: (agg["ms_ta"], agg["n_ta"], 8.0 * agg["segments"] if pk == 2 else B_TRACE_ANY * agg["shadow"]),
             # resident plan: the whole pipeline's algorithmic bytes (280 B/segment + 320 B/sample) belong to one kernel
             path_kernel: (agg["ms_path"], agg["n_path"], 280.0 * agg["segments"] + B_SPLAT * agg["samples"]),
-            # ordered film replay: reads the sample log once per texel group, writes the block tiles (k_film_columns<4,2> over the
-            # 16-byte class records — k_film_groups, its round-3 predecessor, only with MIW_FILM_COLUMNS=0 —, k_film_blocks over the
-            # 24-byte position log of filters without phase classes)
-            film_kernel_name(hc.log_record_bytes): (agg["ms_fb"], agg["n_film"], float(hc.log_record_bytes) * agg["samples"]),
+            # ordered film replay (device/film_kernels.h): k_film_lanes over the tile-interleaved 16-byte log (k_film_quads for shards of
+            # fewer than 448 tiles), k_film_blocks over the 24-byte position log of filters without phase classes
+            film_kernel_name(hc.log_record_bytes, hc.film_kernel): (agg["ms_fb"], agg["n_film"], float(hc.log_record_bytes) * agg["samples"]),
         }
         roofline = None
         if not args.no_profile and (agg["n_shade"] or agg["n_path"]):

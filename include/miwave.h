@@ -304,6 +304,10 @@ typedef struct {
      * over place_measure_spp samples per pixel; place_max_pixel = x | y << 16 of that pixel. 0 when the last render was not placed. */
     uint32_t place_cost_max, place_cost_unit, place_max_pixel, place_measure_spp;
     double place_cost_mean;
+    /* the block replay of the last render with film_mode 1 (device/film_kernels.h): 0 = k_film_blocks (24-byte log), 1 = k_film_groups,
+     * 2 = k_film_columns, 3 = k_film_quads (the default for shards of fewer than 448 tiles), 4 = k_film_lanes (the default from 448 tiles on),
+     * and whether the render kernels wrote the 16-byte log interleaved over groups of 64 tiles for it (miw/film.h: log_index) */
+    uint32_t film_kernel, log_interleaved;
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -670,7 +670,15 @@ __device__ __forceinline__ void film_pk_acc(miw_f2 &sum, const miw_f2 x) {
     sum += x;
 #endif
 }
-template <int R0, int R1, int P0, int P1, int U>
+// one record of the log; NT: a streaming load (the replay reads a line once per lane; its three other readers come much later)
+template <int NT>
+__device__ __forceinline__ uint4 film_load_rec(const U4 *p) {
+    typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
+    if (NT) { const u4v_ v = __builtin_nontemporal_load(reinterpret_cast<const u4v_ *>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    const U4 t = *p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+template <int R0, int R1, int P0, int P1, int U, int NT>
 __device__ __forceinline__ void film_lanes_pixel(miw_f2 (&acc)[MIW_FL_BS][MIW_FL_BS / 2][MIW_FILM_CHANNELS], uint4 (&nxt)[U], uint32_t cnt,
                                                  const U4 *n_run, uint32_t n_cnt, const U4 *run, uint32_t step_max,
                                                  uint32_t bxa, uint32_t bya, uint32_t off_rej, uint32_t js) {
@@ -690,8 +698,7 @@ __device__ __forceinline__ void film_lanes_pixel(miw_f2 (&acc)[MIW_FL_BS][MIW_FL
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const uint32_t j = t_j0 + (uint32_t) i;
-            const U4 t = t_run[(j < t_last ? j : t_last) * js];
-            nxt[i] = make_uint4(t.x, t.y, t.z, t.w);
+            nxt[i] = film_load_rec<NT>(t_run + (j < t_last ? j : t_last) * js);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -724,7 +731,7 @@ __device__ __forceinline__ void film_lanes_pixel(miw_f2 (&acc)[MIW_FL_BS][MIW_FL
 #ifndef MIW_FL_WAVES
 #define MIW_FL_WAVES 3
 #endif
-template <int U>
+template <int U, int NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES, 8))) void k_film_lanes(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = texel blocks per tile row / column */, uint32_t n_tiles, float *tiles) {
     constexpr int BS = MIW_FL_BS, WS = MIW_FQ_WSTRIDE(MIW_FL_BS), LEAD = BS - 1, LCAP = 64;
     extern __shared__ float s_w[];                           // (count + 1) x WS weights; row `count` = 0
@@ -789,8 +796,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES
         const uint32_t last = cnt ? cnt - 1u : 0u;
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            const U4 t = run[((uint32_t) i < last ? (uint32_t) i : last) * js];
-            nxt[i] = make_uint4(t.x, t.y, t.z, t.w);
+            nxt[i] = film_load_rec<NT>(run + ((uint32_t) i < last ? (uint32_t) i : last) * js);
             __builtin_amdgcn_sched_barrier(0);           // record 0 first, as inside the loop
         }
     };
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES
         const uint32_t bxa = w_base + 4u * (uint32_t) (LEAD + ax), bya = w_base + 4u * (uint32_t) (LEAD + ay);
         const int code = __builtin_amdgcn_readfirstlane(((r0 * 4 + r1) * 2 + (c0 >> 1)) * 2 + (c1 >> 1));
 #define MIW_FL_CASE(R0, R1, P0, P1) case ((R0 * 4 + R1) * 2 + P0) * 2 + P1: \
-            film_lanes_pixel<R0, R1, P0, P1, U>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js); break;
+            film_lanes_pixel<R0, R1, P0, P1, U, NT>(acc, nxt, cur.cnt, nx.run, nx.cnt, cur.run, step_max, bxa, bya, off_rej, js); break;
 #define MIW_FL_ROWS(R0, R1) MIW_FL_CASE(R0, R1, 0, 0) MIW_FL_CASE(R0, R1, 0, 1) MIW_FL_CASE(R0, R1, 1, 1)
         switch (code) {
             MIW_FL_ROWS(0, 0) MIW_FL_ROWS(0, 1) MIW_FL_ROWS(0, 2) MIW_FL_ROWS(0, 3) MIW_FL_ROWS(1, 1) MIW_FL_ROWS(1, 2) MIW_FL_ROWS(1, 3)

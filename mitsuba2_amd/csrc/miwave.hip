@@ -1156,7 +1156,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // block position in 64 consecutive tiles — wants those tiles' logs interleaved record by record (path.h: log_index), so the
     // choice is made before the render kernels write the log. MIW_FILM_LANES = 0, or naming another kernel's shape
     // (MIW_FILM_QUADS / _COLUMNS / _GROUP), keeps [lane][sample] and the group kernels; MIW_FILM_LANES = 2: k_film_lanes over [lane][sample].
-    int film_lanes = rec16 && c->classes.reach <= 2 && !getenv("MIW_FILM_COLUMNS") && !getenv("MIW_FILM_GROUP") && !getenv("MIW_FILM_QUADS") ? 1 : 0;
+    // k_film_lanes' wavefronts are few and long (81 per 64 tiles, each the serial replay of 64 pixel runs: ~6 ms at 512 spp however few
+    // there are), so shards of fewer than 7 x 64 tiles keep the group kernel: 255 tiles (a rank's eighth of a 1080p frame) 4.1 ms by
+    // k_film_quads against 6.1, 510 tiles 7.1 against 6.65, 1 020 tiles 12.9 against 10.2 (gpurun q10)
+    int film_lanes = rec16 && c->classes.reach <= 2 && n_tiles >= 448u && !getenv("MIW_FILM_COLUMNS") && !getenv("MIW_FILM_GROUP") && !getenv("MIW_FILM_QUADS") ? 1 : 0;
     if (const char *e = getenv("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
     const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
     const size_t log_entries = log_il ? log_capacity(log_il, n_tiles, bs2, std::max<uint32_t>(cfg->spp, 1)) : log_lanes_entries;
@@ -1185,6 +1188,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     }
     c->counters.log_bytes = film_mode == 1 ? (uint64_t) log_entries * rec_bytes : 0u;
     c->counters.log_record_bytes = film_mode == 1 ? (uint32_t) rec_bytes : 0u;
+    c->counters.film_kernel = 0u; c->counters.log_interleaved = film_mode == 1 && rec16 && log_il ? 1u : 0u;
     c->counters.film_mode = (uint32_t) film_mode;
     HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
     HIP_TRY(c, hipMemcpyAsync(c->d_block_ids.p, cfg->block_ids, cfg->block_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -1754,14 +1758,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // round 5, the default: one 4 x 4 texel block per lane, a wavefront = one block position in 64 tiles, the sample loop specialised
                     // for the rows / column pairs a pixel's footprint covers (k_film_lanes; MIW_FILM_LANES = 0: the kernels below)
                     const bool lanes = film_lanes != 0;
+                    c->counters.film_kernel = lanes ? 4u : quads ? 3u : (columns == 42 || columns == 44 || columns == 82) ? 2u : 1u;   // (mi_counters)
                     if (lanes) {
                         PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
                         const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
                         const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
-                        int fl_u = 4;                                     // records per lane and trip (MIW_FL_U = 8: two cache-line sectors per lane in flight)
-                        if (const char *e = getenv("MIW_FL_U")) fl_u = atoi(e);
-                        if (fl_u == 8) MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<8>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
-                        else MIW_TIMED(4, hipLaunchKernelGGL(k_film_lanes<4>, dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        int fl_nt = 1;                                    // the log read with streaming loads (16.8 vs 17.05 ms at C2, gpurun q9); MIW_FL_NT = 0: plain loads
+                        if (const char *e = getenv("MIW_FL_NT")) fl_nt = atoi(e);
+                        if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
                     } else if (quads) {
                         PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
                         const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);

@@ -272,7 +272,7 @@ def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
     window, 11 spp (trips of 16 records end inside a run)."""
     from mitsuba2_amd import scenes
     films = {}
-    for name, env in (("lanes", {}), ("quads", {"MIW_FILM_QUADS": "24"}), ("quads42", {"MIW_FILM_QUADS": "42"}), ("quads28", {"MIW_FILM_QUADS": "28"}), ("quads44", {"MIW_FILM_QUADS": "44"}),
+    for name, env in (("lanes", {"MIW_FILM_LANES": "1"}), ("lanes_plain_log", {"MIW_FILM_LANES": "2"}), ("default", {}), ("quads", {"MIW_FILM_QUADS": "24"}), ("quads42", {"MIW_FILM_QUADS": "42"}), ("quads28", {"MIW_FILM_QUADS": "28"}), ("quads44", {"MIW_FILM_QUADS": "44"}),
                       ("columns", {"MIW_FILM_QUADS": "0"}), ("groups", {"MIW_FILM_COLUMNS": "0"})):
         for k in ("MIW_FILM_LANES", "MIW_FILM_QUADS", "MIW_FILM_COLUMNS", "MIW_FILM_GROUP"):
             monkeypatch.delenv(k, raising=False)
@@ -283,9 +283,12 @@ def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
         integ = native.PathIntegrator()
         assert integ.render(scene, sensor) is True
         films[name] = sensor.film.data((70, 131, 5)).copy()
+        c = integ.counters()
+        # (15 tiles: below 448 the default is the group kernel; MIW_FILM_LANES = 1 asks for the block-per-lane kernel over its own log layout)
+        assert (c.film_kernel, c.log_interleaved) == {"lanes": (4, 1), "lanes_plain_log": (4, 0), "default": (3, 0), "quads": (3, 0), "quads42": (3, 0),
+                                                      "quads28": (3, 0), "quads44": (3, 0), "columns": (2, 0), "groups": (1, 0)}[name], (name, c.film_kernel, c.log_interleaved)
         if name == "lanes":
             o32, _, _ = oracle.render(scene.desc(), integ.render_job(sensor), threads=8)
-    assert np.array_equal(films["quads"], o32)
     for name in films:
         assert np.array_equal(films[name], o32), name
 

@@ -55,11 +55,11 @@ def test_film_replay_keeps_its_sample_loops_free_of_scratch(tmp_path):
                           "--cuda-device-only", "-o", str(tmp_path / "probe.s")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = open(tmp_path / "probe.s").read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z12k_film_lanesILi4E"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z12k_film_lanesILi4ELi0E"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
     meta = "\n".join(lines)
-    blk = meta[meta.index(".name:           _Z12k_film_lanesILi4E"):]
+    blk = meta[meta.index(".name:           _Z12k_film_lanesILi4ELi0E"):]
     assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 168
     loops = 0
     for i, l in enumerate(body):

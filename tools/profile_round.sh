@@ -26,7 +26,7 @@ pmc() {   # [ENV=VAL] pmc <name> <bench args...>  (the environment of the call r
 pmc c2
 pmc c3 --scene matball --spp 64
 pmc c4 --scene interior --spp 16
-MIW_BVH8=0 pmc c4bvh4 --scene interior --spp 16          # the 4-wide twin of the same build: traffic and wait share against the 8-wide walk's
+[ -n "$LEAN" ] || MIW_BVH8=0 pmc c4bvh4 --scene interior --spp 16          # the 4-wide twin of the same build: traffic and wait share against the 8-wide walk's
 cd $repo
 line() {  # line <name> [ENV=VAL ...] -- <bench args...>: one bench line into $out/${tag}_<name>.log
   local name=$1; shift
