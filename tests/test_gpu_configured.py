@@ -168,7 +168,9 @@ def test_c4_full_frame_at_2048spp_through_the_sample_log(native):
     film, st = dev.render(job, samples_per_launch=2048)
     c = dev.counters()
     assert st == 0 and c.film_mode == 1 and c.path_kernel == 1 and c.samples == W * H * 2048
-    assert c.log_record_bytes == 16 and c.log_bytes == 2040 * 1024 * 2048 * 16          # one record per lane (2040 blocks of 32 x 32, clipped edge blocks included) and sample
+    # one 16-byte record per lane (2040 blocks of 32 x 32, clipped edge blocks included) and sample, written interleaved over groups of 64
+    # tiles for k_film_lanes (miw/film.h: log_index; the last group padded: 2048 tiles' worth of records)
+    assert c.log_record_bytes == 16 and (c.film_kernel, c.log_interleaved) == (4, 1) and c.log_bytes == 2048 * 1024 * 2048 * 16
     for sid, (b, x0, y0) in zip(G.C4_FULL_BLOCKS, G.full_job_blocks(job.cfg, G.C4_FULL_BLOCKS)):
         want = rec["interiors"][str(sid)]
         assert (b, [x0, y0]) == (want["block"], want["origin"])
