@@ -293,6 +293,28 @@ def test_film_replay_kernels_agree(native, oracle, rfilter, monkeypatch):
         assert np.array_equal(films[name], o32), name
 
 
+@pytest.mark.parametrize("crop,n_threads,bs,rfilter", [((48, 48), 576, 2, "gaussian"), ((32, 32), 1024, 1, "tent"), ((100, 76), 450, 4, "mitchell"), ((197, 157), 480, 8, "box")])
+def test_film_replay_by_texel_blocks_on_tiny_blocks(native, oracle, crop, n_threads, bs, rfilter):
+    """integrator.cpp:88-97 halves the block size until there are as many blocks as worker threads. From 448 tiles on the film is
+    replayed by k_film_lanes (a 4 x 4 texel block per lane over the tile-interleaved log) whatever the block size: tiles of 2 x 2 and
+    1 x 1 pixels (bordered: 6 x 6 / 5 x 5 texels — a tile narrower than two texel blocks, windows clipped on every side), ragged
+    last tiles, more than one group of 64 tiles with a partial last group; every filter reach."""
+    from mitsuba2_amd import scenes
+    w, h = crop
+    scene, _ = scenes.cornell_box(384, 216, 5, device=-1, seed=9)
+    sensor = scenes.cornell_sensor(384, 216, 5, rfilter=rfilter, crop_offset_x=40, crop_offset_y=20, crop_width=w, crop_height=h)
+    job = native.PathIntegrator().render_job(sensor, n_threads=n_threads)
+    assert job.cfg.block_size == bs and job.cfg.block_count >= 448, (job.cfg.block_size, job.cfg.block_count)
+    o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
+    dev = native.Device(0)
+    dev.upload(scene.desc())
+    film, st = dev.render(job)
+    c = dev.counters()
+    assert st == 0 and (c.film_kernel, c.log_interleaved, c.samples) == (4, 1, ost.samples)
+    assert np.array_equal(film, o32)
+    dev.close()
+
+
 def test_render_samples_per_pass(native, oracle, dev):
     """samples_per_pass < sample_count (integrator.cpp:75-86) through the host classes: three passes of 2 spp, each
     seeded from its own block ids and accumulated onto the film (mi_render_cfg::accumulate) == the oracle run the
