@@ -1,5 +1,6 @@
-// Film assembly: k_film_resolve (float64 sums), k_film_blocks (texel patches, 24-byte position log), k_film_groups
-// (16-byte class records, 4 x 2 texel groups), k_film_merge.
+// Film assembly: k_film_resolve (float64 sums), k_film_blocks (texel patches, 24-byte position log), the replays of the 16-byte
+// class records — k_film_lanes (a 4 x 4 texel block per lane over the tile-interleaved log: the default from 448 tiles on), k_film_quads
+// (texel groups inside DPP quads: smaller shards), k_film_columns / k_film_groups (rounds 4 / 3, kept as twins) —, k_film_merge.
 // Part of the single translation unit csrc/miwave.hip (included there, in this order; not a stand-alone header).
 __global__ void k_film_resolve(const double *accum, float *out32, double *out64, size_t n, int accumulate) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64) void k_film_columns(FilmRec F, BlockReplayArgs 
 //  * what is left for the LDS is the class table: one x weight per lane and sample and the GH y weights of its column
 //    (neighbours in a class's row, which carries zeros in front and behind: "row outside the window" is an index, not a select);
 //  * the sums are packed float32 instructions over pairs of rows (v_pk_mul_f32 / v_pk_add_f32: two IEEE products / sums each).
-// A column of 4 texels under a 2-wide group (the default, k_film_quads<2, 4>) walks a 6 x 8 pixel window for 8 texels: the same
+// A column of 4 texels under a 2-wide group (k_film_quads<2, 4>) walks a 6 x 8 pixel window for 8 texels: the same
 // 48 pixels per group as 4 x 2, i.e. the same log traffic, but ~31 vector instructions per (lane, sample) serve FOUR texels
 // (4 x 2 in this form: ~18 for two; k_film_columns<4, 2>: ~24 + the staging for two).
 // Groups are numbered through ALL tiles (a wave takes 64 / GW consecutive groups, which may straddle two tiles): 36 x 36

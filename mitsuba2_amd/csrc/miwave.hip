@@ -1745,13 +1745,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
                                    const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
                                    MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
-                    // round 5: groups of 2 x 4 texels inside DPP quads, the records broadcast by quad_perm operands instead of staged through
-                    // LDS (k_film_quads<2, 4>, the default; MIW_FILM_QUADS = 42 / 28 / 44: other group shapes, = 0: the kernels below — also
-                    // taken when a tile has fewer groups than a wavefront takes, i.e. tiny blocks)
+                    // round 5: groups of 4 x 2 (2 x 4: MIW_FILM_QUADS = 24) texels inside DPP quads, the records broadcast by quad_perm operands instead of
+                    // staged through LDS (k_film_quads; MIW_FILM_QUADS = 24 / 28 / 44: other group shapes, = 0: the kernels below — also taken when a tile
+                    // has fewer groups than a wavefront takes, i.e. tiny blocks)
                     int columns = 42;
                     if (const char *e = getenv("MIW_FILM_COLUMNS")) columns = atoi(e);
-                    int quads = getenv("MIW_FILM_COLUMNS") == nullptr && getenv("MIW_FILM_GROUP") == nullptr ? 24 : 0;
-                    if (const char *e = getenv("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 24 : atoi(e);
+                    // (what runs here by default are shards of fewer than 448 tiles — k_film_lanes takes the rest —: 4 x 2 groups, twice as many and half as
+                    // long wavefronts as 2 x 4: a rank's eighth of a 1080p frame 3.63 ms against 4.13, k_film_columns 4.19, gpurun q11; a whole frame 24.1 / 23.8)
+                    int quads = getenv("MIW_FILM_COLUMNS") == nullptr && getenv("MIW_FILM_GROUP") == nullptr ? 42 : 0;
+                    if (const char *e = getenv("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 42 : atoi(e);
                     if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
                     const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
                     if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
