@@ -174,6 +174,35 @@ def live_counters(argv_workload, kernel):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+GOLDEN_FRAMES = {      # the oracle's committed answers for the configurations AS CONFIGURED (tests/golden/make_golden_r3.py .. _r5.py)
+    "c2": ("tests/golden/round3.json", "c2_full_1920x1080_512spp"),
+    "c3": ("tests/golden/round4.json", "c3_full_1920x1080_1024spp"),
+    "c4": ("tests/golden/round5.json", "c4_full_1920x1080_2048spp"),
+    "c5": ("tests/golden/round4.json", "c5_full_1920x1080_512spp_spectral"),
+}
+
+
+def film_parity(film, which, samples=None, segments=None):
+    """Ties the frame that was just TIMED to the oracle: sha256 of the float32 film on the device (one download, outside the timed
+    region) against the digest the scalar oracle produced for this exact job (tests/golden/*.json, a committed fixture: nothing
+    under oracle/ or /root/reference is read here), plus the sample / segment counts of the last frame. `match` is False when a
+    kernel change moved a single bit of the film."""
+    import hashlib
+    path, key = GOLDEN_FRAMES[which]
+    out = {"golden": "%s:%s" % (path, key), "film_sha256": None, "match": None}
+    try:
+        rec = json.load(open(os.path.join(ROOT, path)))[key]
+        out["film_sha256"] = hashlib.sha256(film.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+        out["golden_sha256"] = rec["sha256"]
+        out["match"] = out["film_sha256"] == rec["sha256"]
+        if samples is not None:
+            out["counts_match"] = (int(samples), int(segments)) == (int(rec["samples"]), int(rec["segments"]))
+            out["match"] = bool(out["match"] and out["counts_match"])
+    except Exception as e:
+        out["error"] = repr(e)[:200]
+    return out
+
+
 def run_extras(api, scenes, film, C):
     """The other BASELINE configurations AS CONFIGURED, outside the timed headline, so that the driver's own bench line observes
     the tree kernels and the spectral variant at their configured sizes: configs[2] (material balls, 40 972 triangles) at 1024 spp,
@@ -183,7 +212,7 @@ def run_extras(api, scenes, film, C):
     import torch
     out = {}
 
-    def timed(tag, scene, sensor, spp, note):
+    def timed(tag, scene, sensor, spp, note, golden=None):
         device = api.Device(0)                   # world == 1: the benchmark runs on GPU 0
         try:
             # The tree is built twice and the SECOND build is quoted: the first device work after the previous configuration's context was
@@ -212,19 +241,21 @@ def run_extras(api, scenes, film, C):
                         "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris,
                                 "nodes2": bvh.bvh_nodes, "nodes8": bvh.bvh8_nodes, "depth8": bvh.bvh8_depth, "ms_bvh4": round(bvh.ms_bvh4, 2), "ms_bvh8": round(bvh.ms_bvh8, 2),
                                 "build_ms_first_in_this_context": round(first_build_ms, 1)}}
+            if golden:                            # the frame just timed against the oracle's digest of this configuration
+                out[tag]["parity"] = film_parity(film, golden, c.samples, c.segments)
         finally:
             device.close()
 
     try:
         scene, sensor = scenes.cornell_box(1920, 1080, 1024, diffuse_only=False, device=-1)
-        timed("c3_matball_1024spp", scene, sensor, 1024, "BASELINE configs[2] (GGX conductor + bk7 dielectric balls, 40 972 triangles), 1920x1080 @ its 1024 spp")
+        timed("c3_matball_1024spp", scene, sensor, 1024, "BASELINE configs[2] (GGX conductor + bk7 dielectric balls, 40 972 triangles), 1920x1080 @ its 1024 spp", "c3")
         scene, sensor = scenes.interior_scene(1920, 1080, 2048, device=-1)
-        timed("c4_interior_2048spp", scene, sensor, 2048, "BASELINE configs[3] class (911 362 triangles, area light + 1024x512 environment map), 1920x1080 @ its 2048 spp, one GPU")
+        timed("c4_interior_2048spp", scene, sensor, 2048, "BASELINE configs[3] class (911 362 triangles, area light + 1024x512 environment map), 1920x1080 @ its 2048 spp, one GPU", "c4")
         if os.path.exists(api.default_srgb_coeff()):
             api.set_variant("scalar_spectral"); api.set_srgb_model(api.default_srgb_coeff())
             try:
                 scene, sensor = scenes.cornell_box(1920, 1080, 512, diffuse_only=True, glass_block=True, device=-1)
-                timed("c5_spectral_glassblock_512spp", scene, sensor, 512, "BASELINE configs[4] (scalar_spectral Cornell box with a bk7 dielectric block), 1920x1080 @ its 512 spp")
+                timed("c5_spectral_glassblock_512spp", scene, sensor, 512, "BASELINE configs[4] (scalar_spectral Cornell box with a bk7 dielectric block), 1920x1080 @ its 512 spp", "c5")
             finally:
                 api.set_variant("scalar_rgb")
     except Exception as e:                    # the headline line must not die with an extra
@@ -504,6 +535,13 @@ def main():
             import oracle_py
             O = oracle_py.load(args.variant)
             cpu = cpu_baseline(O, np, scene, make_integrator, sensor, W, H, SPP)
+        # parity of the frame that was timed: the device film of the LAST timed step against the oracle's committed digest of this
+        # exact job (the default headline workload only; an N-rank film differs from it by <= 1 ulp at block borders and is not hashed)
+        parity = None
+        headline = (world == 1 and args.scene == "cornell" and args.variant == "scalar_rgb" and args.shard_of <= 1
+                    and args.integrator == "path" and (W, H, SPP) == (1920, 1080, 512) and shard != "passes")
+        if headline and args.steps > 0:
+            parity = film_parity(film, "c2", hc.samples, hc.segments)
         extras = None
         if (not args.no_extras and world == 1 and args.scene == "cornell" and args.variant == "scalar_rgb" and args.shard_of <= 1
                 and args.integrator == "path" and (W, H, SPP) == (1920, 1080, 512)):
@@ -531,7 +569,7 @@ def main():
                                 if path_kernel == "k_path_resident" else "resident, wave-level phase machine: path + walk state in registers, "
                                 "per-lane LDS stack, nodes / triangles through L1 / L2" + (" (%d-wide quantised tree)" % hc.tree_width if hc.tree_width else "")}[hc.plan],
                        "film": {1: "sample log (%d B per sample) + ordered float32 gather (bit-identical to scalar_rgb order)" % hc.log_record_bytes, 2: "float64 atomics"}[hc.film_mode]},
-            "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         if args.integrator == "direct":
             out["config"]["workload"] = out["config"]["workload"].replace("path integrator max_depth=-1 rr_depth=5", "direct integrator shading_samples=1")

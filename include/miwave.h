@@ -308,6 +308,10 @@ typedef struct {
      * 2 = k_film_columns, 3 = k_film_quads (the default for shards of fewer than 448 tiles), 4 = k_film_lanes (the default from 448 tiles on),
      * and whether the render kernels wrote the 16-byte log interleaved over groups of 64 tiles for it (miw/film.h: log_index) */
     uint32_t film_kernel, log_interleaved;
+    /* ---- round 6 (appended) ---- */
+    uint32_t pooled;           /* 1: the last render's phase machine was k_path_pooled (device/pooled_kernel.h: walk jobs pooled across the
+                                  workgroup through LDS; path_kernel stays 1, tree_width 8); 0: k_path_phased or another kernel             */
+    uint32_t pool_waves;       /* wavefronts per workgroup of that launch (= jobs per LDS column); 0: not pooled                          */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

@@ -52,13 +52,16 @@ __device__ __forceinline__ void tri_fetch2(const GlobalTris &g, uint32_t a, uint
 #if MIW_TRI_FETCH2_ASM && defined(__HIP_DEVICE_COMPILE__)
     GlobalU4 pa = g.p + 3 * (size_t) a, pb = g.p + 3 * (size_t) b;
     miw_u4 q[6];
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[0]) : "v"(pa));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[1]) : "v"(pa));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(q[2]) : "v"(pa));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[3]) : "v"(pb));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(q[4]) : "v"(pb));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(q[5]) : "v"(pb));
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+    // ONE asm statement, early-clobber outputs: the six destinations are not defined (for the compiler: may not be copied, spilled
+    // or shared with the address registers) before the wait at its end has passed — ADVICE r05
+    asm volatile("global_load_dwordx4 %0, %6, off\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %7, off\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:16\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:32\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]) : "v"(pa), "v"(pb) : "memory");
     __builtin_memcpy(&ta, &q[0], sizeof ta); __builtin_memcpy(&tb, &q[3], sizeof tb);
 #else
     ta = g(a); tb = g(b);
@@ -68,6 +71,8 @@ __device__ __forceinline__ void tri_fetch2(const GlobalTris &g, uint32_t a, uint
 struct LdsColumn { int32_t *p; __device__ __forceinline__ int32_t &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
 // the 8-wide walk's column: MIW_BVH8_STACK node groups of 8 bytes (ds_write_b64 / ds_read_b64; the same 128 bytes per lane)
 struct LdsColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) const { return p[i * MIW_BLOCK]; } };
+// (a launch that does not size the column by the 8-wide tree's depth reuses the 4-wide walk's: it must hold MIW_BVH8_STACK groups)
+static_assert(MIW_STACK_ENTRIES * sizeof(int32_t) >= MIW_BVH8_STACK * sizeof(U2), "the 4-wide walk's LDS column is too small for the 8-wide walk's groups");
 
 #ifndef MIW_PIN_TREE_PTRS
 #define MIW_PIN_TREE_PTRS 1           /* 1: node / triangle table pointers of the walk bodies kept in registers (below); C3 +1.5 %, gpurun r4e */

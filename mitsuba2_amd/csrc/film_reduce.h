@@ -14,6 +14,7 @@
 // per border texel as the reference's thread-timing-dependent Film::put order (src/samplers/independent.cpp:36-40).
 #pragma once
 #include <dlfcn.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <rccl/rccl.h>
@@ -31,6 +32,7 @@ struct RcclApi {
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool load() {
         if (tried) return lib != nullptr;
@@ -45,6 +47,7 @@ struct RcclApi {
         Reduce = (decltype(Reduce)) dlsym(lib, "ncclReduce");
         GroupStart = (decltype(GroupStart)) dlsym(lib, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd)) dlsym(lib, "ncclGroupEnd");
+        CommDestroy = (decltype(CommDestroy)) dlsym(lib, "ncclCommDestroy");
         GetErrorString = (decltype(GetErrorString)) dlsym(lib, "ncclGetErrorString");
         if (!CommInitAll || !Reduce || !GroupStart || !GroupEnd) { dlclose(lib); lib = nullptr; }
         return lib != nullptr;
@@ -52,6 +55,15 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mutex;
-static std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;    // one communicator set per device list, kept for the process's life
+static std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;    // one communicator set per device list, kept while a context lives
+static std::atomic<int> g_live_contexts{ 0 };
+// mi_destroy of the LAST context releases the communicators (while HIP is certainly still up: a static destructor at process exit
+// could run after the runtime's own teardown). A later mi_film_reduce builds them again.
+static void rccl_release_comms() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.CommDestroy)
+        for (auto &kv : g_rccl_comms) for (ncclComm_t cm : kv.second) (void) g_rccl.CommDestroy(cm);
+    g_rccl_comms.clear();
+}
 
 } // namespace miw

@@ -74,6 +74,9 @@ static_assert(sizeof(BsdfRec) == 128 && sizeof(mi_bsdf) == 128, "bsdf record lay
 static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 
 #define MIW_BLOCK 256
+#ifndef MIW_POOL_NW
+#define MIW_POOL_NW 12              /* wavefronts per workgroup of k_path_pooled (device/pooled_kernel.h): one workgroup per CU, three wavefronts per SIMD */
+#endif
 #define MIW_CNT_SHARDS 1024        /* power of two */
 #define MIW_BRUTE_MAX_LEAF 2        /* triangles per leaf box of the resident plan's candidate filter */
 #define MIW_BRUTE_MAX_TRIS 64       /* <= this many triangles: LDS brute-force sweep instead of the BVH */
@@ -83,6 +86,7 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #include "device/wavefront_kernels.h"
 #include "device/resident_kernel.h"
 #include "device/phased_kernel.h"
+#include "device/pooled_kernel.h"
 #include "device/stream_trace.h"
 #include "device/film_kernels.h"
 #include "device/eval_kernels.h"
@@ -202,6 +206,7 @@ mi_status mi_create(int32_t device, mi_ctx **out) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters) * MIW_CNT_SHARDS) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
     *out = c;
+    g_live_contexts.fetch_add(1);
     return MI_OK;
 }
 
@@ -218,6 +223,7 @@ void mi_destroy(mi_ctx *c) {
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
+    if (g_live_contexts.fetch_sub(1) == 1) rccl_release_comms();
 }
 
 mi_status mi_set_stream(mi_ctx *c, void *s) { if (!c) return MI_ERR_INVALID; c->stream = (hipStream_t) s; return MI_OK; }
@@ -282,13 +288,16 @@ mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uin
                 if (rc != ncclSuccess) return fail(r, MI_ERR_DEVICE, "mi_film_reduce: ncclCommInitAll: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
                 it = g_rccl_comms.emplace(devs, comms).first;
             }
+            // (no return between GroupStart and GroupEnd: a failure is remembered, the group is always closed, then reported — ADVICE r05)
             ncclResult_t rc = g_rccl.GroupStart();
-            for (int32_t i = 0; i < n && rc == ncclSuccess; ++i) {
-                HIP_TRY(r, hipSetDevice(devs[i]));
-                rc = g_rccl.Reduce(films[i], films[i], (size_t) count, ncclFloat, ncclSum, root, it->second[i], ctxs[i]->stream);
+            hipError_t he = hipSuccess;
+            for (int32_t i = 0; i < n && rc == ncclSuccess && he == hipSuccess; ++i) {
+                he = hipSetDevice(devs[i]);
+                if (he == hipSuccess) rc = g_rccl.Reduce(films[i], films[i], (size_t) count, ncclFloat, ncclSum, root, it->second[i], ctxs[i]->stream);
             }
             const ncclResult_t re = g_rccl.GroupEnd();
             if (rc == ncclSuccess) rc = re;
+            if (he != hipSuccess) return fail(r, MI_ERR_DEVICE, "mi_film_reduce: hipSetDevice: %s", hipGetErrorString(he));
             if (rc != ncclSuccess) return fail(r, MI_ERR_DEVICE, "mi_film_reduce: ncclReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
             for (int32_t i = 0; i < n; ++i) { HIP_TRY(r, hipSetDevice(devs[i])); HIP_TRY(r, hipStreamSynchronize(ctxs[i]->stream)); }
             HIP_TRY(r, hipSetDevice(r->device));
@@ -917,6 +926,17 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         }
     }
 
+    // the 8-wide arrays were sized for the worst case (one node per triangle) before the collapse ran: a tree that was refused or is
+    // not adopted gives them back, an adopted one keeps the nodes it has (0.9 M triangles: 6.9 MB instead of 73 MB) — ADVICE r05
+    if (c->nodes8_count == 0) { c->d_nodes8.release(); c->d_tris8.release(); c->d_tri_vn8.release(); }
+    else if (c->d_nodes8.n > 2 * (size_t) c->nodes8_count) {
+        DevBuf<Bvh8Node> fit;
+        HIP_TRY(c, fit.resize(c->nodes8_count));
+        HIP_TRY(c, hipMemcpyAsync(fit.p, c->d_nodes8.p, (size_t) c->nodes8_count * sizeof(Bvh8Node), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->d_nodes8.release(); c->d_nodes8 = fit;
+    }
+
     c->counters.ms_bvh_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->counters.bvh_nodes = v.node_count; c->counters.bvh_tris = v.tri_count; c->counters.bvh_depth = depth;
     c->counters.bvh4_on_device = (v.nodes4 && wide_on_device) ? 1u : 0u; c->counters.ms_bvh4 = ms_bvh4;
@@ -1212,8 +1232,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // run it sizes the column by the tree's depth instead of the 4-wide walk's 32 x 4 bytes, and the bytes that frees go to more
     // levels of the environment warp (round 5: the 0.9 M-triangle interior, depth 10 -> 20 KB of stack, warp levels down to 64 x 32).
     struct LdsLayout { TraceLds cfg; size_t rlds, rlds_plain, table_bytes; bool tables_fit; };
-    const size_t lds_budget = MIW_LDS_PER_WORKGROUP - MIW_LDS_STATIC - MIW_LDS_GRANULE;
-    auto lay_out = [&](size_t base, size_t env_cap) {
+    const size_t lds_budget4 = MIW_LDS_PER_WORKGROUP - MIW_LDS_STATIC - MIW_LDS_GRANULE;
+    auto lay_out = [&](size_t base, size_t env_cap, size_t lds_budget) {
         LdsLayout L; L.cfg = c->lds_cfg; L.rlds = base;
         L.cfg.thr16 = (uint32_t) ((L.rlds + 15) / 16);
         if (rec16) L.rlds = (size_t) L.cfg.thr16 * 16 + (MIW_FC_TABLE + 3) / 4 * 16;
@@ -1243,7 +1263,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         if (L.tables_fit) L.rlds = (size_t) L.cfg.tab16 * 16 + L.table_bytes;
         return L;
     };
-    LdsLayout lay = lay_out(c->lds_bytes, 4096);
+    LdsLayout lay = lay_out(c->lds_bytes, 4096, lds_budget4);
     // will this render walk the 8-wide tree? (the conditions mi_render applies below, known here already; MIW_BVH8=0 keeps the 4-wide walk)
     const bool pre8 = plan == 2 && cfg->integrator != MI_INTEGRATOR_DIRECT && !c->lds_cfg.brute && c->lds_cfg.stack && c->view.nodes4 && c->nodes8_count != 0u &&
                       !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0) && !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0) &&
@@ -1251,17 +1271,33 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     bool stack8_sized = false;
     if (pre8 && !(getenv("MIW_STACK8_FULL") && atoi(getenv("MIW_STACK8_FULL")) != 0)) {
         const size_t base8 = (size_t) c->lds_cfg.stack16 * 16 + (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * MIW_BLOCK * sizeof(U2);
-        const LdsLayout lay8 = lay_out(base8, 12288);
+        const LdsLayout lay8 = lay_out(base8, 12288, lds_budget4);
         if (lay8.tables_fit && base8 <= c->lds_bytes) { lay = lay8; stack8_sized = true; }
+    }
+    // The pooled phase machine (device/pooled_kernel.h, round 6): ONE workgroup of MIW_POOL_NW wavefronts per CU whose lanes share their walks
+    // through LDS — per lane an 8-byte stack entry per tree level + an 80-byte job record + a status byte, then thresholds, tables and the
+    // environment warp's levels once per CU: [stacks][job records][status][thresholds][tables]. All of the CU's 160 KB may be one workgroup's.
+    // MIW_POOLED=0 keeps k_path_phased (A/B runs, and what shards with placed queues run).
+    LdsLayout layp{}; bool pooled_fits = false;
+    if (pre8 && !(getenv("MIW_POOLED") && atoi(getenv("MIW_POOLED")) == 0)) {
+        const size_t NJ = (size_t) MIW_POOL_NW * 64u;
+        size_t base = (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * NJ * sizeof(U2);
+        const uint32_t pool16 = (uint32_t) (base / 16); base += 5u * NJ * 16u;
+        const uint32_t stat16 = (uint32_t) (base / 16); base += NJ;
+        layp = lay_out(base, 32768, (size_t) 160u * 1024u - 1024u);
+        layp.cfg.stack16 = 0u; layp.cfg.pool16 = pool16; layp.cfg.stat16 = stat16; layp.cfg.nodes_staged = layp.cfg.tris_staged = 0u;
+        pooled_fits = layp.tables_fit;
+        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] pooled phase machine: %d wavefronts per workgroup, LDS %zu bytes (stacks %zu, job records %zu, tables %zu of which environment warp levels %u), fits %d\n",
+                                         MIW_POOL_NW, layp.rlds, (size_t) pool16 * 16, 5u * NJ * 16u, layp.table_bytes, layp.cfg.env_top_words * 4u, (int) pooled_fits);
     }
     TraceLds rcfg = lay.cfg; size_t rlds = lay.rlds; const size_t rlds_plain = lay.rlds_plain, table_bytes = lay.table_bytes; const bool tables_fit = lay.tables_fit;
     if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu%s\n",
-                                     rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget, stack8_sized ? "; stack sized for the 8-wide tree's depth" : "");
+                                     rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget4, stack8_sized ? "; stack sized for the 8-wide tree's depth" : "");
 
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
 
     // event pool for per-launch timing
     struct Stamp { int cls; size_t e0, e1; };
@@ -1491,6 +1527,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, (W) == 2 ? view8 : c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
 #define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_PHASED_LAUNCH_(M, A, 4, W, false); else MIW_PHASED_LAUNCH_(M, A, 3, W, false); } while (0)
                 K.tree_width = phased ? (phased8 ? 8u : (c->view.nodes4 ? 4u : 2u)) : 0u;
+                const bool pooled = phased8 && !place && pooled_fits;
+                if (pooled) {
+                    // one workgroup per CU; the vote: shade once the home lanes whose walks are over outnumber the lanes that find walk work
+                    // shade_num : shade_den; a walk loop hands over once fewer than node_exit / tri_exit of its lanes hold a job
+                    TraceLds pcfg = layp.cfg; pcfg.queues = 1u; pcfg.tail_prio = ph_cfg.tail_prio;
+                    pcfg.shade_num = 4; pcfg.shade_den = 3; pcfg.node_exit = 32u; pcfg.tri_exit = 24u;
+                    if (const char *e = getenv("MIW_POOL_VOTE")) { int a = 0, b = 0, n = 0, t = 0; if (sscanf(e, "%d:%d:%d:%d", &a, &b, &n, &t) == 4 && a > 0 && b > 0) { pcfg.shade_num = (uint32_t) a; pcfg.shade_den = (uint32_t) b; pcfg.node_exit = (uint32_t) n; pcfg.tri_exit = (uint32_t) t; } }
+                    const unsigned NJ = MIW_POOL_NW * 64u;
+                    const dim3 qgrid(std::min<unsigned>((n_lanes + NJ - 1u) / NJ, (unsigned) c->cu_count)), qblock(NJ);
+                    SceneView pview = view8;
+#define MIW_POOLED_LAUNCH(M, A) do { HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_pooled<M, A, MIW_POOL_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) layp.rlds)); \
+                                     MIW_TIMED(6, hipLaunchKernelGGL((k_path_pooled<M, A, MIW_POOL_NW>), qgrid, qblock, layp.rlds, s, P, pview, Q, c->d_cnt.p, pcfg, end, c->d_next_pixel.p)); } while (0)
+                    if (c->textured) MIW_POOLED_LAUNCH(MATS_ALL, true);
+                    else if (trio_kernel) MIW_POOLED_LAUNCH(MATS_TRIO, false);
+                    else if (c->rects.empty()) MIW_POOLED_LAUNCH(MATS_PLAIN, false);
+                    else MIW_POOLED_LAUNCH(MATS_PLAIN, true);
+#undef MIW_POOLED_LAUNCH
+                    K.pooled = 1u; K.pool_waves = MIW_POOL_NW;
+                } else
                 if (phased8 && place) {
                     if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 2, true);
                     else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, 2, true);
@@ -1594,6 +1649,23 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                             (double) ps[8 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[8 + k] / std::max<double>((double) tot, 1));
                 memset(ps, 0, sizeof ps);
                 (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), ps, sizeof ps);
+            }
+        }
+#endif
+#if defined(MIW_PHASE_STATS)
+        if (getenv("MIW_DEBUG") && K.pooled) {
+            unsigned long long ps[32];
+            if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pool_stats), sizeof ps) == hipSuccess) {
+                static const char *names[5] = { "vote", "node trip", "triangle trip", "shade", "idle" };
+                unsigned long long tot = 0;
+                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
+                for (int k = 0; k < 5; ++k)
+                    fprintf(stderr, "[miwave] pooled %-13s runs per 64 segments %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
+                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
+                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
+                fprintf(stderr, "[miwave] pooled claims: %.2f tried per segment, %.1f %% won\n", (double) ps[15] / std::max<double>((double) K.segments, 1), 100.0 * (double) ps[16] / std::max<double>((double) ps[15], 1));
+                memset(ps, 0, sizeof ps);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), ps, sizeof ps);
             }
         }
 #endif

@@ -215,19 +215,17 @@ private:
 class Spiral {
 public:
     Spiral(std::array<int, 2> size, std::array<int, 2> offset, size_t block_size, size_t passes = 1);
-    size_t block_count() const { return m_block_count; }
+    size_t block_count() const { return m_cells.size(); }
     size_t max_block_size() const { return m_block_size; }
     void reset();
     // (offset, size, block_id); size == 0 when exhausted (spiral.cpp:27-72)
     struct Block { std::array<int, 2> offset, size; size_t block_id; };
     Block next_block();
 private:
-    enum class Direction { Right = 0, Down, Left, Up };
-    size_t m_block_counter, m_block_count, m_block_size;
-    std::array<int, 2> m_size, m_offset, m_blocks, m_position;
-    Direction m_current_direction;
-    int m_steps_left, m_steps;
-    size_t m_remaining_passes;
+    std::vector<std::array<int, 2>> m_cells;                   // block positions in visiting order (film_sensor.inl: spiral_cells)
+    size_t m_cursor, m_block_size;
+    std::array<int, 2> m_size, m_offset;
+    size_t m_passes_left;
 };
 
 // ---- Sampler (include/mitsuba/render/sampler.h, src/samplers/independent.cpp) -------------

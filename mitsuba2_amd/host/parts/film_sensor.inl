@@ -128,47 +128,51 @@ std::string Film::develop() const {
 // ============================================================================================
 // Spiral
 // ============================================================================================
+// The visiting order is a TABLE here (all the device ever sees of the spiral is the block -> id table of mi_render_cfg): the
+// walk of spiral.cpp:27-72 — from the centre block, legs Right, Down, Left, Up of 1, 1, 2, 2, 3, 3, ... blocks, positions outside
+// the grid skipped — is laid out once per (grid size) by spiral_cells(), and next_block() reads entry after entry.
+// Pinned against the reference's own vectors by tests/test_oracle_kat.py (test_spiral.py:49-80) and against the oracle's
+// independently written walk (oracle/miw_oracle.cpp).
+static std::vector<std::array<int, 2>> spiral_cells(int nx, int ny) {
+    const size_t total = (size_t) std::max(nx, 0) * (size_t) std::max(ny, 0);
+    std::vector<std::array<int, 2>> cells;
+    cells.reserve(total);
+    if (total == 0) return cells;
+    static const int step_x[4] = { 1, 0, -1, 0 }, step_y[4] = { 0, 1, 0, -1 };     // Right, Down, Left, Up
+    int x = nx / 2, y = ny / 2;
+    cells.push_back({ x, y });
+    for (int leg = 0; cells.size() < total; ++leg) {
+        const int len = leg / 2 + 1, dir = leg & 3;
+        for (int s = 0; s < len && cells.size() < total; ++s) {
+            x += step_x[dir]; y += step_y[dir];
+            if (x >= 0 && y >= 0 && x < nx && y < ny) cells.push_back({ x, y });
+        }
+    }
+    return cells;
+}
+
 Spiral::Spiral(std::array<int, 2> size, std::array<int, 2> offset, size_t block_size, size_t passes)
-    : m_block_size(block_size), m_size(size), m_offset(offset), m_remaining_passes(passes) {
-    m_blocks = { (int) std::ceil((float) m_size[0] / (float) m_block_size),
-                 (int) std::ceil((float) m_size[1] / (float) m_block_size) };
-    m_block_count = (size_t) m_blocks[0] * m_blocks[1];
-    reset();
+    : m_block_size(block_size), m_size(size), m_offset(offset), m_passes_left(passes) {
+    const int bs = (int) block_size;
+    m_cells = spiral_cells((size[0] + bs - 1) / bs, (size[1] + bs - 1) / bs);     // ceil(size / block_size) blocks per axis
+    m_cursor = 0;
 }
-void Spiral::reset() {
-    m_block_counter = 0;
-    m_current_direction = Direction::Right;
-    m_position = { m_blocks[0] / 2, m_blocks[1] / 2 };
-    m_steps_left = 1;
-    m_steps = 1;
-}
+void Spiral::reset() { m_cursor = 0; }
 Spiral::Block Spiral::next_block() {
-    if (m_block_count == m_block_counter) {
-        if (m_remaining_passes > 1) { --m_remaining_passes; reset(); }
-        else return { { 0, 0 }, { 0, 0 }, (size_t) -1 };
+    if (m_cursor == m_cells.size()) {                          // this pass is over: the next one restarts at the centre (spiral.cpp:31-38)
+        if (m_passes_left <= 1) return { { 0, 0 }, { 0, 0 }, (size_t) -1 };
+        --m_passes_left; m_cursor = 0;
     }
-    size_t block_id = m_block_counter + (m_remaining_passes - 1) * m_block_count;
-    std::array<int, 2> offset = { m_position[0] * (int) m_block_size, m_position[1] * (int) m_block_size };
-    std::array<int, 2> size = { std::min((int) m_block_size, m_size[0] - offset[0]),
-                                std::min((int) m_block_size, m_size[1] - offset[1]) };
-    offset[0] += m_offset[0]; offset[1] += m_offset[1];
-    ++m_block_counter;
-    if (m_block_counter != m_block_count) {
-        do {
-            switch (m_current_direction) {
-                case Direction::Right: ++m_position[0]; break;
-                case Direction::Down:  ++m_position[1]; break;
-                case Direction::Left:  --m_position[0]; break;
-                case Direction::Up:    --m_position[1]; break;
-            }
-            if (--m_steps_left == 0) {
-                m_current_direction = Direction(((int) m_current_direction + 1) % 4);
-                if (m_current_direction == Direction::Left || m_current_direction == Direction::Right) ++m_steps;
-                m_steps_left = m_steps;
-            }
-        } while (m_position[0] < 0 || m_position[1] < 0 || m_position[0] >= m_blocks[0] || m_position[1] >= m_blocks[1]);
+    const int bs = (int) m_block_size;
+    const std::array<int, 2> cell = m_cells[m_cursor];
+    Block b;
+    b.block_id = m_cursor + (m_passes_left - 1) * m_cells.size();                   // spiral.cpp:41: later passes carry smaller ids
+    for (int a = 0; a < 2; ++a) {
+        b.size[a] = std::min(bs, m_size[a] - cell[a] * bs);    // edge blocks are clipped to the crop window
+        b.offset[a] = cell[a] * bs + m_offset[a];
     }
-    return { offset, size, block_id };
+    ++m_cursor;
+    return b;
 }
 
 // ============================================================================================

@@ -456,6 +456,10 @@ static void flatten(const std::vector<std::shared_ptr<Mesh>> &shapes, std::vecto
 }
 void Scene::build(int device, int bvh_quality) {
     if (m_shapes.empty()) Throw("Scene: no shapes");
+    // a single-device (re)build leaves ONE context: replicas of an earlier build(devices) would keep the old scene and BVH, and
+    // render() would deal spiral blocks to them. build(devices) clears them itself before it calls this, then re-creates them.
+    for (mi_ctx *c : m_replicas) mi_destroy(c);
+    m_replicas.clear();
     flatten(m_shapes, m_positions, m_normals, m_texcoords, m_bitmap_recs, m_bitmap_objs, m_bsdf_tables, m_faces, m_shape_recs, m_bsdf_recs, m_emitters, m_rect_recs, m_sphere_recs);
     m_desc.spheres = m_sphere_recs.empty() ? nullptr : m_sphere_recs.data(); m_desc.sphere_count = (uint32_t) m_sphere_recs.size();
     m_desc.rectangles = m_rect_recs.empty() ? nullptr : m_rect_recs.data(); m_desc.rectangle_count = (uint32_t) m_rect_recs.size();

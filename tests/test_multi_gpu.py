@@ -115,3 +115,24 @@ def test_rccl_branch_of_the_film_reduce_runs_on_one_gpu(native, monkeypatch):
         L.mi_film_free(dev.ctx, film)
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_single_device_rebuild_after_a_multi_gpu_build_drops_the_replicas(native):
+    """ADVICE r05: Scene::build(int) after Scene::build(devices) must leave ONE context — replicas that kept the old scene and
+    BVH would go on receiving their share of the spiral blocks. The rebuilt scene renders the one-context film bit for bit."""
+    from mitsuba2_amd import scenes
+    W, H, SPP = 96, 64, 4
+    scene, sensor = scenes.cornell_box(W, H, SPP, device=0)
+    integ = native.PathIntegrator()
+    assert integ.render(scene, sensor) is True
+    one = sensor.film.data((H, W, 5)).copy()
+    scene.build([0, 0, 0])
+    assert scene.device_count() == 3
+    scene.build(0)
+    assert scene.device_count() == 1
+    integ = native.PathIntegrator()
+    assert integ.render(scene, sensor) is True
+    assert integ.last_reduce() == 0                                # one context: no film reduce ran
+    assert np.array_equal(sensor.film.data((H, W, 5)), one)
