@@ -182,7 +182,9 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 
     // -DMIW_PHASE_STATS=1 (debug builds): per body, how often a wave ran it, with how many lanes, and the wall cycles it took
 #if defined(MIW_PHASE_STATS)
-    unsigned long long ps_runs[4] = { 0, 0, 0, 0 }, ps_lanes[4] = { 0, 0, 0, 0 }, ps_cycles[4] = { 0, 0, 0, 0 }, ps_t0 = __builtin_amdgcn_s_memtime();
+    // (round 6: every stamp stands at the END of what it charges — a node / triangle trip, the E -> S turn, a shade run, the vote — so that no
+    // body is charged the last trip of the loop before it or the vote; buckets: 0 node trip, 1 triangle trip, 2 walk end (turn), 3 shade, 4 vote)
+    unsigned long long ps_runs[5] = { 0, 0, 0, 0, 0 }, ps_lanes[5] = { 0, 0, 0, 0, 0 }, ps_cycles[5] = { 0, 0, 0, 0, 0 }, ps_t0 = __builtin_amdgcn_s_memtime();
 #define MIW_PS(k, lanes_) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ps_runs[k]++; ps_lanes[k] += (unsigned) (lanes_); ps_cycles[k] += now_ - ps_t0; ps_t0 = now_; } while (0)
 #else
 #define MIW_PS(k, lanes_) do { } while (0)
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         const int n_end = 0;
         if ((n_node | n_leaf | n_shade) == 0) break;
         const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
+        MIW_PS(4, 0);                                                    // the vote (+ the loop exit tests of the body before it)
 
         if (n_shade * shade_num >= lead * shade_den && n_shade > 0) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                 MIW_PS(2, n_turn);
             }
             do {
-                MIW_PS(0, count(e_node));
+                const int ps_now_ = count(e_node); (void) ps_now_;
                 if (e_node) {
                     if (Wide == 2) {
                         // one 80-byte node = eight quantised child boxes: the node step of miw/bvh8.h (the CPU checker runs the same statements)
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         cur = next;
                     }
                 }
+                MIW_PS(0, ps_now_);
                 has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
                 e_node = trav && (Wide == 2 ? walk8_node_ready<Spec8>(w8) : cur >= 0 && (Spec || !has_range));
                 const int now = count(e_node);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
             // ---------------- triangle tests: same shape; owns the best hit, tmax, the leaf range, cur and sp ----------------
             const int others = n_shade > n_end * MIW_PHASE_END_WEIGHT ? n_shade : n_end * MIW_PHASE_END_WEIGHT;
             do {
-                MIW_PS(1, count(e_leaf));
+                const int ps_now_ = count(e_leaf); (void) ps_now_;
                 if (e_leaf) {
                     const bool s_walk = mode == PH_TRAV_S;
                     const V3 d_cur = s_walk ? sh.d : L.ray.d;
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     }
 #endif
                 }
+                MIW_PS(1, ps_now_);
                 has_range = Wide == 2 ? walk8_tri_ready(w8) : tri_i < tri_end;
                 e_leaf = trav && has_range;
                 const int now = count(e_leaf);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
 
 #if defined(MIW_PHASE_STATS)
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 4; ++k) { atomicAdd(&g_phase_stats[k], ps_runs[k]); atomicAdd(&g_phase_stats[4 + k], ps_lanes[k]); atomicAdd(&g_phase_stats[8 + k], ps_cycles[k]); }
+        for (int k = 0; k < 5; ++k) { atomicAdd(&g_phase_stats[k], ps_runs[k]); atomicAdd(&g_phase_stats[5 + k], ps_lanes[k]); atomicAdd(&g_phase_stats[10 + k], ps_cycles[k]); }
 #endif
     unsigned long long a = wave_sum(local.segments), b = wave_sum(local.samples), c = wave_sum(local.shadow_rays);
 #if defined(MIW_SECTION_PROFILE) && defined(__HIP_DEVICE_COMPILE__)

@@ -36,18 +36,21 @@ enum : uint32_t { PJ_N = 1u, PJ_T = 2u, PJ_D = 4u, PJ_S = 0x10u, PJ_O = 0x20u, P
 enum : uint32_t { PM_SHADE = 0u, PM_WALK = 1u, PM_OUT = 2u };
 #define MIW_POOL_NOJOB 0xffffffffu
 
-template <int NW> struct PoolColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) const { return p[i * (NW * 64)]; } };
+template <int NJ_> struct PoolColumn8 { U2 *p; __device__ __forceinline__ U2 &operator[](int32_t i) const { return p[i * NJ_]; } };
 
 #if defined(MIW_PHASE_STATS)
 __device__ unsigned long long g_pool_stats[32];    // per bucket (vote, node, triangle, shade, idle): runs, lanes, wall cycles; + claims tried / won
 #endif
 
-// NW = wavefronts per workgroup = jobs per column; the workgroup is the whole CU's share (NW = 12: three wavefronts per SIMD, 168 VGPRs)
-template <int Mats, bool Analytic, int NW>
+// NW = wavefronts per workgroup (one workgroup per CU); PP = pixels (paths) per lane: 1, or 2 — with as many jobs as lanes every
+// job would have to be in service all the time for the lanes to be full (r6a / r6b: they are not: a third of the jobs wait for
+// their shade), so a lane may be the home of TWO pixels: twice the jobs for the same lanes. A column then holds PP x NW jobs:
+// job j = row * 64 + i, row = p * NW + w.
+template <int Mats, bool Analytic, int NW, int PP>
 __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                    TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
-    static_assert(NW % 4 == 0 && NW >= 4 && NW <= 16, "a column's status bytes are whole words");
-    constexpr uint32_t NJ = NW * 64u, NWQ = NW / 4u;
+    constexpr uint32_t ROWS = (uint32_t) (NW * PP), NJ = ROWS * 64u, NWQ = ROWS / 4u;
+    static_assert(ROWS % 4 == 0 && ROWS >= 4 && ROWS <= 16 && (PP == 1 || PP == 2), "a column's status bytes are one to four whole words");
     constexpr bool Spec8 = true;
     extern __shared__ uint4 smem[];
     const float *thr = stage_thresholds(smem, cfg, Q.log_rec ? Q.log_thr : nullptr);
@@ -55,10 +58,12 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
     U2 *const stacks = reinterpret_cast<U2 *>(smem + cfg.stack16);                 // [entry][job]
     uint4 *const pool = smem + cfg.pool16;                                         // [slot 0..4][job]
     uint32_t *const statw = reinterpret_cast<uint32_t *>(smem + cfg.stat16);       // [NWQ][64]: byte b of word k of column i = job (4 k + b) * 64 + i
-    const uint32_t li = threadIdx.x & 63u, wv = threadIdx.x >> 6, me = threadIdx.x;
-    const uint32_t own_k = wv >> 2, own_sh = 8u * (wv & 3u);
+    const uint32_t li = threadIdx.x & 63u, wv = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // (wv: wave-uniform, in an SGPR)
     uint32_t *const colw = statw + li;                                             // this lane's column: colw[k * 64]
-    reinterpret_cast<volatile uint8_t *>(statw)[(own_k * 64u + li) * 4u + (wv & 3u)] = (uint8_t) PJ_C;   // with its home lane
+    for (uint32_t p = 0; p < (uint32_t) PP; ++p) {
+        const uint32_t row = p * NW + wv;
+        reinterpret_cast<volatile uint8_t *>(statw)[((row >> 2) * 64u + li) * 4u + (row & 3u)] = (uint8_t) PJ_C;   // with its home lane
+    }
     __syncthreads();
 
     GlobalU4 tris_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.tris), nodes8_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes8);
@@ -78,12 +83,15 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
     work.film = &P.film; work.thr = thr; work.init_queues(1u);
     __shared__ uint32_t s_prog[NW];
     if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[wv]);
-    LaneRegs L;
-    L.flags = LF_DONE; L.sample_idx = 0; L.rng.state = 0; L.rng.inc = MIW_PCG32_SCALAR_INC;
-    uint32_t pixel = 0;
-    bool have = false, dead_pending = false;
-    ShadowOut sh; sh.has = false; sh.d = v3(0.f); sh.maxt = -1.f; sh.c = spec(0.f);
-    uint32_t mode = PM_SHADE;
+    // what a pixel's home lane keeps in registers: the path state between two scene queries
+    struct Home { LaneRegs L; ShadowOut sh; uint32_t pixel, qlane, mode; bool have, dead_pending; };
+    auto home_init = [](Home &H) {
+        H.L.flags = LF_DONE; H.L.sample_idx = 0; H.L.rng.state = 0; H.L.rng.inc = MIW_PCG32_SCALAR_INC;
+        H.pixel = 0; H.qlane = 0; H.mode = PM_SHADE; H.have = false; H.dead_pending = false;
+        H.sh.has = false; H.sh.d = v3(0.f); H.sh.maxt = -1.f; H.sh.c = spec(0.f);
+    };
+    Home H0, H1; home_init(H0); home_init(H1);
+    if (PP == 1) H1.mode = PM_OUT;
 
 #if defined(MIW_PHASE_STATS)
     unsigned long long ps_runs[5] = { 0, 0, 0, 0, 0 }, ps_lanes[5] = { 0, 0, 0, 0, 0 }, ps_cycles[5] = { 0, 0, 0, 0, 0 }, ps_claims[2] = { 0, 0 }, ps_t0 = __builtin_amdgcn_s_memtime();
@@ -95,9 +103,16 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
 #define MIW_PP_CLAIM(tried_, won_) do { } while (0)
 #endif
     auto count = [](bool p) -> int { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); };
-    auto col_read = [colw](uint32_t (&sw)[NWQ]) {
+    // (the column snapshot is a register VECTOR indexed by compile-time constants: an array indexed inside these lambdas ends up in scratch)
+    auto col_read = [colw](miw_u4 &sw) {
 #pragma unroll
         for (uint32_t k = 0; k < NWQ; ++k) sw[k] = __hip_atomic_load(colw + k * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto status_of = [](const miw_u4 &a, uint32_t row) -> uint32_t {     // the status byte of row `row` (wave-uniform) in a snapshot
+        uint32_t r = a[0];
+#pragma unroll
+        for (uint32_t q = 1; q < NWQ; ++q) r = (row >> 2) == q ? a[q] : r;
+        return (r >> (8u * (row & 3u))) & 0xffu;
     };
     auto lds_fence = []() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -107,37 +122,49 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
     // hand a job back: `st` = its new status byte (no claimed bit); the record words were stored before this call
     auto release = [statw, li, &lds_fence](uint32_t j, uint32_t st) {
         lds_fence();
-        const uint32_t w = j >> 6;
-        reinterpret_cast<volatile uint8_t *>(statw)[((w >> 2) * 64u + li) * 4u + (w & 3u)] = (uint8_t) st;
+        const uint32_t row = j >> 6;
+        reinterpret_cast<volatile uint8_t *>(statw)[((row >> 2) * 64u + li) * 4u + (row & 3u)] = (uint8_t) st;
     };
-    // take a job of this lane's column that is ready for the body `want` (PJ_N / PJ_T) and unclaimed: its own first, else the first / last
-    // ready one (`from_top` alternates between lanes and trips, so that no wavefront's jobs are systematically served last).
-    // -> job index or MIW_POOL_NOJOB; `st` = the status byte it had.
-    auto claim = [&](const uint32_t (&sw)[NWQ], uint32_t want, bool from_top, uint32_t &st) -> uint32_t {
-        const uint32_t shift = want == PJ_N ? 0u : 1u;
-        uint32_t ck = MIW_POOL_NOJOB, cb = 0u;
-        if (((sw[own_k] >> own_sh) & (PJ_C | want)) == want) { ck = own_k; cb = wv & 3u; }
-        else {
-#pragma unroll
-            for (uint32_t q = 0; q < NWQ; ++q) {
-                const uint32_t k = from_top ? NWQ - 1u - q : q;
-                const uint32_t m = (sw[k] >> shift) & ~(sw[k] >> 7) & 0x01010101u;
-                if (ck == MIW_POOL_NOJOB && m != 0u) { ck = k; cb = (from_top ? 31u - (uint32_t) __builtin_clz(m) : (uint32_t) __builtin_ctz(m)) >> 3; }
-            }
-        }
-        if (ck == MIW_POOL_NOJOB) return MIW_POOL_NOJOB;
-        const uint32_t old = __hip_atomic_fetch_or(colw + ck * 64u, PJ_C << (8u * cb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the claimed bit of row `row` of this lane's column, atomically: -> the status byte the job had (with the bit: somebody else holds it)
+    auto take = [colw](uint32_t row) -> uint32_t {
+        const uint32_t sh_ = 8u * (row & 3u);
+        const uint32_t old = __hip_atomic_fetch_or(colw + (row >> 2) * 64u, PJ_C << sh_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" ::: "memory");
 #endif
-        const uint32_t ob = (old >> (8u * cb)) & 0xffu;
+        return (old >> sh_) & 0xffu;
+    };
+    // take a job of this lane's column that is ready for the body `want` (PJ_N / PJ_T) and unclaimed: one of its own pixels' first, else the
+    // first / last ready one (`from_top` alternates between lanes and trips, so that no wavefront's jobs are systematically served last).
+    // -> job index or MIW_POOL_NOJOB; `st` = the status byte it had.
+    auto claim = [&](miw_u4 &sw, uint32_t want, bool from_top, uint32_t &st) -> uint32_t {
+        const uint32_t shift = want == PJ_N ? 0u : 1u;
+        uint32_t row = MIW_POOL_NOJOB;
+        if ((status_of(sw, wv) & (PJ_C | want)) == want) row = wv;
+        else if (PP == 2 && (status_of(sw, NW + wv) & (PJ_C | want)) == want) row = NW + wv;
+        else {
+            uint32_t lo = MIW_POOL_NOJOB, hi = MIW_POOL_NOJOB;
+#pragma unroll
+            for (uint32_t q = 0; q < NWQ; ++q) {
+                const uint32_t m = (sw[q] >> shift) & ~(sw[q] >> 7) & 0x01010101u;
+                if (m != 0u) {
+                    if (lo == MIW_POOL_NOJOB) lo = 4u * q + ((uint32_t) __builtin_ctz(m) >> 3);
+                    hi = 4u * q + ((31u - (uint32_t) __builtin_clz(m)) >> 3);
+                }
+            }
+            row = from_top ? hi : lo;
+        }
+        if (row == MIW_POOL_NOJOB) return MIW_POOL_NOJOB;
+        const uint32_t ob = take(row);
+#pragma unroll
+        for (uint32_t q = 0; q < NWQ; ++q) sw[q] |= (row >> 2) == q ? PJ_C << (8u * (row & 3u)) : 0u;   // (the caller's snapshot: this lane's next claim looks elsewhere)
         if (ob & PJ_C) return MIW_POOL_NOJOB;                      // somebody else was faster
         if (!(ob & want)) {                                       // mine, but no longer in the state this body serves: give it back as it is
-            __hip_atomic_fetch_and(colw + ck * 64u, ~(PJ_C << (8u * cb)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_and(colw + (row >> 2) * 64u, ~(PJ_C << (8u * (row & 3u))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return MIW_POOL_NOJOB;
         }
         st = ob;
-        return (4u * ck + cb) * 64u + li;
+        return row * 64u + li;
     };
     struct SignRay { V3 inv_d; };                                  // (walk8_begin reads the octant = the signs of 1 / d = the signs of d: fast_ray keeps them)
     // A walk of job j is over (`w` empty). If it was the shadow walk and an extension ray waits in slot 4, the record becomes the
@@ -158,146 +185,164 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
         pool[4u * NJ + j] = b;                                     // best.t, u, v
         return true;
     };
+    // is the pixel H (status row `row`) ready for its shade in the snapshot sw?
+    auto shade_ready = [&status_of](const Home &H, const miw_u4 &sw, uint32_t row) -> bool {
+        return H.mode == PM_SHADE || (H.mode == PM_WALK && (status_of(sw, row) & PJ_STATE) == PJ_D);
+    };
+    // ---------------- shade: everything between two scene queries, for the pixel H of this lane (its job: row `row` of the column) ----------------
+    auto shade_path = [&](Home &H, uint32_t row) {
+        const uint32_t me = row * 64u + li;
+        LaneRegs &L = H.L; ShadowOut &sh = H.sh;
+        bool occl = false;
+        F4 hitE; hitE.x = MIW_INFINITY; hitE.y = hitE.z = 0.f; hitE.w = u2f(MIW_MISS);
+        V3 o = v3(0.f);
+        if (H.mode == PM_WALK) {                               // take the finished job back
+            const uint32_t ob = take(row);
+            if ((ob & PJ_STATE) != PJ_D) return;               // (a lane that looked at it a moment ago holds it for an instant; next vote)
+            const uint4 s0 = pool[0u * NJ + me], s1 = pool[1u * NJ + me], s3 = pool[3u * NJ + me], s4 = pool[4u * NJ + me];
+            o = v3(u2f(s0.x), u2f(s0.y), u2f(s0.z));
+            L.ray.d = v3(u2f(s1.x), u2f(s1.y), u2f(s1.z));
+            hitE.x = u2f(s3.z); hitE.y = u2f(s4.y); hitE.z = u2f(s4.z); hitE.w = u2f(s3.w);   // best.t = tmax whenever best.tri is a hit
+            occl = (ob & PJ_O) != 0u;
+        }
+        work.lane = H.qlane;
+        if (!(L.flags & LF_DONE)) {
+            if (sh.has && !occl) L.res = L.res + sh.c;          // path.cpp:171 of the previous vertex
+            sh.has = false;
+            int rstep = STEP_FINISHED;
+            if (!H.dead_pending) rstep = path_step<Mats, Analytic>(P, sc, L, hitE, [o]() { return o; }, sh, &local);
+            if (!H.dead_pending && rstep == STEP_DEAD_PENDING) H.dead_pending = true;   // one more job for its shadow ray
+            else if (H.dead_pending || rstep == STEP_FINISHED) {
+                H.dead_pending = false;
+                auto sink = [&work](uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { work.put(px, sample_idx, pos, aovs); };
+                lane_finish_sample(P, H.pixel, L, sink);
+                local.samples++;
+                L.flags = 0;
+                lane_begin_sample(P, H.pixel, L, sample_end);
+            }
+        }
+        while (L.flags & LF_DONE) {                                 // pixel finished (or no pixel yet): take the next one
+            if (H.have) {
+                U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
+                st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;
+                work.store(st);
+            }
+            U4 st;
+            H.have = work.fetch(H.pixel, st);
+            if (!H.have) break;
+            L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
+            L.sample_idx = st.w; L.flags = 0;
+            lane_begin_sample(P, H.pixel, L, sample_end);
+        }
+        H.qlane = work.lane;
+        if (L.flags & LF_DONE) { H.mode = PM_OUT; return; }         // (its byte keeps the claimed bit: with its home lane for good)
+        // post the job: the shadow walk first when a shadow ray is queued, then the extension walk (dead_pending: the shadow walk only)
+        H.mode = PM_WALK;
+        const bool hasS = sh.has;
+        const V3 d0 = hasS ? sh.d : L.ray.d;
+        const float maxt0 = hasS ? sh.maxt : L.ray.maxt;
+        Walk8 w; SignRay sg{ d0 }; walk8_begin(w, sg);
+        uint4 s;
+        s.x = f2u(L.ray.o.x); s.y = f2u(L.ray.o.y); s.z = f2u(L.ray.o.z); s.w = f2u(L.ray.mint); pool[0u * NJ + me] = s;
+        s.x = f2u(d0.x); s.y = f2u(d0.y); s.z = f2u(d0.z); s.w = f2u(maxt0); pool[1u * NJ + me] = s;
+        s.x = w.gb; s.y = w.gm; s.z = w.tb; s.w = w.tm; pool[2u * NJ + me] = s;
+        s.x = w.tb2; s.y = w.tm2; s.z = f2u(maxt0); s.w = MIW_MISS; pool[3u * NJ + me] = s;
+        if (hasS) { s.x = f2u(L.ray.d.x); s.y = f2u(L.ray.d.y); s.z = f2u(L.ray.d.z); s.w = f2u(H.dead_pending ? -1.f : L.ray.maxt); }
+        else { s.x = f2u(MIW_INFINITY); s.y = 0u; s.z = 0u; s.w = 0u; }
+        pool[4u * NJ + me] = s;
+        release(me, PJ_N | (hasS ? PJ_S : 0u));
+    };
 
-    const int shade_num = (int) cfg.shade_num, shade_den = (int) cfg.shade_den;
-    const int node_min = (int) cfg.node_exit, tri_min = (int) cfg.tri_exit;          // a walk loop hands over once fewer lanes than this hold a job
+    // the vote's constants (host: mi_render; MIW_POOL_VOTE overrides): a wavefront shades the pixels p of its lanes once `shade_min` of them wait
+    // for it (three quarters of those that still have a pixel, when fewer do), or when fewer than `walk_min` of its lanes find walk work; a walk loop
+    // hands over once fewer than node_min (of 128: two jobs per lane) / tri_min (of 64) of its slots hold a job, and looks for new jobs only when
+    // at least claim_min of a slot's lanes are empty (the claim code runs for the whole wavefront whoever needs it)
+    const int shade_min = (int) cfg.shade_num, walk_min = (int) cfg.shade_den;
+    const int node_min = (int) cfg.node_exit, tri_min = (int) cfg.tri_exit, claim_min = (int) cfg.pool_claim_min;
     uint32_t trip = 0;
     for (;;) {
         // ---- the vote ----
-        uint32_t sw[NWQ];
+        miw_u4 sw = { 0u, 0u, 0u, 0u };
         col_read(sw);
-        const uint32_t own = (sw[own_k] >> own_sh) & 0xffu;
-        const bool e_shade = mode == PM_SHADE || (mode == PM_WALK && (own & PJ_STATE) == PJ_D);
+        const bool e_shade0 = shade_ready(H0, sw, wv), e_shade1 = PP == 2 && shade_ready(H1, sw, NW + wv);
         uint32_t any_n = 0u, any_t = 0u;
 #pragma unroll
         for (uint32_t k = 0; k < NWQ; ++k) { const uint32_t free_ = ~(sw[k] >> 7) & 0x01010101u; any_n |= sw[k] & free_; any_t |= (sw[k] >> 1) & free_; }
-        const int n_node = count(any_n != 0u), n_leaf = count(any_t != 0u), n_shade = count(e_shade);
-        if (count(mode == PM_OUT) == 64) break;
+        const int n_node = count(any_n != 0u), n_leaf = count(any_t != 0u), n_shade0 = count(e_shade0), n_shade1 = PP == 2 ? count(e_shade1) : 0;
+        const int n_out0 = count(H0.mode == PM_OUT), n_out1 = PP == 2 ? count(H1.mode == PM_OUT) : 64;
+        if (n_out0 == 64 && n_out1 == 64) break;
         const int lead = n_node > n_leaf ? n_node : n_leaf;
+        auto thr_of = [shade_min](int n_out) -> int { const int q = (3 * (64 - n_out) + 3) / 4; return shade_min < q ? shade_min : q; };
+        const int thr0 = thr_of(n_out0), thr1 = thr_of(n_out1);
+        const bool starved = lead < walk_min;
+        const bool go0 = n_shade0 > 0 && (n_shade0 >= thr0 || starved), go1 = n_shade1 > 0 && (n_shade1 >= thr1 || starved);
         MIW_PP(0, 0);
 
-        if (n_shade > 0 && n_shade * shade_num >= lead * shade_den) {
-            // ---------------- shade: everything between two scene queries, on the home lanes whose walks are over ----------------
-            work.tick(L.sample_idx, mode != PM_OUT && !(L.flags & LF_DONE));
-            if (e_shade) {
-                bool go = true, occl = false;
-                F4 hitE; hitE.x = MIW_INFINITY; hitE.y = hitE.z = 0.f; hitE.w = u2f(MIW_MISS);
-                V3 o = v3(0.f);
-                if (mode == PM_WALK) {                               // take the finished job back
-                    const uint32_t old = __hip_atomic_fetch_or(colw + own_k * 64u, PJ_C << own_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" ::: "memory");
-#endif
-                    const uint32_t ob = (old >> own_sh) & 0xffu;
-                    go = (ob & PJ_STATE) == PJ_D;                    // (else: a lane that looked at it a moment ago holds it for an instant; next vote)
-                    if (go) {
-                        const uint4 s0 = pool[0u * NJ + me], s1 = pool[1u * NJ + me], s3 = pool[3u * NJ + me], s4 = pool[4u * NJ + me];
-                        o = v3(u2f(s0.x), u2f(s0.y), u2f(s0.z));
-                        L.ray.d = v3(u2f(s1.x), u2f(s1.y), u2f(s1.z));
-                        hitE.x = u2f(s3.z); hitE.y = u2f(s4.y); hitE.z = u2f(s4.z); hitE.w = u2f(s3.w);   // best.t = tmax whenever best.tri is a hit
-                        occl = (ob & PJ_O) != 0u;
-                    }
-                }
-                if (go) {
-                    if (!(L.flags & LF_DONE)) {
-                        if (sh.has && !occl) L.res = L.res + sh.c;          // path.cpp:171 of the previous vertex
-                        sh.has = false;
-                        int rstep = STEP_FINISHED;
-                        if (!dead_pending) rstep = path_step<Mats, Analytic>(P, sc, L, hitE, [o]() { return o; }, sh, &local);
-                        if (!dead_pending && rstep == STEP_DEAD_PENDING) dead_pending = true;   // one more job for its shadow ray
-                        else if (dead_pending || rstep == STEP_FINISHED) {
-                            dead_pending = false;
-                            auto sink = [&work](uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { work.put(px, sample_idx, pos, aovs); };
-                            lane_finish_sample(P, pixel, L, sink);
-                            local.samples++;
-                            L.flags = 0;
-                            lane_begin_sample(P, pixel, L, sample_end);
-                        }
-                    }
-                    while (L.flags & LF_DONE) {                                 // pixel finished (or no pixel yet): take the next one
-                        if (have) {
-                            U4 st; st.x = (uint32_t) L.rng.state; st.y = (uint32_t) (L.rng.state >> 32);
-                            st.z = L.sample_idx >= P.spp ? (uint32_t) LF_DONE : 0u; st.w = L.sample_idx;
-                            work.store(st);
-                        }
-                        U4 st;
-                        have = work.fetch(pixel, st);
-                        if (!have) break;
-                        L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
-                        L.sample_idx = st.w; L.flags = 0;
-                        lane_begin_sample(P, pixel, L, sample_end);
-                    }
-                    if (L.flags & LF_DONE) mode = PM_OUT;                       // (its byte keeps the claimed bit: with its home lane for good)
-                    else {
-                        // post the job: the shadow walk first when a shadow ray is queued, then the extension walk (dead_pending: the shadow walk only)
-                        mode = PM_WALK;
-                        const bool hasS = sh.has;
-                        const V3 d0 = hasS ? sh.d : L.ray.d;
-                        const float maxt0 = hasS ? sh.maxt : L.ray.maxt;
-                        Walk8 w; SignRay sg{ d0 }; walk8_begin(w, sg);
-                        uint4 s;
-                        s.x = f2u(L.ray.o.x); s.y = f2u(L.ray.o.y); s.z = f2u(L.ray.o.z); s.w = f2u(L.ray.mint); pool[0u * NJ + me] = s;
-                        s.x = f2u(d0.x); s.y = f2u(d0.y); s.z = f2u(d0.z); s.w = f2u(maxt0); pool[1u * NJ + me] = s;
-                        s.x = w.gb; s.y = w.gm; s.z = w.tb; s.w = w.tm; pool[2u * NJ + me] = s;
-                        s.x = w.tb2; s.y = w.tm2; s.z = f2u(maxt0); s.w = MIW_MISS; pool[3u * NJ + me] = s;
-                        if (hasS) { s.x = f2u(L.ray.d.x); s.y = f2u(L.ray.d.y); s.z = f2u(L.ray.d.z); s.w = f2u(dead_pending ? -1.f : L.ray.maxt); }
-                        else { s.x = f2u(MIW_INFINITY); s.y = 0u; s.z = 0u; s.w = 0u; }
-                        pool[4u * NJ + me] = s;
-                        release(me, PJ_N | (hasS ? PJ_S : 0u));
-                    }
-                }
-            }
-            MIW_PP(3, n_shade);
+        if (go0 || go1) {
+            work.tick(H0.L.sample_idx, H0.mode != PM_OUT && !(H0.L.flags & LF_DONE));
+            if (go0) { if (e_shade0) shade_path(H0, wv); MIW_PP(3, n_shade0); }
+            if (PP == 2 && go1) { if (e_shade1) shade_path(H1, NW + wv); MIW_PP(3, n_shade1); }
         } else if (n_node >= n_leaf && n_node > 0) {
-            // ---------------- node steps on the column's node-ready jobs ----------------
-            uint32_t j = MIW_POOL_NOJOB, sb = 0u;
-            Walk8 w; w.gb = w.gm = w.tb = w.tm = w.tb2 = w.tm2 = 0u;
-            FastRay r; r.inv_d = r.neg_o_inv_d = v3(0.f); r.mint = 0.f;
-            float tmax = 0.f;
-            auto store_walk = [&]() {
-                uint4 s; s.x = w.gb; s.y = w.gm; s.z = w.tb; s.w = w.tm; pool[2u * NJ + j] = s;
-                uint2 t; t.x = w.tb2; t.y = w.tm2; reinterpret_cast<uint2 *>(pool + 3u * NJ + j)[0] = t;
+            // ---------------- node steps on the column's node-ready jobs: every lane works on up to TWO of them, so that two node fetches
+            // (2 x five 16-byte requests) are in flight per lane while it computes — a job record in LDS is what lets one lane hold two
+            // walks (k_path_phased: one walk per lane, tied to its pixel) ----------------
+            struct NodeSlot { uint32_t j, sb; Walk8 w; FastRay r; float tmax; Bvh8Node nd; };
+            NodeSlot A, B;
+            A.j = B.j = MIW_POOL_NOJOB; A.sb = B.sb = 0u; A.tmax = B.tmax = 0.f;
+            A.w.gb = A.w.gm = A.w.tb = A.w.tm = A.w.tb2 = A.w.tm2 = 0u; B.w = A.w;
+            A.r.inv_d = A.r.neg_o_inv_d = v3(0.f); A.r.mint = 0.f; B.r = A.r;
+            auto store_walk = [&](const NodeSlot &t) {
+                uint4 q; q.x = t.w.gb; q.y = t.w.gm; q.z = t.w.tb; q.w = t.w.tm; pool[2u * NJ + t.j] = q;
+                uint2 h; h.x = t.w.tb2; h.y = t.w.tm2; reinterpret_cast<uint2 *>(pool + 3u * NJ + t.j)[0] = h;
             };
+            // an empty slot takes a node-ready job of the column (when enough lanes of the slot are empty to pay for the attempt);
+            // a slot that holds one issues the fetch of its next node
+            auto refill = [&](NodeSlot &t, bool from_top, bool may_claim) {
+                if (may_claim && count(t.j == MIW_POOL_NOJOB) >= claim_min) {
+                    if (t.j == MIW_POOL_NOJOB) {
+                        uint32_t st = 0u;
+                        const uint32_t got = claim(sw, PJ_N, from_top, st);
+                        MIW_PP_CLAIM(1, got != MIW_POOL_NOJOB);
+                        if (got != MIW_POOL_NOJOB) {
+                            t.j = got; t.sb = st & (PJ_S | PJ_O);
+                            const uint4 s0 = pool[0u * NJ + got], s1 = pool[1u * NJ + got], s2 = pool[2u * NJ + got], s3 = pool[3u * NJ + got];
+                            t.r = fast_ray(v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)), v3(u2f(s1.x), u2f(s1.y), u2f(s1.z)), u2f(s0.w));
+                            t.w.gb = s2.x; t.w.gm = s2.y; t.w.tb = s2.z; t.w.tm = s2.w; t.w.tb2 = s3.x; t.w.tm2 = s3.y; t.tmax = u2f(s3.z);
+                        }
+                    }
+                }
+                if (t.j != MIW_POOL_NOJOB) t.nd = node8_at(walk8_next_node(t.w));
+            };
+            // the slot's node has arrived: one node step; a job that is no longer node-ready goes back to the pool (or turns into its extension walk)
+            auto advance = [&](NodeSlot &t) {
+                if (t.j == MIW_POOL_NOJOB) return;
+                walk8_node_step<Spec8>(t.nd, t.r, widen(t.tmax), t.w, PoolColumn8<(int) NJ>{ stacks + t.j });
+                if (walk8_node_ready<Spec8>(t.w)) return;
+                if (walk8_over(t.w)) {
+                    V3 dE;
+                    if (turn_or_finish(t.j, t.sb, t.w, t.tmax, dE)) { const uint4 s0 = pool[0u * NJ + t.j]; t.r = fast_ray(v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)), dE, u2f(s0.w)); return; }
+                    store_walk(t); release(t.j, PJ_D | t.sb);
+                } else { store_walk(t); release(t.j, (walk8_tri_ready(t.w) ? PJ_T : 0u) | t.sb); }   // (not node-ready and not over: it holds triangles)
+                t.j = MIW_POOL_NOJOB;
+            };
+            refill(A, (li & 1u) != 0u, true); refill(B, (li & 1u) == 0u, true);
             for (;;) {
                 ++trip;
-                if (j == MIW_POOL_NOJOB) {
-                    uint32_t st = 0u;
-                    const uint32_t got = claim(sw, PJ_N, ((li ^ trip) & 1u) != 0u, st);
-                    MIW_PP_CLAIM(1, got != MIW_POOL_NOJOB);
-                    if (got != MIW_POOL_NOJOB) {
-                        j = got; sb = st & (PJ_S | PJ_O);
-                        const uint4 s0 = pool[0u * NJ + j], s1 = pool[1u * NJ + j], s2 = pool[2u * NJ + j], s3 = pool[3u * NJ + j];
-                        r = fast_ray(v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)), v3(u2f(s1.x), u2f(s1.y), u2f(s1.z)), u2f(s0.w));
-                        w.gb = s2.x; w.gm = s2.y; w.tb = s2.z; w.tm = s2.w; w.tb2 = s3.x; w.tm2 = s3.y; tmax = u2f(s3.z);
-                    }
-                }
-                const int now = count(j != MIW_POOL_NOJOB);
+                const int now = count(A.j != MIW_POOL_NOJOB) + count(B.j != MIW_POOL_NOJOB);
                 if (now == 0) break;
-                if (j != MIW_POOL_NOJOB) {
-                    const auto &nd = node8_at(walk8_next_node(w));
-                    walk8_node_step<Spec8>(nd, r, widen(tmax), w, PoolColumn8<NW>{ stacks + j });
-                    if (!walk8_node_ready<Spec8>(w)) {
-                        bool keep = false;
-                        if (walk8_over(w)) {
-                            V3 dE;
-                            keep = turn_or_finish(j, sb, w, tmax, dE);
-                            if (keep) { const uint4 s0 = pool[0u * NJ + j]; r = fast_ray(v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)), dE, u2f(s0.w)); }
-                            else { store_walk(); release(j, PJ_D | sb); j = MIW_POOL_NOJOB; }
-                        } else { store_walk(); release(j, (walk8_tri_ready(w) ? PJ_T : 0u) | sb); j = MIW_POOL_NOJOB; }   // (not node-ready and not over: it holds triangles)
-                        (void) keep;
-                    }
-                }
-                MIW_PP(1, now);
-                if (now < node_min) break;                           // (every claimed job got its step: a vote that finds few takers still makes progress)
+                advance(A);
                 col_read(sw);
-                // the home lanes whose walks are over want their shade: leave once they outnumber the lanes at work here
-                if ((trip & 3u) == 0u) {
-                    const uint32_t own2 = (sw[own_k] >> own_sh) & 0xffu;
-                    const int ns = count(mode == PM_SHADE || (mode == PM_WALK && (own2 & PJ_STATE) == PJ_D));
-                    if (ns * shade_num >= now * shade_den && ns > 0) break;
-                }
+                // the home lanes whose walks are over want their shade: leave once enough of them wait
+                const int ns0 = count(shade_ready(H0, sw, wv)), ns1 = PP == 2 ? count(shade_ready(H1, sw, NW + wv)) : 0;
+                const bool leave = now < node_min || ns0 >= thr0 || (PP == 2 && ns1 >= thr1);   // (every claimed job got its step: a vote that finds few takers still makes progress)
+                refill(A, ((li ^ trip) & 1u) != 0u, !leave);
+                advance(B);
+                refill(B, ((li ^ trip) & 1u) == 0u, !leave);
+                MIW_PP(1, now);
+                if (leave) break;
             }
-            if (j != MIW_POOL_NOJOB) { store_walk(); release(j, PJ_N | (walk8_tri_ready(w) ? PJ_T : 0u) | sb); }
+            if (A.j != MIW_POOL_NOJOB) { store_walk(A); release(A.j, PJ_N | (walk8_tri_ready(A.w) ? PJ_T : 0u) | A.sb); }
+            if (B.j != MIW_POOL_NOJOB) { store_walk(B); release(B.j, PJ_N | (walk8_tri_ready(B.w) ? PJ_T : 0u) | B.sb); }
         } else if (n_leaf > 0) {
             // ---------------- triangle tests on the column's triangle-ready jobs ----------------
             uint32_t j = MIW_POOL_NOJOB, sb = 0u;
@@ -311,17 +356,19 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
             };
             for (;;) {
                 ++trip;
-                if (j == MIW_POOL_NOJOB) {
-                    uint32_t st = 0u;
-                    const uint32_t got = claim(sw, PJ_T, ((li ^ trip) & 1u) != 0u, st);
-                    MIW_PP_CLAIM(1, got != MIW_POOL_NOJOB);
-                    if (got != MIW_POOL_NOJOB) {
-                        j = got; sb = st & (PJ_S | PJ_O);
-                        const uint4 s0 = pool[0u * NJ + j], s1 = pool[1u * NJ + j], s2 = pool[2u * NJ + j], s3 = pool[3u * NJ + j];
-                        o = v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)); mint = u2f(s0.w); d = v3(u2f(s1.x), u2f(s1.y), u2f(s1.z)); maxt = u2f(s1.w);
-                        w.gb = s2.x; w.gm = s2.y; w.tb = s2.z; w.tm = s2.w; w.tb2 = s3.x; w.tm2 = s3.y; tmax = u2f(s3.z);
-                        best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = s3.w;
-                        if (!(sb & PJ_S)) { const uint4 s4 = pool[4u * NJ + j]; best.t = u2f(s4.x); best.u = u2f(s4.y); best.v = u2f(s4.z); }
+                if (count(j == MIW_POOL_NOJOB) >= claim_min || trip == 0u) {
+                    if (j == MIW_POOL_NOJOB) {
+                        uint32_t st = 0u;
+                        const uint32_t got = claim(sw, PJ_T, ((li ^ trip) & 1u) != 0u, st);
+                        MIW_PP_CLAIM(1, got != MIW_POOL_NOJOB);
+                        if (got != MIW_POOL_NOJOB) {
+                            j = got; sb = st & (PJ_S | PJ_O);
+                            const uint4 s0 = pool[0u * NJ + j], s1 = pool[1u * NJ + j], s2 = pool[2u * NJ + j], s3 = pool[3u * NJ + j];
+                            o = v3(u2f(s0.x), u2f(s0.y), u2f(s0.z)); mint = u2f(s0.w); d = v3(u2f(s1.x), u2f(s1.y), u2f(s1.z)); maxt = u2f(s1.w);
+                            w.gb = s2.x; w.gm = s2.y; w.tb = s2.z; w.tm = s2.w; w.tb2 = s3.x; w.tm2 = s3.y; tmax = u2f(s3.z);
+                            best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = s3.w;
+                            if (!(sb & PJ_S)) { const uint4 s4 = pool[4u * NJ + j]; best.t = u2f(s4.x); best.u = u2f(s4.y); best.v = u2f(s4.z); }
+                        }
                     }
                 }
                 const int now = count(j != MIW_POOL_NOJOB);
@@ -345,11 +392,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
                 MIW_PP(2, now);
                 if (now < tri_min) break;
                 col_read(sw);
-                if ((trip & 3u) == 0u) {
-                    const uint32_t own2 = (sw[own_k] >> own_sh) & 0xffu;
-                    const int ns = count(mode == PM_SHADE || (mode == PM_WALK && (own2 & PJ_STATE) == PJ_D));
-                    if (ns * shade_num >= now * shade_den && ns > 0) break;
-                }
+                const int ns0 = count(shade_ready(H0, sw, wv)), ns1 = PP == 2 ? count(shade_ready(H1, sw, NW + wv)) : 0;
+                if (ns0 >= thr0 || (PP == 2 && ns1 >= thr1)) break;
             }
             if (j != MIW_POOL_NOJOB) { store_walk(); release(j, PJ_T | (walk8_node_ready<Spec8>(w) ? PJ_N : 0u) | sb); }
         } else {

@@ -21,6 +21,7 @@ struct TraceLds {           // what a trace workgroup finds in its dynamic LDS
     uint32_t tab16;         // packet kernels and the phase machine: uint4 offset of the scene's small tables in dynamic LDS (stage_tables)
     uint32_t tab_words[10]; // dwords of: shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf; packet kernels also: tris, tri_vn, tri_uv (0: absent)
     uint32_t env_top_count, env_top_base, env_top_words;   // the environment warp's top levels behind the tables (envmap.h: EnvTop); 0: none
+    uint32_t pool_claim_min; // k_path_pooled: a walk loop looks for new jobs only when this many lanes of a slot are empty
     uint32_t pool16, stat16; // k_path_pooled (pooled_kernel.h): uint4 offsets of the workgroup's walk-job records (5 x 16 B per lane) and of their status bytes
 };
 

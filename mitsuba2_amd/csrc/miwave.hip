@@ -27,7 +27,7 @@
 __device__ unsigned long long g_sections[16];
 #endif
 #if defined(MIW_PHASE_STATS)
-__device__ unsigned long long g_phase_stats[12];   // k_path_phased: per body (node, triangle, walk end, shade) runs, lanes, wall cycles
+__device__ unsigned long long g_phase_stats[15];   // k_path_phased: per bucket (node trip, triangle trip, walk end, shade, vote) runs, lanes, wall cycles
 #endif
 #if defined(MIW_WALK_STATS)
 __device__ unsigned long long g_walk_stats[8];     // per ray kind (closest 0.., any 4..): node lane-steps, triangle lane-steps, rays
@@ -1279,16 +1279,22 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // environment warp's levels once per CU: [stacks][job records][status][thresholds][tables]. All of the CU's 160 KB may be one workgroup's.
     // MIW_POOLED=0 keeps k_path_phased (A/B runs, and what shards with placed queues run).
     LdsLayout layp{}; bool pooled_fits = false;
-    if (pre8 && !(getenv("MIW_POOLED") && atoi(getenv("MIW_POOLED")) == 0)) {
-        const size_t NJ = (size_t) MIW_POOL_NW * 64u;
+    // shape of the workgroup: NW wavefronts x PP pixels per lane — 12 x 1 (three wavefronts per SIMD), or 8 x 2 (two per SIMD, 256 VGPRs, twice the
+    // jobs per lane: MIW_POOL_SHAPE=8x2; needs 1024 job records + stacks in LDS: trees of up to 8 levels)
+    int pool_nw = 12, pool_pp = 1;
+    if (const char *e = getenv("MIW_POOL_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%dx%d", &a, &b) == 2 && ((a == 12 && b == 1) || (a == 8 && b == 2))) { pool_nw = a; pool_pp = b; } }
+    // (the 8 x 2 shape is instantiated for the MATS_TRIO class only — BASELINE configs 3 / 4)
+    if (!(c->trio && !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0) && c->rects.empty() && !c->textured)) { pool_nw = 12; pool_pp = 1; }
+    if (pre8 && getenv("MIW_POOLED") && atoi(getenv("MIW_POOLED")) != 0) {
+        const size_t NJ = (size_t) pool_nw * pool_pp * 64u;
         size_t base = (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * NJ * sizeof(U2);
         const uint32_t pool16 = (uint32_t) (base / 16); base += 5u * NJ * 16u;
         const uint32_t stat16 = (uint32_t) (base / 16); base += NJ;
         layp = lay_out(base, 32768, (size_t) 160u * 1024u - 1024u);
         layp.cfg.stack16 = 0u; layp.cfg.pool16 = pool16; layp.cfg.stat16 = stat16; layp.cfg.nodes_staged = layp.cfg.tris_staged = 0u;
         pooled_fits = layp.tables_fit;
-        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] pooled phase machine: %d wavefronts per workgroup, LDS %zu bytes (stacks %zu, job records %zu, tables %zu of which environment warp levels %u), fits %d\n",
-                                         MIW_POOL_NW, layp.rlds, (size_t) pool16 * 16, 5u * NJ * 16u, layp.table_bytes, layp.cfg.env_top_words * 4u, (int) pooled_fits);
+        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] pooled phase machine: %d wavefronts per workgroup x %d pixels per lane, LDS %zu bytes (stacks %zu, job records %zu, tables %zu of which environment warp levels %u), fits %d\n",
+                                         pool_nw, pool_pp, layp.rlds, (size_t) pool16 * 16, 5u * NJ * 16u, layp.table_bytes, layp.cfg.env_top_words * 4u, (int) pooled_fits);
     }
     TraceLds rcfg = lay.cfg; size_t rlds = lay.rlds; const size_t rlds_plain = lay.rlds_plain, table_bytes = lay.table_bytes; const bool tables_fit = lay.tables_fit;
     if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu%s\n",
@@ -1529,22 +1535,24 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 K.tree_width = phased ? (phased8 ? 8u : (c->view.nodes4 ? 4u : 2u)) : 0u;
                 const bool pooled = phased8 && !place && pooled_fits;
                 if (pooled) {
-                    // one workgroup per CU; the vote: shade once the home lanes whose walks are over outnumber the lanes that find walk work
-                    // shade_num : shade_den; a walk loop hands over once fewer than node_exit / tri_exit of its lanes hold a job
+                    // one workgroup per CU; the vote's constants travel in the fields the old kernel's vote used (pooled_kernel.h: shade_min, walk_min, node_min, tri_min)
+                    // + pool_claim_min; MIW_POOL_VOTE=shade_min:walk_min:node_min:tri_min:claim_min overrides (A/B runs)
                     TraceLds pcfg = layp.cfg; pcfg.queues = 1u; pcfg.tail_prio = ph_cfg.tail_prio;
-                    pcfg.shade_num = 4; pcfg.shade_den = 3; pcfg.node_exit = 32u; pcfg.tri_exit = 24u;
-                    if (const char *e = getenv("MIW_POOL_VOTE")) { int a = 0, b = 0, n = 0, t = 0; if (sscanf(e, "%d:%d:%d:%d", &a, &b, &n, &t) == 4 && a > 0 && b > 0) { pcfg.shade_num = (uint32_t) a; pcfg.shade_den = (uint32_t) b; pcfg.node_exit = (uint32_t) n; pcfg.tri_exit = (uint32_t) t; } }
-                    const unsigned NJ = MIW_POOL_NW * 64u;
-                    const dim3 qgrid(std::min<unsigned>((n_lanes + NJ - 1u) / NJ, (unsigned) c->cu_count)), qblock(NJ);
+                    pcfg.shade_num = 48; pcfg.shade_den = 16; pcfg.node_exit = 40u; pcfg.tri_exit = 20u; pcfg.pool_claim_min = 8u;
+                    if (const char *e = getenv("MIW_POOL_VOTE")) { int a = 0, b = 0, n = 0, t = 0, m = 0; if (sscanf(e, "%d:%d:%d:%d:%d", &a, &b, &n, &t, &m) == 5 && a > 0 && b >= 0) { pcfg.shade_num = (uint32_t) a; pcfg.shade_den = (uint32_t) b; pcfg.node_exit = (uint32_t) n; pcfg.tri_exit = (uint32_t) t; pcfg.pool_claim_min = (uint32_t) std::max(m, 1); } }
+                    const unsigned NL = (unsigned) pool_nw * 64u;
+                    const dim3 qgrid(std::min<unsigned>((n_lanes + NL - 1u) / NL, (unsigned) c->cu_count)), qblock(NL);
                     SceneView pview = view8;
-#define MIW_POOLED_LAUNCH(M, A) do { HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_pooled<M, A, MIW_POOL_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) layp.rlds)); \
-                                     MIW_TIMED(6, hipLaunchKernelGGL((k_path_pooled<M, A, MIW_POOL_NW>), qgrid, qblock, layp.rlds, s, P, pview, Q, c->d_cnt.p, pcfg, end, c->d_next_pixel.p)); } while (0)
-                    if (c->textured) MIW_POOLED_LAUNCH(MATS_ALL, true);
+#define MIW_POOLED_LAUNCH_(M, A, NW_, PP_) do { HIP_TRY(c, hipFuncSetAttribute((const void *) k_path_pooled<M, A, NW_, PP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) layp.rlds)); \
+                                     MIW_TIMED(6, hipLaunchKernelGGL((k_path_pooled<M, A, NW_, PP_>), qgrid, qblock, layp.rlds, s, P, pview, Q, c->d_cnt.p, pcfg, end, c->d_next_pixel.p)); } while (0)
+#define MIW_POOLED_LAUNCH(M, A) do { if (pool_pp == 2) MIW_POOLED_LAUNCH_(M, A, 8, 2); else MIW_POOLED_LAUNCH_(M, A, 12, 1); } while (0)
+                    if (c->textured) MIW_POOLED_LAUNCH_(MATS_ALL, true, 12, 1);
                     else if (trio_kernel) MIW_POOLED_LAUNCH(MATS_TRIO, false);
-                    else if (c->rects.empty()) MIW_POOLED_LAUNCH(MATS_PLAIN, false);
-                    else MIW_POOLED_LAUNCH(MATS_PLAIN, true);
+                    else if (c->rects.empty()) MIW_POOLED_LAUNCH_(MATS_PLAIN, false, 12, 1);
+                    else MIW_POOLED_LAUNCH_(MATS_PLAIN, true, 12, 1);
 #undef MIW_POOLED_LAUNCH
-                    K.pooled = 1u; K.pool_waves = MIW_POOL_NW;
+#undef MIW_POOLED_LAUNCH_
+                    K.pooled = 1u; K.pool_waves = (uint32_t) pool_nw;
                 } else
                 if (phased8 && place) {
                     if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 2, true);
@@ -1638,15 +1646,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #endif
 #if defined(MIW_PHASE_STATS)
         if (getenv("MIW_DEBUG")) {
-            unsigned long long ps[12];
-            if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
-                static const char *names[4] = { "node step", "triangle test", "walk end", "shade" };
+            unsigned long long ps[15];
+            if (!K.pooled && hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
+                static const char *names[5] = { "node step", "triangle test", "walk end", "shade", "vote" };
                 unsigned long long tot = 0;
-                for (int k = 0; k < 4; ++k) tot += ps[8 + k];
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
+                for (int k = 0; k < 5; ++k)
                     fprintf(stderr, "[miwave] phase %-13s runs/segment %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
-                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[4 + k] / std::max<double>((double) ps[k], 1),
-                            (double) ps[8 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[8 + k] / std::max<double>((double) tot, 1));
+                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
+                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
                 memset(ps, 0, sizeof ps);
                 (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), ps, sizeof ps);
             }

@@ -25,7 +25,16 @@ using namespace miw;
 #include "../mitsuba2_amd/csrc/device/wavefront_kernels.h"
 #include "../mitsuba2_amd/csrc/device/resident_kernel.h"
 #include "../mitsuba2_amd/csrc/device/phased_kernel.h"
-#if defined(MIW_PROBE_C34)   // only the kernels of BASELINE configs 3 / 4: MATS_TRIO over the 8-wide tree (round 5) and its 4-wide twin, four wavefronts per SIMD (tests/test_kernel_budget.py)
+#if defined(MIW_PROBE_POOLED)   // only the pooled phase machine of BASELINE configs 3 / 4 (round 6: device/pooled_kernel.h)
+#ifndef MIW_POOL_NW
+#define MIW_POOL_NW 8
+#endif
+#include "../mitsuba2_amd/csrc/device/pooled_kernel.h"
+#ifndef MIW_POOL_PP
+#define MIW_POOL_PP 2
+#endif
+template __global__ void k_path_pooled<MATS_TRIO, false, MIW_POOL_NW, MIW_POOL_PP>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+#elif defined(MIW_PROBE_C34)   // only the kernels of BASELINE configs 3 / 4: MATS_TRIO over the 8-wide tree (round 5) and its 4-wide twin, four wavefronts per SIMD (tests/test_kernel_budget.py)
 template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 2>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 1>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #else
