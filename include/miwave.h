@@ -255,8 +255,17 @@ typedef struct {
      *   MI_MOMENT_SQUARES  this call delivers X^2 Y^2 Z^2 A W (the m2_ channels);
      * in both a sample is dropped when any of the eleven values fails ImageBlock::put's test (imageblock.cpp:85-109). */
     int32_t moment_pass;
+    /* ---- round 6 (appended; zero = the library chooses, and the context's options apply — mi_set_option below) --------------------
+     * Per-render overrides of the library's own kernel choices: what the parity tests use to put ONE job through several kernels
+     * (every choice produces the same film bits). Not tuning knobs: the defaults are the measured best. */
+    int32_t debug_film_replay;  /* MI_FILM_REPLAY_*: which block replay assembles the film of a film_mode-1 render (and the log format it needs) */
+    int32_t debug_tree_width;   /* 8 | 4: the tree the phase machine walks, when mi_bvh_build produced both                                       */
+    int32_t debug_path_kernel;  /* MI_PATH_KERNEL_*: lock-step kernel / k_path_phased / k_path_pooled for a tree scene                          */
 } mi_render_cfg;
 enum { MI_MOMENT_OFF = 0, MI_MOMENT_VALUES = 1, MI_MOMENT_SQUARES = 2 };
+enum { MI_FILM_REPLAY_AUTO = 0, MI_FILM_REPLAY_BLOCKS = 1 /* 24-byte position log + k_film_blocks */, MI_FILM_REPLAY_GROUPS = 2, MI_FILM_REPLAY_COLUMNS = 3,
+       MI_FILM_REPLAY_QUADS = 4, MI_FILM_REPLAY_LANES = 5 /* tile-interleaved log */, MI_FILM_REPLAY_LANES_PLAIN_LOG = 6 };
+enum { MI_PATH_KERNEL_AUTO = 0, MI_PATH_KERNEL_LOCKSTEP = 1, MI_PATH_KERNEL_PHASED = 2, MI_PATH_KERNEL_POOLED = 3 };
 enum { MI_INTEGRATOR_PATH = 0, MI_INTEGRATOR_DIRECT = 1 };
 
 typedef struct {
@@ -318,6 +327,17 @@ typedef struct {
 
 /* 3 for the scalar_rgb library, 4 for the scalar_spectral library (channels of a Spectrum) */
 int32_t mi_spectrum_channels(void);
+
+/* Options: the switches INTEGRATION.md section 5 lists (A/B runs, fallbacks, test hooks; names MIW_*). mi_create copies the ones set
+ * in the ENVIRONMENT into the context — the only time the library reads the environment; afterwards a context's behaviour does not
+ * depend on its caller's environment. mi_set_option changes one for this context (value NULL: unset; unknown name: MI_ERR_INVALID),
+ * mi_get_option reads it back (NULL: unset), mi_option_count / _name / _help enumerate them. Options consulted by mi_bvh_build
+ * take effect at the next build, the others at the next render. */
+mi_status mi_set_option(mi_ctx *ctx, const char *name, const char *value);
+const char *mi_get_option(mi_ctx *ctx, const char *name);
+int32_t mi_option_count(void);
+const char *mi_option_name(int32_t i);
+const char *mi_option_help(int32_t i);
 
 /* number of visible HIP devices */
 mi_status mi_device_count(int32_t *count);

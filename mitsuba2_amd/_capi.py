@@ -108,7 +108,8 @@ class mi_render_cfg(C.Structure):
                 ("profile", C.c_int32),
                 ("timeout_s", C.c_float), ("plan", C.c_int32), ("samples_per_launch", C.c_int32), ("accumulate", C.c_int32),
                 ("integrator", C.c_int32), ("emitter_samples", C.c_uint32), ("bsdf_samples", C.c_uint32),
-                ("hide_emitters", C.c_int32), ("moment_pass", C.c_int32)]
+                ("hide_emitters", C.c_int32), ("moment_pass", C.c_int32),
+                ("debug_film_replay", C.c_int32), ("debug_tree_width", C.c_int32), ("debug_path_kernel", C.c_int32)]
 
 
 class mi_counters(C.Structure):
@@ -141,7 +142,8 @@ MI_EVAL_STRIDES = {0: (2, 8), 1: (1, 2), 2: (2, 4), 3: (10, 13), 4: (2, 4), 5: (
 MI_SYMBOLS = ["mi_spectrum_channels", "mi_device_count", "mi_create", "mi_destroy", "mi_set_stream", "mi_scene_upload", "mi_bvh_build",
               "mi_trace", "mi_render", "mi_cancel", "mi_get_counters", "mi_last_error", "mi_eval", "mi_selftest",
               "mi_ray_intersect", "mi_sample_emitter_direction", "mi_pdf_emitter_direction", "mi_emitter_eval",
-              "mi_film_alloc", "mi_film_free", "mi_film_download", "mi_film_reduce"]
+              "mi_film_alloc", "mi_film_free", "mi_film_download", "mi_film_reduce",
+              "mi_set_option", "mi_get_option", "mi_option_count", "mi_option_name", "mi_option_help"]
 
 
 VARIANT_SUFFIX = {"scalar_rgb": "", "scalar_spectral": "_spectral"}

@@ -34,10 +34,10 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    bool load() {
+    bool load(bool allowed = true) {
+        if (!allowed) return false;                                                  // option MIW_RCCL=0 of the calling context: the device-add path (A/B runs)
         if (tried) return lib != nullptr;
         tried = true;
-        if (const char *e = getenv("MIW_RCCL")) if (atoi(e) == 0) return false;      // MIW_RCCL=0: the device-add path (A/B runs)
         for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;

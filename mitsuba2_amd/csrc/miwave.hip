@@ -18,6 +18,8 @@
 #include <vector>
 #include <chrono>
 #include <atomic>
+#include <map>
+#include <string>
 #include <algorithm>
 
 #include "../../include/miwave.h"
@@ -86,7 +88,9 @@ static_assert(sizeof(TexRec) == sizeof(mi_texture), "texture record layout");
 #include "device/wavefront_kernels.h"
 #include "device/resident_kernel.h"
 #include "device/phased_kernel.h"
-#include "device/pooled_kernel.h"
+#if !MIW_SPECTRAL
+#include "device/pooled_kernel.h"      /* (experimental, opt-in: the scalar_rgb library only) */
+#endif
 #include "device/stream_trace.h"
 #include "device/film_kernels.h"
 #include "device/eval_kernels.h"
@@ -119,8 +123,59 @@ template <typename T> struct DevBuf {
 // a DevBuf local to one call: freed on every return path (HIP_TRY returns early)
 template <typename T> struct TmpBuf : DevBuf<T> { TmpBuf() = default; TmpBuf(const TmpBuf &) = delete; ~TmpBuf() { this->release(); } };
 
+// ---- options --------------------------------------------------------------------------------
+// Every switch of the library (A/B runs, tests, fallbacks). The ENVIRONMENT is read ONCE, by mi_create, into the context's own copy;
+// after that the caller's environment does not matter to this context: a switch is changed with mi_set_option(ctx, name, value)
+// (value NULL: back to unset). INTEGRATION.md section 5 lists them; mi_render_cfg::debug_* carry the ones a caller may want per render.
+struct KnobInfo { const char *name, *what; };
+static const KnobInfo g_knobs[] = {
+    { "MIW_DEBUG", "1: diagnostics on stderr (LDS layout, builder statistics, phase statistics of -DMIW_PHASE_STATS builds)" },
+    { "MIW_DEBUG_ALLOC", "1: mi_bvh_build times its uploads and allocations" },
+    { "MIW_DEVICE_BUILDER", "mi_bvh_build quality 0: sah (default) | lbvh: which device builder runs" },
+    { "MIW_SAH_HUGE", "0: the device SAH sweep bins every candidate in one workgroup (round 4's form)" },
+    { "MIW_LBVH_LEAF", "radix tree: triangles per leaf" },
+    { "MIW_MAX_LEAF", "host SAH builder: triangles per leaf" },
+    { "MIW_NO_STACK", "1: no LDS-stack walk (stackless BVH2 walk, wavefront plan)" },
+    { "MIW_BVH4", "0: no 4-wide tree (the phase machine steps through the BVH2)" },
+    { "MIW_BVH4_FAN", "2 | 3 | 4: widest node the 4-wide collapse may build" },
+    { "MIW_BVH4_HOST", "1: the 4-wide tree is collapsed on the host from the read-back BVH2" },
+    { "MIW_BVH8", "0: mi_bvh_build skips the 8-wide tree / mi_render keeps the 4-wide walk" },
+    { "MIW_STACK8_FULL", "1: the 8-wide walk keeps the 16-entry LDS column instead of one entry per tree level" },
+    { "MIW_ENV_TOP", "0: the environment warp's top levels are not staged in LDS" },
+    { "MIW_PHASED", "0: tree scenes take the lock-step kernel instead of the phase machine" },
+    { "MIW_PHASED_WAVES", "3 | 4: wavefronts per SIMD the phase machine is launched for" },
+    { "MIW_TRIO", "0: MATS_PLAIN kernels where the MATS_TRIO class would do" },
+    { "MIW_SHADE_VOTE", "num:den of the phase machine's shade vote" },
+    { "MIW_LOOP_EXIT", "node:triangle hand-over ratios of the phase machine's walk loops" },
+    { "MIW_POOLED", "1: tree scenes take k_path_pooled (walk jobs pooled across the workgroup; experimental, slower: DESIGN.md)" },
+    { "MIW_POOL_SHAPE", "12x1 | 8x2: wavefronts per workgroup x pixels per lane of k_path_pooled" },
+    { "MIW_POOL_VOTE", "shade_min:walk_min:node_min:tri_min:claim_min of k_path_pooled" },
+    { "MIW_TAIL_PRIO", "0: no least-progress-first wave priorities" },
+    { "MIW_WG_PER_CU", "workgroups per CU of the packet kernels' persistent grid" },
+    { "MIW_PLACE", "0: shards of about one pixel per lane skip the measuring launch + placed queues" },
+    { "MIW_PLACE_MEASURE", "divisor: the measuring launch runs spp / divisor samples" },
+    { "MIW_PLACE_SPREAD", "0 | 1: placed pieces = consecutive sorted lanes | one lane of every cost stratum" },
+    { "MIW_STREAM", "0: plan 1 walks with one kernel per list slice instead of the persistent stream kernel" },
+    { "MIW_FILM_LEGACY", "1: the 24-byte position log + k_film_blocks for every filter" },
+    { "MIW_FILM_LANES", "0 | 1 | 2: k_film_lanes off / over the tile-interleaved log / over [lane][sample]" },
+    { "MIW_FILM_QUADS", "0 | 24 | 28 | 42 | 44: k_film_quads group shape (0: off)" },
+    { "MIW_FILM_COLUMNS", "0 | 42 | 44 | 82: k_film_columns group shape" },
+    { "MIW_FILM_GROUP", "2 | 3 | 4: k_film_groups group shape" },
+    { "MIW_FL_NT", "0: k_film_lanes reads the log with plain instead of streaming loads" },
+    { "MIW_FQ_U", "2 | 4 | 8: records per trip of k_film_quads" },
+    { "MIW_RCCL", "0: mi_film_reduce never uses RCCL (device add)" },
+    { "MIW_RCCL_FORCE", "1: mi_film_reduce takes the RCCL branch for one context too (tests)" }
+};
+struct Options {
+    std::map<std::string, std::string> v;
+    void from_env() { for (const KnobInfo &k : g_knobs) if (const char *e = getenv(k.name)) v[k.name] = e; }
+    static bool known(const char *name) { for (const KnobInfo &k : g_knobs) if (!strcmp(k.name, name)) return true; return false; }
+    const char *get(const char *name) const { auto it = v.find(name); return it == v.end() ? nullptr : it->second.c_str(); }
+};
+
 struct mi_ctx {
     int device = 0;
+    Options opt;
     hipStream_t stream = nullptr;
     std::string error;
     std::atomic<int> cancel{0};
@@ -203,6 +258,7 @@ mi_status mi_create(int32_t device, mi_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) { g_global_error = "hipSetDevice failed"; return MI_ERR_DEVICE; }
     mi_ctx *c = new mi_ctx();
     c->device = device;
+    c->opt.from_env();                                           // the only place the library reads the environment
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     if (hipHostMalloc((void **) &c->h_cnt, sizeof(Counters) * MIW_CNT_SHARDS) != hipSuccess) { delete c; g_global_error = "hipHostMalloc failed"; return MI_ERR_DEVICE; }
     *out = c;
@@ -229,6 +285,17 @@ void mi_destroy(mi_ctx *c) {
 mi_status mi_set_stream(mi_ctx *c, void *s) { if (!c) return MI_ERR_INVALID; c->stream = (hipStream_t) s; return MI_OK; }
 
 const char *mi_last_error(mi_ctx *c) { return c ? c->error.c_str() : g_global_error.c_str(); }
+
+mi_status mi_set_option(mi_ctx *c, const char *name, const char *value) {
+    if (!c || !name) return MI_ERR_INVALID;
+    if (!Options::known(name)) return fail(c, MI_ERR_INVALID, "mi_set_option: unknown option %s", name);
+    if (value) c->opt.v[name] = value; else c->opt.v.erase(name);
+    return MI_OK;
+}
+const char *mi_get_option(mi_ctx *c, const char *name) { return c && name ? c->opt.get(name) : nullptr; }
+int32_t mi_option_count(void) { return (int32_t) (sizeof(g_knobs) / sizeof(g_knobs[0])); }
+const char *mi_option_name(int32_t i) { return i >= 0 && i < mi_option_count() ? g_knobs[i].name : nullptr; }
+const char *mi_option_help(int32_t i) { return i >= 0 && i < mi_option_count() ? g_knobs[i].what : nullptr; }
 
 mi_status mi_cancel(mi_ctx *c) { if (!c) return MI_ERR_INVALID; c->cancel.store(1); return MI_OK; }
 
@@ -273,14 +340,14 @@ mi_status mi_film_reduce(mi_ctx *const *ctxs, void *const *films, int32_t n, uin
     // (one context: nothing to add — unless MIW_RCCL_FORCE=1 asks for the RCCL branch anyway: a communicator of one rank, an in-place
     // reduce that leaves the film as it is. That is how the branch — dlopen, ncclCommInitAll, the grouped ncclReduce, the stream
     // waits — runs on a one-GPU box: tests/test_multi_gpu.py)
-    const bool force_rccl = getenv("MIW_RCCL_FORCE") && atoi(getenv("MIW_RCCL_FORCE")) != 0;
+    const bool force_rccl = r->opt.get("MIW_RCCL_FORCE") && atoi(r->opt.get("MIW_RCCL_FORCE")) != 0;
     if (count == 0 || (n == 1 && !force_rccl)) return MI_OK;
     std::vector<int> devs(n);
     bool distinct = true;
     for (int32_t i = 0; i < n; ++i) { devs[i] = ctxs[i]->device; for (int32_t j = 0; j < i; ++j) distinct = distinct && devs[j] != devs[i]; }
     if (distinct) {
         std::lock_guard<std::mutex> lock(g_rccl_mutex);
-        if (g_rccl.load()) {
+        if (g_rccl.load(!(r->opt.get("MIW_RCCL") && atoi(r->opt.get("MIW_RCCL")) == 0))) {
             auto it = g_rccl_comms.find(devs);
             if (it == g_rccl_comms.end()) {
                 std::vector<ncclComm_t> comms(n);
@@ -571,13 +638,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
     bool built_on_device = false;
     // quality 0: the 4-wide tree is collapsed on the device as well (bvh4_device.h); these say whether that happened
     bool wide_on_device = false; uint32_t dev4_nodes = 0, dev4_stack = 0;
-    const bool wide_on = !(getenv("MIW_BVH4") && atoi(getenv("MIW_BVH4")) == 0);
+    const bool wide_on = !(c->opt.get("MIW_BVH4") && atoi(c->opt.get("MIW_BVH4")) == 0);
     // the 8-wide tree (the phase machine's default since round 5): off with MIW_BVH8=0, and whenever the 4-wide walk is asked for by name
-    const bool wide8_on = wide_on && !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0) && !getenv("MIW_BVH4_FAN");
+    const bool wide8_on = wide_on && !(c->opt.get("MIW_BVH8") && atoi(c->opt.get("MIW_BVH8")) == 0) && !c->opt.get("MIW_BVH4_FAN");
     uint32_t dev8_nodes = 0, dev8_depth = 0; double ms_bvh8 = 0.0;
     std::vector<uint32_t> sah_level_start;                    // the device SAH builder's level table (first node of every level)
     int max_fan = 4;
-    if (const char *e = getenv("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
+    if (const char *e = c->opt.get("MIW_BVH4_FAN")) max_fan = std::min(4, std::max(2, atoi(e)));
     double ms_bvh4 = 0.0;
     uint32_t tab_words_[10];
     // (the packet kernels read the scene's small tables from LDS: a scene of <= 64 triangles whose tables would not fit beside the
@@ -590,7 +657,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         const int n = (int) tri_count;
         TmpBuf<Tri> d_in; TmpBuf<float> d_vn_in; TmpBuf<uint64_t> d_keys, d_keys_sorted; TmpBuf<uint32_t> d_bounds, d_arrivals, d_height, d_span, d_first;
         uint32_t lbvh_leaf = 2u;                               // triangles per fat leaf (measured on the interior: 1 -> 311, 2 -> 352, 4 -> 334, 8 -> 302 Msamples/s; SAH 369); MIW_LBVH_LEAF = 1 .. 16 overrides
-        if (const char *e = getenv("MIW_LBVH_LEAF")) lbvh_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
+        if (const char *e = c->opt.get("MIW_LBVH_LEAF")) lbvh_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
         if ((uint32_t) n <= lbvh_leaf) lbvh_leaf = 1u;          // (the root must stay an inner node)
         TmpBuf<LbvhBox> d_boxes; TmpBuf<LbvhLinks> d_inner; TmpBuf<int32_t> d_leaf_parent; TmpBuf<unsigned char> d_tmp;
         auto free_tmp = [&]() { d_in.release(); d_vn_in.release(); d_keys.release(); d_keys_sorted.release(); d_bounds.release();
@@ -599,7 +666,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // MIW_DEBUG_ALLOC=1: where the set-up time of a build goes (stderr, ms since the previous mark)
         auto lap_t = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
-            if (!getenv("MIW_DEBUG_ALLOC")) return;
+            if (!c->opt.get("MIW_DEBUG_ALLOC")) return;
             (void) hipStreamSynchronize(s);
             const auto now = std::chrono::steady_clock::now();
             fprintf(stderr, "[miwave]   build set-up: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
@@ -618,13 +685,13 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // tree on the interior / the material balls: A/B runs). A scene the sweep hands back (need_host: coincident centroids) takes
         // the host builder, like quality 1.
         enum { DEV_SAH = 0, DEV_LBVH = 1 } dev_builder = (quality_flags & MI_BVH_RADIX_TREE) ? DEV_LBVH : DEV_SAH;
-        if (const char *e = getenv("MIW_DEVICE_BUILDER")) {        // only the two names override the flag; anything else leaves the caller's choice alone
+        if (const char *e = c->opt.get("MIW_DEVICE_BUILDER")) {        // only the two names override the flag; anything else leaves the caller's choice alone
             if (!strcmp(e, "lbvh")) dev_builder = DEV_LBVH; else if (!strcmp(e, "sah")) dev_builder = DEV_SAH;
         }
         bool sah_need_host = false;
         if (dev_builder == DEV_SAH) {
             uint32_t max_leaf = 4u;                                        // (bvh_build_sah's default leaf size: the same tree; MIW_MAX_LEAF overrides on both sides)
-            if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
+            if (const char *e = c->opt.get("MIW_MAX_LEAF")) max_leaf = (uint32_t) std::min(16, std::max(1, atoi(e)));
             const uint32_t un = (uint32_t) n;
             const float pad = 2.f * pad_unit;
             TmpBuf<SahPrim> d_prim; TmpBuf<uint32_t> d_ia, d_ib, d_flags, d_rank; TmpBuf<SahCand> d_ca, d_cb; TmpBuf<SahDecision> d_dec; TmpBuf<SahState> d_state;
@@ -646,7 +713,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             uint32_t n_cand = 1u, base = 0u, level = 0u;
             bool big_left = true;                                        // candidates of more than MIW_SAH_BIG triangles in the current level
             uint32_t level_max = un;                                     // the largest candidate of the current level (0: none above MIW_SAH_BIG)
-            const bool huge_on = !(getenv("MIW_SAH_HUGE") && atoi(getenv("MIW_SAH_HUGE")) == 0);     // MIW_SAH_HUGE=0: one workgroup per candidate, as round 4 (A/B runs)
+            const bool huge_on = !(c->opt.get("MIW_SAH_HUGE") && atoi(c->opt.get("MIW_SAH_HUGE")) == 0);     // MIW_SAH_HUGE=0: one workgroup per candidate, as round 4 (A/B runs)
             while (n_cand > 0u && !sah_need_host) {
                 const SahCand *cur = (level & 1u) ? d_cb.p : d_ca.p; SahCand *nxt = (level & 1u) ? d_ca.p : d_cb.p;
                 const uint32_t *ic = (level & 1u) ? d_ib.p : d_ia.p; uint32_t *in = (level & 1u) ? d_ia.p : d_ib.p;
@@ -698,7 +765,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 built_on_device = true;
                 sah_level_start = level_start;
                 c->counters.bvh_builder = 3u;
-                if (getenv("MIW_DEBUG")) {
+                if (c->opt.get("MIW_DEBUG")) {
                     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                     fprintf(stderr, "[miwave] device builder: binned SAH by levels, %u triangles, %u inner nodes, depth %u; upload + allocations %.2f ms, %u levels %.2f ms, heights + gather %.2f ms\n",
                             un, node_count, depth, ms(t0, t_setup), level, ms(t_setup, t_levels), ms(t_levels, std::chrono::steady_clock::now()));
@@ -736,14 +803,14 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
             HIP_TRY(c, hipMemcpyAsync(&depth, d_height.p, sizeof depth, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             c->counters.bvh_builder = 1u;
-            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] device builder: LBVH, %u triangles, height %u\n", (uint32_t) n, depth);
+            if (c->opt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] device builder: LBVH, %u triangles, height %u\n", (uint32_t) n, depth);
         node_count = (uint32_t) (n - 1);
         built_on_device = depth <= MIW_BVH_MAX_DEPTH;     // deeper (many coincident centroids): take the SAH builder
         }
         // ---- the 4-wide tree of the phase machine, collapsed level by level on the device (bvh4_device.h); the heights the
         // collapse's fit test needs are the builder's (k_sah_heights / k_lbvh_fit). MIW_BVH4_HOST=1 keeps round 2's read-back + host collapse (A/B runs) ----
         const uint32_t budget4 = MIW_STACK_ENTRIES - 1;    // one entry of slack: the node body's unconditional stores
-        if (built_on_device && wide_on && depth <= budget4 && !getenv("MIW_NO_STACK") && !getenv("MIW_BVH4_HOST")) {
+        if (built_on_device && wide_on && depth <= budget4 && !c->opt.get("MIW_NO_STACK") && !c->opt.get("MIW_BVH4_HOST")) {
             auto t4 = std::chrono::steady_clock::now();
             TmpBuf<Bvh4Item> fa, fb; TmpBuf<Bvh4Levels> lv;
             HIP_TRY(c, fa.resize(n)); HIP_TRY(c, fb.resize(n)); HIP_TRY(c, lv.resize(1)); HIP_TRY(c, c->d_nodes4.resize(n));
@@ -766,7 +833,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // ---- the 8-wide tree (miw/bvh8.h) from the same BVH2, on the device as well (bvh8_device.h): the programme bottom-up over the
         // builder's levels, the collapse top-down, triangles + vertex normals gathered into the tree's order. SAH sweep only (the
         // radix tree has no level table: it keeps the 4-wide tree). MIW_BVH8=0 / MIW_BVH4=0 / MIW_BVH4_FAN switch it off (A/B runs). ----
-        if (built_on_device && dev_builder == DEV_SAH && wide8_on && !getenv("MIW_NO_STACK")) {
+        if (built_on_device && dev_builder == DEV_SAH && wide8_on && !c->opt.get("MIW_NO_STACK")) {
             auto t8 = std::chrono::steady_clock::now();
             TmpBuf<Bvh8Dp> d_dp; TmpBuf<int32_t> ga, gb; TmpBuf<Bvh8Levels> lv8; TmpBuf<uint32_t> d_perm;
             HIP_TRY(c, d_dp.resize(node_count)); HIP_TRY(c, ga.resize(n)); HIP_TRY(c, gb.resize(n)); HIP_TRY(c, lv8.resize(1)); HIP_TRY(c, d_perm.resize(n));
@@ -801,7 +868,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // ---- host binned SAH (bvh_build.h) ----
         // tiny scenes are swept through their SAH leaves' boxes (trace2): leaf size tuned for that filter
         uint32_t max_leaf = tiny ? MIW_BRUTE_MAX_LEAF : 4u;
-        if (const char *e = getenv("MIW_MAX_LEAF")) max_leaf = (uint32_t) atoi(e);
+        if (const char *e = c->opt.get("MIW_MAX_LEAF")) max_leaf = (uint32_t) atoi(e);
         r = bvh_build_sah(c->tris_in, -1.f, max_leaf);
         if (r.depth > MIW_BVH_MAX_DEPTH) return fail(c, MI_ERR_INVALID, "BVH depth %u exceeds the traversal trail", r.depth);
         if (!c->tri_vn_in.empty()) {
@@ -871,7 +938,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // A whole tree that fits 16 KiB could be walked out of LDS with the stackless trail walk; measured (r02 triangle-count
         // series: 172 triangles, 375 Msamples/s that way against 850 with the LDS-stack walk of the phase machine, whose
         // node fetches hit L1) that only pays for the forced-tree test path of <= 64 triangles, which keeps it covered.
-        const bool stack_ok = depth <= MIW_STACK_ENTRIES && !getenv("MIW_NO_STACK");
+        const bool stack_ok = depth <= MIW_STACK_ENTRIES && !c->opt.get("MIW_NO_STACK");
         const bool resident_tree = all <= 16 * 1024 && (!stack_ok || v.tri_count <= MIW_BRUTE_MAX_TRIS);
         if (resident_tree) { c->lds_cfg.nodes_staged = v.node_count; c->lds_cfg.tris_staged = v.tri_count; }
         else { c->lds_cfg.nodes_staged = MIW_LDS_TOP ? std::min<uint32_t>(v.node_count, 255) : 0u; c->lds_cfg.tris_staged = 0; }
@@ -888,7 +955,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
         // coordinates beyond the quantisation range) is rendered by the lock-step kernel.
         if (c->lds_cfg.stack && wide_on && wide_on_device) {
             v.nodes4 = c->d_nodes4.p; c->nodes4_count = dev4_nodes; c->nodes4_stack = dev4_stack;
-            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4 (device): %u nodes (bvh2 %u), stack bound %u, %.2f ms\n", dev4_nodes, node_count, dev4_stack, ms_bvh4);
+            if (c->opt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4 (device): %u nodes (bvh2 %u), stack bound %u, %.2f ms\n", dev4_nodes, node_count, dev4_stack, ms_bvh4);
         } else if (c->lds_cfg.stack && wide_on) {
             auto t4 = std::chrono::steady_clock::now();
             if (built_on_device) {
@@ -902,14 +969,14 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 v.nodes4 = c->d_nodes4.p; c->nodes4_count = (uint32_t) b4.nodes.size(); c->nodes4_stack = b4.stack_bound;
             }
             ms_bvh4 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t4).count();
-            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4: %zu nodes (bvh2 %u), depth %u, stack bound %u, ok %d\n", b4.nodes.size(), node_count, b4.depth, b4.stack_bound, (int) b4.ok);
+            if (c->opt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh4: %zu nodes (bvh2 %u), depth %u, stack bound %u, ok %d\n", b4.nodes.size(), node_count, b4.depth, b4.stack_bound, (int) b4.ok);
         }
         // The 8-wide tree (miw/bvh8.h; walked instead of the 4-wide one whenever it exists — mi_render, MIW_BVH8=0 at render time keeps
         // the 4-wide walk): collapsed on the device above, or here on the host from the host-built BVH2 (quality 1). c->view keeps
         // the BVH2's triangle order; mi_render hands the phase machine a view whose tris / tri_vn are d_tris8 / d_tri_vn8.
         if (c->lds_cfg.stack && v.nodes4 && dev8_nodes) {
             c->nodes8_count = dev8_nodes; c->nodes8_depth = dev8_depth; wide8_on_device = true;
-            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8 (device): %u nodes (bvh2 %u, bvh4 %u), depth %u, %.2f ms\n", dev8_nodes, node_count, c->nodes4_count, dev8_depth, ms_bvh8);
+            if (c->opt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8 (device): %u nodes (bvh2 %u, bvh4 %u), depth %u, %.2f ms\n", dev8_nodes, node_count, c->nodes4_count, dev8_depth, ms_bvh8);
         } else if (c->lds_cfg.stack && v.nodes4 && wide8_on && !built_on_device) {
             auto t8 = std::chrono::steady_clock::now();
             const Bvh8BuildResult b8 = bvh8_collapse(r.nodes, tri_count);
@@ -922,7 +989,7 @@ mi_status mi_bvh_build(mi_ctx *c, int32_t quality) {
                 c->nodes8_count = (uint32_t) b8.nodes.size(); c->nodes8_depth = b8.depth;
             }
             ms_bvh8 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t8).count();
-            if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8: %zu nodes (bvh2 %u), depth %u, ok %d, %.2f ms\n", b8.nodes.size(), node_count, b8.depth, (int) b8.ok, ms_bvh8);
+            if (c->opt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] bvh8: %zu nodes (bvh2 %u), depth %u, ok %d, %.2f ms\n", b8.nodes.size(), node_count, b8.depth, (int) b8.ok, ms_bvh8);
         }
     }
 
@@ -1102,6 +1169,28 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
 mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     if (!c || !cfg || !film) return MI_ERR_INVALID;
     if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_render: call mi_scene_upload and mi_bvh_build first");
+    // this render's options: the context's, under the job's debug overrides (include/miwave.h: mi_render_cfg::debug_*)
+    Options ropt = c->opt;
+    switch (cfg->debug_film_replay) {
+        case MI_FILM_REPLAY_AUTO: break;
+        case MI_FILM_REPLAY_BLOCKS: ropt.v["MIW_FILM_LEGACY"] = "1"; break;
+        case MI_FILM_REPLAY_GROUPS: ropt.v.erase("MIW_FILM_LEGACY"); ropt.v["MIW_FILM_LANES"] = "0"; ropt.v["MIW_FILM_QUADS"] = "0"; ropt.v["MIW_FILM_COLUMNS"] = "0"; break;
+        case MI_FILM_REPLAY_COLUMNS: ropt.v.erase("MIW_FILM_LEGACY"); ropt.v["MIW_FILM_LANES"] = "0"; ropt.v["MIW_FILM_QUADS"] = "0"; ropt.v.erase("MIW_FILM_COLUMNS"); ropt.v.erase("MIW_FILM_GROUP"); break;
+        case MI_FILM_REPLAY_QUADS: ropt.v.erase("MIW_FILM_LEGACY"); ropt.v["MIW_FILM_LANES"] = "0"; ropt.v.erase("MIW_FILM_COLUMNS"); ropt.v.erase("MIW_FILM_GROUP"); if (ropt.get("MIW_FILM_QUADS") && atoi(ropt.get("MIW_FILM_QUADS")) == 0) ropt.v.erase("MIW_FILM_QUADS"); break;
+        case MI_FILM_REPLAY_LANES: ropt.v.erase("MIW_FILM_LEGACY"); ropt.v["MIW_FILM_LANES"] = "1"; break;
+        case MI_FILM_REPLAY_LANES_PLAIN_LOG: ropt.v.erase("MIW_FILM_LEGACY"); ropt.v["MIW_FILM_LANES"] = "2"; break;
+        default: return fail(c, MI_ERR_INVALID, "render: debug_film_replay must be one of MI_FILM_REPLAY_*");
+    }
+    if (cfg->debug_tree_width == 4) ropt.v["MIW_BVH8"] = "0";
+    else if (cfg->debug_tree_width == 8) ropt.v.erase("MIW_BVH8");
+    else if (cfg->debug_tree_width != 0) return fail(c, MI_ERR_INVALID, "render: debug_tree_width must be 0, 4 or 8");
+    switch (cfg->debug_path_kernel) {
+        case MI_PATH_KERNEL_AUTO: break;
+        case MI_PATH_KERNEL_LOCKSTEP: ropt.v["MIW_PHASED"] = "0"; break;
+        case MI_PATH_KERNEL_PHASED: ropt.v.erase("MIW_PHASED"); ropt.v["MIW_POOLED"] = "0"; break;
+        case MI_PATH_KERNEL_POOLED: ropt.v.erase("MIW_PHASED"); ropt.v["MIW_POOLED"] = "1"; break;
+        default: return fail(c, MI_ERR_INVALID, "render: debug_path_kernel must be one of MI_PATH_KERNEL_*");
+    }
     RenderParams P;
     mi_status st = fill_params(c, cfg, P);
     if (st != MI_OK) return st;
@@ -1160,7 +1249,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // The log format: 16-byte records with phase classes where the host enumeration covers the filter (film_classes.h: box, tent,
     // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
     bool rec16 = false;
-    if (film_mode != 2 && bs2 <= 65536u && !getenv("MIW_FILM_LEGACY")) {
+    if (film_mode != 2 && bs2 <= 65536u && !ropt.get("MIW_FILM_LEGACY")) {
         // the cache key: the filter's fields only, in a zero-filled record (padding bytes of a stack copy would make memcmp miss)
         FilmRec key; memset(&key, 0, sizeof key);
         key.border = P.film.border; key.radius = P.film.radius; key.scale_factor = P.film.scale_factor; memcpy(key.lut, P.film.lut, sizeof key.lut);
@@ -1179,8 +1268,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // k_film_lanes' wavefronts are few and long (81 per 64 tiles, each the serial replay of 64 pixel runs: ~6 ms at 512 spp however few
     // there are), so shards of fewer than 7 x 64 tiles keep the group kernel: 255 tiles (a rank's eighth of a 1080p frame) 4.1 ms by
     // k_film_quads against 6.1, 510 tiles 7.1 against 6.65, 1 020 tiles 12.9 against 10.2 (gpurun q10)
-    int film_lanes = rec16 && c->classes.reach <= 2 && n_tiles >= 448u && !getenv("MIW_FILM_COLUMNS") && !getenv("MIW_FILM_GROUP") && !getenv("MIW_FILM_QUADS") ? 1 : 0;
-    if (const char *e = getenv("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
+    int film_lanes = rec16 && c->classes.reach <= 2 && n_tiles >= 448u && !ropt.get("MIW_FILM_COLUMNS") && !ropt.get("MIW_FILM_GROUP") && !ropt.get("MIW_FILM_QUADS") ? 1 : 0;
+    if (const char *e = ropt.get("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
     const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
     const size_t log_entries = log_il ? log_capacity(log_il, n_tiles, bs2, std::max<uint32_t>(cfg->spp, 1)) : log_lanes_entries;
     const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
@@ -1243,7 +1332,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // inside the 64 KB a workgroup may ask for — at fewer workgroups per CU past 40 KB)
         L.tables_fit = (size_t) L.cfg.tab16 * 16 + L.table_bytes <= (c->lds_cfg.brute ? 64u * 1024u : lds_budget);
         L.cfg.env_top_count = L.cfg.env_top_base = L.cfg.env_top_words = 0;
-        if (L.tables_fit && c->have_env && !(getenv("MIW_ENV_TOP") && atoi(getenv("MIW_ENV_TOP")) == 0)) {
+        if (L.tables_fit && c->have_env && !(ropt.get("MIW_ENV_TOP") && atoi(ropt.get("MIW_ENV_TOP")) == 0)) {
             // ... and as many of the environment warp's smallest levels as fit what is left (at most env_cap): levels are stored from
             // the largest (0) to the smallest (n_levels - 1), so the top `count` levels are the tail of the array
             const EnvmapRec &e = c->env_host;
@@ -1266,10 +1355,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     LdsLayout lay = lay_out(c->lds_bytes, 4096, lds_budget4);
     // will this render walk the 8-wide tree? (the conditions mi_render applies below, known here already; MIW_BVH8=0 keeps the 4-wide walk)
     const bool pre8 = plan == 2 && cfg->integrator != MI_INTEGRATOR_DIRECT && !c->lds_cfg.brute && c->lds_cfg.stack && c->view.nodes4 && c->nodes8_count != 0u &&
-                      !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0) && !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0) &&
-                      !(getenv("MIW_PHASED_WAVES") && atoi(getenv("MIW_PHASED_WAVES")) != 4) && film_mode == 1;
+                      !(ropt.get("MIW_BVH8") && atoi(ropt.get("MIW_BVH8")) == 0) && !(ropt.get("MIW_PHASED") && atoi(ropt.get("MIW_PHASED")) == 0) &&
+                      !(ropt.get("MIW_PHASED_WAVES") && atoi(ropt.get("MIW_PHASED_WAVES")) != 4) && film_mode == 1;
     bool stack8_sized = false;
-    if (pre8 && !(getenv("MIW_STACK8_FULL") && atoi(getenv("MIW_STACK8_FULL")) != 0)) {
+    if (pre8 && !(ropt.get("MIW_STACK8_FULL") && atoi(ropt.get("MIW_STACK8_FULL")) != 0)) {
         const size_t base8 = (size_t) c->lds_cfg.stack16 * 16 + (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * MIW_BLOCK * sizeof(U2);
         const LdsLayout lay8 = lay_out(base8, 12288, lds_budget4);
         if (lay8.tables_fit && base8 <= c->lds_bytes) { lay = lay8; stack8_sized = true; }
@@ -1282,10 +1371,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     // shape of the workgroup: NW wavefronts x PP pixels per lane — 12 x 1 (three wavefronts per SIMD), or 8 x 2 (two per SIMD, 256 VGPRs, twice the
     // jobs per lane: MIW_POOL_SHAPE=8x2; needs 1024 job records + stacks in LDS: trees of up to 8 levels)
     int pool_nw = 12, pool_pp = 1;
-    if (const char *e = getenv("MIW_POOL_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%dx%d", &a, &b) == 2 && ((a == 12 && b == 1) || (a == 8 && b == 2))) { pool_nw = a; pool_pp = b; } }
+    if (const char *e = ropt.get("MIW_POOL_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%dx%d", &a, &b) == 2 && ((a == 12 && b == 1) || (a == 8 && b == 2))) { pool_nw = a; pool_pp = b; } }
     // (the 8 x 2 shape is instantiated for the MATS_TRIO class only — BASELINE configs 3 / 4)
-    if (!(c->trio && !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0) && c->rects.empty() && !c->textured)) { pool_nw = 12; pool_pp = 1; }
-    if (pre8 && getenv("MIW_POOLED") && atoi(getenv("MIW_POOLED")) != 0) {
+    if (!(c->trio && !(ropt.get("MIW_TRIO") && atoi(ropt.get("MIW_TRIO")) == 0) && c->rects.empty() && !c->textured)) { pool_nw = 12; pool_pp = 1; }
+    if (pre8 && ropt.get("MIW_POOLED") && atoi(ropt.get("MIW_POOLED")) != 0) {
         const size_t NJ = (size_t) pool_nw * pool_pp * 64u;
         size_t base = (size_t) std::max<uint32_t>(c->nodes8_depth, 2u) * NJ * sizeof(U2);
         const uint32_t pool16 = (uint32_t) (base / 16); base += 5u * NJ * 16u;
@@ -1293,11 +1382,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         layp = lay_out(base, 32768, (size_t) 160u * 1024u - 1024u);
         layp.cfg.stack16 = 0u; layp.cfg.pool16 = pool16; layp.cfg.stat16 = stat16; layp.cfg.nodes_staged = layp.cfg.tris_staged = 0u;
         pooled_fits = layp.tables_fit;
-        if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] pooled phase machine: %d wavefronts per workgroup x %d pixels per lane, LDS %zu bytes (stacks %zu, job records %zu, tables %zu of which environment warp levels %u), fits %d\n",
+        if (ropt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] pooled phase machine: %d wavefronts per workgroup x %d pixels per lane, LDS %zu bytes (stacks %zu, job records %zu, tables %zu of which environment warp levels %u), fits %d\n",
                                          pool_nw, pool_pp, layp.rlds, (size_t) pool16 * 16, 5u * NJ * 16u, layp.table_bytes, layp.cfg.env_top_words * 4u, (int) pooled_fits);
     }
     TraceLds rcfg = lay.cfg; size_t rlds = lay.rlds; const size_t rlds_plain = lay.rlds_plain, table_bytes = lay.table_bytes; const bool tables_fit = lay.tables_fit;
-    if (getenv("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu%s\n",
+    if (ropt.get("MIW_DEBUG")) fprintf(stderr, "[miwave] LDS per workgroup: %zu bytes dynamic with the scene tables (%zu without), tables %zu B of which environment warp levels %u B, budget %zu%s\n",
                                      rlds, rlds_plain, table_bytes, rcfg.env_top_words * 4u, lds_budget4, stack8_sized ? "; stack sized for the 8-wide tree's depth" : "");
 
     mi_counters &K = c->counters;
@@ -1378,25 +1467,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         // Which path kernel runs (decided here because placement depends on it): tree scenes with the LDS-stack walk get the wave-level
         // phase machine (device/phased_kernel.h; MIW_PHASED=0 keeps the lock-step kernel, MIW_TRIO=0 the full BSDF table: A/B runs)
         const bool tiny = c->lds_cfg.brute != 0;
-        const bool phased_on = !(getenv("MIW_PHASED") && atoi(getenv("MIW_PHASED")) == 0);
-        const bool trio_on = !(getenv("MIW_TRIO") && atoi(getenv("MIW_TRIO")) == 0);
+        const bool phased_on = !(ropt.get("MIW_PHASED") && atoi(ropt.get("MIW_PHASED")) == 0);
+        const bool trio_on = !(ropt.get("MIW_TRIO") && atoi(ropt.get("MIW_TRIO")) == 0);
         const bool trio_kernel = c->trio && trio_on && c->rects.empty() && !c->textured;   // 52 KB of code instead of 84
         const bool phased = phased_on && !direct && !tiny && c->lds_cfg.stack && (c->view.nodes4 != nullptr || trio_kernel) && (tables_fit || !MIW_LDS_TABLES);
         // 4 waves per SIMD for every tree (measured: 0.9 M triangles +7 - 11 %, 41 k triangles +-0 before the register diet, +8 % after); MIW_PHASED_WAVES = 3 | 4 overrides
         int ph_waves = 4;
-        if (const char *e = getenv("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
+        if (const char *e = ropt.get("MIW_PHASED_WAVES")) ph_waves = atoi(e) == 4 ? 4 : 3;
         const bool phased_placeable = phased && c->view.nodes4 != nullptr && ph_waves == 4;     // (the Placed instantiations: the 4-wide tree at four waves per SIMD)
         // the 8-wide tree whenever mi_bvh_build produced one (four waves per SIMD only; MIW_BVH8=0 here keeps the 4-wide walk: A/B runs in one process)
-        const bool phased8 = phased_placeable && c->nodes8_count != 0u && !(getenv("MIW_BVH8") && atoi(getenv("MIW_BVH8")) == 0);
+        const bool phased8 = phased_placeable && c->nodes8_count != 0u && !(ropt.get("MIW_BVH8") && atoi(ropt.get("MIW_BVH8")) == 0);
         if (stack8_sized && !phased8) return fail(c, MI_ERR_STATE, "render: the LDS stack was sized for the 8-wide walk, which this launch does not run");
         SceneView view8 = c->view;
         if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
         const uint32_t res_waves = phased ? (uint32_t) ph_waves : (c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u);
         bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
-        if (const char *e = getenv("MIW_PLACE")) place = place && atoi(e) != 0;
+        if (const char *e = ropt.get("MIW_PLACE")) place = place && atoi(e) != 0;
         uint32_t measure_div = 8u;                                 // the measuring launch runs spp / 8 samples (MIW_PLACE_MEASURE = divisor)
-        if (const char *e = getenv("MIW_PLACE_MEASURE")) measure_div = (uint32_t) std::max(2, atoi(e));
+        if (const char *e = ropt.get("MIW_PLACE_MEASURE")) measure_div = (uint32_t) std::max(2, atoi(e));
         const uint32_t measure_end = place ? std::max<uint32_t>(16u, cfg->spp / measure_div) : 0u;
         const uint32_t n_pieces = (n_lanes + 63u) / 64u;
         size_t place_tmp_bytes = 0;
@@ -1446,7 +1535,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // interior — every pixel dear, its walks bound by memory latency, tree and triangles beyond the L2s — gains from every
                     // wavefront carrying the same mix. Rule: spread when the tree does not fit the aggregate L2 (32 MB). MIW_PLACE_SPREAD = 0 | 1 overrides.
                     bool spread = phased && ((phased8 ? (size_t) c->nodes8_count * sizeof(Bvh8Node) : (size_t) c->nodes4_count * sizeof(Bvh4Node)) + (size_t) c->view.tri_count * sizeof(Tri)) > ((size_t) 32 << 20);
-                    if (const char *e = getenv("MIW_PLACE_SPREAD")) spread = atoi(e) != 0;
+                    if (const char *e = ropt.get("MIW_PLACE_SPREAD")) spread = atoi(e) != 0;
                     Q.piece_a = spread ? 1u : 64u; Q.piece_b = spread ? n_pieces : 1u;
                     std::vector<uint32_t> cost(n_pieces);
                     HIP_TRY(c, hipMemcpy2DAsync(cost.data(), sizeof(uint32_t), c->d_cost_sorted.p, Q.piece_a * sizeof(uint32_t), sizeof(uint32_t), n_pieces, hipMemcpyDeviceToHost, s));
@@ -1499,7 +1588,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // least-progress-first priorities below every pixel of such a shard should start at once: 42.3 vs 49.6 ms on the 1/8
                 // shard of C2, profiles/r03.)
                 unsigned wg_per_cu = 4u;
-                if (const char *e = getenv("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
+                if (const char *e = ropt.get("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
                 const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * wg_per_cu));
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, (T) != 0 ? rlds : rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
@@ -1519,27 +1608,31 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // 42.3 ms; 1/8 of the material balls -14 %), it also shortens the drain of a full frame (C2 275.9 -> 268.7 ms), so it is
                 // always on. MIW_TAIL_PRIO = 0 | 1 overrides.
                 rcfg.tail_prio = 1u;
-                if (const char *e = getenv("MIW_TAIL_PRIO")) rcfg.tail_prio = atoi(e) ? 1u : 0u;
+                if (const char *e = ropt.get("MIW_TAIL_PRIO")) rcfg.tail_prio = atoi(e) ? 1u : 0u;
                 TraceLds ph_cfg = rcfg;
                 ph_cfg.shade_num = 2; ph_cfg.shade_den = c->have_env ? 4 : 3;
-                if (const char *e = getenv("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
+                if (const char *e = ropt.get("MIW_SHADE_VOTE")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0) { ph_cfg.shade_num = (uint32_t) a; ph_cfg.shade_den = (uint32_t) b; } }
                 // when the walk loops hand over (phased_kernel.h): a loop runs on until its lanes are outnumbered 2 : 1 by the other walk body's, or
                 // node_exit : 1 / tri_exit : 1 by the lanes waiting for another body. Measured on the 8-wide walk (gpurun r5f - r5h, Msamples/s,
                 // material balls / interior): rounds 3 - 4's rule (1 : 1 against the other body, waiting + half the lanes that left) 1 119 / 463;
                 // 2 : 1 with node 1, triangle 1 -> 1 161 / 471; triangle 2 -> 1 174 / 472; node 2 -> 1 147 / 478; node 2, triangle 3 -> . / 481
                 // (the interior's shade runs are long: loops that wait for them less often win there). MIW_LOOP_EXIT=node:triangle overrides.
                 ph_cfg.node_exit = c->have_env ? 2u : 1u; ph_cfg.tri_exit = c->have_env ? 3u : 2u;
-                if (const char *e = getenv("MIW_LOOP_EXIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a >= 0 && b >= 0) { ph_cfg.node_exit = (uint32_t) a; ph_cfg.tri_exit = (uint32_t) b; } }
+                if (const char *e = ropt.get("MIW_LOOP_EXIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a >= 0 && b >= 0) { ph_cfg.node_exit = (uint32_t) a; ph_cfg.tri_exit = (uint32_t) b; } }
 #define MIW_PHASED_LAUNCH_(M, A, WV, W, PL) MIW_TIMED(6, hipLaunchKernelGGL((k_path_phased<M, A, MIW_PHASE_SPEC != 0, WV, W, PL>), phgrid, block, rlds, s, P, (W) == 2 ? view8 : c->view, Q, c->d_cnt.p, ph_cfg, end, c->d_next_pixel.p))
 #define MIW_PHASED_LAUNCH(M, A, W) do { if (ph_waves == 4) MIW_PHASED_LAUNCH_(M, A, 4, W, false); else MIW_PHASED_LAUNCH_(M, A, 3, W, false); } while (0)
                 K.tree_width = phased ? (phased8 ? 8u : (c->view.nodes4 ? 4u : 2u)) : 0u;
+#if MIW_SPECTRAL
+                const bool pooled = false;
+                if (pooled) { }
+#else
                 const bool pooled = phased8 && !place && pooled_fits;
                 if (pooled) {
                     // one workgroup per CU; the vote's constants travel in the fields the old kernel's vote used (pooled_kernel.h: shade_min, walk_min, node_min, tri_min)
                     // + pool_claim_min; MIW_POOL_VOTE=shade_min:walk_min:node_min:tri_min:claim_min overrides (A/B runs)
                     TraceLds pcfg = layp.cfg; pcfg.queues = 1u; pcfg.tail_prio = ph_cfg.tail_prio;
                     pcfg.shade_num = 48; pcfg.shade_den = 16; pcfg.node_exit = 40u; pcfg.tri_exit = 20u; pcfg.pool_claim_min = 8u;
-                    if (const char *e = getenv("MIW_POOL_VOTE")) { int a = 0, b = 0, n = 0, t = 0, m = 0; if (sscanf(e, "%d:%d:%d:%d:%d", &a, &b, &n, &t, &m) == 5 && a > 0 && b >= 0) { pcfg.shade_num = (uint32_t) a; pcfg.shade_den = (uint32_t) b; pcfg.node_exit = (uint32_t) n; pcfg.tri_exit = (uint32_t) t; pcfg.pool_claim_min = (uint32_t) std::max(m, 1); } }
+                    if (const char *e = ropt.get("MIW_POOL_VOTE")) { int a = 0, b = 0, n = 0, t = 0, m = 0; if (sscanf(e, "%d:%d:%d:%d:%d", &a, &b, &n, &t, &m) == 5 && a > 0 && b >= 0) { pcfg.shade_num = (uint32_t) a; pcfg.shade_den = (uint32_t) b; pcfg.node_exit = (uint32_t) n; pcfg.tri_exit = (uint32_t) t; pcfg.pool_claim_min = (uint32_t) std::max(m, 1); } }
                     const unsigned NL = (unsigned) pool_nw * 64u;
                     const dim3 qgrid(std::min<unsigned>((n_lanes + NL - 1u) / NL, (unsigned) c->cu_count)), qblock(NL);
                     SceneView pview = view8;
@@ -1553,7 +1646,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #undef MIW_POOLED_LAUNCH
 #undef MIW_POOLED_LAUNCH_
                     K.pooled = 1u; K.pool_waves = (uint32_t) pool_nw;
-                } else
+                }
+#endif
+                else
                 if (phased8 && place) {
                     if (c->textured) MIW_PHASED_LAUNCH_(MATS_ALL, true, 4, 2, true);
                     else if (trio_kernel) MIW_PHASED_LAUNCH_(MATS_TRIO, false, 4, 2, true);
@@ -1617,7 +1712,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         Counters sum;
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
-        if (K.placed && getenv("MIW_DEBUG")) {                     // how the placed launch went: SIMDs that registered, lanes handed out per queue
+        if (K.placed && ropt.get("MIW_DEBUG")) {                     // how the placed launch went: SIMDs that registered, lanes handed out per queue
             std::vector<uint32_t> cur(n_simd), ids(1u + (1u << 14)), cost(n_pieces);
             (void) hipMemcpy(cur.data(), c->d_next_pixel.p, n_simd * sizeof(uint32_t), hipMemcpyDeviceToHost);
             (void) hipMemcpy(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -1645,7 +1740,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
 #endif
 #if defined(MIW_PHASE_STATS)
-        if (getenv("MIW_DEBUG")) {
+        if (ropt.get("MIW_DEBUG")) {
             unsigned long long ps[15];
             if (!K.pooled && hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
                 static const char *names[5] = { "node step", "triangle test", "walk end", "shade", "vote" };
@@ -1660,8 +1755,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             }
         }
 #endif
-#if defined(MIW_PHASE_STATS)
-        if (getenv("MIW_DEBUG") && K.pooled) {
+#if defined(MIW_PHASE_STATS) && !MIW_SPECTRAL
+        if (ropt.get("MIW_DEBUG") && K.pooled) {
             unsigned long long ps[32];
             if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pool_stats), sizeof ps) == hipSuccess) {
                 static const char *names[5] = { "vote", "node trip", "triangle trip", "shade", "idle" };
@@ -1678,7 +1773,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
 #endif
 #if defined(MIW_WALK_STATS)
-        if (getenv("MIW_DEBUG")) {
+        if (ropt.get("MIW_DEBUG")) {
             unsigned long long st[8]; float stf[8];
             if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_walk_stats), sizeof st) == hipSuccess && hipMemcpyFromSymbol(stf, HIP_SYMBOL(g_walk_statsf), sizeof stf) == hipSuccess) {
                 for (int k = 0; k < 2; ++k) {
@@ -1693,7 +1788,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
 #endif
 #if defined(MIW_SECTION_PROFILE)
-        if (getenv("MIW_DEBUG")) {
+        if (ropt.get("MIW_DEBUG")) {
             unsigned long long sec[16];
             if (hipMemcpyFromSymbol(sec, HIP_SYMBOL(g_sections), sizeof sec) == hipSuccess) {
                 static const char *names[13] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin",
@@ -1729,7 +1824,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 
         // trees walked with the LDS stack: one persistent stream kernel serves the E and the S rays of an iteration
         // (device/stream_trace.h); MIW_STREAM=0 keeps the slice-per-workgroup kernels (A/B runs)
-        const bool stream_on = !(getenv("MIW_STREAM") && atoi(getenv("MIW_STREAM")) == 0);
+        const bool stream_on = !(ropt.get("MIW_STREAM") && atoi(ropt.get("MIW_STREAM")) == 0);
         const bool stream = stream_on && c->lds_cfg.stack && !c->lds_cfg.brute && c->lds_cfg.nodes_staged == 0;
         K.path_kernel = stream ? 2u : 0u;
         if (stream) {
@@ -1817,7 +1912,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // 4x4 3.06 but spends 0.77 wave-iterations per sample; 4x2 (4.4 rows, 0.55) balances HBM reads against issue slots.
                     // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4).
                     int group = 3;
-                    if (const char *e = getenv("MIW_FILM_GROUP")) group = atoi(e);
+                    if (const char *e = ropt.get("MIW_FILM_GROUP")) group = atoi(e);
                     const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
 #define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
                     // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups;
@@ -1829,11 +1924,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     // staged through LDS (k_film_quads; MIW_FILM_QUADS = 24 / 28 / 44: other group shapes, = 0: the kernels below — also taken when a tile
                     // has fewer groups than a wavefront takes, i.e. tiny blocks)
                     int columns = 42;
-                    if (const char *e = getenv("MIW_FILM_COLUMNS")) columns = atoi(e);
+                    if (const char *e = ropt.get("MIW_FILM_COLUMNS")) columns = atoi(e);
                     // (what runs here by default are shards of fewer than 448 tiles — k_film_lanes takes the rest —: 4 x 2 groups, twice as many and half as
                     // long wavefronts as 2 x 4: a rank's eighth of a 1080p frame 3.63 ms against 4.13, k_film_columns 4.19, gpurun q11; a whole frame 24.1 / 23.8)
-                    int quads = getenv("MIW_FILM_COLUMNS") == nullptr && getenv("MIW_FILM_GROUP") == nullptr ? 42 : 0;
-                    if (const char *e = getenv("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 42 : atoi(e);
+                    int quads = ropt.get("MIW_FILM_COLUMNS") == nullptr && ropt.get("MIW_FILM_GROUP") == nullptr ? 42 : 0;
+                    if (const char *e = ropt.get("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 42 : atoi(e);
                     if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
                     const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
                     if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
@@ -1846,7 +1941,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                         const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
                         const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
                         int fl_nt = 1;                                    // the log read with streaming loads (16.8 vs 17.05 ms at C2, gpurun q9); MIW_FL_NT = 0: plain loads
-                        if (const char *e = getenv("MIW_FL_NT")) fl_nt = atoi(e);
+                        if (const char *e = ropt.get("MIW_FL_NT")) fl_nt = atoi(e);
                         if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
                         else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
                     } else if (quads) {
@@ -1855,7 +1950,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                         const size_t qbytes = (size_t) (c->classes.count + 1u) * (size_t) (5u + 2u * qh) * sizeof(float);
 #define MIW_FQ_LAUNCH(GW, GH, U) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH, U>), dim3(waves), dim3(64), qbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p))
                         int fq_u = 4;
-                        if (const char *e = getenv("MIW_FQ_U")) fq_u = atoi(e);
+                        if (const char *e = ropt.get("MIW_FQ_U")) fq_u = atoi(e);
                         if (quads == 24) { if (fq_u == 8) MIW_FQ_LAUNCH(2, 4, 8); else if (fq_u == 2) MIW_FQ_LAUNCH(2, 4, 2); else MIW_FQ_LAUNCH(2, 4, 4); }
                         else if (quads == 42) { if (fq_u == 8) MIW_FQ_LAUNCH(4, 2, 8); else MIW_FQ_LAUNCH(4, 2, 4); }
                         else if (quads == 28) MIW_FQ_LAUNCH(2, 8, 4); else MIW_FQ_LAUNCH(4, 4, 4);

@@ -140,7 +140,7 @@ def test_emulated_render_walks_trees_with_the_8_wide_bodies(native, oracle, monk
 def test_phase_machine_over_bvh8_equals_oracle(native, oracle, quality):
     """The film of the material-ball scene rendered by k_path_phased over the 8-wide tree — collapsed on the device from the
     device-built SAH tree (quality 0) and on the host from the host-built one (quality 1) — is the oracle's bit for bit, and so
-    is the film of the same context rendered over the 4-wide tree (MIW_BVH8=0 at render time); the two builders agree on the
+    is the film of the same context rendered over the 4-wide tree (debug_tree_width = 4 / option MIW_BVH8=0 at render time); the two builders agree on the
     8-wide tree's node count and depth (same programme, same BVH2)."""
     from mitsuba2_amd import scenes
     scene, sensor = scenes.cornell_box(48, 40, 8, diffuse_only=False, ball_level=3, device=-1)
@@ -156,12 +156,12 @@ def test_phase_machine_over_bvh8_equals_oracle(native, oracle, quality):
         assert st == 0 and c.path_kernel == 1 and c.tree_width == 8
         assert c.samples == ost.samples and c.segments == ost.segments
         assert np.array_equal(g, o32)
-        os.environ["MIW_BVH8"] = "0"
-        try:
-            g4, st = dev.render(job)
-            assert st == 0 and dev.counters().tree_width == 4 and np.array_equal(g4, o32)
-        finally:
-            os.environ.pop("MIW_BVH8", None)
+        g4, st = dev.render(job, tree_width=4)                  # mi_render_cfg::debug_tree_width (the library reads the environment in mi_create only)
+        assert st == 0 and dev.counters().tree_width == 4 and np.array_equal(g4, o32)
+        dev.set_option("MIW_BVH8", "0")                           # ... and the context's own switch does the same
+        g4b, st = dev.render(job)
+        dev.set_option("MIW_BVH8", None)
+        assert st == 0 and dev.counters().tree_width == 4 and np.array_equal(g4b, o32)
         want = oracle.emu_trace8(scene.desc(), np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32))["bvh8"]
         assert (b.bvh8_nodes, b.bvh8_depth) == (want["nodes8"], want["depth"])
     finally:

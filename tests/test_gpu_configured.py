@@ -62,11 +62,7 @@ def test_c2_full_frame_is_the_oracles(native):
     assert 0 < c.shadow_rays <= rec["shadow_rays"]           # the device skips shadow rays that carry a zero contribution
     _assert_film(film, rec, "C2 1920x1080 @ 512 spp")
     # the 24-byte position log + texel-patch replay (filters without phase classes take it) is the same film
-    os.environ["MIW_FILM_LEGACY"] = "1"
-    try:
-        legacy, st = dev.render(native.PathIntegrator().render_job(sensor))
-    finally:
-        del os.environ["MIW_FILM_LEGACY"]
+    legacy, st = dev.render(native.PathIntegrator().render_job(sensor), film_replay=1)      # MI_FILM_REPLAY_BLOCKS
     assert st == 0 and dev.counters().log_record_bytes == 24 and np.array_equal(legacy, film)
     dev.close()
 

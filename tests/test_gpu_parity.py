@@ -677,12 +677,13 @@ def test_placed_queues_and_priorities_do_not_change_the_film(native, which):
     job = integ.render_job(sensor)
     films = {}
     for name, env in (("default", {}), ("plain", {"MIW_PLACE": "0", "MIW_TAIL_PRIO": "0"})):
-        os.environ.update(env)
+        for k, v in env.items():
+            dev.set_option(k, v)                                  # (the context's own switches: the environment is read in mi_create only)
         try:
             films[name], st = dev.render(job, samples_per_launch=128)
         finally:
             for k in env:
-                del os.environ[k]
+                dev.set_option(k, None)
         c = dev.counters()
         assert st == 0 and c.samples > 0
         assert c.placed == (1 if name == "default" else 0) and c.n_path == (2 if name == "default" else 1)

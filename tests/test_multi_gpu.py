@@ -105,7 +105,7 @@ def test_rccl_branch_of_the_film_reduce_runs_on_one_gpu(native, monkeypatch):
         assert hip.hipMemcpy(film, ramp.ctypes.data_as(C.c_void_p), n * 4, 1) == 0          # hipMemcpyHostToDevice
         ctxs = (C.c_void_p * 1)(dev.ctx); films = (C.c_void_p * 1)(film); how = C.c_int32(-1)
         assert L.mi_film_reduce(ctxs, films, 1, n, 0, C.byref(how)) == 0 and how.value == 0          # one context: nothing to do
-        monkeypatch.setenv("MIW_RCCL_FORCE", "1")
+        dev.set_option("MIW_RCCL_FORCE", "1")                      # (a switch of the context: the environment is read in mi_create only)
         st = L.mi_film_reduce(ctxs, films, 1, n, 0, C.byref(how))
         assert st == 0, dev.L.mi_last_error(dev.ctx)
         assert how.value == 2, "the RCCL branch did not run (librccl missing on this box?)"          # MI_REDUCE_RCCL

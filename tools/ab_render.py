@@ -52,8 +52,13 @@ def main():
             for rep in range(args.reps + 1):                       # (repetition 0 warms up)
                 for v in variants:
                     kv = dict(p.split("=", 1) for p in v.split(",") if p)
-                    old = {k: os.environ.get(k) for k in kv}
-                    os.environ.update(kv)
+                    known = dev.options()
+                    old = {k: (dev.get_option(k) if k in known else os.environ.get(k)) for k in kv}
+                    for k, val in kv.items():                       # the library's switches live in the context (read from the environment
+                        if k in known:                              # once, by mi_create): mi_set_option; anything else: the environment
+                            dev.set_option(k, val)
+                        else:
+                            os.environ[k] = val
                     try:
                         print("[ab] %s | %s | rep %d" % (name, v or "(defaults)", rep), file=sys.stderr, flush=True)
                         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -61,7 +66,9 @@ def main():
                         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
                     finally:
                         for k, o in old.items():
-                            if o is None:
+                            if k in known:
+                                dev.set_option(k, o)
+                            elif o is None:
                                 os.environ.pop(k, None)
                             else:
                                 os.environ[k] = o
