@@ -295,6 +295,63 @@ def reduce_label(backend):
     return {"nccl": "RCCL", "gloo": "gloo (host)"}.get(backend, backend)
 
 
+REDUCE_HOW = {0: "none (one context)", 1: "device add, rank order (contexts share a GPU, or RCCL unavailable)", 2: "RCCL ncclReduce (mi_film_reduce)"}
+
+
+def native_reduce_main(args):
+    """`--native-reduce`: the N-GPU frame from ONE process through the C++ host layer — Scene::build(devices) puts the scene on N
+    contexts, SamplingIntegrator::render runs one host thread per context over its shard of the spiral blocks (global block-id -> seed
+    table) and closes the frame with mi_film_reduce; the root's film comes down to the host once per step (inside the timed region:
+    that is what Integrator::render returns). `--dry-ranks`: the plan only (CPU tier): devices, reduce route, nothing rendered."""
+    n = max(args.gpus, 1)
+    devices = [0] * n if args.share_gpu else list(range(n))
+    if args.dry_ranks:
+        print(json.dumps({"n_gpus": n, "ranks_seen": len(devices), "backend": None, "route": "one process, %d contexts" % n, "devices": devices,
+                          "reduce": "mi_film_reduce: " + (REDUCE_HOW[0] if n == 1 else REDUCE_HOW[1] if args.share_gpu else REDUCE_HOW[2])}), flush=True)
+        return
+    import numpy as np
+    from mitsuba2_amd import api, scenes
+    W, H, SPP = args.width, args.height, args.spp
+    if args.variant != "scalar_rgb":
+        api.set_variant(args.variant); api.set_srgb_model(api.default_srgb_coeff())
+    if args.scene == "interior":
+        scene, sensor = scenes.interior_scene(W, H, SPP, device=-1)
+    elif args.scene == "glassblock":
+        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=True, glass_block=True, device=-1)
+    else:
+        scene, sensor = scenes.cornell_box(W, H, SPP, diffuse_only=(args.scene == "cornell"), ball_level=args.tess, device=-1)
+    scene.build(devices if n > 1 else devices[0], args.bvh_quality)
+    integ = (api.DirectIntegrator if args.integrator == "direct" else api.PathIntegrator)()
+    for _ in range(args.warmup):
+        integ.render(scene, sensor)
+    t0 = time.perf_counter()
+    samples = segments = 0; ms_path = 0.0
+    for _ in range(args.steps):
+        assert integ.render(scene, sensor) is True
+        c = integ.counters()
+        samples += c.samples; segments += c.segments; ms_path += c.ms_path
+    elapsed = time.perf_counter() - t0
+    film = sensor.film.data((H, W, 5))
+    value = float(W) * H * SPP * args.steps / elapsed / 1e6
+    s_bar = segments / max(samples, 1)
+    alg = 280.0 * segments + B_SPLAT * samples
+    print(json.dumps({
+        "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
+        "n_gpus": n, "ranks_seen": scene.device_count(), "route": "one process: one context + one host thread per GPU (Scene::build(devices)), film reduced by mi_film_reduce",
+        "reduce_how": REDUCE_HOW.get(integ.last_reduce(), str(integ.last_reduce())), "devices": devices,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "variant": args.variant, "integrator": args.integrator, "shard": "tiles",
+        "config": {"workload": "%s, %dx%d @ %d spp, %s integrator" % (args.scene, W, H, SPP, args.integrator),
+                   "parallelism": "tile-shard x%d in one process + mi_film_reduce" % n if n > 1 else "single GPU",
+                   "film": "downloaded to the host once per step (inside the timed region)"},
+        # the slowest context's path-kernel time per step (mi_counters::ms_path is the maximum over the contexts) against its share of the bytes
+        "roofline": {"bound": None, "kernel": "path kernel (slowest context)", "achieved": (alg / n) / (ms_path * 1e-3) / 1e9 if ms_path > 0 else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / n) / (ms_path * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_path > 0 else None,
+                     "traffic": None, "segments_per_sample": s_bar},
+        "cpu_baseline": None, "film_mean_y": float(np.asarray(film)[..., 1].mean()),
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +369,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank path on a box with fewer GPUs than ranks, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--native-reduce", action="store_true", help="N > 1 from ONE process: the scene is built on N contexts (Scene::build(devices): one context + one "
+                    "host thread per GPU), SamplingIntegrator::render shards the spiral blocks over them and mi_film_reduce sums the partial films "
+                    "(RCCL ncclReduce between distinct GPUs, a rank-ordered device add when contexts share one) - the route next to the "
+                    "torch.distributed one (one process per GPU). The JSON line carries ranks_seen and reduce_how")
     ap.add_argument("--dry-ranks", action="store_true", help="testing only (CPU tier): every rank joins the process group, takes part in one "
                     "all-reduce and rank 0 prints {n_gpus, ranks_seen}; nothing is rendered")
     ap.add_argument("--shard-of", type=int, default=0, help="testing only (N = 1): render one shard of this many — what one rank "
@@ -344,6 +405,8 @@ def main():
                     help="resident plan: samples each pixel advances per launch (-1 = all spp in one launch, 0 = library default)")
     args = ap.parse_args()
 
+    if args.native_reduce:
+        return native_reduce_main(args)
     # N ranks: under a launcher (the driver's torch.distributed.run: WORLD_SIZE is set) this process is one of them; alone with
     # --gpus N > 1 it becomes the launcher of N ranks of itself
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -444,10 +507,13 @@ def main():
         agg["n_film"] += 1
     sync()
     elapsed = time.perf_counter() - t0
+    ranks_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(t); ranks_seen = int(t.item())
 
     if rank == 0:
         total_samples = float(W) * H * SPP * args.steps
@@ -548,7 +614,9 @@ def main():
             extras = run_extras(api, scenes, film, C)
         out = {
             "metric": "Msamples/sec (whole node), 1080p/512spp path integrator", "value": value, "unit": "Msamples/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "route": "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU",
+            "reduce_how": ("torch.distributed.reduce(sum) over " + reduce_label(args.backend)) if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "variant": args.variant, "integrator": args.integrator, "shard": shard if world > 1 or args.shard_of > 1 else None,
             "shard_index": args.shard_index if args.shard_of > 1 and world == 1 else None,

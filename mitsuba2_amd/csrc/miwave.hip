@@ -18,6 +18,7 @@
 #include <vector>
 #include <chrono>
 #include <atomic>
+#include <cmath>
 #include <map>
 #include <string>
 #include <algorithm>
@@ -1295,6 +1296,19 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         HIP_TRY(c, c->d_accum.resize(film_n));
         HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
     }
+#if defined(MIW_DEBUG_POISON)
+    // Debug tier (-DMIW_DEBUG_POISON=1 builds; the reference poisons its GPU interactions in debug builds the same way,
+    // src/librender/scene_optix.inl:475-480): every buffer a render kernel is supposed to WRITE before anything reads it starts as
+    // NaN bit patterns (0xff bytes) — the sample log, plan 1's queues, the block tiles — and mi_render fails when a NaN reaches the film.
+    // A slot that is read without having been written (an indexing error, a lane that skipped its log write) then shows up as
+    // MI_ERR_STATE instead of as a plausible-looking stale value from the previous frame.
+    {
+        auto poison = [&](void *p, size_t bytes) -> hipError_t { return p && bytes ? hipMemsetAsync(p, 0xff, bytes, s) : hipSuccess; };
+        HIP_TRY(c, poison(c->q_log_rec.p, c->q_log_rec.n * sizeof(U4))); HIP_TRY(c, poison(c->q_log_pos.p, c->q_log_pos.n * sizeof(F2))); HIP_TRY(c, poison(c->q_log_val.p, c->q_log_val.n * sizeof(F4)));
+        if (plan == 1) for (DevBuf<F4> *q : { &c->q_tp, &c->q_res, &c->q_ray_o, &c->q_ray_d, &c->q_hit, &c->q_sh_d, &c->q_sh_c }) HIP_TRY(c, poison(q->p, q->n * sizeof(F4)));
+        HIP_TRY(c, poison(c->d_tiles.p, c->d_tiles.n * sizeof(float)));
+    }
+#endif
     c->counters.log_bytes = film_mode == 1 ? (uint64_t) log_entries * rec_bytes : 0u;
     c->counters.log_record_bytes = film_mode == 1 ? (uint32_t) rec_bytes : 0u;
     c->counters.film_kernel = 0u; c->counters.log_interleaved = film_mode == 1 && rec16 && log_il ? 1u : 0u;
@@ -1976,6 +1990,15 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(s));
         if (cfg->profile) drain_stamps();
+#if defined(MIW_DEBUG_POISON)
+        if (result == MI_OK) {                                    // (a cancelled render leaves unwritten slots by design)
+            std::vector<unsigned char> host(film_n * elem);
+            HIP_TRY(c, hipMemcpy(host.data(), dst, film_n * elem, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < film_n; ++i) bad += cfg->film_f64 ? std::isnan(((const double *) host.data())[i]) : std::isnan(((const float *) host.data())[i]);
+            if (bad) return fail(c, MI_ERR_STATE, "render (poisoned build): %zu film values are NaN - a log / queue / tile slot was read before it was written", bad);
+        }
+#endif
     }
 #undef MIW_TIMED
     K.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

@@ -230,7 +230,8 @@ class Oracle:
 
 def load(variant="scalar_rgb"):
     if variant not in _libs:
-        path = os.path.join(ROOT, "oracle", "_build", "libmiw_oracle%s.so" % VARIANT_SUFFIX[variant])
+        # MIW_ORACLE_DIR: another build of the checker (tools/sanitize_cpu.sh: the AddressSanitizer + UBSan build of the same sources)
+        path = os.path.join(os.environ.get("MIW_ORACLE_DIR") or os.path.join(ROOT, "oracle", "_build"), "libmiw_oracle%s.so" % VARIANT_SUFFIX[variant])
         if not os.path.exists(path):
             raise ImportError(path + " missing: python -m mitsuba2_amd.build --oracle")
         _libs[variant] = Oracle(C.CDLL(path), 4 if variant == "scalar_spectral" else 3)

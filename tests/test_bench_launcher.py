@@ -26,6 +26,17 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert j == {"n_gpus": 2, "ranks_seen": 2, "backend": "gloo", "reduce": "gloo (host)"}
 
 
+def test_native_reduce_route_is_one_process_of_n_contexts():
+    """`--native-reduce` (VERDICT r05 item 10): the one-process route — Scene::build(devices) + mi_film_reduce — one command away from
+    an 8-GPU lease; the dry run prints its plan: N contexts, distinct devices -> RCCL, a shared device -> the rank-ordered add"""
+    j, _ = _run(["--gpus", "4", "--native-reduce", "--dry-ranks"])
+    assert j["n_gpus"] == 4 and j["ranks_seen"] == 4 and j["devices"] == [0, 1, 2, 3] and "RCCL" in j["reduce"] and "one process" in j["route"]
+    j, _ = _run(["--gpus", "3", "--native-reduce", "--share-gpu", "--dry-ranks"])
+    assert j["devices"] == [0, 0, 0] and "device add" in j["reduce"]
+    j, _ = _run(["--gpus", "1", "--native-reduce", "--dry-ranks"])
+    assert j["ranks_seen"] == 1 and "none" in j["reduce"]
+
+
 def test_one_gpu_is_one_process():
     j, _ = _run(["--gpus", "1", "--dry-ranks"])
     assert j["n_gpus"] == 1 and j["ranks_seen"] == 1 and j["reduce"] is None
