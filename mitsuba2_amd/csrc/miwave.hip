@@ -1167,6 +1167,332 @@ static mi_status fill_params(mi_ctx *c, const mi_render_cfg *cfg, RenderParams &
     return MI_OK;
 }
 
+// ---- per-launch timing of one mi_render: HIP events from the context's pool around every launch, summed per launch class into mi_counters ----
+struct LaunchTimer {
+    struct Stamp { int cls; size_t e0, e1; };
+    mi_ctx *c; mi_counters &K; bool on;
+    std::vector<Stamp> stamps; size_t ev_used = 0;
+    hipError_t get_event(size_t &idx) {
+        if (ev_used == c->ev_pool.size()) {
+            hipEvent_t e; hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) return r;
+            c->ev_pool.push_back(e);
+        }
+        idx = ev_used++;
+        return hipSuccess;
+    }
+    void drain() {
+        if (!on) return;
+        for (const Stamp &t : stamps) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev_pool[t.e0], c->ev_pool[t.e1]) != hipSuccess) continue;
+            switch (t.cls) {
+                case 0: K.ms_trace_closest += ms; break;
+                case 1: K.ms_trace_any += ms; break;
+                case 2: K.ms_shade += ms; break;
+                case 3: K.ms_init += ms; break;
+                case 6: K.ms_path += ms; break;
+                case 4: K.ms_film_blocks += ms; K.ms_resolve += ms; break;
+                case 5: K.ms_film_merge += ms; K.ms_resolve += ms; break;
+                default: K.ms_resolve += ms; break;
+            }
+        }
+        stamps.clear(); ev_used = 0;
+    }
+};
+
+// ---- mi_render, phase "film plan": how ImageBlock::put is realised for this job (mi_render_cfg::film_mode), the sample log's record
+// format (16-byte class records where film_classes.h covers the filter, 24-byte positions otherwise), its layout ([lane][sample], or interleaved
+// over groups of 64 tiles for k_film_lanes) and its allocation ----
+struct FilmPlan { int film_mode = 0; bool rec16 = false; int film_lanes = 0; uint32_t log_il = 0; size_t log_entries = 0, rec_bytes = 0; };
+static mi_status plan_film_log(mi_ctx *c, const mi_render_cfg *cfg, const Options &ropt, const RenderParams &P, hipStream_t s, int plan,
+                               uint32_t n_tiles, uint32_t n_lanes, uint32_t bs2, uint32_t bs2_log2, size_t film_n, FilmPlan &FP) {
+    (void) plan;
+    // film mode: sample log + ordered gather if the log fits, else float64 atomics
+    int film_mode = cfg->film_mode;
+    const size_t nl = std::max<uint32_t>(n_lanes, 1);
+    if (film_mode < 0 || film_mode > 2) return fail(c, MI_ERR_INVALID, "render: film_mode must be 0, 1 or 2");
+    const size_t log_lanes_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
+    // The log format: 16-byte records with phase classes where the host enumeration covers the filter (film_classes.h: box, tent,
+    // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
+    bool rec16 = false;
+    if (film_mode != 2 && bs2 <= 65536u && !ropt.get("MIW_FILM_LEGACY")) {
+        // the cache key: the filter's fields only, in a zero-filled record (padding bytes of a stack copy would make memcmp miss)
+        FilmRec key; memset(&key, 0, sizeof key);
+        key.border = P.film.border; key.radius = P.film.radius; key.scale_factor = P.film.scale_factor; memcpy(key.lut, P.film.lut, sizeof key.lut);
+        // (a filter the enumeration refuses is remembered as well — classes_valid — instead of being enumerated again by every render)
+        if (!c->classes_valid || memcmp(&key, &c->classes_of, sizeof key) != 0 || (c->classes.ok && !c->d_fc_thr.p)) {
+            c->classes = film_classes_build(P.film);             // ~30 ms, once per filter
+            c->classes_of = key; c->classes_valid = true;
+            if (c->classes.ok) { HIP_TRY(c, c->d_fc_thr.upload(c->classes.thr, s)); HIP_TRY(c, c->d_fc_w.upload(c->classes.w, s)); HIP_TRY(c, hipStreamSynchronize(s)); }
+        }
+        rec16 = c->classes.ok;
+    }
+    // The replay kernel for the 16-byte records (device/film_kernels.h): k_film_lanes — one 4 x 4 texel block per lane, a wavefront = one
+    // block position in 64 consecutive tiles — wants those tiles' logs interleaved record by record (path.h: log_index), so the
+    // choice is made before the render kernels write the log. MIW_FILM_LANES = 0, or naming another kernel's shape
+    // (MIW_FILM_QUADS / _COLUMNS / _GROUP), keeps [lane][sample] and the group kernels; MIW_FILM_LANES = 2: k_film_lanes over [lane][sample].
+    // k_film_lanes' wavefronts are few and long (81 per 64 tiles, each the serial replay of 64 pixel runs: ~6 ms at 512 spp however few
+    // there are), so shards of fewer than 7 x 64 tiles keep the group kernel: 255 tiles (a rank's eighth of a 1080p frame) 4.1 ms by
+    // k_film_quads against 6.1, 510 tiles 7.1 against 6.65, 1 020 tiles 12.9 against 10.2 (gpurun q10)
+    int film_lanes = rec16 && c->classes.reach <= 2 && n_tiles >= 448u && !ropt.get("MIW_FILM_COLUMNS") && !ropt.get("MIW_FILM_GROUP") && !ropt.get("MIW_FILM_QUADS") ? 1 : 0;
+    if (const char *e = ropt.get("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
+    const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
+    const size_t log_entries = log_il ? log_capacity(log_il, n_tiles, bs2, std::max<uint32_t>(cfg->spp, 1)) : log_lanes_entries;
+    const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
+    if (film_mode != 2) {
+        size_t need = log_entries * rec_bytes;
+        size_t have = c->q_log_pos.n * sizeof(F2) + c->q_log_val.n * sizeof(F4) + c->q_log_rec.n * sizeof(U4), free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        bool fits = need <= (size_t) ((double) (free_b + have) * 0.8);
+        if (!fits) {
+            if (film_mode == 1) return fail(c, MI_ERR_INVALID, "render: sample log needs %zu MiB, only %zu MiB free", need >> 20, free_b >> 20);
+            film_mode = 2; rec16 = false;
+        } else film_mode = 1;
+    }
+    if (film_mode == 1) {
+        if (rec16) {
+            if (c->q_log_rec.n < log_entries) { c->q_log_rec.release(); c->q_log_pos.release(); c->q_log_val.release(); }
+            HIP_TRY(c, c->q_log_rec.resize(log_entries));
+        } else {
+            if (c->q_log_pos.n < log_entries) { c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); }
+            HIP_TRY(c, c->q_log_pos.resize(log_entries)); HIP_TRY(c, c->q_log_val.resize(log_entries));
+        }
+    } else {
+        HIP_TRY(c, c->d_accum.resize(film_n));
+        HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
+    }
+#if defined(MIW_DEBUG_POISON)
+    // Debug tier (-DMIW_DEBUG_POISON=1 builds; the reference poisons its GPU interactions in debug builds the same way,
+    // src/librender/scene_optix.inl:475-480): every buffer a render kernel is supposed to WRITE before anything reads it starts as
+    // NaN bit patterns (0xff bytes) — the sample log, plan 1's queues, the block tiles — and mi_render fails when a NaN reaches the film.
+    // A slot that is read without having been written (an indexing error, a lane that skipped its log write) then shows up as
+    // MI_ERR_STATE instead of as a plausible-looking stale value from the previous frame.
+    {
+        auto poison = [&](void *p, size_t bytes) -> hipError_t { return p && bytes ? hipMemsetAsync(p, 0xff, bytes, s) : hipSuccess; };
+        HIP_TRY(c, poison(c->q_log_rec.p, c->q_log_rec.n * sizeof(U4))); HIP_TRY(c, poison(c->q_log_pos.p, c->q_log_pos.n * sizeof(F2))); HIP_TRY(c, poison(c->q_log_val.p, c->q_log_val.n * sizeof(F4)));
+        if (plan == 1) for (DevBuf<F4> *q : { &c->q_tp, &c->q_res, &c->q_ray_o, &c->q_ray_d, &c->q_hit, &c->q_sh_d, &c->q_sh_c }) HIP_TRY(c, poison(q->p, q->n * sizeof(F4)));
+        HIP_TRY(c, poison(c->d_tiles.p, c->d_tiles.n * sizeof(float)));
+    }
+#endif
+    c->counters.log_bytes = film_mode == 1 ? (uint64_t) log_entries * rec_bytes : 0u;
+    c->counters.log_record_bytes = film_mode == 1 ? (uint32_t) rec_bytes : 0u;
+    c->counters.film_kernel = 0u; c->counters.log_interleaved = film_mode == 1 && rec16 && log_il ? 1u : 0u;
+    c->counters.film_mode = (uint32_t) film_mode;
+    FP.film_mode = film_mode; FP.rec16 = rec16; FP.film_lanes = film_lanes; FP.log_il = log_il; FP.log_entries = log_entries; FP.rec_bytes = rec_bytes;
+    return MI_OK;
+}
+
+// ---- mi_render, debug builds: what the instrumented kernels counted (printed when the option MIW_DEBUG is set) ----
+static void print_debug_statistics(mi_ctx *c, const Options &ropt, mi_counters &K) {
+    (void) c; (void) ropt; (void) K;
+#if defined(MIW_VERIFY_FILTER)
+        {
+            unsigned int n = 0; float buf[256];
+            (void) hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_verify_n), sizeof n);
+            (void) hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_verify), sizeof buf);
+            fprintf(stderr, "[miwave] filter verification: %u mismatching queries\n", n);
+            for (unsigned i = 0; i < n && i < 16; ++i) {
+                const float *r = buf + i * 16; uint32_t a, b; memcpy(&a, r + 9, 4); memcpy(&b, r + 10, 4);
+                fprintf(stderr, "  kind %g o=(%.9g %.9g %.9g) mint=%.9g d=(%.9g %.9g %.9g) maxt=%.9g brute=%u filter=%u t_brute=%.9g t_filter=%.9g\n",
+                        r[8], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], a, b, r[11], r[12]);
+            }
+            n = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_verify_n), &n, sizeof n);
+        }
+#endif
+#if defined(MIW_PHASE_STATS)
+        if (ropt.get("MIW_DEBUG")) {
+            unsigned long long ps[15];
+            if (!K.pooled && hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
+                static const char *names[5] = { "node step", "triangle test", "walk end", "shade", "vote" };
+                unsigned long long tot = 0;
+                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
+                for (int k = 0; k < 5; ++k)
+                    fprintf(stderr, "[miwave] phase %-13s runs/segment %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
+                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
+                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
+                memset(ps, 0, sizeof ps);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), ps, sizeof ps);
+            }
+        }
+#endif
+#if defined(MIW_PHASE_STATS) && !MIW_SPECTRAL
+        if (ropt.get("MIW_DEBUG") && K.pooled) {
+            unsigned long long ps[32];
+            if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pool_stats), sizeof ps) == hipSuccess) {
+                static const char *names[5] = { "vote", "node trip", "triangle trip", "shade", "idle" };
+                unsigned long long tot = 0;
+                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
+                for (int k = 0; k < 5; ++k)
+                    fprintf(stderr, "[miwave] pooled %-13s runs per 64 segments %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
+                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
+                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
+                fprintf(stderr, "[miwave] pooled claims: %.2f tried per segment, %.1f %% won\n", (double) ps[15] / std::max<double>((double) K.segments, 1), 100.0 * (double) ps[16] / std::max<double>((double) ps[15], 1));
+                memset(ps, 0, sizeof ps);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), ps, sizeof ps);
+            }
+        }
+#endif
+#if defined(MIW_WALK_STATS)
+        if (ropt.get("MIW_DEBUG")) {
+            unsigned long long st[8]; float stf[8];
+            if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_walk_stats), sizeof st) == hipSuccess && hipMemcpyFromSymbol(stf, HIP_SYMBOL(g_walk_statsf), sizeof stf) == hipSuccess) {
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned long long *a = st + 4 * k; const float *f = stf + 4 * k;
+                    fprintf(stderr, "[miwave] walk stats %s: rays %llu, node steps/ray %.2f (SIMT eff %.3f), triangle tests/ray %.2f (SIMT eff %.3f)\n",
+                            k ? "any-hit" : "closest", a[2], (double) a[0] / std::max<double>(a[2], 1), (double) a[0] / (64.0 * std::max(f[0], 1.f)),
+                            (double) a[1] / std::max<double>(a[2], 1), (double) a[1] / (64.0 * std::max(f[1], 1.f)));
+                }
+                memset(st, 0, sizeof st); memset(stf, 0, sizeof stf);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), st, sizeof st); (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_statsf), stf, sizeof stf);
+            }
+        }
+#endif
+#if defined(MIW_SECTION_PROFILE)
+        if (ropt.get("MIW_DEBUG")) {
+            unsigned long long sec[16];
+            if (hipMemcpyFromSymbol(sec, HIP_SYMBOL(g_sections), sizeof sec) == hipSuccess) {
+                static const char *names[13] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin",
+                                                 "walks + votes", "shade: surface interaction", "shade: emitter hit + MIS", "shade: RR + emitter sampling + bsdf eval",
+                                                 "shade: bsdf sample", "shade: finish + next sample", "shade: pixel fetch + walk start" };
+                unsigned long long tot = 0;
+                for (int i = 0; i < 13; ++i) tot += sec[i];
+                for (int i = 0; i < 13; ++i) if (sec[i]) fprintf(stderr, "[miwave] section %-40s %6.2f %%\n", names[i], 100.0 * (double) sec[i] / (double) std::max<unsigned long long>(tot, 1));
+                memset(sec, 0, sizeof sec);
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_sections), sec, sizeof sec);
+            }
+        }
+#endif
+}
+
+// ---- mi_render, phase "film": the ordered replay of the sample log into block tiles (device/film_kernels.h; which kernel: the log
+// format, the shard's tile count, the options) + the merge of the tiles into the film, or the resolve of the float64 sums ----
+static mi_status assemble_film(mi_ctx *c, const mi_render_cfg *cfg, const Options &ropt, const RenderParams &P, hipStream_t s, LaunchTimer &T, const FilmPlan &FP,
+                               uint32_t n_tiles, uint32_t bs, uint32_t bs2_log2, uint32_t blocks_x, uint32_t blocks_y, size_t film_n, void *film, mi_status result) {
+    const int film_mode = FP.film_mode; const bool rec16 = FP.rec16; const int film_lanes = FP.film_lanes; const uint32_t log_il = FP.log_il;
+    (void) result;
+#define MIW_TIMED(cls_, launch) do {                                                   \
+        size_t e0_ = 0, e1_ = 0;                                                       \
+        if (T.on) { HIP_TRY(c, T.get_event(e0_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e0_], s)); } \
+        launch;                                                                        \
+        if (T.on) { HIP_TRY(c, T.get_event(e1_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e1_], s)); \
+                    T.stamps.push_back({ cls_, e0_, e1_ }); }                          \
+    } while (0)
+    {
+        const size_t elem = cfg->film_f64 ? sizeof(double) : sizeof(float);
+        void *dst = film;
+        const bool staged = !cfg->film_on_device;
+        if (staged) {
+            HIP_TRY(c, c->d_out.resize(film_n * elem)); dst = c->d_out.p;
+            if (cfg->accumulate) HIP_TRY(c, hipMemcpyAsync(c->d_out.p, film, film_n * elem, hipMemcpyHostToDevice, s));
+        }
+        float *dst32 = cfg->film_f64 ? nullptr : (float *) dst;
+        double *dst64 = cfg->film_f64 ? (double *) dst : nullptr;
+        if (film_mode == 1) {
+            // block -> tile map of this shard
+            std::vector<int32_t> block_tile(cfg->block_count, -1);
+            for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
+            HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
+            HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            BlockReplayArgs A;
+            A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
+            A.log_rec = rec16 ? c->q_log_rec.p : nullptr; A.log_il = rec16 ? log_il : 0u;
+            A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
+            A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
+            A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
+            A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
+            const uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
+            A.tile_stride = side * side * MIW_FILM_CHANNELS;
+            HIP_TRY(c, c->d_tiles.resize((size_t) std::max<uint32_t>(n_tiles, 1) * A.tile_stride));
+            if (n_tiles) {
+                PatchArgs PA;
+                PA.patches_x = PA.patches_y = (side + MIW_FP_SIDE - 1) / MIW_FP_SIDE;
+                PA.reach = (int32_t) floorf(cfg->filter_radius + .5f);
+                const dim3 fgrid(n_tiles * PA.patches_x * PA.patches_y);
+                const bool wide = cfg->filter_radius > 0.5f + MIW_RAY_EPSILON;
+                if (rec16) {
+                    // 16-byte class records -> per-group pixel lists (k_film_groups). Group shape: 2x2 reads 6.25 sample rows per texel,
+                    // 4x4 3.06 but spends 0.77 wave-iterations per sample; 4x2 (4.4 rows, 0.55) balances HBM reads against issue slots.
+                    // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4).
+                    int group = 3;
+                    if (const char *e = ropt.get("MIW_FILM_GROUP")) group = atoi(e);
+                    const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
+#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
+                    // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups;
+                    // round 5 measured 2 x 4 and 2 x 2 groups as well: 27.6 / 27.5 ms against 25.6 at C2, gpurun r5p — not kept)
+#define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
+                                   const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
+                                   MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
+                    // round 5: groups of 4 x 2 (2 x 4: MIW_FILM_QUADS = 24) texels inside DPP quads, the records broadcast by quad_perm operands instead of
+                    // staged through LDS (k_film_quads; MIW_FILM_QUADS = 24 / 28 / 44: other group shapes, = 0: the kernels below — also taken when a tile
+                    // has fewer groups than a wavefront takes, i.e. tiny blocks)
+                    int columns = 42;
+                    if (const char *e = ropt.get("MIW_FILM_COLUMNS")) columns = atoi(e);
+                    // (what runs here by default are shards of fewer than 448 tiles — k_film_lanes takes the rest —: 4 x 2 groups, twice as many and half as
+                    // long wavefronts as 2 x 4: a rank's eighth of a 1080p frame 3.63 ms against 4.13, k_film_columns 4.19, gpurun q11; a whole frame 24.1 / 23.8)
+                    int quads = ropt.get("MIW_FILM_COLUMNS") == nullptr && ropt.get("MIW_FILM_GROUP") == nullptr ? 42 : 0;
+                    if (const char *e = ropt.get("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 42 : atoi(e);
+                    if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
+                    const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
+                    if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
+                    // round 5, the default: one 4 x 4 texel block per lane, a wavefront = one block position in 64 tiles, the sample loop specialised
+                    // for the rows / column pairs a pixel's footprint covers (k_film_lanes; MIW_FILM_LANES = 0: the kernels below)
+                    const bool lanes = film_lanes != 0;
+                    c->counters.film_kernel = lanes ? 4u : quads ? 3u : (columns == 42 || columns == 44 || columns == 82) ? 2u : 1u;   // (mi_counters)
+                    if (lanes) {
+                        PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
+                        const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
+                        const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
+                        int fl_nt = 1;                                    // the log read with streaming loads (16.8 vs 17.05 ms at C2, gpurun q9); MIW_FL_NT = 0: plain loads
+                        if (const char *e = ropt.get("MIW_FL_NT")) fl_nt = atoi(e);
+                        if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                    } else if (quads) {
+                        PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
+                        const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);
+                        const size_t qbytes = (size_t) (c->classes.count + 1u) * (size_t) (5u + 2u * qh) * sizeof(float);
+#define MIW_FQ_LAUNCH(GW, GH, U) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH, U>), dim3(waves), dim3(64), qbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p))
+                        int fq_u = 4;
+                        if (const char *e = ropt.get("MIW_FQ_U")) fq_u = atoi(e);
+                        if (quads == 24) { if (fq_u == 8) MIW_FQ_LAUNCH(2, 4, 8); else if (fq_u == 2) MIW_FQ_LAUNCH(2, 4, 2); else MIW_FQ_LAUNCH(2, 4, 4); }
+                        else if (quads == 42) { if (fq_u == 8) MIW_FQ_LAUNCH(4, 2, 8); else MIW_FQ_LAUNCH(4, 2, 4); }
+                        else if (quads == 28) MIW_FQ_LAUNCH(2, 8, 4); else MIW_FQ_LAUNCH(4, 4, 4);
+#undef MIW_FQ_LAUNCH
+                    } else if (columns == 42) MIW_FC_LAUNCH(4, 2); else if (columns == 44) MIW_FC_LAUNCH(4, 4); else if (columns == 82) MIW_FC_LAUNCH(8, 2);
+                    else if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
+#undef MIW_FC_LAUNCH
+#undef MIW_FG_LAUNCH
+                } else if (wide)
+                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
+                else
+                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<false>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
+            }
+            MIW_TIMED(5, hipLaunchKernelGGL(k_film_merge, dim3(((uint32_t) cfg->crop_w + 255u) / 256u, (uint32_t) cfg->crop_h), dim3(256), 0, s,
+                                            P.film, A, c->d_tiles.p, dst32, dst64, cfg->accumulate));
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(s));            // block_tile (host vector) must outlive the copy
+        } else {
+            dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
+            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, dst32, dst64, film_n, cfg->accumulate));
+        }
+        if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_out.p, film_n * elem, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));
+        T.drain();
+#if defined(MIW_DEBUG_POISON)
+        if (result == MI_OK) {                                    // (a cancelled render leaves unwritten slots by design)
+            std::vector<unsigned char> host(film_n * elem);
+            HIP_TRY(c, hipMemcpy(host.data(), dst, film_n * elem, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < film_n; ++i) bad += cfg->film_f64 ? std::isnan(((const double *) host.data())[i]) : std::isnan(((const float *) host.data())[i]);
+            if (bad) return fail(c, MI_ERR_STATE, "render (poisoned build): %zu film values are NaN - a log / queue / tile slot was read before it was written", bad);
+        }
+#endif
+    }
+#undef MIW_TIMED
+    return MI_OK;
+}
+
 mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     if (!c || !cfg || !film) return MI_ERR_INVALID;
     if (!c->have_bvh) return fail(c, MI_ERR_STATE, "mi_render: call mi_scene_upload and mi_bvh_build first");
@@ -1243,76 +1569,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     HIP_TRY(c, c->d_cnt.resize(MIW_CNT_SHARDS));
     HIP_TRY(c, hipMemsetAsync(c->d_cnt.p, 0, sizeof(Counters) * MIW_CNT_SHARDS, s));
 
-    // film mode: sample log + ordered gather if the log fits, else float64 atomics
-    int film_mode = cfg->film_mode;
-    if (film_mode < 0 || film_mode > 2) return fail(c, MI_ERR_INVALID, "render: film_mode must be 0, 1 or 2");
-    const size_t log_lanes_entries = (size_t) nl * std::max<uint32_t>(cfg->spp, 1);
-    // The log format: 16-byte records with phase classes where the host enumeration covers the filter (film_classes.h: box, tent,
-    // gaussian, mitchell, catmullrom), positions + values (24 bytes) otherwise. MIW_FILM_LEGACY=1 forces the latter (A/B runs).
-    bool rec16 = false;
-    if (film_mode != 2 && bs2 <= 65536u && !ropt.get("MIW_FILM_LEGACY")) {
-        // the cache key: the filter's fields only, in a zero-filled record (padding bytes of a stack copy would make memcmp miss)
-        FilmRec key; memset(&key, 0, sizeof key);
-        key.border = P.film.border; key.radius = P.film.radius; key.scale_factor = P.film.scale_factor; memcpy(key.lut, P.film.lut, sizeof key.lut);
-        // (a filter the enumeration refuses is remembered as well — classes_valid — instead of being enumerated again by every render)
-        if (!c->classes_valid || memcmp(&key, &c->classes_of, sizeof key) != 0 || (c->classes.ok && !c->d_fc_thr.p)) {
-            c->classes = film_classes_build(P.film);             // ~30 ms, once per filter
-            c->classes_of = key; c->classes_valid = true;
-            if (c->classes.ok) { HIP_TRY(c, c->d_fc_thr.upload(c->classes.thr, s)); HIP_TRY(c, c->d_fc_w.upload(c->classes.w, s)); HIP_TRY(c, hipStreamSynchronize(s)); }
-        }
-        rec16 = c->classes.ok;
-    }
-    // The replay kernel for the 16-byte records (device/film_kernels.h): k_film_lanes — one 4 x 4 texel block per lane, a wavefront = one
-    // block position in 64 consecutive tiles — wants those tiles' logs interleaved record by record (path.h: log_index), so the
-    // choice is made before the render kernels write the log. MIW_FILM_LANES = 0, or naming another kernel's shape
-    // (MIW_FILM_QUADS / _COLUMNS / _GROUP), keeps [lane][sample] and the group kernels; MIW_FILM_LANES = 2: k_film_lanes over [lane][sample].
-    // k_film_lanes' wavefronts are few and long (81 per 64 tiles, each the serial replay of 64 pixel runs: ~6 ms at 512 spp however few
-    // there are), so shards of fewer than 7 x 64 tiles keep the group kernel: 255 tiles (a rank's eighth of a 1080p frame) 4.1 ms by
-    // k_film_quads against 6.1, 510 tiles 7.1 against 6.65, 1 020 tiles 12.9 against 10.2 (gpurun q10)
-    int film_lanes = rec16 && c->classes.reach <= 2 && n_tiles >= 448u && !ropt.get("MIW_FILM_COLUMNS") && !ropt.get("MIW_FILM_GROUP") && !ropt.get("MIW_FILM_QUADS") ? 1 : 0;
-    if (const char *e = ropt.get("MIW_FILM_LANES")) film_lanes = rec16 && c->classes.reach <= 2 ? atoi(e) : 0;
-    const uint32_t log_il = film_lanes == 1 ? bs2_log2 + 1u : 0u;
-    const size_t log_entries = log_il ? log_capacity(log_il, n_tiles, bs2, std::max<uint32_t>(cfg->spp, 1)) : log_lanes_entries;
-    const size_t rec_bytes = rec16 ? sizeof(U4) : sizeof(F2) + sizeof(F4);
-    if (film_mode != 2) {
-        size_t need = log_entries * rec_bytes;
-        size_t have = c->q_log_pos.n * sizeof(F2) + c->q_log_val.n * sizeof(F4) + c->q_log_rec.n * sizeof(U4), free_b = 0, total_b = 0;
-        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
-        bool fits = need <= (size_t) ((double) (free_b + have) * 0.8);
-        if (!fits) {
-            if (film_mode == 1) return fail(c, MI_ERR_INVALID, "render: sample log needs %zu MiB, only %zu MiB free", need >> 20, free_b >> 20);
-            film_mode = 2; rec16 = false;
-        } else film_mode = 1;
-    }
-    if (film_mode == 1) {
-        if (rec16) {
-            if (c->q_log_rec.n < log_entries) { c->q_log_rec.release(); c->q_log_pos.release(); c->q_log_val.release(); }
-            HIP_TRY(c, c->q_log_rec.resize(log_entries));
-        } else {
-            if (c->q_log_pos.n < log_entries) { c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); }
-            HIP_TRY(c, c->q_log_pos.resize(log_entries)); HIP_TRY(c, c->q_log_val.resize(log_entries));
-        }
-    } else {
-        HIP_TRY(c, c->d_accum.resize(film_n));
-        HIP_TRY(c, hipMemsetAsync(c->d_accum.p, 0, film_n * sizeof(double), s));
-    }
-#if defined(MIW_DEBUG_POISON)
-    // Debug tier (-DMIW_DEBUG_POISON=1 builds; the reference poisons its GPU interactions in debug builds the same way,
-    // src/librender/scene_optix.inl:475-480): every buffer a render kernel is supposed to WRITE before anything reads it starts as
-    // NaN bit patterns (0xff bytes) — the sample log, plan 1's queues, the block tiles — and mi_render fails when a NaN reaches the film.
-    // A slot that is read without having been written (an indexing error, a lane that skipped its log write) then shows up as
-    // MI_ERR_STATE instead of as a plausible-looking stale value from the previous frame.
-    {
-        auto poison = [&](void *p, size_t bytes) -> hipError_t { return p && bytes ? hipMemsetAsync(p, 0xff, bytes, s) : hipSuccess; };
-        HIP_TRY(c, poison(c->q_log_rec.p, c->q_log_rec.n * sizeof(U4))); HIP_TRY(c, poison(c->q_log_pos.p, c->q_log_pos.n * sizeof(F2))); HIP_TRY(c, poison(c->q_log_val.p, c->q_log_val.n * sizeof(F4)));
-        if (plan == 1) for (DevBuf<F4> *q : { &c->q_tp, &c->q_res, &c->q_ray_o, &c->q_ray_d, &c->q_hit, &c->q_sh_d, &c->q_sh_c }) HIP_TRY(c, poison(q->p, q->n * sizeof(F4)));
-        HIP_TRY(c, poison(c->d_tiles.p, c->d_tiles.n * sizeof(float)));
-    }
-#endif
-    c->counters.log_bytes = film_mode == 1 ? (uint64_t) log_entries * rec_bytes : 0u;
-    c->counters.log_record_bytes = film_mode == 1 ? (uint32_t) rec_bytes : 0u;
-    c->counters.film_kernel = 0u; c->counters.log_interleaved = film_mode == 1 && rec16 && log_il ? 1u : 0u;
-    c->counters.film_mode = (uint32_t) film_mode;
+    // film mode: sample log + ordered gather if the log fits, else float64 atomics; the log's format and layout follow the replay kernel
+    FilmPlan FP;
+    { const mi_status fs = plan_film_log(c, cfg, ropt, P, s, plan, n_tiles, n_lanes, bs2, bs2_log2, film_n, FP); if (fs != MI_OK) return fs; }
+    const int film_mode = FP.film_mode; const bool rec16 = FP.rec16; const int film_lanes = FP.film_lanes; const uint32_t log_il = FP.log_il;
     HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
     HIP_TRY(c, hipMemcpyAsync(c->d_block_ids.p, cfg->block_ids, cfg->block_count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (cfg->tile_list && n_tiles) {
@@ -1408,42 +1668,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
     K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
 
-    // event pool for per-launch timing
-    struct Stamp { int cls; size_t e0, e1; };
-    std::vector<Stamp> stamps;
-    size_t ev_used = 0;
-    auto get_event = [&](size_t &idx) -> hipError_t {
-        if (ev_used == c->ev_pool.size()) {
-            hipEvent_t e; hipError_t r = hipEventCreate(&e);
-            if (r != hipSuccess) return r;
-            c->ev_pool.push_back(e);
-        }
-        idx = ev_used++;
-        return hipSuccess;
-    };
-    auto drain_stamps = [&]() {
-        for (const Stamp &t : stamps) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev_pool[t.e0], c->ev_pool[t.e1]) != hipSuccess) continue;
-            switch (t.cls) {
-                case 0: K.ms_trace_closest += ms; break;
-                case 1: K.ms_trace_any += ms; break;
-                case 2: K.ms_shade += ms; break;
-                case 3: K.ms_init += ms; break;
-                case 6: K.ms_path += ms; break;
-                case 4: K.ms_film_blocks += ms; K.ms_resolve += ms; break;
-                case 5: K.ms_film_merge += ms; K.ms_resolve += ms; break;
-                default: K.ms_resolve += ms; break;
-            }
-        }
-        stamps.clear(); ev_used = 0;
-    };
+    LaunchTimer T{ c, K, cfg->profile != 0 };                    // HIP-event time per launch class (mi_counters::ms_*)
 #define MIW_TIMED(cls_, launch) do {                                                   \
         size_t e0_ = 0, e1_ = 0;                                                       \
-        if (cfg->profile) { HIP_TRY(c, get_event(e0_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e0_], s)); } \
+        if (T.on) { HIP_TRY(c, T.get_event(e0_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e0_], s)); } \
         launch;                                                                        \
-        if (cfg->profile) { HIP_TRY(c, get_event(e1_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e1_], s)); \
-                            stamps.push_back({ cls_, e0_, e1_ }); }                    \
+        if (T.on) { HIP_TRY(c, T.get_event(e1_)); HIP_TRY(c, hipEventRecord(c->ev_pool[e1_], s)); \
+                    T.stamps.push_back({ cls_, e0_, e1_ }); }                          \
     } while (0)
 
     mi_status result = MI_OK;
@@ -1718,7 +1949,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             if ((++launches % sync_every == 0 || cfg->timeout_s > 0.f || c->cancel.load()) && done < cfg->spp) {
                 HIP_TRY(c, hipGetLastError());
                 HIP_TRY(c, hipStreamSynchronize(s));
-                if (cfg->profile) drain_stamps();
+                T.drain();
                 if (c->cancel.load() || out_of_time()) { result = MI_ERR_CANCELLED; break; }
             }
         }
@@ -1739,84 +1970,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             fprintf(stderr, "[miwave] placed queues: %u SIMDs numbered, %u distinct hardware keys (bits used 0x%x), %u of %u queues drained (%u asked beyond their end), "
                             "cost of the dearest pixel of a piece min / mean / max = %u / %.0f / %u (iterations, or 256-cycle units)\n", ids[0], keys, key_or, full, n_simd, over, cmin, (double) csum / n_pieces, cmax);
         }
-#if defined(MIW_VERIFY_FILTER)
-        {
-            unsigned int n = 0; float buf[256];
-            (void) hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_verify_n), sizeof n);
-            (void) hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_verify), sizeof buf);
-            fprintf(stderr, "[miwave] filter verification: %u mismatching queries\n", n);
-            for (unsigned i = 0; i < n && i < 16; ++i) {
-                const float *r = buf + i * 16; uint32_t a, b; memcpy(&a, r + 9, 4); memcpy(&b, r + 10, 4);
-                fprintf(stderr, "  kind %g o=(%.9g %.9g %.9g) mint=%.9g d=(%.9g %.9g %.9g) maxt=%.9g brute=%u filter=%u t_brute=%.9g t_filter=%.9g\n",
-                        r[8], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], a, b, r[11], r[12]);
-            }
-            n = 0; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_verify_n), &n, sizeof n);
-        }
-#endif
-#if defined(MIW_PHASE_STATS)
-        if (ropt.get("MIW_DEBUG")) {
-            unsigned long long ps[15];
-            if (!K.pooled && hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_phase_stats), sizeof ps) == hipSuccess) {
-                static const char *names[5] = { "node step", "triangle test", "walk end", "shade", "vote" };
-                unsigned long long tot = 0;
-                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
-                for (int k = 0; k < 5; ++k)
-                    fprintf(stderr, "[miwave] phase %-13s runs/segment %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
-                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
-                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
-                memset(ps, 0, sizeof ps);
-                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stats), ps, sizeof ps);
-            }
-        }
-#endif
-#if defined(MIW_PHASE_STATS) && !MIW_SPECTRAL
-        if (ropt.get("MIW_DEBUG") && K.pooled) {
-            unsigned long long ps[32];
-            if (hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pool_stats), sizeof ps) == hipSuccess) {
-                static const char *names[5] = { "vote", "node trip", "triangle trip", "shade", "idle" };
-                unsigned long long tot = 0;
-                for (int k = 0; k < 5; ++k) tot += ps[10 + k];
-                for (int k = 0; k < 5; ++k)
-                    fprintf(stderr, "[miwave] pooled %-13s runs per 64 segments %7.2f  lanes/run %5.1f  cycles/run %7.0f  share of wave cycles %5.1f %%\n", names[k],
-                            64.0 * (double) ps[k] / std::max<double>((double) K.segments, 1), (double) ps[5 + k] / std::max<double>((double) ps[k], 1),
-                            (double) ps[10 + k] / std::max<double>((double) ps[k], 1), 100.0 * (double) ps[10 + k] / std::max<double>((double) tot, 1));
-                fprintf(stderr, "[miwave] pooled claims: %.2f tried per segment, %.1f %% won\n", (double) ps[15] / std::max<double>((double) K.segments, 1), 100.0 * (double) ps[16] / std::max<double>((double) ps[15], 1));
-                memset(ps, 0, sizeof ps);
-                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), ps, sizeof ps);
-            }
-        }
-#endif
-#if defined(MIW_WALK_STATS)
-        if (ropt.get("MIW_DEBUG")) {
-            unsigned long long st[8]; float stf[8];
-            if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_walk_stats), sizeof st) == hipSuccess && hipMemcpyFromSymbol(stf, HIP_SYMBOL(g_walk_statsf), sizeof stf) == hipSuccess) {
-                for (int k = 0; k < 2; ++k) {
-                    const unsigned long long *a = st + 4 * k; const float *f = stf + 4 * k;
-                    fprintf(stderr, "[miwave] walk stats %s: rays %llu, node steps/ray %.2f (SIMT eff %.3f), triangle tests/ray %.2f (SIMT eff %.3f)\n",
-                            k ? "any-hit" : "closest", a[2], (double) a[0] / std::max<double>(a[2], 1), (double) a[0] / (64.0 * std::max(f[0], 1.f)),
-                            (double) a[1] / std::max<double>(a[2], 1), (double) a[1] / (64.0 * std::max(f[1], 1.f)));
-                }
-                memset(st, 0, sizeof st); memset(stf, 0, sizeof stf);
-                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), st, sizeof st); (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_statsf), stf, sizeof stf);
-            }
-        }
-#endif
-#if defined(MIW_SECTION_PROFILE)
-        if (ropt.get("MIW_DEBUG")) {
-            unsigned long long sec[16];
-            if (hipMemcpyFromSymbol(sec, HIP_SYMBOL(g_sections), sizeof sec) == hipSuccess) {
-                static const char *names[13] = { "fetch/begin", "leaf boxes", "E candidates", "S candidates", "path_step", "finish+begin",
-                                                 "walks + votes", "shade: surface interaction", "shade: emitter hit + MIS", "shade: RR + emitter sampling + bsdf eval",
-                                                 "shade: bsdf sample", "shade: finish + next sample", "shade: pixel fetch + walk start" };
-                unsigned long long tot = 0;
-                for (int i = 0; i < 13; ++i) tot += sec[i];
-                for (int i = 0; i < 13; ++i) if (sec[i]) fprintf(stderr, "[miwave] section %-40s %6.2f %%\n", names[i], 100.0 * (double) sec[i] / (double) std::max<unsigned long long>(tot, 1));
-                memset(sec, 0, sizeof sec);
-                (void) hipMemcpyToSymbol(HIP_SYMBOL(g_sections), sec, sizeof sec);
-            }
-        }
-#endif
-        if (cfg->profile) drain_stamps();
+        print_debug_statistics(c, ropt, K);                      // (debug builds only: -DMIW_PHASE_STATS / _WALK_STATS / _SECTION_PROFILE / _VERIFY_FILTER)
+        T.drain();
     }
 #if !MIW_SPECTRAL
     else if (n_lanes > 0) {
@@ -1877,7 +2032,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             Counters sum;
             mi_status rs = read_counters(sum);
             if (rs != MI_OK) return rs;
-            if (cfg->profile) drain_stamps();
+            T.drain();
             // active_lanes accumulates over the counting launches: the last one's share is the delta
             unsigned long long active_now = sum.active_lanes - active_prev;
             active_prev = sum.active_lanes;
@@ -1889,117 +2044,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #endif
 
     // film assembly -> caller's buffer (device pointer, or staged through d_out for a host pointer)
-    {
-        const size_t elem = cfg->film_f64 ? sizeof(double) : sizeof(float);
-        void *dst = film;
-        const bool staged = !cfg->film_on_device;
-        if (staged) {
-            HIP_TRY(c, c->d_out.resize(film_n * elem)); dst = c->d_out.p;
-            if (cfg->accumulate) HIP_TRY(c, hipMemcpyAsync(c->d_out.p, film, film_n * elem, hipMemcpyHostToDevice, s));
-        }
-        float *dst32 = cfg->film_f64 ? nullptr : (float *) dst;
-        double *dst64 = cfg->film_f64 ? (double *) dst : nullptr;
-        if (film_mode == 1) {
-            // block -> tile map of this shard
-            std::vector<int32_t> block_tile(cfg->block_count, -1);
-            for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
-            HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
-            HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            BlockReplayArgs A;
-            A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
-            A.log_rec = rec16 ? c->q_log_rec.p : nullptr; A.log_il = rec16 ? log_il : 0u;
-            A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
-            A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
-            A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
-            A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
-            const uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
-            A.tile_stride = side * side * MIW_FILM_CHANNELS;
-            HIP_TRY(c, c->d_tiles.resize((size_t) std::max<uint32_t>(n_tiles, 1) * A.tile_stride));
-            if (n_tiles) {
-                PatchArgs PA;
-                PA.patches_x = PA.patches_y = (side + MIW_FP_SIDE - 1) / MIW_FP_SIDE;
-                PA.reach = (int32_t) floorf(cfg->filter_radius + .5f);
-                const dim3 fgrid(n_tiles * PA.patches_x * PA.patches_y);
-                const bool wide = cfg->filter_radius > 0.5f + MIW_RAY_EPSILON;
-                if (rec16) {
-                    // 16-byte class records -> per-group pixel lists (k_film_groups). Group shape: 2x2 reads 6.25 sample rows per texel,
-                    // 4x4 3.06 but spends 0.77 wave-iterations per sample; 4x2 (4.4 rows, 0.55) balances HBM reads against issue slots.
-                    // MIW_FILM_GROUP = 2 | 3 | 4 overrides (2x2 / 4x2 / 4x4).
-                    int group = 3;
-                    if (const char *e = ropt.get("MIW_FILM_GROUP")) group = atoi(e);
-                    const size_t wbytes = (size_t) (c->classes.count + 1u) * MIW_FG_WSTRIDE * sizeof(float);
-#define MIW_FG_LAUNCH(GW, GH) MIW_TIMED(4, hipLaunchKernelGGL((k_film_groups<GW, GH>), fgrid, dim3(64), wbytes, s, P.film, A, PA, c->d_tiles.p))
-                    // round 4: a column of GH texels per lane (k_film_columns; MIW_FILM_COLUMNS = 0: the one-texel-per-lane kernel, 42 / 44: 4 x 2 / 4 x 4 groups;
-                    // round 5 measured 2 x 4 and 2 x 2 groups as well: 27.6 / 27.5 ms against 25.6 at C2, gpurun r5p — not kept)
-#define MIW_FC_LAUNCH(GW, GH) do { PatchArgs PC = PA; PC.patches_x = (side + (GW) - 1) / (GW); PC.patches_y = (side + (GH) - 1) / (GH); \
-                                   const uint32_t per_wave = 64u / (GW), wpt = (PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave; \
-                                   MIW_TIMED(4, hipLaunchKernelGGL((k_film_columns<GW, GH>), dim3(n_tiles * wpt), dim3(64), wbytes, s, P.film, A, PC, c->d_tiles.p)); } while (0)
-                    // round 5: groups of 4 x 2 (2 x 4: MIW_FILM_QUADS = 24) texels inside DPP quads, the records broadcast by quad_perm operands instead of
-                    // staged through LDS (k_film_quads; MIW_FILM_QUADS = 24 / 28 / 44: other group shapes, = 0: the kernels below — also taken when a tile
-                    // has fewer groups than a wavefront takes, i.e. tiny blocks)
-                    int columns = 42;
-                    if (const char *e = ropt.get("MIW_FILM_COLUMNS")) columns = atoi(e);
-                    // (what runs here by default are shards of fewer than 448 tiles — k_film_lanes takes the rest —: 4 x 2 groups, twice as many and half as
-                    // long wavefronts as 2 x 4: a rank's eighth of a 1080p frame 3.63 ms against 4.13, k_film_columns 4.19, gpurun q11; a whole frame 24.1 / 23.8)
-                    int quads = ropt.get("MIW_FILM_COLUMNS") == nullptr && ropt.get("MIW_FILM_GROUP") == nullptr ? 42 : 0;
-                    if (const char *e = ropt.get("MIW_FILM_QUADS")) quads = atoi(e) == 1 ? 42 : atoi(e);
-                    if ((quads != 24 && quads != 42 && quads != 28 && quads != 44) || c->classes.reach > 2) quads = 0;   // (the kernel's LDS rows hold windows of <= 5 weights)
-                    const uint32_t qw = (uint32_t) quads / 10u, qh = (uint32_t) quads % 10u;
-                    if (quads && ((side + qw - 1) / qw) * ((side + qh - 1) / qh) < 64u / qw) quads = 0;
-                    // round 5, the default: one 4 x 4 texel block per lane, a wavefront = one block position in 64 tiles, the sample loop specialised
-                    // for the rows / column pairs a pixel's footprint covers (k_film_lanes; MIW_FILM_LANES = 0: the kernels below)
-                    const bool lanes = film_lanes != 0;
-                    c->counters.film_kernel = lanes ? 4u : quads ? 3u : (columns == 42 || columns == 44 || columns == 82) ? 2u : 1u;   // (mi_counters)
-                    if (lanes) {
-                        PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
-                        const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
-                        const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
-                        int fl_nt = 1;                                    // the log read with streaming loads (16.8 vs 17.05 ms at C2, gpurun q9); MIW_FL_NT = 0: plain loads
-                        if (const char *e = ropt.get("MIW_FL_NT")) fl_nt = atoi(e);
-                        if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
-                        else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
-                    } else if (quads) {
-                        PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
-                        const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);
-                        const size_t qbytes = (size_t) (c->classes.count + 1u) * (size_t) (5u + 2u * qh) * sizeof(float);
-#define MIW_FQ_LAUNCH(GW, GH, U) MIW_TIMED(4, hipLaunchKernelGGL((k_film_quads<GW, GH, U>), dim3(waves), dim3(64), qbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p))
-                        int fq_u = 4;
-                        if (const char *e = ropt.get("MIW_FQ_U")) fq_u = atoi(e);
-                        if (quads == 24) { if (fq_u == 8) MIW_FQ_LAUNCH(2, 4, 8); else if (fq_u == 2) MIW_FQ_LAUNCH(2, 4, 2); else MIW_FQ_LAUNCH(2, 4, 4); }
-                        else if (quads == 42) { if (fq_u == 8) MIW_FQ_LAUNCH(4, 2, 8); else MIW_FQ_LAUNCH(4, 2, 4); }
-                        else if (quads == 28) MIW_FQ_LAUNCH(2, 8, 4); else MIW_FQ_LAUNCH(4, 4, 4);
-#undef MIW_FQ_LAUNCH
-                    } else if (columns == 42) MIW_FC_LAUNCH(4, 2); else if (columns == 44) MIW_FC_LAUNCH(4, 4); else if (columns == 82) MIW_FC_LAUNCH(8, 2);
-                    else if (group == 4) MIW_FG_LAUNCH(4, 4); else if (group == 2) MIW_FG_LAUNCH(2, 2); else MIW_FG_LAUNCH(4, 2);
-#undef MIW_FC_LAUNCH
-#undef MIW_FG_LAUNCH
-                } else if (wide)
-                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<true>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
-                else
-                    MIW_TIMED(4, hipLaunchKernelGGL(k_film_blocks<false>, fgrid, dim3(64), 0, s, P.film, A, PA, c->d_tiles.p));
-            }
-            MIW_TIMED(5, hipLaunchKernelGGL(k_film_merge, dim3(((uint32_t) cfg->crop_w + 255u) / 256u, (uint32_t) cfg->crop_h), dim3(256), 0, s,
-                                            P.film, A, c->d_tiles.p, dst32, dst64, cfg->accumulate));
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipStreamSynchronize(s));            // block_tile (host vector) must outlive the copy
-        } else {
-            dim3 block(256), grid((unsigned) ((film_n + 255) / 256));
-            MIW_TIMED(4, hipLaunchKernelGGL(k_film_resolve, grid, block, 0, s, c->d_accum.p, dst32, dst64, film_n, cfg->accumulate));
-        }
-        if (staged) HIP_TRY(c, hipMemcpyAsync(film, c->d_out.p, film_n * elem, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(s));
-        if (cfg->profile) drain_stamps();
-#if defined(MIW_DEBUG_POISON)
-        if (result == MI_OK) {                                    // (a cancelled render leaves unwritten slots by design)
-            std::vector<unsigned char> host(film_n * elem);
-            HIP_TRY(c, hipMemcpy(host.data(), dst, film_n * elem, hipMemcpyDeviceToHost));
-            size_t bad = 0;
-            for (size_t i = 0; i < film_n; ++i) bad += cfg->film_f64 ? std::isnan(((const double *) host.data())[i]) : std::isnan(((const float *) host.data())[i]);
-            if (bad) return fail(c, MI_ERR_STATE, "render (poisoned build): %zu film values are NaN - a log / queue / tile slot was read before it was written", bad);
-        }
-#endif
-    }
+    { const mi_status fs = assemble_film(c, cfg, ropt, P, s, T, FP, n_tiles, bs, bs2_log2, blocks_x, blocks_y, film_n, film, result); if (fs != MI_OK) return fs; }
 #undef MIW_TIMED
     K.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (result == MI_ERR_CANCELLED) c->error = "render cancelled";

@@ -167,6 +167,23 @@ def main():
         open(path, "w").write("\n".join(out + notes) + "\n")
         traffic["scalar_rgb/%s/1920x1080@%d/plan2/film1/launch%d" % (key, spp, spp)] = traffic_entry(g, name, sha, "profiles/" + os.path.basename(path))
 
+    # ---- plan 1 (round 6): the wavefront plan with its SoA queues in HBM, the structure north_star names — its REAL queue traffic ----
+    if glob.glob(g + "_c3plan1_trace"):
+        path = os.path.join(ROOT, "profiles", "%s_c3_plan1_kernel_stats_pmc.txt" % tag)
+        out = [head, cmd % (" --scene matball --spp 64 --plan 1", tag),
+               "# plan 1 on the material balls, 1920x1080 @ 64 spp: k_init_lanes, the persistent k_trace_stream + k_sort_hits, k_shade per depth-loop iteration over", 
+               "# SoA queues of 16-byte fields in HBM (DESIGN.md section 4.3) — kernel_stats.csv verbatim", stats("c3plan1"), "", pmc_head, pmc_text(g, "c3plan1"), "",
+               "# bench line of the same session (256 spp)", bench_line(g, "bench_c3_plan1")]
+        try:
+            e = traffic_entry(g, "c3plan1", sha, "profiles/" + os.path.basename(path))
+            j = last_json(g + "_c3plan1_trace.log") or {}
+            tot = sum(v["hbm_bytes_per_launch"] * 0 + v["read_bytes"] + v["write_bytes"] for k, v in e.items() if isinstance(v, dict))
+            out += ["", "# real HBM-side bytes of the whole frame, all kernels (FETCH_SIZE x 2 + WRITE_SIZE, summed over the launches): %.1f GB" % (tot / 1e9)]
+            traffic["scalar_rgb/matball/1920x1080@64/plan1/film1/launch64"] = e
+        except Exception as ex:
+            out.append("# (traffic summary failed: %r)" % (ex,))
+        open(path, "w").write("\n".join(out) + "\n")
+
     # every rank's tile shard of an 8-GPU frame + the floor (tools/shard_table.py, same session)
     if os.path.exists(g + "_shards.txt"):
         open(os.path.join(ROOT, "profiles", "%s_shards.txt" % tag), "w").write(head + "\n" + open(g + "_shards.txt").read())

@@ -26,6 +26,7 @@ pmc() {   # [ENV=VAL] pmc <name> <bench args...>  (the environment of the call r
 pmc c2
 pmc c3 --scene matball --spp 64
 pmc c4 --scene interior --spp 16
+pmc c3plan1 --scene matball --spp 64 --plan 1                                # round 6: the wavefront plan (SoA queues in HBM: the architecture north_star names) — REAL queue bytes against 8 TB/s
 [ -n "$LEAN" ] || MIW_BVH8=0 pmc c4bvh4 --scene interior --spp 16          # the 4-wide twin of the same build: traffic and wait share against the 8-wide walk's
 cd $repo
 line() {  # line <name> [ENV=VAL ...] -- <bench args...>: one bench line into $out/${tag}_<name>.log
@@ -40,9 +41,12 @@ line bench_c3_bvh4 MIW_BVH8=0 -- $C3 --spp 256                    # the 4-wide w
 line bench_c3_plan1 -- $C3 --spp 256 --plan 1                     # wavefront plan (stream walk kernel)
 line bench_c3_hostsah -- $C3 --spp 256 --bvh-quality 1            # the same trees built / collapsed by the host
 line bench_c3_lbvh -- $C3 --spp 256 --bvh-quality 64              # MI_BVH_RADIX_TREE: the radix tree of rounds 2 - 3 (4-wide walk)
+line bench_c3_pooled MIW_POOLED=1 -- $C3 --spp 256                # round 6: k_path_pooled (opt-in), 12 x 1 and 8 x 2
+line bench_c3_pooled82 MIW_POOLED=1 MIW_POOL_SHAPE=8x2 -- $C3 --spp 256
 line bench_c5 -- --variant scalar_spectral --scene glassblock --steps 1 --warmup 1
 line bench_c4 MIW_DEBUG=1 -- $C4 --spp 32                         # configs[3] class, device-built SAH tree (the default); .err: the builder's timing
 line bench_c4_bvh4 MIW_BVH8=0 -- $C4 --spp 32
+line bench_c4_pooled MIW_POOLED=1 -- $C4 --spp 32
 line bench_c4_hostsah -- $C4 --spp 32 --bvh-quality 1
 line bench_c4_lbvh -- $C4 --spp 32 --bvh-quality 64
 line bench_c4_sah_r4 MIW_SAH_HUGE=0 MIW_DEBUG=1 -- $C4 --spp 16   # the builder with one workgroup per candidate (round 4's launch shape): build ms
