@@ -212,7 +212,7 @@ def run_extras(api, scenes, film, C):
     import torch
     out = {}
 
-    def timed(tag, scene, sensor, spp, note, golden=None):
+    def timed(tag, scene, sensor, spp, note, golden=None, plan=0):
         device = api.Device(0)                   # world == 1: the benchmark runs on GPU 0
         try:
             # The tree is built twice and the SECOND build is quoted: the first device work after the previous configuration's context was
@@ -225,7 +225,7 @@ def run_extras(api, scenes, film, C):
             bvh = device.counters()
             job = api.PathIntegrator().render_job(sensor)
             cfg = job.cfg
-            cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = 0; cfg.profile = 1; cfg.plan = 0; cfg.samples_per_launch = int(cfg.spp)
+            cfg.film_on_device = 1; cfg.film_f64 = 0; cfg.film_mode = 0; cfg.profile = 1; cfg.plan = plan; cfg.samples_per_launch = int(cfg.spp)
             device.check(device.L.mi_set_stream(device.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             ms = []
             for _ in range(2):
@@ -236,7 +236,10 @@ def run_extras(api, scenes, film, C):
             out[tag] = {"workload": note, "spp": spp, "value": 1920.0 * 1080 * spp / (ms[-1] * 1e-3) / 1e6, "unit": "Msamples/sec",
                         "ms_per_frame": ms[-1], "ms_first_frame": ms[0], "ms_path_kernel": c.ms_path, "ms_film": c.ms_resolve,
                         "samples": int(c.samples), "segments_per_sample": c.segments / max(c.samples, 1),
-                        "path_kernel": "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident", "tree_width": int(c.tree_width),
+                        "path_kernel": ("k_path_pooled" if getattr(c, "pooled", 0) else "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident") if c.plan == 2 else
+                                       ("k_trace_stream + k_sort_hits + k_shade" if c.path_kernel == 2 else "k_trace<closest|any> + k_shade"),
+                        "plan": int(c.plan), "tree_width": int(c.tree_width),
+                        "kernel_ms": {"trace": round(c.ms_trace_closest, 2), "sort": round(c.ms_trace_any, 2), "shade": round(c.ms_shade, 2)} if c.plan == 1 else None,
                         "log_bytes": int(c.log_bytes),
                         "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris,
                                 "nodes2": bvh.bvh_nodes, "nodes8": bvh.bvh8_nodes, "depth8": bvh.bvh8_depth, "ms_bvh4": round(bvh.ms_bvh4, 2), "ms_bvh8": round(bvh.ms_bvh8, 2),
@@ -249,6 +252,11 @@ def run_extras(api, scenes, film, C):
     try:
         scene, sensor = scenes.cornell_box(1920, 1080, 1024, diffuse_only=False, device=-1)
         timed("c3_matball_1024spp", scene, sensor, 1024, "BASELINE configs[2] (GGX conductor + bk7 dielectric balls, 40 972 triangles), 1920x1080 @ its 1024 spp", "c3")
+        # the same geometry through plan 1 — SoA ray / hit / shadow queues in HBM, ballot + prefix-sum compaction, material-sorted shading: the
+        # architecture north_star names, kept as the both-plans twin of every parity test — at 256 spp; its film is the oracle's as well
+        # (tests/test_gpu_parity.py, test_gpu_configured.py::test_c3_window*), its time is what the queue traffic costs
+        scene, sensor = scenes.cornell_box(1920, 1080, 256, diffuse_only=False, device=-1)
+        timed("c3_matball_plan1_256spp", scene, sensor, 256, "BASELINE configs[2] geometry through the wavefront plan (plan 1: SoA queues in HBM, one kernel per stage), 1920x1080 @ 256 spp", plan=1)
         scene, sensor = scenes.interior_scene(1920, 1080, 2048, device=-1)
         timed("c4_interior_2048spp", scene, sensor, 2048, "BASELINE configs[3] class (911 362 triangles, area light + 1024x512 environment map), 1920x1080 @ its 2048 spp, one GPU", "c4")
         if os.path.exists(api.default_srgb_coeff()):

@@ -19,9 +19,110 @@
 #define MIW_STREAM_BATCH 16         /* lanes that must have finished / be idle before the wave stops stepping to retire / refill them */
 #endif
 
-__global__ __launch_bounds__(MIW_BLOCK, MIW_STREAM_WAVES) void k_trace_stream(SceneView sc, LaneQueues Q, TraceLds cfg, WorkLists io,
+// Wide = 0: the BVH2 walk of rounds 2 - 5 (one node = two boxes, one triangle per test). Wide = 2 (round 6): the 8-wide quantised tree and the
+// two walk bodies of the resident plan's phase machine (miw/bvh8.h: walk8_node_step / walk8_tri_step — node groups, triangle pairs, the speculating
+// walk), the stack one 8-byte group per level in the same 128-byte LDS column; the hit record then names triangles in the 8-wide tree's order, so
+// the host hands k_sort_hits and k_shade the same view (tris / tri_vn of that order).
+template <int Wide>
+__global__ __launch_bounds__(MIW_BLOCK, Wide == 2 ? 4 : MIW_STREAM_WAVES) void k_trace_stream(SceneView sc, LaneQueues Q, TraceLds cfg, WorkLists io,
                                                                                 uint32_t n_segments, uint32_t *next_segment) {
     extern __shared__ uint4 smem[];
+    if constexpr (Wide == 2) {
+        U2 *stack8 = reinterpret_cast<U2 *>(smem + cfg.stack16) + threadIdx.x;
+        GlobalU4 tris_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.tris), nodes8_g = (GlobalU4) reinterpret_cast<uintptr_t>(sc.nodes8);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(nodes8_g)); asm volatile("" : "+s"(tris_g));        // (phased_kernel.h: MIW_PIN_TREE_PTRS)
+#endif
+        auto node8_at = [nodes8_g](uint32_t i) -> Bvh8Node {
+            GlobalU4 p = nodes8_g + 5 * (size_t) i;
+            miw_u4 q[5] = { p[0], p[1], p[2], p[3], p[4] };
+            Bvh8Node n; __builtin_memcpy(&n, q, sizeof n); return n;
+        };
+        const GlobalTris tri_at_g{ tris_g };
+        const PrimCtx ctx = prim_ctx(sc);
+        const uint32_t me = threadIdx.x & 63u;
+        auto count = [](bool p) -> int { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); };
+        uint32_t seg = 0, n_e = 0, n_tot = 0, next = 0;
+        bool more = true;
+        bool has_ray = false, any_hit = false, found = false;
+        uint32_t lane = 0;
+        V3 o = v3(0.f), d = v3(0.f);
+        float mint = 0.f, maxt = 0.f, tmax = 0.f;
+        FastRay r; r.inv_d = r.neg_o_inv_d = v3(0.f); r.mint = 0.f;
+        Walk8 w8; w8.gb = w8.gm = w8.tb = w8.tm = w8.tb2 = w8.tm2 = 0u;
+        Hit best; best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+        for (;;) {
+            // ---- retire finished walks ----
+            const bool e_end = has_ray && walk8_over(w8);
+            int n_end = count(e_end);
+            const int n_live = count(has_ray) - n_end;
+            if (n_end > 0 && (n_end >= MIW_STREAM_BATCH || n_live == 0 || !more)) {
+                if (e_end) {
+                    if (any_hit) Q.sh_vis[lane] = found ? 0u : 1u;
+                    else { F4 h; h.x = best.t; h.y = best.u; h.z = best.v; h.w = u2f(best.tri); Q.hit[lane] = h; }
+                    has_ray = false;
+                }
+                n_end = 0;
+            }
+            // ---- refill idle lanes from the stream ----
+            int n_idle = count(!has_ray);
+            if (more && (n_idle >= MIW_STREAM_BATCH || n_idle + n_end == 64)) {
+                while (n_idle > 0) {
+                    if (next == n_tot) {
+                        uint32_t sg = 0;
+                        if (me == 0) sg = atomicAdd(next_segment, 1u);
+                        sg = (uint32_t) __builtin_amdgcn_readfirstlane((int) sg);
+                        if (sg >= n_segments) { more = false; break; }
+                        seg = sg;
+                        n_e = io.count[sg * WL_LISTS + WL_E];
+                        n_tot = n_e + io.count[sg * WL_LISTS + WL_S];
+                        next = 0;
+                        continue;
+                    }
+                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
+                    const uint32_t rank = (uint32_t) __builtin_popcountll(idle & ((1ull << me) - 1ull));
+                    const uint32_t avail = n_tot - next, take = avail < (uint32_t) n_idle ? avail : (uint32_t) n_idle;
+                    if (!has_ray && rank < take) {
+                        const uint32_t e = next + rank;
+                        any_hit = e >= n_e;
+                        lane = any_hit ? io.list[WL_S][seg * MIW_BLOCK + (e - n_e)] : io.list[WL_E][seg * MIW_BLOCK + e];
+                        const F4 ro = Q.ray_o[lane], rd = any_hit ? Q.sh_d[lane] : Q.ray_d[lane];
+                        o = v3(ro.x, ro.y, ro.z); mint = ro.w; d = v3(rd.x, rd.y, rd.z); maxt = rd.w;
+                        r = fast_ray(o, d, mint); tmax = maxt;
+                        walk8_begin(w8, r); found = false;
+                        best.t = MIW_INFINITY; best.u = best.v = 0.f; best.tri = MIW_MISS; best.prim = 0xffffffffu;
+                        has_ray = true;
+                    }
+                    next += take; n_idle -= (int) take;
+                }
+            }
+            if (count(has_ray) == 0) break;
+            // ---- walk: the body with more ready lanes; a loop hands over once it is outnumbered 2 : 1 or enough walks have ended to retire ----
+            bool e_node = has_ray && walk8_node_ready<true>(w8), e_leaf = has_ray && walk8_tri_ready(w8);
+            int n_node = count(e_node), n_leaf = count(e_leaf);
+            if (n_node >= n_leaf && n_node > 0) {
+                do {
+                    if (e_node) {
+                        const auto &nd = node8_at(walk8_next_node(w8));
+                        walk8_node_step<true>(nd, r, widen(tmax), w8, LdsColumn8{ stack8 });
+                    }
+                    e_node = has_ray && walk8_node_ready<true>(w8);
+                    const int now = count(e_node);
+                    n_leaf = count(has_ray && walk8_tri_ready(w8));
+                    if (now == 0 || 2 * now < n_leaf || count(has_ray && walk8_over(w8)) >= MIW_STREAM_BATCH) break;
+                } while (true);
+            } else if (n_leaf > 0) {
+                do {
+                    if (e_leaf) walk8_tri_step<true, true>(tri_at_g, ctx, o, d, mint, maxt, any_hit, best, tmax, found, w8);
+                    e_leaf = has_ray && walk8_tri_ready(w8);
+                    const int now = count(e_leaf);
+                    n_node = count(has_ray && walk8_node_ready<true>(w8));
+                    if (now == 0 || 2 * now <= n_node || count(has_ray && walk8_over(w8)) >= MIW_STREAM_BATCH) break;
+                } while (true);
+            }
+        }
+        return;
+    }
     int32_t *stack = reinterpret_cast<int32_t *>(smem + cfg.stack16) + threadIdx.x;
     const BvhNode *gnodes = sc.nodes;
     const Tri *gtris = sc.tris;

@@ -1996,11 +1996,17 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         const bool stream_on = !(ropt.get("MIW_STREAM") && atoi(ropt.get("MIW_STREAM")) == 0);
         const bool stream = stream_on && c->lds_cfg.stack && !c->lds_cfg.brute && c->lds_cfg.nodes_staged == 0;
         K.path_kernel = stream ? 2u : 0u;
+        // round 6: the stream kernel walks the 8-wide tree (the phase machine's two walk bodies) wherever mi_bvh_build produced it; its hit records then
+        // name triangles in that tree's order, so k_sort_hits and k_shade get the view with the triangles / vertex normals of that order
+        const bool stream8 = stream && c->view.nodes4 != nullptr && c->nodes8_count != 0u && !(ropt.get("MIW_BVH8") && atoi(ropt.get("MIW_BVH8")) == 0);
+        SceneView pview = c->view;
+        if (stream8) { pview.nodes8 = c->d_nodes8.p; pview.tris = c->d_tris8.p; if (pview.tri_vn) pview.tri_vn = c->d_tri_vn8.p; }
+        K.tree_width = stream8 ? 8u : 0u;
         if (stream) {
             HIP_TRY(c, c->d_next_pixel.resize(1));
             HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, sizeof(uint32_t), s));
         }
-        const dim3 sgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * MIW_STREAM_WAVES));
+        const dim3 sgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * (stream8 ? 4u : (unsigned) MIW_STREAM_WAVES)));
         const int check_every = 16;
         bool first = true;
         unsigned long long active_prev = 0;
@@ -2009,8 +2015,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
             for (int it = 0; it < check_every; ++it, parity ^= 1u) {
                 const WorkLists &cur = WL[parity], &nxt = WL[parity ^ 1u];
                 if (stream) {
-                    MIW_TIMED(0, hipLaunchKernelGGL(k_trace_stream, sgrid, block, c->lds_bytes, s, c->view, Q, c->lds_cfg, cur, (uint32_t) n_wg, c->d_next_pixel.p));
-                    MIW_TIMED(1, hipLaunchKernelGGL(k_sort_hits, grid, block, 0, s, c->view, Q, cur, c->d_next_pixel.p));
+                    if (stream8) MIW_TIMED(0, hipLaunchKernelGGL(k_trace_stream<2>, sgrid, block, c->lds_bytes, s, pview, Q, c->lds_cfg, cur, (uint32_t) n_wg, c->d_next_pixel.p));
+                    else MIW_TIMED(0, hipLaunchKernelGGL(k_trace_stream<0>, sgrid, block, c->lds_bytes, s, pview, Q, c->lds_cfg, cur, (uint32_t) n_wg, c->d_next_pixel.p));
+                    MIW_TIMED(1, hipLaunchKernelGGL(k_sort_hits, grid, block, 0, s, pview, Q, cur, c->d_next_pixel.p));
                     K.n_trace_closest++; K.n_trace_any++;
                 } else {
                     if (!first) {
@@ -2022,9 +2029,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 }
                 const uint32_t count_active = it == check_every - 1 ? 1u : 0u;
                 if (film_mode == 1)
-                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, count_active, cur, nxt));
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, P, pview, Q, (double *) nullptr, c->d_cnt.p, count_active, cur, nxt));
                 else
-                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, count_active, cur, nxt));
+                    MIW_TIMED(2, hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, P, pview, Q, c->d_accum.p, c->d_cnt.p, count_active, cur, nxt));
                 K.n_shade++; K.iterations++;
                 first = false;
             }

@@ -34,6 +34,9 @@ using namespace miw;
 #define MIW_POOL_PP 2
 #endif
 template __global__ void k_path_pooled<MATS_TRIO, false, MIW_POOL_NW, MIW_POOL_PP>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+#elif defined(MIW_PROBE_PLAIN_ALL)   // the path integrator's phase machine for the general scene classes (for comparison with the direct one)
+template __global__ void k_path_phased<MATS_PLAIN, true, MIW_PHASE_SPEC != 0, 4, 2, false>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
+template __global__ void k_path_phased<MATS_ALL, true, MIW_PHASE_SPEC != 0, 4, 2, false>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 #elif defined(MIW_PROBE_C34)   // only the kernels of BASELINE configs 3 / 4: MATS_TRIO over the 8-wide tree (round 5) and its 4-wide twin, four wavefronts per SIMD (tests/test_kernel_budget.py)
 template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 2>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);
 template __global__ void k_path_phased<MATS_TRIO, false, MIW_PHASE_SPEC != 0, 4, 1>(RenderParams, SceneView, LaneQueues, Counters *, TraceLds, uint32_t, uint32_t *);

@@ -14,5 +14,5 @@ g++ $flags -DMIW_SPECTRAL=1 oracle/miw_oracle.cpp oracle/wavefront_emu.cpp -o $o
 asan=$(gcc -print-file-name=libasan.so); ubsan=$(gcc -print-file-name=libubsan.so)
 k=${1:-"kat or emu or walk or bvh or film or spiral or leaves or chunk or oracle or spectral or hier2d or texture or sphere or rect"}
 # (python itself is not instrumented: leak reports of the interpreter are noise -> detect_leaks=0; everything else is fatal)
-MIW_ORACLE_DIR=$out LD_PRELOAD="$asan $ubsan" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:strict_string_checks=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+MIW_TEST_NO_BUILD=1 MIW_ORACLE_DIR=$out LD_PRELOAD="$asan $ubsan" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:strict_string_checks=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   python -m pytest tests -x -q -m "not gpu" -k "$k" -p no:cacheprovider 2>&1 | tail -15
