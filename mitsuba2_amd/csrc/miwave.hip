@@ -221,6 +221,7 @@ struct mi_ctx {
     DevBuf<uint32_t> d_block_ids, d_tile_list; DevBuf<int32_t> d_block_tile; DevBuf<float> d_tiles;
     DevBuf<Counters> d_cnt;
     Counters *h_cnt = nullptr;          // pinned
+    std::vector<uint32_t> h_piece_list, h_simd_ids;   // the placed launch's dealing (host side): uploaded without waiting, so they live here
 
     std::vector<hipEvent_t> ev_pool;
     mi_counters counters{};
@@ -1762,6 +1763,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         }
         const uint32_t sync_every = 8;
         uint32_t launches = 0;
+        bool place_stats_due = false;                              // (profile runs) the measuring launch's statistics, fetched after the last launch
         for (uint32_t done = 0; done < cfg->spp; ) {
             uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
             if (film_mode == 1) {
@@ -1782,31 +1784,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     bool spread = phased && ((phased8 ? (size_t) c->nodes8_count * sizeof(Bvh8Node) : (size_t) c->nodes4_count * sizeof(Bvh4Node)) + (size_t) c->view.tri_count * sizeof(Tri)) > ((size_t) 32 << 20);
                     if (const char *e = ropt.get("MIW_PLACE_SPREAD")) spread = atoi(e) != 0;
                     Q.piece_a = spread ? 1u : 64u; Q.piece_b = spread ? n_pieces : 1u;
+                    // one host round trip between the measuring launch and the placed one: the pieces' costs and the SIMD registry come back together
+                    // (round 6; the statistics of the measuring launch — mi_counters::place_* — are read after the frame's last launch, below)
                     std::vector<uint32_t> cost(n_pieces);
                     HIP_TRY(c, hipMemcpy2DAsync(cost.data(), sizeof(uint32_t), c->d_cost_sorted.p, Q.piece_a * sizeof(uint32_t), sizeof(uint32_t), n_pieces, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    if (cfg->profile) {        // what the measuring launch found (mi_counters::place_*): the shard's dearest pixel and the mean
-                        std::vector<uint32_t> all(n_lanes); uint32_t first_lane = 0, px = 0;
-                        HIP_TRY(c, hipMemcpyAsync(all.data(), c->d_cost_sorted.p, (size_t) n_lanes * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                        HIP_TRY(c, hipMemcpyAsync(&first_lane, c->d_lane_sorted.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                        HIP_TRY(c, hipStreamSynchronize(s));
-                        if (first_lane < n_lanes) HIP_TRY(c, hipMemcpy(&px, c->q_pixel.p + first_lane, sizeof(uint32_t), hipMemcpyDeviceToHost));
-                        double sum = 0.0; uint32_t with = 0;
-                        for (uint32_t v : all) if (v) { sum += (double) v; ++with; }
-                        K.place_cost_max = all.empty() ? 0u : all[0]; K.place_cost_mean = with ? sum / with : 0.0; K.place_max_pixel = px;
-                        K.place_cost_unit = phased ? 1u : 0u; K.place_measure_spp = measure_end;
-                    }
                     // longest piece first onto the SIMD queue with the smallest sum that still has a free slot
                     // the SIMDs the measuring launch ran on, numbered 0 .. nqueues - 1 (simd_ids[1 + hardware key]; word 0 = the "all dry" flag)
-                    std::vector<uint32_t> ids(c->d_simd_ids.n);
+                    std::vector<uint32_t> &ids = c->h_simd_ids;
+                    ids.resize(c->d_simd_ids.n);
                     HIP_TRY(c, hipMemcpyAsync(ids.data(), c->d_simd_ids.p, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(c, hipStreamSynchronize(s));
+                    place_stats_due = cfg->profile != 0;
                     uint32_t nqueues = 0;
                     for (size_t k = 1; k < ids.size(); ++k) ids[k] = ids[k] ? nqueues++ : 0xffffffffu;
                     ids[0] = 0u;
                     if (nqueues < 2u || (uint64_t) nqueues * MIW_PLACE_PIECES < n_pieces) nqueues = 0;   // (cannot happen on a whole device; then: one queue)
                     if (nqueues) {
-                    std::vector<uint32_t> order(n_pieces), list((size_t) nqueues * MIW_PLACE_PIECES, 0xffffffffu), fill(nqueues, 0u);
+                    std::vector<uint32_t> order(n_pieces), fill(nqueues, 0u);
+                    std::vector<uint32_t> &list = c->h_piece_list;                                          // (context-owned: the upload below is not waited for)
+                    list.assign((size_t) nqueues * MIW_PLACE_PIECES, 0xffffffffu);
                     for (uint32_t i = 0; i < n_pieces; ++i) order[i] = i;
                     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
                     std::vector<std::pair<uint64_t, uint32_t>> heap;                                       // (sum, queue), smallest sum on top
@@ -1823,7 +1819,6 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     HIP_TRY(c, c->d_piece_list.resize(list.size()));
                     HIP_TRY(c, hipMemcpyAsync(c->d_piece_list.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                     HIP_TRY(c, hipMemcpyAsync(c->d_simd_ids.p, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));                                                     // the host vectors must outlive the copies
                     rcfg.queues = nqueues; Q.piece_list = c->d_piece_list.p; Q.lane_sorted = c->d_lane_sorted.p; Q.simd_ids = c->d_simd_ids.p;
                     K.placed = 1u;
                     }
@@ -1957,6 +1952,17 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         Counters sum;
         mi_status rs = read_counters(sum);
         if (rs != MI_OK) return rs;
+        if (place_stats_due) {             // what the measuring launch found (mi_counters::place_*): the shard's dearest pixel and the mean
+            std::vector<uint32_t> all(n_lanes); uint32_t first_lane = 0, px = 0;
+            HIP_TRY(c, hipMemcpyAsync(all.data(), c->d_cost_sorted.p, (size_t) n_lanes * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(&first_lane, c->d_lane_sorted.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            if (first_lane < n_lanes) HIP_TRY(c, hipMemcpy(&px, c->q_pixel.p + first_lane, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            double csum = 0.0; uint32_t with = 0;
+            for (uint32_t v : all) if (v) { csum += (double) v; ++with; }
+            K.place_cost_max = all.empty() ? 0u : all[0]; K.place_cost_mean = with ? csum / with : 0.0; K.place_max_pixel = px;
+            K.place_cost_unit = phased ? 1u : 0u; K.place_measure_spp = measure_end;
+        }
         if (K.placed && ropt.get("MIW_DEBUG")) {                     // how the placed launch went: SIMDs that registered, lanes handed out per queue
             std::vector<uint32_t> cur(n_simd), ids(1u + (1u << 14)), cost(n_pieces);
             (void) hipMemcpy(cur.data(), c->d_next_pixel.p, n_simd * sizeof(uint32_t), hipMemcpyDeviceToHost);
