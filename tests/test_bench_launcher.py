@@ -68,3 +68,32 @@ def test_bench_names_the_film_kernel_that_runs():
     import bench
     assert bench.film_kernel_name(24, 0) == "k_film_blocks" and bench.film_kernel_name(24, 4) == "k_film_blocks"
     assert [bench.film_kernel_name(16, k) for k in (1, 2, 3, 4)] == ["k_film_groups", "k_film_columns", "k_film_quads", "k_film_lanes"]
+
+
+def test_a_film_that_is_not_the_oracles_makes_the_parity_field_false():
+    """the bench line's `parity.match` must turn false when a single bit of the timed film moves. CPU tier: the hashing /
+    comparison itself against the committed digests (the GPU run of the default line is what makes it true: profiles/r06_bench_default_line.json)."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import bench
+    for which in ("c2", "c3", "c4", "c5"):
+        path, key = bench.GOLDEN_FRAMES[which]
+        rec = json.load(open(os.path.join(ROOT, path)))[key]
+        film = torch.zeros(1080 * 1920 * 5, dtype=torch.float32)
+        out = bench.film_parity(film, which, rec["samples"], rec["segments"])
+        assert out["golden_sha256"] == rec["sha256"] and out["match"] is False and out["counts_match"] is True and "error" not in out
+        out = bench.film_parity(film, which, rec["samples"] + 1, rec["segments"])         # the film AND the counts must be the oracle's
+        assert out["match"] is False and out["counts_match"] is False
+    # the comparison is the digest of the float32 bytes: a buffer that hashes to the golden value matches, one flipped bit does not
+    import hashlib
+    film = torch.arange(64, dtype=torch.float32)
+    bench.GOLDEN_FRAMES["_t"] = ("tests/golden/round3.json", "c2_full_1920x1080_512spp")
+    try:
+        rec = json.load(open(os.path.join(ROOT, "tests/golden/round3.json")))["c2_full_1920x1080_512spp"]
+        real = bench.film_parity(film, "_t")
+        assert real["match"] is False and real["film_sha256"] == hashlib.sha256(film.numpy().tobytes()).hexdigest()
+        flipped = film.clone(); flipped.view(torch.int32)[7] ^= 1
+        assert bench.film_parity(flipped, "_t")["film_sha256"] != real["film_sha256"]
+    finally:
+        del bench.GOLDEN_FRAMES["_t"]
