@@ -321,6 +321,10 @@ typedef struct {
     uint32_t pooled;           /* 1: the last render's phase machine was k_path_pooled (device/pooled_kernel.h: walk jobs pooled across the
                                   workgroup through LDS; path_kernel stays 1, tree_width 8); 0: k_path_phased or another kernel             */
     uint32_t pool_waves;       /* wavefronts per workgroup of that launch (= jobs per LDS column); 0: not pooled                          */
+    uint32_t film_overlapped;  /* 1: the last render's film replay (k_film_lanes) was queued beside the path kernel on three more streams, one launch per
+                                  set of 64-tile groups behind the flags the groups' last finished pixels raise (full frames of the packet / lock-step
+                                  kernels, one launch for all samples; MIW_FILM_OVERLAP=0 switches it off); ms_film_blocks then overlaps ms_path */
+    uint32_t film_groups;      /* launches of that replay; 0: one launch after the path kernel                                            */
 } mi_counters;
 
 /* ---- entry points -------------------------------------------------------------------- */

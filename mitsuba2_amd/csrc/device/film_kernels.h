@@ -732,14 +732,19 @@ __device__ __forceinline__ void film_lanes_pixel(miw_f2 (&acc)[MIW_FL_BS][MIW_FL
 #ifndef MIW_FL_WAVES
 #define MIW_FL_WAVES 3
 #endif
-template <int U, int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIW_FL_WAVES, 8))) void k_film_lanes(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = texel blocks per tile row / column */, uint32_t n_tiles, float *tiles) {
+// WV = wavefronts per SIMD the kernel is compiled for: 3 (168 registers; the replay on its own) or, with U = 2, 4 (128 registers, the sample loops still free
+// of scratch: tests/test_kernel_budget.py) — the form that fits BESIDE three wavefronts of the 120-register packet kernel (miwave.hip: overlap_enqueue).
+template <int U, int NT, int WV = MIW_FL_WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WV, 8))) void k_film_lanes(FilmRec F, BlockReplayArgs A, PatchArgs PA /* patches_x / _y = texel blocks per tile row / column */, uint32_t n_tiles, float *tiles,
+                  uint32_t group0 /* the first group of 64 tiles this launch replays (several launches when the replay runs beside the render: miwave.hip, overlap_enqueue) */,
+                  uint32_t prio /* s_setprio of its wavefronts, 0 .. 3 (beside the path kernel, whose wavefronts raise theirs: resident_kernel.h tick()) */) {
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3); else if (prio == 2u) __builtin_amdgcn_s_setprio(2); else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     constexpr int BS = MIW_FL_BS, WS = MIW_FQ_WSTRIDE(MIW_FL_BS), LEAD = BS - 1, LCAP = 64;
     extern __shared__ float s_w[];                           // (count + 1) x WS weights; row `count` = 0
     __shared__ unsigned short s_list[LCAP];
     const uint32_t l = threadIdx.x;
     const uint32_t n_pos = PA.patches_x * PA.patches_y;
-    const uint32_t tw = blockIdx.x / n_pos, pos = blockIdx.x % n_pos;
+    const uint32_t tw = blockIdx.x / n_pos + group0, pos = blockIdx.x % n_pos;
     const int tx0 = (int) (pos % PA.patches_x) * BS, ty0 = (int) (pos / PA.patches_x) * BS;      // (wave-uniform) the block inside its tile
     const uint32_t tile = tw * 64u + l;
     const bool live = tile < n_tiles;

@@ -45,7 +45,10 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // clock out — four registers less carried through every body of the phase machine; shards of about one pixel per resident lane
 // get the Placed = true instantiation of their kernel. Clock: a pixel's cost is the time it held its lane (s_memtime, the phase
 // machine: its lanes do not iterate together) instead of the wavefront's iterations while it did (the lock-step packet kernel).
-template <bool Placed = true, bool Clock = false>
+// Groups: store() counts finished pixels per group of 64 tiles (the film replay beside the render, miwave.hip: overlap_prepare) — compiled into the lock-step /
+// packet kernels only: in the phase machine the same statements cost 16 more spilled registers (24 -> 40, tests/test_kernel_budget.py), and its frames spend
+// under 2 % in the replay.
+template <bool Placed = true, bool Clock = false, bool Groups = !Clock>
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
@@ -158,6 +161,16 @@ struct QueueWork {
     __device__ __forceinline__ void store(U4 st) {
         Q->st[lane] = st;
         if (Placed && Q->lane_cost) Q->lane_cost[lane] = cost_clock() - t_fetch + 1u;   // what this pixel cost in this (the measuring) launch
+        // film replay beside the render: this pixel's log is complete — count it in its group of 64 tiles; the pixel that completes the group
+        // makes everything written before the counts visible and raises the group's flag (mi_render: the replay's stream waits on it)
+        if (Groups && Q->group_done && (st.z & LF_DONE)) {        // (nullptr in every launch but the single full-frame one)
+            __threadfence();
+            const uint32_t g = lane >> Q->group_shift;
+            if (atomicAdd(Q->group_done + g, 1u) + 1u == Q->group_expected[g]) {
+                __threadfence_system();
+                __hip_atomic_store(Q->group_flag + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     __device__ __forceinline__ void put(uint32_t pixel, uint32_t sample_idx, V2 pos, const float *aovs) {
         if (Q->log_rec) {                                       // wave-uniform: one format per render

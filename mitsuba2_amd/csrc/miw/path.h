@@ -73,6 +73,10 @@ struct LaneQueues {
     // about the same and finish together — or (1, pieces) — a piece takes every pieces-th sorted lane, one pixel of every cost
     // stratum (which cut a launch gets: mi_render, by measurement)
     uint32_t *lane_cost; const uint32_t *lane_sorted; const uint32_t *piece_list; uint32_t *simd_ids; uint32_t piece_a, piece_b;
+    // film replay beside the render (round 6; full frames over the tile-interleaved log, device/resident_kernel.h: QueueWork::store): per group of
+    // 64 tiles, how many pixels have run all their samples (group_done, device memory) against how many there are (group_expected); the pixel
+    // that completes a group raises its flag (group_flag: host-coherent memory the replay's stream waits on). nullptr: off
+    uint32_t *group_done = nullptr; const uint32_t *group_expected = nullptr; uint32_t *group_flag = nullptr; uint32_t group_shift = 0;
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)

@@ -163,6 +163,12 @@ static const KnobInfo g_knobs[] = {
     { "MIW_FILM_COLUMNS", "0 | 42 | 44 | 82: k_film_columns group shape" },
     { "MIW_FILM_GROUP", "2 | 3 | 4: k_film_groups group shape" },
     { "MIW_FL_NT", "0: k_film_lanes reads the log with plain instead of streaming loads" },
+    { "MIW_FILM_OVERLAP", "1: part of the film replay of a full Cornell-class frame is queued on three more streams beside the path kernel, sets of 64-tile groups each behind the flags their last pixels raise (default 0: measured +0 - 1 %); 2: without the waits (timing probe: the film is the previous frame's)" },
+    { "MIW_FILM_OVERLAP_SET", "groups of 64 tiles per launch of that replay (default 4)" },
+    { "MIW_FILM_OVERLAP_ROOM", "workgroups the path kernel's grid is short of filling the device while the replay runs beside it (default 32: one per CU on 32 CUs)" },
+    { "MIW_FILM_OVERLAP_LEAN", "0: the launches of that replay are the 168-register kernel (default 1: the 128-register form)" },
+    { "MIW_FILM_OVERLAP_BESIDE", "groups of 64 tiles replayed beside the path kernel; the rest in one launch after it (default: three quarters)" },
+    { "MIW_FILM_OVERLAP_PRIO", "s_setprio of the replay wavefronts that run beside the path kernel, 0 .. 3 (default 0)" },
     { "MIW_FQ_U", "2 | 4 | 8: records per trip of k_film_quads" },
     { "MIW_RCCL", "0: mi_film_reduce never uses RCCL (device add)" },
     { "MIW_RCCL_FORCE", "1: mi_film_reduce takes the RCCL branch for one context too (tests)" }
@@ -222,6 +228,14 @@ struct mi_ctx {
     DevBuf<Counters> d_cnt;
     Counters *h_cnt = nullptr;          // pinned
     std::vector<uint32_t> h_piece_list, h_simd_ids;   // the placed launch's dealing (host side): uploaded without waiting, so they live here
+    // film replay beside the render (round 6): a second stream, fork / join events, per group of 64 tiles the pixels done / expected (device) and
+    // the flag its last pixel raises (host-coherent: what hipStreamWaitValue32 polls)
+    hipStream_t stream2[3] = { nullptr, nullptr, nullptr }; hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };   // (kernels of ONE stream run one after the other: three replay streams)
+    DevBuf<uint32_t> d_group_done, d_group_expected; uint32_t *h_group_flag = nullptr; uint32_t group_flag_cap = 0;
+    std::vector<uint32_t> h_group_expected; std::vector<int32_t> h_block_tile;
+    int overlap_state = -1;             // -1: not tried; 0: the runtime refused (hipStreamWaitValue32 / the allocations); 1: available
+    bool replay_enqueued = false;       // this frame's k_film_lanes launches already sit in the replay streams (assemble_film only joins)
+    uint32_t replay_launches = 0;
 
     std::vector<hipEvent_t> ev_pool;
     mi_counters counters{};
@@ -279,6 +293,10 @@ void mi_destroy(mi_ctx *c) {
     c->d_accum.release(); c->d_out.release(); c->d_next_pixel.release(); c->d_lane_cost.release(); c->d_cost_sorted.release(); c->d_lane_iota.release(); c->d_lane_sorted.release(); c->d_place_tmp.release(); c->d_piece_list.release(); c->d_simd_ids.release(); c->d_lists.release(); c->d_list_counts.release(); c->d_block_ids.release(); c->d_tile_list.release(); c->d_cnt.release();
     c->q_log_pos.release(); c->q_log_val.release(); c->q_log_rec.release(); c->d_fc_thr.release(); c->d_fc_w.release(); c->d_block_tile.release(); c->d_tiles.release();
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
+    c->d_group_done.release(); c->d_group_expected.release();
+    if (c->h_group_flag) (void) hipHostFree(c->h_group_flag);
+    if (c->ev_fork) (void) hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 3; ++i) { if (c->ev_join[i]) (void) hipEventDestroy(c->ev_join[i]); if (c->stream2[i]) (void) hipStreamDestroy(c->stream2[i]); }
     if (c->h_cnt) (void) hipHostFree(c->h_cnt);
     delete c;
     if (g_live_contexts.fetch_sub(1) == 1) rccl_release_comms();
@@ -1366,10 +1384,133 @@ static void print_debug_statistics(mi_ctx *c, const Options &ropt, mi_counters &
 #endif
 }
 
+// ---- mi_render, what every replay kernel is handed: the log, the pixel states, the class tables, the block -> tile map of this shard (uploaded from a
+// context-owned vector: nobody waits for that copy), the tile buffer ----
+struct FilmReplay { BlockReplayArgs A; uint32_t side = 0; uint32_t beside = 0; /* groups of 64 tiles replayed beside the path kernel (overlap_enqueue); the launch after it takes the rest */ };
+static mi_status film_replay_setup(mi_ctx *c, const mi_render_cfg *cfg, hipStream_t s, const FilmPlan &FP, uint32_t n_tiles, uint32_t bs, uint32_t bs2_log2,
+                                   uint32_t blocks_x, uint32_t blocks_y, FilmReplay &R) {
+    const bool rec16 = FP.rec16;
+    std::vector<int32_t> &block_tile = c->h_block_tile;
+    block_tile.assign(cfg->block_count, -1);
+    for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
+    HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
+    HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    BlockReplayArgs &A = R.A;
+    A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
+    A.log_rec = rec16 ? c->q_log_rec.p : nullptr; A.log_il = rec16 ? FP.log_il : 0u;
+    A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
+    A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
+    A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
+    A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
+    R.side = bs + 2u * (uint32_t) cfg->filter_border;
+    A.tile_stride = R.side * R.side * MIW_FILM_CHANNELS;
+    HIP_TRY(c, c->d_tiles.resize((size_t) std::max<uint32_t>(n_tiles, 1) * A.tile_stride));
+    return MI_OK;
+}
+
+// The film replay of a full frame BESIDE its render (round 6). k_film_lanes waits on memory (a quarter of its issue slots used), the path kernels on
+// issue slots (0.14 TB/s of HBM), and a path kernel's last ~30 ms run at falling occupancy (a lane's last pixel is a serial stream of spp samples): so
+// the replay is queued on a second stream BEFORE the path kernel has run, one launch per group of 64 tiles (the unit of the tile-interleaved log), each
+// behind a stream-level wait (hipStreamWaitValue32: the command processor polls, no wavefront spins) for the flag the group's LAST finished pixel raises
+// (resident_kernel.h: QueueWork::store counts finished pixels per group). The groups finish in queue order, so their replays run in the wave slots the
+// path kernel's tail frees, and only the last groups' replay is left when the path kernel ends. Same kernels, same log, same additions: the same film.
+// A raise-all launch behind the path kernel releases every wait whatever the counts said (a stream can never be left waiting).
+__global__ void k_raise_flags(uint32_t *flag, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store(flag + i, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static mi_status overlap_prepare(mi_ctx *c, const mi_render_cfg *cfg, hipStream_t s, uint32_t n_tiles, uint32_t bs, uint32_t blocks_x, LaneQueues &Q, uint32_t bs2_log2) {
+    const uint32_t n_groups = (n_tiles + 63u) / 64u;
+    if (!c->ev_fork) {
+        bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 3 && ok; ++i)
+            ok = hipStreamCreateWithFlags(&c->stream2[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void) hipGetLastError(); c->overlap_state = 0; return MI_OK; }
+    }
+    if (c->group_flag_cap < n_groups) {
+        if (c->h_group_flag) (void) hipHostFree(c->h_group_flag);
+        c->h_group_flag = nullptr; c->group_flag_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(1024u, n_groups);
+        if (hipHostMalloc((void **) &c->h_group_flag, cap * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError(); c->overlap_state = 0; return MI_OK; }
+        c->group_flag_cap = cap;
+    }
+    // pixels per group: the pixels of its tiles that lie inside the film (k_init_pixels marks the others done: they are never fetched, never stored)
+    std::vector<uint32_t> &expected = c->h_group_expected;
+    expected.assign(n_groups, 0u);
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t b = cfg->tile_list ? cfg->tile_list[t] : t, bx = b % blocks_x, by = b / blocks_x;
+        const int32_t bw = std::min<int32_t>((int32_t) bs, cfg->crop_w - (int32_t) (bx * bs)), bh = std::min<int32_t>((int32_t) bs, cfg->crop_h - (int32_t) (by * bs));
+        expected[t >> 6] += (uint32_t) (std::max(bw, 0) * std::max(bh, 0));
+    }
+    HIP_TRY(c, c->d_group_done.resize(n_groups)); HIP_TRY(c, c->d_group_expected.resize(n_groups));
+    memset(c->h_group_flag, 0, n_groups * sizeof(uint32_t));     // (the previous frame's stream work is complete: mi_render ends with a wait)
+    HIP_TRY(c, hipMemsetAsync(c->d_group_done.p, 0, n_groups * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_group_expected.p, expected.data(), n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    Q.group_done = c->d_group_done.p; Q.group_expected = c->d_group_expected.p; Q.group_flag = c->h_group_flag; Q.group_shift = bs2_log2 + 6u;
+    return MI_OK;
+}
+// after the path kernel has been launched on `s`: fork, the waits + launches on stream2, the release-all behind the path kernel, the join event
+static mi_status overlap_enqueue(mi_ctx *c, const Options &ropt, const RenderParams &P, hipStream_t s, LaunchTimer &T, FilmReplay &R, uint32_t n_tiles, bool wait_flags) {
+    const uint32_t n_all = (n_tiles + 63u) / 64u;
+    // how many groups are replayed BESIDE the path kernel; the rest in one launch after it (assemble_film). What runs after it cannot take less than one
+    // wavefront's chain (~8 - 10 ms) however little it is; measured at C2 (gpurun r6m): three quarters beside 263.6 ms, half 266.1, none 265.8
+    uint32_t n_groups = n_all * 3u / 4u;
+    if (const char *e = ropt.get("MIW_FILM_OVERLAP_BESIDE")) n_groups = (uint32_t) std::min<long>(std::max<long>(atol(e), 0), (long) n_all);
+    int prio = 0;
+    if (const char *e = ropt.get("MIW_FILM_OVERLAP_PRIO")) prio = std::min(3, std::max(0, atoi(e)));
+    PatchArgs PC; PC.patches_x = PC.patches_y = (R.side + MIW_FL_BS - 1) / MIW_FL_BS; PC.reach = c->classes.reach;
+    const uint32_t n_pos = PC.patches_x * PC.patches_y;
+    const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
+    int fl_nt = 1;
+    if (const char *e = ropt.get("MIW_FL_NT")) fl_nt = atoi(e);
+    // One launch replays a SET of groups (MIW_FILM_OVERLAP_SET, default 4: 324 wavefronts) behind the flags of all of them; the sets go round the three
+    // replay streams — kernels of one stream run one after the other, and a replay kernel lasts as long as ONE of its wavefronts (64 pixel runs, a
+    // serial chain of ~4 ms) however few there are: one launch per group on one stream would be a chain of 32 such kernels.
+    uint32_t set = 4u;
+    if (const char *e = ropt.get("MIW_FILM_OVERLAP_SET")) set = (uint32_t) std::max(1, atoi(e));
+    bool lean_ok = fl_nt != 0;
+    if (const char *e = ropt.get("MIW_FILM_OVERLAP_LEAN")) lean_ok = lean_ok && atoi(e) != 0;
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipStreamWaitEvent(c->stream2[i], c->ev_fork, 0));
+    uint32_t launches = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += set, ++launches) {
+        hipStream_t b = c->stream2[launches % 3u];
+        const uint32_t g1 = std::min(n_groups, g0 + set);
+        if (wait_flags)
+            for (uint32_t g = g0; g < g1; ++g) {
+                const hipError_t e = hipStreamWaitValue32(b, c->h_group_flag + g, 1u, hipStreamWaitValueGte, 0xffffffffu);
+                if (e != hipSuccess) {                           // the runtime refuses stream memory operations
+                    (void) hipGetLastError();
+                    c->overlap_state = 0;
+                    if (g == 0) return MI_OK;                    // nothing has been launched: assemble_film replays as before
+                    return fail(c, MI_ERR_DEVICE, "hipStreamWaitValue32 failed mid-frame: %s", hipGetErrorString(e));
+                }
+            }
+        size_t e0 = 0, e1 = 0;
+        if (T.on) { HIP_TRY(c, T.get_event(e0)); HIP_TRY(c, hipEventRecord(c->ev_pool[e0], b)); }
+        // (a partial last group of tiles: the kernel's lanes past n_tiles idle, as in the one-launch replay)
+        // these sets run while the path kernel does — in the wave slots mi_render keeps free of it (MIW_FILM_OVERLAP_ROOM: on that many CUs the path kernel
+        // has three workgroups instead of four, which leaves 152 registers per SIMD) — as the 128-register form of the replay (two records in flight per lane)
+        const bool lean = lean_ok;
+        if (lean) hipLaunchKernelGGL((k_film_lanes<2, 1, 4>), dim3((g1 - g0) * n_pos), dim3(64), lbytes, b, P.film, R.A, PC, (uint32_t) n_tiles, c->d_tiles.p, g0, (uint32_t) prio);
+        else if (fl_nt) hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3((g1 - g0) * n_pos), dim3(64), lbytes, b, P.film, R.A, PC, (uint32_t) n_tiles, c->d_tiles.p, g0, (uint32_t) prio);
+        else hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3((g1 - g0) * n_pos), dim3(64), lbytes, b, P.film, R.A, PC, (uint32_t) n_tiles, c->d_tiles.p, g0, (uint32_t) prio);
+        if (T.on) { HIP_TRY(c, T.get_event(e1)); HIP_TRY(c, hipEventRecord(c->ev_pool[e1], b)); T.stamps.push_back({ 4, e0, e1 }); }
+    }
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipEventRecord(c->ev_join[i], c->stream2[i]));
+    c->replay_launches = launches;
+    R.beside = n_groups;
+    hipLaunchKernelGGL(k_raise_flags, dim3((n_all + 255u) / 256u), dim3(256), 0, s, c->h_group_flag, n_all);   // behind the path kernel: no wait outlives it
+    HIP_TRY(c, hipGetLastError());
+    c->replay_enqueued = true;
+    c->overlap_state = 1;
+    return MI_OK;
+}
+
 // ---- mi_render, phase "film": the ordered replay of the sample log into block tiles (device/film_kernels.h; which kernel: the log
 // format, the shard's tile count, the options) + the merge of the tiles into the film, or the resolve of the float64 sums ----
 static mi_status assemble_film(mi_ctx *c, const mi_render_cfg *cfg, const Options &ropt, const RenderParams &P, hipStream_t s, LaunchTimer &T, const FilmPlan &FP,
-                               uint32_t n_tiles, uint32_t bs, uint32_t bs2_log2, uint32_t blocks_x, uint32_t blocks_y, size_t film_n, void *film, mi_status result) {
+                               uint32_t n_tiles, uint32_t bs, uint32_t bs2_log2, uint32_t blocks_x, uint32_t blocks_y, size_t film_n, void *film, mi_status result,
+                               const FilmReplay *queued /* != nullptr: the replay's launches already sit in stream2 (overlap_enqueue) */) {
     const int film_mode = FP.film_mode; const bool rec16 = FP.rec16; const int film_lanes = FP.film_lanes; const uint32_t log_il = FP.log_il;
     (void) result;
 #define MIW_TIMED(cls_, launch) do {                                                   \
@@ -1390,21 +1531,11 @@ static mi_status assemble_film(mi_ctx *c, const mi_render_cfg *cfg, const Option
         float *dst32 = cfg->film_f64 ? nullptr : (float *) dst;
         double *dst64 = cfg->film_f64 ? (double *) dst : nullptr;
         if (film_mode == 1) {
-            // block -> tile map of this shard
-            std::vector<int32_t> block_tile(cfg->block_count, -1);
-            for (uint32_t t = 0; t < n_tiles; ++t) block_tile[cfg->tile_list ? cfg->tile_list[t] : t] = (int32_t) t;
-            HIP_TRY(c, c->d_block_tile.resize(cfg->block_count));
-            HIP_TRY(c, hipMemcpyAsync(c->d_block_tile.p, block_tile.data(), block_tile.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            BlockReplayArgs A;
-            A.log_pos = c->q_log_pos.p; A.log_val = c->q_log_val.p; A.st = c->q_st.p; A.spp = cfg->spp;
-            A.log_rec = rec16 ? c->q_log_rec.p : nullptr; A.log_il = rec16 ? log_il : 0u;
-            A.cls.thr = c->d_fc_thr.p; A.cls.w = c->d_fc_w.p; A.cls.count = rec16 ? c->classes.count : 0u; A.cls.reach = rec16 ? c->classes.reach : 0;
-            A.block_ids = c->d_block_ids.p; A.block_tile = c->d_block_tile.p;
-            A.tile_list = cfg->tile_list ? c->d_tile_list.p : nullptr;
-            A.blocks_x = blocks_x; A.blocks_y = blocks_y; A.bs2_log2 = bs2_log2;
-            const uint32_t side = bs + 2u * (uint32_t) cfg->filter_border;
-            A.tile_stride = side * side * MIW_FILM_CHANNELS;
-            HIP_TRY(c, c->d_tiles.resize((size_t) std::max<uint32_t>(n_tiles, 1) * A.tile_stride));
+            FilmReplay R;
+            if (queued) R = *queued;                              // (set up before the path kernel was launched)
+            else { const mi_status rs = film_replay_setup(c, cfg, s, FP, n_tiles, bs, bs2_log2, blocks_x, blocks_y, R); if (rs != MI_OK) return rs; }
+            BlockReplayArgs &A = R.A;
+            const uint32_t side = R.side;
             if (n_tiles) {
                 PatchArgs PA;
                 PA.patches_x = PA.patches_y = (side + MIW_FP_SIDE - 1) / MIW_FP_SIDE;
@@ -1442,12 +1573,16 @@ static mi_status assemble_film(mi_ctx *c, const mi_render_cfg *cfg, const Option
                     c->counters.film_kernel = lanes ? 4u : quads ? 3u : (columns == 42 || columns == 44 || columns == 82) ? 2u : 1u;   // (mi_counters)
                     if (lanes) {
                         PatchArgs PC = PA; PC.patches_x = PC.patches_y = (side + MIW_FL_BS - 1) / MIW_FL_BS;
-                        const uint32_t waves = ((uint32_t) n_tiles + 63u) / 64u * PC.patches_x * PC.patches_y;
                         const size_t lbytes = (size_t) (c->classes.count + 1u) * MIW_FQ_WSTRIDE(MIW_FL_BS) * sizeof(float);
                         int fl_nt = 1;                                    // the log read with streaming loads (16.8 vs 17.05 ms at C2, gpurun q9); MIW_FL_NT = 0: plain loads
                         if (const char *e = ropt.get("MIW_FL_NT")) fl_nt = atoi(e);
-                        if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
-                        else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p));
+                        // (the groups of 64 tiles below `first` were replayed beside the path kernel, on the replay streams: overlap_enqueue)
+                        const uint32_t first = queued ? queued->beside : 0u, groups_all = ((uint32_t) n_tiles + 63u) / 64u;
+                        const uint32_t waves_rest = (groups_all - first) * PC.patches_x * PC.patches_y;
+                        if (waves_rest == 0u) { }
+                        else if (fl_nt) MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 1>), dim3(waves_rest), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p, first, 0u));
+                        else MIW_TIMED(4, hipLaunchKernelGGL((k_film_lanes<4, 0>), dim3(waves_rest), dim3(64), lbytes, s, P.film, A, PC, (uint32_t) n_tiles, c->d_tiles.p, first, 0u));
+                        if (queued) { for (int i = 0; i < 3; ++i) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join[i], 0)); }
                     } else if (quads) {
                         PatchArgs PC = PA; PC.patches_x = (side + qw - 1) / qw; PC.patches_y = (side + qh - 1) / qh;
                         const uint32_t per_wave = 64u / qw, waves = (uint32_t) (((size_t) n_tiles * PC.patches_x * PC.patches_y + per_wave - 1u) / per_wave);
@@ -1572,6 +1707,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 
     // film mode: sample log + ordered gather if the log fits, else float64 atomics; the log's format and layout follow the replay kernel
     FilmPlan FP;
+    FilmReplay replay;                                            // (filled before the path kernel when the replay is queued beside it)
     { const mi_status fs = plan_film_log(c, cfg, ropt, P, s, plan, n_tiles, n_lanes, bs2, bs2_log2, film_n, FP); if (fs != MI_OK) return fs; }
     const int film_mode = FP.film_mode; const bool rec16 = FP.rec16; const int film_lanes = FP.film_lanes; const uint32_t log_il = FP.log_il;
     HIP_TRY(c, c->d_block_ids.resize(cfg->block_count));
@@ -1667,7 +1803,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.film_overlapped = 0; K.film_groups = 0; c->replay_enqueued = false; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
 
     LaunchTimer T{ c, K, cfg->profile != 0 };                    // HIP-event time per launch class (mi_counters::ms_*)
 #define MIW_TIMED(cls_, launch) do {                                                   \
@@ -1764,12 +1900,27 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         const uint32_t sync_every = 8;
         uint32_t launches = 0;
         bool place_stats_due = false;                              // (profile runs) the measuring launch's statistics, fetched after the last launch
+        // the film replay beside the render (overlap_prepare / overlap_enqueue above): frames replayed by k_film_lanes over the tile-interleaved log whose
+        // samples all run in ONE launch (a pixel is complete when that launch stores it), no placement, no time limit
+        // OPT-IN (MIW_FILM_OVERLAP=1): measured at C2 (gpurun r6k - r6m, profiles/r06_experiments.txt) it hides up to 3/4 of the replay and gains 0 - 1 % of the
+        // frame — the wave slots it needs cost the path kernel in proportion (32 workgroups short: +6 ms), a replay wavefront beside three packet-kernel
+        // wavefronts takes 20 - 30 ms instead of 5, and what is left after the path kernel cannot take less than one wavefront's chain (~8 - 10 ms)
+        int overlap_mode = 0;
+        if (const char *e = ropt.get("MIW_FILM_OVERLAP")) overlap_mode = atoi(e);
+        const bool overlap = overlap_mode != 0 && c->overlap_state != 0 && film_mode == 1 && FP.rec16 && FP.film_lanes != 0 && FP.log_il != 0 && !place && !phased /* (QueueWork<..., Groups = false>) */ && tiny && c->diffuse_only && !MIW_SPECTRAL && !direct /* the 120-register packet kernel: the only one a replay wavefront fits beside */ &&
+                             per_launch >= cfg->spp && cfg->timeout_s <= 0.f && n_tiles > 0;
         for (uint32_t done = 0; done < cfg->spp; ) {
             uint32_t end = cfg->spp - done < per_launch ? cfg->spp : done + per_launch;
             if (film_mode == 1) {
                 // persistent grid: <= 4 workgroups per CU, fed from the shared pixel queue
                 HIP_TRY(c, hipMemsetAsync(c->d_next_pixel.p, 0, c->d_next_pixel.n * sizeof(uint32_t), s));
                 rcfg.queues = 1u; Q.lane_cost = nullptr; Q.lane_sorted = nullptr; Q.piece_list = nullptr; Q.simd_ids = nullptr;
+                if (overlap && done == 0) {                          // the replay's arguments and the per-group counters, in front of the path kernel
+                    mi_status os = film_replay_setup(c, cfg, s, FP, n_tiles, bs, bs2_log2, blocks_x, blocks_y, replay);
+                    if (os == MI_OK) os = overlap_prepare(c, cfg, s, n_tiles, bs, blocks_x, Q, bs2_log2);
+                    if (os != MI_OK) return os;
+                    if (Q.group_done) HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+                }
                 if (place && done == 0) { end = measure_end; Q.lane_cost = c->d_lane_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch
                 else if (place) {
                     // the lanes by what their pixel cost, dearest first (device radix sort), cut into pieces of 64: consecutive sorted lanes
@@ -1821,7 +1972,13 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // shard of C2, profiles/r03.)
                 unsigned wg_per_cu = 4u;
                 if (const char *e = ropt.get("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
-                const dim3 pgrid(std::min<unsigned>(grid.x, (unsigned) c->cu_count * wg_per_cu));
+                unsigned room = 0u;                                // wave slots kept free for the replay that runs beside this launch (overlap_enqueue)
+                if (Q.group_done) { room = 32u; if (const char *e = ropt.get("MIW_FILM_OVERLAP_ROOM")) room = (unsigned) std::max(0, atoi(e)); }
+                // (room is counted from what is RESIDENT — the kernels compiled for three wavefronts per SIMD get a fourth workgroup per CU queued behind the
+                // first three, which would take every slot a shorter grid leaves)
+                const unsigned resident = (unsigned) c->cu_count * (direct ? (unsigned) MIW_DIRECT_WAVES : (unsigned) res_waves);
+                const unsigned full = room ? std::min((unsigned) c->cu_count * wg_per_cu, resident) : (unsigned) c->cu_count * wg_per_cu;
+                const dim3 pgrid(std::min<unsigned>(grid.x, full > 2u * room ? full - room : full));
 #define MIW_PATH_LAUNCH(T, M) MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, T, M, false>), pgrid, block, (T) != 0 ? rlds : rlds_plain, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p))
                 // kernel variants: no BSDF dispatch when every shape is plain diffuse (64-bit candidate masks: that
                 // variant fits 4 waves per SIMD without spills); else 32-bit candidate masks up to 32 triangles
@@ -1930,6 +2087,12 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 1>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
             else
                 MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<false, 0>), grid, block, c->lds_bytes + tile_bytes, s, P, c->view, Q, c->d_accum.p, c->d_cnt.p, c->lds_cfg, end, TA, (uint32_t *) nullptr));
+            if (Q.group_done) {                                      // the path kernel is in `s`: queue the replay beside it
+                const mi_status os = overlap_enqueue(c, ropt, P, s, T, replay, n_tiles, overlap_mode != 2);
+                if (os != MI_OK) return os;
+                if (c->replay_enqueued) { K.film_overlapped = 1u; K.film_groups = c->replay_launches; }
+                Q.group_done = nullptr; Q.group_expected = nullptr; Q.group_flag = nullptr;
+            }
             K.n_path++; K.iterations++;
             done = end;
             // cancel() / timeout take effect at launch granularity (the reference checks should_stop() per block)
@@ -2049,7 +2212,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
 #endif
 
     // film assembly -> caller's buffer (device pointer, or staged through d_out for a host pointer)
-    { const mi_status fs = assemble_film(c, cfg, ropt, P, s, T, FP, n_tiles, bs, bs2_log2, blocks_x, blocks_y, film_n, film, result); if (fs != MI_OK) return fs; }
+    { const mi_status fs = assemble_film(c, cfg, ropt, P, s, T, FP, n_tiles, bs, bs2_log2, blocks_x, blocks_y, film_n, film, result, c->replay_enqueued ? &replay : nullptr); c->replay_enqueued = false; if (fs != MI_OK) return fs; }
 #undef MIW_TIMED
     K.ms_render = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (result == MI_ERR_CANCELLED) c->error = "render cancelled";

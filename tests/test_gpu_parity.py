@@ -312,6 +312,17 @@ def test_film_replay_by_texel_blocks_on_tiny_blocks(native, oracle, crop, n_thre
     c = dev.counters()
     assert st == 0 and (c.film_kernel, c.log_interleaved, c.samples) == (4, 1, ost.samples)
     assert np.array_equal(film, o32)
+    # round 6, opt-in (MIW_FILM_OVERLAP=1): three quarters of that replay queued BESIDE the path kernel — sets of four 64-tile groups on three more streams,
+    # each behind the flags its groups' last finished pixels raise (miwave.hip: overlap_enqueue), the rest in one launch after it — is the same film
+    assert (c.film_overlapped, c.film_groups) == (0, 0)
+    dev.set_option("MIW_FILM_OVERLAP", "1")
+    launches = (((job.cfg.block_count + 63) // 64) * 3 // 4 + 3) // 4
+    for _ in range(2):                                            # (twice: the flags and counters of the frame before are reset)
+        beside, st = dev.render(job)
+        c1 = dev.counters()
+        assert st == 0 and np.array_equal(beside, o32) and c1.film_kernel == 4
+        assert (c1.film_overlapped, c1.film_groups) in ((1, launches), (0, 0)), (c1.film_overlapped, c1.film_groups)   # (0, 0): the runtime refuses stream memory operations
+    dev.set_option("MIW_FILM_OVERLAP", None)
     dev.close()
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU session of round 6 (overwritten per session; results under gpurun_out/<tag>_*). Usage: bash tools/gpu_session.sh <tag>
-# This one (r6j): the placed launch dealt in alternating rounds on the host (no cost copy, no heap): its parity tests, every rank's C2 / C3 shard
-tag=${1:-r6j}; out=$(pwd)/gpurun_out; mkdir -p $out
-(timeout 900 python -m pytest tests -m gpu -x -q -k "placed or shard or multi_gpu or options" 2>&1 | grep -v "^$" | tail -6) > $out/${tag}_pytest_placed.txt; grep -h "passed\|failed" $out/${tag}_pytest_placed.txt
-timeout 900 python tools/shard_table.py --configs c2,c3 --out $out/${tag}_shards.txt --json $out/${tag}_shards.json > $out/${tag}_shards.log 2>&1; grep -h "max-rank\|^floor" $out/${tag}_shards.txt
+# This one: the round's profile session on the final kernels (tools/profile_round.sh), the smoke entry and the whole GPU tier first
+tag=${1:-r06}; out=$(pwd)/gpurun_out; mkdir -p $out
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3) > $out/${tag}_smoke.txt; tail -1 $out/${tag}_smoke.txt
+(timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^$" | tail -12) > $out/${tag}_pytest_gpu.txt; grep -h "passed\|failed" $out/${tag}_pytest_gpu.txt
+LEAN=1 bash tools/profile_round.sh $tag > $out/${tag}_profile_round.log 2>&1; tail -30 $out/${tag}_profile_round.log

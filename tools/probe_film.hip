@@ -29,5 +29,6 @@ using namespace miw;
 template __global__ void k_film_columns<4, 2>(FilmRec, BlockReplayArgs, PatchArgs, float *);
 template __global__ void k_film_quads<2, 4, 4>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *);
 template __global__ void k_film_quads<4, 2, 4>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *);
-template __global__ void k_film_lanes<4, 0>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *);
-template __global__ void k_film_lanes<4, 1>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *);
+template __global__ void k_film_lanes<4, 0>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *, uint32_t, uint32_t);
+template __global__ void k_film_lanes<4, 1>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *, uint32_t, uint32_t);
+template __global__ void k_film_lanes<2, 1, 4>(FilmRec, BlockReplayArgs, PatchArgs, uint32_t, float *, uint32_t, uint32_t);   // the 128-register form that runs beside the path kernel (round 6)
