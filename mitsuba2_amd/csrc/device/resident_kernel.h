@@ -45,10 +45,10 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // clock out — four registers less carried through every body of the phase machine; shards of about one pixel per resident lane
 // get the Placed = true instantiation of their kernel. Clock: a pixel's cost is the time it held its lane (s_memtime, the phase
 // machine: its lanes do not iterate together) instead of the wavefront's iterations while it did (the lock-step packet kernel).
-// Groups: store() counts finished pixels per group of 64 tiles (the film replay beside the render, miwave.hip: overlap_prepare) — compiled into the lock-step /
-// packet kernels only: in the phase machine the same statements cost 16 more spilled registers (24 -> 40, tests/test_kernel_budget.py), and its frames spend
-// under 2 % in the replay.
-template <bool Placed = true, bool Clock = false, bool Groups = !Clock>
+// Groups: store() counts finished pixels per group of 64 tiles (the film replay beside the render, miwave.hip: overlap_prepare) — compiled into ONE more
+// instantiation of the plain-diffuse packet kernel, launched when that replay is asked for (the only path kernel a replay wavefront fits beside; the default
+// kernels stay as they were: the statements cost the packet kernel ~1 ms of its 247 even when switched off, the phase machine 16 more spilled registers).
+template <bool Placed = true, bool Clock = false, bool Groups = false>
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
@@ -192,8 +192,19 @@ struct QueueWork {
 #endif
 // Analytic: the scene holds analytic shapes (rectangles); packet scenes (Tiny) never do.
 // Integ: which SamplingIntegrator::sample the pixel loop runs (path.h / direct.h).
-template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH>
-__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? 4 : 3) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+// Wavefronts per SIMD the packet kernels are compiled for = workgroups per CU mi_render launches of them. Round 6 (gpurun r6n): the plain-diffuse kernel — the
+// headline's — at FIVE (96 registers; 12 values spilled, stored once in front of the pixel loop and reloaded at a dozen places of its body, none inside the box or
+// candidate loops): 248.1 -> 238.3 ms at C2, the film bit-identical — the kernel's throughput follows its resident wavefronts (32 workgroups short of the device cost
+// it 2.4 %, r6l), and the spills that made a fifth wavefront 21 - 30 % SLOWER in round 3 went away with the register diets of rounds 3 - 5. Six: 81 spilled, no.
+// The other scalar_rgb packet kernels (BSDF dispatch, textures) fit 128 registers without scratch: four instead of three; the spectral ones do not (93 spilled): three.
+#ifndef MIW_PACKET_WAVES_ALL
+#define MIW_PACKET_WAVES_ALL (MIW_SPECTRAL ? 3 : 4)
+#endif
+#ifndef MIW_PACKET_WAVES
+#define MIW_PACKET_WAVES 5
+#endif
+template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH, bool Groups = false>
+__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? MIW_PACKET_WAVES : MIW_PACKET_WAVES_ALL) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES
         trace2<Tiny, Analytic>(sc, cfg, smem, o, mint, dE, maxtE, hasE, dS, maxtS, hasS, hE, occS);
     };
     if (UseLog) {
-        QueueWork<Tiny != 0> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+        QueueWork<Tiny != 0, false, Groups> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
         work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
         __shared__ uint32_t s_prog[MIW_BLOCK / 64];
         if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);

@@ -1862,7 +1862,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         if (stack8_sized && !phased8) return fail(c, MI_ERR_STATE, "render: the LDS stack was sized for the 8-wide walk, which this launch does not run");
         SceneView view8 = c->view;
         if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
-        const uint32_t res_waves = phased ? (uint32_t) ph_waves : (c->diffuse_only && !MIW_SPECTRAL ? 4u : 3u);
+        // wavefronts per SIMD of the path kernel this render launches (resident_kernel.h / phased_kernel.h / trace.h: what each is compiled for)
+        const uint32_t res_waves = phased ? (uint32_t) ph_waves : !tiny ? (uint32_t) MIW_TREE_WAVES : (c->diffuse_only && !MIW_SPECTRAL ? (uint32_t) MIW_PACKET_WAVES : (uint32_t) MIW_PACKET_WAVES_ALL);
         bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = ropt.get("MIW_PLACE")) place = place && atoi(e) != 0;
@@ -1966,11 +1967,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     K.placed = 1u;
                     }
                 }
-                // persistent grid: 4 workgroups per CU. The plain-diffuse packet kernel is compiled for 4 waves per SIMD
-                // (128 VGPRs; +8 % over 3 on C2). (Round 2 launched 3 per CU for shards of about one pixel per resident lane; with the
+                // persistent grid: as many workgroups per CU as the kernel is compiled for wavefronts per SIMD — the plain-diffuse packet kernel FIVE since
+                // round 6 (96 registers: 248.1 -> 238.3 ms at C2, resident_kernel.h), the other scalar_rgb packet kernels four. (Round 2 launched 3 per CU for shards of about one pixel per resident lane; with the
                 // least-progress-first priorities below every pixel of such a shard should start at once: 42.3 vs 49.6 ms on the 1/8
                 // shard of C2, profiles/r03.)
-                unsigned wg_per_cu = 4u;
+                unsigned wg_per_cu = std::max(4u, direct ? 4u : (unsigned) res_waves);   // (never fewer than four: a kernel compiled for three keeps a fourth workgroup queued behind them)
                 if (const char *e = ropt.get("MIW_WG_PER_CU")) wg_per_cu = (unsigned) std::max(1, atoi(e));
                 unsigned room = 0u;                                // wave slots kept free for the replay that runs beside this launch (overlap_enqueue)
                 if (Q.group_done) { room = 32u; if (const char *e = ropt.get("MIW_FILM_OVERLAP_ROOM")) room = (unsigned) std::max(0, atoi(e)); }
@@ -2070,6 +2071,10 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     else MIW_DIRECT_LAUNCH(0, MATS_PLAIN, true);
 #undef MIW_DIRECT_LAUNCH
                 }
+                else if (Q.group_done && c->view.tri_count <= 32u)     // (overlap: tiny && diffuse_only) the instantiation that counts finished pixels per group of 64 tiles
+                    MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 2, MATS_DIFFUSE, false, INTEG_PATH, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+                else if (Q.group_done)
+                    MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_DIFFUSE, false, INTEG_PATH, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 else if (tiny && c->diffuse_only && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_DIFFUSE);   // 32-bit candidate masks (BASELINE config 2: 32 triangles)
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in

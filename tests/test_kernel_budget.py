@@ -33,8 +33,29 @@ def _resources(probe, kernel, tmp_path, *defs):
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
 
 
-def test_cornell_packet_kernel_fits_four_waves_without_spills(tmp_path):
+def test_cornell_packet_kernel_fits_five_waves_with_no_scratch_in_its_inner_loops(tmp_path):
+    """The headline kernel (BASELINE configs[1]): since round 6 compiled for FIVE wavefronts per SIMD — 96 registers, at most 12 values in scratch, stored once in
+    front of the pixel loop and reloaded in its body, never inside the leaf-box or candidate loops (resident_kernel.h: MIW_PACKET_WAVES; 248.1 -> 238.3 ms, gpurun r6n).
+    At four (-DMIW_PACKET_WAVES=4: rounds 3 - 5) it fits 128 registers without any."""
     r = _resources("probe_resident.hip", "k_path_residentILb1ELi2ELi1ELb0ELj0E", tmp_path)
+    assert r["waves"] == 5 and r["vgprs"] <= 96 and r["spilled"] <= 12, r
+    out = subprocess.run([HIPCC] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-S", os.path.join(ROOT, "tools", "probe_resident.hip"),
+                          "--cuda-device-only", "-o", str(tmp_path / "probe.s")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = open(tmp_path / "probe.s").read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z15k_path_residentILb1ELi2ELi1ELb0ELj0E"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    depth = ""
+    inner = total = 0
+    for l in lines[start:end]:
+        m = re.match(r"^\.LBB\d+_\d+:\s*;?(.*)", l)
+        if m:
+            depth = m.group(1)
+        if "scratch_" in l:
+            total += 1
+            inner += 0 if re.search(r"Depth=1\b", depth) or "Depth=" not in depth else 1
+    assert total <= 24 and inner == 0, (total, inner)
+    r = _resources("probe_resident.hip", "k_path_residentILb1ELi2ELi1ELb0ELj0E", tmp_path, "-DMIW_PACKET_WAVES=4")
     assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] == 0, r
 
 
