@@ -196,6 +196,8 @@ struct QueueWork {
 // headline's — at FIVE (96 registers; 12 values spilled, stored once in front of the pixel loop and reloaded at a dozen places of its body, none inside the box or
 // candidate loops): 248.1 -> 238.3 ms at C2, the film bit-identical — the kernel's throughput follows its resident wavefronts (32 workgroups short of the device cost
 // it 2.4 %, r6l), and the spills that made a fifth wavefront 21 - 30 % SLOWER in round 3 went away with the register diets of rounds 3 - 5. Six: 81 spilled, no.
+// (Five is for the kernel with 32-bit candidate masks, Tiny == 2: scenes of <= 32 triangles; its 64-bit twin, Tiny == 1, would spill 45 at 96 registers
+// and stays at four, unmeasured at five.)
 // The other scalar_rgb packet kernels (BSDF dispatch, textures) fit 128 registers without scratch: four instead of three; the spectral ones do not (93 spilled): three.
 #ifndef MIW_PACKET_WAVES_ALL
 #define MIW_PACKET_WAVES_ALL (MIW_SPECTRAL ? 3 : 4)
@@ -204,7 +206,7 @@ struct QueueWork {
 #define MIW_PACKET_WAVES 5
 #endif
 template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH, bool Groups = false>
-__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? MIW_PACKET_WAVES : MIW_PACKET_WAVES_ALL) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? (Tiny == 2 ? MIW_PACKET_WAVES : 4) : MIW_PACKET_WAVES_ALL) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);

@@ -1863,7 +1863,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         SceneView view8 = c->view;
         if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
         // wavefronts per SIMD of the path kernel this render launches (resident_kernel.h / phased_kernel.h / trace.h: what each is compiled for)
-        const uint32_t res_waves = phased ? (uint32_t) ph_waves : !tiny ? (uint32_t) MIW_TREE_WAVES : (c->diffuse_only && !MIW_SPECTRAL ? (uint32_t) MIW_PACKET_WAVES : (uint32_t) MIW_PACKET_WAVES_ALL);
+        const uint32_t res_waves = phased ? (uint32_t) ph_waves : !tiny ? (uint32_t) MIW_TREE_WAVES : (c->diffuse_only && !MIW_SPECTRAL ? (c->view.tri_count <= 32u ? (uint32_t) MIW_PACKET_WAVES : 4u) : (uint32_t) MIW_PACKET_WAVES_ALL);
         bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = ropt.get("MIW_PLACE")) place = place && atoi(e) != 0;
