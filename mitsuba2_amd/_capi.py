@@ -128,7 +128,8 @@ class mi_counters(C.Structure):
                 ("tree_width", C.c_uint32), ("bvh8_nodes", C.c_uint32), ("bvh8_depth", C.c_uint32), ("bvh8_on_device", C.c_uint32), ("ms_bvh8", C.c_double),
                 ("place_cost_max", C.c_uint32), ("place_cost_unit", C.c_uint32), ("place_max_pixel", C.c_uint32), ("place_measure_spp", C.c_uint32),
                 ("place_cost_mean", C.c_double), ("film_kernel", C.c_uint32), ("log_interleaved", C.c_uint32),
-                ("pooled", C.c_uint32), ("pool_waves", C.c_uint32), ("film_overlapped", C.c_uint32), ("film_groups", C.c_uint32)]
+                ("pooled", C.c_uint32), ("pool_waves", C.c_uint32), ("film_overlapped", C.c_uint32), ("film_groups", C.c_uint32),
+                ("job_chunk", C.c_uint32), ("job_chunks", C.c_uint32)]
 
 
 MI_INTEGRATOR_PATH, MI_INTEGRATOR_DIRECT = 0, 1

@@ -97,6 +97,9 @@ static_assert(MIW_STACK_ENTRIES * sizeof(int32_t) >= MIW_BVH8_STACK * sizeof(U2)
 // Placed: the pixel queue is QueueWork<true> (resident_kernel.h) — shards of about one pixel per resident lane: a measuring launch,
 // then every wavefront takes pixels of about equal cost from the queue of its SIMD. The full-frame kernel keeps Placed = false
 // and the four registers the queue choice costs.
+#ifndef MIW_PHASED_JOBS
+#define MIW_PHASED_JOBS 1      /* the full-frame instantiations draw chunk jobs (resident_kernel.h: QueueWork::fetch_job); 0 compiles them out (A/B builds) */
+#endif
 template <int Mats, bool Analytic, bool Spec, int Waves = MIW_TREE_WAVES, int Wide = 1, bool Placed = false>
 __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P, SceneView sc, LaneQueues Q, Counters *cnt,
                                                                              TraceLds cfg, uint32_t sample_end, uint32_t *next_pixel) {
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
     if ((threadIdx.x & 63u) == 0) { unsigned long long *b_ = miw_sec_buf(); for (int i = 0; i < 15; ++i) b_[i] = 0; b_[15] = __builtin_amdgcn_s_memtime(); }
 #endif
 
-    QueueWork<Placed, true> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+    QueueWork<Placed, true, false, MIW_PHASED_JOBS != 0 && !Placed> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     work.film = &P.film; work.thr = thr; work.init_queues(cfg.queues ? cfg.queues : 1u);
     __shared__ uint32_t s_prog[MIW_BLOCK / 64];
     if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[threadIdx.x >> 6]);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                         lane_finish_sample(P, pixel, L, sink);
                         local.samples++;
                         L.flags = 0;
-                        lane_begin_sample(P, pixel, L, sample_end);
+                        lane_begin_sample(P, pixel, L, work.job_end(L.sample_idx, sample_end));   // (the end of the lane's JOB: chunk jobs, resident_kernel.h)
                     }
                 }
                 MIW_SECTION(11);
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     L.sample_idx = st.w; L.flags = 0;
                     lane_begin_sample(P, pixel, L, sample_end);
                 }
-                if (L.flags & LF_DONE) mode = PH_OUT;
+                if (L.flags & LF_DONE) mode = work.exhausted() ? PH_OUT : PH_SHADE;   // (not exhausted: a chunk job waiting for the chunk before it — it asks again in the next shade run)
                 else if (!dead_pending) { mode = PH_TRAV_E; begin_walk(L.ray.d, L.ray.maxt); }
                 else { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }       // dead_pending implies a queued shadow ray
             }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_path_pooled(RenderParams P, Scen
     const PrimCtx ctx = prim_ctx(sc);
     LaneCounters local; local.segments = local.samples = local.shadow_rays = 0;
 
-    QueueWork<false, true> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
+    QueueWork<false, true, false, false> work; work.Q = &Q; work.next_pixel = next_pixel; work.n_lanes = P.n_lanes; work.spp = P.spp; work.lane = 0; work.warn_negative = P.film.warn_negative;
     work.film = &P.film; work.thr = thr; work.init_queues(1u);
     __shared__ uint32_t s_prog[NW];
     if (cfg.tail_prio) work.enable_tail_prio(sample_end, &s_prog[wv]);

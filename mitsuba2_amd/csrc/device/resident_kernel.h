@@ -48,7 +48,8 @@ struct TileArgs {               // film_mode 2 in the resident plan; side == 0: 
 // Groups: store() counts finished pixels per group of 64 tiles (the film replay beside the render, miwave.hip: overlap_prepare) — compiled into ONE more
 // instantiation of the plain-diffuse packet kernel, launched when that replay is asked for (the only path kernel a replay wavefront fits beside; the default
 // kernels stay as they were: the statements cost the packet kernel ~1 ms of its 247 even when switched off, the phase machine 16 more spilled registers).
-template <bool Placed = true, bool Clock = false, bool Groups = false>
+// Jobs: chunk jobs (below) compiled in — the packet kernels always, the phase machine's full-frame instantiations by MIW_PHASED_JOBS (phased_kernel.h).
+template <bool Placed = true, bool Clock = false, bool Groups = false, bool Jobs = true>
 struct QueueWork {
     const LaneQueues *Q; uint32_t *next_pixel; uint32_t n_lanes, spp, lane, warn_negative;
     const FilmRec *film; const float *thr;      // 16-byte records (Q->log_rec): the film geometry and the phase thresholds in LDS
@@ -68,6 +69,7 @@ struct QueueWork {
     __device__ __forceinline__ void init_queues(uint32_t queues) {
         nq = Placed ? queues : 1u; per = nq > 1u ? MIW_PLACE_PIECES * 64u : n_lanes; q = 0u; dry = 0; t_fetch = 0;
         ticks = 0; quarter = 0; tail_prio = 0; sample_end_ = spp;
+        if (Jobs) job_pend() = 0u;                              // (each lane its own word: no barrier)
         if (Placed && Q->simd_ids) {
             // which SIMD this wavefront runs on. The measuring launch only marks the SIMD as present (the host numbers the present
             // ones 0 .. n - 1 afterwards); the placed launch looks its queue up.
@@ -107,7 +109,55 @@ struct QueueWork {
     __device__ __forceinline__ void enable_tail_prio(uint32_t sample_end, uint32_t *wave_word) {
         tail_prio = 1u; sample_end_ = sample_end; quarter = 0; prog = wave_word; *prog = 0xffffffffu; __builtin_amdgcn_s_setprio(3);
     }
+    // ---- chunk jobs (round 6; LaneQueues::job_chunk != 0: full frames, one queue, all samples in one launch) ----
+    // Why: a pixel's samples are one serial job (one PCG32 stream per pixel, integrator.cpp:196-209) of ~35 ms at C2, the lanes are not in step, so when the
+    // queue runs dry every lane is somewhere inside such a job: the last ~35 ms of the launch run at falling lane occupancy. Measured (gpurun r6o): the path
+    // kernel's time is a straight line in the pixel count, 102.4 ns per pixel + 26.5 ms that do not depend on it — 11 % of the headline kernel. A pixel's state is
+    // 16 bytes (Q->st), so a pixel can change lanes between two samples: the queue holds (chunk, slot) pairs, chunk-major, every lane draws from it until it is
+    // empty, and the tail is as long as ONE CHUNK. Chunk j of a slot is ready when the slot's sample counter stands at its first sample — its predecessor
+    // is n_lanes jobs back in the queue, complete long ago in a frame of several pixels per lane. If it is not, the lane must not spin here (the lane running
+    // the chunk before may be a neighbour in this very wavefront): it parks the job in its word of LDS (id + 1; 0: none; ~0: the queue is empty), reports "nothing
+    // now" and asks again on its next trip. The state words cross CUs and XCDs inside one launch: sc1 accesses (past the XCD's L2), the RNG words
+    // written first, the counter words after they have landed; the reader takes all four in ONE 16-byte load (never the new counter beside the old RNG words).
+    // Cost: one atomic on one address per job — chunks of 8 / 16 / 32 samples ran the frame in 702 / 496 / 305 ms (gpurun r6p; 64 and 128: 226.8 / 226.5,
+    // 256: 230.6, jobs of whole pixels: 239.3) — so mi_render cuts chunks of at least 64 samples.
+    typedef uint32_t U4v __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ static uint32_t &job_pend() { __shared__ uint32_t s_job_pend[MIW_BLOCK]; return s_job_pend[threadIdx.x & (MIW_BLOCK - 1)]; }
+    __device__ __forceinline__ bool exhausted() const { return !Jobs || !Q->job_chunk || job_pend() == 0xffffffffu; }   // after fetch() said false: for good, or "ask again"
+    __device__ __forceinline__ uint32_t job_end(uint32_t sample_idx, uint32_t sample_end) const {   // called after a sample has finished: sample_idx >= 1
+        return Jobs && (sample_idx & Q->job_mask) == 0u ? sample_idx : sample_end;              // (job_mask = job_chunk - 1, or ~0 without chunks: never zero then)
+    }
+    __device__ __forceinline__ bool fetch_job(uint32_t &pixel, U4 &st) {
+        for (;;) {
+            const uint32_t parked = job_pend();
+            if (parked == 0xffffffffu) return false;
+            uint32_t id = parked - 1u;
+            const bool fresh = parked == 0u;
+            const unsigned long long b = __ballot(fresh);
+            if (fresh) {
+                const uint32_t me = threadIdx.x & 63u, leader = (uint32_t) __ffsll((long long) b) - 1u;
+                uint32_t base = 0;
+                if (me == leader) base = atomicAdd(next_pixel, (uint32_t) __popcll(b));
+                base = (uint32_t) __shfl((int) base, (int) leader, 64);
+                id = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u));
+                if (id >= Q->job_total) { job_pend() = 0xffffffffu; return false; }
+            }
+            const uint32_t j = id / n_lanes, slot = id - j * n_lanes;
+            const uint32_t px = Q->pixel[slot];
+            U4v w;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(Q->st + slot) : "memory");
+#endif
+            if (w.z & LF_DONE) { job_pend() = 0u; continue; }                     // pixel outside its clipped block, or already complete
+            if (w.w != Q->job_first + j * Q->job_chunk) { job_pend() = id + 1u; return false; }   // the chunk before is still running: ask again
+            job_pend() = 0u;
+            lane = slot; pixel = px;
+            st.x = w.x; st.y = w.y; st.z = w.z; st.w = w.w;
+            return true;
+        }
+    }
     __device__ __forceinline__ bool fetch(uint32_t &pixel, U4 &st) {
+        if (Jobs && Q->job_chunk) return fetch_job(pixel, st);       // (wave-uniform)
         for (;;) {
             if (!Placed) {                                      // one queue: a ballot, one atomic, the lanes' ranks
                 const unsigned long long b = __ballot(1);
@@ -159,6 +209,13 @@ struct QueueWork {
         return Clock ? (uint32_t) (__builtin_amdgcn_s_memtime() >> 8) : ticks;      // units of 256 shader cycles, or wavefront iterations
     }
     __device__ __forceinline__ void store(U4 st) {
+        if (Jobs && Q->job_chunk) {                             // chunk jobs: another lane (another XCD) takes the pixel on inside this launch
+            unsigned long long *words = reinterpret_cast<unsigned long long *>(Q->st + lane);
+            __hip_atomic_store(words, (unsigned long long) st.x | ((unsigned long long) st.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the RNG words have landed before the counter that publishes them leaves
+            __hip_atomic_store(words + 1, (unsigned long long) st.z | ((unsigned long long) st.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         Q->st[lane] = st;
         if (Placed && Q->lane_cost) Q->lane_cost[lane] = cost_clock() - t_fetch + 1u;   // what this pixel cost in this (the measuring) launch
         // film replay beside the render: this pixel's log is complete — count it in its group of 64 tiles; the pixel that completes the group
@@ -205,8 +262,11 @@ struct QueueWork {
 #ifndef MIW_PACKET_WAVES
 #define MIW_PACKET_WAVES 5
 #endif
-template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH, bool Groups = false>
-__global__ __launch_bounds__(MIW_BLOCK, Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? (Tiny == 2 ? MIW_PACKET_WAVES : 4) : MIW_PACKET_WAVES_ALL) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
+// Waves != 0 names the wavefronts per SIMD outright: <..., 4> of the plain-diffuse kernel is the 128-register form (no scratch) that a SHARD of at most four
+// wavefronts' worth of pixels per SIMD gets — a rank's eighth of a 1080p frame is 4 050 wavefronts for 1 024 SIMDs: a fifth wave slot would stay empty and the
+// 96-register squeeze costs each wavefront 3.4 % (r6n: 256.4 vs 248.0 ms with four workgroups per CU).
+template <bool UseLog, int Tiny, int Mats = MATS_ALL, bool Analytic = (Tiny == 0), uint32_t Integ = INTEG_PATH, bool Groups = false, int Waves = 0>
+__global__ __launch_bounds__(MIW_BLOCK, Waves ? Waves : Integ == INTEG_DIRECT ? MIW_DIRECT_WAVES : Tiny ? ((Mats == MATS_DIFFUSE && !MIW_SPECTRAL) ? (Tiny == 2 ? MIW_PACKET_WAVES : 4) : MIW_PACKET_WAVES_ALL) : MIW_TREE_WAVES) void k_path_resident(RenderParams P, SceneView sc, LaneQueues Q, double *accum, Counters *cnt,
                                                                TraceLds cfg, uint32_t sample_end, TileArgs T, uint32_t *next_pixel) {
     extern __shared__ uint4 smem[];
     stage_to_lds(sc, cfg, smem);

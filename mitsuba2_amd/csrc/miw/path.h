@@ -77,6 +77,11 @@ struct LaneQueues {
     // 64 tiles, how many pixels have run all their samples (group_done, device memory) against how many there are (group_expected); the pixel
     // that completes a group raises its flag (group_flag: host-coherent memory the replay's stream waits on). nullptr: off
     uint32_t *group_done = nullptr; const uint32_t *group_expected = nullptr; uint32_t *group_flag = nullptr; uint32_t group_shift = 0;
+    // pixel jobs cut into CHUNKS of samples (round 6; device/resident_kernel.h: QueueWork::fetch, full frames of the packet kernels): the queue holds
+    // (chunk, pixel slot) pairs, chunk-major — job_total = slots x chunks of this launch; chunk j of a pixel covers the samples
+    // [job_first + j * job_chunk, + job_chunk) and is ready once the slot's state word says the chunk before it is complete. job_chunk = 0: a job = all the
+    // launch's samples of a pixel (every other kernel). A power of two; job_first a multiple of it.
+    uint32_t job_chunk = 0, job_first = 0, job_total = 0, job_mask = 0xffffffffu;   // job_mask = job_chunk - 1 (~0 without chunks: `sample index & mask` is never 0 after a sample)
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)
@@ -506,7 +511,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
             }
             U4 st;
             have = work.fetch(pixel, st);
-            if (!have) break;
+            if (!have) { if (work.exhausted()) break; continue; }    // (not exhausted: the job this lane drew waits for the chunk before it — ask again next trip)
             L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
             L.sample_idx = st.w; L.flags = 0;
             lane_begin_sample(P, pixel, L, sample_end);
@@ -531,7 +536,7 @@ MIW_HD void pixel_stream_render(const RenderParams &P, const SceneView &sc, uint
         lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
-        lane_begin_sample(P, pixel, L, sample_end);
+        lane_begin_sample(P, pixel, L, work.job_end(L.sample_idx, sample_end));   // (the end of this lane's JOB: the launch's last sample, or the chunk's)
         MIW_SECTION(5);
     }
 }
@@ -548,6 +553,8 @@ MIW_HD U4 pixel_render(const RenderParams &P, const SceneView &sc, uint32_t pixe
         uint32_t pixel; U4 st; bool taken; Sink sink;
         MIW_HD bool fetch(uint32_t &px, U4 &s) { if (taken) return false; taken = true; px = pixel; s = st; return true; }
         MIW_HD void store(U4 s) { st = s; }
+        MIW_HD bool exhausted() const { return true; }
+        MIW_HD uint32_t job_end(uint32_t, uint32_t sample_end) const { return sample_end; }
         MIW_HD void tick(uint32_t, bool) { }
         MIW_HD void put(uint32_t px, uint32_t sample_idx, V2 pos, const float *aovs) { sink(px, sample_idx, pos, aovs); }
     } work{ pixel, st, false, sink };

@@ -154,6 +154,9 @@ static const KnobInfo g_knobs[] = {
     { "MIW_TAIL_PRIO", "0: no least-progress-first wave priorities" },
     { "MIW_WG_PER_CU", "workgroups per CU of the packet kernels' persistent grid" },
     { "MIW_PLACE", "0: shards of about one pixel per lane skip the measuring launch + placed queues" },
+    { "MIW_JOB_CHUNK", "samples per pixel job of a full packet-kernel frame (a power of two; default spp / 8, at least 8): the pixels' sample streams are cut into chunks drawn chunk-major from one queue; 0: a job = all the samples of a pixel. MIW_JOB_CHUNK_FORCE=1: also for frames of fewer than two pixels per resident lane (tests)" },
+    { "MIW_JOB_CHUNK_FORCE", "1: chunk jobs whatever the frame's size (tests of the hand-over between lanes)" },
+    { "MIW_PACKET_SHARD4", "0: a plain-diffuse packet job of at most four wavefronts of pixels per SIMD keeps the five-wavefront (96-register) kernel" },
     { "MIW_PLACE_MEASURE", "divisor: the measuring launch runs spp / divisor samples" },
     { "MIW_PLACE_SPREAD", "0 | 1: placed pieces = consecutive sorted lanes | one lane of every cost stratum" },
     { "MIW_STREAM", "0: plan 1 walks with one kernel per list slice instead of the persistent stream kernel" },
@@ -629,7 +632,7 @@ mi_status mi_scene_upload(mi_ctx *c, const mi_scene_desc *s) {
 // dwords of the tables stage_tables() copies into LDS (shapes, bsdfs, emitters, emit_tri, emit_vnorm, emit_pmf, emit_cdf), each
 // padded to 16 bytes; returns the bytes of the block
 #define MIW_LDS_PER_WORKGROUP (40u * 1024u)       /* 160 KB per CU / four workgroups of 256 (four wavefronts per SIMD) */
-#define MIW_LDS_STATIC 0u                         /* static __shared__ of k_path_phased: s_prog, 16 bytes — inside the granule below */
+#define MIW_LDS_STATIC 1024u                      /* static __shared__ of k_path_phased: s_job_pend (QueueWork: a word per lane); s_prog, 16 bytes, inside the granule below */
 #define MIW_LDS_GRANULE 512u                      /* LDS is handed out in granules: dynamic + static, rounded up, must stay inside 40 KB */
 static size_t lds_table_bytes(const mi_ctx *c, uint32_t words[10], bool with_tris) {
     words[0] = (uint32_t) (c->shapes.size() * sizeof(ShapeRec) / 4); words[1] = (uint32_t) (c->bsdfs.size() * sizeof(BsdfRec) / 4);
@@ -1803,7 +1806,7 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
     mi_counters &K = c->counters;
     K.samples = K.segments = K.shadow_rays = K.iterations = 0; K.lanes = n_lanes;
     K.ms_trace_closest = K.ms_trace_any = K.ms_shade = K.ms_init = K.ms_resolve = K.ms_path = K.ms_film_blocks = K.ms_film_merge = K.ms_film_pack = 0;
-    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.film_overlapped = 0; K.film_groups = 0; c->replay_enqueued = false; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
+    K.n_trace_closest = K.n_trace_any = K.n_shade = K.n_path = 0; K.path_kernel = 0; K.placed = 0; K.tree_width = 0; K.pooled = 0; K.pool_waves = 0; K.film_overlapped = 0; K.film_groups = 0; K.job_chunk = 0; K.job_chunks = 0; c->replay_enqueued = false; K.place_cost_max = K.place_cost_unit = K.place_max_pixel = K.place_measure_spp = 0; K.place_cost_mean = 0.0;
 
     LaunchTimer T{ c, K, cfg->profile != 0 };                    // HIP-event time per launch class (mi_counters::ms_*)
 #define MIW_TIMED(cls_, launch) do {                                                   \
@@ -1863,7 +1866,11 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
         SceneView view8 = c->view;
         if (phased8) { view8.nodes8 = c->d_nodes8.p; view8.tris = c->d_tris8.p; if (view8.tri_vn) view8.tri_vn = c->d_tri_vn8.p; }
         // wavefronts per SIMD of the path kernel this render launches (resident_kernel.h / phased_kernel.h / trace.h: what each is compiled for)
-        const uint32_t res_waves = phased ? (uint32_t) ph_waves : !tiny ? (uint32_t) MIW_TREE_WAVES : (c->diffuse_only && !MIW_SPECTRAL ? (c->view.tri_count <= 32u ? (uint32_t) MIW_PACKET_WAVES : 4u) : (uint32_t) MIW_PACKET_WAVES_ALL);
+        // (the plain-diffuse packet kernel of <= 32 triangles: five — or, when the job's pixels fill no more than four wavefronts per SIMD (a rank's shard), the
+        // 128-register instantiation for four: resident_kernel.h; MIW_PACKET_SHARD4=0 keeps five)
+        bool packet_shard4 = !phased && tiny && c->diffuse_only && !MIW_SPECTRAL && !direct && c->view.tri_count <= 32u && MIW_PACKET_WAVES > 4 && film_mode == 1 && n_lanes <= 64u * 4u * n_simd;
+        if (const char *e = ropt.get("MIW_PACKET_SHARD4")) packet_shard4 = packet_shard4 && atoi(e) != 0;
+        const uint32_t res_waves = phased ? (uint32_t) ph_waves : !tiny ? (uint32_t) MIW_TREE_WAVES : (c->diffuse_only && !MIW_SPECTRAL ? (c->view.tri_count <= 32u && !packet_shard4 ? (uint32_t) MIW_PACKET_WAVES : 4u) : (uint32_t) MIW_PACKET_WAVES_ALL);
         bool place = film_mode == 1 && !direct && (tiny || phased_placeable) && n_lanes >= 64u * n_simd / 2u && n_lanes <= 64u * res_waves * n_simd &&
                      cfg->spp >= 128u && per_launch >= cfg->spp && cfg->timeout_s <= 0.f;
         if (const char *e = ropt.get("MIW_PLACE")) place = place && atoi(e) != 0;
@@ -1921,6 +1928,25 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     if (os == MI_OK) os = overlap_prepare(c, cfg, s, n_tiles, bs, blocks_x, Q, bs2_log2);
                     if (os != MI_OK) return os;
                     if (Q.group_done) HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+                }
+                // chunk jobs (resident_kernel.h: QueueWork::fetch): full frames of the packet kernels, all samples in one launch. Without them a frame of N pixels
+                // on L resident lanes lasts ceil(N / L) rounds of one PIXEL (every lane starts at once, a pixel's samples are one serial job, the jobs are about
+                // equally long): C2 = 6.33 -> 7; with chunks of spp / 8 samples ceil(8 N / L) / 8 = 6.375.
+                Q.job_chunk = Q.job_first = Q.job_total = 0u; Q.job_mask = 0xffffffffu;
+                // Every job costs one atomic on ONE address (the queue's counter) and a hand-over (a 16-byte state word out and in, past the L2): chunks of
+                // 8 / 16 / 32 samples ran C2 in 702 / 496 / 305 ms, 64 / 128 / 256 in 226.8 / 226.5 / 230.6, whole pixels in 239.3 (gpurun r6p) — chunks of spp / 8,
+                // never fewer than 64 samples. The phase machine's full frames (C3, C4) take the same queue.
+                if ((tiny || (phased && MIW_PHASED_JOBS != 0)) && !pooled_fits && !direct && !place && !overlap && done == 0 && per_launch >= cfg->spp && cfg->timeout_s <= 0.f) {
+                    uint32_t chunk = 64u;
+                    while (chunk * 16u <= cfg->spp) chunk *= 2u;                      // spp / 8 rounded down to a power of two, at least 64
+                    if (const char *e = ropt.get("MIW_JOB_CHUNK")) { const uint32_t v = (uint32_t) std::max(0, atoi(e)); chunk = (v & (v - 1u)) ? 0u : v; }
+                    bool enough = n_lanes >= 2u * 64u * res_waves * n_simd;            // (a frame of one or two rounds gains nothing and pays the hand-overs)
+                    if (const char *e = ropt.get("MIW_JOB_CHUNK_FORCE")) enough = enough || atoi(e) != 0;
+                    const uint64_t chunks = chunk ? ((uint64_t) cfg->spp + chunk - 1u) / chunk : 0u;
+                    if (chunk && enough && chunks >= 2u && (uint64_t) n_lanes * chunks < (1ull << 31)) {
+                        Q.job_chunk = chunk; Q.job_first = 0u; Q.job_total = (uint32_t) ((uint64_t) n_lanes * chunks); Q.job_mask = chunk - 1u;
+                        K.job_chunk = chunk; K.job_chunks = (uint32_t) chunks;
+                    }
                 }
                 if (place && done == 0) { end = measure_end; Q.lane_cost = c->d_lane_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch
                 else if (place) {
@@ -2075,6 +2101,8 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                     MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 2, MATS_DIFFUSE, false, INTEG_PATH, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 else if (Q.group_done)
                     MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 1, MATS_DIFFUSE, false, INTEG_PATH, true>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
+                else if (packet_shard4 && !Q.group_done)
+                    MIW_TIMED(6, hipLaunchKernelGGL((k_path_resident<true, 2, MATS_DIFFUSE, false, INTEG_PATH, false, 4>), pgrid, block, rlds, s, P, c->view, Q, (double *) nullptr, c->d_cnt.p, rcfg, end, TA, c->d_next_pixel.p));
                 else if (tiny && c->diffuse_only && c->view.tri_count <= 32u) MIW_PATH_LAUNCH(2, MATS_DIFFUSE);   // 32-bit candidate masks (BASELINE config 2: 32 triangles)
                 else if (tiny && c->diffuse_only) MIW_PATH_LAUNCH(1, MATS_DIFFUSE);
                 else if (tiny && c->textured) MIW_PATH_LAUNCH(1, MATS_ALL);           // texture coordinates / bitmap lookups compiled in
