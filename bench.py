@@ -238,7 +238,7 @@ def run_extras(api, scenes, film, C):
                         "samples": int(c.samples), "segments_per_sample": c.segments / max(c.samples, 1),
                         "path_kernel": ("k_path_pooled" if getattr(c, "pooled", 0) else "k_path_phased" if c.path_kernel in (1, 3) else "k_path_resident") if c.plan == 2 else
                                        ("k_trace_stream + k_sort_hits + k_shade" if c.path_kernel == 2 else "k_trace<closest|any> + k_shade"),
-                        "plan": int(c.plan), "tree_width": int(c.tree_width), "film_overlapped": bool(getattr(c, "film_overlapped", 0)),
+                        "plan": int(c.plan), "tree_width": int(c.tree_width), "film_overlapped": bool(getattr(c, "film_overlapped", 0)), "job_chunk": int(getattr(c, "job_chunk", 0)), "job_chunks": int(getattr(c, "job_chunks", 0)),
                         "kernel_ms": {"trace": round(c.ms_trace_closest, 2), "sort": round(c.ms_trace_any, 2), "shade": round(c.ms_shade, 2)} if c.plan == 1 else None,
                         "log_bytes": int(c.log_bytes),
                         "bvh": {"builder": {0: "host binned SAH", 1: "device LBVH", 3: "device binned SAH (level sweep)"}.get(bvh.bvh_builder, "device" if bvh.bvh_on_device else "host binned SAH"), "build_ms": round(bvh.ms_bvh_build, 1), "tris": bvh.bvh_tris,
@@ -601,6 +601,8 @@ def main():
                 "log_bytes": hc.log_bytes, "log_record_bytes": hc.log_record_bytes,
                 # round 6: the film replay queued beside the path kernel (one launch per group of 64 tiles on a second stream): its kernel_ms then overlap the path kernel's
                 "film_overlapped": bool(getattr(hc, "film_overlapped", 0)), "film_groups": int(getattr(hc, "film_groups", 0)),
+                # round 6: the pixels' sample streams cut into halving chunks (smallest: job_chunk samples; job_chunks per pixel) drawn chunk-major from one queue
+                "job_chunk": int(getattr(hc, "job_chunk", 0)), "job_chunks": int(getattr(hc, "job_chunks", 0)),
                 "segments_per_sample": s_bar,
                 "pipeline_alg_bytes_per_sample": b_alg,
                 "pipeline_frac": (value / world) * 1e6 * b_alg / (HBM_PEAK_GBS * 1e9),

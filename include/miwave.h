@@ -325,10 +325,9 @@ typedef struct {
                                   set of 64-tile groups behind the flags the groups' last finished pixels raise (full frames of the packet / lock-step
                                   kernels, one launch for all samples; MIW_FILM_OVERLAP=0 switches it off); ms_film_blocks then overlaps ms_path */
     uint32_t film_groups;      /* launches of that replay; 0: one launch after the path kernel                                            */
-    uint32_t job_chunk;        /* samples per pixel JOB of the last render's path kernel: 0 = a job is all the samples of a pixel; else the pixels' sample streams were
-                                  cut into chunks of this many samples, drawn chunk-major from one queue, a pixel changing lanes between chunks (full frames of the
-                                  packet kernels: the frame then lasts pixels x chunks / resident lanes rounded up to a round of ONE chunk, not of one pixel;
-                                  MIW_JOB_CHUNK=0 switches it off)                                                                          */
+    uint32_t job_chunk;        /* chunk jobs of the last render's path kernel: 0 = a job is all the samples of a pixel; else the pixels' sample streams were cut into
+                                  halving chunks down to this many samples (512 spp, 64: 256 + 128 + 64 + 64), drawn chunk-major from one queue, a pixel changing
+                                  lanes between chunks (full frames: the launch's tail is as long as the smallest chunk, not as a pixel; MIW_JOB_CHUNK=0 switches it off) */
     uint32_t job_chunks;       /* chunks per pixel of that render (0: none)                                                                */
 } mi_counters;
 

@@ -28,7 +28,9 @@
 // path state. MIW_PHASE_SPEC (template Spec): a lane holding an untested leaf range may keep descending; it stalls
 // only when it reaches a second leaf.
 
-enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3 };
+// PH_PARK (chunk jobs, resident_kernel.h): the lane drew a chunk whose predecessor is still running; it asks again in the next shade run but does NOT vote for one —
+// the lane it waits for may be walking in this very wavefront, and parked lanes that outvote the walkers would starve it. A wavefront with nothing but parked lanes runs shade.
+enum : uint32_t { PH_SHADE = 0, PH_TRAV_E = 1, PH_TRAV_S = 2, PH_OUT = 3, PH_PARK = 4 };
 
 // a lane's stack: its column of the workgroup's entry-major LDS array (slot i of lane l at i * MIW_BLOCK + l: conflict-free)
 // The triangle records in global memory as the walk bodies read them: 48 bytes = three 16-byte loads through an explicitly global
@@ -213,15 +215,19 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
         int n_node = count(e_node) + n_turn, n_leaf = count(e_leaf);
         const int n_shade = count(e_shade);
         const int n_end = 0;
-        if ((n_node | n_leaf | n_shade) == 0) break;
+        bool parked_only = false;
+        if ((n_node | n_leaf | n_shade) == 0) {
+            if (!(MIW_PHASED_JOBS != 0 && !Placed) || __ballot(mode == PH_PARK) == 0ull) break;
+            parked_only = true;
+        }
         const int lead = n_node > n_leaf ? n_node : n_leaf;              // the busier walk body
         MIW_PS(4, 0);                                                    // the vote (+ the loop exit tests of the body before it)
 
-        if (n_shade * shade_num >= lead * shade_den && n_shade > 0) {
+        if ((n_shade * shade_num >= lead * shade_den && n_shade > 0) || parked_only) {
             // ---------------- shade: everything between two scene queries (pixel_stream_render's loop body) ----------------
             MIW_SECTION(6);                                              // everything since the last shade body: walks + votes
             work.tick(L.sample_idx, mode != PH_OUT && !(L.flags & LF_DONE));
-            if (e_shade) {
+            if (e_shade || (MIW_PHASED_JOBS != 0 && !Placed && mode == PH_PARK)) {
                 if (!(L.flags & LF_DONE)) {
                     const V3 o = L.ray.o;
                     if (sh.has && !occluded) L.res = L.res + sh.c;          // path.cpp:171 of the previous vertex
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(MIW_BLOCK, Waves) void k_path_phased(RenderParams P
                     L.sample_idx = st.w; L.flags = 0;
                     lane_begin_sample(P, pixel, L, sample_end);
                 }
-                if (L.flags & LF_DONE) mode = work.exhausted() ? PH_OUT : PH_SHADE;   // (not exhausted: a chunk job waiting for the chunk before it — it asks again in the next shade run)
+                if (L.flags & LF_DONE) mode = work.exhausted() ? PH_OUT : PH_PARK;    // (not exhausted: a chunk job waiting for the chunk before it — it asks again in the next shade run)
                 else if (!dead_pending) { mode = PH_TRAV_E; begin_walk(L.ray.d, L.ray.maxt); }
                 else { mode = PH_TRAV_S; begin_walk(sh.d, sh.maxt); }       // dead_pending implies a queued shadow ray
             }

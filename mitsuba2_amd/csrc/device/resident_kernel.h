@@ -114,7 +114,7 @@ struct QueueWork {
     // queue runs dry every lane is somewhere inside such a job: the last ~35 ms of the launch run at falling lane occupancy. Measured (gpurun r6o): the path
     // kernel's time is a straight line in the pixel count, 102.4 ns per pixel + 26.5 ms that do not depend on it — 11 % of the headline kernel. A pixel's state is
     // 16 bytes (Q->st), so a pixel can change lanes between two samples: the queue holds (chunk, slot) pairs, chunk-major, every lane draws from it until it is
-    // empty, and the tail is as long as ONE CHUNK. Chunk j of a slot is ready when the slot's sample counter stands at its first sample — its predecessor
+    // empty, and the tail is as long as the LAST chunk (the chunks halve: LaneQueues::job_min). Chunk j of a slot is ready when the slot's sample counter stands at its first sample — its predecessor
     // is n_lanes jobs back in the queue, complete long ago in a frame of several pixels per lane. If it is not, the lane must not spin here (the lane running
     // the chunk before may be a neighbour in this very wavefront): it parks the job in its word of LDS (id + 1; 0: none; ~0: the queue is empty), reports "nothing
     // now" and asks again on its next trip. The state words cross CUs and XCDs inside one launch: sc1 accesses (past the XCD's L2), the RNG words
@@ -125,7 +125,8 @@ struct QueueWork {
     __device__ __forceinline__ static uint32_t &job_pend() { __shared__ uint32_t s_job_pend[MIW_BLOCK]; return s_job_pend[threadIdx.x & (MIW_BLOCK - 1)]; }
     __device__ __forceinline__ bool exhausted() const { return !Jobs || !Q->job_chunk || job_pend() == 0xffffffffu; }   // after fetch() said false: for good, or "ask again"
     __device__ __forceinline__ uint32_t job_end(uint32_t sample_idx, uint32_t sample_end) const {   // called after a sample has finished: sample_idx >= 1
-        return Jobs && (sample_idx & Q->job_mask) == 0u ? sample_idx : sample_end;              // (job_mask = job_chunk - 1, or ~0 without chunks: never zero then)
+        const uint32_t r = spp - sample_idx;                                                        // samples still to do: a chunk ends where that is a power of two >= job_min
+        return Jobs && (r & (r - 1u)) == 0u && r >= Q->job_min ? sample_idx : sample_end;         // (job_min = 2^31 without chunks; r = 0 at the pixel's end: sample_end decides)
     }
     __device__ __forceinline__ bool fetch_job(uint32_t &pixel, U4 &st) {
         for (;;) {
@@ -149,7 +150,7 @@ struct QueueWork {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(Q->st + slot) : "memory");
 #endif
             if (w.z & LF_DONE) { job_pend() = 0u; continue; }                     // pixel outside its clipped block, or already complete
-            if (w.w != Q->job_first + j * Q->job_chunk) { job_pend() = id + 1u; return false; }   // the chunk before is still running: ask again
+            if (w.w != (j ? spp - (Q->job_pow >> (j - 1u)) : 0u)) { job_pend() = id + 1u; return false; }   // the chunk before is still running: ask again
             job_pend() = 0u;
             lane = slot; pixel = px;
             st.x = w.x; st.y = w.y; st.z = w.z; st.w = w.w;

@@ -148,7 +148,7 @@ MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &s
             }
             U4 st;
             have = work.fetch(pixel, st);
-            if (!have) break;
+            if (!have) { if (work.exhausted()) break; continue; }    // (chunk jobs, path.h: pixel_stream_render)
             L.rng.state = (uint64_t) st.x | ((uint64_t) st.y << 32);
             L.sample_idx = st.w; L.flags = 0;
             lane_begin_sample(P, pixel, L, sample_end);
@@ -189,7 +189,7 @@ MIW_HD void pixel_stream_render_direct(const RenderParams &P, const SceneView &s
         lane_finish_sample(P, pixel, L, sink);
         if (cnt_local) cnt_local->samples++;
         L.flags = 0;
-        lane_begin_sample(P, pixel, L, sample_end);
+        lane_begin_sample(P, pixel, L, work.job_end(L.sample_idx, sample_end));
     }
 }
 

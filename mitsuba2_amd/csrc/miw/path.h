@@ -77,11 +77,12 @@ struct LaneQueues {
     // 64 tiles, how many pixels have run all their samples (group_done, device memory) against how many there are (group_expected); the pixel
     // that completes a group raises its flag (group_flag: host-coherent memory the replay's stream waits on). nullptr: off
     uint32_t *group_done = nullptr; const uint32_t *group_expected = nullptr; uint32_t *group_flag = nullptr; uint32_t group_shift = 0;
-    // pixel jobs cut into CHUNKS of samples (round 6; device/resident_kernel.h: QueueWork::fetch, full frames of the packet kernels): the queue holds
-    // (chunk, pixel slot) pairs, chunk-major — job_total = slots x chunks of this launch; chunk j of a pixel covers the samples
-    // [job_first + j * job_chunk, + job_chunk) and is ready once the slot's state word says the chunk before it is complete. job_chunk = 0: a job = all the
-    // launch's samples of a pixel (every other kernel). A power of two; job_first a multiple of it.
-    uint32_t job_chunk = 0, job_first = 0, job_total = 0, job_mask = 0xffffffffu;   // job_mask = job_chunk - 1 (~0 without chunks: `sample index & mask` is never 0 after a sample)
+    // pixel jobs cut into CHUNKS of samples (round 6; device/resident_kernel.h: QueueWork::fetch_job, full frames, all samples in one launch): the queue holds
+    // (chunk, pixel slot) pairs, chunk-major — job_total = slots x chunks. The chunks HALVE: a chunk ends where the number of samples still to do is a power of two
+    // >= job_min (512 spp, job_min 64: 256 + 128 + 64 + 64 — half of a pixel's work in its first job, the launch's tail as long as the last), so chunk j > 0 starts
+    // at sample spp - (job_pow >> (j - 1)), job_pow = the largest power of two below spp; a chunk is ready once the slot's state word stands at its first sample.
+    // job_chunk = 0: a job = all the launch's samples of a pixel (every other launch); job_min = 2^31 then: no sample count reaches it.
+    uint32_t job_chunk = 0, job_pow = 0, job_total = 0, job_min = 0x80000000u;
 };
 
 // Which SamplingIntegrator::sample runs per camera sample, and the direct integrator's constants (direct.cpp:78-104)

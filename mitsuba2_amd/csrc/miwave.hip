@@ -154,7 +154,7 @@ static const KnobInfo g_knobs[] = {
     { "MIW_TAIL_PRIO", "0: no least-progress-first wave priorities" },
     { "MIW_WG_PER_CU", "workgroups per CU of the packet kernels' persistent grid" },
     { "MIW_PLACE", "0: shards of about one pixel per lane skip the measuring launch + placed queues" },
-    { "MIW_JOB_CHUNK", "samples per pixel job of a full packet-kernel frame (a power of two; default spp / 8, at least 8): the pixels' sample streams are cut into chunks drawn chunk-major from one queue; 0: a job = all the samples of a pixel. MIW_JOB_CHUNK_FORCE=1: also for frames of fewer than two pixels per resident lane (tests)" },
+    { "MIW_JOB_CHUNK", "smallest chunk of a full frame's pixel jobs, in samples (a power of two; default 64, the phase machine 32): the pixels' sample streams are cut into halving chunks drawn chunk-major from one queue; 0: a job = all the samples of a pixel" },
     { "MIW_JOB_CHUNK_FORCE", "1: chunk jobs whatever the frame's size (tests of the hand-over between lanes)" },
     { "MIW_PACKET_SHARD4", "0: a plain-diffuse packet job of at most four wavefronts of pixels per SIMD keeps the five-wavefront (96-register) kernel" },
     { "MIW_PLACE_MEASURE", "divisor: the measuring launch runs spp / divisor samples" },
@@ -1932,20 +1932,23 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 // chunk jobs (resident_kernel.h: QueueWork::fetch): full frames of the packet kernels, all samples in one launch. Without them a frame of N pixels
                 // on L resident lanes lasts ceil(N / L) rounds of one PIXEL (every lane starts at once, a pixel's samples are one serial job, the jobs are about
                 // equally long): C2 = 6.33 -> 7; with chunks of spp / 8 samples ceil(8 N / L) / 8 = 6.375.
-                Q.job_chunk = Q.job_first = Q.job_total = 0u; Q.job_mask = 0xffffffffu;
-                // Every job costs one atomic on ONE address (the queue's counter) and a hand-over (a 16-byte state word out and in, past the L2): chunks of
-                // 8 / 16 / 32 samples ran C2 in 702 / 496 / 305 ms, 64 / 128 / 256 in 226.8 / 226.5 / 230.6, whole pixels in 239.3 (gpurun r6p) — chunks of spp / 8,
-                // never fewer than 64 samples. The phase machine's full frames (C3, C4) take the same queue.
-                if ((tiny || (phased && MIW_PHASED_JOBS != 0)) && !pooled_fits && !direct && !place && !overlap && done == 0 && per_launch >= cfg->spp && cfg->timeout_s <= 0.f) {
-                    uint32_t chunk = 64u;
-                    while (chunk * 16u <= cfg->spp) chunk *= 2u;                      // spp / 8 rounded down to a power of two, at least 64
-                    if (const char *e = ropt.get("MIW_JOB_CHUNK")) { const uint32_t v = (uint32_t) std::max(0, atoi(e)); chunk = (v & (v - 1u)) ? 0u : v; }
+                Q.job_chunk = Q.job_pow = Q.job_total = 0u; Q.job_min = 0x80000000u;
+                // Every job costs one atomic on ONE address (the queue's counter) and a hand-over (a 16-byte state word out and in, past the L2): uniform chunks of
+                // 8 / 16 / 32 samples ran C2 in 702 / 496 / 305 ms, 64 / 128 / 256 in 226.8 / 226.5 / 230.6, whole pixels in 239.3 (gpurun r6p). So the chunks
+                // HALVE — a chunk ends where the samples still to do are a power of two — down to job_min samples (512 spp: 256 + 128 + 64 + 64): four hand-overs
+                // per pixel instead of eight, the tail as long as the smallest. The phase machine's full frames (C3, C4) take the same queue.
+                if ((tiny || (phased && MIW_PHASED_JOBS != 0)) && !pooled_fits && !place && !overlap && done == 0 && per_launch >= cfg->spp && cfg->timeout_s <= 0.f) {
+                    uint32_t jmin = tiny ? 64u : 32u;                                 // (gpurun r6s, halving chunks: C2 4 461 / 4 316 / 4 389 Msamples/s at 64 / 32 / 128; C3 1 298 / 1 305, C4 522 / 528 at 64 / 32)
+                    if (const char *e = ropt.get("MIW_JOB_CHUNK")) { const uint32_t v = (uint32_t) std::max(0, atoi(e)); jmin = (v & (v - 1u)) ? 0u : v; }
                     bool enough = n_lanes >= 2u * 64u * res_waves * n_simd;            // (a frame of one or two rounds gains nothing and pays the hand-overs)
                     if (const char *e = ropt.get("MIW_JOB_CHUNK_FORCE")) enough = enough || atoi(e) != 0;
-                    const uint64_t chunks = chunk ? ((uint64_t) cfg->spp + chunk - 1u) / chunk : 0u;
-                    if (chunk && enough && chunks >= 2u && (uint64_t) n_lanes * chunks < (1ull << 31)) {
-                        Q.job_chunk = chunk; Q.job_first = 0u; Q.job_total = (uint32_t) ((uint64_t) n_lanes * chunks); Q.job_mask = chunk - 1u;
-                        K.job_chunk = chunk; K.job_chunks = (uint32_t) chunks;
+                    uint32_t pow2 = 1u;
+                    while (pow2 * 2u < cfg->spp) pow2 *= 2u;                          // the largest power of two below spp
+                    uint64_t chunks = 1u;
+                    for (uint32_t r = pow2; jmin && r >= jmin && r < cfg->spp; r >>= 1) ++chunks;
+                    if (jmin && enough && chunks >= 2u && (uint64_t) n_lanes * chunks < (1ull << 31)) {
+                        Q.job_chunk = jmin; Q.job_min = jmin; Q.job_pow = pow2; Q.job_total = (uint32_t) ((uint64_t) n_lanes * chunks);
+                        K.job_chunk = jmin; K.job_chunks = (uint32_t) chunks;
                     }
                 }
                 if (place && done == 0) { end = measure_end; Q.lane_cost = c->d_lane_cost.p; Q.simd_ids = c->d_simd_ids.p; }   // the measuring launch

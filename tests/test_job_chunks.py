@@ -6,7 +6,7 @@ the queue holds (chunk, pixel) pairs, chunk-major, and a pixel changes lanes bet
 memory inside one launch. The film must not notice: the arithmetic per sample, the order of the samples of a pixel and the log index
 stay what they were. GPU tier: forced on small frames (fewer pixels than lanes: all chunks of a pixel are drawn at once by different
 lanes — often of the same wavefront — and every chunk but the first has to WAIT for the one before it: the hand-over path), several
-chunk sizes, the packet-kernel classes (plain diffuse 32-bit / 64-bit masks, BSDF dispatch, spectral) and the switch."""
+chunk sizes, the kernel classes (plain diffuse 32-bit / 64-bit masks, BSDF dispatch, the phase machine over a tree) and the switch."""
 import ctypes as C
 import os
 
@@ -35,17 +35,17 @@ def test_chunk_jobs_render_the_oracles_film(native, oracle, kind):
     from mitsuba2_amd import scenes
     from mitsuba2_amd import api
     if kind == "diffuse32":
-        scene, sensor = scenes.cornell_box(96, 80, 64, device=-1)                                    # 32 triangles, plain diffuse: the headline's kernel
+        scene, sensor = scenes.cornell_box(64, 48, 32, device=-1)                                    # 32 triangles, plain diffuse: the headline's kernel
     elif kind == "diffuse64":                                                                       # 36 triangles: its 64-bit-mask twin
         v = np.array([(150, 330, 150), (250, 330, 150), (200, 330, 250), (200, 420, 190)], np.float32)
         f = np.array([(0, 1, 2), (0, 3, 1), (1, 3, 2), (2, 3, 0)], np.int32)
         meshes = scenes.cornell_box_meshes() + [api.Mesh("pyramid", v, f, bsdf=api.BSDF("diffuse", reflectance=(0.4, 0.5, 0.7)))]
         scene = api.Scene(meshes).build(-1)
-        sensor = scenes.cornell_sensor(96, 80, 64, 0, "gaussian")
+        sensor = scenes.cornell_sensor(64, 48, 32, 0, "gaussian")
     elif kind == "tree":
-        scene, sensor = scenes.cornell_box(96, 80, 64, device=-1, diffuse_only=False, ball_level=3)  # 2 572 triangles: the phase machine over the 8-wide tree (C3's kernel)
+        scene, sensor = scenes.cornell_box(64, 48, 32, device=-1, diffuse_only=False, ball_level=3)  # 2 572 triangles: the phase machine over the 8-wide tree (C3's kernel)
     else:
-        scene, sensor = scenes.cornell_box(96, 80, 64, device=-1, diffuse_only=False, ball_level=0)  # BSDF dispatch (conductor + dielectric), still a packet scene
+        scene, sensor = scenes.cornell_box(64, 48, 32, device=-1, diffuse_only=False, ball_level=0)  # BSDF dispatch (conductor + dielectric), still a packet scene
     job = native.PathIntegrator().render_job(sensor, n_threads=8)
     o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
     dev = native.Device(0)
@@ -55,9 +55,9 @@ def test_chunk_jobs_render_the_oracles_film(native, oracle, kind):
         c = dev.counters()
         assert st == 0 and c.job_chunk == 0 and c.path_kernel == (1 if kind == "tree" else 0) and np.array_equal(g, o32)
         dev.set_option("MIW_JOB_CHUNK_FORCE", "1")
-        g, st = dev.render(job)                                       # default chunk: spp / 8 but at least 64 samples — 64 spp is one chunk: a job = a pixel
+        g, st = dev.render(job)                                       # default chunk: spp / 8 but at least 64 samples — 32 spp is one chunk: a job = a pixel
         assert st == 0 and dev.counters().job_chunk == 0 and np.array_equal(g, o32)
-        for chunk, chunks in ((8, 8), (16, 4), (32, 2), (1, 64), (4, 16)):
+        for chunk, chunks in ((8, 3), (16, 2), (1, 6)):               # halving chunks down to `chunk` samples: 16 + 8 + 8, 16 + 16, 16 + 8 + 4 + 2 + 1 + 1
             dev.set_option("MIW_JOB_CHUNK", str(chunk))
             g, st = dev.render(job)
             c = dev.counters()
@@ -66,7 +66,7 @@ def test_chunk_jobs_render_the_oracles_film(native, oracle, kind):
         dev.set_option("MIW_JOB_CHUNK", "0")                          # the switch
         g, st = dev.render(job)
         assert st == 0 and dev.counters().job_chunk == 0 and np.array_equal(g, o32)
-        dev.set_option("MIW_JOB_CHUNK", "24")                         # not a power of two: refused (a job = a pixel)
+        dev.set_option("MIW_JOB_CHUNK", "12")                         # not a power of two: refused (a job = a pixel)
         g, st = dev.render(job)
         assert st == 0 and dev.counters().job_chunk == 0 and np.array_equal(g, o32)
     finally:
@@ -76,17 +76,17 @@ def test_chunk_jobs_render_the_oracles_film(native, oracle, kind):
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
 def test_chunk_jobs_with_a_ragged_last_chunk_and_clipped_blocks(native, oracle):
-    """spp not a multiple of the chunk (the last chunk is short), a frame whose blocks are clipped (slots without a pixel are skipped in
+    """spp not a power of two (the first chunk takes the odd part), a frame whose blocks are clipped (slots without a pixel are skipped in
     every chunk), a crop window."""
     from mitsuba2_amd import scenes
-    scene, sensor = scenes.cornell_box(75, 53, 44, device=-1)
+    scene, sensor = scenes.cornell_box(75, 53, 22, device=-1)
     job = native.PathIntegrator().render_job(sensor, n_threads=8)
     o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
     dev = native.Device(0)
     try:
         dev.upload(scene.desc())
         dev.set_option("MIW_JOB_CHUNK_FORCE", "1")
-        for chunk, chunks in ((0, 0), (8, 6), (16, 3), (32, 2)):
+        for chunk, chunks in ((0, 0), (8, 3), (16, 2), (4, 4)):       # 22 spp: 6 + 8 + 8, 6 + 16, 6 + 8 + 4 + 4
             if chunk:
                 dev.set_option("MIW_JOB_CHUNK", str(chunk))
             g, st = dev.render(job)

@@ -34,11 +34,11 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipc
 
 
 def test_cornell_packet_kernel_fits_five_waves_with_no_scratch_in_its_inner_loops(tmp_path):
-    """The headline kernel (BASELINE configs[1]): since round 6 compiled for FIVE wavefronts per SIMD — 96 registers, at most 16 values in scratch, stored once in
+    """The headline kernel (BASELINE configs[1]): since round 6 compiled for FIVE wavefronts per SIMD — 96 registers, at most 19 values in scratch, stored once in
     front of the pixel loop and reloaded in its body, never inside the leaf-box or candidate loops (resident_kernel.h: MIW_PACKET_WAVES; 248.1 -> 238.3 ms, gpurun r6n).
     At four (-DMIW_PACKET_WAVES=4: rounds 3 - 5) it fits 128 registers without any."""
     r = _resources("probe_resident.hip", "k_path_residentILb1ELi2ELi1ELb0ELj0E", tmp_path)
-    assert r["waves"] == 5 and r["vgprs"] <= 96 and r["spilled"] <= 16, r      # (12 before the chunk jobs of QueueWork::fetch_job; 239.3 -> 226.8 ms with them, gpurun r6p)
+    assert r["waves"] == 5 and r["vgprs"] <= 96 and r["spilled"] <= 19, r      # (12 before the chunk jobs of QueueWork::fetch_job; 239.4 -> 221.9 ms with them, gpurun r6p - r6s)
     out = subprocess.run([HIPCC] + [f for f in FLAGS if not f.startswith("-Rpass")] + ["-S", os.path.join(ROOT, "tools", "probe_resident.hip"),
                           "--cuda-device-only", "-o", str(tmp_path / "probe.s")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -54,7 +54,7 @@ def test_cornell_packet_kernel_fits_five_waves_with_no_scratch_in_its_inner_loop
         if "scratch_" in l:
             total += 1
             inner += 0 if re.search(r"Depth=1\b", depth) or "Depth=" not in depth else 1
-    assert total <= 28 and inner == 0, (total, inner)
+    assert total <= 32 and inner == 0, (total, inner)
     r = _resources("probe_resident.hip", "k_path_residentILb1ELi2ELi1ELb0ELj0E", tmp_path, "-DMIW_PACKET_WAVES=4")
     assert r["waves"] == 4 and r["vgprs"] <= 128 and r["spilled"] == 0, r
 
