@@ -25,6 +25,24 @@ import bench  # noqa: E402
 import rocprof_summary  # noqa: E402
 
 
+def drop_stale_passes(g):
+    """gpurun MERGES a session's files into gpurun_out/: a tag profiled twice leaves two sessions' CSVs (named by process id) in every pass directory and
+    every counter would be summed over both. Keep the newest process's files per directory."""
+    import re
+    for d in glob.glob(g + "_*/**/", recursive=True):
+        by = collections.defaultdict(list)
+        for f in os.listdir(d):
+            m = re.match(r"(\d+)_.*\.csv$", f)
+            if m:
+                by[m.group(1)].append(os.path.join(d, f))
+        if len(by) > 1:
+            newest = max(by, key=lambda k: max(os.path.getmtime(f) for f in by[k]))
+            for k, fs in by.items():
+                if k != newest:
+                    for f in fs:
+                        os.remove(f)
+
+
 def last_json(path):
     try:
         return json.loads(open(path).read().strip().splitlines()[-1])
@@ -109,6 +127,7 @@ def main():
     tag = sys.argv[1]
     os.chdir(ROOT)
     g = os.path.join("gpurun_out", tag)
+    drop_stale_passes(g)
     sha = bench.kernel_src_sha16()
     head = "# kernel sources sha256[:16] = %s (bench.kernel_src_sha16(): mitsuba2_amd/csrc/**/*.{h,hip})" % sha
     cmd = "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline%s   (tools/profile_round.sh %s)"
