@@ -256,9 +256,10 @@ struct QueueWork {
 // it 2.4 %, r6l), and the spills that made a fifth wavefront 21 - 30 % SLOWER in round 3 went away with the register diets of rounds 3 - 5. Six: 81 spilled, no.
 // (Five is for the kernel with 32-bit candidate masks, Tiny == 2: scenes of <= 32 triangles; its 64-bit twin, Tiny == 1, would spill 45 at 96 registers
 // and stays at four, unmeasured at five.)
-// The other scalar_rgb packet kernels (BSDF dispatch, textures) fit 128 registers without scratch: four instead of three; the spectral ones do not (93 spilled): three.
+// The other scalar_rgb packet kernels (BSDF dispatch, textures) fit 128 registers without scratch: four instead of three. The spectral ones keep 93 values in scratch at 128
+// registers — and are 10.5 % faster there all the same (C5: path kernel 575.4 -> 519.2 ms, 1 790 -> 1 978 Msamples/s, gpurun r6u): four as well.
 #ifndef MIW_PACKET_WAVES_ALL
-#define MIW_PACKET_WAVES_ALL (MIW_SPECTRAL ? 3 : 4)
+#define MIW_PACKET_WAVES_ALL 4
 #endif
 #ifndef MIW_PACKET_WAVES
 #define MIW_PACKET_WAVES 5

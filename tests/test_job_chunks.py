@@ -98,3 +98,48 @@ def test_chunk_jobs_with_a_ragged_last_chunk_and_clipped_blocks(native, oracle):
             assert st == 0 and (c.samples, c.segments) == (ost.samples, ost.segments) and np.array_equal(g, o32), chunk
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_chunk_jobs_of_the_direct_integrator(native, oracle):
+    """direct.h: pixel_stream_render_direct draws the same queue (its packet kernels; 1 / 3+2 samples per shading point)."""
+    from mitsuba2_amd import scenes
+    scene, sensor = scenes.cornell_box(64, 48, 16, device=-1)
+    dev = native.Device(0)
+    try:
+        dev.upload(scene.desc())
+        dev.set_option("MIW_JOB_CHUNK_FORCE", "1")
+        for kw in (dict(), dict(emitter_samples=3, bsdf_samples=2)):
+            job = native.DirectIntegrator(**kw).render_job(sensor)
+            o32, _, ost = oracle.render(scene.desc(), job, threads=8, want_f64=False)
+            for chunk, chunks in ((4, 3), (1, 5)):                    # 16 spp: 8 + 4 + 4; 8 + 4 + 2 + 1 + 1
+                dev.set_option("MIW_JOB_CHUNK", str(chunk))
+                g, st = dev.render(job)
+                c = dev.counters()
+                assert st == 0 and (c.job_chunk, c.job_chunks) == (chunk, chunks), (c.job_chunk, c.job_chunks)
+                assert (c.samples, c.segments) == (ost.samples, ost.segments) and np.array_equal(g, o32), (kw, chunk)
+    finally:
+        dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_chunk_jobs_in_the_spectral_variant(spectral, oracle_spectral):
+    """the scalar_spectral library's packet kernel (C5's: glass block, 4 wavelengths per sample) and its phase machine."""
+    from mitsuba2_amd import scenes
+    for kw in (dict(glass_block=True), dict(diffuse_only=False, ball_level=2)):
+        scene, sensor = scenes.cornell_box(64, 48, 16, device=-1, **kw)
+        job = spectral.PathIntegrator().render_job(sensor, n_threads=8)
+        o32, _, ost = oracle_spectral.render(scene.desc(), job, threads=8, want_f64=False)
+        d = spectral.Device(0)
+        try:
+            d.upload(scene.desc())
+            d.set_option("MIW_JOB_CHUNK_FORCE", "1")
+            d.set_option("MIW_JOB_CHUNK", "2")
+            g, st = d.render(job)
+            c = d.counters()
+            assert st == 0 and (c.job_chunk, c.job_chunks) == (2, 4), (c.job_chunk, c.job_chunks)      # 8 + 4 + 2 + 2
+            assert (c.samples, c.segments) == (ost.samples, ost.segments) and np.array_equal(g, o32), kw
+        finally:
+            d.close()
