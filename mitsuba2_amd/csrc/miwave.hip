@@ -1940,7 +1940,9 @@ mi_status mi_render(mi_ctx *c, const mi_render_cfg *cfg, void *film) {
                 if ((tiny || (phased && MIW_PHASED_JOBS != 0)) && !pooled_fits && !place && !overlap && done == 0 && per_launch >= cfg->spp && cfg->timeout_s <= 0.f) {
                     uint32_t jmin = tiny ? 64u : 32u;                                 // (gpurun r6s, halving chunks: C2 4 461 / 4 316 / 4 389 Msamples/s at 64 / 32 / 128; C3 1 298 / 1 305, C4 522 / 528 at 64 / 32)
                     if (const char *e = ropt.get("MIW_JOB_CHUNK")) { const uint32_t v = (uint32_t) std::max(0, atoi(e)); jmin = (v & (v - 1u)) ? 0u : v; }
-                    bool enough = n_lanes >= 2u * 64u * res_waves * n_simd;            // (a frame of one or two rounds gains nothing and pays the hand-overs)
+                    // from 1.2 pixels per resident lane on (gpurun r6z, a rank's shard of C2 with / without: 4 ranks = 1.6 pixels per lane 67.8 / 79.1 ms, 5 ranks = 1.3: 58.7 / 67.5,
+                    // 6 ranks = 1.06: 54.9 / 54.6; at about ONE pixel per lane every pixel is in flight all the time and no lane finds a second job: 8 ranks 47.1 against the placed launches' 41.4)
+                    bool enough = (uint64_t) n_lanes * 5u >= (uint64_t) 6u * 64u * res_waves * n_simd;
                     if (const char *e = ropt.get("MIW_JOB_CHUNK_FORCE")) enough = enough || atoi(e) != 0;
                     uint32_t pow2 = 1u;
                     while (pow2 * 2u < cfg->spp) pow2 *= 2u;                          // the largest power of two below spp
